@@ -1,0 +1,106 @@
+"""Parity cases shared by oracle/gen_golden.py and the tests (TEST INFRASTRUCTURE).
+
+A case is fully determined by its name: ``build(name)`` returns the synthetic
+inputs (p0, target description, moves, weights, nsteps, thin_by, seed).  The
+target description is a plain dict so that the same case can be fed to the
+reference (as a NumPy callable), to the oracle, and to the device library
+(as a target descriptor).
+"""
+import numpy as np
+
+from . import sampler_oracle as so
+
+
+def _dense_params(D, seed):
+    """SURVEY.md 8d, C2 construction: Sigma = A A^T / D + 0.1 I."""
+    rs = np.random.RandomState(seed)
+    mu = rs.randn(D)
+    A = rs.randn(D, D)
+    cov = A @ A.T / D + 0.1 * np.eye(D)
+    icov = np.linalg.inv(cov)
+    icov = 0.5 * (icov + icov.T)
+    return mu, cov, icov
+
+
+def make_target(desc):
+    """desc -> vectorised numpy callable (n, D) -> (n,)."""
+    k = desc["kind"]
+    if k == "iso":
+        return so.iso_gauss
+    if k == "diag":
+        return lambda x: so.diag_gauss(x, desc["mu"], desc["ivar"])
+    if k == "dense":
+        return lambda x: so.dense_gauss(x, desc["mu"], desc["icov"])
+    if k == "rosenbrock":
+        return so.rosenbrock
+    if k == "box":
+        def box(x):
+            x = np.atleast_2d(x)
+            bad = np.any((x > 1) | (x < 0), axis=1)
+            return np.where(bad, -np.inf, 0.0)
+        return box
+    raise ValueError(k)
+
+
+# name -> (N, D, target kind, moves, weights, nsteps, thin_by, seed, p0 kind)
+_S = so.MoveSpec
+CASES = {
+    # BASELINE config 1 (plumbing case), reference run per-walker (vectorize=False)
+    "c1_stretch_32x5_iso": dict(N=32, D=5, target="iso", moves=[_S("stretch")], nsteps=50, seed=1234, per_walker=True),
+    # non power-of-two halves: randint / shuffle rejection paths
+    "stretch_50x3_iso": dict(N=50, D=3, target="iso", moves=[_S("stretch")], nsteps=30, seed=7),
+    "stretch_a3_66x7_diag": dict(N=66, D=7, target="diag", moves=[_S("stretch", a=3.0)], nsteps=20, seed=11),
+    "stretch_256x16_dense": dict(N=256, D=16, target="dense", moves=[_S("stretch")], nsteps=10, seed=21),
+    "stretch_128x64_dense": dict(N=128, D=64, target="dense", moves=[_S("stretch")], nsteps=6, seed=22),
+    "stretch_128x8_rosen": dict(N=128, D=8, target="rosenbrock", moves=[_S("stretch")], nsteps=10, seed=31, p0="rosen"),
+    "stretch_nsplits3_45x2": dict(N=45, D=2, target="iso", moves=[_S("stretch", nsplits=3)], nsteps=15, seed=41),
+    "stretch_nsplits5_fixed_40x2": dict(N=40, D=2, target="iso", moves=[_S("stretch", nsplits=5, randomize_split=False)], nsteps=15, seed=42),
+    "stretch_box_32x1": dict(N=32, D=1, target="box", moves=[_S("stretch")], nsteps=40, seed=51, p0="uniform"),
+    "stretch_thin3_32x2": dict(N=32, D=2, target="iso", moves=[_S("stretch")], nsteps=8, thin_by=3, seed=61),
+    "stretch_wide_16x130_live": dict(N=16, D=130, target="diag", moves=[_S("stretch", live_dangerously=True)], nsteps=6, seed=71),
+    "de_64x4_iso": dict(N=64, D=4, target="iso", moves=[_S("de")], nsteps=20, seed=101),
+    "de_g1_s01_30x3": dict(N=30, D=3, target="iso", moves=[_S("de", gamma0=1.0, sigma=0.1)], nsteps=20, seed=102),
+    "snooker_64x4_iso": dict(N=64, D=4, target="iso", moves=[_S("snooker")], nsteps=20, seed=201),
+    "snooker_38x3_diag": dict(N=38, D=3, target="diag", moves=[_S("snooker", gammas=1.2)], nsteps=15, seed=202),
+    # BASELINE config 4 shape at oracle-feasible size
+    "mix_de_snooker_128x8_dense": dict(N=128, D=8, target="dense", moves=[_S("de"), _S("snooker")], weights=[0.8, 0.2], nsteps=25, seed=301),
+    "mix_stretch_de_64x5": dict(N=64, D=5, target="iso", moves=[_S("stretch"), _S("de")], nsteps=20, seed=302),
+}
+
+# Larger cases: only a digest of the reference output is committed.
+DIGEST_CASES = {
+    "stretch_4096x64_dense": dict(N=4096, D=64, target="dense", moves=[_S("stretch")], nsteps=3, seed=401),
+    "stretch_2048x32_rosen": dict(N=2048, D=32, target="rosenbrock", moves=[_S("stretch")], nsteps=3, seed=402, p0="rosen"),
+    "stretch_2048x1024_diag": dict(N=2048, D=1024, target="diag", moves=[_S("stretch")], nsteps=2, seed=403),
+    "mix_de_snooker_1024x64_dense": dict(N=1024, D=64, target="dense", moves=[_S("de"), _S("snooker")], weights=[0.8, 0.2], nsteps=6, seed=404),
+}
+
+
+def build(name):
+    spec = dict(CASES.get(name) or DIGEST_CASES[name])
+    N, D, seed = spec["N"], spec["D"], spec["seed"]
+    kind = spec["target"]
+    desc = {"kind": kind}
+    if kind == "diag":
+        rs = np.random.RandomState(seed + 1000)
+        desc["mu"] = rs.randn(D)
+        desc["ivar"] = 1.0 / (0.1 + rs.rand(D))
+    elif kind == "dense":
+        mu, cov, icov = _dense_params(D, seed + 1000)
+        desc.update(mu=mu, cov=cov, icov=icov)
+    rs = np.random.RandomState(seed)
+    p0kind = spec.get("p0", "randn")
+    if p0kind == "uniform":
+        p0 = rs.rand(N, D)
+    elif p0kind == "rosen":
+        p0 = 1.0 + 0.1 * rs.randn(N, D)
+    elif kind == "dense":
+        p0 = desc["mu"] + rs.randn(N, D) @ np.linalg.cholesky(desc["cov"]).T
+    elif kind == "diag":
+        p0 = desc["mu"] + rs.randn(N, D) / np.sqrt(desc["ivar"])
+    else:
+        p0 = rs.randn(N, D)
+    spec.update(p0=p0, desc=desc, weights=spec.get("weights"),
+                thin_by=spec.get("thin_by", 1), per_walker=spec.get("per_walker", False),
+                rng_seed=seed + 5000)
+    return spec
