@@ -1,0 +1,1205 @@
+// libemx: C ABI + host runtime of the MI355X split-ensemble sampler hot path.
+// See include/emx.h for the contract and the reference lines each entry point replaces.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/emx.h"
+#include "emx_kernels.hpp"
+#include "emx_rng.hpp"
+#include "mt19937_legacy.hpp"
+
+using namespace emx;
+
+namespace {
+
+std::string g_err;
+
+constexpr int PLAN_RING = 4;
+
+struct HostPlan {  // plan-order arrays of one step
+    std::vector<int32_t> off, order, p0, p1, p2;
+    std::vector<double> s0, uacc;
+    void resize(int64_t N, int S) {
+        off.assign(S + 1, 0);
+        order.resize(N);
+        p0.resize(N);
+        p1.resize(N);
+        p2.resize(N);
+        s0.resize(N);
+        uacc.resize(N);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// exact (NumPy-stream) plan of one step: every draw red_blue.py / stretch.py / de.py /
+// de_snooker.py make for one propose(), in their order.
+// ------------------------------------------------------------------------------------------
+inline void de_pair(uint64_t k, uint64_t nc, uint64_t& first, uint64_t& second) {
+    // moves/de.py:67-77 in closed form
+    const uint64_t T = nc * (nc - 1) / 2;
+    const uint64_t kk = k < T ? k : k - T;
+    uint64_t i = (uint64_t)((1.0 + std::sqrt(1.0 + 8.0 * (double)kk)) / 2.0);
+    while (i * (i - 1) / 2 > kk) --i;
+    while ((i + 1) * i / 2 <= kk) ++i;
+    const uint64_t j = kk - i * (i - 1) / 2;
+    if (k < T) {
+        first = i;
+        second = j;
+    } else {
+        first = j;
+        second = i;
+    }
+}
+
+template <typename I32, typename F64>
+int make_exact_plan(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc& mv, std::vector<int32_t>& labels,
+                    int32_t* off, I32* order, I32* p0, I32* p1, I32* p2, F64* s0, F64* uacc) {
+    const int S = mv.nsplits;
+    if (S < 2 || S > 255) return -1;
+    if (mv.kind == EMX_MOVE_SNOOKER && S < 4) return -1;
+    labels.resize(N);
+    for (int64_t i = 0; i < N; ++i) labels[i] = (int32_t)(i % S);          // red_blue.py:78
+    if (mv.randomize_split) mt.shuffle(labels.data(), N);                   // red_blue.py:80
+    // boolean-mask gather order (red_blue.py:85): ascending walker index inside each set
+    std::vector<int32_t> cnt(S + 1, 0);
+    for (int64_t i = 0; i < N; ++i) cnt[labels[i] + 1]++;
+    for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
+    for (int s = 0; s <= S; ++s) off[s] = cnt[s];
+    {
+        std::vector<int32_t> cur(cnt.begin(), cnt.end() - 1);
+        for (int64_t i = 0; i < N; ++i) order[cur[labels[i]]++] = (int32_t)i;
+    }
+    for (int split = 0; split < S; ++split) {
+        const int64_t base = off[split], ns = off[split + 1] - off[split], nc = N - ns;
+        auto comp = [&](uint64_t r) -> int32_t {  // complement = concatenation of the other sets (stretch.py:27)
+            return (int64_t)r < base ? order[r] : order[r + ns];
+        };
+        if (mv.kind == EMX_MOVE_STRETCH) {
+            for (int64_t t = 0; t < ns; ++t) {                              // stretch.py:30
+                const double u = mt.next_double();
+                const double tt = (mv.a - 1.0) * u + 1.0;
+                s0[base + t] = tt * tt / mv.a;
+            }
+            for (int64_t t = 0; t < ns; ++t) {                              // stretch.py:32
+                p0[base + t] = comp(mt.randint((uint64_t)nc));
+                p1[base + t] = p2[base + t] = order[base + t];
+            }
+        } else if (mv.kind == EMX_MOVE_DE) {
+            const uint64_t pop = (uint64_t)nc * (uint64_t)(nc - 1);
+            for (int64_t t = 0; t < ns; ++t) {                              // de.py:49-50
+                uint64_t f, s;
+                de_pair(mt.randint(pop), (uint64_t)nc, f, s);
+                p0[base + t] = comp(f);
+                p1[base + t] = comp(s);
+                p2[base + t] = order[base + t];
+            }
+            for (int64_t t = 0; t < ns; ++t) {                              // de.py:56
+                const double g = mt.next_gauss();
+                s0[base + t] = mv.g0 * (1.0 + mv.sigma * g);
+            }
+        } else if (mv.kind == EMX_MOVE_SNOOKER) {
+            int cs[3], q = 0;
+            for (int s = 0; s < S && q < 3; ++s)
+                if (s != split) cs[q++] = s;
+            for (int64_t t = 0; t < ns; ++t) {                              // de_snooker.py:37-40
+                int32_t w[3];
+                for (int k = 0; k < 3; ++k) {
+                    const int j = cs[k];
+                    const uint64_t r = mt.randint((uint64_t)(off[j + 1] - off[j]));
+                    w[k] = order[off[j] + (int64_t)r];
+                }
+                for (int i = 2; i > 0; --i) {                               // shuffle(w)
+                    const int j = (int)mt.random_interval((uint64_t)i);
+                    std::swap(w[i], w[j]);
+                }
+                p0[base + t] = w[0];
+                p1[base + t] = w[1];
+                p2[base + t] = w[2];
+                s0[base + t] = 0.0;
+            }
+        } else {
+            return -1;
+        }
+        for (int64_t t = 0; t < ns; ++t) uacc[base + t] = mt.next_double();  // red_blue.py:100
+    }
+    (void)D;
+    return 0;
+}
+
+template <int MOVE>
+void host_native_plan(const NativeArgs& na, int64_t N, const emx_move_desc& mv, int32_t* off, int32_t* order,
+                      int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc) {
+    const int S = mv.nsplits;
+    off[0] = 0;
+    for (int s = 0; s < S; ++s) off[s + 1] = off[s] + (int32_t)((N - s + S - 1) / S);
+    for (int s = 0; s < S; ++s)
+        for (int t = 0; t < off[s + 1] - off[s]; ++t) {
+            const int pos = off[s] + t;
+            int i, a0, a1, a2;
+            double z, u;
+            native_slot<MOVE>(na, (int)N, S, s, t, mv.a, mv.sigma, mv.g0, i, a0, a1, a2, z, u);
+            order[pos] = i;
+            p0[pos] = a0;
+            p1[pos] = a1;
+            p2[pos] = a2;
+            s0[pos] = z;
+            uacc[pos] = u;
+        }
+}
+
+int philox_move_choice(uint64_t seed, uint64_t step, const double* cdf, int n) {
+    const Philox4 r = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), 0x4d4f5645u /*'MOVE'*/, 0, (uint32_t)seed,
+                                    (uint32_t)(seed >> 32));
+    const double u = u53(r.v[0], r.v[1]);
+    int k = 0;
+    while (k < n - 1 && u >= cdf[k]) ++k;
+    return k;
+}
+
+struct Shape {
+    int G, V, CH;
+};
+
+Shape pick_shape(int D, int Dcover) {
+    Shape s;
+    s.V = (D % 2 == 0) ? 2 : 1;
+    const int cols = (Dcover + s.V - 1) / s.V;
+    int G = 4;
+    while (G < cols && G < 64) G <<= 1;
+    int CH = 1;
+    while (G * CH < cols) CH <<= 1;
+    s.G = G;
+    s.CH = CH;
+    return s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+struct emx_mt {
+    MT19937Legacy mt;
+};
+
+struct emx_ctx {
+    int device = 0;
+    int64_t N = 0;
+    int32_t D = 0;
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    int num_cu = 256;
+    // state
+    double *X = nullptr, *lp = nullptr;
+    uint8_t* acc = nullptr;
+    uint32_t *acc_count = nullptr, *status = nullptr;
+    int32_t* iota = nullptr;
+    // target
+    int target = EMX_TARGET_HOST;
+    double *tp0 = nullptr, *tp1 = nullptr;
+    double tscale = 1.0;
+    int Dp = 0;
+    // moves
+    std::vector<emx_move_desc> moves;
+    std::vector<double> cdf;
+    // rng
+    int rng_mode = EMX_RNG_PHILOX;
+    MT19937Legacy mt;
+    uint64_t ph_seed = 0, ph_step = 0;
+    // plan ring (device) + pinned host staging
+    struct PlanSlot {
+        int32_t *order = nullptr, *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+        double *s0 = nullptr, *uacc = nullptr;
+        char* host = nullptr;  // pinned: [order|p0|p1|p2](int32 N each) [s0|uacc](double N each)
+        hipEvent_t consumed = nullptr;
+        bool busy = false;
+    } ring[PLAN_RING];
+    int ring_pos = 0;
+    std::vector<int32_t> labels_scratch;
+    // current step
+    struct Cur {
+        bool active = false;
+        int move = 0, S = 2, slot = 0;
+        bool store = false;
+        bool native = false;
+        std::vector<int32_t> off;
+        NativeArgs nat{};
+    } cur;
+    // chain
+    double *chain = nullptr, *chain_lp = nullptr;
+    int64_t cap = 0, stored = 0, proposals = 0;
+    // split-phase buffers
+    double *qout = nullptr, *fout = nullptr, *newlp = nullptr;
+    double *evalX = nullptr, *evallp = nullptr;
+    // sharding
+    int rank = 0, world = 1;
+    double *sendbuf = nullptr, *gathered = nullptr;
+    int64_t sendbuf_rows = 0, gathered_rows = 0;
+    // tuning
+    int64_t tune_spw = 0, tune_bpc = 2;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> prof;
+    int prof_max = 0, prof_n = 0;
+    std::string err;
+};
+
+#define FAIL(ctx, code, ...)                         \
+    do {                                             \
+        char _b[512];                                \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);       \
+        if (ctx) (ctx)->err = _b; else g_err = _b;   \
+        return (code);                               \
+    } while (0)
+
+#define HIPOK(ctx, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) FAIL(ctx, -2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define NEED(ctx, cond, ...)               \
+    do {                                   \
+        if (!(cond)) FAIL(ctx, -1, __VA_ARGS__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// kernel dispatch
+// ------------------------------------------------------------------------------------------
+namespace {
+
+template <int MOVE, bool DENSE>
+hipError_t launch_halfstep(const Shape& sh, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
+#define EMX_CASE(g, v, c)                                                                             \
+    if (sh.G == g && sh.V == v && sh.CH == c) {                                                        \
+        auto kern = k_halfstep<g, v, c, MOVE, DENSE>;                                                  \
+        if (lds > 48 * 1024) {                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                             \
+        }                                                                                              \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                             \
+        return hipGetLastError();                                                                      \
+    }
+    if constexpr (!DENSE) {
+        EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(16, 1, 1) EMX_CASE(32, 1, 1) EMX_CASE(64, 1, 1)
+        EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(16, 2, 1) EMX_CASE(32, 2, 1) EMX_CASE(64, 2, 1)
+        EMX_CASE(64, 1, 2) EMX_CASE(64, 1, 4) EMX_CASE(64, 1, 8)
+        EMX_CASE(64, 2, 2) EMX_CASE(64, 2, 4) EMX_CASE(64, 2, 8)
+        if constexpr (MOVE == MOVE_STRETCH || MOVE == MOVE_EVAL) {
+            EMX_CASE(64, 1, 16) EMX_CASE(64, 2, 16)
+        }
+    } else {
+        EMX_CASE(16, 1, 1) EMX_CASE(32, 1, 1) EMX_CASE(64, 1, 1) EMX_CASE(64, 1, 2)
+        EMX_CASE(8, 2, 1) EMX_CASE(16, 2, 1) EMX_CASE(32, 2, 1) EMX_CASE(64, 2, 1)
+    }
+#undef EMX_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t dispatch_halfstep(int move, bool dense, const Shape& sh, dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                             const HalfStepArgs& a) {
+    switch (move) {
+        case MOVE_STRETCH:
+            return dense ? launch_halfstep<MOVE_STRETCH, true>(sh, grid, block, lds, st, a)
+                         : launch_halfstep<MOVE_STRETCH, false>(sh, grid, block, lds, st, a);
+        case MOVE_DE:
+            return dense ? launch_halfstep<MOVE_DE, true>(sh, grid, block, lds, st, a)
+                         : launch_halfstep<MOVE_DE, false>(sh, grid, block, lds, st, a);
+        case MOVE_SNOOKER:
+            return dense ? launch_halfstep<MOVE_SNOOKER, true>(sh, grid, block, lds, st, a)
+                         : launch_halfstep<MOVE_SNOOKER, false>(sh, grid, block, lds, st, a);
+        case MOVE_EVAL:
+            return dense ? launch_halfstep<MOVE_EVAL, true>(sh, grid, block, lds, st, a)
+                         : launch_halfstep<MOVE_EVAL, false>(sh, grid, block, lds, st, a);
+    }
+    return hipErrorInvalidValue;
+}
+
+size_t dense_lds_bytes(int Dp, int waves) {
+    const int RS = Dp + (((Dp >> 4) & 1) ? 0 : 16);
+    const int RT = Dp + 2;
+    return ((size_t)Dp * RS + Dp + (size_t)waves * (16 * RT + 32)) * sizeof(double);
+}
+
+// launch one fused (or propose-only) half-step over the slots [t_lo, t_hi) of `split`
+int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, int ns, int t_lo, int t_hi, bool native,
+                 const NativeArgs& nat, const emx_move_desc* mv, const emx_ctx::PlanSlot* ps, const int32_t* order,
+                 double* X, double* lp, double* chain, double* chain_lp, double* sendbuf) {
+    if (t_hi <= t_lo) return 0;
+    const bool dense = target == EMX_TARGET_DENSE_GAUSS;
+    const int D = c->D;
+    const Shape sh = pick_shape(D, dense ? c->Dp : D);
+    const int WPW = 64 / sh.G;
+    const int nown = t_hi - t_lo;
+    // slots per wave: enough waves to fill 256 CUs x 16 waves, batches no smaller than one pass
+    int64_t spw = c->tune_spw;
+    if (spw <= 0) {
+        spw = 64;
+        while (spw > WPW && nown / spw < (int64_t)c->num_cu * 16) spw >>= 1;
+        if (spw < WPW) spw = WPW;
+    }
+    if (dense && spw < 16) spw = 16;
+    if (spw > 64) spw = 64;
+    spw = (spw / WPW) * WPW;
+    if (spw < WPW) spw = WPW;
+    int waves_per_block = 4;
+    size_t lds = 0;
+    if (dense) {
+        while (waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
+        lds = dense_lds_bytes(c->Dp, waves_per_block);
+        if (lds > 160 * 1024) {
+            c->err = "dense Gaussian target: ndim too large for the LDS-resident precision matrix (max 112)";
+            return -1;
+        }
+    }
+    const int64_t nbatch = (nown + spw - 1) / spw;
+    int64_t nblocks = (nbatch + waves_per_block - 1) / waves_per_block;
+    if (dense) nblocks = std::min<int64_t>(nblocks, (int64_t)c->num_cu * c->tune_bpc);
+    HalfStepArgs a{};
+    a.X = X;
+    a.lp = lp;
+    a.acc = c->acc;
+    a.acc_count = c->acc_count;
+    a.chain = chain;
+    a.chain_lp = chain_lp;
+    a.status = c->status;
+    a.qout = c->qout;
+    a.fout = c->fout;
+    a.sendbuf = sendbuf;
+    a.order = order ? order : (ps ? ps->order : nullptr);
+    a.p0 = ps ? ps->p0 : nullptr;
+    a.p1 = ps ? ps->p1 : nullptr;
+    a.p2 = ps ? ps->p2 : nullptr;
+    a.s0 = ps ? ps->s0 : nullptr;
+    a.uacc = ps ? ps->uacc : nullptr;
+    a.tp0 = c->tp0;
+    a.tp1 = c->tp1;
+    a.tscale = c->tscale;
+    if (mv) {
+        a.a = mv->a;
+        a.sigma = mv->sigma;
+        a.g0 = mv->g0;
+        a.gammas = mv->gammas;
+    }
+    a.nat = nat;
+    a.N = (int32_t)c->N;
+    a.D = D;
+    a.S = S;
+    a.split = split;
+    a.pos0 = pos0;
+    a.ns = ns;
+    a.t_lo = t_lo;
+    a.t_hi = t_hi;
+    a.spw = (int32_t)spw;
+    a.native = native ? 1 : 0;
+    a.target = target;
+    a.Dp = dense ? c->Dp : 16;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;
+    if (prof) {
+        e0 = c->prof[2 * c->prof_n];
+        e1 = c->prof[2 * c->prof_n + 1];
+        if (hipEventRecord(e0, c->stream) != hipSuccess) return -2;
+    }
+    hipError_t e = dispatch_halfstep(move, dense, sh, dim3((unsigned)nblocks), dim3(64 * waves_per_block), lds, c->stream, a);
+    if (e != hipSuccess) {
+        char b[256];
+        snprintf(b, sizeof(b), "half-step launch failed (G=%d V=%d CH=%d move=%d dense=%d ndim=%d): %s", sh.G, sh.V, sh.CH,
+                 move, (int)dense, D, e == hipErrorInvalidValue ? "unsupported ndim for this build" : hipGetErrorString(e));
+        c->err = b;
+        return -2;
+    }
+    if (prof) {
+        if (hipEventRecord(e1, c->stream) != hipSuccess) return -2;
+        c->prof_n++;
+    }
+    return 0;
+}
+
+void shard_range(int64_t ns, int rank, int world, int64_t& lo, int64_t& hi) {
+    lo = ns * rank / world;
+    hi = ns * (rank + 1) / world;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* emx_version(void) { return "emx 0.1 (gfx950)"; }
+
+const char* emx_last_error(const emx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int emx_device_count(int32_t* n) {
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) {
+        *n = 0;
+        g_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return -2;
+    }
+    *n = k;
+    return 0;
+}
+
+int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
+    *out = nullptr;
+    emx_ctx* nullctx = nullptr;
+    NEED(nullctx, nwalkers >= 2 && nwalkers < (1ll << 31) && ndim >= 1, "invalid ensemble shape (%lld, %d)",
+         (long long)nwalkers, ndim);
+    int n = 0;
+    if (emx_device_count(&n) != 0 || n <= 0) FAIL(nullctx, -3, "no HIP device available (there is no CPU fallback)");
+    NEED(nullctx, device >= 0 && device < n, "device %d out of range (%d devices)", device, n);
+    HIPOK(nullctx, hipSetDevice(device));
+    emx_ctx* c = new emx_ctx();
+    c->device = device;
+    c->N = nwalkers;
+    c->D = ndim;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    const size_t N = (size_t)nwalkers, D = (size_t)ndim;
+#define ALLOC(ptr, bytes)                                         \
+    do {                                                          \
+        hipError_t _e = hipMalloc((void**)&(ptr), (bytes));       \
+        if (_e != hipSuccess) {                                   \
+            g_err = std::string("hipMalloc: ") + hipGetErrorString(_e); \
+            emx_destroy(c);                                       \
+            return -2;                                            \
+        }                                                         \
+    } while (0)
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        g_err = "hipStreamCreate failed";
+        delete c;
+        return -2;
+    }
+    c->stream = c->own_stream;
+    ALLOC(c->X, N * D * 8);
+    ALLOC(c->lp, N * 8);
+    ALLOC(c->acc, N);
+    ALLOC(c->acc_count, N * 4);
+    ALLOC(c->status, 4);
+    ALLOC(c->iota, N * 4);
+    ALLOC(c->qout, N * D * 8);
+    ALLOC(c->fout, N * 8);
+    ALLOC(c->newlp, N * 8);
+    ALLOC(c->evalX, N * D * 8);
+    ALLOC(c->evallp, N * 8);
+    for (int r = 0; r < PLAN_RING; ++r) {
+        auto& s = c->ring[r];
+        ALLOC(s.order, N * 4);
+        ALLOC(s.p0, N * 4);
+        ALLOC(s.p1, N * 4);
+        ALLOC(s.p2, N * 4);
+        ALLOC(s.s0, N * 8);
+        ALLOC(s.uacc, N * 8);
+        if (hipHostMalloc((void**)&s.host, N * 32, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming) != hipSuccess) {
+            g_err = "pinned plan buffer allocation failed";
+            emx_destroy(c);
+            return -2;
+        }
+    }
+#undef ALLOC
+    hipMemsetAsync(c->acc, 0, N, c->stream);
+    hipMemsetAsync(c->acc_count, 0, N * 4, c->stream);
+    hipMemsetAsync(c->status, 0, 4, c->stream);
+    hipMemsetAsync(c->lp, 0, N * 8, c->stream);
+    {
+        std::vector<int32_t> io(N);
+        for (size_t i = 0; i < N; ++i) io[i] = (int32_t)i;
+        hipMemcpyAsync(c->iota, io.data(), N * 4, hipMemcpyHostToDevice, c->stream);
+        hipStreamSynchronize(c->stream);
+    }
+    hipEventCreate(&c->ev0);
+    hipEventCreate(&c->ev1);
+    emx_move_desc d{};
+    d.kind = EMX_MOVE_STRETCH;
+    d.nsplits = 2;
+    d.randomize_split = 1;
+    d.a = 2.0;
+    d.sigma = 1e-5;
+    d.g0 = 2.38 / std::sqrt(2.0 * ndim);
+    d.gammas = 1.7;
+    c->moves.assign(1, d);
+    c->cdf.assign(1, 1.0);
+    *out = c;
+    return 0;
+}
+
+int emx_destroy(emx_ctx* c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->X, c->lp, c->acc, c->acc_count, c->status, c->iota, c->qout, c->fout, c->newlp, c->evalX,
+                    c->evallp, c->tp0, c->tp1, c->chain, c->chain_lp, c->sendbuf, c->gathered};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    for (auto& s : c->ring) {
+        void* q[] = {s.order, s.p0, s.p1, s.p2, s.s0, s.uacc};
+        for (void* p : q)
+            if (p) hipFree(p);
+        if (s.host) hipHostFree(s.host);
+        if (s.consumed) hipEventDestroy(s.consumed);
+    }
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    for (auto e : c->prof) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+int emx_set_stream(emx_ctx* c, void* s) {
+    NEED(c, c, "null ctx");
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+int emx_sync(emx_ctx* c) {
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int emx_status(emx_ctx* c, uint32_t* bits) {
+    HIPOK(c, hipMemcpyAsync(bits, c->status, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (*bits) HIPOK(c, hipMemsetAsync(c->status, 0, 4, c->stream));
+    return 0;
+}
+
+int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
+    if (!strcmp(key, "spw")) {
+        c->tune_spw = v;
+        return 0;
+    }
+    if (!strcmp(key, "blocks_per_cu")) {
+        c->tune_bpc = v > 0 ? v : 2;
+        return 0;
+    }
+    FAIL(c, -1, "unknown tuning key %s", key);
+}
+
+int emx_set_state(emx_ctx* c, const double* coords, const double* log_prob) {
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipMemcpyAsync(c->X, coords, (size_t)c->N * c->D * 8, hipMemcpyHostToDevice, c->stream));
+    if (log_prob) HIPOK(c, hipMemcpyAsync(c->lp, log_prob, (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int emx_get_state(emx_ctx* c, double* coords, double* log_prob) {
+    HIPOK(c, hipSetDevice(c->device));
+    if (coords) HIPOK(c, hipMemcpyAsync(coords, c->X, (size_t)c->N * c->D * 8, hipMemcpyDeviceToHost, c->stream));
+    if (log_prob) HIPOK(c, hipMemcpyAsync(log_prob, c->lp, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int emx_get_accepted(emx_ctx* c, uint8_t* mask) {
+    HIPOK(c, hipMemcpyAsync(mask, c->acc, (size_t)c->N, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1, double scale) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, kind >= EMX_TARGET_HOST && kind <= EMX_TARGET_BOX, "unknown target kind %d", kind);
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (c->tp0) hipFree(c->tp0), c->tp0 = nullptr;
+    if (c->tp1) hipFree(c->tp1), c->tp1 = nullptr;
+    const size_t D = (size_t)c->D;
+    if (kind == EMX_TARGET_DIAG_GAUSS || kind == EMX_TARGET_DENSE_GAUSS) {
+        NEED(c, p0 && p1, "target needs (mu, ivar|icov)");
+        const size_t n1 = kind == EMX_TARGET_DENSE_GAUSS ? D * D : D;
+        if (kind == EMX_TARGET_DENSE_GAUSS) {
+            c->Dp = (int)((D + 15) / 16 * 16);
+            NEED(c, dense_lds_bytes(c->Dp, 1) <= 160 * 1024,
+                 "dense Gaussian target supports ndim <= 112 (LDS-resident precision matrix); got %d", c->D);
+        }
+        HIPOK(c, hipMalloc((void**)&c->tp0, D * 8));
+        HIPOK(c, hipMalloc((void**)&c->tp1, n1 * 8));
+        HIPOK(c, hipMemcpy(c->tp0, p0, D * 8, hipMemcpyHostToDevice));
+        HIPOK(c, hipMemcpy(c->tp1, p1, n1 * 8, hipMemcpyHostToDevice));
+    }
+    c->target = kind;
+    c->tscale = (kind == EMX_TARGET_ROSENBROCK) ? (scale != 0.0 ? scale : 20.0) : 1.0;
+    return 0;
+}
+
+static int eval_rows(emx_ctx* c, double* X, double* lp, int64_t n) {
+    NEED(c, c->target != EMX_TARGET_HOST, "no device target set");
+    NativeArgs nat{};
+    emx_move_desc mv = c->moves[0];
+    const int64_t saveN = c->N;
+    int rc = launch_split(c, MOVE_EVAL, c->target, 1, 0, 0, (int)n, 0, (int)n, false, nat, &mv, nullptr, c->iota, X, lp,
+                          nullptr, nullptr, nullptr);
+    (void)saveN;
+    return rc;
+}
+
+int emx_eval_state_log_prob(emx_ctx* c) {
+    HIPOK(c, hipSetDevice(c->device));
+    return eval_rows(c, c->X, c->lp, c->N);
+}
+
+int emx_eval_log_prob(emx_ctx* c, const double* coords, int64_t n, double* out) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, n >= 0 && n <= c->N, "emx_eval_log_prob: n must be <= nwalkers");
+    if (n == 0) return 0;
+    HIPOK(c, hipMemcpyAsync(c->evalX, coords, (size_t)n * c->D * 8, hipMemcpyHostToDevice, c->stream));
+    int rc = eval_rows(c, c->evalX, c->evallp, n);
+    if (rc) return rc;
+    HIPOK(c, hipMemcpyAsync(out, c->evallp, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const double* cdf) {
+    NEED(c, nmoves >= 1, "need at least one move");
+    for (int i = 0; i < nmoves; ++i) {
+        NEED(c, moves[i].kind >= 0 && moves[i].kind <= 2, "unknown move kind");
+        NEED(c, moves[i].nsplits >= 2 && moves[i].nsplits <= 64, "nsplits must be in [2, 64]");
+        NEED(c, moves[i].kind != EMX_MOVE_SNOOKER || moves[i].nsplits >= 4, "snooker needs nsplits >= 4");
+        NEED(c, moves[i].nsplits <= c->N, "more splits than walkers");
+    }
+    c->moves.assign(moves, moves + nmoves);
+    c->cdf.assign(cdf, cdf + nmoves);
+    return 0;
+}
+
+int emx_set_rng_mode(emx_ctx* c, int32_t mode) {
+    NEED(c, mode >= 0 && mode <= 2, "unknown rng mode");
+    c->rng_mode = mode;
+    return 0;
+}
+
+int emx_rng_set_mt19937(emx_ctx* c, const uint32_t key[624], int32_t pos, int32_t hg, double cached) {
+    NEED(c, pos >= 0 && pos <= 624, "bad MT19937 position");
+    c->mt.set_state(key, pos, hg, cached);
+    return 0;
+}
+
+int emx_rng_get_mt19937(emx_ctx* c, uint32_t key[624], int32_t* pos, int32_t* hg, double* cached) {
+    memcpy(key, c->mt.key, sizeof(c->mt.key));
+    *pos = c->mt.pos;
+    *hg = c->mt.has_gauss;
+    *cached = c->mt.gauss;
+    return 0;
+}
+
+int emx_rng_set_philox(emx_ctx* c, uint64_t seed, uint64_t step) {
+    c->ph_seed = seed;
+    c->ph_step = step;
+    return 0;
+}
+
+int emx_rng_get_philox(emx_ctx* c, uint64_t* seed, uint64_t* step) {
+    *seed = c->ph_seed;
+    *step = c->ph_step;
+    return 0;
+}
+
+int emx_chain_config(emx_ctx* c, int64_t cap) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, cap >= c->stored, "capacity below the number of stored steps");
+    if (cap == c->cap) return 0;
+    double *nc = nullptr, *nl = nullptr;
+    const size_t row = (size_t)c->N * c->D * 8, lrow = (size_t)c->N * 8;
+    if (cap > 0) {
+        hipError_t e = hipMalloc((void**)&nc, row * cap);
+        if (e != hipSuccess) FAIL(c, -4, "chain allocation of %.2f GB failed: %s", row * cap / 1e9, hipGetErrorString(e));
+        e = hipMalloc((void**)&nl, lrow * cap);
+        if (e != hipSuccess) {
+            hipFree(nc);
+            FAIL(c, -4, "chain log_prob allocation failed: %s", hipGetErrorString(e));
+        }
+        if (c->stored > 0) {
+            HIPOK(c, hipMemcpyAsync(nc, c->chain, row * c->stored, hipMemcpyDeviceToDevice, c->stream));
+            HIPOK(c, hipMemcpyAsync(nl, c->chain_lp, lrow * c->stored, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (c->chain) hipFree(c->chain);
+    if (c->chain_lp) hipFree(c->chain_lp);
+    c->chain = nc;
+    c->chain_lp = nl;
+    c->cap = cap;
+    return 0;
+}
+
+int emx_chain_reset(emx_ctx* c) {
+    HIPOK(c, hipSetDevice(c->device));
+    c->stored = 0;
+    c->proposals = 0;
+    HIPOK(c, hipMemsetAsync(c->acc_count, 0, (size_t)c->N * 4, c->stream));
+    return 0;
+}
+
+int emx_iteration(emx_ctx* c, int64_t* stored, int64_t* proposals) {
+    *stored = c->stored;
+    *proposals = c->proposals;
+    return 0;
+}
+
+int emx_chain_read(emx_ctx* c, int32_t what, int64_t start, int64_t stop, int64_t stride, double* out) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, stride >= 1 && start >= 0 && stop <= c->stored, "chain slice out of range");
+    const size_t row = what == 0 ? (size_t)c->N * c->D * 8 : (size_t)c->N * 8;
+    const char* base = what == 0 ? (const char*)c->chain : (const char*)c->chain_lp;
+    char* o = (char*)out;
+    if (stride == 1) {
+        if (stop > start)
+            HIPOK(c, hipMemcpyAsync(o, base + row * start, row * (stop - start), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        for (int64_t s = start; s < stop; s += stride, o += row)
+            HIPOK(c, hipMemcpyAsync(o, base + row * s, row, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int emx_accepted_counts(emx_ctx* c, double* out) {
+    std::vector<uint32_t> h((size_t)c->N);
+    HIPOK(c, hipMemcpyAsync(h.data(), c->acc_count, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < c->N; ++i) out[i] = (double)h[i];
+    return 0;
+}
+
+// ---- stepping ----------------------------------------------------------------------------
+static int upload_plan(emx_ctx* c, emx_ctx::PlanSlot& s) {
+    const size_t N = (size_t)c->N;
+    int32_t* hi = (int32_t*)s.host;
+    double* hd = (double*)(s.host + N * 16);
+    HIPOK(c, hipMemcpyAsync(s.order, hi, N * 4, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(s.p0, hi + N, N * 4, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(s.p1, hi + 2 * N, N * 4, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(s.p2, hi + 3 * N, N * 4, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(s.s0, hd, N * 8, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(s.uacc, hd + N, N * 8, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+static int acquire_slot(emx_ctx* c, emx_ctx::PlanSlot** out) {
+    c->ring_pos = (c->ring_pos + 1) % PLAN_RING;
+    auto& s = c->ring[c->ring_pos];
+    if (s.busy) {
+        HIPOK(c, hipEventSynchronize(s.consumed));
+        s.busy = false;
+    }
+    *out = &s;
+    return 0;
+}
+
+int emx_step_begin(emx_ctx* c, int32_t store, int32_t* move_out, int32_t* S_out) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, !c->cur.active, "emx_step_begin: previous step not ended");
+    if (store) NEED(c, c->stored < c->cap, "chain capacity exhausted (call emx_chain_config)");
+    auto& cur = c->cur;
+    cur.store = store != 0;
+    cur.native = false;
+    const int nm = (int)c->moves.size();
+    if (c->rng_mode == EMX_RNG_MT19937) {
+        cur.move = c->mt.choice_cdf(c->cdf.data(), nm);                        // ensemble.py:406
+        const emx_move_desc& mv = c->moves[cur.move];
+        cur.S = mv.nsplits;
+        NEED(c, c->N >= 2 && (mv.kind != EMX_MOVE_DE || c->N - (c->N + cur.S - 1) / cur.S >= 2),
+             "complement too small for this move");
+        emx_ctx::PlanSlot* ps;
+        int rc = acquire_slot(c, &ps);
+        if (rc) return rc;
+        cur.slot = c->ring_pos;
+        cur.off.assign(cur.S + 1, 0);
+        const size_t N = (size_t)c->N;
+        int32_t* hi = (int32_t*)ps->host;
+        double* hd = (double*)(ps->host + N * 16);
+        rc = make_exact_plan(c->mt, c->N, c->D, mv, c->labels_scratch, cur.off.data(), hi, hi + N, hi + 2 * N, hi + 3 * N,
+                             hd, hd + N);
+        NEED(c, rc == 0, "plan generation failed");
+        rc = upload_plan(c, *ps);
+        if (rc) return rc;
+    } else if (c->rng_mode == EMX_RNG_PHILOX) {
+        cur.move = philox_move_choice(c->ph_seed, c->ph_step, c->cdf.data(), nm);
+        const emx_move_desc& mv = c->moves[cur.move];
+        cur.S = mv.nsplits;
+        cur.native = true;
+        cur.nat.seed = c->ph_seed;
+        cur.nat.step = c->ph_step;
+        cur.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, c->ph_step);
+        cur.off.assign(cur.S + 1, 0);
+        for (int s = 0; s < cur.S; ++s) cur.off[s + 1] = cur.off[s] + (int32_t)((c->N - s + cur.S - 1) / cur.S);
+        cur.slot = -1;
+    } else {
+        // INPUTS: emx_plan_set must follow
+        cur.move = -1;
+        cur.S = 0;
+        cur.slot = -1;
+    }
+    cur.active = true;
+    if (move_out) *move_out = cur.move;
+    if (S_out) *S_out = cur.S;
+    return 0;
+}
+
+int emx_plan_set(emx_ctx* c, int32_t move_index, const int32_t* off, const int32_t* order, const int32_t* p0,
+                 const int32_t* p1, const int32_t* p2, const double* s0, const double* uacc) {
+    NEED(c, c->cur.active, "emx_plan_set outside a step");
+    NEED(c, move_index >= 0 && move_index < (int)c->moves.size(), "bad move index");
+    auto& cur = c->cur;
+    cur.move = move_index;
+    cur.S = c->moves[move_index].nsplits;
+    cur.native = false;
+    cur.off.assign(off, off + cur.S + 1);
+    NEED(c, cur.off[0] == 0 && cur.off[cur.S] == c->N, "plan offsets must cover all walkers");
+    emx_ctx::PlanSlot* ps;
+    int rc = acquire_slot(c, &ps);
+    if (rc) return rc;
+    cur.slot = c->ring_pos;
+    const size_t N = (size_t)c->N;
+    int32_t* hi = (int32_t*)ps->host;
+    double* hd = (double*)(ps->host + N * 16);
+    memcpy(hi, order, N * 4);
+    memcpy(hi + N, p0, N * 4);
+    memcpy(hi + 2 * N, p1 ? p1 : order, N * 4);
+    memcpy(hi + 3 * N, p2 ? p2 : order, N * 4);
+    if (s0) memcpy(hd, s0, N * 8); else memset(hd, 0, N * 8);
+    memcpy(hd + N, uacc, N * 8);
+    return upload_plan(c, *ps);
+}
+
+int emx_plan_get(emx_ctx* c, int32_t* off, int32_t* order, int32_t* p0, int32_t* p1, int32_t* p2, double* s0,
+                 double* uacc) {
+    NEED(c, c->cur.active, "emx_plan_get outside a step");
+    auto& cur = c->cur;
+    const size_t N = (size_t)c->N;
+    memcpy(off, cur.off.data(), (cur.S + 1) * 4);
+    if (cur.native) {
+        // let the device evaluate the native plan (the same function the half-step kernels inline)
+        auto& ps = c->ring[0];
+        if (ps.busy) {
+            HIPOK(c, hipEventSynchronize(ps.consumed));
+            ps.busy = false;
+        }
+        const emx_move_desc& mv = c->moves[cur.move];
+        dim3 g((unsigned)((N + 255) / 256)), b(256);
+        switch (mv.kind) {
+            case EMX_MOVE_STRETCH:
+                hipLaunchKernelGGL(k_native_plan<MOVE_STRETCH>, g, b, 0, c->stream, cur.nat, (int)N, cur.S, mv.a, mv.sigma,
+                                   mv.g0, ps.order, ps.p0, ps.p1, ps.p2, ps.s0, ps.uacc);
+                break;
+            case EMX_MOVE_DE:
+                hipLaunchKernelGGL(k_native_plan<MOVE_DE>, g, b, 0, c->stream, cur.nat, (int)N, cur.S, mv.a, mv.sigma,
+                                   mv.g0, ps.order, ps.p0, ps.p1, ps.p2, ps.s0, ps.uacc);
+                break;
+            default:
+                hipLaunchKernelGGL(k_native_plan<MOVE_SNOOKER>, g, b, 0, c->stream, cur.nat, (int)N, cur.S, mv.a, mv.sigma,
+                                   mv.g0, ps.order, ps.p0, ps.p1, ps.p2, ps.s0, ps.uacc);
+        }
+        HIPOK(c, hipGetLastError());
+        HIPOK(c, hipMemcpyAsync(order, ps.order, N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipMemcpyAsync(p0, ps.p0, N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipMemcpyAsync(p1, ps.p1, N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipMemcpyAsync(p2, ps.p2, N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipMemcpyAsync(s0, ps.s0, N * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipMemcpyAsync(uacc, ps.uacc, N * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    NEED(c, cur.slot >= 0, "no plan available");
+    auto& ps = c->ring[cur.slot];
+    const int32_t* hi = (const int32_t*)ps.host;
+    const double* hd = (const double*)(ps.host + N * 16);
+    memcpy(order, hi, N * 4);
+    memcpy(p0, hi + N, N * 4);
+    memcpy(p1, hi + 2 * N, N * 4);
+    memcpy(p2, hi + 3 * N, N * 4);
+    memcpy(s0, hd, N * 8);
+    memcpy(uacc, hd + N, N * 8);
+    return 0;
+}
+
+static int do_halfstep(emx_ctx* c, int split, int target) {
+    auto& cur = c->cur;
+    NEED(c, cur.active && cur.move >= 0, "half-step outside a planned step");
+    NEED(c, split >= 0 && split < cur.S, "split out of range");
+    const emx_move_desc& mv = c->moves[cur.move];
+    const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
+    int64_t lo = 0, hi = ns;
+    if (c->world > 1) shard_range(ns, c->rank, c->world, lo, hi);
+    double *chain = nullptr, *chain_lp = nullptr;
+    if (cur.store) {
+        chain = c->chain + (size_t)c->stored * c->N * c->D;
+        chain_lp = c->chain_lp + (size_t)c->stored * c->N;
+    }
+    emx_ctx::PlanSlot* ps = cur.slot >= 0 ? &c->ring[cur.slot] : nullptr;
+    double* sb = nullptr;
+    if (c->world > 1 && target != EMX_TARGET_HOST) sb = c->sendbuf;
+    return launch_split(c, mv.kind, target, cur.S, split, pos0, ns, (int)lo, (int)hi, cur.native, cur.nat, &mv, ps,
+                        nullptr, c->X, c->lp, chain, chain_lp, sb);
+}
+
+int emx_halfstep(emx_ctx* c, int32_t split) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, c->target != EMX_TARGET_HOST, "emx_halfstep needs a device target (use emx_propose/emx_accept)");
+    return do_halfstep(c, split, c->target);
+}
+
+int emx_propose(emx_ctx* c, int32_t split, double* q_out, int64_t* ns_out) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, c->world == 1, "split-phase host targets are single-rank");
+    int rc = do_halfstep(c, split, EMX_TARGET_HOST);
+    if (rc) return rc;
+    const auto& cur = c->cur;
+    const int64_t ns = cur.off[split + 1] - cur.off[split];
+    if (ns_out) *ns_out = ns;
+    if (q_out && ns > 0)
+        HIPOK(c, hipMemcpyAsync(q_out, c->qout, (size_t)ns * c->D * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int emx_accept(emx_ctx* c, int32_t split, const double* new_lp) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, cur.active && cur.move >= 0, "emx_accept outside a planned step");
+    const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
+    if (ns <= 0) return 0;
+    HIPOK(c, hipMemcpyAsync(c->newlp, new_lp, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
+    AcceptArgs a{};
+    a.X = c->X;
+    a.lp = c->lp;
+    a.acc = c->acc;
+    a.acc_count = c->acc_count;
+    if (cur.store) {
+        a.chain = c->chain + (size_t)c->stored * c->N * c->D;
+        a.chain_lp = c->chain_lp + (size_t)c->stored * c->N;
+    }
+    a.status = c->status;
+    a.qout = c->qout;
+    a.fout = c->fout;
+    a.new_lp = c->newlp;
+    a.order = cur.slot >= 0 ? c->ring[cur.slot].order : nullptr;
+    a.uacc = cur.slot >= 0 ? c->ring[cur.slot].uacc : nullptr;
+    a.nat = cur.nat;
+    a.N = (int32_t)c->N;
+    a.D = c->D;
+    a.S = cur.S;
+    a.split = split;
+    a.pos0 = pos0;
+    a.ns = ns;
+    a.native = cur.native ? 1 : 0;
+    a.move = c->moves[cur.move].kind;
+    hipLaunchKernelGGL(k_accept, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, c->stream, a);
+    HIPOK(c, hipGetLastError());
+    return 0;
+}
+
+int emx_step_end(emx_ctx* c) {
+    auto& cur = c->cur;
+    NEED(c, cur.active, "emx_step_end without emx_step_begin");
+    if (cur.slot >= 0) {
+        auto& s = c->ring[cur.slot];
+        HIPOK(c, hipEventRecord(s.consumed, c->stream));
+        s.busy = true;
+    }
+    if (cur.store) c->stored++;
+    c->proposals++;
+    if (c->rng_mode == EMX_RNG_PHILOX) c->ph_step++;
+    cur.active = false;
+    return 0;
+}
+
+int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, thin_by >= 1, "Invalid thinning argument");
+    NEED(c, c->rng_mode != EMX_RNG_INPUTS, "emx_run needs an RNG mode that generates plans");
+    NEED(c, c->target != EMX_TARGET_HOST, "emx_run needs a device target");
+    NEED(c, c->world == 1, "emx_run is single-rank; sharded runs drive emx_halfstep from the host layer");
+    if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
+    int64_t i = 0;
+    for (int64_t it = 0; it < nsteps; ++it)
+        for (int k = 0; k < thin_by; ++k, ++i) {
+            const int st = store && ((i + 1) % thin_by == 0);                   // ensemble.py:416
+            int mvi, S;
+            int rc = emx_step_begin(c, st, &mvi, &S);
+            if (rc) return rc;
+            for (int s = 0; s < S; ++s) {
+                rc = do_halfstep(c, s, c->target);
+                if (rc) {
+                    c->cur.active = false;
+                    return rc;
+                }
+            }
+            rc = emx_step_end(c);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+// ---- sharding ----------------------------------------------------------------------------
+int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, world >= 1 && rank >= 0 && rank < world, "bad (rank, world)");
+    c->rank = rank;
+    c->world = world;
+    if (world > 1) {
+        // the largest sub-ensemble is ceil(N/2); per-rank share rounded up
+        const int64_t maxns = (c->N + 1) / 2 + 1;
+        const int64_t per = (maxns + world - 1) / world + 1;
+        if (c->sendbuf) hipFree(c->sendbuf), c->sendbuf = nullptr;
+        if (c->gathered) hipFree(c->gathered), c->gathered = nullptr;
+        HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * c->D * 8));
+        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * world * c->D * 8));
+        c->sendbuf_rows = per;
+        c->gathered_rows = per * world;
+    }
+    return 0;
+}
+
+int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
+    switch (which) {
+        case 0: *ptr = c->X; *nbytes = c->N * c->D * 8; return 0;
+        case 1: *ptr = c->lp; *nbytes = c->N * 8; return 0;
+        case 2: *ptr = c->sendbuf; *nbytes = c->sendbuf_rows * c->D * 8; return 0;
+        case 3: *ptr = c->gathered; *nbytes = c->gathered_rows * c->D * 8; return 0;
+    }
+    FAIL(c, -1, "unknown device pointer id %d", which);
+}
+
+int emx_shard_slots(emx_ctx* c, int32_t split, int64_t* lo, int64_t* hi, int64_t* ns) {
+    auto& cur = c->cur;
+    NEED(c, cur.active && split >= 0 && split < cur.S, "emx_shard_slots outside a planned step");
+    *ns = cur.off[split + 1] - cur.off[split];
+    shard_range(*ns, c->rank, c->world, *lo, *hi);
+    return 0;
+}
+
+int emx_scatter_gathered(emx_ctx* c, int32_t split) {
+    // `gathered` holds world blocks of `sendbuf_rows` rows; block r carries rank r's slots.
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, cur.active && c->world > 1, "emx_scatter_gathered needs an active sharded step");
+    const int ns = cur.off[split + 1] - cur.off[split];
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) continue;
+        int64_t lo, hi;
+        shard_range(ns, r, c->world, lo, hi);
+        if (hi <= lo) continue;
+        ScatterArgs a{};
+        a.X = c->X;
+        // rows of rank r start at block offset; express as a virtual (ns, D) array shifted so row t maps right
+        a.gathered = c->gathered + ((size_t)r * c->sendbuf_rows - (size_t)lo) * c->D;
+        a.order = cur.slot >= 0 ? c->ring[cur.slot].order : nullptr;
+        a.nat = cur.nat;
+        a.N = (int32_t)c->N;
+        a.D = c->D;
+        a.S = cur.S;
+        a.split = split;
+        a.pos0 = cur.off[split];
+        a.ns = (int32_t)hi;
+        a.native = cur.native ? 1 : 0;
+        a.own_lo = 0;
+        a.own_hi = (int32_t)lo;   // skip slots below lo
+        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((hi + 3) / 4)), dim3(256), 0, c->stream, a);
+        HIPOK(c, hipGetLastError());
+    }
+    return 0;
+}
+
+// ---- measurement -------------------------------------------------------------------------
+int emx_timer_start(emx_ctx* c) {
+    HIPOK(c, hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+
+int emx_timer_stop(emx_ctx* c, float* ms) {
+    HIPOK(c, hipEventRecord(c->ev1, c->stream));
+    HIPOK(c, hipEventSynchronize(c->ev1));
+    HIPOK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+int emx_profile_enable(emx_ctx* c, int32_t max_launches) {
+    HIPOK(c, hipSetDevice(c->device));
+    for (auto e : c->prof) hipEventDestroy(e);
+    c->prof.clear();
+    c->prof_max = max_launches;
+    c->prof_n = 0;
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipEvent_t e;
+        HIPOK(c, hipEventCreate(&e));
+        c->prof.push_back(e);
+    }
+    return 0;
+}
+
+int emx_profile_read(emx_ctx* c, float* ms_out, int32_t* n) {
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    const int k = std::min<int>(*n, c->prof_n);
+    for (int i = 0; i < k; ++i) HIPOK(c, hipEventElapsedTime(&ms_out[i], c->prof[2 * i], c->prof[2 * i + 1]));
+    *n = k;
+    c->prof_n = 0;
+    return 0;
+}
+
+// ---- host-only helpers -------------------------------------------------------------------
+emx_mt* emx_mt_create(const uint32_t key[624], int32_t pos, int32_t hg, double cached) {
+    emx_mt* m = new emx_mt();
+    m->mt.set_state(key, pos, hg, cached);
+    return m;
+}
+void emx_mt_destroy(emx_mt* m) { delete m; }
+void emx_mt_get_state(const emx_mt* m, uint32_t key[624], int32_t* pos, int32_t* hg, double* cached) {
+    memcpy(key, m->mt.key, sizeof(m->mt.key));
+    *pos = m->mt.pos;
+    *hg = m->mt.has_gauss;
+    *cached = m->mt.gauss;
+}
+void emx_mt_random_sample(emx_mt* m, int64_t n, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = m->mt.next_double();
+}
+void emx_mt_randint(emx_mt* m, uint64_t bound, int64_t n, int64_t* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = (int64_t)m->mt.randint(bound);
+}
+void emx_mt_randn(emx_mt* m, int64_t n, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = m->mt.next_gauss();
+}
+void emx_mt_shuffle_labels(emx_mt* m, int64_t n, int32_t S, int32_t* labels) {
+    for (int64_t i = 0; i < n; ++i) labels[i] = (int32_t)(i % S);
+    m->mt.shuffle(labels, n);
+}
+int32_t emx_mt_choice_cdf(emx_mt* m, const double* cdf, int32_t n) { return m->mt.choice_cdf(cdf, n); }
+
+int emx_host_plan_mt(emx_mt* m, int64_t N, int32_t D, const emx_move_desc* mv, int32_t* off, int32_t* order, int32_t* p0,
+                     int32_t* p1, int32_t* p2, double* s0, double* uacc) {
+    std::vector<int32_t> labels;
+    return make_exact_plan(m->mt, N, D, *mv, labels, off, order, p0, p1, p2, s0, uacc);
+}
+
+int emx_host_plan_philox(uint64_t seed, uint64_t step, int64_t N, const emx_move_desc* mv, int32_t* off, int32_t* order,
+                         int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc) {
+    NativeArgs na{};
+    na.seed = seed;
+    na.step = step;
+    na.pk = make_perm_key((uint64_t)N, seed, step);
+    switch (mv->kind) {
+        case EMX_MOVE_STRETCH: host_native_plan<MOVE_STRETCH>(na, N, *mv, off, order, p0, p1, p2, s0, uacc); return 0;
+        case EMX_MOVE_DE: host_native_plan<MOVE_DE>(na, N, *mv, off, order, p0, p1, p2, s0, uacc); return 0;
+        case EMX_MOVE_SNOOKER: host_native_plan<MOVE_SNOOKER>(na, N, *mv, off, order, p0, p1, p2, s0, uacc); return 0;
+    }
+    return -1;
+}
+
+int32_t emx_host_move_choice_philox(uint64_t seed, uint64_t step, const double* cdf, int32_t n) {
+    return philox_move_choice(seed, step, cdf, n);
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// Counter-based RNG (Philox4x32-10) and the keyed walker permutation used by the native
+// (EMX_RNG_PHILOX) mode.  Every function is __host__ __device__ so that the host can
+// reproduce, bit for bit, the plan a kernel derives in flight (used by the parity tests).
+//
+// The native mode replaces the reference's serial MT19937 consumer
+// (red_blue.py:80 shuffle, stretch.py:30-32, red_blue.py:100) with draws that are a pure
+// function of (seed, step, walker): same distributions, different stream.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define EMX_HD __host__ __device__ __forceinline__
+#else
+#define EMX_HD inline
+#endif
+
+namespace emx {
+
+EMX_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+struct Philox4 {
+    uint32_t v[4];
+};
+
+// Philox4x32-10 (Salmon et al. 2011), key = 64-bit seed, counter = 128 bits.
+EMX_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += W0;
+        k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0;
+    o.v[1] = c1;
+    o.v[2] = c2;
+    o.v[3] = c3;
+    return o;
+}
+
+// 53-bit uniform in [0,1) from two words (same construction as MT19937 random_sample).
+EMX_HD double u53(uint32_t a, uint32_t b) {
+    return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// Unbiased-enough bounded integer in [0, n): 64-bit multiply-high (bias < n / 2^64).
+EMX_HD uint64_t bounded64(uint32_t a, uint32_t b, uint64_t n) {
+    const uint64_t r = ((uint64_t)a << 32) | (uint64_t)b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(r, n);
+#else
+    return (uint64_t)(((unsigned __int128)r * (unsigned __int128)n) >> 64);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+// Keyed bijection on [0, n): the per-step random split.  Walker w belongs to
+// sub-ensemble  perm(w) % nsplits  and is member number  perm(w) / nsplits  of it, which
+// gives exactly the set sizes of `arange(n) % nsplits` shuffled (red_blue.py:78-80).
+// Built from invertible k-bit mixers (xorshift / odd multiply-add), cycle-walked for
+// non-power-of-two n.
+// ---------------------------------------------------------------------------------------
+struct PermKey {
+    uint64_t n;
+    uint32_t bits;       // k = ceil(log2(n)), >= 1
+    uint32_t mask;       // 2^k - 1   (n <= 2^31)
+    uint32_t m1, c1, m2, c2, m3, c3;         // odd multipliers / offsets
+    uint32_t m1inv, m2inv, m3inv;            // inverses mod 2^k
+    uint32_t s1, s2;                          // xorshift amounts
+};
+
+EMX_HD uint32_t perm_mix(uint32_t x, const PermKey& k) {
+    x = (x * k.m1 + k.c1) & k.mask;
+    x ^= x >> k.s1;
+    x = (x * k.m2 + k.c2) & k.mask;
+    x ^= x >> k.s2;
+    x = (x * k.m3 + k.c3) & k.mask;
+    x ^= x >> k.s1;
+    return x;
+}
+
+EMX_HD uint32_t unxorshift(uint32_t y, uint32_t s, uint32_t bits) {
+    uint32_t x = y;
+    for (uint32_t sh = s; sh < bits; sh += s) x ^= y >> sh;
+    return x;
+}
+
+EMX_HD uint32_t perm_unmix(uint32_t x, const PermKey& k) {
+    x = unxorshift(x, k.s1, k.bits);
+    x = ((x - k.c3) * k.m3inv) & k.mask;
+    x = unxorshift(x, k.s2, k.bits);
+    x = ((x - k.c2) * k.m2inv) & k.mask;
+    x = unxorshift(x, k.s1, k.bits);
+    x = ((x - k.c1) * k.m1inv) & k.mask;
+    return x;
+}
+
+EMX_HD uint32_t perm_fwd(uint32_t w, const PermKey& k) {
+    uint32_t x = perm_mix(w, k);
+    while (x >= k.n) x = perm_mix(x, k);
+    return x;
+}
+
+EMX_HD uint32_t perm_inv(uint32_t p, const PermKey& k) {
+    uint32_t x = perm_unmix(p, k);
+    while (x >= k.n) x = perm_unmix(x, k);
+    return x;
+}
+
+inline uint32_t modinv_pow2(uint32_t a) {  // a odd; inverse mod 2^32 (Newton)
+    uint32_t x = a;
+    for (int i = 0; i < 5; ++i) x *= 2u - a * x;
+    return x;
+}
+
+inline PermKey make_perm_key(uint64_t n, uint64_t seed, uint64_t step) {
+    PermKey k{};
+    k.n = n;
+    uint32_t bits = 1;
+    while ((1ull << bits) < n) ++bits;
+    k.bits = bits;
+    k.mask = bits >= 32 ? 0xffffffffu : (uint32_t)((1ull << bits) - 1);
+    const Philox4 a = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), 0x5045524du /*'PERM'*/, 0, (uint32_t)seed,
+                                    (uint32_t)(seed >> 32));
+    const Philox4 b = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), 0x5045524du, 1, (uint32_t)seed,
+                                    (uint32_t)(seed >> 32));
+    k.m1 = a.v[0] | 1u;
+    k.c1 = a.v[1];
+    k.m2 = a.v[2] | 1u;
+    k.c2 = a.v[3];
+    k.m3 = b.v[0] | 1u;
+    k.c3 = b.v[1];
+    // multipliers ~ golden-ratio-like: force some high/low structure so that tiny k still mixes
+    k.m1 = (k.m1 & ~6u) | 4u | 1u;  // == 5 mod 8: maximal multiplicative order
+    k.m2 = (k.m2 & ~6u) | 4u | 1u;
+    k.m3 = (k.m3 & ~6u) | 4u | 1u;
+    k.m1inv = modinv_pow2(k.m1);
+    k.m2inv = modinv_pow2(k.m2);
+    k.m3inv = modinv_pow2(k.m3);
+    k.s1 = bits > 1 ? (bits + 1) / 2 : 1;
+    k.s2 = bits > 2 ? (bits + 2) / 3 : 1;
+    return k;
+}
+
+}  // namespace emx

@@ -1,0 +1,240 @@
+"""DeviceEnsemble: the Python handle on one libemx context (one ensemble on one MI355X).
+
+This is the host side of the C ABI in include/emx.h; it owns no algorithmic logic beyond
+argument marshalling.  There is no CPU fallback: construction raises when the HIP library
+or a GPU is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EmxError, MoveDesc
+
+__all__ = ["DeviceEnsemble", "EmxError"]
+
+_STATUS_NAN_LOGP = 1
+_STATUS_BAD_COORD = 2
+
+
+def _as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError("expected array of shape %s, got %s" % (shape, a.shape))
+    return a
+
+
+class DeviceEnsemble:
+    def __init__(self, nwalkers, ndim, device=0):
+        self.lib = _lib.load()
+        self.nwalkers = int(nwalkers)
+        self.ndim = int(ndim)
+        ctx = C.c_void_p()
+        rc = self.lib.emx_create(int(device), self.nwalkers, self.ndim, C.byref(ctx))
+        if rc != 0:
+            raise EmxError((self.lib.emx_last_error(None) or b"emx_create failed").decode())
+        self.ctx = ctx
+        self._target_kind = _lib.TARGET_HOST
+        self._moves = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.emx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(self.lib, self.ctx, rc)
+
+    # ---- state ----
+    def set_state(self, coords, log_prob=None):
+        coords = _as_f64(coords, (self.nwalkers, self.ndim))
+        lp = None if log_prob is None else _as_f64(log_prob, (self.nwalkers,))
+        self._ck(self.lib.emx_set_state(self.ctx, coords.ctypes.data, None if lp is None else lp.ctypes.data))
+
+    def get_state(self, coords=True, log_prob=True):
+        x = np.empty((self.nwalkers, self.ndim)) if coords else None
+        lp = np.empty(self.nwalkers) if log_prob else None
+        self._ck(self.lib.emx_get_state(self.ctx, None if x is None else x.ctypes.data,
+                                        None if lp is None else lp.ctypes.data))
+        return x, lp
+
+    def accepted_mask(self):
+        m = np.empty(self.nwalkers, dtype=np.uint8)
+        self._ck(self.lib.emx_get_accepted(self.ctx, m))
+        return m.astype(bool)
+
+    def status(self):
+        bits = C.c_uint32(0)
+        self._ck(self.lib.emx_status(self.ctx, C.byref(bits)))
+        return bits.value
+
+    def raise_on_status(self):
+        """Mirror the reference's ValueErrors (ensemble.py:476-479, 550-551)."""
+        bits = self.status()
+        if bits & _STATUS_BAD_COORD:
+            raise ValueError("At least one parameter value was infinite or NaN")
+        if bits & _STATUS_NAN_LOGP:
+            raise ValueError("Probability function returned NaN")
+
+    def sync(self):
+        self._ck(self.lib.emx_sync(self.ctx))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.emx_set_stream(self.ctx, stream_ptr))
+
+    def set_tuning(self, key, value):
+        self._ck(self.lib.emx_set_tuning(self.ctx, key.encode(), int(value)))
+
+    # ---- target ----
+    def set_target(self, kind, p0=None, p1=None, scale=0.0):
+        a0 = None if p0 is None else _as_f64(p0)
+        a1 = None if p1 is None else _as_f64(p1)
+        self._ck(self.lib.emx_set_target(self.ctx, int(kind), None if a0 is None else a0.ctypes.data,
+                                         None if a1 is None else a1.ctypes.data, float(scale)))
+        self._target_kind = int(kind)
+
+    def eval_state_log_prob(self):
+        self._ck(self.lib.emx_eval_state_log_prob(self.ctx))
+
+    def eval_log_prob(self, coords):
+        coords = _as_f64(coords)
+        if coords.ndim != 2 or coords.shape[1] != self.ndim:
+            raise ValueError("coords must be (n, ndim)")
+        out = np.empty(coords.shape[0])
+        for lo in range(0, coords.shape[0], self.nwalkers):
+            blk = np.ascontiguousarray(coords[lo:lo + self.nwalkers])
+            o = np.empty(blk.shape[0])
+            self._ck(self.lib.emx_eval_log_prob(self.ctx, blk, blk.shape[0], o))
+            out[lo:lo + blk.shape[0]] = o
+        return out
+
+    # ---- moves / rng ----
+    def set_moves(self, descs, cdf):
+        arr = (MoveDesc * len(descs))(*descs)
+        cdf = _as_f64(cdf)
+        self._ck(self.lib.emx_set_moves(self.ctx, len(descs), arr, cdf))
+        self._moves = list(descs)
+
+    def set_rng_mode(self, mode):
+        self._ck(self.lib.emx_set_rng_mode(self.ctx, int(mode)))
+
+    def set_mt19937(self, state):
+        key = np.ascontiguousarray(state[1], dtype=np.uint32)
+        self._ck(self.lib.emx_rng_set_mt19937(self.ctx, key, int(state[2]), int(state[3]), float(state[4])))
+
+    def get_mt19937(self):
+        key = np.empty(624, dtype=np.uint32)
+        pos, hg, cached = C.c_int32(), C.c_int32(), C.c_double()
+        self._ck(self.lib.emx_rng_get_mt19937(self.ctx, key, C.byref(pos), C.byref(hg), C.byref(cached)))
+        return ("MT19937", key, pos.value, hg.value, cached.value)
+
+    def set_philox(self, seed, step=0):
+        self._ck(self.lib.emx_rng_set_philox(self.ctx, int(seed) & (2**64 - 1), int(step)))
+
+    def get_philox(self):
+        s, t = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.emx_rng_get_philox(self.ctx, C.byref(s), C.byref(t)))
+        return s.value, t.value
+
+    # ---- chain / run ----
+    def chain_config(self, capacity):
+        self._ck(self.lib.emx_chain_config(self.ctx, int(capacity)))
+
+    def chain_reset(self):
+        self._ck(self.lib.emx_chain_reset(self.ctx))
+
+    def run(self, nsteps, thin_by=1, store=True):
+        self._ck(self.lib.emx_run(self.ctx, int(nsteps), int(thin_by), int(bool(store))))
+
+    def iteration(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.emx_iteration(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def chain_read(self, what, start, stop, stride=1):
+        nsel = len(range(start, stop, stride))
+        shape = (nsel, self.nwalkers, self.ndim) if what == 0 else (nsel, self.nwalkers)
+        out = np.empty(shape)
+        if nsel:
+            self._ck(self.lib.emx_chain_read(self.ctx, what, start, stop, stride, out))
+        return out
+
+    def accepted_counts(self):
+        out = np.empty(self.nwalkers)
+        self._ck(self.lib.emx_accepted_counts(self.ctx, out))
+        return out
+
+    # ---- split-phase ----
+    def step_begin(self, store=False):
+        mv, S = C.c_int32(), C.c_int32()
+        self._ck(self.lib.emx_step_begin(self.ctx, int(bool(store)), C.byref(mv), C.byref(S)))
+        return mv.value, S.value
+
+    def halfstep(self, split):
+        self._ck(self.lib.emx_halfstep(self.ctx, int(split)))
+
+    def propose(self, split):
+        ns = C.c_int64()
+        q = np.empty((self.nwalkers, self.ndim))
+        self._ck(self.lib.emx_propose(self.ctx, int(split), q.ctypes.data, C.byref(ns)))
+        return q[: ns.value]
+
+    def accept(self, split, new_log_prob):
+        self._ck(self.lib.emx_accept(self.ctx, int(split), _as_f64(new_log_prob)))
+
+    def step_end(self):
+        self._ck(self.lib.emx_step_end(self.ctx))
+
+    def plan_set(self, move_index, plan):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        self._ck(self.lib.emx_plan_set(self.ctx, int(move_index), i32(plan["off"]), i32(plan["order"]), i32(plan["p0"]),
+                                       i32(plan["p1"]), i32(plan["p2"]), _as_f64(plan["s0"]), _as_f64(plan["uacc"])))
+
+    def plan_get(self, nsplits):
+        N = self.nwalkers
+        off = np.zeros(nsplits + 1, dtype=np.int32)
+        order, p0, p1, p2 = (np.empty(N, dtype=np.int32) for _ in range(4))
+        s0, uacc = np.empty(N), np.empty(N)
+        self._ck(self.lib.emx_plan_get(self.ctx, off, order, p0, p1, p2, s0, uacc))
+        return dict(off=off, order=order, p0=p0, p1=p1, p2=p2, s0=s0, uacc=uacc)
+
+    # ---- sharding ----
+    def set_shard(self, rank, world):
+        self._ck(self.lib.emx_set_shard(self.ctx, int(rank), int(world)))
+
+    def device_ptr(self, which):
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(self.lib.emx_device_ptr(self.ctx, int(which), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def shard_slots(self, split):
+        lo, hi, ns = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.emx_shard_slots(self.ctx, int(split), C.byref(lo), C.byref(hi), C.byref(ns)))
+        return lo.value, hi.value, ns.value
+
+    def scatter_gathered(self, split):
+        self._ck(self.lib.emx_scatter_gathered(self.ctx, int(split)))
+
+    # ---- measurement ----
+    def timer_start(self):
+        self._ck(self.lib.emx_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.lib.emx_timer_stop(self.ctx, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, max_launches):
+        self._ck(self.lib.emx_profile_enable(self.ctx, int(max_launches)))
+
+    def profile_read(self, max_launches):
+        out = np.empty(max_launches, dtype=np.float32)
+        n = C.c_int32(max_launches)
+        self._ck(self.lib.emx_profile_read(self.ctx, out, C.byref(n)))
+        return out[: n.value]

@@ -1,0 +1,158 @@
+/* libemx -- C ABI of the MI355X split-ensemble sampler hot path.
+ *
+ * The reference (dfm/emcee) has no FFI: its boundary for this path is the duck-typed Python
+ * protocol  EnsembleSampler.sample -> Move.propose(model, state) -> model.compute_log_prob_fn
+ * (SURVEY.md 8b).  Each entry point below names the reference code it replaces (paths relative
+ * to /root/reference/src/emcee).  The Python host layer (emcee_amd/) binds these through ctypes;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions: every function returns 0 on success and a negative code on error, with a
+ * message available from emx_last_error(); no C++ exception crosses the boundary; the caller
+ * owns all host buffers, the library owns all device buffers; a context is bound to one
+ * device and is not thread-safe; all device work is asynchronous on the context's stream
+ * except calls that copy results to host memory.  Arrays are C-contiguous float64 unless
+ * noted.  There is NO CPU fallback: without a usable HIP device emx_create fails.
+ */
+#ifndef EMX_H
+#define EMX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct emx_ctx emx_ctx;
+
+enum emx_target_kind {
+    EMX_TARGET_HOST = 0,       /* log-prob evaluated by the caller (split-phase API)            */
+    EMX_TARGET_ISO_GAUSS = 1,  /* -0.5 sum x^2            tests/integration/test_proposal.py:21 */
+    EMX_TARGET_DIAG_GAUSS = 2, /* -0.5 sum ivar (x-mu)^2  docs/index.rst:41-45                 */
+    EMX_TARGET_DENSE_GAUSS = 3,/* -0.5 (x-mu)^T icov (x-mu)  docs/tutorials/quickstart.ipynb:76 */
+    EMX_TARGET_ROSENBROCK = 4, /* -sum[100 (x_{i+1}-x_i^2)^2 + (1-x_i)^2] / scale (BASELINE C3) */
+    EMX_TARGET_BOX = 5         /* 0 inside [0,1]^D else -inf   test_proposal.py:25-28           */
+};
+
+enum emx_move_kind { EMX_MOVE_STRETCH = 0, EMX_MOVE_DE = 1, EMX_MOVE_SNOOKER = 2 };
+
+enum emx_rng_mode {
+    EMX_RNG_INPUTS = 0,  /* every step's plan is supplied with emx_plan_set                     */
+    EMX_RNG_MT19937 = 1, /* NumPy legacy RandomState stream: same seed => same chain as emcee   */
+    EMX_RNG_PHILOX = 2   /* counter-based, generated inside the kernels (throughput mode)       */
+};
+
+/* moves/red_blue.py:37-42, moves/stretch.py:22, moves/de.py:28-31,33-38, moves/de_snooker.py:26-29 */
+typedef struct emx_move_desc {
+    int32_t kind;            /* emx_move_kind                                   */
+    int32_t nsplits;         /* RedBlueMove.nsplits (snooker: 4)                */
+    int32_t randomize_split; /* RedBlueMove.randomize_split                     */
+    int32_t reserved;
+    double a;                /* StretchMove.a                                   */
+    double sigma;            /* DEMove.sigma                                    */
+    double g0;               /* DEMove.g0 = gamma0 or 2.38/sqrt(2 ndim)         */
+    double gammas;           /* DESnookerMove.gammas                            */
+} emx_move_desc;
+
+/* ---- library / context ---------------------------------------------------------------- */
+const char* emx_version(void);
+const char* emx_last_error(const emx_ctx* ctx); /* ctx may be NULL: last creation error */
+int emx_device_count(int32_t* n);
+/* EnsembleSampler.__init__ (ensemble.py:79-137): one context per (device, ensemble). */
+int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out);
+int emx_destroy(emx_ctx* ctx);
+/* adopt an external hipStream_t (e.g. torch's current stream); NULL restores the own stream */
+int emx_set_stream(emx_ctx* ctx, void* hip_stream);
+int emx_sync(emx_ctx* ctx);
+/* sticky device status: bit0 NaN log-prob (ensemble.py:550-551), bit1 non-finite coordinate
+ * (ensemble.py:476-479).  Reading clears it. */
+int emx_status(emx_ctx* ctx, uint32_t* bits);
+int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value); /* "spw", "blocks_per_cu" */
+
+/* ---- state: State(coords, log_prob) (state.py:10-45) ---------------------------------- */
+int emx_set_state(emx_ctx* ctx, const double* coords, const double* log_prob /* or NULL */);
+int emx_get_state(emx_ctx* ctx, double* coords /* or NULL */, double* log_prob /* or NULL */);
+int emx_get_accepted(emx_ctx* ctx, uint8_t* mask /* N */); /* `accepted` of the last propose */
+
+/* ---- target: the batched log-prob (ensemble.py:458-553, vectorised) -------------------- */
+/* p0/p1: DIAG (mu, ivar); DENSE (mu, icov[D*D]); others NULL.  scale: Rosenbrock divisor. */
+int emx_set_target(emx_ctx* ctx, int32_t kind, const double* p0, const double* p1, double scale);
+/* log-prob of the current state, stored as the state's log_prob (ensemble.py:350-351) */
+int emx_eval_state_log_prob(emx_ctx* ctx);
+/* EnsembleSampler.compute_log_prob(coords) for n host rows (n <= nwalkers per call) */
+int emx_eval_log_prob(emx_ctx* ctx, const double* coords, int64_t n, double* out);
+
+/* ---- moves & RNG ------------------------------------------------------------------------ */
+/* ensemble.py:115-129: move list + normalised cumulative weights (cdf[nmoves-1] == 1) */
+int emx_set_moves(emx_ctx* ctx, int32_t nmoves, const emx_move_desc* moves, const double* cdf);
+int emx_set_rng_mode(emx_ctx* ctx, int32_t mode);
+/* numpy RandomState.get_state()/set_state() tuple round trip (ensemble.py:216-238) */
+int emx_rng_set_mt19937(emx_ctx* ctx, const uint32_t key[624], int32_t pos, int32_t has_gauss, double cached);
+int emx_rng_get_mt19937(emx_ctx* ctx, uint32_t key[624], int32_t* pos, int32_t* has_gauss, double* cached);
+int emx_rng_set_philox(emx_ctx* ctx, uint64_t seed, uint64_t step);
+int emx_rng_get_philox(emx_ctx* ctx, uint64_t* seed, uint64_t* step);
+
+/* ---- the hot loop (ensemble.py:403-424): nsteps stored steps, nsteps*thin_by proposals -- */
+int emx_chain_config(emx_ctx* ctx, int64_t capacity_steps); /* Backend.grow (backend.py:164-185) */
+int emx_chain_reset(emx_ctx* ctx);                            /* Backend.reset (backend.py:19-35) */
+int emx_run(emx_ctx* ctx, int64_t nsteps, int32_t thin_by, int32_t store);
+int emx_iteration(emx_ctx* ctx, int64_t* stored_steps, int64_t* proposals);
+/* Backend.get_value slices (backend.py:42-58): steps start, start+stride, ... < stop.
+ * what: 0 chain -> out[(nsel, N, D)], 1 log_prob -> out[(nsel, N)]. */
+int emx_chain_read(emx_ctx* ctx, int32_t what, int64_t start, int64_t stop, int64_t stride, double* out);
+int emx_accepted_counts(emx_ctx* ctx, double* out /* N, backend.accepted */);
+
+/* ---- split-phase stepping: Move.propose pieces for host log-probs and sharded runs ------ */
+/* Begin a step: choose the move (ensemble.py:406), build the split plan (red_blue.py:76-80 and
+ * every draw of the step).  move_out/nsplits_out report the choice. */
+int emx_step_begin(emx_ctx* ctx, int32_t store_this_step, int32_t* move_out, int32_t* nsplits_out);
+/* fused half-step on the device target (red_blue.py:81-104 for one split) */
+int emx_halfstep(emx_ctx* ctx, int32_t split);
+/* host-target variant: proposals q (ns, D) in ascending-walker order (red_blue.py:90) ... */
+int emx_propose(emx_ctx* ctx, int32_t split, double* q_out, int64_t* ns_out);
+/* ... and Metropolis accept + commit given their log-probs (red_blue.py:96-104) */
+int emx_accept(emx_ctx* ctx, int32_t split, const double* new_log_prob);
+int emx_step_end(emx_ctx* ctx);
+/* INPUTS mode / tests: set or read back the plan of the step begun (arrays of length N in
+ * plan order: split 0's members ascending, then split 1's, ...; off has nsplits+1 entries) */
+int emx_plan_set(emx_ctx* ctx, int32_t move_index, const int32_t* off, const int32_t* order, const int32_t* p0,
+                 const int32_t* p1, const int32_t* p2, const double* s0, const double* uacc);
+int emx_plan_get(emx_ctx* ctx, int32_t* off, int32_t* order, int32_t* p0, int32_t* p1, int32_t* p2, double* s0,
+                 double* uacc);
+
+/* ---- walker-sharded multi-GPU (one process per GPU; collectives stay in the host layer) -- */
+int emx_set_shard(emx_ctx* ctx, int32_t rank, int32_t world);
+/* raw device pointers for zero-copy wrapping (torch.distributed all-gather buffers):
+ * which: 0 coords (N,D), 1 log_prob (N), 2 sendbuf (max slots/rank, D), 3 gathered (max ns, D) */
+int emx_device_ptr(emx_ctx* ctx, int32_t which, void** ptr, int64_t* nbytes);
+int emx_shard_slots(emx_ctx* ctx, int32_t split, int64_t* t_lo, int64_t* t_hi, int64_t* ns);
+/* after the all-gather of `sendbuf`s into `gathered`: write the other ranks' rows into X */
+int emx_scatter_gathered(emx_ctx* ctx, int32_t split);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+int emx_timer_start(emx_ctx* ctx);                 /* hipEventRecord on the context stream */
+int emx_timer_stop(emx_ctx* ctx, float* ms);       /* record + synchronize + elapsed       */
+/* per-launch hipEvent timing of the half-step kernel: enable, run, then read the durations */
+int emx_profile_enable(emx_ctx* ctx, int32_t max_launches);
+int emx_profile_read(emx_ctx* ctx, float* ms_out, int32_t* n_inout);
+
+/* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------------------- */
+typedef struct emx_mt emx_mt;
+emx_mt* emx_mt_create(const uint32_t key[624], int32_t pos, int32_t has_gauss, double cached);
+void emx_mt_destroy(emx_mt* m);
+void emx_mt_get_state(const emx_mt* m, uint32_t key[624], int32_t* pos, int32_t* has_gauss, double* cached);
+void emx_mt_random_sample(emx_mt* m, int64_t n, double* out);
+void emx_mt_randint(emx_mt* m, uint64_t bound, int64_t n, int64_t* out);
+void emx_mt_randn(emx_mt* m, int64_t n, double* out);
+void emx_mt_shuffle_labels(emx_mt* m, int64_t n, int32_t nsplits, int32_t* labels);
+int32_t emx_mt_choice_cdf(emx_mt* m, const double* cdf, int32_t n);
+/* one step's exact plan on the host (the producer emx_run uses in MT19937 mode) */
+int emx_host_plan_mt(emx_mt* m, int64_t nwalkers, int32_t ndim, const emx_move_desc* mv, int32_t* off, int32_t* order,
+                     int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc);
+/* one step's native plan on the host (the function the kernels evaluate in flight) */
+int emx_host_plan_philox(uint64_t seed, uint64_t step, int64_t nwalkers, const emx_move_desc* mv, int32_t* off,
+                         int32_t* order, int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc);
+int32_t emx_host_move_choice_philox(uint64_t seed, uint64_t step, const double* cdf, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMX_H */

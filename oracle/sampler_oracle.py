@@ -301,3 +301,52 @@ def integrated_time(x, c=5):
         win = np.argmin(m) if np.any(m) else len(taus) - 1
         tau[d] = taus[win]
     return tau
+
+
+# --------------------------------------------------------------------------
+# "Inputs mode": replay a fully resolved step plan (the arrays the device
+# consumes: plan order, partner walkers, zz/gamma, accept uniforms) with the
+# reference's arithmetic.  Used to check the native (Philox) mode, whose draws
+# come from the device, against NumPy math, and for teacher-forced parity.
+# --------------------------------------------------------------------------
+def propose_planned(coords, log_prob, lp_fn, plan, move):
+    """In-place red/blue step from a resolved plan; returns the accepted mask.
+
+    plan: dict(off, order, p0, p1, p2, s0, uacc) in plan order (split 0's
+    members, then split 1's, ...).  Arithmetic per stretch.py:33, de.py:53-62,
+    de_snooker.py:41-46, red_blue.py:96-104.
+    """
+    N, ndim = coords.shape
+    off, order = plan["off"], plan["order"]
+    accepted = np.zeros(N, dtype=bool)
+    for split in range(len(off) - 1):
+        sl = slice(off[split], off[split + 1])
+        idx = order[sl]
+        s = coords[idx]
+        if move.kind == "stretch":
+            zz = plan["s0"][sl]
+            cj = coords[plan["p0"][sl]]
+            q = cj - (cj - s) * zz[:, None]
+            factors = (ndim - 1.0) * np.log(zz)
+        elif move.kind == "de":
+            diffs = coords[plan["p1"][sl]] - coords[plan["p0"][sl]]
+            q = s + plan["s0"][sl][:, None] * diffs
+            factors = np.zeros(len(idx))
+        else:
+            z, z1, z2 = coords[plan["p0"][sl]], coords[plan["p1"][sl]], coords[plan["p2"][sl]]
+            q = np.empty_like(s)
+            met = np.empty(len(idx))
+            for i in range(len(idx)):
+                delta = s[i] - z[i]
+                norm = np.linalg.norm(delta)
+                u = delta / norm
+                q[i] = s[i] + u * move.gammas * (np.dot(u, z1[i]) - np.dot(u, z2[i]))
+                met[i] = np.log(np.linalg.norm(q[i] - z[i])) - np.log(norm)
+            factors = (ndim - 1.0) * met
+        new_lp = np.asarray(lp_fn(q), dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            acc = factors + new_lp - log_prob[idx] > np.log(plan["uacc"][sl])
+        accepted[idx] = acc
+        coords[idx[acc]] = q[acc]
+        log_prob[idx[acc]] = new_lp[acc]
+    return accepted

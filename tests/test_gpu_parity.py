@@ -1,0 +1,233 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the
+reference-generated golden fixtures.  Run with `-m gpu` on an MI355X box.
+
+Tolerances (BASELINE.json north_star): accept masks / indices bit-exact; float64
+coordinates and log-probs within 1e-6 relative.  The tests below are tighter where the
+arithmetic allows it: stretch and DE proposals involve no reduction, so coordinates are
+required to be BIT-IDENTICAL to the reference; snooker coordinates (norms and dots are
+reductions, summed in a different order) and all log-probs are held to 1e-11 relative.
+"""
+import numpy as np
+import pytest
+
+from emcee_amd import _lib
+from oracle import cases
+from oracle import sampler_oracle as so
+
+from emx_testlib import cdf_of, move_desc, philox_plan
+from helpers import digest, load_digests, load_golden, rng_for_case, rng_from_fixture, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+LP_RTOL = 1e-11
+
+
+def _dev():
+    from emcee_amd.device import DeviceEnsemble
+    return DeviceEnsemble
+
+
+def set_target(ens, desc):
+    k = desc["kind"]
+    if k == "iso":
+        ens.set_target(_lib.TARGET_ISO)
+    elif k == "diag":
+        ens.set_target(_lib.TARGET_DIAG, desc["mu"], desc["ivar"])
+    elif k == "dense":
+        ens.set_target(_lib.TARGET_DENSE, desc["mu"], desc["icov"])
+    elif k == "rosenbrock":
+        ens.set_target(_lib.TARGET_ROSENBROCK, scale=20.0)
+    elif k == "box":
+        ens.set_target(_lib.TARGET_BOX)
+    else:
+        raise ValueError(k)
+
+
+def make_ens(spec, p0):
+    ens = _dev()(spec["N"], spec["D"])
+    set_target(ens, spec["desc"])
+    descs = [move_desc(m, spec["D"]) for m in spec["moves"]]
+    ens.set_moves(descs, cdf_of(spec["weights"], len(descs)))
+    ens.set_state(p0)
+    ens.eval_state_log_prob()
+    return ens
+
+
+def assert_lp_close(a, b):
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin)
+    assert np.array_equal(a[~fin], b[~fin])
+    np.testing.assert_allclose(a[fin], b[fin], rtol=LP_RTOL, atol=1e-13)
+
+
+def has_snooker(spec):
+    return any(m.kind == "snooker" for m in spec["moves"])
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_exact_mode_reproduces_reference_fixture(name):
+    """MT19937 mode, free-running from the fixture's RNG state: same chain as reference emcee."""
+    g = load_golden(name)
+    spec = cases.build(name)
+    ens = make_ens(spec, g["p0"])
+    ens.set_rng_mode(_lib.RNG_MT19937)
+    ens.set_mt19937(rng_from_fixture(g).get_state())
+    ens.chain_config(spec["nsteps"])
+    ens.run(spec["nsteps"], thin_by=spec["thin_by"], store=True)
+    assert ens.status() == 0
+    chain = ens.chain_read(0, 0, spec["nsteps"])
+    lps = ens.chain_read(1, 0, spec["nsteps"])
+    acc = ens.accepted_counts()
+    assert np.array_equal(acc, g["accepted_count"]), "accept decisions differ from the reference"
+    if has_snooker(spec):
+        np.testing.assert_allclose(chain, g["chain"], rtol=1e-11, atol=1e-13)
+    else:
+        assert np.array_equal(chain, g["chain"]), "coordinates are not bit-identical to the reference"
+    assert_lp_close(lps, g["log_prob"])
+    st = ens.get_mt19937()
+    assert np.array_equal(st[1], g["rng_key1"]) and st[2] == int(g["rng_pos1"])
+    assert st[3] == int(g["rng_has_gauss1"]) and st[4] == float(g["rng_cached1"])
+    x, lp = ens.get_state()
+    assert np.array_equal(x, chain[-1]) and np.array_equal(lp, lps[-1])
+    ens.close()
+
+
+@pytest.mark.parametrize("name", list(cases.DIGEST_CASES))
+def test_exact_mode_mid_size_against_oracle(name):
+    spec = cases.build(name)
+    out = run_oracle(spec, spec["p0"], rng_for_case(spec))
+    d = load_digests()[name]
+    if digest(spec["p0"]) == d.get("p0"):
+        assert digest(out["chain"]) == d["chain"], "oracle no longer matches the reference digest"
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_MT19937)
+    ens.set_mt19937(rng_for_case(spec).get_state())
+    ens.chain_config(spec["nsteps"])
+    ens.run(spec["nsteps"], thin_by=spec["thin_by"], store=True)
+    assert ens.status() == 0
+    chain = ens.chain_read(0, 0, spec["nsteps"])
+    assert np.array_equal(ens.accepted_counts(), out["accepted_count"])
+    if has_snooker(spec):
+        np.testing.assert_allclose(chain, out["chain"], rtol=1e-11, atol=1e-13)
+    else:
+        assert np.array_equal(chain, out["chain"])
+    assert_lp_close(ens.chain_read(1, 0, spec["nsteps"]), out["log_prob"])
+    ens.close()
+
+
+NATIVE_CASES = ["c1_stretch_32x5_iso", "stretch_50x3_iso", "stretch_128x64_dense", "stretch_128x8_rosen",
+                "stretch_nsplits3_45x2", "stretch_wide_16x130_live", "de_64x4_iso", "de_g1_s01_30x3",
+                "snooker_64x4_iso", "snooker_38x3_diag", "mix_de_snooker_128x8_dense", "stretch_box_32x1"]
+
+
+@pytest.mark.parametrize("name", NATIVE_CASES)
+def test_native_mode_step_by_step_against_oracle(name):
+    """Philox mode: the device's own plan of every step (read back with emx_plan_get) is replayed
+    through the oracle on the device's pre-step state; accept masks and new state must agree."""
+    spec = cases.build(name)
+    fn = cases.make_target(spec["desc"])
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_PHILOX)
+    seed = 0xC0FFEE + spec["seed"]
+    ens.set_philox(seed, 0)
+    cdf = cdf_of(spec["weights"], len(spec["moves"]))
+    nacc = 0
+    for step in range(8):
+        x0, lp0 = ens.get_state()
+        k, S = ens.step_begin(store=False)
+        assert k == ens.lib.emx_host_move_choice_philox(seed, step, cdf, len(cdf))
+        mv = spec["moves"][k]
+        plan = ens.plan_get(S)
+        host = philox_plan(seed, step, spec["N"], move_desc(mv, spec["D"]))
+        for key in ("off", "order", "p0", "p1", "p2"):
+            assert np.array_equal(plan[key], host[key]), (step, key)
+        np.testing.assert_allclose(plan["s0"], host["s0"], rtol=1e-14)
+        assert np.array_equal(plan["uacc"], host["uacc"])
+        for s in range(S):
+            ens.halfstep(s)
+        ens.step_end()
+        assert ens.status() == 0
+        x1, lp1 = ens.get_state()
+        acc_dev = ens.accepted_mask()
+        xo, lpo = x0.copy(), lp0.copy()
+        acc_or = so.propose_planned(xo, lpo, fn, plan, mv)
+        assert np.array_equal(acc_dev, acc_or), "accept mask differs at step %d" % step
+        if mv.kind == "snooker":
+            np.testing.assert_allclose(x1, xo, rtol=1e-11, atol=1e-13)
+        else:
+            assert np.array_equal(x1, xo), "coordinates differ at step %d" % step
+        assert_lp_close(lp1, lpo)
+        nacc += acc_dev.sum()
+    assert nacc > 0
+    ens.close()
+
+
+@pytest.mark.parametrize("name", ["c1_stretch_32x5_iso", "de_64x4_iso", "snooker_64x4_iso", "stretch_128x64_dense"])
+def test_host_target_split_phase_equals_fused(name):
+    """emx_propose / emx_accept with the log-prob evaluated by NumPy on the host gives the same
+    chain as the fused device target (the arbitrary-Python-callable path of the drop-in)."""
+    g = load_golden(name)
+    spec = cases.build(name)
+    fn = cases.make_target(spec["desc"])
+    ens = make_ens(spec, g["p0"])
+    ens.set_rng_mode(_lib.RNG_MT19937)
+    ens.set_mt19937(rng_from_fixture(g).get_state())
+    nst = min(10, spec["nsteps"])
+    ens.chain_config(nst)
+    for it in range(nst):
+        k, S = ens.step_begin(store=True)
+        for s in range(S):
+            q = ens.propose(s)
+            ens.accept(s, fn(q))
+        ens.step_end()
+    chain = ens.chain_read(0, 0, nst)
+    if has_snooker(spec):
+        np.testing.assert_allclose(chain, g["chain"][:nst], rtol=1e-11, atol=1e-13)
+    else:
+        assert np.array_equal(chain, g["chain"][:nst])
+    ens.close()
+
+
+@pytest.mark.parametrize("kind,D", [("iso", 1), ("iso", 5), ("iso", 64), ("iso", 129), ("diag", 7), ("diag", 1024),
+                                    ("diag", 2048), ("rosenbrock", 2), ("rosenbrock", 32), ("rosenbrock", 33),
+                                    ("rosenbrock", 300), ("dense", 3), ("dense", 16), ("dense", 17), ("dense", 64),
+                                    ("dense", 100), ("dense", 112), ("box", 3)])
+def test_batched_log_prob_eval(kind, D):
+    rs = np.random.RandomState(D)
+    N = 200
+    desc = {"kind": kind}
+    if kind == "diag":
+        desc.update(mu=rs.randn(D), ivar=1.0 / (0.1 + rs.rand(D)))
+    if kind == "dense":
+        mu, cov, icov = cases._dense_params(D, 5)
+        desc.update(mu=mu, icov=icov)
+    x = rs.randn(N, D) * (0.6 if kind == "box" else 1.0) + (0.5 if kind == "box" else 0.0)
+    ens = _dev()(N, D)
+    set_target(ens, desc)
+    got = ens.eval_log_prob(x[:77])
+    assert_lp_close(got, cases.make_target(desc)(x[:77]))
+    ens.set_state(x)
+    ens.eval_state_log_prob()
+    assert_lp_close(ens.get_state()[1], cases.make_target(desc)(x))
+    ens.close()
+
+
+def test_dense_ndim_limit_is_loud():
+    ens = _dev()(300, 128)
+    with pytest.raises(_lib.EmxError):
+        ens.set_target(_lib.TARGET_DENSE, np.zeros(128), np.eye(128))
+    ens.close()
+
+
+def test_nan_log_prob_is_reported():
+    """ensemble.py:550-551: NaN log-prob -> ValueError (sticky status bit here)."""
+    N, D = 32, 2
+    ens = _dev()(N, D)
+    ens.set_target(_lib.TARGET_DIAG, np.zeros(D), np.array([1.0, np.nan]))
+    ens.set_state(np.random.RandomState(0).randn(N, D))
+    ens.eval_state_log_prob()
+    assert ens.status() & 1
+    with pytest.raises(ValueError):
+        ens.eval_state_log_prob()
+        ens.raise_on_status()
+    ens.close()
