@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Contract bench: walker-updates/sec of the fused red/blue stretch-move step on MI355X.
+
+`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one
+rank per GPU).  A "step" is one full ensemble step = both half-steps of the stretch move over
+one ensemble of synthetic walkers resident in HBM (BASELINE.json configs[1]:
+nwalkers=65536 per GPU, ndim=64, correlated Gaussian with dense precision matrix, a=2.0).
+Weak scaling: the ensemble grows with N (65536 walkers per GPU); every rank updates its slots
+and one all-gather per half-step replicates the result (emcee_amd/parallel.py).
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields, incl. `roofline` and
+`cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WALKERS_PER_GPU = 65536
+NDIM = 64
+HBM_PEAK_GBPS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def dense_gaussian(ndim, seed=0):
+    """Sigma = A A^T / D + 0.1 I, dense Sigma^-1."""
+    rs = np.random.RandomState(seed)
+    mu = rs.randn(ndim)
+    A = rs.randn(ndim, ndim)
+    cov = A @ A.T / ndim + 0.1 * np.eye(ndim)
+    icov = np.linalg.inv(cov)
+    return mu, cov, 0.5 * (icov + icov.T)
+
+
+def initial_walkers(n, mu, cov, seed=1):
+    rs = np.random.RandomState(seed)
+    return mu + rs.randn(n, len(mu)) @ np.linalg.cholesky(cov).T   # equilibrium start
+
+
+def cpu_baseline(mu, cov, icov, budget_s=15.0):
+    """NumPy oracle (port of reference emcee's vectorised path) on the host cores, bounded sample."""
+    from oracle import sampler_oracle as so
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # noqa: BLE001
+        threadpool_limits = None
+    n = WALKERS_PER_GPU
+    p0 = initial_walkers(n, mu, cov)
+    fn = lambda x: so.dense_gauss(x, mu, icov)  # noqa: E731
+    rs = np.random.RandomState(7)
+
+    def go():
+        t0 = time.perf_counter()
+        out = so.run(p0, 1, fn, rs, store=False)
+        t1 = time.perf_counter() - t0
+        nst = int(min(40, max(3, budget_s / max(t1, 1e-3))))
+        t0 = time.perf_counter()
+        so.run(out["coords"], nst, fn, rs, store=False, log_prob0=out["lp"])
+        return nst, time.perf_counter() - t0
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            nst, dt = go()
+        cores = 1
+    else:
+        nst, dt = go()
+        cores = os.cpu_count()
+    return {"value": n * nst / dt, "unit": "walker-updates/s", "cores": cores, "kind": "port",
+            "sample": "oracle/sampler_oracle.py (NumPy restatement of emcee's vectorize=True path), "
+                      "%d steps of the same 65536x64 dense-Gaussian stretch workload, %.1f s, BLAS threads=%d, host has %d cores"
+                      % (nst, dt, cores, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--store", action="store_true", help="append every step to the device chain")
+    ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded RCCL path even at world size 1 (testing)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    K, W = args.steps, args.warmup
+
+    import torch
+    from emcee_amd import _lib
+    from emcee_amd.device import DeviceEnsemble
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    sharded = world > 1 or args.force_dist
+    if sharded:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = WALKERS_PER_GPU * world
+    mu, cov, icov = dense_gaussian(NDIM)
+    p0 = initial_walkers(n, mu, cov)
+
+    ens = DeviceEnsemble(n, NDIM, device=local_rank)
+    ens.set_target(_lib.TARGET_DENSE, mu, icov)
+    ens.set_moves([_lib.MoveDesc(_lib.MOVE_STRETCH, 2, 1, 0, 2.0, 1e-5, 2.38 / np.sqrt(2 * NDIM), 1.7)], np.array([1.0]))
+    if args.rng == "philox":
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(20260923, 0)
+    else:
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        ens.set_mt19937(np.random.RandomState(20260923).get_state())
+    ens.set_state(p0)
+    ens.eval_state_log_prob()
+    if args.store:
+        ens.chain_config(K + W)
+
+    if sharded:
+        from emcee_amd.parallel import DeviceEngine, ShardedStepper
+        ens.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels + RCCL ordered on one stream
+        eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank))
+        stepper = ShardedStepper(eng, lambda out, inp: dist.all_gather_into_tensor(out, inp))
+        run = lambda k: stepper.run(k, 1, args.store)  # noqa: E731
+    else:
+        run = lambda k: ens.run(k, 1, args.store)  # noqa: E731
+
+    def fence():
+        ens.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(W)
+    fence()
+    ens.timer_start()
+    t0 = time.perf_counter()
+    run(K)
+    gpu_ms = ens.timer_stop()          # hipEvents on the stream the kernels are launched on
+    fence()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, gpu_ms = float(t[0]), float(t[1])
+
+    acc_frac = float(ens.accepted_mask().mean())
+    status = ens.status()
+
+    # per-launch hipEvent durations of the half-step kernel (separate pass: event records perturb)
+    per_launch_us = None
+    if not sharded:
+        ens.profile_enable(128)
+        ens.run(64, 1, False)
+        pl = ens.profile_read(128)
+        if len(pl):
+            per_launch_us = float(np.median(pl) * 1e3)
+
+    if rank == 0:
+        nsplits = 2
+        launches = K * nsplits
+        slots_per_launch = WALKERS_PER_GPU // nsplits                 # per GPU
+        B = 24 * NDIM + 17 + ((8 * NDIM + 8) if args.store else 0)    # algorithmic bytes / walker-update
+        avg_launch_s = gpu_ms * 1e-3 / launches                        # timed-region events / launches
+        achieved = slots_per_launch * B / avg_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("c2_stretch_dense_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "walker-updates/sec (whole node), 64-dim correlated Gaussian, StretchMove a=2",
+            "value": n * K / wall, "unit": "walker-updates/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: nwalkers=%d (65536/GPU), ndim=64, dense-precision Gaussian, "
+                                   "StretchMove a=2.0, nsplits=2, rng=%s, store=%s" % (n, args.rng, args.store),
+                       "nwalkers": n, "ndim": NDIM, "parallelism": "walker-sharded x%d" % world},
+            "steps_per_s": K / wall, "accept_frac": acc_frac, "device_status": status,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "emx::k_halfstep<32,2,1,STRETCH,DENSE>",
+                         "algorithmic_bytes_per_walker_update": B, "walker_updates_per_launch": slots_per_launch,
+                         "avg_launch_us": avg_launch_s * 1e6, "per_launch_event_us": per_launch_us,
+                         "note": "avg_launch_us = hipEvent time of the timed region / launches (includes the "
+                                 "inter-kernel gap); per_launch_event_us brackets single launches"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(mu, cov, icov)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    ens.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

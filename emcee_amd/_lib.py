@@ -68,6 +68,7 @@ SIGNATURES = {
     "emx_plan_set": (C.c_int, [_P, C.c_int32, _ip, _ip, _ip, _ip, _ip, _dp, _dp]),
     "emx_plan_get": (C.c_int, [_P, _ip, _ip, _ip, _ip, _ip, _dp, _dp]),
     "emx_set_shard": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "emx_set_shard_buffers": (C.c_int, [_P, _P, _P, C.c_int64]),
     "emx_device_ptr": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "emx_shard_slots": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "emx_scatter_gathered": (C.c_int, [_P, C.c_int32]),
@@ -94,6 +95,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (libamdhip64) with the same SONAME as /opt/rocm's.
+    # Whichever loads first serves the whole process, and torch cannot initialise on the system
+    # runtime ("No HIP GPUs are available").  Import torch first when it is installed so that
+    # libemx, torch and RCCL share ONE runtime; libemx itself needs nothing from torch.
+    if not os.environ.get("EMX_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001
+            pass
     if not os.path.exists(LIB_PATH):
         raise EmxError("libemx.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`. "
                        "There is no CPU fallback." % LIB_PATH)

@@ -239,6 +239,7 @@ struct emx_ctx {
     int rank = 0, world = 1;
     double *sendbuf = nullptr, *gathered = nullptr;
     int64_t sendbuf_rows = 0, gathered_rows = 0;
+    bool own_shard_bufs = false;
     // tuning
     int64_t tune_spw = 0, tune_bpc = 2;
     // timing
@@ -537,7 +538,8 @@ int emx_destroy(emx_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->X, c->lp, c->acc, c->acc_count, c->status, c->iota, c->qout, c->fout, c->newlp, c->evalX,
-                    c->evallp, c->tp0, c->tp1, c->chain, c->chain_lp, c->sendbuf, c->gathered};
+                    c->evallp, c->tp0, c->tp1, c->chain, c->chain_lp, c->own_shard_bufs ? c->sendbuf : nullptr,
+                    c->own_shard_bufs ? c->gathered : nullptr};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (auto& s : c->ring) {
@@ -941,7 +943,7 @@ static int do_halfstep(emx_ctx* c, int split, int target) {
     }
     emx_ctx::PlanSlot* ps = cur.slot >= 0 ? &c->ring[cur.slot] : nullptr;
     double* sb = nullptr;
-    if (c->world > 1 && target != EMX_TARGET_HOST) sb = c->sendbuf;
+    if (c->sendbuf && target != EMX_TARGET_HOST) sb = c->sendbuf;
     return launch_split(c, mv.kind, target, cur.S, split, pos0, ns, (int)lo, (int)hi, cur.native, cur.nat, &mv, ps,
                         nullptr, c->X, c->lp, chain, chain_lp, sb);
 }
@@ -1022,7 +1024,7 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     NEED(c, thin_by >= 1, "Invalid thinning argument");
     NEED(c, c->rng_mode != EMX_RNG_INPUTS, "emx_run needs an RNG mode that generates plans");
     NEED(c, c->target != EMX_TARGET_HOST, "emx_run needs a device target");
-    NEED(c, c->world == 1, "emx_run is single-rank; sharded runs drive emx_halfstep from the host layer");
+    NEED(c, c->world == 1 && !c->sendbuf, "emx_run is single-rank; sharded runs drive emx_halfstep from the host layer");
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     int64_t i = 0;
     for (int64_t it = 0; it < nsteps; ++it)
@@ -1045,22 +1047,48 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
 }
 
 // ---- sharding ----------------------------------------------------------------------------
+static int64_t shard_rows_per_rank(int64_t N, int world) {
+    const int64_t maxns = (N + 1) / 2 + 1;   // largest sub-ensemble (nsplits >= 2)
+    return (maxns + world - 1) / world + 1;
+}
+
 int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, world >= 1 && rank >= 0 && rank < world, "bad (rank, world)");
+    HIPOK(c, hipStreamSynchronize(c->stream));
     c->rank = rank;
     c->world = world;
+    if (c->own_shard_bufs) {
+        if (c->sendbuf) hipFree(c->sendbuf);
+        if (c->gathered) hipFree(c->gathered);
+    }
+    c->sendbuf = c->gathered = nullptr;
+    c->own_shard_bufs = false;
+    c->sendbuf_rows = c->gathered_rows = 0;
     if (world > 1) {
-        // the largest sub-ensemble is ceil(N/2); per-rank share rounded up
-        const int64_t maxns = (c->N + 1) / 2 + 1;
-        const int64_t per = (maxns + world - 1) / world + 1;
-        if (c->sendbuf) hipFree(c->sendbuf), c->sendbuf = nullptr;
-        if (c->gathered) hipFree(c->gathered), c->gathered = nullptr;
-        HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * c->D * 8));
-        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * world * c->D * 8));
+        const int64_t per = shard_rows_per_rank(c->N, world);
+        HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));
+        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * world * (c->D + 2) * 8));
+        c->own_shard_bufs = true;
         c->sendbuf_rows = per;
         c->gathered_rows = per * world;
     }
+    return 0;
+}
+
+int emx_set_shard_buffers(emx_ctx* c, void* sendbuf, void* gathered, int64_t rows_per_rank) {
+    NEED(c, c->world >= 1, "emx_set_shard_buffers: call emx_set_shard first");
+    NEED(c, rows_per_rank >= shard_rows_per_rank(c->N, c->world), "shard buffers too small");
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (c->own_shard_bufs) {
+        if (c->sendbuf) hipFree(c->sendbuf);
+        if (c->gathered) hipFree(c->gathered);
+        c->own_shard_bufs = false;
+    }
+    c->sendbuf = (double*)sendbuf;
+    c->gathered = (double*)gathered;
+    c->sendbuf_rows = rows_per_rank;
+    c->gathered_rows = rows_per_rank * c->world;
     return 0;
 }
 
@@ -1068,8 +1096,8 @@ int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
     switch (which) {
         case 0: *ptr = c->X; *nbytes = c->N * c->D * 8; return 0;
         case 1: *ptr = c->lp; *nbytes = c->N * 8; return 0;
-        case 2: *ptr = c->sendbuf; *nbytes = c->sendbuf_rows * c->D * 8; return 0;
-        case 3: *ptr = c->gathered; *nbytes = c->gathered_rows * c->D * 8; return 0;
+        case 2: *ptr = c->sendbuf; *nbytes = c->sendbuf_rows * (c->D + 2) * 8; return 0;
+        case 3: *ptr = c->gathered; *nbytes = c->gathered_rows * (c->D + 2) * 8; return 0;
     }
     FAIL(c, -1, "unknown device pointer id %d", which);
 }
@@ -1083,11 +1111,13 @@ int emx_shard_slots(emx_ctx* c, int32_t split, int64_t* lo, int64_t* hi, int64_t
 }
 
 int emx_scatter_gathered(emx_ctx* c, int32_t split) {
-    // `gathered` holds world blocks of `sendbuf_rows` rows; block r carries rank r's slots.
+    // `gathered` holds `world` blocks of `sendbuf_rows` records; block r carries rank r's slots.
     HIPOK(c, hipSetDevice(c->device));
     auto& cur = c->cur;
-    NEED(c, cur.active && c->world > 1, "emx_scatter_gathered needs an active sharded step");
+    NEED(c, cur.active && c->gathered, "emx_scatter_gathered needs an active sharded step");
+    NEED(c, split >= 0 && split < cur.S, "split out of range");
     const int ns = cur.off[split + 1] - cur.off[split];
+    const int64_t rec = c->D + 2;
     for (int r = 0; r < c->world; ++r) {
         if (r == c->rank) continue;
         int64_t lo, hi;
@@ -1095,8 +1125,15 @@ int emx_scatter_gathered(emx_ctx* c, int32_t split) {
         if (hi <= lo) continue;
         ScatterArgs a{};
         a.X = c->X;
-        // rows of rank r start at block offset; express as a virtual (ns, D) array shifted so row t maps right
-        a.gathered = c->gathered + ((size_t)r * c->sendbuf_rows - (size_t)lo) * c->D;
+        a.lp = c->lp;
+        a.acc = c->acc;
+        a.acc_count = c->acc_count;
+        if (cur.store) {
+            a.chain = c->chain + (size_t)c->stored * c->N * c->D;
+            a.chain_lp = c->chain_lp + (size_t)c->stored * c->N;
+        }
+        // block r starts at record r * sendbuf_rows and holds slot lo first: shift so that slot t indexes directly
+        a.gathered = c->gathered + ((int64_t)r * c->sendbuf_rows - lo) * rec;
         a.order = cur.slot >= 0 ? c->ring[cur.slot].order : nullptr;
         a.nat = cur.nat;
         a.N = (int32_t)c->N;
@@ -1104,11 +1141,10 @@ int emx_scatter_gathered(emx_ctx* c, int32_t split) {
         a.S = cur.S;
         a.split = split;
         a.pos0 = cur.off[split];
-        a.ns = (int32_t)hi;
+        a.t_lo = (int32_t)lo;
+        a.t_hi = (int32_t)hi;
         a.native = cur.native ? 1 : 0;
-        a.own_lo = 0;
-        a.own_hi = (int32_t)lo;   // skip slots below lo
-        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((hi + 3) / 4)), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256), 0, c->stream, a);
         HIPOK(c, hipGetLastError());
     }
     return 0;

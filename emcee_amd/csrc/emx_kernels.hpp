@@ -50,7 +50,8 @@ struct HalfStepArgs {
     // split-phase outputs (target == TGT_NONE): proposals in slot order
     double* qout;         // (ns, D)
     double* fout;         // (ns)   factors
-    double* sendbuf;      // sharded runs: final rows of the owned slots, (t_hi - t_lo, D) or nullptr
+    double* sendbuf;      // sharded runs: final [row | log_prob | accepted] of the owned slots,
+                          // (t_hi - t_lo, D + 2) or nullptr
     // plan (exact / inputs mode), slot-indexed at position pos0 + t
     const int32_t* order;
     const int32_t* p0;
@@ -509,8 +510,14 @@ __global__ __launch_bounds__(256) void k_halfstep(const HalfStepArgs A) {
                     }
                 }
                 if (live && A.chain) store_row<G, V, CH>(accept ? q : xi, A.chain + (size_t)i * D, D, gl);
-                if (live && A.sendbuf)
-                    store_row<G, V, CH>(accept ? q : xi, A.sendbuf + (size_t)(t0 + srow - A.t_lo) * D, D, gl);
+                if (live && A.sendbuf) {
+                    double* sb = A.sendbuf + (size_t)(t0 + srow - A.t_lo) * (D + 2);
+                    store_row<G, V, CH>(accept ? q : xi, sb, D, gl);
+                    if (gl == 0) {
+                        sb[D] = accept ? lp_new : lp_old;
+                        sb[D + 1] = accept ? 1.0 : 0.0;
+                    }
+                }
             }
         } else {
             // ---- stage q into the wave's LDS tile; every PPT passes (16 rows) contract with Sinv ----
@@ -560,6 +567,7 @@ __global__ __launch_bounds__(256) void k_halfstep(const HalfStepArgs A) {
             const int tb = (p / PPT) * 16;                     // first slot of the tile
             const bool mine = lane >= tb && lane < tb + 16 && lane < nslot;
             bool acc = false;
+            double lp_fin = sl.lp_old;
             if (mine) {
                 const double lpn = -0.5 * qfS[lane - tb];
                 if (lpn != lpn) atomicOr(A.status, ST_NAN_LOGP);
@@ -570,6 +578,7 @@ __global__ __launch_bounds__(256) void k_halfstep(const HalfStepArgs A) {
                     acc = lnpdiff > sl.logu;
                     A.acc[sl.i] = acc ? 1 : 0;
                     if (acc) A.lp[sl.i] = lpn;
+                    if (acc) lp_fin = lpn;
                     if (A.chain_lp) {
                         A.chain_lp[sl.i] = acc ? lpn : sl.lp_old;
                         if (acc) A.acc_count[sl.i] += 1u;
@@ -584,6 +593,7 @@ __global__ __launch_bounds__(256) void k_halfstep(const HalfStepArgs A) {
                     const int sidx = tb + row;
                     const bool lv = sidx < nslot;
                     const int wi = __shfl(sl.i, lv ? sidx : 0, 64);
+                    const double lpf = __shfl(lp_fin, lv ? sidx : 0, 64);
                     const bool ac = lv && ((am64 >> sidx) & 1ull);
                     if (!lv) continue;
                     Row<G, V, CH> rr;
@@ -600,7 +610,14 @@ __global__ __launch_bounds__(256) void k_halfstep(const HalfStepArgs A) {
                     if (A.chain || A.sendbuf) {
                         if (!ac) load_row<G, V, CH>(rr, A.X + (size_t)wi * D, D, gl);
                         if (A.chain) store_row<G, V, CH>(rr, A.chain + (size_t)wi * D, D, gl);
-                        if (A.sendbuf) store_row<G, V, CH>(rr, A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * D, D, gl);
+                        if (A.sendbuf) {
+                            double* sb = A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2);
+                            store_row<G, V, CH>(rr, sb, D, gl);
+                            if (gl == 0) {
+                                sb[D] = lpf;
+                                sb[D + 1] = ac ? 1.0 : 0.0;
+                            }
+                        }
                     }
                 }
             }
@@ -690,27 +707,45 @@ __global__ void k_native_plan(NativeArgs nat, int N, int S, double a, double sig
     uacc[pos] = u;
 }
 
-// sharded runs: scatter the all-gathered rows of the other ranks' slots into the local replica
+// sharded runs: write the all-gathered [row | log_prob | accepted] records of the other ranks'
+// slots into the local replica (and the stored chain step, if any)
 struct ScatterArgs {
     double* X;
-    const double* gathered;   // (ns, D) slot order
+    double* lp;
+    uint8_t* acc;
+    uint32_t* acc_count;
+    double* chain;
+    double* chain_lp;
+    const double* gathered;   // virtual (ns, D + 2) array in slot order
     const int32_t* order;
     NativeArgs nat;
-    int32_t N, D, S, split, pos0, ns, native, own_lo, own_hi;
+    int32_t N, D, S, split, pos0, t_lo, t_hi, native;
 };
 
 __global__ __launch_bounds__(256) void k_scatter_rows(const ScatterArgs A) {
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (t >= A.ns || (t >= A.own_lo && t < A.own_hi)) return;
+    const int t = A.t_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= A.t_hi) return;
     int i;
     if (A.native)
         i = (int)perm_inv((uint32_t)(t * A.S + A.split), A.nat.pk);
     else
         i = A.order[A.pos0 + t];
-    const double* src = A.gathered + (size_t)t * A.D;
+    const double* src = A.gathered + (size_t)t * (A.D + 2);
     double* dst = A.X + (size_t)i * A.D;
     for (int d = lane; d < A.D; d += 64) dst[d] = src[d];
+    if (A.chain)
+        for (int d = lane; d < A.D; d += 64) A.chain[(size_t)i * A.D + d] = src[d];
+    if (lane == 0) {
+        const double l = src[A.D];
+        const bool ac = src[A.D + 1] != 0.0;
+        A.lp[i] = l;
+        A.acc[i] = ac ? 1 : 0;
+        if (A.chain_lp) {
+            A.chain_lp[i] = l;
+            if (ac) A.acc_count[i] += 1u;
+        }
+    }
 }
 
 }  // namespace emx

@@ -208,6 +208,9 @@ class DeviceEnsemble:
     def set_shard(self, rank, world):
         self._ck(self.lib.emx_set_shard(self.ctx, int(rank), int(world)))
 
+    def set_shard_buffers(self, sendbuf_ptr, gathered_ptr, rows):
+        self._ck(self.lib.emx_set_shard_buffers(self.ctx, sendbuf_ptr, gathered_ptr, int(rows)))
+
     def device_ptr(self, which):
         p, n = C.c_void_p(), C.c_int64()
         self._ck(self.lib.emx_device_ptr(self.ctx, int(which), C.byref(p), C.byref(n)))

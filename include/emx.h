@@ -120,8 +120,11 @@ int emx_plan_get(emx_ctx* ctx, int32_t* off, int32_t* order, int32_t* p0, int32_
 
 /* ---- walker-sharded multi-GPU (one process per GPU; collectives stay in the host layer) -- */
 int emx_set_shard(emx_ctx* ctx, int32_t rank, int32_t world);
+/* use caller-owned device buffers (e.g. torch tensors handed to RCCL) for the exchange:
+ * sendbuf (rows_per_rank, D+2), gathered (world*rows_per_rank, D+2); records = [row | log_prob | accepted] */
+int emx_set_shard_buffers(emx_ctx* ctx, void* sendbuf, void* gathered, int64_t rows_per_rank);
 /* raw device pointers for zero-copy wrapping (torch.distributed all-gather buffers):
- * which: 0 coords (N,D), 1 log_prob (N), 2 sendbuf (max slots/rank, D), 3 gathered (max ns, D) */
+ * which: 0 coords (N,D), 1 log_prob (N), 2 sendbuf (rows/rank, D+2), 3 gathered (world*rows/rank, D+2) */
 int emx_device_ptr(emx_ctx* ctx, int32_t which, void** ptr, int64_t* nbytes);
 int emx_shard_slots(emx_ctx* ctx, int32_t split, int64_t* t_lo, int64_t* t_hi, int64_t* ns);
 /* after the all-gather of `sendbuf`s into `gathered`: write the other ranks' rows into X */

@@ -20,6 +20,9 @@ from helpers import digest, load_digests, load_golden, rng_for_case, rng_from_fi
 pytestmark = pytest.mark.gpu
 
 LP_RTOL = 1e-11
+# snooker: u = delta/|delta| and two dot products are reductions (different summation order
+# than BLAS), amplified for near-zero coordinates; the contract is 1e-6 relative.
+SNOOKER_RTOL, SNOOKER_ATOL = 1e-9, 1e-10
 
 
 def _dev():
@@ -53,11 +56,11 @@ def make_ens(spec, p0):
     return ens
 
 
-def assert_lp_close(a, b):
+def assert_lp_close(a, b, rtol=LP_RTOL):
     fin = np.isfinite(b)
     assert np.array_equal(np.isfinite(a), fin)
     assert np.array_equal(a[~fin], b[~fin])
-    np.testing.assert_allclose(a[fin], b[fin], rtol=LP_RTOL, atol=1e-13)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=rtol, atol=1e-13)
 
 
 def has_snooker(spec):
@@ -80,10 +83,10 @@ def test_exact_mode_reproduces_reference_fixture(name):
     acc = ens.accepted_counts()
     assert np.array_equal(acc, g["accepted_count"]), "accept decisions differ from the reference"
     if has_snooker(spec):
-        np.testing.assert_allclose(chain, g["chain"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(chain, g["chain"], rtol=SNOOKER_RTOL, atol=SNOOKER_ATOL)
     else:
         assert np.array_equal(chain, g["chain"]), "coordinates are not bit-identical to the reference"
-    assert_lp_close(lps, g["log_prob"])
+    assert_lp_close(lps, g["log_prob"], SNOOKER_RTOL if has_snooker(spec) else LP_RTOL)
     st = ens.get_mt19937()
     assert np.array_equal(st[1], g["rng_key1"]) and st[2] == int(g["rng_pos1"])
     assert st[3] == int(g["rng_has_gauss1"]) and st[4] == float(g["rng_cached1"])
@@ -108,10 +111,11 @@ def test_exact_mode_mid_size_against_oracle(name):
     chain = ens.chain_read(0, 0, spec["nsteps"])
     assert np.array_equal(ens.accepted_counts(), out["accepted_count"])
     if has_snooker(spec):
-        np.testing.assert_allclose(chain, out["chain"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(chain, out["chain"], rtol=SNOOKER_RTOL, atol=SNOOKER_ATOL)
     else:
         assert np.array_equal(chain, out["chain"])
-    assert_lp_close(ens.chain_read(1, 0, spec["nsteps"]), out["log_prob"])
+    assert_lp_close(ens.chain_read(1, 0, spec["nsteps"]), out["log_prob"],
+                    SNOOKER_RTOL if has_snooker(spec) else LP_RTOL)
     ens.close()
 
 
@@ -153,10 +157,10 @@ def test_native_mode_step_by_step_against_oracle(name):
         acc_or = so.propose_planned(xo, lpo, fn, plan, mv)
         assert np.array_equal(acc_dev, acc_or), "accept mask differs at step %d" % step
         if mv.kind == "snooker":
-            np.testing.assert_allclose(x1, xo, rtol=1e-11, atol=1e-13)
+            np.testing.assert_allclose(x1, xo, rtol=SNOOKER_RTOL, atol=SNOOKER_ATOL)
         else:
             assert np.array_equal(x1, xo), "coordinates differ at step %d" % step
-        assert_lp_close(lp1, lpo)
+        assert_lp_close(lp1, lpo, SNOOKER_RTOL if mv.kind == "snooker" else LP_RTOL)
         nacc += acc_dev.sum()
     assert nacc > 0
     ens.close()
@@ -182,7 +186,7 @@ def test_host_target_split_phase_equals_fused(name):
         ens.step_end()
     chain = ens.chain_read(0, 0, nst)
     if has_snooker(spec):
-        np.testing.assert_allclose(chain, g["chain"][:nst], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(chain, g["chain"][:nst], rtol=SNOOKER_RTOL, atol=SNOOKER_ATOL)
     else:
         assert np.array_equal(chain, g["chain"][:nst])
     ens.close()

@@ -1,0 +1,84 @@
+"""Sharded path on ONE GPU: `world` logical ranks (one libemx context each) in one process,
+exchanging through an in-process all-gather.  Every rank's replica and chain must equal the
+single-rank run bit for bit (the kernels make identical decisions; only the work is split)."""
+import numpy as np
+import pytest
+
+from emcee_amd import _lib
+from emcee_amd.parallel import DeviceEngine, LocalGroup, ShardedStepper
+from oracle import cases
+
+from emx_testlib import cdf_of, move_desc
+from helpers import load_golden, rng_from_fixture
+from test_gpu_parity import make_ens
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,world,rng", [
+    ("c1_stretch_32x5_iso", 2, "mt"), ("stretch_50x3_iso", 3, "mt"), ("stretch_128x64_dense", 2, "mt"),
+    ("stretch_128x64_dense", 4, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt"),
+    ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
+    ("stretch_nsplits3_45x2", 2, "mt"),
+])
+def test_logical_ranks_equal_single_rank(name, world, rng):
+    import torch
+    g = load_golden(name)
+    spec = cases.build(name)
+    nst = min(8, spec["nsteps"])
+
+    def setup(ens):
+        if rng == "mt":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(rng_from_fixture(g).get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(777, 0)
+        ens.chain_config(nst)
+
+    ref = make_ens(spec, g["p0"])
+    setup(ref)
+    ref.run(nst, 1, True)
+    ref_chain, ref_lp, ref_acc = ref.chain_read(0, 0, nst), ref.chain_read(1, 0, nst), ref.accepted_counts()
+    if rng == "mt" and not any(m.kind == "snooker" for m in spec["moves"]):
+        assert np.array_equal(ref_chain, g["chain"][:nst])
+
+    group = LocalGroup(world)
+    steppers = []
+    for r in range(world):
+        ens = make_ens(spec, g["p0"])
+        setup(ens)
+        eng = DeviceEngine(ens, r, world, torch.device("cuda", 0))
+        steppers.append(ShardedStepper(eng, None))
+    for _ in range(nst):
+        _run_step(group, steppers)
+    for s in steppers:
+        ens = s.engine.ens
+        assert ens.status() == 0
+        assert np.array_equal(ens.chain_read(0, 0, nst), ref_chain)
+        assert np.array_equal(ens.chain_read(1, 0, nst), ref_lp)
+        assert np.array_equal(ens.accepted_counts(), ref_acc)
+        x, lp = ens.get_state()
+        assert np.array_equal(x, ref_chain[-1]) and np.array_equal(lp, ref_lp[-1])
+        ens.close()
+    ref.close()
+
+
+def _run_step(group, steppers):
+    """LocalGroup.run_step with explicit stream syncs: the contexts run on their own streams
+    while the in-process all-gather runs on torch's."""
+    import torch
+    engines = [s.engine for s in steppers]
+    res = [e.step_begin(True) for e in engines]
+    assert all(r == res[0] for r in res)
+    for split in range(res[0][1]):
+        for e in engines:
+            e.halfstep(split)
+        for e in engines:
+            e.ens.sync()
+        group._all_gather(engines)
+        torch.cuda.synchronize()
+        for e in engines:
+            e.scatter_gathered(split)
+    for e in engines:
+        e.step_end()
