@@ -61,8 +61,10 @@ SIGNATURES = {
     "emx_chain_read": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _dp]),
     "emx_accepted_counts": (C.c_int, [_P, _dp]),
     "emx_step_begin": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "emx_step_begin_with": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "emx_accept_proposals": (C.c_int, [_P, C.c_int32, _dp, _dp, _dp]),
     "emx_halfstep": (C.c_int, [_P, C.c_int32]),
-    "emx_propose": (C.c_int, [_P, C.c_int32, _P, C.POINTER(C.c_int64)]),
+    "emx_propose": (C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(C.c_int64)]),
     "emx_accept": (C.c_int, [_P, C.c_int32, _dp]),
     "emx_step_end": (C.c_int, [_P]),
     "emx_plan_set": (C.c_int, [_P, C.c_int32, _ip, _ip, _ip, _ip, _ip, _dp, _dp]),
@@ -85,6 +87,7 @@ SIGNATURES = {
     "emx_mt_shuffle_labels": (None, [_P, C.c_int64, C.c_int32, _ip]),
     "emx_mt_choice_cdf": (C.c_int32, [_P, _dp, C.c_int32]),
     "emx_host_plan_mt": (C.c_int, [_P, C.c_int64, C.c_int32, C.POINTER(MoveDesc), _ip, _ip, _ip, _ip, _ip, _dp, _dp]),
+    "emx_host_split_draws": (C.c_int, [_P, C.c_int64, C.POINTER(MoveDesc), _ip, _ip, C.c_int32, _ip, _ip, _ip, _dp]),
     "emx_host_plan_philox": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(MoveDesc), _ip, _ip, _ip, _ip, _ip, _dp, _dp]),
     "emx_host_move_choice_philox": (C.c_int32, [C.c_uint64, C.c_uint64, _dp, C.c_int32]),
 }

@@ -1,0 +1,225 @@
+"""Backend: chain storage (reference ``backends/backend.py:11-237``), device-resident by default.
+
+When a sampler drives the GPU path it attaches its :class:`DeviceEnsemble`: the chain
+``(nsteps, nwalkers, ndim)``, the log-prob chain and the per-walker accept counters then live in
+HBM (the half-step kernel appends to them directly) and ``get_value`` copies only the requested
+``discard/thin`` slice to the host.  Without a device attached (user-written moves running
+through ``Move.propose``) it is a plain in-memory store with the reference's ``save_step``."""
+import numpy as np
+
+from .. import autocorr
+from ..state import State
+
+__all__ = ["Backend"]
+
+
+class Backend(object):
+    """A backend that keeps the chain in memory (HBM when attached to a device ensemble)."""
+
+    def __init__(self, dtype=None):
+        self.initialized = False
+        self.dtype = np.float64 if dtype is None else dtype
+        self._dev = None
+
+    # ---- lifecycle ----
+    def reset(self, nwalkers, ndim):
+        """Clear the state of the chain and empty the backend."""
+        self.nwalkers = int(nwalkers)
+        self.ndim = int(ndim)
+        self._iteration = 0
+        self._accepted = np.zeros(self.nwalkers, dtype=self.dtype)
+        self._chain = np.empty((0, self.nwalkers, self.ndim), dtype=self.dtype)
+        self._log_prob = np.empty((0, self.nwalkers), dtype=self.dtype)
+        self.blobs = None
+        self.random_state = None
+        self.initialized = True
+        if self._dev is not None:
+            self._dev.chain_reset()
+
+    def _attach(self, ens):
+        """Move storage to the device ensemble ``ens`` (idempotent)."""
+        if self._dev is ens:
+            return
+        if self._dev is not None:
+            self._detach()
+        ens.chain_reset()
+        if self._iteration > 0:
+            raise RuntimeError("cannot attach a device to a backend that already holds host samples")
+        self._dev = ens
+
+    def _detach(self):
+        """Pull everything to host arrays and drop the device."""
+        if self._dev is None:
+            return
+        it = self.iteration
+        self._chain = self._dev.chain_read(0, 0, it)
+        self._log_prob = self._dev.chain_read(1, 0, it)
+        self._accepted = self._dev.accepted_counts().astype(self.dtype)
+        self._iteration = it
+        self._dev = None
+
+    # ---- reference attributes ----
+    @property
+    def iteration(self):
+        if self._dev is not None:
+            return self._dev.iteration()[0]
+        return self._iteration
+
+    @iteration.setter
+    def iteration(self, v):
+        self._iteration = v
+
+    @property
+    def accepted(self):
+        if self._dev is not None:
+            return self._dev.accepted_counts().astype(self.dtype)
+        return self._accepted
+
+    @accepted.setter
+    def accepted(self, v):
+        self._accepted = v
+
+    @property
+    def chain(self):
+        if self._dev is not None:
+            return self._dev.chain_read(0, 0, self.iteration)
+        return self._chain
+
+    @chain.setter
+    def chain(self, v):
+        self._chain = v
+
+    @property
+    def log_prob(self):
+        if self._dev is not None:
+            return self._dev.chain_read(1, 0, self.iteration)
+        return self._log_prob
+
+    @log_prob.setter
+    def log_prob(self, v):
+        self._log_prob = v
+
+    def has_blobs(self):
+        """Returns ``True`` if the model includes blobs"""
+        return self.blobs is not None
+
+    def get_value(self, name, flat=False, thin=1, discard=0):
+        it = self.iteration
+        if it <= 0:
+            raise AttributeError("you must run the sampler with 'store == True' before accessing the results")
+        if name == "blobs" and not self.has_blobs():
+            return None
+        start = discard + thin - 1                     # reference backend.py:53
+        if self._dev is not None and name in ("chain", "log_prob"):
+            v = self._dev.chain_read(0 if name == "chain" else 1, min(start, it), it, thin)
+        else:
+            v = getattr(self, name)[start:it:thin]
+        if flat:
+            s = list(v.shape[1:])
+            s[0] = int(np.prod(v.shape[:2]))
+            return v.reshape(s)
+        return v
+
+    def get_chain(self, **kwargs):
+        """Get the stored chain of MCMC samples (``flat``, ``thin``, ``discard`` as in the reference)."""
+        return self.get_value("chain", **kwargs)
+
+    def get_blobs(self, **kwargs):
+        """Get the chain of blobs for each sample in the chain."""
+        return self.get_value("blobs", **kwargs)
+
+    def get_log_prob(self, **kwargs):
+        """Get the chain of log probabilities evaluated at the MCMC samples."""
+        return self.get_value("log_prob", **kwargs)
+
+    def get_last_sample(self):
+        """Access the most recent sample in the chain"""
+        if (not self.initialized) or self.iteration <= 0:
+            raise AttributeError("you must run the sampler with 'store == True' before accessing the results")
+        it = self.iteration
+        blobs = self.get_blobs(discard=it - 1)
+        if blobs is not None:
+            blobs = blobs[0]
+        return State(self.get_chain(discard=it - 1)[0], log_prob=self.get_log_prob(discard=it - 1)[0],
+                     blobs=blobs, random_state=self.random_state)
+
+    def get_autocorr_time(self, discard=0, thin=1, **kwargs):
+        """Integrated autocorrelation time per parameter, in steps (reference backend.py:130-150)."""
+        x = self.get_chain(discard=discard, thin=thin)
+        return thin * autocorr.integrated_time(x, **kwargs)
+
+    @property
+    def shape(self):
+        """The dimensions of the ensemble ``(nwalkers, ndim)``"""
+        return self.nwalkers, self.ndim
+
+    # ---- growth / saving ----
+    def _check_blobs(self, blobs):
+        has_blobs = self.has_blobs()
+        if has_blobs and blobs is None:
+            raise ValueError("inconsistent use of blobs")
+        if self.iteration > 0 and blobs is not None and not has_blobs:
+            raise ValueError("inconsistent use of blobs")
+
+    def grow(self, ngrow, blobs):
+        """Expand the storage space by ``ngrow`` samples (reference backend.py:164-185)."""
+        self._check_blobs(blobs)
+        it = self.iteration
+        if self._dev is not None:
+            self._dev.chain_config(it + ngrow)
+            have = 0 if self.blobs is None else len(self.blobs)
+        else:
+            i = ngrow - (len(self._chain) - it)
+            a = np.empty((i, self.nwalkers, self.ndim), dtype=self.dtype)
+            self._chain = np.concatenate((self._chain, a), axis=0)
+            a = np.empty((i, self.nwalkers), dtype=self.dtype)
+            self._log_prob = np.concatenate((self._log_prob, a), axis=0)
+            have = len(self._chain) - i
+        if blobs is not None:
+            i = it + ngrow - (0 if self.blobs is None else len(self.blobs))
+            dt = np.dtype((blobs.dtype, blobs.shape[1:]))
+            a = np.empty((max(i, 0), self.nwalkers), dtype=dt)
+            self.blobs = a if self.blobs is None else np.concatenate((self.blobs, a), axis=0)
+        del have
+
+    def _check(self, state, accepted):
+        self._check_blobs(state.blobs)
+        nwalkers, ndim = self.shape
+        has_blobs = self.has_blobs()
+        if state.coords.shape != (nwalkers, ndim):
+            raise ValueError("invalid coordinate dimensions; expected {0}".format((nwalkers, ndim)))
+        if state.log_prob.shape != (nwalkers,):
+            raise ValueError("invalid log probability size; expected {0}".format(nwalkers))
+        if state.blobs is not None and not has_blobs:
+            raise ValueError("unexpected blobs")
+        if state.blobs is None and has_blobs:
+            raise ValueError("expected blobs, but none were given")
+        if state.blobs is not None and len(state.blobs) != nwalkers:
+            raise ValueError("invalid blobs size; expected {0}".format(nwalkers))
+        if accepted.shape != (nwalkers,):
+            raise ValueError("invalid acceptance size; expected {0}".format(nwalkers))
+
+    def save_step(self, state, accepted):
+        """Save a step to the (host) backend: reference backend.py:214-231."""
+        if self._dev is not None:
+            self._detach()
+        self._check(state, accepted)
+        self._chain[self._iteration, :, :] = state.coords
+        self._log_prob[self._iteration, :] = state.log_prob
+        if state.blobs is not None:
+            self.blobs[self._iteration, :] = state.blobs
+        self._accepted = self._accepted + accepted
+        self.random_state = state.random_state
+        self._iteration += 1
+
+    def _device_step_saved(self, state_blobs, random_state):
+        """Book-keeping after the kernel appended a step to the device chain."""
+        if state_blobs is not None:
+            self.blobs[self.iteration - 1, :] = state_blobs
+        self.random_state = random_state
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exception_type, exception_value, traceback):
+        pass

@@ -58,25 +58,12 @@ inline void de_pair(uint64_t k, uint64_t nc, uint64_t& first, uint64_t& second) 
     }
 }
 
+// proposal draws of ONE get_proposal call (stretch.py:30-32 | de.py:49-56 | de_snooker.py:37-40)
 template <typename I32, typename F64>
-int make_exact_plan(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc& mv, std::vector<int32_t>& labels,
-                    int32_t* off, I32* order, I32* p0, I32* p1, I32* p2, F64* s0, F64* uacc) {
+int draw_split_proposal(MT19937Legacy& mt, int64_t N, const emx_move_desc& mv, const int32_t* off, const I32* order,
+                        int split, I32* p0, I32* p1, I32* p2, F64* s0) {
     const int S = mv.nsplits;
-    if (S < 2 || S > 255) return -1;
-    if (mv.kind == EMX_MOVE_SNOOKER && S < 4) return -1;
-    labels.resize(N);
-    for (int64_t i = 0; i < N; ++i) labels[i] = (int32_t)(i % S);          // red_blue.py:78
-    if (mv.randomize_split) mt.shuffle(labels.data(), N);                   // red_blue.py:80
-    // boolean-mask gather order (red_blue.py:85): ascending walker index inside each set
-    std::vector<int32_t> cnt(S + 1, 0);
-    for (int64_t i = 0; i < N; ++i) cnt[labels[i] + 1]++;
-    for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
-    for (int s = 0; s <= S; ++s) off[s] = cnt[s];
     {
-        std::vector<int32_t> cur(cnt.begin(), cnt.end() - 1);
-        for (int64_t i = 0; i < N; ++i) order[cur[labels[i]]++] = (int32_t)i;
-    }
-    for (int split = 0; split < S; ++split) {
         const int64_t base = off[split], ns = off[split + 1] - off[split], nc = N - ns;
         auto comp = [&](uint64_t r) -> int32_t {  // complement = concatenation of the other sets (stretch.py:27)
             return (int64_t)r < base ? order[r] : order[r + ns];
@@ -127,6 +114,31 @@ int make_exact_plan(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc
         } else {
             return -1;
         }
+    }
+    return 0;
+}
+
+template <typename I32, typename F64>
+int make_exact_plan(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc& mv, std::vector<int32_t>& labels,
+                    int32_t* off, I32* order, I32* p0, I32* p1, I32* p2, F64* s0, F64* uacc) {
+    const int S = mv.nsplits;
+    if (S < 2 || S > 255) return -1;
+    if (mv.kind == EMX_MOVE_SNOOKER && S < 4) return -1;
+    labels.resize(N);
+    for (int64_t i = 0; i < N; ++i) labels[i] = (int32_t)(i % S);          // red_blue.py:78
+    if (mv.randomize_split) mt.shuffle(labels.data(), N);                   // red_blue.py:80
+    // boolean-mask gather order (red_blue.py:85): ascending walker index inside each set
+    std::vector<int32_t> cnt(S + 1, 0);
+    for (int64_t i = 0; i < N; ++i) cnt[labels[i] + 1]++;
+    for (int s = 0; s < S; ++s) cnt[s + 1] += cnt[s];
+    for (int s = 0; s <= S; ++s) off[s] = cnt[s];
+    {
+        std::vector<int32_t> cur(cnt.begin(), cnt.end() - 1);
+        for (int64_t i = 0; i < N; ++i) order[cur[labels[i]]++] = (int32_t)i;
+    }
+    for (int split = 0; split < S; ++split) {
+        const int64_t base = off[split], ns = off[split + 1] - off[split];
+        if (draw_split_proposal(mt, N, mv, off, order, split, p0, p1, p2, s0) != 0) return -1;
         for (int64_t t = 0; t < ns; ++t) uacc[base + t] = mt.next_double();  // red_blue.py:100
     }
     (void)D;
@@ -801,7 +813,18 @@ static int acquire_slot(emx_ctx* c, emx_ctx::PlanSlot** out) {
     return 0;
 }
 
+static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32_t* move_out, int32_t* S_out);
+
 int emx_step_begin(emx_ctx* c, int32_t store, int32_t* move_out, int32_t* S_out) {
+    return step_begin_impl(c, store, -1, move_out, S_out);
+}
+
+int emx_step_begin_with(emx_ctx* c, int32_t store, int32_t move_index, int32_t* S_out) {
+    NEED(c, move_index >= 0 && move_index < (int)c->moves.size(), "bad move index");
+    return step_begin_impl(c, store, move_index, nullptr, S_out);
+}
+
+static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32_t* move_out, int32_t* S_out) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, !c->cur.active, "emx_step_begin: previous step not ended");
     if (store) NEED(c, c->stored < c->cap, "chain capacity exhausted (call emx_chain_config)");
@@ -810,7 +833,7 @@ int emx_step_begin(emx_ctx* c, int32_t store, int32_t* move_out, int32_t* S_out)
     cur.native = false;
     const int nm = (int)c->moves.size();
     if (c->rng_mode == EMX_RNG_MT19937) {
-        cur.move = c->mt.choice_cdf(c->cdf.data(), nm);                        // ensemble.py:406
+        cur.move = forced_move >= 0 ? forced_move : c->mt.choice_cdf(c->cdf.data(), nm);   // ensemble.py:406
         const emx_move_desc& mv = c->moves[cur.move];
         cur.S = mv.nsplits;
         NEED(c, c->N >= 2 && (mv.kind != EMX_MOVE_DE || c->N - (c->N + cur.S - 1) / cur.S >= 2),
@@ -829,7 +852,7 @@ int emx_step_begin(emx_ctx* c, int32_t store, int32_t* move_out, int32_t* S_out)
         rc = upload_plan(c, *ps);
         if (rc) return rc;
     } else if (c->rng_mode == EMX_RNG_PHILOX) {
-        cur.move = philox_move_choice(c->ph_seed, c->ph_step, c->cdf.data(), nm);
+        cur.move = forced_move >= 0 ? forced_move : philox_move_choice(c->ph_seed, c->ph_step, c->cdf.data(), nm);
         const emx_move_desc& mv = c->moves[cur.move];
         cur.S = mv.nsplits;
         cur.native = true;
@@ -954,7 +977,7 @@ int emx_halfstep(emx_ctx* c, int32_t split) {
     return do_halfstep(c, split, c->target);
 }
 
-int emx_propose(emx_ctx* c, int32_t split, double* q_out, int64_t* ns_out) {
+int emx_propose(emx_ctx* c, int32_t split, double* q_out, double* factors_out, int64_t* ns_out) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, c->world == 1, "split-phase host targets are single-rank");
     int rc = do_halfstep(c, split, EMX_TARGET_HOST);
@@ -964,6 +987,8 @@ int emx_propose(emx_ctx* c, int32_t split, double* q_out, int64_t* ns_out) {
     if (ns_out) *ns_out = ns;
     if (q_out && ns > 0)
         HIPOK(c, hipMemcpyAsync(q_out, c->qout, (size_t)ns * c->D * 8, hipMemcpyDeviceToHost, c->stream));
+    if (factors_out && ns > 0)
+        HIPOK(c, hipMemcpyAsync(factors_out, c->fout, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1002,6 +1027,18 @@ int emx_accept(emx_ctx* c, int32_t split, const double* new_lp) {
     hipLaunchKernelGGL(k_accept, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, c->stream, a);
     HIPOK(c, hipGetLastError());
     return 0;
+}
+
+int emx_accept_proposals(emx_ctx* c, int32_t split, const double* q, const double* factors, const double* new_lp) {
+    // custom RedBlueMove.get_proposal (host code): the caller supplies q and factors (red_blue.py:90)
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, cur.active && cur.move >= 0 && split >= 0 && split < cur.S, "emx_accept_proposals outside a planned step");
+    const int ns = cur.off[split + 1] - cur.off[split];
+    if (ns <= 0) return 0;
+    HIPOK(c, hipMemcpyAsync(c->qout, q, (size_t)ns * c->D * 8, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(c->fout, factors, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
+    return emx_accept(c, split, new_lp);
 }
 
 int emx_step_end(emx_ctx* c) {
@@ -1218,6 +1255,13 @@ int emx_host_plan_mt(emx_mt* m, int64_t N, int32_t D, const emx_move_desc* mv, i
                      int32_t* p1, int32_t* p2, double* s0, double* uacc) {
     std::vector<int32_t> labels;
     return make_exact_plan(m->mt, N, D, *mv, labels, off, order, p0, p1, p2, s0, uacc);
+}
+
+int emx_host_split_draws(emx_mt* m, int64_t N, const emx_move_desc* mv, const int32_t* off, const int32_t* order,
+                         int32_t split, int32_t* p0, int32_t* p1, int32_t* p2, double* s0) {
+    if (mv->nsplits < 2 || split < 0 || split >= mv->nsplits) return -1;
+    if (mv->kind == EMX_MOVE_SNOOKER && mv->nsplits < 4) return -1;
+    return draw_split_proposal(m->mt, N, *mv, off, order, split, p0, p1, p2, s0);
 }
 
 int emx_host_plan_philox(uint64_t seed, uint64_t step, int64_t N, const emx_move_desc* mv, int32_t* off, int32_t* order,

@@ -176,13 +176,25 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_step_begin(self.ctx, int(bool(store)), C.byref(mv), C.byref(S)))
         return mv.value, S.value
 
+    def step_begin_with(self, move_index, store=False):
+        S = C.c_int32()
+        self._ck(self.lib.emx_step_begin_with(self.ctx, int(bool(store)), int(move_index), C.byref(S)))
+        return S.value
+
+    def accept_proposals(self, split, q, factors, new_log_prob):
+        self._ck(self.lib.emx_accept_proposals(self.ctx, int(split), _as_f64(q), _as_f64(factors), _as_f64(new_log_prob)))
+
     def halfstep(self, split):
         self._ck(self.lib.emx_halfstep(self.ctx, int(split)))
 
-    def propose(self, split):
+    def propose(self, split, with_factors=False):
         ns = C.c_int64()
         q = np.empty((self.nwalkers, self.ndim))
-        self._ck(self.lib.emx_propose(self.ctx, int(split), q.ctypes.data, C.byref(ns)))
+        f = np.empty(self.nwalkers) if with_factors else None
+        self._ck(self.lib.emx_propose(self.ctx, int(split), q.ctypes.data, None if f is None else f.ctypes.data,
+                                      C.byref(ns)))
+        if with_factors:
+            return q[: ns.value], f[: ns.value]
         return q[: ns.value]
 
     def accept(self, split, new_log_prob):

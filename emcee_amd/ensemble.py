@@ -1,0 +1,616 @@
+"""EnsembleSampler: the drop-in driver of the GPU hot path (reference ``ensemble.py:32-713``).
+
+Same constructor, ``sample()`` generator, ``run_mcmc()``, ``compute_log_prob()``, ``get_*``
+accessors, errors and RNG-state semantics as reference emcee.  What runs where:
+
+* ``log_prob_fn`` is a :class:`emcee_amd.targets.DeviceTarget` and every move is a built-in
+  split-ensemble move  ->  **fused path**: one HIP launch per half-step does proposal, batched
+  log-prob, Metropolis accept, commit and chain append; ``run_mcmc`` is a single C call.
+* any other ``log_prob_fn`` with built-in moves  ->  **split-phase path**: proposal and
+  accept/commit stay on the GPU, only the callable (optionally through ``pool.map``) runs on
+  the host, exactly where reference emcee calls it (``moves/red_blue.py:93``).
+* user-written moves  ->  their own ``propose(model, state)`` is called as in the reference.
+
+``rng="mt19937"`` (default) replays NumPy's legacy MT19937 stream: the same seed gives the same
+chain as reference emcee.  ``rng="philox"`` generates all draws inside the kernels (counter
+based), the throughput mode.  There is no CPU fallback: a missing GPU raises.
+"""
+import warnings
+from itertools import count
+
+import numpy as np
+
+from . import _lib
+from .backends import Backend
+from .model import Model
+from .moves import StretchMove
+from .pbar import get_progress_bar
+from .state import State
+from .targets import DeviceTarget
+from .utils import deprecation_warning
+
+__all__ = ["EnsembleSampler", "walkers_independent"]
+
+try:
+    from collections.abc import Iterable
+except ImportError:  # pragma: no cover
+    from collections import Iterable
+
+try:
+    from numpy.exceptions import VisibleDeprecationWarning
+except ImportError:  # pragma: no cover
+    from numpy import VisibleDeprecationWarning
+
+
+def _native_desc(move, ndim):
+    """MoveDesc of a built-in move (ours, or a reference emcee instance of the same class name
+    with an un-overridden get_proposal); None for anything else."""
+    if hasattr(move, "_is_native"):
+        return move._desc(ndim) if move._is_native() else None
+    for klass in type(move).__mro__:
+        if "get_proposal" in klass.__dict__:
+            owner, mod = klass.__name__, klass.__module__
+            break
+    else:
+        return None
+    if not mod.startswith("emcee.moves"):
+        return None
+    try:
+        ns, rs = int(move.nsplits), int(bool(move.randomize_split))
+        if owner == "StretchMove":
+            return _lib.MoveDesc(_lib.MOVE_STRETCH, ns, rs, 0, float(move.a), 0.0, 0.0, 0.0)
+        if owner == "DEMove":
+            g0 = move.gamma0 if move.gamma0 is not None else 2.38 / np.sqrt(2 * ndim)
+            return _lib.MoveDesc(_lib.MOVE_DE, ns, rs, 0, 2.0, float(move.sigma), float(g0), 0.0)
+        if owner == "DESnookerMove":
+            return _lib.MoveDesc(_lib.MOVE_SNOOKER, ns, rs, 0, 2.0, 0.0, 0.0, float(move.gammas))
+    except AttributeError:
+        return None
+    return None
+
+
+class EnsembleSampler(object):
+    """An ensemble MCMC sampler (see the module docstring; arguments as in reference
+    ``ensemble.py:41-77``, plus ``rng`` and ``device``)."""
+
+    def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, moves=None, args=None, kwargs=None, backend=None,
+                 vectorize=False, blobs_dtype=None, parameter_names=None,
+                 # Deprecated...
+                 a=None, postargs=None, threads=None, live_dangerously=None, runtime_sortingfn=None,
+                 # emcee_amd extensions
+                 rng="mt19937", device=0):
+        if a is not None:
+            deprecation_warning("The 'a' argument is deprecated, use 'moves' instead")
+        if threads is not None:
+            deprecation_warning("The 'threads' argument is deprecated")
+        if runtime_sortingfn is not None:
+            deprecation_warning("The 'runtime_sortingfn' argument is deprecated")
+        if live_dangerously is not None:
+            deprecation_warning("The 'live_dangerously' argument is deprecated")
+
+        # move schedule (reference ensemble.py:115-129)
+        if moves is None:
+            self._moves = [StretchMove()]
+            self._weights = [1.0]
+        elif isinstance(moves, Iterable):
+            try:
+                self._moves, self._weights = zip(*moves)
+            except TypeError:
+                self._moves = moves
+                self._weights = np.ones(len(moves))
+        else:
+            self._moves = [moves]
+            self._weights = [1.0]
+        self._weights = np.atleast_1d(self._weights).astype(float)
+        self._weights /= np.sum(self._weights)
+
+        if rng not in ("mt19937", "philox"):
+            raise ValueError("rng must be 'mt19937' or 'philox'")
+        self.rng = rng
+        self.device = int(device)
+        self.pool = pool
+        self.vectorize = vectorize
+        self.blobs_dtype = blobs_dtype
+        self.ndim = ndim
+        self.nwalkers = nwalkers
+        self.backend = Backend() if backend is None else backend
+        self._ens = None
+        self._philox_step = 0
+
+        if not self.backend.initialized:
+            self._previous_state = None
+            self.reset()
+            state = np.random.get_state()
+        else:
+            if self.backend.shape != (self.nwalkers, self.ndim):
+                raise ValueError(("the shape of the backend ({0}) is incompatible with the shape of the sampler ({1})"
+                                  ).format(self.backend.shape, (self.nwalkers, self.ndim)))
+            state = self.backend.random_state
+            if state is None:
+                state = np.random.get_state()
+            it = self.backend.iteration
+            if it > 0:
+                self._previous_state = self.get_last_sample()
+            else:
+                self._previous_state = None
+
+        # private generator, seeded from the global NumPy state (reference ensemble.py:164-167)
+        self._random = np.random.mtrand.RandomState()
+        self._random.set_state(state)
+
+        self._device_target = log_prob_fn if isinstance(log_prob_fn, DeviceTarget) else None
+        self.log_prob_fn = _FunctionWrapper(log_prob_fn, args, kwargs)
+
+        self.params_are_named = parameter_names is not None
+        if self.params_are_named:
+            assert isinstance(parameter_names, (list, dict))
+            assert not self.vectorize, "named parameters with vectorization unsupported for now"
+            seen, uniq = set(), []
+            for name in parameter_names:
+                if name not in seen:
+                    uniq.append(name)
+                    seen.add(name)
+            assert len(uniq) == len(parameter_names), f"duplicate parameters: {seen}"
+            if isinstance(parameter_names, list):
+                assert len(parameter_names) == ndim, "name all parameters or set `parameter_names` to `None`"
+                parameter_names = {name: i for i, name in enumerate(parameter_names)}
+            assert len(parameter_names) <= ndim, "too many names"
+            values = [v if isinstance(v, list) else [v] for v in parameter_names.values()]
+            values = set(item for sub in values for item in sub)
+            assert values == set(np.arange(ndim)), f"not all values appear -- set should be 0 to {ndim-1}"
+            self.parameter_names = parameter_names
+
+    # ------------------------------------------------------------------ RNG / bookkeeping
+    @property
+    def random_state(self):
+        """``get_state()`` of the sampler's private ``numpy.random.RandomState``."""
+        return self._random.get_state()
+
+    @random_state.setter  # NOQA
+    def random_state(self, state):
+        """Try to set the generator state; fails silently like the reference (ensemble.py:228-238)."""
+        try:
+            self._random.set_state(state)
+        except:  # noqa: E722
+            pass
+
+    @property
+    def iteration(self):
+        return self.backend.iteration
+
+    def reset(self):
+        """Reset the bookkeeping parameters"""
+        self.backend.reset(self.nwalkers, self.ndim)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["pool"] = None
+        d["_ens"] = None            # device contexts are not picklable; re-created on demand
+        return d
+
+    # ------------------------------------------------------------------ device plumbing
+    def _device_ensemble(self):
+        if self._ens is None:
+            from .device import DeviceEnsemble
+            self._ens = DeviceEnsemble(self.nwalkers, self.ndim, device=self.device)
+        return self._ens
+
+    def _philox_seed(self):
+        key = self._random.get_state()[1]
+        return (int(key[0]) << 32 | int(key[1])) ^ (int(key[2]) << 16)
+
+    def _configure_device(self, descs, fused):
+        ens = self._device_ensemble()
+        if fused:
+            self._device_target.bind(ens)
+        else:
+            ens.set_target(_lib.TARGET_HOST)
+        cdf = np.cumsum(self._weights)
+        cdf /= cdf[-1]
+        ens.set_moves(descs, cdf)
+        if self.rng == "mt19937":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(self._random.get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(self._philox_seed(), self._philox_step)
+        return ens
+
+    def _sync_rng_from_device(self, ens):
+        if self.rng == "mt19937":
+            self._random.set_state(ens.get_mt19937())
+        else:
+            self._philox_step = ens.get_philox()[1]
+
+    # ------------------------------------------------------------------ sampling
+    def sample(self, initial_state, log_prob0=None, rstate0=None, blobs0=None, iterations=1, tune=False,
+               skip_initial_state_check=False, thin_by=1, thin=None, store=True, progress=False,
+               progress_kwargs=None):
+        """Advance the chain as a generator; yields the :class:`State` every ``thin_by`` steps.
+
+        Arguments and error behaviour as reference ``ensemble.py:258-424``."""
+        if iterations is None and store:
+            raise ValueError("'store' must be False when 'iterations' is None")
+        state = State(initial_state, copy=True)
+        state_shape = np.shape(state.coords)
+        if state_shape != (self.nwalkers, self.ndim):
+            raise ValueError(f"incompatible input dimensions {state_shape}")
+        if (not skip_initial_state_check) and (not walkers_independent(state.coords)):
+            raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
+                             "linearly independent for the best performance")
+
+        if rstate0 is not None:
+            deprecation_warning("The 'rstate0' argument is deprecated, use a 'State' instead")
+            state.random_state = rstate0
+        self.random_state = state.random_state
+
+        if log_prob0 is not None:
+            deprecation_warning("The 'log_prob0' argument is deprecated, use a 'State' instead")
+            state.log_prob = log_prob0
+        if blobs0 is not None:
+            deprecation_warning("The 'blobs0' argument is deprecated, use a 'State' instead")
+            state.blobs = blobs0
+        if state.log_prob is None:
+            state.log_prob, state.blobs = self.compute_log_prob(state.coords)
+        if np.shape(state.log_prob) != (self.nwalkers,):
+            raise ValueError("incompatible input dimensions")
+        if np.any(np.isnan(state.log_prob)):
+            raise ValueError("The initial log_prob was NaN")
+
+        # which execution path
+        descs = [_native_desc(m, self.ndim) for m in self._moves]
+        native = all(d is not None for d in descs)
+        fused = native and self._device_target is not None and state.blobs is None
+        own_backend = isinstance(self.backend, Backend)
+        for m in self._moves:
+            live = getattr(m, "live_dangerously", False)
+            if native and self.nwalkers < 2 * self.ndim and not live:       # reference red_blue.py:64-70
+                raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice "
+                                   "the number of dimensions.")
+
+        if thin is not None:
+            deprecation_warning("The 'thin' argument is deprecated. Use 'thin_by' instead.")
+            thin = int(thin)
+            if thin <= 0:
+                raise ValueError("Invalid thinning argument")
+            yield_step = 1
+            checkpoint_step = thin
+            nsaves = None if iterations is None else iterations // checkpoint_step
+        else:
+            thin_by = int(thin_by)
+            if thin_by <= 0:
+                raise ValueError("Invalid thinning argument")
+            yield_step = thin_by
+            checkpoint_step = thin_by
+            nsaves = iterations
+
+        ens = None
+        if native:
+            ens = self._configure_device(descs, fused)
+            ens.set_state(state.coords, np.asarray(state.log_prob, dtype=np.float64))
+            if own_backend and store:
+                if self.backend._dev is not ens:
+                    if self.backend.iteration > 0:
+                        self.backend._detach()          # host samples from an earlier (custom-move) run
+                    else:
+                        self.backend._attach(ens)
+        elif own_backend:
+            self.backend._detach()
+        dev_store = native and store and own_backend and self.backend._dev is ens
+        if store:
+            self.backend.grow(nsaves, state.blobs)
+
+        map_fn = self.pool.map if self.pool is not None else map
+        model = Model(self.log_prob_fn, self.compute_log_prob, map_fn, self._random)
+        if progress_kwargs is None:
+            progress_kwargs = {}
+
+        total = None if iterations is None else iterations * yield_step
+        with get_progress_bar(progress, total, **progress_kwargs) as pbar:
+            i = 0
+            for _ in count() if iterations is None else range(iterations):
+                for _ in range(yield_step):
+                    save = store and (i + 1) % checkpoint_step == 0
+                    if native:
+                        accepted = self._device_step(ens, state, fused, save and dev_store)
+                        move = None
+                    else:
+                        move = self._random.choice(self._moves, p=self._weights)     # ensemble.py:406
+                        state, accepted = move.propose(model, state)
+                    state.random_state = self.random_state
+                    if tune and move is not None:
+                        move.tune(state, accepted)
+                    if save:
+                        if dev_store:
+                            self.backend._device_step_saved(state.blobs, state.random_state)
+                        else:
+                            if native:
+                                state.coords, state.log_prob = ens.get_state()
+                            self.backend.save_step(state, accepted)
+                    pbar.update(1)
+                    i += 1
+                if native:
+                    state.coords, state.log_prob = ens.get_state()
+                yield state
+
+    def _device_step(self, ens, state, fused, store):
+        """One full step of the built-in moves on the device; returns the accepted mask."""
+        if fused:
+            ens.run(1, 1, store)
+            ens.raise_on_status()
+            self._sync_rng_from_device(ens)
+            return ens.accepted_mask()
+        # split-phase: the callable runs on the host between propose and accept (red_blue.py:90-104)
+        k, nsplits = ens.step_begin(store)
+        pending = []
+        for split in range(nsplits):
+            q = ens.propose(split)
+            new_lp, new_blobs = self.compute_log_prob(q)
+            ens.accept(split, np.asarray(new_lp, dtype=np.float64))
+            if new_blobs is not None:
+                pending.append((split, new_blobs))
+        plan = ens.plan_get(nsplits) if pending else None
+        ens.step_end()
+        ens.raise_on_status()
+        self._sync_rng_from_device(ens)
+        accepted = ens.accepted_mask()
+        for split, new_blobs in pending:
+            if state.blobs is None:
+                raise ValueError("If you start sampling with a given log_prob, you also need to provide the "
+                                 "current list of blobs at that position.")
+            members = plan["order"][plan["off"][split]:plan["off"][split + 1]]
+            acc = accepted[members]
+            state.blobs[members[acc]] = np.asarray(new_blobs)[acc]
+        return accepted
+
+    def run_mcmc(self, initial_state, nsteps, **kwargs):
+        """Iterate :func:`sample` for ``nsteps`` iterations and return the result.
+
+        ``initial_state=None`` resumes from the last state (reference ensemble.py:426-456).  With a
+        device target, built-in moves and no progress bar the whole run is one native call."""
+        if initial_state is None:
+            if self._previous_state is None:
+                raise ValueError("Cannot have `initial_state=None` if run_mcmc has never been called.")
+            initial_state = self._previous_state
+
+        fast = self._fast_run(initial_state, nsteps, **kwargs)
+        if fast is not None:
+            self._previous_state = fast
+            return fast
+
+        results = None
+        for results in self.sample(initial_state, iterations=nsteps, **kwargs):
+            pass
+        self._previous_state = results
+        return results
+
+    def _fast_run(self, initial_state, nsteps, **kw):
+        """``run_mcmc`` as ONE emx_run call when nothing on the host has to see the intermediate
+        steps.  Returns None when the general generator path is required."""
+        allowed = {"skip_initial_state_check", "thin_by", "store", "tune", "progress"}
+        if set(kw) - allowed or kw.get("progress", False) or self._device_target is None:
+            return None
+        if not isinstance(self.backend, Backend) or nsteps is None or nsteps < 1:
+            return None
+        descs = [_native_desc(m, self.ndim) for m in self._moves]
+        if any(d is None for d in descs):
+            return None
+        thin_by = int(kw.get("thin_by", 1))
+        store = kw.get("store", True)
+        if thin_by <= 0:
+            raise ValueError("Invalid thinning argument")
+        state = State(initial_state, copy=True)
+        if state.blobs is not None:
+            return None
+        if np.shape(state.coords) != (self.nwalkers, self.ndim):
+            raise ValueError(f"incompatible input dimensions {np.shape(state.coords)}")
+        if (not kw.get("skip_initial_state_check", False)) and (not walkers_independent(state.coords)):
+            raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
+                             "linearly independent for the best performance")
+        for m in self._moves:
+            if self.nwalkers < 2 * self.ndim and not getattr(m, "live_dangerously", False):
+                raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice "
+                                   "the number of dimensions.")
+        self.random_state = state.random_state
+        ens = self._configure_device(descs, True)
+        if state.log_prob is None:
+            ens.set_state(state.coords)
+            ens.eval_state_log_prob()
+            ens.raise_on_status()
+            lp0 = ens.get_state(coords=False)[1]
+        else:
+            lp0 = np.asarray(state.log_prob, dtype=np.float64)
+            if np.shape(lp0) != (self.nwalkers,):
+                raise ValueError("incompatible input dimensions")
+            ens.set_state(state.coords, lp0)
+        if np.any(np.isnan(lp0)):
+            raise ValueError("The initial log_prob was NaN")
+        if store:
+            if self.backend._dev is not ens:
+                if self.backend.iteration > 0:
+                    return None
+                self.backend._attach(ens)
+            self.backend.grow(nsteps, None)
+        ens.run(nsteps, thin_by, store and self.backend._dev is ens)
+        ens.raise_on_status()
+        self._sync_rng_from_device(ens)
+        coords, lp = ens.get_state()
+        out = State(coords, log_prob=lp, random_state=self.random_state)
+        if store:
+            self.backend.random_state = out.random_state
+        return out
+
+    # ------------------------------------------------------------------ batched log-prob
+    def compute_log_prob(self, coords):
+        """Calculate the vector of log-probability for the walkers -> ``(log_prob, blobs)``.
+
+        Device targets are evaluated by the batched kernel; other callables as in reference
+        ``ensemble.py:458-553`` (``vectorize``, ``pool.map``, blobs, NaN / inf guards)."""
+        p = coords
+        if np.any(np.isinf(p)):
+            raise ValueError("At least one parameter value was infinite")
+        if np.any(np.isnan(p)):
+            raise ValueError("At least one parameter value was NaN")
+
+        if self._device_target is not None:
+            ens = self._device_ensemble()
+            self._device_target.bind(ens) if ens._target_kind != self._device_target.kind else None
+            log_prob = ens.eval_log_prob(np.atleast_2d(p))
+            ens.status()
+            if np.any(np.isnan(log_prob)):
+                raise ValueError("Probability function returned NaN")
+            return log_prob, None
+
+        if self.params_are_named:
+            p = ndarray_to_list_of_dicts(p, self.parameter_names)
+
+        if self.vectorize:
+            results = self.log_prob_fn(p)
+        else:
+            map_func = self.pool.map if self.pool is not None else map
+            results = list(map_func(self.log_prob_fn, p))
+
+        try:
+            blob = [l[1:] for l in results if len(l) > 1]       # noqa: E741
+            if not len(blob):
+                raise IndexError
+            log_prob = np.array([_scalar(l[0]) for l in results])   # noqa: E741
+        except (IndexError, TypeError):
+            log_prob = np.array([_scalar(l) for l in results])      # noqa: E741
+            blob = None
+        else:
+            if self.blobs_dtype is not None:
+                dt = self.blobs_dtype
+            else:
+                try:
+                    with warnings.catch_warnings(record=True):
+                        warnings.simplefilter("error", VisibleDeprecationWarning)
+                        try:
+                            dt = np.atleast_1d(blob[0]).dtype
+                        except Warning:
+                            deprecation_warning("You have provided blobs that are not all the same shape or size. "
+                                                "This means they must be placed in an object array. Numpy has "
+                                                "deprecated this automatic detection, so please specify "
+                                                "blobs_dtype=np.dtype('object')")
+                            dt = np.dtype("object")
+                except ValueError:
+                    dt = np.dtype("object")
+                if dt.kind in "US":
+                    dt = np.dtype("object")
+            blob = np.array(blob, dtype=dt)
+            shape = blob.shape[1:]
+            if len(shape):
+                axes = np.arange(len(shape))[np.array(shape) == 1] + 1
+                if len(axes):
+                    blob = np.squeeze(blob, tuple(axes))
+
+        if np.any(np.isnan(log_prob)):
+            raise ValueError("Probability function returned NaN")
+        return log_prob, blob
+
+    # ------------------------------------------------------------------ results
+    @property
+    def acceptance_fraction(self):
+        """The fraction of proposed steps that were accepted"""
+        return self.backend.accepted / float(self.backend.iteration)
+
+    def get_chain(self, **kwargs):
+        return self.get_value("chain", **kwargs)
+
+    def get_blobs(self, **kwargs):
+        return self.get_value("blobs", **kwargs)
+
+    def get_log_prob(self, **kwargs):
+        return self.get_value("log_prob", **kwargs)
+
+    def get_last_sample(self, **kwargs):
+        return self.backend.get_last_sample()
+
+    def get_value(self, name, **kwargs):
+        return self.backend.get_value(name, **kwargs)
+
+    def get_autocorr_time(self, **kwargs):
+        return self.backend.get_autocorr_time(**kwargs)
+
+    get_chain.__doc__ = Backend.get_chain.__doc__
+    get_blobs.__doc__ = Backend.get_blobs.__doc__
+    get_log_prob.__doc__ = Backend.get_log_prob.__doc__
+    get_last_sample.__doc__ = Backend.get_last_sample.__doc__
+    get_autocorr_time.__doc__ = Backend.get_autocorr_time.__doc__
+
+    # deprecated aliases of the reference (ensemble.py:560-595)
+    @property
+    def chain(self):  # pragma: no cover
+        deprecation_warning("chain is deprecated, use get_chain() instead")
+        return np.swapaxes(self.get_chain(), 0, 1)
+
+    @property
+    def flatchain(self):  # pragma: no cover
+        deprecation_warning("flatchain is deprecated, use get_chain(flat=True) instead")
+        return self.get_chain(flat=True)
+
+    @property
+    def lnprobability(self):  # pragma: no cover
+        deprecation_warning("lnprobability is deprecated, use get_log_prob() instead")
+        return np.swapaxes(self.get_log_prob(), 0, 1)
+
+    @property
+    def flatlnprobability(self):  # pragma: no cover
+        deprecation_warning("flatlnprobability is deprecated, use get_log_prob(flat=True) instead")
+        return self.get_log_prob(flat=True)
+
+    @property
+    def acor(self):  # pragma: no cover
+        deprecation_warning("acor is deprecated, use get_autocorr_time() instead")
+        return self.get_autocorr_time()
+
+
+class _FunctionWrapper(object):
+    """Bundle ``args`` / ``kwargs`` with the callable so that it pickles for ``pool.map``."""
+
+    def __init__(self, f, args, kwargs):
+        self.f = f
+        self.args = args or []
+        self.kwargs = kwargs or {}
+
+    def __call__(self, x):
+        try:
+            return self.f(x, *self.args, **self.kwargs)
+        except:  # pragma: no cover  # noqa: E722
+            import traceback
+            print("emcee: Exception while calling your likelihood function:")
+            print("  params:", x)
+            print("  args:", self.args)
+            print("  kwargs:", self.kwargs)
+            print("  exception:")
+            traceback.print_exc()
+            raise
+
+
+def walkers_independent(coords):
+    """Initial-state conditioning check (reference ``ensemble.py:653-663``): the scaled, centred
+    walker matrix must have condition number <= 1e8.  One-off host check outside the step loop."""
+    if not np.all(np.isfinite(coords)):
+        return False
+    C = coords - np.mean(coords, axis=0)[None, :]
+    colmax = np.amax(np.abs(C), axis=0)
+    if np.any(colmax == 0):
+        return False
+    C /= colmax
+    C /= np.sqrt(np.sum(C ** 2, axis=0))
+    return np.linalg.cond(C.astype(float)) <= 1e8
+
+
+def ndarray_to_list_of_dicts(x, key_map):
+    """(N, ndim) array -> list of {name: value(s)} dicts (reference ``ensemble.py:685-700``)."""
+    return [{key: xi[val] for key, val in key_map.items()} for xi in x]
+
+
+def _scalar(fx):
+    """Coerce a log-prob return value to a Python float (reference ``ensemble.py:703-713``)."""
+    if not np.isscalar(fx):
+        try:
+            fx = np.asarray(fx).item()
+        except (TypeError, ValueError) as e:
+            raise ValueError("log_prob_fn should return scalar") from e
+    return float(fx)

@@ -1,0 +1,105 @@
+"""Device-resident log-probability targets.
+
+Passing one of these as ``log_prob_fn`` lets :class:`emcee_amd.EnsembleSampler` fuse the
+batched log-prob evaluation (reference ``ensemble.py:458-553``) into the half-step kernel.
+Any other callable still works: proposals and the Metropolis accept stay on the GPU and only
+the callable itself runs on the host (split-phase path).
+
+Calling a target object evaluates it ON THE DEVICE (through ``emx_eval_log_prob``); there is
+no NumPy twin in the product.  The formulas are restated for the parity tests in
+``oracle/sampler_oracle.py`` only.
+"""
+import numpy as np
+
+from . import _lib
+
+__all__ = ["DeviceTarget", "IsoGaussian", "DiagGaussian", "DenseGaussian", "Rosenbrock", "UniformBox"]
+
+
+class DeviceTarget(object):
+    """Base class: subclasses provide ``kind`` and the parameter arrays."""
+
+    kind = _lib.TARGET_HOST
+    ndim = None
+
+    def emx_params(self):
+        """-> (kind, p0, p1, scale) for emx_set_target."""
+        return self.kind, None, None, 0.0
+
+    def bind(self, ens):
+        kind, p0, p1, scale = self.emx_params()
+        ens.set_target(kind, p0, p1, scale)
+
+    def __call__(self, x):
+        from .device import DeviceEnsemble
+        x = np.asarray(x, dtype=np.float64)
+        single = x.ndim == 1
+        rows = np.atleast_2d(x)
+        key = rows.shape[1]
+        cache = self.__dict__.setdefault("_eval_ctx", {})
+        ens = cache.get(key)
+        if ens is None:
+            ens = DeviceEnsemble(max(1024, 2), key)
+            self.bind(ens)
+            cache[key] = ens
+        out = ens.eval_log_prob(rows)
+        return float(out[0]) if single else out
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_eval_ctx", None)
+        return d
+
+
+class IsoGaussian(DeviceTarget):
+    """log p = -0.5 sum(x^2)   (reference tests/integration/test_proposal.py:21-22)."""
+    kind = _lib.TARGET_ISO
+
+
+class DiagGaussian(DeviceTarget):
+    """log p = -0.5 sum(ivar (x - mean)^2)   (reference docs/index.rst:41-45)."""
+    kind = _lib.TARGET_DIAG
+
+    def __init__(self, mean, ivar):
+        self.mean = np.ascontiguousarray(mean, dtype=np.float64)
+        self.ivar = np.ascontiguousarray(ivar, dtype=np.float64)
+        if self.mean.shape != self.ivar.shape or self.mean.ndim != 1:
+            raise ValueError("mean and ivar must be 1-d arrays of equal length")
+        self.ndim = len(self.mean)
+
+    def emx_params(self):
+        return self.kind, self.mean, self.ivar, 0.0
+
+
+class DenseGaussian(DeviceTarget):
+    """log p = -0.5 (x - mean)^T icov (x - mean)   (reference docs/tutorials/quickstart.ipynb:76).
+
+    Evaluated with v_mfma_f64_16x16x4_f64 against an LDS-resident ``icov`` (ndim <= 112)."""
+    kind = _lib.TARGET_DENSE
+
+    def __init__(self, mean, icov):
+        self.mean = np.ascontiguousarray(mean, dtype=np.float64)
+        self.icov = np.ascontiguousarray(icov, dtype=np.float64)
+        n = len(self.mean)
+        if self.icov.shape != (n, n):
+            raise ValueError("icov must be (ndim, ndim)")
+        self.ndim = n
+
+    def emx_params(self):
+        return self.kind, self.mean, self.icov, 0.0
+
+
+class Rosenbrock(DeviceTarget):
+    """log p = -sum_i [100 (x_{i+1} - x_i^2)^2 + (1 - x_i)^2] / scale   (BASELINE config 3)."""
+    kind = _lib.TARGET_ROSENBROCK
+
+    def __init__(self, scale=20.0):
+        self.scale = float(scale)
+
+    def emx_params(self):
+        return self.kind, None, None, self.scale
+
+
+class UniformBox(DeviceTarget):
+    """0 inside [0, 1]^ndim, -inf outside   (reference test_proposal.py:25-28)."""
+    kind = _lib.TARGET_BOX

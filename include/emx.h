@@ -104,12 +104,17 @@ int emx_accepted_counts(emx_ctx* ctx, double* out /* N, backend.accepted */);
 /* Begin a step: choose the move (ensemble.py:406), build the split plan (red_blue.py:76-80 and
  * every draw of the step).  move_out/nsplits_out report the choice. */
 int emx_step_begin(emx_ctx* ctx, int32_t store_this_step, int32_t* move_out, int32_t* nsplits_out);
+/* same, for a move the caller already chose (Move.propose called directly: no choice draw) */
+int emx_step_begin_with(emx_ctx* ctx, int32_t store_this_step, int32_t move_index, int32_t* nsplits_out);
 /* fused half-step on the device target (red_blue.py:81-104 for one split) */
 int emx_halfstep(emx_ctx* ctx, int32_t split);
 /* host-target variant: proposals q (ns, D) in ascending-walker order (red_blue.py:90) ... */
-int emx_propose(emx_ctx* ctx, int32_t split, double* q_out, int64_t* ns_out);
+int emx_propose(emx_ctx* ctx, int32_t split, double* q_out, double* factors_out /* or NULL */, int64_t* ns_out);
 /* ... and Metropolis accept + commit given their log-probs (red_blue.py:96-104) */
 int emx_accept(emx_ctx* ctx, int32_t split, const double* new_log_prob);
+/* user-defined RedBlueMove.get_proposal: q (ns, D) and factors (ns) come from the caller */
+int emx_accept_proposals(emx_ctx* ctx, int32_t split, const double* q, const double* factors,
+                         const double* new_log_prob);
 int emx_step_end(emx_ctx* ctx);
 /* INPUTS mode / tests: set or read back the plan of the step begun (arrays of length N in
  * plan order: split 0's members ascending, then split 1's, ...; off has nsplits+1 entries) */
@@ -150,6 +155,9 @@ int32_t emx_mt_choice_cdf(emx_mt* m, const double* cdf, int32_t n);
 /* one step's exact plan on the host (the producer emx_run uses in MT19937 mode) */
 int emx_host_plan_mt(emx_mt* m, int64_t nwalkers, int32_t ndim, const emx_move_desc* mv, int32_t* off, int32_t* order,
                      int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc);
+/* the draws of ONE RedBlueMove.get_proposal(s, c, random) call for `split` of a given partition */
+int emx_host_split_draws(emx_mt* m, int64_t nwalkers, const emx_move_desc* mv, const int32_t* off,
+                         const int32_t* order, int32_t split, int32_t* p0, int32_t* p1, int32_t* p2, double* s0);
 /* one step's native plan on the host (the function the kernels evaluate in flight) */
 int emx_host_plan_philox(uint64_t seed, uint64_t step, int64_t nwalkers, const emx_move_desc* mv, int32_t* off,
                          int32_t* order, int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc);

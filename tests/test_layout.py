@@ -1,0 +1,55 @@
+"""Boundary hygiene (CPU): the C-ABI library loads and exports every symbol include/emx.h
+declares; the product never touches oracle/ and has no CPU fallback."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "emx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(emx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from emcee_amd import _lib
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) > 45
+    for s in syms:
+        assert hasattr(lib, s), "libemx.so does not export %s" % s
+    # and the ctypes table covers the header (no untyped entry points)
+    assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
+    assert lib.emx_version().startswith(b"emx")
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "emcee_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "/root/reference" in txt.replace(
+                        "/root/reference/src/emcee", ""):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    from emcee_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    import numpy as np
+    import emcee_amd
+    from emcee_amd.device import DeviceEnsemble, EmxError
+    with pytest.raises(EmxError):
+        DeviceEnsemble(32, 2)
+    s = emcee_amd.EnsembleSampler(32, 2, emcee_amd.targets.IsoGaussian())
+    with pytest.raises(EmxError):
+        s.run_mcmc(np.random.RandomState(0).randn(32, 2), 2)
+    s = emcee_amd.EnsembleSampler(32, 2, lambda p: -0.5 * np.sum(p ** 2))
+    with pytest.raises(EmxError):
+        s.run_mcmc(np.random.RandomState(0).randn(32, 2), 2)
