@@ -218,6 +218,18 @@ class Backend(object):
             self.blobs[self.iteration - 1, :] = state_blobs
         self.random_state = random_state
 
+    def __getstate__(self):
+        """Pickling materialises the device chain on the host (contexts are process-local)."""
+        d = dict(self.__dict__)
+        if self._dev is not None:
+            it = self.iteration
+            d["_chain"] = self._dev.chain_read(0, 0, it)
+            d["_log_prob"] = self._dev.chain_read(1, 0, it)
+            d["_accepted"] = self._dev.accepted_counts().astype(self.dtype)
+            d["_iteration"] = it
+            d["_dev"] = None
+        return d
+
     def __enter__(self):
         return self
 
