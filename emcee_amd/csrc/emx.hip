@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -21,7 +22,7 @@ namespace {
 
 std::string g_err;
 
-constexpr int PLAN_RING = 4;
+constexpr int PLAN_RING = 16;
 
 struct HostPlan {  // plan-order arrays of one step
     std::vector<int32_t> off, order, p0, p1, p2;
@@ -179,16 +180,22 @@ struct Shape {
     int G, V, CH;
 };
 
+// Row layout for a row of `Dcover` doubles: G lanes x CH chunks x V doubles, chosen to minimise
+// the instructions per walker (few lanes per walker -> short cross-lane reductions, many walkers per
+// pass) while every chunk of a row is still read as whole 128-byte lines (G*V*8 >= 128 B).
+constexpr int shape_g(int cols) {
+    return cols <= 4 ? 4 : cols <= 32 ? 8 : cols <= 64 ? 16 : cols <= 128 ? 32 : 64;
+}
+constexpr int shape_ch(int cols) {
+    return cols <= 8 ? 1 : cols <= 16 ? 2 : cols <= 256 ? 4 : cols <= 512 ? 8 : 16;
+}
+
 Shape pick_shape(int D, int Dcover) {
     Shape s;
     s.V = (D % 2 == 0) ? 2 : 1;
     const int cols = (Dcover + s.V - 1) / s.V;
-    int G = 4;
-    while (G < cols && G < 64) G <<= 1;
-    int CH = 1;
-    while (G * CH < cols) CH <<= 1;
-    s.G = G;
-    s.CH = CH;
+    s.G = shape_g(cols);
+    s.CH = shape_ch(cols);
     return s;
 }
 
@@ -225,12 +232,19 @@ struct emx_ctx {
     // plan ring (device) + pinned host staging
     struct PlanSlot {
         int32_t *order = nullptr, *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
-        double *s0 = nullptr, *uacc = nullptr;
+        double *s0 = nullptr, *uacc = nullptr, *logu = nullptr, *fac = nullptr;
         char* host = nullptr;  // pinned: [order|p0|p1|p2](int32 N each) [s0|uacc](double N each)
         hipEvent_t consumed = nullptr;
-        bool busy = false;
+        bool busy = false, host_written = false;
     } ring[PLAN_RING];
     int ring_pos = 0;
+    struct Prepared {   // native plans already evaluated on the device, in step order
+        int move, S, slot;
+        uint64_t step;
+        NativeArgs nat;
+    };
+    std::deque<Prepared> prepared;
+    int64_t prep_hint = 1;   // upcoming steps the caller will take (emx_run sets it): batch size of the native prep
     std::vector<int32_t> labels_scratch;
     // current step
     struct Cur {
@@ -253,7 +267,7 @@ struct emx_ctx {
     int64_t sendbuf_rows = 0, gathered_rows = 0;
     bool own_shard_bufs = false;
     // tuning
-    int64_t tune_spw = 0, tune_bpc = 2;
+    int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 8, tune_ablate = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof;
@@ -285,62 +299,82 @@ struct emx_ctx {
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int MOVE, bool DENSE>
-hipError_t launch_halfstep(const Shape& sh, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
-#define EMX_CASE(g, v, c)                                                                             \
-    if (sh.G == g && sh.V == v && sh.CH == c) {                                                        \
-        auto kern = k_halfstep<g, v, c, MOVE, DENSE>;                                                  \
-        if (lds > 48 * 1024) {                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e;                                                             \
-        }                                                                                              \
-        hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                             \
-        return hipGetLastError();                                                                      \
+template <int G, int V, int CH, int MOVE, int DPB>
+hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
+    auto kern = k_halfstep<G, V, CH, MOVE, DPB>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
     }
-    if constexpr (!DENSE) {
-        EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(16, 1, 1) EMX_CASE(32, 1, 1) EMX_CASE(64, 1, 1)
-        EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(16, 2, 1) EMX_CASE(32, 2, 1) EMX_CASE(64, 2, 1)
-        EMX_CASE(64, 1, 2) EMX_CASE(64, 1, 4) EMX_CASE(64, 1, 8)
-        EMX_CASE(64, 2, 2) EMX_CASE(64, 2, 4) EMX_CASE(64, 2, 8)
-        if constexpr (MOVE == MOVE_STRETCH || MOVE == MOVE_EVAL) {
-            EMX_CASE(64, 1, 16) EMX_CASE(64, 2, 16)
-        }
-    } else {
-        EMX_CASE(16, 1, 1) EMX_CASE(32, 1, 1) EMX_CASE(64, 1, 1) EMX_CASE(64, 1, 2)
-        EMX_CASE(8, 2, 1) EMX_CASE(16, 2, 1) EMX_CASE(32, 2, 1) EMX_CASE(64, 2, 1)
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    return hipGetLastError();
+}
+
+template <int MOVE>
+hipError_t launch_valu(const Shape& sh, dim3 grid, dim3 block, hipStream_t st, const HalfStepArgs& a) {
+#define EMX_CASE(g, v, c) \
+    if (sh.G == g && sh.V == v && sh.CH == c) return launch_one<g, v, c, MOVE, 0>(grid, block, 0, st, a);
+    EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4) EMX_CASE(16, 1, 4) EMX_CASE(32, 1, 4)
+    EMX_CASE(64, 1, 4) EMX_CASE(64, 1, 8)
+    EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
+    EMX_CASE(64, 2, 4) EMX_CASE(64, 2, 8)
+    if constexpr (MOVE == MOVE_STRETCH || MOVE == MOVE_EVAL) {
+        EMX_CASE(64, 1, 16) EMX_CASE(64, 2, 16)
     }
 #undef EMX_CASE
     return hipErrorInvalidValue;
 }
 
-hipError_t dispatch_halfstep(int move, bool dense, const Shape& sh, dim3 grid, dim3 block, size_t lds, hipStream_t st,
-                             const HalfStepArgs& a) {
+// dense: the row layout follows from (Dp, V): cols = Dp / V
+constexpr int dense_g(int dpb, int v) { return shape_g(dpb * 16 / v); }
+constexpr int dense_ch(int dpb, int v) { return shape_ch(dpb * 16 / v); }
+
+template <int MOVE>
+hipError_t launch_dense(int dpb, int V, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
+#define EMX_CASE(b, v) \
+    if (dpb == b && V == v) return launch_one<dense_g(b, v), v, dense_ch(b, v), MOVE, b>(grid, block, lds, st, a);
+    EMX_CASE(1, 1) EMX_CASE(2, 1) EMX_CASE(3, 1) EMX_CASE(4, 1) EMX_CASE(5, 1) EMX_CASE(6, 1) EMX_CASE(7, 1)
+    EMX_CASE(1, 2) EMX_CASE(2, 2) EMX_CASE(3, 2) EMX_CASE(4, 2) EMX_CASE(5, 2) EMX_CASE(6, 2) EMX_CASE(7, 2)
+#undef EMX_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t dispatch_halfstep(int move, bool dense, int dpb, const Shape& sh, dim3 grid, dim3 block, size_t lds,
+                             hipStream_t st, const HalfStepArgs& a) {
     switch (move) {
         case MOVE_STRETCH:
-            return dense ? launch_halfstep<MOVE_STRETCH, true>(sh, grid, block, lds, st, a)
-                         : launch_halfstep<MOVE_STRETCH, false>(sh, grid, block, lds, st, a);
+            return dense ? launch_dense<MOVE_STRETCH>(dpb, sh.V, grid, block, lds, st, a)
+                         : launch_valu<MOVE_STRETCH>(sh, grid, block, st, a);
         case MOVE_DE:
-            return dense ? launch_halfstep<MOVE_DE, true>(sh, grid, block, lds, st, a)
-                         : launch_halfstep<MOVE_DE, false>(sh, grid, block, lds, st, a);
+            return dense ? launch_dense<MOVE_DE>(dpb, sh.V, grid, block, lds, st, a) : launch_valu<MOVE_DE>(sh, grid, block, st, a);
         case MOVE_SNOOKER:
-            return dense ? launch_halfstep<MOVE_SNOOKER, true>(sh, grid, block, lds, st, a)
-                         : launch_halfstep<MOVE_SNOOKER, false>(sh, grid, block, lds, st, a);
+            return dense ? launch_dense<MOVE_SNOOKER>(dpb, sh.V, grid, block, lds, st, a)
+                         : launch_valu<MOVE_SNOOKER>(sh, grid, block, st, a);
         case MOVE_EVAL:
-            return dense ? launch_halfstep<MOVE_EVAL, true>(sh, grid, block, lds, st, a)
-                         : launch_halfstep<MOVE_EVAL, false>(sh, grid, block, lds, st, a);
+            return dense ? launch_dense<MOVE_EVAL>(dpb, sh.V, grid, block, lds, st, a) : launch_valu<MOVE_EVAL>(sh, grid, block, st, a);
     }
     return hipErrorInvalidValue;
 }
 
 size_t dense_lds_bytes(int Dp, int waves) {
-    const int RS = Dp + (((Dp >> 4) & 1) ? 0 : 16);
     const int RT = Dp + 2;
-    return ((size_t)Dp * RS + Dp + (size_t)waves * (16 * RT + 32)) * sizeof(double);
+    return ((size_t)Dp * Dp + Dp + (size_t)waves * (16 * RT + 32)) * sizeof(double);
+}
+
+int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
+    const int WPW = 64 / G;
+    const int nr = move == MOVE_STRETCH ? 2 : move == MOVE_DE ? 3 : move == MOVE_SNOOKER ? 4 : 1;
+    int pf = 48 / (nr * CH * V);
+    pf = pf < 1 ? 1 : (pf > 8 ? 8 : pf);
+    int p2 = 1;
+    while (p2 * 2 <= pf) p2 *= 2;
+    if (dense && p2 > 16 / WPW) p2 = 16 / WPW;
+    return p2 < G ? p2 : G;
 }
 
 // launch one fused (or propose-only) half-step over the slots [t_lo, t_hi) of `split`
 int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, int ns, int t_lo, int t_hi, bool native,
-                 const NativeArgs& nat, const emx_move_desc* mv, const emx_ctx::PlanSlot* ps, const int32_t* order,
+                 bool plan_has_logs, const NativeArgs& nat, const emx_move_desc* mv, const emx_ctx::PlanSlot* ps, const int32_t* order,
                  double* X, double* lp, double* chain, double* chain_lp, double* sendbuf) {
     if (t_hi <= t_lo) return 0;
     const bool dense = target == EMX_TARGET_DENSE_GAUSS;
@@ -348,13 +382,9 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     const Shape sh = pick_shape(D, dense ? c->Dp : D);
     const int WPW = 64 / sh.G;
     const int nown = t_hi - t_lo;
-    // slots per wave: enough waves to fill 256 CUs x 16 waves, batches no smaller than one pass
-    int64_t spw = c->tune_spw;
-    if (spw <= 0) {
-        spw = 64;
-        while (spw > WPW && nown / spw < (int64_t)c->num_cu * 16) spw >>= 1;
-        if (spw < WPW) spw = WPW;
-    }
+    const int PF = prefetch_depth_host(sh.G, sh.V, sh.CH, move, dense);
+    // slots per wave: one prefetch batch (PF passes) unless the grid would be tiny or huge
+    int64_t spw = c->tune_spw > 0 ? c->tune_spw : (int64_t)PF * WPW;
     if (dense && spw < 16) spw = 16;
     if (spw > 64) spw = 64;
     spw = (spw / WPW) * WPW;
@@ -362,6 +392,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     int waves_per_block = 4;
     size_t lds = 0;
     if (dense) {
+        waves_per_block = (int)c->tune_wpb;
         while (waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
         lds = dense_lds_bytes(c->Dp, waves_per_block);
         if (lds > 160 * 1024) {
@@ -389,6 +420,9 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.p2 = ps ? ps->p2 : nullptr;
     a.s0 = ps ? ps->s0 : nullptr;
     a.uacc = ps ? ps->uacc : nullptr;
+    a.logu = ps ? ps->logu : nullptr;
+    a.fac = ps ? ps->fac : nullptr;
+    (void)plan_has_logs;
     a.tp0 = c->tp0;
     a.tp1 = c->tp1;
     a.tscale = c->tscale;
@@ -411,6 +445,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.native = native ? 1 : 0;
     a.target = target;
     a.Dp = dense ? c->Dp : 16;
+    a.ablate = (int32_t)c->tune_ablate;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;
     if (prof) {
@@ -418,7 +453,8 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         e1 = c->prof[2 * c->prof_n + 1];
         if (hipEventRecord(e0, c->stream) != hipSuccess) return -2;
     }
-    hipError_t e = dispatch_halfstep(move, dense, sh, dim3((unsigned)nblocks), dim3(64 * waves_per_block), lds, c->stream, a);
+    hipError_t e = dispatch_halfstep(move, dense, c->Dp / 16, sh, dim3((unsigned)nblocks), dim3(64 * waves_per_block), lds,
+                                     c->stream, a);
     if (e != hipSuccess) {
         char b[256];
         snprintf(b, sizeof(b), "half-step launch failed (G=%d V=%d CH=%d move=%d dense=%d ndim=%d): %s", sh.G, sh.V, sh.CH,
@@ -511,9 +547,10 @@ int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
         ALLOC(s.p2, N * 4);
         ALLOC(s.s0, N * 8);
         ALLOC(s.uacc, N * 8);
-        if (hipHostMalloc((void**)&s.host, N * 32, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming) != hipSuccess) {
-            g_err = "pinned plan buffer allocation failed";
+        ALLOC(s.logu, N * 8);
+        ALLOC(s.fac, N * 8);
+        if (hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming) != hipSuccess) {
+            g_err = "plan event creation failed";
             emx_destroy(c);
             return -2;
         }
@@ -555,7 +592,7 @@ int emx_destroy(emx_ctx* c) {
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (auto& s : c->ring) {
-        void* q[] = {s.order, s.p0, s.p1, s.p2, s.s0, s.uacc};
+        void* q[] = {s.order, s.p0, s.p1, s.p2, s.s0, s.uacc, s.logu, s.fac};
         for (void* p : q)
             if (p) hipFree(p);
         if (s.host) hipHostFree(s.host);
@@ -592,6 +629,18 @@ int emx_status(emx_ctx* c, uint32_t* bits) {
 int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "spw")) {
         c->tune_spw = v;
+        return 0;
+    }
+    if (!strcmp(key, "prep_hint")) {   // upcoming steps driven through emx_step_begin: native prep batch size
+        c->prep_hint = v > 0 ? v : 1;
+        return 0;
+    }
+    if (!strcmp(key, "ablate")) {
+        c->tune_ablate = v;
+        return 0;
+    }
+    if (!strcmp(key, "waves_per_block")) {
+        c->tune_wpb = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 8;
         return 0;
     }
     if (!strcmp(key, "blocks_per_cu")) {
@@ -635,13 +684,42 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
         const size_t n1 = kind == EMX_TARGET_DENSE_GAUSS ? D * D : D;
         if (kind == EMX_TARGET_DENSE_GAUSS) {
             c->Dp = (int)((D + 15) / 16 * 16);
-            NEED(c, dense_lds_bytes(c->Dp, 1) <= 160 * 1024,
+            NEED(c, c->Dp <= 112 && dense_lds_bytes(c->Dp, 1) <= 160 * 1024,
                  "dense Gaussian target supports ndim <= 112 (LDS-resident precision matrix); got %d", c->D);
         }
         HIPOK(c, hipMalloc((void**)&c->tp0, D * 8));
-        HIPOK(c, hipMalloc((void**)&c->tp1, n1 * 8));
         HIPOK(c, hipMemcpy(c->tp0, p0, D * 8, hipMemcpyHostToDevice));
-        HIPOK(c, hipMemcpy(c->tp1, p1, n1 * 8, hipMemcpyHostToDevice));
+        if (kind == EMX_TARGET_DENSE_GAUSS) {
+            // -0.5 d^T A d with A = sym(icov) = L L^T  ==  -0.5 |L^T d|^2.  Factor once on the host and upload the
+            // image the kernel stages into LDS: L in MFMA B-fragment order (zero padded) followed by the mean.
+            const int Dp = c->Dp, KK = Dp / 4, n = (int)D;
+            std::vector<double> Lm((size_t)n * n, 0.0);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double sum = 0.5 * (p1[(size_t)i * n + j] + p1[(size_t)j * n + i]);
+                    for (int k = 0; k < j; ++k) sum -= Lm[(size_t)i * n + k] * Lm[(size_t)j * n + k];
+                    if (i == j) {
+                        NEED(c, sum > 0.0 && std::isfinite(sum),
+                             "dense Gaussian target: icov must be symmetric positive definite (Cholesky failed at row %d)", i);
+                        Lm[(size_t)i * n + i] = std::sqrt(sum);
+                    } else {
+                        Lm[(size_t)i * n + j] = sum / Lm[(size_t)j * n + j];
+                    }
+                }
+            std::vector<double> img((size_t)Dp * Dp + Dp, 0.0);
+            for (int nb = 0; nb < Dp / 16; ++nb)
+                for (int kk = 0; kk < KK; ++kk)
+                    for (int l = 0; l < 64; ++l) {
+                        const int k = 4 * kk + (l >> 4), col = 16 * nb + (l & 15);
+                        if (k < n && col < n && k >= col) img[((size_t)nb * KK + kk) * 64 + l] = Lm[(size_t)k * n + col];
+                    }
+            for (int d = 0; d < n; ++d) img[(size_t)Dp * Dp + d] = p0[d];
+            HIPOK(c, hipMalloc((void**)&c->tp1, img.size() * 8));
+            HIPOK(c, hipMemcpy(c->tp1, img.data(), img.size() * 8, hipMemcpyHostToDevice));
+        } else {
+            HIPOK(c, hipMalloc((void**)&c->tp1, n1 * 8));
+            HIPOK(c, hipMemcpy(c->tp1, p1, n1 * 8, hipMemcpyHostToDevice));
+        }
     }
     c->target = kind;
     c->tscale = (kind == EMX_TARGET_ROSENBROCK) ? (scale != 0.0 ? scale : 20.0) : 1.0;
@@ -653,7 +731,7 @@ static int eval_rows(emx_ctx* c, double* X, double* lp, int64_t n) {
     NativeArgs nat{};
     emx_move_desc mv = c->moves[0];
     const int64_t saveN = c->N;
-    int rc = launch_split(c, MOVE_EVAL, c->target, 1, 0, 0, (int)n, 0, (int)n, false, nat, &mv, nullptr, c->iota, X, lp,
+    int rc = launch_split(c, MOVE_EVAL, c->target, 1, 0, 0, (int)n, 0, (int)n, false, false, nat, &mv, nullptr, c->iota, X, lp,
                           nullptr, nullptr, nullptr);
     (void)saveN;
     return rc;
@@ -686,12 +764,14 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
     }
     c->moves.assign(moves, moves + nmoves);
     c->cdf.assign(cdf, cdf + nmoves);
+    c->prepared.clear();
     return 0;
 }
 
 int emx_set_rng_mode(emx_ctx* c, int32_t mode) {
     NEED(c, mode >= 0 && mode <= 2, "unknown rng mode");
     c->rng_mode = mode;
+    c->prepared.clear();
     return 0;
 }
 
@@ -712,6 +792,7 @@ int emx_rng_get_mt19937(emx_ctx* c, uint32_t key[624], int32_t* pos, int32_t* hg
 int emx_rng_set_philox(emx_ctx* c, uint64_t seed, uint64_t step) {
     c->ph_seed = seed;
     c->ph_step = step;
+    c->prepared.clear();
     return 0;
 }
 
@@ -799,16 +880,25 @@ static int upload_plan(emx_ctx* c, emx_ctx::PlanSlot& s) {
     HIPOK(c, hipMemcpyAsync(s.p2, hi + 3 * N, N * 4, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipMemcpyAsync(s.s0, hd, N * 8, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipMemcpyAsync(s.uacc, hd + N, N * 8, hipMemcpyHostToDevice, c->stream));
+    const int stretch = c->cur.move >= 0 && c->moves[c->cur.move].kind == EMX_MOVE_STRETCH;
+    hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (int)N, (int)c->D, stretch,
+                       s.s0, s.uacc, s.logu, s.fac);
+    HIPOK(c, hipGetLastError());
     return 0;
 }
 
-static int acquire_slot(emx_ctx* c, emx_ctx::PlanSlot** out) {
+// Next ring slot.  A slot whose pinned staging buffer the HOST is about to rewrite must first have
+// been consumed by the device (event); device-written plans (native mode) are ordered by the stream.
+static int acquire_slot(emx_ctx* c, emx_ctx::PlanSlot** out, bool host_written) {
     c->ring_pos = (c->ring_pos + 1) % PLAN_RING;
     auto& s = c->ring[c->ring_pos];
-    if (s.busy) {
+    if (s.busy && host_written) {
         HIPOK(c, hipEventSynchronize(s.consumed));
         s.busy = false;
     }
+    if (host_written && !s.host)   // pinned staging is only needed by the host-generated (exact / inputs) plans
+        HIPOK(c, hipHostMalloc((void**)&s.host, (size_t)c->N * 32, hipHostMallocDefault));
+    s.host_written = host_written;
     *out = &s;
     return 0;
 }
@@ -839,7 +929,7 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         NEED(c, c->N >= 2 && (mv.kind != EMX_MOVE_DE || c->N - (c->N + cur.S - 1) / cur.S >= 2),
              "complement too small for this move");
         emx_ctx::PlanSlot* ps;
-        int rc = acquire_slot(c, &ps);
+        int rc = acquire_slot(c, &ps, true);
         if (rc) return rc;
         cur.slot = c->ring_pos;
         cur.off.assign(cur.S + 1, 0);
@@ -852,16 +942,59 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         rc = upload_plan(c, *ps);
         if (rc) return rc;
     } else if (c->rng_mode == EMX_RNG_PHILOX) {
-        cur.move = forced_move >= 0 ? forced_move : philox_move_choice(c->ph_seed, c->ph_step, c->cdf.data(), nm);
-        const emx_move_desc& mv = c->moves[cur.move];
-        cur.S = mv.nsplits;
+        if (forced_move >= 0) c->prepared.clear();
+        if (!c->prepared.empty() && c->prepared.front().step != c->ph_step) c->prepared.clear();
+        if (c->prepared.empty()) {
+            // evaluate the plans of the next nb steps (both splits each) in one full-width launch
+            int64_t nbw = forced_move >= 0 ? 1 : c->prep_hint;
+            const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(nbw, NATIVE_BATCH_MAX));
+            NativeBatchArgs B{};
+            B.N = (int32_t)c->N;
+            B.D = c->D;
+            B.nb = nb;
+            for (int b = 0; b < nb; ++b) {
+                const uint64_t step = c->ph_step + (uint64_t)b;
+                const int mi = forced_move >= 0 ? forced_move : philox_move_choice(c->ph_seed, step, c->cdf.data(), nm);
+                const emx_move_desc& m = c->moves[mi];
+                emx_ctx::PlanSlot* ps;
+                int rc = acquire_slot(c, &ps, false);
+                if (rc) return rc;
+                emx_ctx::Prepared pr{};
+                pr.move = mi;
+                pr.S = m.nsplits;
+                pr.slot = c->ring_pos;
+                pr.step = step;
+                pr.nat.seed = c->ph_seed;
+                pr.nat.step = step;
+                pr.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, step);
+                c->prepared.push_back(pr);
+                B.nat[b] = pr.nat;
+                B.order[b] = ps->order;
+                B.p0[b] = ps->p0;
+                B.p1[b] = ps->p1;
+                B.p2[b] = ps->p2;
+                B.s0[b] = ps->s0;
+                B.uacc[b] = ps->uacc;
+                B.logu[b] = ps->logu;
+                B.fac[b] = ps->fac;
+                B.a[b] = m.a;
+                B.sigma[b] = m.sigma;
+                B.g0[b] = m.g0;
+                B.move[b] = m.kind;
+                B.S[b] = m.nsplits;
+            }
+            hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), (unsigned)nb), dim3(256), 0, c->stream, B);
+            HIPOK(c, hipGetLastError());
+        }
+        const emx_ctx::Prepared pr = c->prepared.front();
+        c->prepared.pop_front();
+        cur.move = pr.move;
+        cur.S = pr.S;
         cur.native = true;
-        cur.nat.seed = c->ph_seed;
-        cur.nat.step = c->ph_step;
-        cur.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, c->ph_step);
+        cur.nat = pr.nat;
+        cur.slot = pr.slot;
         cur.off.assign(cur.S + 1, 0);
         for (int s = 0; s < cur.S; ++s) cur.off[s + 1] = cur.off[s] + (int32_t)((c->N - s + cur.S - 1) / cur.S);
-        cur.slot = -1;
     } else {
         // INPUTS: emx_plan_set must follow
         cur.move = -1;
@@ -885,7 +1018,7 @@ int emx_plan_set(emx_ctx* c, int32_t move_index, const int32_t* off, const int32
     cur.off.assign(off, off + cur.S + 1);
     NEED(c, cur.off[0] == 0 && cur.off[cur.S] == c->N, "plan offsets must cover all walkers");
     emx_ctx::PlanSlot* ps;
-    int rc = acquire_slot(c, &ps);
+    int rc = acquire_slot(c, &ps, true);
     if (rc) return rc;
     cur.slot = c->ring_pos;
     const size_t N = (size_t)c->N;
@@ -907,28 +1040,9 @@ int emx_plan_get(emx_ctx* c, int32_t* off, int32_t* order, int32_t* p0, int32_t*
     const size_t N = (size_t)c->N;
     memcpy(off, cur.off.data(), (cur.S + 1) * 4);
     if (cur.native) {
-        // let the device evaluate the native plan (the same function the half-step kernels inline)
-        auto& ps = c->ring[0];
-        if (ps.busy) {
-            HIPOK(c, hipEventSynchronize(ps.consumed));
-            ps.busy = false;
-        }
-        const emx_move_desc& mv = c->moves[cur.move];
-        dim3 g((unsigned)((N + 255) / 256)), b(256);
-        switch (mv.kind) {
-            case EMX_MOVE_STRETCH:
-                hipLaunchKernelGGL(k_native_plan<MOVE_STRETCH>, g, b, 0, c->stream, cur.nat, (int)N, cur.S, mv.a, mv.sigma,
-                                   mv.g0, ps.order, ps.p0, ps.p1, ps.p2, ps.s0, ps.uacc);
-                break;
-            case EMX_MOVE_DE:
-                hipLaunchKernelGGL(k_native_plan<MOVE_DE>, g, b, 0, c->stream, cur.nat, (int)N, cur.S, mv.a, mv.sigma,
-                                   mv.g0, ps.order, ps.p0, ps.p1, ps.p2, ps.s0, ps.uacc);
-                break;
-            default:
-                hipLaunchKernelGGL(k_native_plan<MOVE_SNOOKER>, g, b, 0, c->stream, cur.nat, (int)N, cur.S, mv.a, mv.sigma,
-                                   mv.g0, ps.order, ps.p0, ps.p1, ps.p2, ps.s0, ps.uacc);
-        }
-        HIPOK(c, hipGetLastError());
+        // the plan was evaluated on the device by k_native_plan at emx_step_begin
+        NEED(c, cur.slot >= 0, "no plan available");
+        auto& ps = c->ring[cur.slot];
         HIPOK(c, hipMemcpyAsync(order, ps.order, N * 4, hipMemcpyDeviceToHost, c->stream));
         HIPOK(c, hipMemcpyAsync(p0, ps.p0, N * 4, hipMemcpyDeviceToHost, c->stream));
         HIPOK(c, hipMemcpyAsync(p1, ps.p1, N * 4, hipMemcpyDeviceToHost, c->stream));
@@ -967,7 +1081,7 @@ static int do_halfstep(emx_ctx* c, int split, int target) {
     emx_ctx::PlanSlot* ps = cur.slot >= 0 ? &c->ring[cur.slot] : nullptr;
     double* sb = nullptr;
     if (c->sendbuf && target != EMX_TARGET_HOST) sb = c->sendbuf;
-    return launch_split(c, mv.kind, target, cur.S, split, pos0, ns, (int)lo, (int)hi, cur.native, cur.nat, &mv, ps,
+    return launch_split(c, mv.kind, target, cur.S, split, pos0, ns, (int)lo, (int)hi, false, cur.native, cur.nat, &mv, ps,
                         nullptr, c->X, c->lp, chain, chain_lp, sb);
 }
 
@@ -1022,7 +1136,7 @@ int emx_accept(emx_ctx* c, int32_t split, const double* new_lp) {
     a.split = split;
     a.pos0 = pos0;
     a.ns = ns;
-    a.native = cur.native ? 1 : 0;
+    a.native = 0;   // order / uacc come from the plan slot in every mode
     a.move = c->moves[cur.move].kind;
     hipLaunchKernelGGL(k_accept, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, c->stream, a);
     HIPOK(c, hipGetLastError());
@@ -1046,8 +1160,10 @@ int emx_step_end(emx_ctx* c) {
     NEED(c, cur.active, "emx_step_end without emx_step_begin");
     if (cur.slot >= 0) {
         auto& s = c->ring[cur.slot];
-        HIPOK(c, hipEventRecord(s.consumed, c->stream));
-        s.busy = true;
+        if (s.host_written) {
+            HIPOK(c, hipEventRecord(s.consumed, c->stream));
+            s.busy = true;
+        }
     }
     if (cur.store) c->stored++;
     c->proposals++;
@@ -1068,6 +1184,7 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
         for (int k = 0; k < thin_by; ++k, ++i) {
             const int st = store && ((i + 1) % thin_by == 0);                   // ensemble.py:416
             int mvi, S;
+            c->prep_hint = nsteps * thin_by - i;
             int rc = emx_step_begin(c, st, &mvi, &S);
             if (rc) return rc;
             for (int s = 0; s < S; ++s) {
@@ -1080,6 +1197,7 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
             rc = emx_step_end(c);
             if (rc) return rc;
         }
+    c->prep_hint = 1;
     return 0;
 }
 
@@ -1180,7 +1298,7 @@ int emx_scatter_gathered(emx_ctx* c, int32_t split) {
         a.pos0 = cur.off[split];
         a.t_lo = (int32_t)lo;
         a.t_hi = (int32_t)hi;
-        a.native = cur.native ? 1 : 0;
+        a.native = 0;
         hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256), 0, c->stream, a);
         HIPOK(c, hipGetLastError());
     }

@@ -59,6 +59,8 @@ struct HalfStepArgs {
     const int32_t* p2;
     const double* s0;
     const double* uacc;
+    const double* logu;   // optional: log(uacc) precomputed by k_native_plan
+    const double* fac;    // optional: (D-1) ln zz precomputed by k_native_plan
     // target
     const double* tp0;    // mu  (diag, dense)
     const double* tp1;    // ivar (diag) | icov (dense, (D, D) row-major)
@@ -75,16 +77,56 @@ struct HalfStepArgs {
     int32_t native;       // 1: derive the plan from Philox in flight
     int32_t target;
     int32_t Dp;           // dense: D rounded up to 16
+    int32_t ablate;       // timing experiments only (tools/ablate.py): skip-phase bit mask, 0 in production
 };
 
 // ----------------------------------------------------------------------------------------
 // group helpers
 // ----------------------------------------------------------------------------------------
+// Cross-lane sums without the LDS crossbar: DPP row operations inside a 16-lane row, then the
+// gfx950 v_permlane16_swap / v_permlane32_swap pair sums.  Every lane of the (aligned, contiguous)
+// G-lane group ends up with the group total.  Must be called from wave-uniform control flow.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double sum_swap16(double x) {   // x[l] + x[l ^ 16]
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+__device__ __forceinline__ double sum_swap32(double x) {   // x[l] + x[l ^ 32]
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 template <int G>
 __device__ __forceinline__ double group_sum(double x) {
-#pragma unroll
-    for (int m = G >> 1; m > 0; m >>= 1) x += __shfl_xor(x, m, 64);
+    if constexpr (G >= 2) x += dpp_f64<0xB1>(x);    // quad_perm [1,0,3,2]  : l ^ 1
+    if constexpr (G >= 4) x += dpp_f64<0x4E>(x);    // quad_perm [2,3,0,1]  : l ^ 2
+    if constexpr (G >= 8) x += dpp_f64<0x141>(x);   // row_half_mirror      : other quad of the 8
+    if constexpr (G >= 16) x += dpp_f64<0x140>(x);  // row_mirror           : other half of the row
+    if constexpr (G >= 32) x = sum_swap16(x);
+    if constexpr (G >= 64) x = sum_swap32(x);
     return x;
+}
+
+// any-lane-in-group predicate from one ballot (no data movement)
+template <int G>
+__device__ __forceinline__ bool group_any(bool pred, int sub) {
+    const unsigned long long m = __ballot(pred);
+    if constexpr (G == 64) {
+        return m != 0ull;
+    } else {
+        return ((m >> (sub * G)) & ((1ull << G) - 1ull)) != 0ull;
+    }
 }
 
 __device__ __forceinline__ int set_size(int N, int S, int j) { return (N - j + S - 1) / S; }
@@ -242,8 +284,9 @@ __device__ __forceinline__ void store_row(const Row<G, V, CH>& r, double* __rest
 // ----------------------------------------------------------------------------------------
 template <int G, int V, int CH>
 __device__ __forceinline__ double eval_valu_target(const Row<G, V, CH>& q, const Row<G, V, CH>& mu,
-                                                   const Row<G, V, CH>& iv, int target, double tscale, int D, int gl,
-                                                   int lane) {
+                                                   const Row<G, V, CH>& iv, const double* __restrict__ tp0,
+                                                   const double* __restrict__ tp1, int target, double tscale, int D,
+                                                   int gl, int lane) {
     double acc = 0.0;
     if (target == TGT_ISO) {
 #pragma unroll
@@ -253,23 +296,44 @@ __device__ __forceinline__ double eval_valu_target(const Row<G, V, CH>& q, const
         return -0.5 * group_sum<G>(acc);
     }
     if (target == TGT_DIAG) {
+        if constexpr (CH <= 4) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
+            for (int c = 0; c < CH; ++c)
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const double d = q.x[c][v] - mu.x[c][v];
-                acc = fma(iv.x[c][v] * d, d, acc);
+                for (int v = 0; v < V; ++v) {
+                    const double d = q.x[c][v] - mu.x[c][v];
+                    acc = fma(iv.x[c][v] * d, d, acc);
+                }
+        } else {
+            // wide rows: stream (mu, ivar) from L1/L2 chunk by chunk instead of pinning 4*CH*V registers
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int d0 = (c * G + gl) * V;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int dd = d0 + v;
+                    const double m = dd < D ? tp0[dd] : 0.0;
+                    const double w = dd < D ? tp1[dd] : 0.0;
+                    const double d = q.x[c][v] - m;
+                    acc = fma(w * d, d, acc);
+                }
             }
+        }
         return -0.5 * group_sum<G>(acc);
     }
     if (target == TGT_ROSEN) {
         // sum_{d < D-1} 100 (x_{d+1} - x_d^2)^2 + (1 - x_d)^2   
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            // first element of the next lane / next chunk
-            const double nxt_lane = __shfl(q.x[c][0], lane + 1, 64);
-            double nxt_chunk = 0.0;
-            if (c + 1 < CH) nxt_chunk = __shfl(q.x[c + 1 < CH ? c + 1 : c][0], lane - gl, 64);
+            // first element of the next lane / of the next chunk (held by the group's first lane)
+            double nxt_lane, nxt_chunk = 0.0;
+            if constexpr (G <= 16) {
+                nxt_lane = dpp_f64<0x101>(q.x[c][0]);                                   // row_shl:1  -> lane + 1
+                if (c + 1 < CH) nxt_chunk = dpp_f64<0x110 + (G - 1)>(q.x[c + 1 < CH ? c + 1 : c][0]);   // row_shr:G-1 -> lane - (G-1)
+            } else {
+                nxt_lane = __shfl(q.x[c][0], lane + 1, 64);
+                if (c + 1 < CH) nxt_chunk = __shfl(q.x[c + 1 < CH ? c + 1 : c][0], lane - gl, 64);
+            }
             const double nxt = (gl == G - 1) ? nxt_chunk : nxt_lane;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
@@ -302,8 +366,11 @@ __device__ __forceinline__ double eval_valu_target(const Row<G, V, CH>& q, const
 
 // ----------------------------------------------------------------------------------------
 // The half-step kernel.
-//   G lanes per walker row, V doubles per lane per chunk, CH chunks, MOVE, DENSE target.
-// Dynamic LDS (DENSE only): Sinv[Dp][Dp+16] | mu[Dp] | per wave: tile[16][Dp+2], qf[16], fac[16]
+//   G lanes per walker row, V doubles per lane per chunk, CH chunks, MOVE,
+//   DPB = Dp/16 for the dense-Gaussian (MFMA) target, 0 for element-wise targets.
+// A wave prefetches the rows of PF passes (PF * 64/G walkers) before touching any of them, so a
+// batch costs one memory round trip instead of PF.
+// Dynamic LDS (dense only): Sfrag[Dp*Dp] (MFMA B-fragment order) | mu[Dp] | per wave: tile[16][Dp+2], qf[16], fac[16]
 // ----------------------------------------------------------------------------------------
 #define EMX_WAVE_SYNC()                                        \
     do {                                                       \
@@ -312,44 +379,138 @@ __device__ __forceinline__ double eval_valu_target(const Row<G, V, CH>& q, const
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-template <int G, int V, int CH, int MOVE, bool DENSE>
-__global__ __launch_bounds__(256) void k_halfstep(const HalfStepArgs A) {
+template <int MOVE>
+constexpr int rows_per_pass() {
+    return MOVE == MOVE_STRETCH ? 2 : MOVE == MOVE_DE ? 3 : MOVE == MOVE_SNOOKER ? 4 : 1;
+}
+
+template <int G, int V, int CH, int MOVE, int DPB>
+constexpr int prefetch_depth() {
+    constexpr int WPW = 64 / G;
+    int pf = 48 / (rows_per_pass<MOVE>() * CH * V);        // <= 48 doubles of rows in flight per lane
+    pf = pf < 1 ? 1 : (pf > 8 ? 8 : pf);
+    int p2 = 1;
+    while (p2 * 2 <= pf) p2 *= 2;
+    if (DPB > 0 && p2 > 16 / WPW) p2 = 16 / WPW;           // dense: a batch never spans two 16-row MFMA tiles
+    return p2 < G ? p2 : G;                                // at most 64 slots per batch
+}
+
+// proposal from the prefetched rows; rounding order as in stretch.py:33 / de.py:53-62 / de_snooker.py:41-46
+template <int G, int V, int CH, int MOVE>
+__device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row<G, V, CH>& xa,
+                                              const Row<G, V, CH>& xb, const Row<G, V, CH>& xc, double s0,
+                                              double gammas, int D, int gl, Row<G, V, CH>& q, double& factor) {
+    if constexpr (MOVE == MOVE_STRETCH) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double diff = xa.x[c][v] - xi.x[c][v];   // c[rint] - s
+                const double prod = diff * s0;                  // ... * zz
+                q.x[c][v] = xa.x[c][v] - prod;                  // c[rint] - (...)
+            }
+    } else if constexpr (MOVE == MOVE_DE) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double diff = xb.x[c][v] - xa.x[c][v];   // c[pair[1]] - c[pair[0]]
+                const double prod = s0 * diff;                  // gamma * diffs
+                q.x[c][v] = xi.x[c][v] + prod;                  // s + ...
+            }
+    } else if constexpr (MOVE == MOVE_SNOOKER) {
+        // xa = z, xb = z1, xc = z2
+        double n2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double dl = xi.x[c][v] - xa.x[c][v];     // delta = s[i] - z
+                n2 = fma(dl, dl, n2);
+            }
+        const double norm = sqrt(group_sum<G>(n2));
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double u = (xi.x[c][v] - xa.x[c][v]) / norm;
+                d1 = fma(u, xb.x[c][v], d1);
+                d2 = fma(u, xc.x[c][v], d2);
+            }
+        d1 = group_sum<G>(d1);
+        d2 = group_sum<G>(d2);
+        const double dd = d1 - d2;
+        double m2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const double u = (xi.x[c][v] - xa.x[c][v]) / norm;
+                const double ug = u * gammas;                   // u * gammas
+                const double prod = ug * dd;                    // * (dot(u,z1) - dot(u,z2))
+                const int d = (c * G + gl) * V + v;
+                q.x[c][v] = d < D ? xi.x[c][v] + prod : 0.0;
+                const double e = q.x[c][v] - xa.x[c][v];
+                m2 = fma(e, e, m2);
+            }
+        const double nq = sqrt(group_sum<G>(m2));
+        factor = ((double)D - 1.0) * (log(nq) - log(norm));
+    } else {
+        q = xi;
+    }
+}
+
+template <int G, int V, int CH, int MOVE, int DPB>
+__global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     static_assert(G >= 4 && G <= 64 && (64 % G) == 0, "G lanes per walker");
+    constexpr bool DENSE = DPB > 0;
     constexpr int WPW = 64 / G;       // walkers per pass (<= 16)
     constexpr int PPT = 16 / WPW;     // passes per 16-row dense tile
+    constexpr int PF = prefetch_depth<G, V, CH, MOVE, DPB>();
+    constexpr int NR = rows_per_pass<MOVE>();
+    constexpr int Dp = DPB * 16;      // dense: padded dimension
+    constexpr int KK = Dp / 4;        // MFMA k-steps
+    constexpr int RT = Dp + 2;        // tile row stride (doubles): conflict-free A-fragment reads
+    static_assert(!DENSE || G * V * CH >= Dp, "row layout must cover the padded dimension");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int sub = lane / G;
     const int gl = lane % G;
     const int D = A.D;
-    const int Dp = A.Dp;
-    const int RS = Dp + (((Dp >> 4) & 1) ? 0 : 16);   // Sinv row stride == 16 (mod 32): conflict-free B reads
-    const int RT = Dp + 2;    // tile row stride: conflict-free A-fragment reads
 
-    double* Sinv = smem;
-    double* muS = smem + (size_t)Dp * RS;
+    double* Sfrag = smem;
+    double* muS = smem + (size_t)Dp * Dp;
     double* tile = muS + Dp + (size_t)wib * (16 * RT + 32);
     double* qfS = tile + 16 * RT;
     double* facS = qfS + 16;
 
-    if constexpr (DENSE) {
-        // stage the precision matrix (zero padded) and the mean once per workgroup
-        for (int e = threadIdx.x; e < Dp * Dp; e += blockDim.x) {
-            const int r = e / Dp, c = e - r * Dp;
-            Sinv[r * RS + c] = (r < D && c < D) ? A.tp1[(size_t)r * D + c] : 0.0;
-        }
-        for (int e = threadIdx.x; e < Dp; e += blockDim.x) muS[e] = e < D ? A.tp0[e] : 0.0;
-        __syncthreads();
-    }
+    // Dense target: A.tp1 holds the image the MFMA stage wants in LDS -- the Cholesky factor L of the
+    // precision matrix (icov = L L^T) in B-fragment order, zero padded, followed by the padded mean:
+    //   img[(nb*KK + kk)*64 + l] = L[k = 4 kk + (l >> 4)][n = 16 nb + (l & 15)],  img[Dp*Dp + d] = mu[d]
+    // (built once by emx_set_target).  Its global loads are issued first and written to LDS only after
+    // the first batch's row loads are in flight; one workgroup barrier precedes the first MFMA stage.
+    constexpr int IMG2 = (Dp * Dp + Dp) / 2;                // image size in double2
+    bool stage_pending = DENSE;
+    // copy the image global -> LDS; called once per wave, right after its first batch of row loads has
+    // been issued, so that both latencies overlap (no long-lived staging registers)
+#define EMX_STAGE_COPY()                                                              \
+    do {                                                                              \
+        if constexpr (DENSE) {                                                        \
+            const double2* img_ = reinterpret_cast<const double2*>(A.tp1);            \
+            double2* dst_ = reinterpret_cast<double2*>(smem);                         \
+            for (int e_ = threadIdx.x; e_ < IMG2; e_ += blockDim.x) dst_[e_] = img_[e_]; \
+        }                                                                             \
+    } while (0)
 
-    // per-lane target parameters (diag Gaussian): same columns for every walker of the wave
+    // per-lane diag-Gaussian parameters (narrow rows): same columns for every walker of the wave
     Row<G, V, CH> mu, iv;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int v = 0; v < V; ++v) mu.x[c][v] = iv.x[c][v] = 0.0;
-    if (!DENSE && A.target == TGT_DIAG) {
+    if (!DENSE && CH <= 4 && A.target == TGT_DIAG) {
         load_row<G, V, CH>(mu, A.tp0, D, gl);
         load_row<G, V, CH>(iv, A.tp1, D, gl);
     }
@@ -357,274 +518,263 @@ __global__ __launch_bounds__(256) void k_halfstep(const HalfStepArgs A) {
     const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int spw = A.spw;
-    for (int t0 = A.t_lo + wave * spw; t0 < A.t_hi; t0 += nwaves * spw) {   // wave-uniform batch loop
-    const int nslot = min(spw, A.t_hi - t0);
-
-    // ---------------- phase A: lane l <-> slot t0 + l ----------------
-    Slot sl;
-    {
-        const bool valid = lane < nslot;
-        const int t = t0 + (valid ? lane : 0);
-        double uacc;
-        if (A.native) {
-            native_slot<MOVE>(A.nat, A.N, A.S, A.split, t, A.a, A.sigma, A.g0, sl.i, sl.p0, sl.p1, sl.p2, sl.s0, uacc);
-        } else {
-            const int pos = A.pos0 + t;
-            sl.i = A.order[pos];
-            sl.p0 = (MOVE == MOVE_EVAL) ? sl.i : A.p0[pos];
-            sl.p1 = (MOVE == MOVE_DE || MOVE == MOVE_SNOOKER) ? A.p1[pos] : sl.i;
-            sl.p2 = (MOVE == MOVE_SNOOKER) ? A.p2[pos] : sl.i;
-            sl.s0 = (MOVE == MOVE_STRETCH || MOVE == MOVE_DE) ? A.s0[pos] : 1.0;
-            uacc = (MOVE == MOVE_EVAL) ? 0.5 : A.uacc[pos];
+    if (A.t_lo + wave * spw >= A.t_hi) {      // idle wave: still owes its share of the staging and the barrier
+        if constexpr (DENSE) {
+            EMX_STAGE_COPY();
+            __syncthreads();
         }
-        sl.logu = log(uacc);
-        sl.lp_old = (MOVE == MOVE_EVAL) ? 0.0 : A.lp[sl.i];
-        sl.factor = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(sl.s0) : 0.0;   // stretch.py:31
+        return;
     }
+    for (int t0 = A.t_lo + wave * spw; t0 < A.t_hi; t0 += nwaves * spw) {   // wave-uniform batch loop
+        const int nslot = min(spw, A.t_hi - t0);
+        const int npass = (nslot + WPW - 1) / WPW;
+        const int pbase = A.pos0 + t0;          // plan position of the wave's first slot
 
-    const int npass = (nslot + WPW - 1) / WPW;
-
-    for (int p = 0; p < npass; ++p) {
-        const int srow = p * WPW + sub;             // slot (= phase-A lane) handled by this group
-        const bool live = srow < nslot;
-        const int src = live ? srow : 0;
-        const int i = __shfl(sl.i, src, 64);
-        const int j0 = __shfl(sl.p0, src, 64);
-        const double s0 = __shfl(sl.s0, src, 64);
-        double factor = __shfl(sl.factor, src, 64);
-        const double lp_old = __shfl(sl.lp_old, src, 64);
-        const double logu = __shfl(sl.logu, src, 64);
-
-        Row<G, V, CH> xi, q;
-        load_row<G, V, CH>(xi, A.X + (size_t)i * D, D, gl);
-
-        if constexpr (MOVE == MOVE_STRETCH) {
-            Row<G, V, CH> xj;
-            load_row<G, V, CH>(xj, A.X + (size_t)j0 * D, D, gl);
+        for (int pb = 0; pb < npass; pb += PF) {
+            // -------- plan entries of the batch: every lane of a group reads its walker's entry
+            //          (same address across the group: one request, broadcast) --------
+            int wi[PF], ja[PF], jb[NR >= 3 ? PF : 1], jc[NR >= 4 ? PF : 1];
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const double diff = xj.x[c][v] - xi.x[c][v];   // c[rint] - s
-                    const double prod = diff * s0;                  // ... * zz
-                    q.x[c][v] = xj.x[c][v] - prod;                  // c[rint] - (...)   (stretch.py:33)
-                }
-        } else if constexpr (MOVE == MOVE_DE) {
-            const int j1 = __shfl(sl.p1, src, 64);
-            Row<G, V, CH> x1, x2;
-            load_row<G, V, CH>(x1, A.X + (size_t)j0 * D, D, gl);   // pair[0]
-            load_row<G, V, CH>(x2, A.X + (size_t)j1 * D, D, gl);   // pair[1]
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const double diff = x2.x[c][v] - x1.x[c][v];   // np.diff(c[pairs], axis=1)  (de.py:53)
-                    const double prod = s0 * diff;                  // gamma * diffs
-                    q.x[c][v] = xi.x[c][v] + prod;                  // s + ...               (de.py:62)
-                }
-        } else if constexpr (MOVE == MOVE_SNOOKER) {
-            const int j1 = __shfl(sl.p1, src, 64);
-            const int j2 = __shfl(sl.p2, src, 64);
-            Row<G, V, CH> z, z1, z2;
-            load_row<G, V, CH>(z, A.X + (size_t)j0 * D, D, gl);
-            load_row<G, V, CH>(z1, A.X + (size_t)j1 * D, D, gl);
-            load_row<G, V, CH>(z2, A.X + (size_t)j2 * D, D, gl);
-            double n2 = 0.0;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const double dl = xi.x[c][v] - z.x[c][v];       // delta = s[i] - z   (de_snooker.py:41)
-                    n2 = fma(dl, dl, n2);
-                }
-            const double norm = sqrt(group_sum<G>(n2));
-            double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const double u = (xi.x[c][v] - z.x[c][v]) / norm;
-                    d1 = fma(u, z1.x[c][v], d1);
-                    d2 = fma(u, z2.x[c][v], d2);
-                }
-            d1 = group_sum<G>(d1);
-            d2 = group_sum<G>(d2);
-            const double dd = d1 - d2;
-            double m2 = 0.0;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const double u = (xi.x[c][v] - z.x[c][v]) / norm;
-                    const double ug = u * A.gammas;                 // u * gammas
-                    const double prod = ug * dd;                    // * (dot(u,z1) - dot(u,z2))
-                    const int d = (c * G + gl) * V + v;
-                    q.x[c][v] = d < D ? xi.x[c][v] + prod : 0.0;    // (de_snooker.py:44)
-                    const double e = q.x[c][v] - z.x[c][v];
-                    m2 = fma(e, e, m2);
-                }
-            const double nq = sqrt(group_sum<G>(m2));
-            factor = ((double)D - 1.0) * (log(nq) - log(norm));     // (de_snooker.py:45-46)
-        } else {  // MOVE_EVAL
-            q = xi;
-        }
-
-        // non-finite proposal -> sticky error (ensemble.py:476-479); the proposal is rejected
-        bool badq = false;
-        if constexpr (MOVE != MOVE_EVAL) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int v = 0; v < V; ++v) badq |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
-            badq = group_sum<G>(badq ? 1.0 : 0.0) > 0.0;
-            if (live && badq && gl == 0) atomicOr(A.status, ST_BAD_COORD);
-        }
-
-        if (A.target == TGT_NONE) {
-            // split-phase: hand the proposal to the host log-prob (red_blue.py:90-93)
-            if (live) {
-                const int t = t0 + srow;
-                store_row<G, V, CH>(q, A.qout + (size_t)t * D, D, gl);
-                if (gl == 0) A.fout[t] = factor;
+            for (int k = 0; k < PF; ++k) {
+                const int srow = (pb + k) * WPW + sub;
+                const int pos = pbase + (srow < nslot ? srow : 0);
+                wi[k] = A.order[pos];
+                if constexpr (NR >= 2) ja[k] = A.p0[pos];
+                if constexpr (NR >= 3) jb[k] = A.p1[pos];
+                if constexpr (NR >= 4) jc[k] = A.p2[pos];
             }
-            continue;
-        }
-
-        if constexpr (!DENSE) {
-            const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.target, A.tscale, D, gl, lane);
-            if (live && gl == 0 && (lp_new != lp_new)) atomicOr(A.status, ST_NAN_LOGP);   // ensemble.py:550-551
-            if constexpr (MOVE == MOVE_EVAL) {
-                if (live && gl == 0) A.lp[i] = lp_new;
-            } else {
-                const double lnpdiff = factor + lp_new - lp_old;                  // red_blue.py:99
-                const bool accept = live && !badq && (lnpdiff > logu);            // red_blue.py:100
-                if (accept) {
-                    store_row<G, V, CH>(q, A.X + (size_t)i * D, D, gl);          // move.py:33
-                    if (gl == 0) A.lp[i] = lp_new;                                // move.py:34
-                }
-                if (live && gl == 0) {
-                    A.acc[i] = accept ? 1 : 0;
-                    if (A.chain_lp) {
-                        A.chain_lp[i] = accept ? lp_new : lp_old;
-                        if (accept) A.acc_count[i] += 1u;
+            // -------- issue every row load of the batch (+ the per-walker scalars) --------
+            Row<G, V, CH> xi[PF], xa[NR >= 2 ? PF : 1], xb[NR >= 3 ? PF : 1], xc[NR >= 4 ? PF : 1];
+            double s0v[PF], facv[PF], lpov[PF], loguv[PF];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int srow = (pb + k) * WPW + sub;
+                const int pos = pbase + (srow < nslot ? srow : 0);
+                if (!(A.ablate & 32)) load_row<G, V, CH>(xi[k], A.X + (size_t)wi[k] * D, D, gl);
+                if constexpr (NR >= 2) if (!(A.ablate & 32)) load_row<G, V, CH>(xa[k], A.X + (size_t)ja[k] * D, D, gl);
+                if constexpr (NR >= 3) load_row<G, V, CH>(xb[k], A.X + (size_t)jb[k] * D, D, gl);
+                if constexpr (NR >= 4) load_row<G, V, CH>(xc[k], A.X + (size_t)jc[k] * D, D, gl);
+                if constexpr (MOVE != MOVE_EVAL) {
+                    s0v[k] = (MOVE == MOVE_SNOOKER) ? 0.0 : A.s0[pos];
+                    facv[k] = A.fac[pos];
+                    if (!DENSE || A.target == TGT_NONE) {
+                        lpov[k] = A.lp[wi[k]];
+                        loguv[k] = A.logu[pos];
+                    } else {
+                        lpov[k] = 0.0;
+                        loguv[k] = 0.0;
                     }
-                }
-                if (live && A.chain) store_row<G, V, CH>(accept ? q : xi, A.chain + (size_t)i * D, D, gl);
-                if (live && A.sendbuf) {
-                    double* sb = A.sendbuf + (size_t)(t0 + srow - A.t_lo) * (D + 2);
-                    store_row<G, V, CH>(accept ? q : xi, sb, D, gl);
-                    if (gl == 0) {
-                        sb[D] = accept ? lp_new : lp_old;
-                        sb[D + 1] = accept ? 1.0 : 0.0;
-                    }
-                }
-            }
-        } else {
-            // ---- stage q into the wave's LDS tile; every PPT passes (16 rows) contract with Sinv ----
-            const int trow = srow & 15;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    const int d = (c * G + gl) * V + v;
-                    if (d < Dp) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] : muS[d];   // dead rows: zero residual
-                }
-            if (gl == 0) facS[trow] = badq ? -__builtin_inf() : factor;
-            const bool tile_done = ((p + 1) % PPT == 0) || (p + 1 == npass);
-            if (!tile_done) continue;
-            EMX_WAVE_SYNC();
-            {
-                // Y = (Q - mu) Sinv  (16 x Dp) by v_mfma_f64_16x16x4_f64; qf[w] = sum_n Y[w][n] (Q - mu)[w][n]
-                const int am = lane & 15, ak = lane >> 4;
-                double part[4] = {0.0, 0.0, 0.0, 0.0};
-                typedef double d4 __attribute__((ext_vector_type(4)));
-                for (int nb = 0; nb < Dp / 16; ++nb) {
-                    d4 accv = {0.0, 0.0, 0.0, 0.0};
-                    for (int kk = 0; kk < Dp / 4; ++kk) {
-                        const int k = 4 * kk + ak;
-                        const double av = tile[am * RT + k] - muS[k];       // A[i = lane & 15][k = lane >> 4]
-                        const double bv = Sinv[k * RS + 16 * nb + am];      // B[k = lane >> 4][j = lane & 15]
-                        accv = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, accv, 0, 0, 0);
-                    }
-                    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-                    const int n = 16 * nb + am;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int w = ak + 4 * r;
-                        const double dv = tile[w * RT + n] - muS[n];
-                        part[r] = fma(accv[r], dv, part[r]);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int m = 8; m > 0; m >>= 1) part[r] += __shfl_xor(part[r], m, 64);
-                    if (am == 0) qfS[ak + 4 * r] = part[r];
-                }
-            }
-            EMX_WAVE_SYNC();
-            // ---- decisions for the (up to) 16 slots of this tile, lane-parallel: lane l <-> slot l ----
-            const int tb = (p / PPT) * 16;                     // first slot of the tile
-            const bool mine = lane >= tb && lane < tb + 16 && lane < nslot;
-            bool acc = false;
-            double lp_fin = sl.lp_old;
-            if (mine) {
-                const double lpn = -0.5 * qfS[lane - tb];
-                if (lpn != lpn) atomicOr(A.status, ST_NAN_LOGP);
-                if constexpr (MOVE == MOVE_EVAL) {
-                    A.lp[sl.i] = lpn;
                 } else {
-                    const double lnpdiff = facS[lane - tb] + lpn - sl.lp_old;
-                    acc = lnpdiff > sl.logu;
-                    A.acc[sl.i] = acc ? 1 : 0;
-                    if (acc) A.lp[sl.i] = lpn;
-                    if (acc) lp_fin = lpn;
-                    if (A.chain_lp) {
-                        A.chain_lp[sl.i] = acc ? lpn : sl.lp_old;
-                        if (acc) A.acc_count[sl.i] += 1u;
-                    }
+                    s0v[k] = facv[k] = lpov[k] = loguv[k] = 0.0;
                 }
             }
-            if constexpr (MOVE != MOVE_EVAL) {
-                const unsigned long long am64 = __ballot(acc);
-                // commit the tile's rows in the (G, V, CH) row layout: accepted rows come from LDS
-                for (int pp = 0; pp < PPT; ++pp) {
-                    const int row = pp * WPW + sub;              // 0..15
-                    const int sidx = tb + row;
-                    const bool lv = sidx < nslot;
-                    const int wi = __shfl(sl.i, lv ? sidx : 0, 64);
-                    const double lpf = __shfl(lp_fin, lv ? sidx : 0, 64);
-                    const bool ac = lv && ((am64 >> sidx) & 1ull);
-                    if (!lv) continue;
-                    Row<G, V, CH> rr;
-                    if (ac) {
+
+            if constexpr (DENSE) {
+                if (stage_pending && pb == 0 && t0 == A.t_lo + wave * spw) EMX_STAGE_COPY();   // rows are in flight: overlap
+            }
+
+            // -------- proposals (+ element-wise target, decision, commit) --------
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int p = pb + k;
+                if (p < npass) {                                   // wave-uniform
+                    const int srow = p * WPW + sub;                // slot of this group inside the wave's range
+                    const bool live = srow < nslot;
+                    const int i = wi[k];
+                    double factor = facv[k];
+
+                    Row<G, V, CH> q;
+                    make_proposal<G, V, CH, MOVE>(xi[k], xa[NR >= 2 ? k : 0], xb[NR >= 3 ? k : 0], xc[NR >= 4 ? k : 0],
+                                                  s0v[k], A.gammas, D, gl, q, factor);
+
+                    // non-finite proposal -> sticky error (ensemble.py:476-479); the proposal is rejected
+                    bool badq = false;
+                    if constexpr (MOVE != MOVE_EVAL) {
+                        bool bl = false;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+#pragma unroll
+                            for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
+                        badq = group_any<G>(bl, sub);
+                        if (live && badq && gl == 0) atomicOr(A.status, ST_BAD_COORD);
+                    }
+
+                    if (A.target == TGT_NONE) {
+                        // split-phase: hand the proposal to the host log-prob (red_blue.py:90-93)
+                        if (live) {
+                            const int t = t0 + srow;
+                            store_row<G, V, CH>(q, A.qout + (size_t)t * D, D, gl);
+                            if (gl == 0) A.fout[t] = factor;
+                        }
+                    } else if constexpr (!DENSE) {
+                        const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
+                        if (live && gl == 0 && (lp_new != lp_new)) atomicOr(A.status, ST_NAN_LOGP);   // ensemble.py:550-551
+                        if constexpr (MOVE == MOVE_EVAL) {
+                            if (live && gl == 0) A.lp[i] = lp_new;
+                        } else {
+                            const double lp_old = lpov[k];
+                            const double lnpdiff = factor + lp_new - lp_old;                  // red_blue.py:99
+                            const bool accept = live && !badq && (lnpdiff > loguv[k]);        // red_blue.py:100
+                            if (accept) {
+                                store_row<G, V, CH>(q, A.X + (size_t)i * D, D, gl);          // move.py:33
+                                if (gl == 0) A.lp[i] = lp_new;                                // move.py:34
+                            }
+                            if (live && gl == 0) {
+                                A.acc[i] = accept ? 1 : 0;
+                                if (A.chain_lp) {
+                                    A.chain_lp[i] = accept ? lp_new : lp_old;
+                                    if (accept) A.acc_count[i] += 1u;
+                                }
+                            }
+                            if (live && A.chain) store_row<G, V, CH>(accept ? q : xi[k], A.chain + (size_t)i * D, D, gl);
+                            if (live && A.sendbuf) {
+                                double* sb = A.sendbuf + (size_t)(t0 + srow - A.t_lo) * (D + 2);
+                                store_row<G, V, CH>(accept ? q : xi[k], sb, D, gl);
+                                if (gl == 0) {
+                                    sb[D] = accept ? lp_new : lp_old;
+                                    sb[D + 1] = accept ? 1.0 : 0.0;
+                                }
+                            }
+                        }
+                    } else {
+                        // dense: the proposal goes to the wave's LDS tile (MFMA A operand, and commit source)
+                        const int trow = srow & 15;
 #pragma unroll
                         for (int c = 0; c < CH; ++c)
 #pragma unroll
                             for (int v = 0; v < V; ++v) {
                                 const int d = (c * G + gl) * V + v;
-                                rr.x[c][v] = d < D ? tile[row * RT + d] : 0.0;
+                                if (d < Dp && !(A.ablate & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] : muS[d];   // dead row: zero residual
                             }
-                        store_row<G, V, CH>(rr, A.X + (size_t)wi * D, D, gl);
-                    }
-                    if (A.chain || A.sendbuf) {
-                        if (!ac) load_row<G, V, CH>(rr, A.X + (size_t)wi * D, D, gl);
-                        if (A.chain) store_row<G, V, CH>(rr, A.chain + (size_t)wi * D, D, gl);
-                        if (A.sendbuf) {
-                            double* sb = A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2);
-                            store_row<G, V, CH>(rr, sb, D, gl);
-                            if (gl == 0) {
-                                sb[D] = lpf;
-                                sb[D + 1] = ac ? 1.0 : 0.0;
-                            }
-                        }
+                        if (gl == 0) facS[trow] = badq ? -__builtin_inf() : factor;
                     }
                 }
             }
-            EMX_WAVE_SYNC();
+
+            if constexpr (DENSE) {
+                const int plast = (pb + PF < npass ? pb + PF : npass) - 1;          // last pass of this batch
+                const bool tile_done = ((plast + 1) % PPT == 0) || (plast + 1 == npass);
+                if (A.target != TGT_NONE && tile_done && !(A.ablate & 16)) {
+                    // ---- one 16-row tile: Y = R Sinv by v_mfma_f64_16x16x4_f64 (R = Q - mu), qf[w] = sum_n Y[w][n] R[w][n] ----
+                    const int tb = (plast / PPT) * 16;                  // first slot of the tile
+                    // lanes 0..15 <-> the tile's rows: their walker and decision scalars (L1/L2-hot lines)
+                    const int myrow = lane & 15;
+                    const bool mine = lane < 16 && tb + myrow < nslot;
+                    const int mypos = pbase + (tb + myrow < nslot ? tb + myrow : 0);
+                    const int my_i = A.order[mypos];
+                    double my_lpo = 0.0, my_logu = 0.0;
+                    if constexpr (MOVE != MOVE_EVAL) {
+                        my_lpo = A.lp[my_i];
+                        my_logu = A.logu[mypos];
+                    }
+                    if (stage_pending) {
+                        __syncthreads();                 // image + this wave's tile visible (once per workgroup)
+                        stage_pending = false;
+                    } else {
+                        EMX_WAVE_SYNC();
+                    }
+                    {
+                        // Y = R L (R = Q - mu, 16 x Dp) by v_mfma_f64_16x16x4_f64; L is lower triangular, so the
+                        // k-steps below the diagonal block of column block nb vanish; qf[w] = sum_n Y[w][n]^2
+                        const int am = lane & 15, ak = lane >> 4;
+                        typedef double d4 __attribute__((ext_vector_type(4)));
+                        double afr[KK];
+#pragma unroll
+                        for (int kk = 0; kk < KK; ++kk)
+                            afr[kk] = tile[am * RT + 4 * kk + ak] - muS[4 * kk + ak];           // A[i = lane&15][k = lane>>4]
+                        double part[4] = {0.0, 0.0, 0.0, 0.0};
+                        if (!(A.ablate & 1))
+#pragma unroll
+                        for (int nb = 0; nb < DPB; ++nb) {
+                            d4 accv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int kk = 4 * nb; kk < KK; ++kk)
+                                accv = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], Sfrag[(nb * KK + kk) * 64 + lane], accv, 0, 0, 0);
+                            // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double tot = group_sum<16>(part[r]);       // over the 16 columns held by this row of lanes
+                            if (am == 0) qfS[ak + 4 * r] = tot;
+                        }
+                    }
+                    EMX_WAVE_SYNC();
+                    // ---- decisions for the (up to) 16 rows of this tile on lanes 0..15 ----
+                    bool acc = false;
+                    double lp_fin = my_lpo;
+                    if (mine) {
+                        const double lpn = -0.5 * qfS[myrow];
+                        if (lpn != lpn) atomicOr(A.status, ST_NAN_LOGP);
+                        if constexpr (MOVE == MOVE_EVAL) {
+                            A.lp[my_i] = lpn;
+                        } else {
+                            const double lnpdiff = facS[myrow] + lpn - my_lpo;
+                            acc = lnpdiff > my_logu;
+                            A.acc[my_i] = acc ? 1 : 0;
+                            if (acc) {
+                                A.lp[my_i] = lpn;
+                                lp_fin = lpn;
+                            }
+                            if (A.chain_lp) {
+                                A.chain_lp[my_i] = lp_fin;
+                                if (acc) A.acc_count[my_i] += 1u;
+                            }
+                        }
+                    }
+                    if constexpr (MOVE != MOVE_EVAL) {
+                        const unsigned long long am64 = __ballot(acc);       // bit r <-> tile row r
+                        if (A.sendbuf && lane < 16) qfS[myrow] = lp_fin;
+                        if (A.sendbuf) EMX_WAVE_SYNC();
+                        // commit the tile's rows in the (G, V, CH) row layout: accepted rows come from LDS
+                        for (int pp = 0; pp < ((A.ablate & 8) ? 0 : PPT); ++pp) {
+                            const int row = pp * WPW + sub;              // 0..15
+                            const int sidx = tb + row;
+                            const bool lv = sidx < nslot;
+                            const bool ac = lv && ((am64 >> row) & 1ull);
+                            if (!lv || !(ac || A.chain || A.sendbuf)) continue;
+                            const int wi2 = A.order[pbase + sidx];
+                            Row<G, V, CH> rr;
+                            if (ac) {
+#pragma unroll
+                                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                                    for (int v = 0; v < V; ++v) {
+                                        const int d = (c * G + gl) * V + v;
+                                        rr.x[c][v] = d < D ? tile[row * RT + d] : 0.0;
+                                    }
+                                store_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
+                            }
+                            if (A.chain || A.sendbuf) {
+                                if (!ac) load_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
+                                if (A.chain) store_row<G, V, CH>(rr, A.chain + (size_t)wi2 * D, D, gl);
+                                if (A.sendbuf) {
+                                    double* sb = A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2);
+                                    store_row<G, V, CH>(rr, sb, D, gl);
+                                    if (gl == 0) {
+                                        sb[D] = qfS[row];
+                                        sb[D + 1] = ac ? 1.0 : 0.0;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    EMX_WAVE_SYNC();
+                }
+            }
         }
-    }
     }   // batch loop
+}
+
+// logs of a host-supplied plan (exact / inputs modes), full width: logu = ln(uacc),
+// fac = (D-1) ln zz for the stretch move (stretch.py:31), 0 otherwise
+__global__ void k_plan_logs(int N, int D, int stretch, const double* __restrict__ s0, const double* __restrict__ uacc,
+                            double* __restrict__ logu, double* __restrict__ fac) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= N) return;
+    logu[pos] = log(uacc[pos]);
+    fac[pos] = stretch ? ((double)D - 1.0) * log(s0[pos]) : 0.0;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -684,10 +834,13 @@ __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
     }
 }
 
-// Dump the native-mode plan of one step (parity tests replay it through the oracle).
+// Native-mode plan of one step, evaluated full width (one lane per walker): the Philox rounds, the
+// keyed-permutation inversions and the two f64 logs are paid once per walker here instead of on the
+// few active lanes of the half-step kernel's phase A.  Also what emx_plan_get returns to the tests.
 template <int MOVE>
-__global__ void k_native_plan(NativeArgs nat, int N, int S, double a, double sigma, double g0, int32_t* order,
-                              int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc) {
+__global__ void k_native_plan(NativeArgs nat, int N, int S, int D, double a, double sigma, double g0, int32_t* order,
+                              int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc, double* logu,
+                              double* fac) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= N) return;
     int split = 0, t = pos;
@@ -705,6 +858,57 @@ __global__ void k_native_plan(NativeArgs nat, int N, int S, double a, double sig
     p2[pos] = a2;
     s0[pos] = z;
     uacc[pos] = u;
+    logu[pos] = log(u);
+    fac[pos] = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
+}
+
+// Native plans of up to 8 consecutive steps in ONE launch (grid.y = step): a single step's plan is
+// only N lanes of latency-bound work (Philox, permutation inversions, two logs), so batching fills the
+// machine and amortises the launch.
+constexpr int NATIVE_BATCH_MAX = 8;
+struct NativeBatchArgs {
+    NativeArgs nat[NATIVE_BATCH_MAX];
+    int32_t* order[NATIVE_BATCH_MAX];
+    int32_t* p0[NATIVE_BATCH_MAX];
+    int32_t* p1[NATIVE_BATCH_MAX];
+    int32_t* p2[NATIVE_BATCH_MAX];
+    double* s0[NATIVE_BATCH_MAX];
+    double* uacc[NATIVE_BATCH_MAX];
+    double* logu[NATIVE_BATCH_MAX];
+    double* fac[NATIVE_BATCH_MAX];
+    double a[NATIVE_BATCH_MAX], sigma[NATIVE_BATCH_MAX], g0[NATIVE_BATCH_MAX];
+    int32_t move[NATIVE_BATCH_MAX], S[NATIVE_BATCH_MAX];
+    int32_t N, D, nb;
+};
+
+__global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs B) {
+    const int b = blockIdx.y;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= B.N) return;
+    const int N = B.N, S = B.S[b];
+    int split = 0, t = pos;
+    for (int s = 0; s < S; ++s) {
+        const int n = (N - s + S - 1) / S;
+        if (t < n) { split = s; break; }
+        t -= n;
+    }
+    int i, a0, a1, a2;
+    double z, u;
+    const int mv = B.move[b];
+    if (mv == MOVE_STRETCH)
+        native_slot<MOVE_STRETCH>(B.nat[b], N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
+    else if (mv == MOVE_DE)
+        native_slot<MOVE_DE>(B.nat[b], N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
+    else
+        native_slot<MOVE_SNOOKER>(B.nat[b], N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
+    B.order[b][pos] = i;
+    B.p0[b][pos] = a0;
+    B.p1[b][pos] = a1;
+    B.p2[b][pos] = a2;
+    B.s0[b][pos] = z;
+    B.uacc[b][pos] = u;
+    B.logu[b][pos] = log(u);
+    B.fac[b][pos] = (mv == MOVE_STRETCH) ? ((double)B.D - 1.0) * log(z) : 0.0;
 }
 
 // sharded runs: write the all-gathered [row | log_prob | accepted] records of the other ranks'

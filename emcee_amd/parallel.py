@@ -52,10 +52,16 @@ class ShardedStepper:
 
     def run(self, nsteps, thin_by=1, store=False):
         i = 0
+        total = nsteps * thin_by
+        hint = getattr(self.engine, "set_prep_hint", None)
         for _ in range(nsteps):
             for _ in range(thin_by):
+                if hint is not None:
+                    hint(total - i)            # lets the native plan kernel batch the remaining steps
                 self.step(store and (i + 1) % thin_by == 0)
                 i += 1
+        if hint is not None:
+            hint(1)
 
 
 class DeviceEngine:
@@ -72,6 +78,9 @@ class DeviceEngine:
         self.sendbuf = torch.zeros(rows * rec, dtype=torch.float64, device=dev)
         self.gathered = torch.zeros(world * rows * rec, dtype=torch.float64, device=dev)
         ens.set_shard_buffers(self.sendbuf.data_ptr(), self.gathered.data_ptr(), rows)
+
+    def set_prep_hint(self, n):
+        self.ens.set_tuning("prep_hint", n)
 
     def step_begin(self, store):
         return self.ens.step_begin(store)

@@ -73,7 +73,8 @@ int emx_get_state(emx_ctx* ctx, double* coords /* or NULL */, double* log_prob /
 int emx_get_accepted(emx_ctx* ctx, uint8_t* mask /* N */); /* `accepted` of the last propose */
 
 /* ---- target: the batched log-prob (ensemble.py:458-553, vectorised) -------------------- */
-/* p0/p1: DIAG (mu, ivar); DENSE (mu, icov[D*D]); others NULL.  scale: Rosenbrock divisor. */
+/* p0/p1: DIAG (mu, ivar); DENSE (mu, icov[D*D], symmetric positive definite: factored once as
+ * L L^T, the kernel evaluates -0.5 |L^T (x-mu)|^2); others NULL.  scale: Rosenbrock divisor. */
 int emx_set_target(emx_ctx* ctx, int32_t kind, const double* p0, const double* p1, double scale);
 /* log-prob of the current state, stored as the state's log_prob (ensemble.py:350-351) */
 int emx_eval_state_log_prob(emx_ctx* ctx);
