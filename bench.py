@@ -193,11 +193,12 @@ def main():
             "steps_per_s": K / wall, "accept_frac": acc_frac, "device_status": status,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "emx::k_halfstep<32,2,1,STRETCH,DENSE>",
+                         "kernel": "emx::k_halfstep<8,2,4,STRETCH,DPB=4> (G=8 lanes/walker, V=2, CH=4; f64 MFMA dense target)",
                          "algorithmic_bytes_per_walker_update": B, "walker_updates_per_launch": slots_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "per_launch_event_us": per_launch_us,
-                         "note": "avg_launch_us = hipEvent time of the timed region / launches (includes the "
-                                 "inter-kernel gap); per_launch_event_us brackets single launches"},
+                         "note": "avg_launch_us = hipEvent time of the timed region / half-step launches: it includes the "
+                                 "inter-kernel gaps and the batched plan kernel (k_native_plan_batch, 1 launch per 8 steps); "
+                                 "per_launch_event_us brackets single half-step launches with hipEvents"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(mu, cov, icov)

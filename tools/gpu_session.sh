@@ -19,6 +19,7 @@ tail -2 gpurun_out/prof_${R}_trace.log
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof_${R}/pmc_fetch -o c2 -f csv -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/prof_${R}_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof_${R}/pmc_write -o c2 -f csv -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/prof_${R}_write.log 2>&1
 find gpurun_out/prof_${R} -name "*.csv" | head -20
+bash tools/pmc_session.sh > gpurun_out/pmc_${R}.txt 2>&1; tail -20 gpurun_out/pmc_${R}.txt
 # keep only small summaries
 find gpurun_out/prof_${R} -name "*kernel_trace.csv" -size +4M -exec sh -c 'head -400 "$1" > "$1.head"; rm "$1"' _ {} \;
 find gpurun_out/prof_${R} -name "*counter_collection.csv" -size +4M -exec sh -c 'head -2000 "$1" > "$1.head"; rm "$1"' _ {} \;
