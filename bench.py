@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded RCCL path even at world size 1 (testing)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="sharded runs: ncclAllGather enqueued by libemx itself (default) or torch.distributed")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,7 +109,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.comm == "torch":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")      # bootstrap / barriers only; the data path is libemx -> RCCL
 
     n = WALKERS_PER_GPU * world
     mu, cov, icov = dense_gaussian(NDIM)
@@ -127,12 +132,17 @@ def main():
     if args.store:
         ens.chain_config(K + W)
 
-    if sharded:
+    if sharded and args.comm == "torch":
         from emcee_amd.parallel import DeviceEngine, ShardedStepper
         ens.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels + RCCL ordered on one stream
         eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank))
         stepper = ShardedStepper(eng, lambda out, inp: dist.all_gather_into_tensor(out, inp))
         run = lambda k: stepper.run(k, 1, args.store)  # noqa: E731
+    elif sharded:
+        uid = [DeviceEnsemble.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ens.comm_init(rank, world, uid[0])          # ncclCommInitRank; emx_run now exchanges per half-step
+        run = lambda k: ens.run(k, 1, args.store)  # noqa: E731
     else:
         run = lambda k: ens.run(k, 1, args.store)  # noqa: E731
 
@@ -152,7 +162,7 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device="cuda" if args.comm == "torch" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, gpu_ms = float(t[0]), float(t[1])
 
@@ -189,7 +199,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: nwalkers=%d (65536/GPU), ndim=64, dense-precision Gaussian, "
                                    "StretchMove a=2.0, nsplits=2, rng=%s, store=%s" % (n, args.rng, args.store),
-                       "nwalkers": n, "ndim": NDIM, "parallelism": "walker-sharded x%d" % world},
+                       "nwalkers": n, "ndim": NDIM,
+                       "parallelism": "walker-sharded x%d%s" % (world, (", all-gather via %s" % args.comm) if sharded else "")},
             "steps_per_s": K / wall, "accept_frac": acc_frac, "device_status": status,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -74,6 +74,10 @@ SIGNATURES = {
     "emx_device_ptr": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "emx_shard_slots": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "emx_scatter_gathered": (C.c_int, [_P, C.c_int32]),
+    "emx_comm_load": (C.c_int, [C.c_char_p]),
+    "emx_comm_get_unique_id": (C.c_int, [_u8p]),
+    "emx_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, _u8p]),
+    "emx_comm_destroy": (C.c_int, [_P]),
     "emx_timer_start": (C.c_int, [_P]),
     "emx_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "emx_profile_enable": (C.c_int, [_P, C.c_int32]),

@@ -2,6 +2,8 @@
 // See include/emx.h for the contract and the reference lines each entry point replaces.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -176,6 +178,46 @@ int philox_move_choice(uint64_t seed, uint64_t step, const double* cdf, int n) {
     return k;
 }
 
+// ---- RCCL, resolved at run time (the process may already hold PyTorch's copy) ----------------
+struct RcclId {
+    char internal[128];
+};
+struct RcclApi {
+    void* h = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+} g_rccl;
+constexpr int RCCL_FLOAT64 = 8;   // ncclFloat64 (rccl.h:467)
+
+int rccl_load(const char* path, std::string& err) {
+    if (g_rccl.h) return 0;
+    const char* cands[] = {path, getenv("EMX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* cnd : cands) {
+        if (!cnd || !*cnd) continue;
+        h = dlopen(cnd, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+        return -5;
+    }
+    g_rccl.GetUniqueId = (int (*)(RcclId*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
+        err = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllGather";
+        return -5;
+    }
+    g_rccl.h = h;
+    return 0;
+}
+
 struct Shape {
     int G, V, CH;
 };
@@ -266,6 +308,7 @@ struct emx_ctx {
     double *sendbuf = nullptr, *gathered = nullptr;
     int64_t sendbuf_rows = 0, gathered_rows = 0;
     bool own_shard_bufs = false;
+    void* comm = nullptr;   // ncclComm_t when the exchange is driven from here (emx_comm_init)
     // tuning
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 8, tune_ablate = 0;
     // timing
@@ -586,6 +629,7 @@ int emx_destroy(emx_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm), c->comm = nullptr;
     void* ptrs[] = {c->X, c->lp, c->acc, c->acc_count, c->status, c->iota, c->qout, c->fout, c->newlp, c->evalX,
                     c->evallp, c->tp0, c->tp1, c->chain, c->chain_lp, c->own_shard_bufs ? c->sendbuf : nullptr,
                     c->own_shard_bufs ? c->gathered : nullptr};
@@ -1177,7 +1221,8 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     NEED(c, thin_by >= 1, "Invalid thinning argument");
     NEED(c, c->rng_mode != EMX_RNG_INPUTS, "emx_run needs an RNG mode that generates plans");
     NEED(c, c->target != EMX_TARGET_HOST, "emx_run needs a device target");
-    NEED(c, c->world == 1 && !c->sendbuf, "emx_run is single-rank; sharded runs drive emx_halfstep from the host layer");
+    NEED(c, (c->world == 1 && !c->sendbuf) || c->comm,
+         "emx_run on a sharded context needs emx_comm_init (or drive emx_halfstep / the collective from the host layer)");
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     int64_t i = 0;
     for (int64_t it = 0; it < nsteps; ++it)
@@ -1189,6 +1234,16 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
             if (rc) return rc;
             for (int s = 0; s < S; ++s) {
                 rc = do_halfstep(c, s, c->target);
+                if (!rc && c->comm) {
+                    // the one exchange per half-step: every rank's [row | log_prob | accepted] records to every rank
+                    const int e = g_rccl.AllGather(c->sendbuf, c->gathered, (size_t)c->sendbuf_rows * (c->D + 2), RCCL_FLOAT64,
+                                                   c->comm, c->stream);
+                    if (e != 0) {
+                        c->err = std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+                        rc = -6;
+                    }
+                    if (!rc && c->world > 1) rc = emx_scatter_gathered(c, s);
+                }
                 if (rc) {
                     c->cur.active = false;
                     return rc;
@@ -1301,6 +1356,64 @@ int emx_scatter_gathered(emx_ctx* c, int32_t split) {
         a.native = 0;
         hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256), 0, c->stream, a);
         HIPOK(c, hipGetLastError());
+    }
+    return 0;
+}
+
+// ---- RCCL driven from the library (one process per GPU) ----------------------------------
+int emx_comm_load(const char* librccl_path) {
+    std::string err;
+    const int rc = rccl_load(librccl_path, err);
+    if (rc) g_err = err;
+    return rc;
+}
+
+int emx_comm_get_unique_id(uint8_t id[128]) {
+    std::string err;
+    if (rccl_load(nullptr, err)) {
+        g_err = err;
+        return -5;
+    }
+    RcclId u;
+    const int e = g_rccl.GetUniqueId(&u);
+    if (e != 0) {
+        g_err = "ncclGetUniqueId failed";
+        return -6;
+    }
+    memcpy(id, u.internal, 128);
+    return 0;
+}
+
+int emx_comm_init(emx_ctx* c, int32_t rank, int32_t world, const uint8_t id[128]) {
+    HIPOK(c, hipSetDevice(c->device));
+    std::string err;
+    if (rccl_load(nullptr, err)) FAIL(c, -5, "%s", err.c_str());
+    NEED(c, !c->comm, "communicator already initialised");
+    int rc = emx_set_shard(c, rank, world);
+    if (rc) return rc;
+    if (!c->sendbuf) {   // world == 1: still exercise the exchange buffers
+        const int64_t per = (c->N + 1) / 2 + 2;
+        HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));
+        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * (c->D + 2) * 8));
+        c->own_shard_bufs = true;
+        c->sendbuf_rows = per;
+        c->gathered_rows = per;
+    }
+    RcclId u;
+    memcpy(u.internal, id, 128);
+    const int e = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (e != 0) {
+        c->comm = nullptr;
+        FAIL(c, -6, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    }
+    return 0;
+}
+
+int emx_comm_destroy(emx_ctx* c) {
+    if (c->comm) {
+        hipStreamSynchronize(c->stream);
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
     }
     return 0;
 }

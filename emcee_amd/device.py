@@ -236,6 +236,41 @@ class DeviceEnsemble:
     def scatter_gathered(self, split):
         self._ck(self.lib.emx_scatter_gathered(self.ctx, int(split)))
 
+    # ---- library-driven RCCL ----
+    @staticmethod
+    def rccl_unique_id():
+        """128-byte ncclUniqueId (rank 0); broadcast it with any host-side channel."""
+        lib = _lib.load()
+        DeviceEnsemble._load_rccl(lib)
+        uid = np.zeros(128, dtype=np.uint8)
+        rc = lib.emx_comm_get_unique_id(uid)
+        if rc != 0:
+            raise EmxError((lib.emx_last_error(None) or b"ncclGetUniqueId failed").decode())
+        return uid
+
+    @staticmethod
+    def _load_rccl(lib):
+        import os
+        path = os.environ.get("EMX_RCCL_LIB")
+        if not path:
+            try:   # share PyTorch's RCCL when torch is in the process
+                import torch
+                cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+                path = cand if os.path.exists(cand) else None
+            except Exception:  # noqa: BLE001
+                path = None
+        rc = lib.emx_comm_load(path.encode() if path else None)
+        if rc != 0:
+            raise EmxError((lib.emx_last_error(None) or b"cannot load librccl").decode())
+
+    def comm_init(self, rank, world, unique_id):
+        self._load_rccl(self.lib)
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        self._ck(self.lib.emx_comm_init(self.ctx, int(rank), int(world), uid))
+
+    def comm_destroy(self):
+        self._ck(self.lib.emx_comm_destroy(self.ctx))
+
     # ---- measurement ----
     def timer_start(self):
         self._ck(self.lib.emx_timer_start(self.ctx))

@@ -136,6 +136,16 @@ int emx_shard_slots(emx_ctx* ctx, int32_t split, int64_t* t_lo, int64_t* t_hi, i
 /* after the all-gather of `sendbuf`s into `gathered`: write the other ranks' rows into X */
 int emx_scatter_gathered(emx_ctx* ctx, int32_t split);
 
+/* RCCL driven by the library itself (ncclAllGather enqueued on the context stream between the
+ * half-step kernels, so that emx_run covers sharded runs with no host round trip per step).
+ * librccl is resolved with dlopen (path, $EMX_RCCL_LIB, librccl.so.1): pass PyTorch's copy when
+ * torch is loaded so that the process holds ONE RCCL.  Rank 0 creates the id, the host layer
+ * broadcasts its 128 bytes, every rank calls emx_comm_init. */
+int emx_comm_load(const char* librccl_path /* or NULL */);
+int emx_comm_get_unique_id(uint8_t id[128]);
+int emx_comm_init(emx_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[128]);
+int emx_comm_destroy(emx_ctx* ctx);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 int emx_timer_start(emx_ctx* ctx);                 /* hipEventRecord on the context stream */
 int emx_timer_stop(emx_ctx* ctx, float* ms);       /* record + synchronize + elapsed       */

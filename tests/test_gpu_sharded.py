@@ -82,3 +82,28 @@ def _run_step(group, steppers):
             e.scatter_gathered(split)
     for e in engines:
         e.step_end()
+
+
+def test_library_driven_rccl_world1():
+    """emx_comm_init + sharded emx_run (ncclAllGather enqueued by libemx) at world size 1:
+    exercises the RCCL linkage and the exchange buffers; the chain must equal the plain run."""
+    from emcee_amd.device import DeviceEnsemble
+    name = "stretch_128x64_dense"
+    g = load_golden(name)
+    spec = cases.build(name)
+    chains = []
+    for use_comm in (False, True):
+        ens = make_ens(spec, g["p0"])
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(4242, 0)
+        ens.chain_config(10)
+        if use_comm:
+            ens.comm_init(0, 1, DeviceEnsemble.rccl_unique_id())
+        ens.run(10, 1, True)
+        assert ens.status() == 0
+        chains.append((ens.chain_read(0, 0, 10), ens.chain_read(1, 0, 10), ens.accepted_counts()))
+        if use_comm:
+            ens.comm_destroy()
+        ens.close()
+    for a, b in zip(*chains):
+        assert np.array_equal(a, b)
