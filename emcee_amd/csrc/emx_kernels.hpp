@@ -74,7 +74,7 @@ struct HalfStepArgs {
     int32_t pos0, ns;     // first plan position / number of slots of this split
     int32_t t_lo, t_hi;   // slots updated by this rank
     int32_t spw;          // slots per wave
-    int32_t native;       // 1: derive the plan from Philox in flight
+    int32_t native;       // unused by k_halfstep (plans always come from a plan slot); kept for ABI stability
     int32_t target;
     int32_t Dp;           // dense: D rounded up to 16
     int32_t ablate;       // timing experiments only (tools/ablate.py): skip-phase bit mask, 0 in production
@@ -128,34 +128,6 @@ __device__ __forceinline__ bool group_any(bool pred, int sub) {
         return ((m >> (sub * G)) & ((1ull << G) - 1ull)) != 0ull;
     }
 }
-
-__device__ __forceinline__ int set_size(int N, int S, int j) { return (N - j + S - 1) / S; }
-
-// complement position r (sets != split, concatenated in set order) -> (set j, member tt)
-__device__ __forceinline__ void comp_locate(int N, int S, int split, int64_t r, int& j, int& tt) {
-    j = 0;
-    for (int s = 0; s < S; ++s) {
-        if (s == split) continue;
-        const int n = set_size(N, S, s);
-        if (r < n) {
-            j = s;
-            tt = (int)r;
-            return;
-        }
-        r -= n;
-    }
-    j = (split == S - 1) ? S - 2 : S - 1;  // unreachable for r < Nc
-    tt = 0;
-}
-
-struct Slot {
-    int i;            // walker to update
-    int p0, p1, p2;   // partner walkers
-    double s0;        // zz (stretch) | gamma (DE)
-    double logu;      // log of the accept uniform
-    double lp_old;
-    double factor;    // (D-1) ln zz for stretch, else filled later
-};
 
 // Native-mode draws for slot t of `split`: a pure function of (seed, step, walker).
 template <int MOVE>
