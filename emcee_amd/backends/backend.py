@@ -145,6 +145,16 @@ class Backend(object):
 
     def get_autocorr_time(self, discard=0, thin=1, **kwargs):
         """Integrated autocorrelation time per parameter, in steps (reference backend.py:130-150)."""
+        if self._dev is not None and kwargs.get("has_walkers", True):
+            try:    # chain is in HBM: batched FFTs next to it, only the mean ACF comes back
+                from .._devfft import integrated_time_device
+                kw = {k: v for k, v in kwargs.items() if k in ("c", "tol", "quiet")}
+                if len(kw) == len(kwargs):
+                    return thin * integrated_time_device(self._dev, self.iteration, discard=discard, thin=thin, **kw)
+            except autocorr.AutocorrError:
+                raise
+            except Exception as e:  # noqa: BLE001  (torch missing / view unsupported): host estimator below
+                autocorr.logger.debug("device autocorr unavailable (%s); using the host estimator", e)
         x = self.get_chain(discard=discard, thin=thin)
         return thin * autocorr.integrated_time(x, **kwargs)
 

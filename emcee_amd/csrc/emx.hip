@@ -1308,6 +1308,8 @@ int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
         case 1: *ptr = c->lp; *nbytes = c->N * 8; return 0;
         case 2: *ptr = c->sendbuf; *nbytes = c->sendbuf_rows * (c->D + 2) * 8; return 0;
         case 3: *ptr = c->gathered; *nbytes = c->gathered_rows * (c->D + 2) * 8; return 0;
+        case 4: *ptr = c->chain; *nbytes = c->stored * c->N * c->D * 8; return 0;
+        case 5: *ptr = c->chain_lp; *nbytes = c->stored * c->N * 8; return 0;
     }
     FAIL(c, -1, "unknown device pointer id %d", which);
 }

@@ -619,6 +619,13 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                 if (d < Dp && !(A.ablate & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] : muS[d];   // dead row: zero residual
                             }
                         if (gl == 0) facS[trow] = badq ? -__builtin_inf() : factor;
+                        // stored step / sharded run: the current row goes out now (fire and forget); an accepted
+                        // proposal overwrites it after the decision -- no reload of rejected rows in the commit
+                        if constexpr (MOVE != MOVE_EVAL) {
+                            if (live && A.chain) store_row<G, V, CH>(xi[k], A.chain + (size_t)i * D, D, gl);
+                            if (live && A.sendbuf)
+                                store_row<G, V, CH>(xi[k], A.sendbuf + (size_t)(t0 + srow - A.t_lo) * (D + 2), D, gl);
+                        }
                     }
                 }
             }
@@ -705,31 +712,25 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             const int sidx = tb + row;
                             const bool lv = sidx < nslot;
                             const bool ac = lv && ((am64 >> row) & 1ull);
-                            if (!lv || !(ac || A.chain || A.sendbuf)) continue;
+                            if (!lv) continue;
+                            if (A.sendbuf && gl == 0) {
+                                double* sb = A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2);
+                                sb[D] = qfS[row];
+                                sb[D + 1] = ac ? 1.0 : 0.0;
+                            }
+                            if (!ac) continue;
                             const int wi2 = A.order[pbase + sidx];
                             Row<G, V, CH> rr;
-                            if (ac) {
 #pragma unroll
-                                for (int c = 0; c < CH; ++c)
+                            for (int c = 0; c < CH; ++c)
 #pragma unroll
-                                    for (int v = 0; v < V; ++v) {
-                                        const int d = (c * G + gl) * V + v;
-                                        rr.x[c][v] = d < D ? tile[row * RT + d] : 0.0;
-                                    }
-                                store_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
-                            }
-                            if (A.chain || A.sendbuf) {
-                                if (!ac) load_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
-                                if (A.chain) store_row<G, V, CH>(rr, A.chain + (size_t)wi2 * D, D, gl);
-                                if (A.sendbuf) {
-                                    double* sb = A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2);
-                                    store_row<G, V, CH>(rr, sb, D, gl);
-                                    if (gl == 0) {
-                                        sb[D] = qfS[row];
-                                        sb[D + 1] = ac ? 1.0 : 0.0;
-                                    }
+                                for (int v = 0; v < V; ++v) {
+                                    const int d = (c * G + gl) * V + v;
+                                    rr.x[c][v] = d < D ? tile[row * RT + d] : 0.0;
                                 }
-                            }
+                            store_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
+                            if (A.chain) store_row<G, V, CH>(rr, A.chain + (size_t)wi2 * D, D, gl);
+                            if (A.sendbuf) store_row<G, V, CH>(rr, A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2), D, gl);
                         }
                     }
                     EMX_WAVE_SYNC();

@@ -130,7 +130,8 @@ int emx_set_shard(emx_ctx* ctx, int32_t rank, int32_t world);
  * sendbuf (rows_per_rank, D+2), gathered (world*rows_per_rank, D+2); records = [row | log_prob | accepted] */
 int emx_set_shard_buffers(emx_ctx* ctx, void* sendbuf, void* gathered, int64_t rows_per_rank);
 /* raw device pointers for zero-copy wrapping (torch.distributed all-gather buffers):
- * which: 0 coords (N,D), 1 log_prob (N), 2 sendbuf (rows/rank, D+2), 3 gathered (world*rows/rank, D+2) */
+ * which: 0 coords (N,D), 1 log_prob (N), 2 sendbuf (rows/rank, D+2), 3 gathered (world*rows/rank, D+2),
+ *        4 chain (stored, N, D), 5 chain log_prob (stored, N) */
 int emx_device_ptr(emx_ctx* ctx, int32_t which, void** ptr, int64_t* nbytes);
 int emx_shard_slots(emx_ctx* ctx, int32_t split, int64_t* t_lo, int64_t* t_hi, int64_t* ns);
 /* after the all-gather of `sendbuf`s into `gathered`: write the other ranks' rows into X */

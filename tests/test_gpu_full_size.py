@@ -1,0 +1,104 @@
+"""Parity at the FULL sizes of BASELINE.json's configs (the oracle still finishes in seconds for a
+couple of steps), plus size-independent invariants of longer native runs at those sizes."""
+import numpy as np
+import pytest
+
+from emcee_amd import _lib
+from oracle import cases
+from oracle import sampler_oracle as so
+
+from emx_testlib import cdf_of, move_desc
+from test_gpu_parity import assert_lp_close, make_ens, set_target
+
+pytestmark = pytest.mark.gpu
+
+S = so.MoveSpec
+
+
+def full_spec(N, D, target, moves, weights=None, seed=0, p0="randn"):
+    spec = dict(N=N, D=D, target=target, moves=moves, weights=weights, seed=seed, p0=p0, nsteps=2, thin_by=1)
+    cases.DIGEST_CASES["_tmp_full"] = dict(N=N, D=D, target=target, moves=moves, weights=weights, nsteps=2, seed=seed, p0=p0)
+    out = cases.build("_tmp_full")
+    del cases.DIGEST_CASES["_tmp_full"]
+    return out
+
+
+FULL = {
+    "c2_65536x64_dense_stretch": lambda: full_spec(65536, 64, "dense", [S("stretch")], seed=11),
+    "c3_262144x32_rosenbrock_stretch": lambda: full_spec(262144, 32, "rosenbrock", [S("stretch")], seed=12, p0="rosen"),
+    "c4_65536x64_dense_de_snooker": lambda: full_spec(65536, 64, "dense", [S("de"), S("snooker")], weights=[0.8, 0.2], seed=13),
+    "c5_16384x1024_diag_stretch": lambda: full_spec(16384, 1024, "diag", [S("stretch")], seed=14),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_exact_mode_equals_oracle_at_full_size(name):
+    """MT19937 mode, free running for 2 steps at the BASELINE size: same accept masks, bit-identical
+    coordinates (stretch / DE), same final generator state as the reference-pinned oracle."""
+    spec = FULL[name]()
+    fn = cases.make_target(spec["desc"])
+    rs = np.random.RandomState(spec["rng_seed"])
+    nst = 2 if "snooker" not in name else 3
+    out = so.run(spec["p0"], nst, fn, rs, moves=spec["moves"], weights=spec["weights"])
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_MT19937)
+    ens.set_mt19937(np.random.RandomState(spec["rng_seed"]).get_state())
+    ens.chain_config(nst)
+    ens.run(nst, 1, True)
+    assert ens.status() == 0
+    assert np.array_equal(ens.accepted_counts(), out["accepted_count"])
+    chain = ens.chain_read(0, 0, nst)
+    used = [spec["moves"][k].kind for k in out["move_choices"]]
+    if "snooker" in used:
+        np.testing.assert_allclose(chain, out["chain"], rtol=1e-9, atol=1e-10)
+    else:
+        assert np.array_equal(chain, out["chain"])
+    assert_lp_close(ens.chain_read(1, 0, nst), out["log_prob"], 1e-9 if "snooker" in used else 1e-11)
+    a, b = ens.get_mt19937(), rs.get_state()
+    assert np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
+    ens.close()
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_native_mode_invariants_at_full_size(name):
+    """Philox mode, 30 steps at the BASELINE size.  Invariants that hold for any correct run:
+    (i) stored log-prob == target evaluated at the stored coordinates; (ii) a walker's row changes
+    between consecutive stored steps iff it was accepted, and the per-walker accept counters add
+    up; (iii) every walker is proposed exactly once per step (the split is a partition);
+    (iv) acceptance fraction in the regime the reference shows for this target."""
+    spec = FULL[name]()
+    fn = cases.make_target(spec["desc"])
+    N, D = spec["N"], spec["D"]
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_PHILOX)
+    ens.set_philox(99, 0)
+    nst = 6
+    ens.chain_config(nst)
+    ens.run(24, 1, False)
+    x_prev, _ = ens.get_state()
+    changed_total = np.zeros(N)
+    for it in range(nst):
+        k, nsplits = ens.step_begin(store=True)
+        plan = ens.plan_get(nsplits)
+        assert np.array_equal(np.sort(plan["order"]), np.arange(N))               # (iii)
+        for s in range(nsplits):
+            ens.halfstep(s)
+        ens.step_end()
+        x, lp = ens.get_state()
+        acc = ens.accepted_mask()
+        moved = np.any(x != x_prev, axis=1)
+        assert np.array_equal(moved, acc)                                          # (ii)
+        changed_total += acc
+        x_prev = x
+    assert ens.status() == 0
+    chain = ens.chain_read(0, 0, nst)
+    lps = ens.chain_read(1, 0, nst)
+    assert np.array_equal(chain[-1], x_prev)
+    assert np.array_equal(ens.accepted_counts(), changed_total)
+    sel = np.random.RandomState(0).choice(N, size=min(N, 4096), replace=False)
+    for it in (0, nst - 1):
+        assert_lp_close(lps[it][sel], fn(chain[it][sel]), 1e-11)                    # (i)
+    frac = changed_total.mean() / nst
+    lo, hi = {"c2": (0.10, 0.25), "c3": (0.10, 0.45), "c4": (0.10, 0.45), "c5": (0.005, 0.12)}[name[:2]]
+    assert lo < frac < hi, frac                                                    # (iv)
+    ens.close()

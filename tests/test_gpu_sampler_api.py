@@ -346,3 +346,24 @@ def test_compute_log_prob_and_autocorr_time():
     s.run_mcmc(np.random.randn(64, 2), 3000)
     tau = s.get_autocorr_time(quiet=True)
     assert tau.shape == (2,) and np.all(tau > 1) and np.all(tau < 60)
+
+
+def test_device_autocorr_equals_host_estimator():
+    """tau from batched FFTs on the HBM-resident chain == the host estimator."""
+    from emcee_amd import autocorr
+    from emcee_amd._devfft import integrated_time_device, mean_acf
+    np.random.seed(5)
+    s = emcee_amd.EnsembleSampler(96, 3, targets.IsoGaussian(), rng="philox")
+    s.run_mcmc(np.random.randn(96, 3), 1500)
+    ens = s.backend._dev
+    assert ens is not None
+    for discard, thin in ((0, 1), (100, 3)):
+        host_chain = s.get_chain(discard=discard, thin=thin)
+        tau_h = autocorr.integrated_time(host_chain, quiet=True)
+        tau_d = integrated_time_device(ens, s.iteration, discard=discard, thin=thin, quiet=True)
+        np.testing.assert_allclose(tau_d, tau_h, rtol=1e-8)
+        f = mean_acf(ens, s.iteration, discard=discard, thin=thin)
+        assert f.shape == (host_chain.shape[0], 3) and abs(f[0, 0] - 1.0) < 1e-12
+    np.testing.assert_allclose(s.get_autocorr_time(quiet=True), autocorr.integrated_time(s.get_chain(), quiet=True), rtol=1e-8)
+    with pytest.raises(autocorr.AutocorrError):
+        s.get_autocorr_time(tol=1e6)
