@@ -132,17 +132,39 @@ def main():
     if args.store:
         ens.chain_config(K + W)
 
-    if sharded and args.comm == "torch":
+    def torch_path(group=None):
         from emcee_amd.parallel import DeviceEngine, ShardedStepper
         ens.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels + RCCL ordered on one stream
         eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank))
-        stepper = ShardedStepper(eng, lambda out, inp: dist.all_gather_into_tensor(out, inp))
-        run = lambda k: stepper.run(k, 1, args.store)  # noqa: E731
+        stepper = ShardedStepper(eng, lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group))
+        return lambda k: stepper.run(k, 1, args.store)
+
+    comm_used = None
+    if sharded and args.comm == "torch":
+        run = torch_path()
+        comm_used = "torch.distributed(nccl)"
     elif sharded:
-        uid = [DeviceEnsemble.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ens.comm_init(rank, world, uid[0])          # ncclCommInitRank; emx_run now exchanges per half-step
-        run = lambda k: ens.run(k, 1, args.store)  # noqa: E731
+        ok = 1
+        try:
+            uid = [DeviceEnsemble.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ens.comm_init(rank, world, uid[0])      # ncclCommInitRank; emx_run now exchanges per half-step
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print("[bench] library-driven RCCL unavailable on rank %d (%s); falling back to torch.distributed" % (rank, e),
+                  file=sys.stderr)
+        flag = torch.tensor([ok])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            run = lambda k: ens.run(k, 1, args.store)  # noqa: E731
+            comm_used = "libemx->RCCL"
+        else:
+            try:
+                ens.comm_destroy()
+            except Exception:  # noqa: BLE001
+                pass
+            run = torch_path(dist.new_group(backend="nccl"))
+            comm_used = "torch.distributed(nccl) [fallback]"
     else:
         run = lambda k: ens.run(k, 1, args.store)  # noqa: E731
 
@@ -200,7 +222,7 @@ def main():
             "config": {"workload": "configs[1]: nwalkers=%d (65536/GPU), ndim=64, dense-precision Gaussian, "
                                    "StretchMove a=2.0, nsplits=2, rng=%s, store=%s" % (n, args.rng, args.store),
                        "nwalkers": n, "ndim": NDIM,
-                       "parallelism": "walker-sharded x%d%s" % (world, (", all-gather via %s" % args.comm) if sharded else "")},
+                       "parallelism": "walker-sharded x%d%s" % (world, (", all-gather via %s" % comm_used) if sharded else "")},
             "steps_per_s": K / wall, "accept_frac": acc_frac, "device_status": status,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -122,13 +122,13 @@ int draw_split_proposal(MT19937Legacy& mt, int64_t N, const emx_move_desc& mv, c
 }
 
 template <typename I32, typename F64>
-int make_exact_plan(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc& mv, std::vector<int32_t>& labels,
+int make_exact_plan(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc& mv, std::vector<uint8_t>& labels,
                     int32_t* off, I32* order, I32* p0, I32* p1, I32* p2, F64* s0, F64* uacc) {
     const int S = mv.nsplits;
     if (S < 2 || S > 255) return -1;
     if (mv.kind == EMX_MOVE_SNOOKER && S < 4) return -1;
     labels.resize(N);
-    for (int64_t i = 0; i < N; ++i) labels[i] = (int32_t)(i % S);          // red_blue.py:78
+    for (int64_t i = 0; i < N; ++i) labels[i] = (uint8_t)(i % S);          // red_blue.py:78 (one byte per label: L1-resident shuffle)
     if (mv.randomize_split) mt.shuffle(labels.data(), N);                   // red_blue.py:80
     // boolean-mask gather order (red_blue.py:85): ascending walker index inside each set
     std::vector<int32_t> cnt(S + 1, 0);
@@ -287,7 +287,7 @@ struct emx_ctx {
     };
     std::deque<Prepared> prepared;
     int64_t prep_hint = 1;   // upcoming steps the caller will take (emx_run sets it): batch size of the native prep
-    std::vector<int32_t> labels_scratch;
+    std::vector<uint8_t> labels_scratch;
     // current step
     struct Cur {
         bool active = false;
@@ -1486,7 +1486,7 @@ int32_t emx_mt_choice_cdf(emx_mt* m, const double* cdf, int32_t n) { return m->m
 
 int emx_host_plan_mt(emx_mt* m, int64_t N, int32_t D, const emx_move_desc* mv, int32_t* off, int32_t* order, int32_t* p0,
                      int32_t* p1, int32_t* p2, double* s0, double* uacc) {
-    std::vector<int32_t> labels;
+    std::vector<uint8_t> labels;
     return make_exact_plan(m->mt, N, D, *mv, labels, off, order, p0, p1, p2, s0, uacc);
 }
 

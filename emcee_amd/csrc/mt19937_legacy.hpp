@@ -18,43 +18,66 @@
 namespace emx {
 
 struct MT19937Legacy {
-    uint32_t key[624];
+    uint32_t key[624];      // NumPy's (untempered) state words
+    uint32_t out[624];      // the same block, tempered: what next32() hands out
     int pos = 624;
     int has_gauss = 0;
     double gauss = 0.0;
 
-    void set_state(const uint32_t* k, int p, int hg, double g) {
-        std::memcpy(key, k, sizeof(key));
-        pos = p;
-        has_gauss = hg;
-        gauss = g;
-    }
-
-    void twist() {
-        constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX = 0x9908b0dfu;
-        int kk;
-        uint32_t y;
-        for (kk = 0; kk < 624 - 397; kk++) {
-            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
-            key[kk] = key[kk + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX);
-        }
-        for (; kk < 623; kk++) {
-            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
-            key[kk] = key[kk + (397 - 624)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX);
-        }
-        y = (key[623] & UPPER) | (key[0] & LOWER);
-        key[623] = key[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX);
-        pos = 0;
-    }
-
-    inline uint32_t next32() {
-        if (pos == 624) twist();
-        uint32_t y = key[pos++];
+    static inline uint32_t temper(uint32_t y) {
         y ^= (y >> 11);
         y ^= (y << 7) & 0x9d2c5680u;
         y ^= (y << 15) & 0xefc60000u;
         y ^= (y >> 18);
         return y;
+    }
+
+    void set_state(const uint32_t* k, int p, int hg, double g) {
+        std::memcpy(key, k, sizeof(key));
+        for (int i = 0; i < 624; ++i) out[i] = temper(key[i]);
+        pos = p;
+        has_gauss = hg;
+        gauss = g;
+    }
+
+    // Regenerate the whole 624-word block.  Each segment only reads words that are still "old"
+    // inside one vector (key[kk+1] is read before key[kk..] is written), so the loops vectorise.
+    void twist() {
+        constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX = 0x9908b0dfu;
+        uint32_t* __restrict k = key;
+        int kk;
+#if defined(__clang__)
+#pragma clang loop vectorize(enable) interleave(enable)
+#endif
+        for (kk = 0; kk < 624 - 397; kk++) {
+            const uint32_t y = (k[kk] & UPPER) | (k[kk + 1] & LOWER);
+            k[kk] = k[kk + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX);
+        }
+        // the second segment reads words written 227 positions earlier: chunks of <= 227 are independent
+        for (int base = 624 - 397; base < 623; base += 224) {
+            const int end = base + 224 < 623 ? base + 224 : 623;
+#if defined(__clang__)
+#pragma clang loop vectorize(enable) interleave(enable)
+#endif
+            for (kk = base; kk < end; kk++) {
+                const uint32_t y = (k[kk] & UPPER) | (k[kk + 1] & LOWER);
+                k[kk] = k[kk - 227] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX);
+            }
+        }
+        {
+            const uint32_t y = (k[623] & UPPER) | (k[0] & LOWER);
+            k[623] = k[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX);
+        }
+#if defined(__clang__)
+#pragma clang loop vectorize(enable) interleave(enable)
+#endif
+        for (int i = 0; i < 624; ++i) out[i] = temper(k[i]);
+        pos = 0;
+    }
+
+    inline uint32_t next32() {
+        if (__builtin_expect(pos == 624, 0)) twist();
+        return out[pos++];
     }
 
     inline uint64_t next64() {
