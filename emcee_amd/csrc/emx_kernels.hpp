@@ -719,7 +719,15 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                 sb[D + 1] = ac ? 1.0 : 0.0;
                             }
                             if (!ac) continue;
-                            const int wi2 = A.order[pbase + sidx];
+                            // the walker index is still in registers when the batch is exactly this tile
+                            int wi2;
+                            if constexpr (PF == PPT) {
+                                wi2 = wi[0];
+#pragma unroll
+                                for (int k2 = 1; k2 < PF; ++k2) wi2 = (pp == k2) ? wi[k2] : wi2;
+                            } else {
+                                wi2 = A.order[pbase + sidx];
+                            }
                             Row<G, V, CH> rr;
 #pragma unroll
                             for (int c = 0; c < CH; ++c)

@@ -25,7 +25,7 @@ from .backends import Backend
 from .model import Model
 from .moves import StretchMove
 from .pbar import get_progress_bar
-from .state import State
+from .state import DeviceState, State
 from .targets import DeviceTarget
 from .utils import deprecation_warning
 
@@ -288,6 +288,9 @@ class EnsembleSampler(object):
         if native:
             ens = self._configure_device(descs, fused)
             ens.set_state(state.coords, np.asarray(state.log_prob, dtype=np.float64))
+            if state.blobs is None:
+                # from here on the state lives in HBM; the yielded object copies it back lazily
+                state = DeviceState(ens, random_state=state.random_state)
             if own_backend and store:
                 if self.backend._dev is not ens:
                     if self.backend.iteration > 0:
@@ -312,8 +315,11 @@ class EnsembleSampler(object):
                 for _ in range(yield_step):
                     save = store and (i + 1) % checkpoint_step == 0
                     if native:
-                        accepted = self._device_step(ens, state, fused, save and dev_store)
+                        accepted = self._device_step(ens, state, fused, save and dev_store,
+                                                     need_mask=save and not dev_store)
                         move = None
+                        if isinstance(state, DeviceState):
+                            state._invalidate()
                     else:
                         move = self._random.choice(self._moves, p=self._weights)     # ensemble.py:406
                         state, accepted = move.propose(model, state)
@@ -324,22 +330,23 @@ class EnsembleSampler(object):
                         if dev_store:
                             self.backend._device_step_saved(state.blobs, state.random_state)
                         else:
-                            if native:
+                            if native and not isinstance(state, DeviceState):
                                 state.coords, state.log_prob = ens.get_state()
                             self.backend.save_step(state, accepted)
                     pbar.update(1)
                     i += 1
-                if native:
+                if native and not isinstance(state, DeviceState):
                     state.coords, state.log_prob = ens.get_state()
                 yield state
 
-    def _device_step(self, ens, state, fused, store):
-        """One full step of the built-in moves on the device; returns the accepted mask."""
+    def _device_step(self, ens, state, fused, store, need_mask=True):
+        """One full step of the built-in moves on the device; returns the accepted mask (None when
+        nobody on the host needs it: the device chain keeps its own accept counters)."""
         if fused:
             ens.run(1, 1, store)
             ens.raise_on_status()
             self._sync_rng_from_device(ens)
-            return ens.accepted_mask()
+            return ens.accepted_mask() if need_mask else None
         # split-phase: the callable runs on the host between propose and accept (red_blue.py:90-104)
         k, nsplits = ens.step_begin(store)
         pending = []
@@ -381,6 +388,10 @@ class EnsembleSampler(object):
         results = None
         for results in self.sample(initial_state, iterations=nsteps, **kwargs):
             pass
+        if isinstance(results, DeviceState):
+            # hand back a plain snapshot: later runs must not change what the caller holds
+            results = State(results.coords, log_prob=results.log_prob, blobs=results.blobs,
+                            random_state=results.random_state)
         self._previous_state = results
         return results
 

@@ -5,7 +5,7 @@ from copy import deepcopy
 
 import numpy as np
 
-__all__ = ["State"]
+__all__ = ["State", "DeviceState"]
 
 
 class State(object):
@@ -51,3 +51,54 @@ class State(object):
     def __repr__(self):
         return "State({0}, log_prob={1}, blobs={2}, random_state={3})".format(
             self.coords, self.log_prob, self.blobs, self.random_state)
+
+
+class DeviceState(State):
+    """A :class:`State` whose ``coords`` / ``log_prob`` live on the GPU and are copied to the host
+    only when read.
+
+    ``EnsembleSampler.sample`` yields one of these per iteration when the built-in moves run on the
+    device: like the reference -- which mutates and re-yields one ``State`` object
+    (``ensemble.py:409-424``) -- the object always reflects the sampler's *current* position, but a
+    loop that never looks at the coordinates never pays the (nwalkers x ndim) PCIe copy.
+    Assigning to ``coords`` / ``log_prob`` detaches that field from the device."""
+
+    __slots__ = ("_ens", "_c", "_lp")
+
+    def __init__(self, ens, blobs=None, random_state=None):
+        self._ens = ens
+        self._c = None
+        self._lp = None
+        self.blobs = blobs
+        self.random_state = random_state
+
+    def _invalidate(self):
+        """Called by the sampler after every device step."""
+        self._c = None
+        self._lp = None
+
+    def _fetch(self):
+        if self._ens is not None and (self._c is None or self._lp is None):
+            c, lp = self._ens.get_state()
+            if self._c is None:
+                self._c = c
+            if self._lp is None:
+                self._lp = lp
+
+    @property
+    def coords(self):
+        self._fetch()
+        return self._c
+
+    @coords.setter
+    def coords(self, v):
+        self._c = v
+
+    @property
+    def log_prob(self):
+        self._fetch()
+        return self._lp
+
+    @log_prob.setter
+    def log_prob(self, v):
+        self._lp = v
