@@ -58,6 +58,7 @@ SIGNATURES = {
     "emx_chain_reset": (C.c_int, [_P]),
     "emx_run": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32]),
     "emx_iteration": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "emx_graph_state": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "emx_chain_read": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _dp]),
     "emx_accepted_counts": (C.c_int, [_P, _dp]),
     "emx_step_begin": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

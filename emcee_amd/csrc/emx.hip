@@ -309,6 +309,20 @@ struct emx_ctx {
     int64_t sendbuf_rows = 0, gathered_rows = 0;
     bool own_shard_bufs = false;
     void* comm = nullptr;   // ncclComm_t when the exchange is driven from here (emx_comm_init)
+    // hipGraph replay of the native 8-step block (single move, thin_by 1, one rank)
+    struct GraphSlot {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool valid = false;
+        int64_t spw = -1, wpb = -1, bpc = -1;
+        int target = -1;
+    } gslot[2];                      // [store]
+    StepDesc* d_desc = nullptr;      // NATIVE_BATCH_MAX descriptors
+    GraphCounters* d_ctr = nullptr;
+    GraphCounters* h_ctr = nullptr;  // pinned staging for the counters
+    bool graph_disabled = false;
+    bool graph_warm = false;         // one ordinary step has run (function attributes set, kernels loaded)
+    int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 8, tune_ablate = 0;
     // timing
@@ -317,6 +331,8 @@ struct emx_ctx {
     int prof_max = 0, prof_n = 0;
     std::string err;
 };
+
+static void graph_invalidate(emx_ctx* c);
 
 #define FAIL(ctx, code, ...)                         \
     do {                                             \
@@ -418,7 +434,8 @@ int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
 // launch one fused (or propose-only) half-step over the slots [t_lo, t_hi) of `split`
 int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, int ns, int t_lo, int t_hi, bool native,
                  bool plan_has_logs, const NativeArgs& nat, const emx_move_desc* mv, const emx_ctx::PlanSlot* ps, const int32_t* order,
-                 double* X, double* lp, double* chain, double* chain_lp, double* sendbuf) {
+                 double* X, double* lp, double* chain, double* chain_lp, double* sendbuf,
+                 const StepDesc* step_desc = nullptr) {
     if (t_hi <= t_lo) return 0;
     const bool dense = target == EMX_TARGET_DENSE_GAUSS;
     const int D = c->D;
@@ -489,6 +506,9 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.target = target;
     a.Dp = dense ? c->Dp : 16;
     a.ablate = (int32_t)c->tune_ablate;
+    a.desc = step_desc;
+    a.chain_all = c->chain;
+    a.chain_lp_all = c->chain_lp;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;
     if (prof) {
@@ -642,6 +662,13 @@ int emx_destroy(emx_ctx* c) {
         if (s.host) hipHostFree(s.host);
         if (s.consumed) hipEventDestroy(s.consumed);
     }
+    for (auto& g : c->gslot) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
+    if (c->d_desc) hipFree(c->d_desc);
+    if (c->d_ctr) hipFree(c->d_ctr);
+    if (c->h_ctr) hipHostFree(c->h_ctr);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (auto e : c->prof) hipEventDestroy(e);
@@ -673,6 +700,10 @@ int emx_status(emx_ctx* c, uint32_t* bits) {
 int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "spw")) {
         c->tune_spw = v;
+        return 0;
+    }
+    if (!strcmp(key, "graph")) {        // 1: replay the native 8-step block as a hipGraph (default 0: plain launches)
+        c->tune_graph = v;
         return 0;
     }
     if (!strcmp(key, "prep_hint")) {   // upcoming steps driven through emx_step_begin: native prep batch size
@@ -765,6 +796,8 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
             HIPOK(c, hipMemcpy(c->tp1, p1, n1 * 8, hipMemcpyHostToDevice));
         }
     }
+    graph_invalidate(c);
+    c->graph_warm = false;
     c->target = kind;
     c->tscale = (kind == EMX_TARGET_ROSENBROCK) ? (scale != 0.0 ? scale : 20.0) : 1.0;
     return 0;
@@ -809,6 +842,8 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
     c->moves.assign(moves, moves + nmoves);
     c->cdf.assign(cdf, cdf + nmoves);
     c->prepared.clear();
+    graph_invalidate(c);
+    c->graph_warm = false;
     return 0;
 }
 
@@ -837,6 +872,7 @@ int emx_rng_set_philox(emx_ctx* c, uint64_t seed, uint64_t step) {
     c->ph_seed = seed;
     c->ph_step = step;
     c->prepared.clear();
+    graph_invalidate(c);   // the seed is baked into the captured advance kernel
     return 0;
 }
 
@@ -866,6 +902,7 @@ int emx_chain_config(emx_ctx* c, int64_t cap) {
         }
     }
     HIPOK(c, hipStreamSynchronize(c->stream));
+    graph_invalidate(c);   // captured kernels hold the chain base pointers
     if (c->chain) hipFree(c->chain);
     if (c->chain_lp) hipFree(c->chain_lp);
     c->chain = nc;
@@ -879,6 +916,12 @@ int emx_chain_reset(emx_ctx* c) {
     c->stored = 0;
     c->proposals = 0;
     HIPOK(c, hipMemsetAsync(c->acc_count, 0, (size_t)c->N * 4, c->stream));
+    return 0;
+}
+
+int emx_graph_state(emx_ctx* c, int32_t* disabled, int32_t* captured) {
+    *disabled = c->graph_disabled ? 1 : 0;
+    *captured = (c->gslot[0].valid ? 1 : 0) | (c->gslot[1].valid ? 2 : 0);
     return 0;
 }
 
@@ -1216,6 +1259,104 @@ int emx_step_end(emx_ctx* c) {
     return 0;
 }
 
+static void graph_invalidate(emx_ctx* c) {
+    for (auto& g : c->gslot) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+        g.exec = nullptr;
+        g.graph = nullptr;
+        g.valid = false;
+    }
+}
+
+// Replay NATIVE_BATCH_MAX native steps as ONE hipGraph launch: [k_graph_advance, k_native_plan_batch,
+// S half-steps x 8].  Returns the instantiated graph for this configuration (capturing it on first use),
+// or nullptr when the ordinary launch path must be used.
+static emx_ctx::GraphSlot* graph_ready(emx_ctx* c, int store) {
+    constexpr int NB = NATIVE_BATCH_MAX;
+    if (c->graph_disabled || !c->tune_graph || !c->graph_warm) return nullptr;
+    if (c->rng_mode != EMX_RNG_PHILOX || c->moves.size() != 1 || c->world != 1 || c->comm || c->sendbuf) return nullptr;
+    if (c->prof_max > 0 || c->tune_ablate || c->cur.active || !c->prepared.empty()) return nullptr;
+    if (store && c->stored + NB > c->cap) return nullptr;
+    auto& g = c->gslot[store ? 1 : 0];
+    const emx_move_desc& mv = c->moves[0];
+    if (g.valid && (g.spw != c->tune_spw || g.wpb != c->tune_wpb || g.bpc != c->tune_bpc || g.target != c->target)) graph_invalidate(c);
+    if (!c->d_desc) {
+        if (hipMalloc((void**)&c->d_desc, sizeof(StepDesc) * NB) != hipSuccess ||
+            hipMalloc((void**)&c->d_ctr, sizeof(GraphCounters)) != hipSuccess ||
+            false) {
+            c->graph_disabled = true;
+            return nullptr;
+        }
+    }
+    if (!g.valid) {
+        const int S = mv.nsplits;
+        std::vector<int32_t> off(S + 1, 0);
+        for (int s = 0; s < S; ++s) off[s + 1] = off[s] + (int32_t)((c->N - s + S - 1) / S);
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            c->graph_disabled = true;
+            return nullptr;
+        }
+        bool ok = true;
+        hipLaunchKernelGGL(k_graph_advance, dim3(1), dim3(64), 0, c->stream, c->d_ctr, c->d_desc,
+                           (unsigned long long)c->ph_seed, (int)c->N, NB, store);
+        NativeBatchArgs B{};
+        B.N = (int32_t)c->N;
+        B.D = c->D;
+        B.nb = NB;
+        B.desc = c->d_desc;
+        const int slot0 = PLAN_RING - NB;           // the upper half of the ring is reserved for the graph
+        for (int b = 0; b < NB; ++b) {
+            auto& ps = c->ring[slot0 + b];
+            B.order[b] = ps.order;
+            B.p0[b] = ps.p0;
+            B.p1[b] = ps.p1;
+            B.p2[b] = ps.p2;
+            B.s0[b] = ps.s0;
+            B.uacc[b] = ps.uacc;
+            B.logu[b] = ps.logu;
+            B.fac[b] = ps.fac;
+            B.a[b] = mv.a;
+            B.sigma[b] = mv.sigma;
+            B.g0[b] = mv.g0;
+            B.move[b] = mv.kind;
+            B.S[b] = S;
+        }
+        hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), (unsigned)NB), dim3(256), 0, c->stream, B);
+        NativeArgs nat{};
+        for (int b = 0; b < NB && ok; ++b)
+            for (int sp = 0; sp < S && ok; ++sp) {
+                const int rc = launch_split(c, mv.kind, c->target, S, sp, off[sp], off[sp + 1] - off[sp], 0, off[sp + 1] - off[sp],
+                                            false, true, nat, &mv, &c->ring[slot0 + b], nullptr, c->X, c->lp, nullptr, nullptr,
+                                            nullptr, c->d_desc + b);
+                ok = rc == 0;
+            }
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (!ok || e != hipSuccess || !graph) {
+            if (graph) hipGraphDestroy(graph);
+            c->graph_disabled = true;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        hipGraphExec_t exec = nullptr;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            hipGraphDestroy(graph);
+            c->graph_disabled = true;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        g.graph = graph;
+        g.exec = exec;
+        g.valid = true;
+        g.spw = c->tune_spw;
+        g.wpb = c->tune_wpb;
+        g.bpc = c->tune_bpc;
+        g.target = c->target;
+    }
+    return &g;
+}
+
 int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, thin_by >= 1, "Invalid thinning argument");
@@ -1224,12 +1365,30 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     NEED(c, (c->world == 1 && !c->sendbuf) || c->comm,
          "emx_run on a sharded context needs emx_comm_init (or drive emx_halfstep / the collective from the host layer)");
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
-    int64_t i = 0;
-    for (int64_t it = 0; it < nsteps; ++it)
-        for (int k = 0; k < thin_by; ++k, ++i) {
+    const int64_t total = nsteps * thin_by;
+    bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
+    for (int64_t i = 0; i < total;) {
+        if (thin_by == 1 && total - i >= NATIVE_BATCH_MAX) {
+            emx_ctx::GraphSlot* g = graph_ready(c, store);
+            if (g) {
+                if (!ctr_synced) {
+                    hipLaunchKernelGGL(k_graph_set, dim3(1), dim3(1), 0, c->stream, c->d_ctr, (unsigned long long)c->ph_step,
+                                       (long long)c->stored);
+                    ctr_synced = true;
+                }
+                HIPOK(c, hipGraphLaunch(g->exec, c->stream));      // 8 steps: plan + 8 x nsplits half-steps
+                c->ph_step += NATIVE_BATCH_MAX;
+                c->proposals += NATIVE_BATCH_MAX;
+                if (store) c->stored += NATIVE_BATCH_MAX;
+                i += NATIVE_BATCH_MAX;
+                continue;
+            }
+        }
+        {
             const int st = store && ((i + 1) % thin_by == 0);                   // ensemble.py:416
             int mvi, S;
-            c->prep_hint = nsteps * thin_by - i;
+            c->prep_hint = total - i;
+            if (thin_by == 1 && !c->graph_disabled && c->tune_graph && !c->graph_warm) c->prep_hint = 1;   // graph follows
             int rc = emx_step_begin(c, st, &mvi, &S);
             if (rc) return rc;
             for (int s = 0; s < S; ++s) {
@@ -1251,7 +1410,11 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
             }
             rc = emx_step_end(c);
             if (rc) return rc;
+            c->graph_warm = true;
+            ctr_synced = false;
+            ++i;
         }
+    }
     c->prep_hint = 1;
     return 0;
 }

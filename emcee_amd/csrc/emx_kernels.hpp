@@ -38,6 +38,17 @@ struct NativeArgs {
     PermKey pk;
 };
 
+// hipGraph replay: everything that changes from one replay of the captured 8-step block to the next
+// lives in device memory, written by k_graph_advance (the first node of the graph).
+struct StepDesc {
+    NativeArgs nat;            // seed, step, per-step keyed permutation
+    long long stored_idx;      // chain row this step appends to, -1: not stored
+};
+struct GraphCounters {
+    unsigned long long step_base;
+    long long stored_base;
+};
+
 struct HalfStepArgs {
     // ensemble state
     double* X;            // (N, D) row-major
@@ -78,6 +89,10 @@ struct HalfStepArgs {
     int32_t target;
     int32_t Dp;           // dense: D rounded up to 16
     int32_t ablate;       // timing experiments only (tools/ablate.py): skip-phase bit mask, 0 in production
+    // graph replay: chain row resolved on the device from desc->stored_idx
+    const StepDesc* desc;
+    double* chain_all;
+    double* chain_lp_all;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -451,6 +466,13 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     const int sub = lane / G;
     const int gl = lane % G;
     const int D = A.D;
+    double* chain_ = A.chain;
+    double* chain_lp_ = A.chain_lp;
+    if (A.desc) {      // hipGraph replay: this step's chain row comes from the device-side descriptor
+        const long long sidx_ = A.desc->stored_idx;
+        chain_ = sidx_ >= 0 ? A.chain_all + (size_t)sidx_ * A.N * D : nullptr;
+        chain_lp_ = sidx_ >= 0 ? A.chain_lp_all + (size_t)sidx_ * A.N : nullptr;
+    }
 
     double* Sfrag = smem;
     double* muS = smem + (size_t)Dp * Dp;
@@ -593,12 +615,12 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             }
                             if (live && gl == 0) {
                                 A.acc[i] = accept ? 1 : 0;
-                                if (A.chain_lp) {
-                                    A.chain_lp[i] = accept ? lp_new : lp_old;
+                                if (chain_lp_) {
+                                    chain_lp_[i] = accept ? lp_new : lp_old;
                                     if (accept) A.acc_count[i] += 1u;
                                 }
                             }
-                            if (live && A.chain) store_row<G, V, CH>(accept ? q : xi[k], A.chain + (size_t)i * D, D, gl);
+                            if (live && chain_) store_row<G, V, CH>(accept ? q : xi[k], chain_ + (size_t)i * D, D, gl);
                             if (live && A.sendbuf) {
                                 double* sb = A.sendbuf + (size_t)(t0 + srow - A.t_lo) * (D + 2);
                                 store_row<G, V, CH>(accept ? q : xi[k], sb, D, gl);
@@ -622,7 +644,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         // stored step / sharded run: the current row goes out now (fire and forget); an accepted
                         // proposal overwrites it after the decision -- no reload of rejected rows in the commit
                         if constexpr (MOVE != MOVE_EVAL) {
-                            if (live && A.chain) store_row<G, V, CH>(xi[k], A.chain + (size_t)i * D, D, gl);
+                            if (live && chain_) store_row<G, V, CH>(xi[k], chain_ + (size_t)i * D, D, gl);
                             if (live && A.sendbuf)
                                 store_row<G, V, CH>(xi[k], A.sendbuf + (size_t)(t0 + srow - A.t_lo) * (D + 2), D, gl);
                         }
@@ -696,8 +718,8 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                 A.lp[my_i] = lpn;
                                 lp_fin = lpn;
                             }
-                            if (A.chain_lp) {
-                                A.chain_lp[my_i] = lp_fin;
+                            if (chain_lp_) {
+                                chain_lp_[my_i] = lp_fin;
                                 if (acc) A.acc_count[my_i] += 1u;
                             }
                         }
@@ -737,7 +759,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                     rr.x[c][v] = d < D ? tile[row * RT + d] : 0.0;
                                 }
                             store_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
-                            if (A.chain) store_row<G, V, CH>(rr, A.chain + (size_t)wi2 * D, D, gl);
+                            if (chain_) store_row<G, V, CH>(rr, chain_ + (size_t)wi2 * D, D, gl);
                             if (A.sendbuf) store_row<G, V, CH>(rr, A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2), D, gl);
                         }
                     }
@@ -860,6 +882,7 @@ struct NativeBatchArgs {
     double a[NATIVE_BATCH_MAX], sigma[NATIVE_BATCH_MAX], g0[NATIVE_BATCH_MAX];
     int32_t move[NATIVE_BATCH_MAX], S[NATIVE_BATCH_MAX];
     int32_t N, D, nb;
+    const StepDesc* desc;   // graph replay: per-step NativeArgs from device memory instead of nat[]
 };
 
 __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs B) {
@@ -876,12 +899,13 @@ __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs
     int i, a0, a1, a2;
     double z, u;
     const int mv = B.move[b];
+    const NativeArgs nat = B.desc ? B.desc[b].nat : B.nat[b];
     if (mv == MOVE_STRETCH)
-        native_slot<MOVE_STRETCH>(B.nat[b], N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
+        native_slot<MOVE_STRETCH>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
     else if (mv == MOVE_DE)
-        native_slot<MOVE_DE>(B.nat[b], N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
+        native_slot<MOVE_DE>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
     else
-        native_slot<MOVE_SNOOKER>(B.nat[b], N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
+        native_slot<MOVE_SNOOKER>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
     B.order[b][pos] = i;
     B.p0[b][pos] = a0;
     B.p1[b][pos] = a1;
@@ -890,6 +914,30 @@ __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs
     B.uacc[b][pos] = u;
     B.logu[b][pos] = log(u);
     B.fac[b][pos] = (mv == MOVE_STRETCH) ? ((double)B.D - 1.0) * log(z) : 0.0;
+}
+
+__global__ void k_graph_set(GraphCounters* ctr, unsigned long long step_base, long long stored_base) {
+    ctr->step_base = step_base;
+    ctr->stored_base = stored_base;
+}
+
+// First node of the captured 8-step graph: derive this replay's per-step descriptors from the device
+// counters and advance them (one block; every lane reads the counters before lane 0 updates them).
+__global__ void k_graph_advance(GraphCounters* ctr, StepDesc* desc, unsigned long long seed, int N, int nb, int store) {
+    const int b = threadIdx.x;
+    const unsigned long long base = ctr->step_base;
+    const long long sb = ctr->stored_base;
+    __syncthreads();
+    if (b < nb) {
+        desc[b].nat.seed = seed;
+        desc[b].nat.step = base + (unsigned long long)b;
+        desc[b].nat.pk = make_perm_key((uint64_t)N, seed, base + (unsigned long long)b);
+        desc[b].stored_idx = store ? sb + b : -1;
+    }
+    if (b == 0) {
+        ctr->step_base = base + (unsigned long long)nb;
+        if (store) ctr->stored_base = sb + nb;
+    }
 }
 
 // sharded runs: write the all-gathered [row | log_prob | accepted] records of the other ranks'

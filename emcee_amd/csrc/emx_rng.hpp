@@ -113,13 +113,13 @@ EMX_HD uint32_t perm_inv(uint32_t p, const PermKey& k) {
     return x;
 }
 
-inline uint32_t modinv_pow2(uint32_t a) {  // a odd; inverse mod 2^32 (Newton)
+EMX_HD uint32_t modinv_pow2(uint32_t a) {  // a odd; inverse mod 2^32 (Newton)
     uint32_t x = a;
     for (int i = 0; i < 5; ++i) x *= 2u - a * x;
     return x;
 }
 
-inline PermKey make_perm_key(uint64_t n, uint64_t seed, uint64_t step) {
+EMX_HD PermKey make_perm_key(uint64_t n, uint64_t seed, uint64_t step) {
     PermKey k{};
     k.n = n;
     uint32_t bits = 1;

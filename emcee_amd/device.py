@@ -157,6 +157,11 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_iteration(self.ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def graph_state(self):
+        d, cap = C.c_int32(), C.c_int32()
+        self._ck(self.lib.emx_graph_state(self.ctx, C.byref(d), C.byref(cap)))
+        return bool(d.value), cap.value
+
     def chain_read(self, what, start, stop, stride=1):
         nsel = len(range(start, stop, stride))
         shape = (nsel, self.nwalkers, self.ndim) if what == 0 else (nsel, self.nwalkers)

@@ -235,3 +235,38 @@ def test_nan_log_prob_is_reported():
         ens.eval_state_log_prob()
         ens.raise_on_status()
     ens.close()
+
+
+@pytest.mark.parametrize("name", ["stretch_128x64_dense", "stretch_128x8_rosen", "de_64x4_iso", "snooker_64x4_iso",
+                                  "stretch_nsplits3_45x2"])
+@pytest.mark.parametrize("store", [True, False])
+def test_graph_replay_equals_plain_launches(name, store):
+    """emx_run replays the native 8-step block as a hipGraph; the chain must be bit-identical to
+    the same run issued as plain launches (tuning graph=0), and the graph must really be used."""
+    spec = cases.build(name)
+    spec["weights"] = None
+    spec["moves"] = spec["moves"][:1]
+    outs = []
+    for graph in (0, 1):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(31337, 0)
+        ens.set_tuning("graph", graph)
+        ens.chain_config(64)
+        ens.run(3, 1, store)          # plain
+        ens.run(37, 1, store)         # 1 plain + 4 graph blocks + 4 plain
+        ens.run(20, 1, store)         # counters re-synchronised across calls
+        assert ens.status() == 0
+        disabled, captured = ens.graph_state()
+        if graph:
+            assert not disabled and captured == (2 if store else 1), (disabled, captured)
+        else:
+            assert captured == 0
+        x, lp = ens.get_state()
+        nst = ens.iteration()[0]
+        assert nst == (60 if store else 0) and ens.iteration()[1] == 60
+        outs.append((x, lp, ens.accepted_mask(), ens.chain_read(0, 0, nst), ens.chain_read(1, 0, nst), ens.accepted_counts(),
+                     ens.get_philox()))
+        ens.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
