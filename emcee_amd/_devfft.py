@@ -58,8 +58,7 @@ def integrated_time_device(ens, nstored, discard=0, thin=1, c=5, tol=50, quiet=F
     n_t, n_d = f.shape
     tau_est = np.empty(n_d)
     for d in range(n_d):
-        taus = 2.0 * np.cumsum(f[:, d]) - 1.0
-        tau_est[d] = taus[autocorr.auto_window(taus, c)]
+        _, tau_est[d] = autocorr.tau_from_mean_acf(f[:, d], c)
     flag = tol * tau_est > n_t
     if np.any(flag):
         msg = ("The chain is shorter than {0} times the integrated autocorrelation time for {1} parameter(s). "

@@ -1,9 +1,11 @@
-"""Integrated autocorrelation time (reference ``autocorr.py:11-136``), host side.
+"""Integrated autocorrelation time, host side (API of the reference's ``autocorr`` module).
 
-Same estimator (FFT autocorrelation per walker, averaged over walkers per dimension, Sokal's
-automatic window with step ``c``), but batched: one real FFT over all walkers of a dimension
-instead of the reference's Python loop over walkers.  Not part of the step loop;
-a rocFFT version is the section-8f "next" item."""
+Estimator (reference ``autocorr.py:49-123``, Sokal's recipe): normalised autocorrelation
+function of every walker's series by FFT, averaged over walkers for each parameter, cumulative
+sum ``tau(M) = 2 sum_{t<=M} rho(t) - 1`` and the smallest window ``M >= c tau(M)``.  Here the FFTs
+of all walkers of one parameter are taken in a single batched real transform instead of one
+Python call per walker; ``emcee_amd/_devfft.py`` runs the same thing on the GPU for chains that
+live in HBM."""
 import logging
 
 import numpy as np
@@ -13,74 +15,90 @@ __all__ = ["function_1d", "integrated_time", "AutocorrError"]
 logger = logging.getLogger(__name__)
 
 
+class AutocorrError(Exception):
+    """The chain is too short for a reliable estimate; ``.tau`` holds the current one."""
+
+    def __init__(self, tau, *args, **kwargs):
+        super(AutocorrError, self).__init__(*args, **kwargs)
+        self.tau = tau
+
+
 def next_pow_two(n):
-    """Smallest power of two >= n."""
-    i = 1
-    while i < n:
-        i = i << 1
-    return i
+    """Smallest power of two that is >= n."""
+    p = 1
+    while p < n:
+        p *= 2
+    return p
 
 
-def _acf_columns(x):
-    """Normalised ACF of every column of x (n_t, m)."""
-    n_t = x.shape[0]
-    n = next_pow_two(n_t)
-    f = np.fft.rfft(x - np.mean(x, axis=0), n=2 * n, axis=0)
-    acf = np.fft.irfft(f * np.conjugate(f), n=2 * n, axis=0)[:n_t]
-    acf /= acf[0]
-    return acf
+def _batched_acf(series):
+    """Normalised ACF along axis 0 of a (n_t, m) array, all m columns in one real FFT pair."""
+    n_t = series.shape[0]
+    size = 2 * next_pow_two(n_t)
+    centred = series - series.mean(axis=0)
+    spectrum = np.fft.rfft(centred, n=size, axis=0)
+    power = spectrum.real ** 2 + spectrum.imag ** 2
+    acf = np.fft.irfft(power, n=size, axis=0)[:n_t]
+    return acf / acf[0]
 
 
 def function_1d(x):
-    """Normalised autocorrelation function of a 1-D series."""
+    """Normalised autocorrelation function of one 1-d time series."""
     x = np.atleast_1d(x)
-    if len(x.shape) != 1:
+    if x.ndim != 1:
         raise ValueError("invalid dimensions for 1D autocorrelation function")
-    return _acf_columns(x[:, None].astype(float))[:, 0]
+    return _batched_acf(np.asarray(x, dtype=float).reshape(-1, 1)).ravel()
 
 
 def auto_window(taus, c):
-    m = np.arange(len(taus)) < c * taus
-    if np.any(m):
-        return np.argmin(m)
-    return len(taus) - 1
+    """Sokal's automatic window: the first lag M with M >= c * tau(M).
+
+    Degenerate inputs follow the reference (``autocorr.py:42-46``) exactly: if no lag is below
+    ``c * tau`` at all the last lag is used, and if every lag is below it the window is 0."""
+    below = np.arange(len(taus)) < c * taus
+    if not below.any():
+        return len(taus) - 1
+    reached = np.flatnonzero(~below)
+    return int(reached[0]) if len(reached) else 0
+
+
+def _as_steps_walkers_params(x, has_walkers):
+    x = np.atleast_1d(x)
+    if x.ndim == 1:
+        return x[:, None, None]
+    if x.ndim == 2:
+        return x[:, :, None] if has_walkers else x[:, None, :]
+    if x.ndim == 3:
+        return x
+    raise ValueError("invalid dimensions")
+
+
+def tau_from_mean_acf(rho, c):
+    """(window, tau) from a walker-averaged ACF of one parameter."""
+    taus = 2.0 * np.cumsum(rho) - 1.0
+    w = auto_window(taus, c)
+    return w, taus[w]
 
 
 def integrated_time(x, c=5, tol=50, quiet=False, has_walkers=True):
-    """Estimate the integrated autocorrelation time of a (n_step, n_walker, n_param) series.
+    """Integrated autocorrelation time per parameter of ``x``.
 
-    Same arguments, return value and :class:`AutocorrError` behaviour as the reference
-    (``autocorr.py:49-123``)."""
-    x = np.atleast_1d(x)
-    if len(x.shape) == 1:
-        x = x[:, np.newaxis, np.newaxis]
-    if len(x.shape) == 2:
-        x = x[:, np.newaxis, :] if not has_walkers else x[:, :, np.newaxis]
-    if len(x.shape) != 3:
-        raise ValueError("invalid dimensions")
-    n_t, n_w, n_d = x.shape
+    ``x`` is ``(n_step,)``, ``(n_step, n_walker)`` (or ``(n_step, n_param)`` with
+    ``has_walkers=False``) or ``(n_step, n_walker, n_param)``.  ``c`` is the window step, ``tol`` the
+    number of autocorrelation times the chain must span; shorter chains raise
+    :class:`AutocorrError` (or only warn when ``quiet``)."""
+    chain = _as_steps_walkers_params(x, has_walkers)
+    n_t, _, n_d = chain.shape
     tau_est = np.empty(n_d)
-    windows = np.empty(n_d, dtype=int)
     for d in range(n_d):
-        f = np.mean(_acf_columns(np.asarray(x[:, :, d], dtype=float)), axis=1)
-        taus = 2.0 * np.cumsum(f) - 1.0
-        windows[d] = auto_window(taus, c)
-        tau_est[d] = taus[windows[d]]
-    flag = tol * tau_est > n_t
-    if np.any(flag):
+        rho = _batched_acf(np.asarray(chain[:, :, d], dtype=float)).mean(axis=1)
+        _, tau_est[d] = tau_from_mean_acf(rho, c)
+    too_short = tol * tau_est > n_t
+    if too_short.any():
         msg = ("The chain is shorter than {0} times the integrated autocorrelation time for {1} parameter(s). "
-               "Use this estimate with caution and run a longer chain!\n").format(tol, np.sum(flag))
+               "Use this estimate with caution and run a longer chain!\n").format(tol, int(too_short.sum()))
         msg += "N/{0} = {1:.0f};\ntau: {2}".format(tol, n_t / tol, tau_est)
         if not quiet:
             raise AutocorrError(tau_est, msg)
         logger.warning(msg)
     return tau_est
-
-
-class AutocorrError(Exception):
-    """Raised if the chain is too short to estimate an autocorrelation time; the current
-    estimate is available as ``.tau``."""
-
-    def __init__(self, tau, *args, **kwargs):
-        self.tau = tau
-        super(AutocorrError, self).__init__(*args, **kwargs)

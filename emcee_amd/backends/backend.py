@@ -23,7 +23,7 @@ class Backend(object):
 
     # ---- lifecycle ----
     def reset(self, nwalkers, ndim):
-        """Clear the state of the chain and empty the backend."""
+        """Forget every stored sample and size the backend for ``(nwalkers, ndim)``."""
         self.nwalkers = int(nwalkers)
         self.ndim = int(ndim)
         self._iteration = 0
@@ -100,7 +100,7 @@ class Backend(object):
         self._log_prob = v
 
     def has_blobs(self):
-        """Returns ``True`` if the model includes blobs"""
+        """Whether blob storage has been set up (the log-prob function returns metadata)."""
         return self.blobs is not None
 
     def get_value(self, name, flat=False, thin=1, discard=0):
@@ -121,19 +121,23 @@ class Backend(object):
         return v
 
     def get_chain(self, **kwargs):
-        """Get the stored chain of MCMC samples (``flat``, ``thin``, ``discard`` as in the reference)."""
+        """Stored samples, ``(nsteps, nwalkers, ndim)``.
+
+        Keyword arguments (all optional): ``flat`` merges the step and walker axes, ``thin`` keeps
+        every thin-th stored step, ``discard`` drops that many initial steps (burn-in)."""
         return self.get_value("chain", **kwargs)
 
     def get_blobs(self, **kwargs):
-        """Get the chain of blobs for each sample in the chain."""
+        """Stored blobs, one per walker and step (``None`` when the model has none); same
+        ``flat`` / ``thin`` / ``discard`` keywords as :meth:`get_chain`."""
         return self.get_value("blobs", **kwargs)
 
     def get_log_prob(self, **kwargs):
-        """Get the chain of log probabilities evaluated at the MCMC samples."""
+        """Stored log-probabilities, ``(nsteps, nwalkers)``; same keywords as :meth:`get_chain`."""
         return self.get_value("log_prob", **kwargs)
 
     def get_last_sample(self):
-        """Access the most recent sample in the chain"""
+        """The most recently stored step as a :class:`State` (with the RNG state saved alongside)."""
         if (not self.initialized) or self.iteration <= 0:
             raise AttributeError("you must run the sampler with 'store == True' before accessing the results")
         it = self.iteration
@@ -160,7 +164,7 @@ class Backend(object):
 
     @property
     def shape(self):
-        """The dimensions of the ensemble ``(nwalkers, ndim)``"""
+        """``(nwalkers, ndim)`` of the ensemble this backend was reset for."""
         return self.nwalkers, self.ndim
 
     # ---- growth / saving ----
@@ -172,7 +176,8 @@ class Backend(object):
             raise ValueError("inconsistent use of blobs")
 
     def grow(self, ngrow, blobs):
-        """Expand the storage space by ``ngrow`` samples (reference backend.py:164-185)."""
+        """Make room for ``ngrow`` more steps (reference backend.py:164-185); ``blobs`` (the current
+        blob array or None) fixes the blob dtype on first use."""
         self._check_blobs(blobs)
         it = self.iteration
         if self._dev is not None:
@@ -193,24 +198,24 @@ class Backend(object):
         del have
 
     def _check(self, state, accepted):
+        """Shape / blob consistency of a step about to be saved (reference backend.py:187-212)."""
         self._check_blobs(state.blobs)
         nwalkers, ndim = self.shape
-        has_blobs = self.has_blobs()
-        if state.coords.shape != (nwalkers, ndim):
-            raise ValueError("invalid coordinate dimensions; expected {0}".format((nwalkers, ndim)))
-        if state.log_prob.shape != (nwalkers,):
-            raise ValueError("invalid log probability size; expected {0}".format(nwalkers))
-        if state.blobs is not None and not has_blobs:
-            raise ValueError("unexpected blobs")
-        if state.blobs is None and has_blobs:
-            raise ValueError("expected blobs, but none were given")
-        if state.blobs is not None and len(state.blobs) != nwalkers:
-            raise ValueError("invalid blobs size; expected {0}".format(nwalkers))
-        if accepted.shape != (nwalkers,):
-            raise ValueError("invalid acceptance size; expected {0}".format(nwalkers))
+        expect = (
+            (state.coords.shape == (nwalkers, ndim), "invalid coordinate dimensions; expected {0}".format((nwalkers, ndim))),
+            (state.log_prob.shape == (nwalkers,), "invalid log probability size; expected {0}".format(nwalkers)),
+            (state.blobs is None or self.has_blobs(), "unexpected blobs"),
+            (state.blobs is not None or not self.has_blobs(), "expected blobs, but none were given"),
+            (state.blobs is None or len(state.blobs) == nwalkers, "invalid blobs size; expected {0}".format(nwalkers)),
+            (accepted.shape == (nwalkers,), "invalid acceptance size; expected {0}".format(nwalkers)),
+        )
+        for ok, message in expect:
+            if not ok:
+                raise ValueError(message)
 
     def save_step(self, state, accepted):
-        """Save a step to the (host) backend: reference backend.py:214-231."""
+        """Append ``state`` and add ``accepted`` to the per-walker counters -- the host-side path
+        (user-written moves, foreign samplers); reference backend.py:214-231."""
         if self._dev is not None:
             self._detach()
         self._check(state, accepted)

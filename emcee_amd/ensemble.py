@@ -79,14 +79,12 @@ class EnsembleSampler(object):
                  a=None, postargs=None, threads=None, live_dangerously=None, runtime_sortingfn=None,
                  # emcee_amd extensions
                  rng="mt19937", device=0):
-        if a is not None:
-            deprecation_warning("The 'a' argument is deprecated, use 'moves' instead")
-        if threads is not None:
-            deprecation_warning("The 'threads' argument is deprecated")
-        if runtime_sortingfn is not None:
-            deprecation_warning("The 'runtime_sortingfn' argument is deprecated")
-        if live_dangerously is not None:
-            deprecation_warning("The 'live_dangerously' argument is deprecated")
+        for value, text in ((a, "The 'a' argument is deprecated, use 'moves' instead"),
+                            (threads, "The 'threads' argument is deprecated"),
+                            (runtime_sortingfn, "The 'runtime_sortingfn' argument is deprecated"),
+                            (live_dangerously, "The 'live_dangerously' argument is deprecated")):
+            if value is not None:
+                deprecation_warning(text)
 
         # move schedule (reference ensemble.py:115-129)
         if moves is None:
@@ -143,22 +141,8 @@ class EnsembleSampler(object):
 
         self.params_are_named = parameter_names is not None
         if self.params_are_named:
-            assert isinstance(parameter_names, (list, dict))
             assert not self.vectorize, "named parameters with vectorization unsupported for now"
-            seen, uniq = set(), []
-            for name in parameter_names:
-                if name not in seen:
-                    uniq.append(name)
-                    seen.add(name)
-            assert len(uniq) == len(parameter_names), f"duplicate parameters: {seen}"
-            if isinstance(parameter_names, list):
-                assert len(parameter_names) == ndim, "name all parameters or set `parameter_names` to `None`"
-                parameter_names = {name: i for i, name in enumerate(parameter_names)}
-            assert len(parameter_names) <= ndim, "too many names"
-            values = [v if isinstance(v, list) else [v] for v in parameter_names.values()]
-            values = set(item for sub in values for item in sub)
-            assert values == set(np.arange(ndim)), f"not all values appear -- set should be 0 to {ndim-1}"
-            self.parameter_names = parameter_names
+            self.parameter_names = _normalize_parameter_names(parameter_names, ndim)
 
     # ------------------------------------------------------------------ RNG / bookkeeping
     @property
@@ -268,21 +252,7 @@ class EnsembleSampler(object):
                 raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice "
                                    "the number of dimensions.")
 
-        if thin is not None:
-            deprecation_warning("The 'thin' argument is deprecated. Use 'thin_by' instead.")
-            thin = int(thin)
-            if thin <= 0:
-                raise ValueError("Invalid thinning argument")
-            yield_step = 1
-            checkpoint_step = thin
-            nsaves = None if iterations is None else iterations // checkpoint_step
-        else:
-            thin_by = int(thin_by)
-            if thin_by <= 0:
-                raise ValueError("Invalid thinning argument")
-            yield_step = thin_by
-            checkpoint_step = thin_by
-            nsaves = iterations
+        yield_step, checkpoint_step, nsaves = _thinning_plan(iterations, thin_by, thin)
 
         ens = None
         if native:
@@ -478,43 +448,10 @@ class EnsembleSampler(object):
         if self.vectorize:
             results = self.log_prob_fn(p)
         else:
-            map_func = self.pool.map if self.pool is not None else map
-            results = list(map_func(self.log_prob_fn, p))
+            mapper = map if self.pool is None else self.pool.map
+            results = list(mapper(self.log_prob_fn, p))
 
-        try:
-            blob = [l[1:] for l in results if len(l) > 1]       # noqa: E741
-            if not len(blob):
-                raise IndexError
-            log_prob = np.array([_scalar(l[0]) for l in results])   # noqa: E741
-        except (IndexError, TypeError):
-            log_prob = np.array([_scalar(l) for l in results])      # noqa: E741
-            blob = None
-        else:
-            if self.blobs_dtype is not None:
-                dt = self.blobs_dtype
-            else:
-                try:
-                    with warnings.catch_warnings(record=True):
-                        warnings.simplefilter("error", VisibleDeprecationWarning)
-                        try:
-                            dt = np.atleast_1d(blob[0]).dtype
-                        except Warning:
-                            deprecation_warning("You have provided blobs that are not all the same shape or size. "
-                                                "This means they must be placed in an object array. Numpy has "
-                                                "deprecated this automatic detection, so please specify "
-                                                "blobs_dtype=np.dtype('object')")
-                            dt = np.dtype("object")
-                except ValueError:
-                    dt = np.dtype("object")
-                if dt.kind in "US":
-                    dt = np.dtype("object")
-            blob = np.array(blob, dtype=dt)
-            shape = blob.shape[1:]
-            if len(shape):
-                axes = np.arange(len(shape))[np.array(shape) == 1] + 1
-                if len(axes):
-                    blob = np.squeeze(blob, tuple(axes))
-
+        log_prob, blob = _split_log_prob_and_blobs(results, self.blobs_dtype)
         if np.any(np.isnan(log_prob)):
             raise ValueError("Probability function returned NaN")
         return log_prob, blob
@@ -549,31 +486,22 @@ class EnsembleSampler(object):
     get_last_sample.__doc__ = Backend.get_last_sample.__doc__
     get_autocorr_time.__doc__ = Backend.get_autocorr_time.__doc__
 
-    # deprecated aliases of the reference (ensemble.py:560-595)
-    @property
-    def chain(self):  # pragma: no cover
-        deprecation_warning("chain is deprecated, use get_chain() instead")
-        return np.swapaxes(self.get_chain(), 0, 1)
-
-    @property
-    def flatchain(self):  # pragma: no cover
-        deprecation_warning("flatchain is deprecated, use get_chain(flat=True) instead")
-        return self.get_chain(flat=True)
-
-    @property
-    def lnprobability(self):  # pragma: no cover
-        deprecation_warning("lnprobability is deprecated, use get_log_prob() instead")
-        return np.swapaxes(self.get_log_prob(), 0, 1)
-
-    @property
-    def flatlnprobability(self):  # pragma: no cover
-        deprecation_warning("flatlnprobability is deprecated, use get_log_prob(flat=True) instead")
-        return self.get_log_prob(flat=True)
-
-    @property
-    def acor(self):  # pragma: no cover
-        deprecation_warning("acor is deprecated, use get_autocorr_time() instead")
-        return self.get_autocorr_time()
+    # deprecated attribute spellings of emcee 2.x (reference ensemble.py:560-595)
+    def __getattr__(self, name):
+        legacy = {
+            "chain": ("get_chain()", lambda s: np.swapaxes(s.get_chain(), 0, 1)),
+            "flatchain": ("get_chain(flat=True)", lambda s: s.get_chain(flat=True)),
+            "lnprobability": ("get_log_prob()", lambda s: np.swapaxes(s.get_log_prob(), 0, 1)),
+            "flatlnprobability": ("get_log_prob(flat=True)", lambda s: s.get_log_prob(flat=True)),
+            "blobs": ("get_blobs()", lambda s: s.get_blobs()),
+            "flatblobs": ("get_blobs(flat=True)", lambda s: s.get_blobs(flat=True)),
+            "acor": ("get_autocorr_time", lambda s: s.get_autocorr_time()),
+        }
+        if name in legacy:
+            replacement, getter = legacy[name]
+            deprecation_warning("{0} is deprecated, use {1} instead".format(name, replacement))
+            return getter(self)
+        raise AttributeError("{0!r} object has no attribute {1!r}".format(type(self).__name__, name))
 
 
 class _FunctionWrapper(object):
@@ -596,6 +524,80 @@ class _FunctionWrapper(object):
             print("  exception:")
             traceback.print_exc()
             raise
+
+
+def _thinning_plan(iterations, thin_by, thin):
+    """-> (steps per yield, steps per stored sample, number of samples to allocate).
+
+    ``thin_by=k`` makes k proposals per yielded / stored sample; the deprecated ``thin=k`` yields
+    every step but stores only every k-th (reference ``ensemble.py:360-386``)."""
+    if thin is None:
+        k = int(thin_by)
+        if k <= 0:
+            raise ValueError("Invalid thinning argument")
+        return k, k, iterations
+    deprecation_warning("The 'thin' argument is deprecated. Use 'thin_by' instead.")
+    k = int(thin)
+    if k <= 0:
+        raise ValueError("Invalid thinning argument")
+    return 1, k, (None if iterations is None else iterations // k)
+
+
+def _normalize_parameter_names(parameter_names, ndim):
+    """Validate ``parameter_names`` (list of names, or dict name -> index / list of indices) and
+    return the dict form.  Same rules as the reference (``ensemble.py:173-214``): no duplicate
+    names, a list must name every dimension, and the indices must cover 0..ndim-1 exactly."""
+    assert isinstance(parameter_names, (list, dict))
+    names = list(parameter_names)
+    dupes = {n for n in names if names.count(n) > 1}
+    assert not dupes, f"duplicate parameters: {dupes}"
+    if isinstance(parameter_names, list):
+        assert len(names) == ndim, "name all parameters or set `parameter_names` to `None`"
+        parameter_names = dict(zip(names, range(ndim)))
+    assert len(parameter_names) <= ndim, "too many names"
+    covered = set()
+    for idx in parameter_names.values():
+        covered.update(idx if isinstance(idx, list) else [idx])
+    assert covered == set(range(ndim)), f"not all values appear -- set should be 0 to {ndim-1}"
+    return parameter_names
+
+
+def _blob_dtype(first_blob):
+    """dtype for the blob array when the user gave none: the first blob's own dtype, falling back
+    to ``object`` for ragged or string blobs (reference ``ensemble.py:514-539``)."""
+    try:
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("error", VisibleDeprecationWarning)
+            try:
+                dt = np.atleast_1d(first_blob).dtype
+            except Warning:
+                deprecation_warning("You have provided blobs that are not all the same shape or size. This means "
+                                    "they must be placed in an object array. Numpy has deprecated this automatic "
+                                    "detection, so please specify blobs_dtype=np.dtype('object')")
+                return np.dtype("object")
+    except ValueError:
+        return np.dtype("object")
+    return np.dtype("object") if dt.kind in "US" else dt
+
+
+def _split_log_prob_and_blobs(results, blobs_dtype):
+    """``log_prob_fn`` may return a scalar or ``(log_prob, blob, ...)`` per walker; separate the two
+    (reference ``ensemble.py:498-547``).  Returns ``(log_prob array, blob array or None)``."""
+    try:
+        blobs = [r[1:] for r in results if len(r) > 1]
+        has_blobs = len(blobs) > 0
+    except (IndexError, TypeError):          # scalars have no len()
+        has_blobs = False
+    if not has_blobs:
+        return np.array([_scalar(r) for r in results]), None
+    log_prob = np.array([_scalar(r[0]) for r in results])
+    dt = blobs_dtype if blobs_dtype is not None else _blob_dtype(blobs[0])
+    blob = np.array(blobs, dtype=dt)
+    # (nwalkers, 1, ...) -> (nwalkers, ...): a single blob per walker is not wrapped
+    unit_axes = tuple(ax for ax in range(1, blob.ndim) if blob.shape[ax] == 1)
+    if unit_axes:
+        blob = np.squeeze(blob, unit_axes)
+    return log_prob, blob
 
 
 def walkers_independent(coords):

@@ -1,34 +1,54 @@
-"""Progress bar shim (reference ``pbar.py``): tqdm when available, otherwise a no-op."""
+"""Progress reporting for ``EnsembleSampler.sample(progress=...)``.
+
+Same contract as the reference's ``pbar.get_progress_bar`` (a context manager with an
+``update(n)`` method; ``progress`` may be ``False``, ``True`` or the name of a tqdm flavour such as
+``"notebook"``), implemented as one small adapter class."""
+import importlib
 import logging
 
 __all__ = ["get_progress_bar"]
 
 logger = logging.getLogger(__name__)
 
-try:
-    import tqdm
-except ImportError:  # pragma: no cover
-    tqdm = None
 
+class _Progress(object):
+    """Context manager wrapping an optional tqdm instance."""
 
-class _NoOpPBar(object):
-    def __enter__(self, *a, **k):
+    def __init__(self, bar=None):
+        self._bar = bar
+
+    def __enter__(self):
+        if self._bar is not None:
+            self._bar.__enter__()
         return self
 
-    def __exit__(self, *a, **k):
-        pass
+    def __exit__(self, *exc):
+        if self._bar is not None:
+            return self._bar.__exit__(*exc)
+        return False
 
     def update(self, count):
-        pass
+        if self._bar is not None:
+            self._bar.update(count)
+
+
+def _tqdm_factory(flavour):
+    """tqdm.tqdm for True, tqdm.<flavour>.tqdm for a string; None when tqdm is not installed."""
+    try:
+        tqdm = importlib.import_module("tqdm")
+    except ImportError:
+        return None
+    if flavour is True:
+        return tqdm.tqdm
+    return getattr(tqdm, "tqdm_" + str(flavour))
 
 
 def get_progress_bar(display, total, **kwargs):
-    """``display``: False -> no bar; True -> tqdm; a string selects ``tqdm.<name>.tqdm``."""
-    if display:
-        if tqdm is None:
-            logger.warning("You must install the tqdm library to use progress indicators with emcee")
-            return _NoOpPBar()
-        if display is True:
-            return tqdm.tqdm(total=total, **kwargs)
-        return getattr(tqdm, "tqdm_" + display)(total=total, **kwargs)
-    return _NoOpPBar()
+    """Return a progress context for ``total`` steps (``None`` = unknown length)."""
+    if not display:
+        return _Progress()
+    factory = _tqdm_factory(display)
+    if factory is None:
+        logger.warning("You must install the tqdm library to use progress indicators with emcee")
+        return _Progress()
+    return _Progress(factory(total=total, **kwargs))
