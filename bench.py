@@ -137,7 +137,7 @@ def main():
         ens.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels + RCCL ordered on one stream
         eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank))
         stepper = ShardedStepper(eng, lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group))
-        return lambda k: stepper.run(k, 1, args.store)
+        return lambda k, st=None: stepper.run(k, 1, args.store if st is None else st)
 
     comm_used = None
     if sharded and args.comm == "torch":
@@ -156,7 +156,7 @@ def main():
         flag = torch.tensor([ok])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 1:
-            run = lambda k: ens.run(k, 1, args.store)  # noqa: E731
+            run = lambda k, st=None: ens.run(k, 1, args.store if st is None else st)  # noqa: E731
             comm_used = "libemx->RCCL"
         else:
             try:
@@ -166,7 +166,7 @@ def main():
             run = torch_path(dist.new_group(backend="nccl"))
             comm_used = "torch.distributed(nccl) [fallback]"
     else:
-        run = lambda k: ens.run(k, 1, args.store)  # noqa: E731
+        run = lambda k, st=None: ens.run(k, 1, args.store if st is None else st)  # noqa: E731
 
     def fence():
         ens.sync()
@@ -177,10 +177,15 @@ def main():
 
     # Untimed spin-up before the contract's W warm-up steps: the first ~50 ms of work on a fresh context run
     # slower (clock ramp, first touch of the plan ring, lazy code-object loading); tools/stall_probe.py.
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < (0.15 if not sharded else 0.5):
-        run(50 if not sharded else 5)
-        ens.sync()
+    if sharded:
+        for _ in range(10):            # a FIXED count: every rank must issue the same collectives
+            run(5, False)
+            ens.sync()
+    else:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.15:
+            run(50, False)
+            ens.sync()
     run(W)
     fence()
     ens.timer_start()
