@@ -26,20 +26,6 @@ std::string g_err;
 
 constexpr int PLAN_RING = 16;
 
-struct HostPlan {  // plan-order arrays of one step
-    std::vector<int32_t> off, order, p0, p1, p2;
-    std::vector<double> s0, uacc;
-    void resize(int64_t N, int S) {
-        off.assign(S + 1, 0);
-        order.resize(N);
-        p0.resize(N);
-        p1.resize(N);
-        p2.resize(N);
-        s0.resize(N);
-        uacc.resize(N);
-    }
-};
-
 // ------------------------------------------------------------------------------------------
 // exact (NumPy-stream) plan of one step: every draw red_blue.py / stretch.py / de.py /
 // de_snooker.py make for one propose(), in their order.
@@ -436,8 +422,8 @@ int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
 }
 
 // launch one fused (or propose-only) half-step over the slots [t_lo, t_hi) of `split`
-int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, int ns, int t_lo, int t_hi, bool native,
-                 bool plan_has_logs, const NativeArgs& nat, const emx_move_desc* mv, const emx_ctx::PlanSlot* ps, const int32_t* order,
+int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, int ns, int t_lo, int t_hi,
+                 const emx_move_desc* mv, const emx_ctx::PlanSlot* ps, const int32_t* order,
                  double* X, double* lp, double* chain, double* chain_lp, double* sendbuf,
                  const StepDesc* step_desc = nullptr) {
     if (t_hi <= t_lo) return 0;
@@ -489,7 +475,6 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.uacc = ps ? ps->uacc : nullptr;
     a.logu = ps ? ps->logu : nullptr;
     a.fac = ps ? ps->fac : nullptr;
-    (void)plan_has_logs;
     a.tp0 = c->tp0;
     a.tp1 = c->tp1;
     a.tscale = c->tscale;
@@ -499,7 +484,6 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         a.g0 = mv->g0;
         a.gammas = mv->gammas;
     }
-    a.nat = nat;
     a.N = (int32_t)c->N;
     a.D = D;
     a.S = S;
@@ -509,7 +493,6 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.t_lo = t_lo;
     a.t_hi = t_hi;
     a.spw = (int32_t)spw;
-    a.native = native ? 1 : 0;
     a.target = target;
     a.Dp = dense ? c->Dp : 16;
     a.ablate = (int32_t)c->tune_ablate;
@@ -818,12 +801,9 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
 
 static int eval_rows(emx_ctx* c, double* X, double* lp, int64_t n) {
     NEED(c, c->target != EMX_TARGET_HOST, "no device target set");
-    NativeArgs nat{};
     emx_move_desc mv = c->moves[0];
-    const int64_t saveN = c->N;
-    int rc = launch_split(c, MOVE_EVAL, c->target, 1, 0, 0, (int)n, 0, (int)n, false, false, nat, &mv, nullptr, c->iota, X, lp,
+    int rc = launch_split(c, MOVE_EVAL, c->target, 1, 0, 0, (int)n, 0, (int)n, &mv, nullptr, c->iota, X, lp,
                           nullptr, nullptr, nullptr);
-    (void)saveN;
     return rc;
 }
 
@@ -1181,7 +1161,7 @@ static int do_halfstep(emx_ctx* c, int split, int target) {
     emx_ctx::PlanSlot* ps = cur.slot >= 0 ? &c->ring[cur.slot] : nullptr;
     double* sb = nullptr;
     if (c->sendbuf && target != EMX_TARGET_HOST) sb = c->sendbuf;
-    return launch_split(c, mv.kind, target, cur.S, split, pos0, ns, (int)lo, (int)hi, false, cur.native, cur.nat, &mv, ps,
+    return launch_split(c, mv.kind, target, cur.S, split, pos0, ns, (int)lo, (int)hi, &mv, ps,
                         nullptr, c->X, c->lp, chain, chain_lp, sb);
 }
 
@@ -1229,14 +1209,12 @@ int emx_accept(emx_ctx* c, int32_t split, const double* new_lp) {
     a.new_lp = c->newlp;
     a.order = cur.slot >= 0 ? c->ring[cur.slot].order : nullptr;
     a.uacc = cur.slot >= 0 ? c->ring[cur.slot].uacc : nullptr;
-    a.nat = cur.nat;
     a.N = (int32_t)c->N;
     a.D = c->D;
     a.S = cur.S;
     a.split = split;
     a.pos0 = pos0;
     a.ns = ns;
-    a.native = 0;   // order / uacc come from the plan slot in every mode
     a.move = c->moves[cur.move].kind;
     hipLaunchKernelGGL(k_accept, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, c->stream, a);
     HIPOK(c, hipGetLastError());
@@ -1336,12 +1314,11 @@ static emx_ctx::GraphSlot* graph_ready(emx_ctx* c, int store) {
             B.S[b] = S;
         }
         hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), (unsigned)NB), dim3(256), 0, c->stream, B);
-        NativeArgs nat{};
         for (int b = 0; b < NB && ok; ++b)
             for (int sp = 0; sp < S && ok; ++sp) {
                 const int rc = launch_split(c, mv.kind, c->target, S, sp, off[sp], off[sp + 1] - off[sp], 0, off[sp + 1] - off[sp],
-                                            false, true, nat, &mv, &c->ring[slot0 + b], nullptr, c->X, c->lp, nullptr, nullptr,
-                                            nullptr, c->d_desc + b);
+                                            &mv, &c->ring[slot0 + b], nullptr, c->X, c->lp, nullptr, nullptr, nullptr,
+                                            c->d_desc + b);
                 ok = rc == 0;
             }
         hipGraph_t graph = nullptr;
@@ -1538,7 +1515,6 @@ int emx_scatter_gathered(emx_ctx* c, int32_t split) {
         // block r starts at record r * sendbuf_rows and holds slot lo first: shift so that slot t indexes directly
         a.gathered = c->gathered + ((int64_t)r * c->sendbuf_rows - lo) * rec;
         a.order = cur.slot >= 0 ? c->ring[cur.slot].order : nullptr;
-        a.nat = cur.nat;
         a.N = (int32_t)c->N;
         a.D = c->D;
         a.S = cur.S;
@@ -1546,7 +1522,6 @@ int emx_scatter_gathered(emx_ctx* c, int32_t split) {
         a.pos0 = cur.off[split];
         a.t_lo = (int32_t)lo;
         a.t_hi = (int32_t)hi;
-        a.native = 0;
         hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((hi - lo + 3) / 4)), dim3(256), 0, c->stream, a);
         HIPOK(c, hipGetLastError());
     }

@@ -80,12 +80,10 @@ struct HalfStepArgs {
     double a;             // stretch scale
     double sigma, g0;     // DE
     double gammas;        // snooker
-    NativeArgs nat;
     int32_t N, D, S, split;
     int32_t pos0, ns;     // first plan position / number of slots of this split
     int32_t t_lo, t_hi;   // slots updated by this rank
     int32_t spw;          // slots per wave
-    int32_t native;       // unused by k_halfstep (plans always come from a plan slot); kept for ABI stability
     int32_t target;
     int32_t Dp;           // dense: D rounded up to 16
     int32_t ablate;       // timing experiments only (tools/ablate.py): skip-phase bit mask, 0 in production
@@ -797,25 +795,15 @@ struct AcceptArgs {
     const double* new_lp;
     const int32_t* order;
     const double* uacc;
-    NativeArgs nat;
-    int32_t N, D, S, split, pos0, ns, native, move;
+    int32_t N, D, S, split, pos0, ns, move;
 };
 
 __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= A.ns) return;
-    int i;
-    double uacc;
-    if (A.native) {
-        int a0, a1, a2;
-        double s0;
-        // only i and uacc are needed; they do not depend on the move
-        native_slot<MOVE_EVAL>(A.nat, A.N, A.S, A.split, t, 2.0, 0.0, 0.0, i, a0, a1, a2, s0, uacc);
-    } else {
-        i = A.order[A.pos0 + t];
-        uacc = A.uacc[A.pos0 + t];
-    }
+    const int i = A.order[A.pos0 + t];
+    const double uacc = A.uacc[A.pos0 + t];
     const double nlp = A.new_lp[t];
     const double lp_old = A.lp[i];
     if (nlp != nlp) atomicOr(A.status, ST_NAN_LOGP);
@@ -837,37 +825,11 @@ __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
     }
 }
 
-// Native-mode plan of one step, evaluated full width (one lane per walker): the Philox rounds, the
-// keyed-permutation inversions and the two f64 logs are paid once per walker here instead of on the
-// few active lanes of the half-step kernel's phase A.  Also what emx_plan_get returns to the tests.
-template <int MOVE>
-__global__ void k_native_plan(NativeArgs nat, int N, int S, int D, double a, double sigma, double g0, int32_t* order,
-                              int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc, double* logu,
-                              double* fac) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= N) return;
-    int split = 0, t = pos;
-    for (int s = 0; s < S; ++s) {
-        const int n = (N - s + S - 1) / S;
-        if (t < n) { split = s; break; }
-        t -= n;
-    }
-    int i, a0, a1, a2;
-    double z, u;
-    native_slot<MOVE>(nat, N, S, split, t, a, sigma, g0, i, a0, a1, a2, z, u);
-    order[pos] = i;
-    p0[pos] = a0;
-    p1[pos] = a1;
-    p2[pos] = a2;
-    s0[pos] = z;
-    uacc[pos] = u;
-    logu[pos] = log(u);
-    fac[pos] = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
-}
-
-// Native plans of up to 8 consecutive steps in ONE launch (grid.y = step): a single step's plan is
-// only N lanes of latency-bound work (Philox, permutation inversions, two logs), so batching fills the
-// machine and amortises the launch.
+// Native-mode plans, evaluated full width (one lane per walker and step): the Philox rounds, the keyed-
+// permutation inversions and the two f64 logs are paid once per walker here, not on the few lanes a
+// half-step group would spare.  Up to 8 consecutive steps per launch (grid.y = step): one step is only N
+// lanes of latency-bound work, so batching fills the machine and amortises the launch.  emx_plan_get
+// returns these arrays to the parity tests.
 constexpr int NATIVE_BATCH_MAX = 8;
 struct NativeBatchArgs {
     NativeArgs nat[NATIVE_BATCH_MAX];
@@ -951,19 +913,14 @@ struct ScatterArgs {
     double* chain_lp;
     const double* gathered;   // virtual (ns, D + 2) array in slot order
     const int32_t* order;
-    NativeArgs nat;
-    int32_t N, D, S, split, pos0, t_lo, t_hi, native;
+    int32_t N, D, S, split, pos0, t_lo, t_hi;
 };
 
 __global__ __launch_bounds__(256) void k_scatter_rows(const ScatterArgs A) {
     const int lane = threadIdx.x & 63;
     const int t = A.t_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= A.t_hi) return;
-    int i;
-    if (A.native)
-        i = (int)perm_inv((uint32_t)(t * A.S + A.split), A.nat.pk);
-    else
-        i = A.order[A.pos0 + t];
+    const int i = A.order[A.pos0 + t];
     const double* src = A.gathered + (size_t)t * (A.D + 2);
     double* dst = A.X + (size_t)i * A.D;
     for (int d = lane; d < A.D; d += 64) dst[d] = src[d];
