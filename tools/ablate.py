@@ -34,7 +34,7 @@ def run(ablate, wpb=8, bpc=2, N=65536, D=64, steps=200, target="dense"):
 
 
 if __name__ == "__main__":
-    names = {0: "full", 1: "no MFMA loop", 4: "no tile writes", 8: "no commit", 16: "no MFMA+decision stage"}
+    names = {0: "full", 64: "empty kernels (launch floor)", 128: "plan+row loads only", 16: "no MFMA+decision stage", 1: "no MFMA loop", 8: "no commit"}
     for rep in range(2):
         for ab, nm in names.items():
             print("ablate=%-3d %-34s %.2f us/step" % (ab, nm, run(ab)), flush=True)
