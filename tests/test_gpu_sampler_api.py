@@ -367,3 +367,63 @@ def test_device_autocorr_equals_host_estimator():
     np.testing.assert_allclose(s.get_autocorr_time(quiet=True), autocorr.integrated_time(s.get_chain(), quiet=True), rtol=1e-8)
     with pytest.raises(autocorr.AutocorrError):
         s.get_autocorr_time(tol=1e6)
+
+
+def test_reference_move_instances_are_recognised_by_duck_typing():
+    """A move object that *is* reference emcee's StretchMove / DEMove (same class name, module
+    ``emcee.moves...``, un-overridden get_proposal) takes the fused device path."""
+    from emcee_amd.ensemble import _native_desc
+
+    def ref_like(name, module, **attrs):
+        def get_proposal(self, s, c, random):          # never called on the device path
+            raise AssertionError("host get_proposal must not run for a built-in move")
+        klass = type(name, (object,), {"get_proposal": get_proposal, "__module__": module})
+        obj = klass()
+        obj.nsplits, obj.randomize_split, obj.live_dangerously = 2, True, False
+        for k, v in attrs.items():
+            setattr(obj, k, v)
+        return obj
+
+    st = ref_like("StretchMove", "emcee.moves.stretch", a=2.5)
+    de = ref_like("DEMove", "emcee.moves.de", sigma=1e-5, gamma0=None)
+    d = _native_desc(st, 4)
+    assert d is not None and d.kind == 0 and d.a == 2.5
+    d = _native_desc(de, 8)
+    assert d is not None and d.kind == 1 and abs(d.g0 - 2.38 / 4.0) < 1e-15
+    assert _native_desc(ref_like("WalkMove", "emcee.moves.walk"), 4) is None
+    assert _native_desc(ref_like("StretchMove", "mypkg.moves", a=2.0), 4) is None
+
+    np.random.seed(3)
+    p0 = np.random.randn(32, 4)
+    a = emcee_amd.EnsembleSampler(32, 4, targets.IsoGaussian(), moves=st)
+    a._random.seed(9)
+    a.run_mcmc(p0, 12)
+    b = emcee_amd.EnsembleSampler(32, 4, targets.IsoGaussian(), moves=moves.StretchMove(a=2.5))
+    b._random.seed(9)
+    b.run_mcmc(p0, 12)
+    assert np.array_equal(a.get_chain(), b.get_chain())
+
+
+def test_resume_reset_growth_and_thinned_acceptance():
+    np.random.seed(8)
+    p0 = np.random.randn(64, 3)
+    s = emcee_amd.EnsembleSampler(64, 3, targets.IsoGaussian())
+    s._random.seed(4)
+    s.run_mcmc(p0, 7)
+    s.run_mcmc(None, 5, thin_by=2)                 # chain grows on the device, 10 more proposals
+    s.run_mcmc(None, 3, store=False)
+    assert s.iteration == 12 and s.get_chain().shape == (12, 64, 3)
+    full = emcee_amd.EnsembleSampler(64, 3, targets.IsoGaussian())
+    full._random.seed(4)
+    full.run_mcmc(p0, 17)
+    c = full.get_chain()
+    assert np.array_equal(s.get_chain()[:7], c[:7])
+    assert np.array_equal(s.get_chain()[7:], c[8:17:2])
+    # backend.accepted only counts the stored proposals (reference backend.py:229 behind ensemble.py:416)
+    moved_stored = np.concatenate([np.any(np.diff(np.concatenate([p0[None], c[:7]]), axis=0) != 0, axis=2),
+                                   np.any(c[8:17:2] != c[7:16:2], axis=2)]).sum(axis=0)
+    assert np.array_equal(s.backend.accepted, moved_stored)
+    s.reset()
+    assert s.iteration == 0
+    s.run_mcmc(p0, 4)
+    assert s.get_chain().shape == (4, 64, 3)
