@@ -12,11 +12,27 @@ DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-fPIC", "-shared"]
 
 
+HASHFILE = LIB + ".srchash"
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def stale():
-    if not os.path.exists(LIB):
+    """True when libemx.so is missing or was built from different sources / flags.  Content based
+    (not mtime based) so that a snapshot copied to another box is not rebuilt needlessly."""
+    if not os.path.exists(LIB) or not os.path.exists(HASHFILE):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+    try:
+        return open(HASHFILE).read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
@@ -29,6 +45,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+    with open(HASHFILE, "w") as f:
+        f.write(_source_hash() + "\n")
     return LIB
 
 
