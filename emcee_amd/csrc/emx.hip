@@ -351,9 +351,11 @@ namespace {
 template <int G, int V, int CH, int MOVE, int DPB>
 hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
     auto kern = k_halfstep<G, V, CH, MOVE, DPB>;
-    if (lds > 48 * 1024) {
+    static size_t lds_granted = 0;      // per instantiation: raise the dynamic-LDS limit once, not per launch
+    if (lds > 48 * 1024 && lds > lds_granted) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        lds_granted = lds;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     return hipGetLastError();
