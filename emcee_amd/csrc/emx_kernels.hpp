@@ -680,9 +680,11 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                 if (A.target != TGT_NONE && tile_done && !(A.ablate & 16)) {
                     // ---- one 16-row tile: Y = R Sinv by v_mfma_f64_16x16x4_f64 (R = Q - mu), qf[w] = sum_n Y[w][n] R[w][n] ----
                     const int tb = (plast / PPT) * 16;                  // first slot of the tile
-                    // lanes 0..15 <-> the tile's rows: their walker and decision scalars (L1/L2-hot lines)
-                    const int myrow = lane & 15;
-                    const bool mine = lane < 16 && tb + myrow < nslot;
+                    // decision lanes: the 16 lanes with (lane & 15) < 4.  After the row reduction lane (am, ak) holds the
+                    // totals of tile rows ak + 4 r, so lane (am = r, ak) decides row ak + 4 r from its own registers
+                    // (no LDS round trip).  Their walker and decision scalars are L1/L2-hot lines.
+                    const int myrow = (lane >> 4) + 4 * (lane & 3);
+                    const bool mine = (lane & 15) < 4 && tb + myrow < nslot;
                     const int mypos = pbase + (tb + myrow < nslot ? tb + myrow : 0);
                     const int my_i = A.order[mypos];
                     double my_lpo = 0.0, my_logu = 0.0;
@@ -691,6 +693,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         my_logu = A.logu[mypos];
                     }
                     EMX_WAVE_SYNC();                     // this wave's tile rows are visible to all of its lanes
+                    double my_qf = 0.0;
                     {
                         // Y = R L (R = Q - mu, 16 x Dp) by v_mfma_f64_16x16x4_f64; L is lower triangular, so the
                         // k-steps below the diagonal block of column block nb vanish; qf[w] = sum_n Y[w][n]^2
@@ -713,17 +716,16 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
                         }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double tot = group_sum<16>(part[r]);       // over the 16 columns held by this row of lanes
-                            if (am == 0) qfS[ak + 4 * r] = tot;
-                        }
+                        for (int r = 0; r < 4; ++r) part[r] = group_sum<16>(part[r]);   // over the 16 columns held by this row of lanes
+                        my_qf = part[0];
+#pragma unroll
+                        for (int r = 1; r < 4; ++r) my_qf = (am == r) ? part[r] : my_qf;
                     }
-                    EMX_WAVE_SYNC();
-                    // ---- decisions for the (up to) 16 rows of this tile on lanes 0..15 ----
+                    // ---- decisions for the (up to) 16 rows of this tile ----
                     bool acc = false;
                     double lp_fin = my_lpo;
                     if (mine) {
-                        const double lpn = -0.5 * qfS[myrow];
+                        const double lpn = -0.5 * my_qf;
                         if (lpn != lpn) atomicOr(A.status, ST_NAN_LOGP);
                         if constexpr (MOVE == MOVE_EVAL) {
                             A.lp[my_i] = lpn;
@@ -742,15 +744,15 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         }
                     }
                     if constexpr (MOVE != MOVE_EVAL) {
-                        const unsigned long long am64 = __ballot(acc);       // bit r <-> tile row r
-                        if (A.sendbuf && lane < 16) qfS[myrow] = lp_fin;
+                        const unsigned long long am64 = __ballot(acc);       // bit (row & 3) * 16 + (row >> 2) <-> tile row
+                        if (A.sendbuf && (lane & 15) < 4) qfS[myrow] = lp_fin;
                         if (A.sendbuf) EMX_WAVE_SYNC();
                         // commit the tile's rows in the (G, V, CH) row layout: accepted rows come from LDS
                         for (int pp = 0; pp < ((A.ablate & 8) ? 0 : PPT); ++pp) {
                             const int row = pp * WPW + sub;              // 0..15
                             const int sidx = tb + row;
                             const bool lv = sidx < nslot;
-                            const bool ac = lv && ((am64 >> row) & 1ull);
+                            const bool ac = lv && ((am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull);
                             if (!lv) continue;
                             if (A.sendbuf && gl == 0) {
                                 double* sb = A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2);

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--thin-by", type=int, default=5)
     ap.add_argument("--burn", type=int, default=2000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--moves", default="stretch", choices=["stretch", "mix"], help="mix = DEMove 0.8 + DESnookerMove 0.2 (BASELINE config 4)")
     a = ap.parse_args()
     N, D = a.nwalkers, a.ndim
     mu, cov, icov = dense_gaussian(D)
@@ -52,7 +53,8 @@ def main():
         from oracle import ref_shim
         emcee = ref_shim.import_reference()
         lp = lambda x: -0.5 * np.einsum("ij,ij->i", (x - mu) @ icov, x - mu)  # noqa: E731
-        s = emcee.EnsembleSampler(N, D, lp, vectorize=True)
+        mv = None if a.moves == "stretch" else [(emcee.moves.DEMove(), 0.8), (emcee.moves.DESnookerMove(), 0.2)]
+        s = emcee.EnsembleSampler(N, D, lp, vectorize=True, moves=mv)
         s._random.seed(11)
         t0 = time.time()
         st = s.run_mcmc(p0, a.burn, skip_initial_state_check=True, store=False)
@@ -62,7 +64,8 @@ def main():
     if a.gpu:
         import emcee_amd
         for rng in ("philox", "mt19937"):
-            s = emcee_amd.EnsembleSampler(N, D, emcee_amd.targets.DenseGaussian(mu, icov), rng=rng)
+            mv = None if a.moves == "stretch" else [(emcee_amd.moves.DEMove(), 0.8), (emcee_amd.moves.DESnookerMove(), 0.2)]
+            s = emcee_amd.EnsembleSampler(N, D, emcee_amd.targets.DenseGaussian(mu, icov), rng=rng, moves=mv)
             s._random.seed(12)
             t0 = time.time()
             st = s.run_mcmc(p0, a.burn, skip_initial_state_check=True, store=False)
