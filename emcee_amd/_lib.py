@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(HERE, "libemx.so")
 TARGET_HOST, TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_ROSENBROCK, TARGET_BOX = range(6)
 MOVE_STRETCH, MOVE_DE, MOVE_SNOOKER = range(3)
 RNG_INPUTS, RNG_MT19937, RNG_PHILOX = range(3)
+EXCHANGE_ALLGATHER, EXCHANGE_PULL = range(2)
 
 
 class MoveDesc(C.Structure):
@@ -75,6 +76,15 @@ SIGNATURES = {
     "emx_device_ptr": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "emx_shard_slots": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "emx_scatter_gathered": (C.c_int, [_P, C.c_int32]),
+    "emx_set_exchange": (C.c_int, [_P, C.c_int32]),
+    "emx_exchange_layout": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "emx_set_exchange_buffers": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
+    "emx_own_walkers": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "emx_pull_prepare": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64)]),
+    "emx_pull_apply": (C.c_int, [_P, C.c_int32]),
+    "emx_replica_pack": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "emx_replica_unpack": (C.c_int, [_P]),
+    "emx_host_pull_capacity": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "emx_comm_load": (C.c_int, [C.c_char_p]),
     "emx_comm_get_unique_id": (C.c_int, [_u8p]),
     "emx_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, _u8p]),

@@ -174,6 +174,11 @@ struct RcclApi {
     int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllToAll)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;     // RCCL extension
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 } g_rccl;
 constexpr int RCCL_FLOAT64 = 8;   // ncclFloat64 (rccl.h:467)
@@ -195,6 +200,11 @@ int rccl_load(const char* path, std::string& err) {
     g_rccl.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.AllToAll = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllToAll");
+    g_rccl.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+    g_rccl.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+    g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
         err = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllGather";
@@ -295,6 +305,16 @@ struct emx_ctx {
     int64_t sendbuf_rows = 0, gathered_rows = 0;
     bool own_shard_bufs = false;
     void* comm = nullptr;   // ncclComm_t when the exchange is driven from here (emx_comm_init)
+    int64_t send_doubles = 0, recv_doubles = 0;     // capacity of sendbuf / gathered
+    // pull exchange (walker-block ownership)
+    int exchange = EMX_EXCHANGE_ALLGATHER;
+    PlanSlot cplan;                   // compact plan: the slots whose walker this rank owns
+    int64_t cplan_rows = 0;
+    int32_t* pull_counts = nullptr;   // [1 + world]
+    int32_t* pull_sendidx = nullptr;  // [world][pull_idx_cap]
+    int64_t pull_idx_cap = 0;
+    int64_t pull_cap_cur = 0;         // records per pair of the prepared half-step
+    int pull_split = -1;
     // hipGraph replay of the native 8-step block (single move, thin_by 1, one rank)
     struct GraphSlot {
         hipGraph_t graph = nullptr;
@@ -427,7 +447,7 @@ int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
 int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, int ns, int t_lo, int t_hi,
                  const emx_move_desc* mv, const emx_ctx::PlanSlot* ps, const int32_t* order,
                  double* X, double* lp, double* chain, double* chain_lp, double* sendbuf,
-                 const StepDesc* step_desc = nullptr) {
+                 const StepDesc* step_desc = nullptr, const int32_t* t_hi_dev = nullptr) {
     if (t_hi <= t_lo) return 0;
     const bool dense = target == EMX_TARGET_DENSE_GAUSS;
     const int D = c->D;
@@ -501,6 +521,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.desc = step_desc;
     a.chain_all = c->chain;
     a.chain_lp_all = c->chain_lp;
+    a.t_hi_dev = t_hi_dev;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;
     if (prof) {
@@ -657,6 +678,12 @@ int emx_destroy(emx_ctx* c) {
     for (auto& g : c->gslot) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
+    }
+    {
+        auto& p = c->cplan;
+        void* q[] = {p.order, p.p0, p.p1, p.p2, p.s0, p.uacc, p.logu, p.fac, c->pull_counts, c->pull_sendidx};
+        for (void* x : q)
+            if (x) hipFree(x);
     }
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_ctr) hipFree(c->d_ctr);
@@ -1161,8 +1188,10 @@ static int do_halfstep(emx_ctx* c, int split, int target) {
         chain_lp = c->chain_lp + (size_t)c->stored * c->N;
     }
     emx_ctx::PlanSlot* ps = cur.slot >= 0 ? &c->ring[cur.slot] : nullptr;
+    NEED(c, c->exchange != EMX_EXCHANGE_PULL || c->world == 1 || target == EMX_TARGET_HOST,
+         "pull exchange: use emx_pull_prepare / emx_pull_apply");
     double* sb = nullptr;
-    if (c->sendbuf && target != EMX_TARGET_HOST) sb = c->sendbuf;
+    if (c->sendbuf && target != EMX_TARGET_HOST && c->exchange == EMX_EXCHANGE_ALLGATHER) sb = c->sendbuf;
     return launch_split(c, mv.kind, target, cur.S, split, pos0, ns, (int)lo, (int)hi, &mv, ps,
                         nullptr, c->X, c->lp, chain, chain_lp, sb);
 }
@@ -1349,6 +1378,27 @@ static emx_ctx::GraphSlot* graph_ready(emx_ctx* c, int store) {
     return &g;
 }
 
+// `count` doubles per pair from sendbuf block q to rank q's gathered block `rank` (RCCL's all-to-all when the
+// library has it, grouped send/recv otherwise)
+static int rccl_all_to_all(emx_ctx* c, size_t count) {
+    int e = 0;
+    if (g_rccl.AllToAll) {
+        e = g_rccl.AllToAll(c->sendbuf, c->gathered, count, RCCL_FLOAT64, c->comm, c->stream);
+    } else {
+        NEED(c, g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd, "librccl lacks ncclSend/ncclRecv");
+        e = g_rccl.GroupStart();
+        for (int q = 0; q < c->world && e == 0; ++q) {
+            if (q == c->rank) continue;
+            e = g_rccl.Send(c->sendbuf + (size_t)q * count, count, RCCL_FLOAT64, q, c->comm, c->stream);
+            if (e == 0) e = g_rccl.Recv(c->gathered + (size_t)q * count, count, RCCL_FLOAT64, q, c->comm, c->stream);
+        }
+        const int e2 = g_rccl.GroupEnd();
+        if (e == 0) e = e2;
+    }
+    if (e != 0) FAIL(c, -6, "RCCL all-to-all failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return 0;
+}
+
 int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, thin_by >= 1, "Invalid thinning argument");
@@ -1399,6 +1449,18 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
             int rc = emx_step_begin(c, st, &mvi, &S);
             if (rc) return rc;
             for (int s = 0; s < S; ++s) {
+                if (c->comm && c->exchange == EMX_EXCHANGE_PULL) {
+                    // partner rows only: pack what the peers will read, all-to-all, fold in, update own walkers
+                    int64_t cap = 0;
+                    rc = emx_pull_prepare(c, s, &cap);
+                    if (!rc) rc = rccl_all_to_all(c, (size_t)cap * (c->D + 1));
+                    if (!rc) rc = emx_pull_apply(c, s);
+                    if (rc) {
+                        c->cur.active = false;
+                        return rc;
+                    }
+                    continue;
+                }
                 rc = do_halfstep(c, s, c->target);
                 if (!rc && c->comm) {
                     // the one exchange per half-step: every rank's [row | log_prob | accepted] records to every rank
@@ -1423,6 +1485,16 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
         }
     }
     c->prep_hint = 1;
+    if (c->comm && c->exchange == EMX_EXCHANGE_PULL) {
+        // re-synchronise the replicas: every rank's block of (coords, log_prob, accepted) to every rank
+        int64_t per = 0;
+        int rc = emx_replica_pack(c, &per);
+        if (rc) return rc;
+        const int e = g_rccl.AllGather(c->sendbuf, c->gathered, (size_t)per * (c->D + 3), RCCL_FLOAT64, c->comm, c->stream);
+        if (e != 0) FAIL(c, -6, "ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+        rc = emx_replica_unpack(c);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -1432,12 +1504,27 @@ static int64_t shard_rows_per_rank(int64_t N, int world) {
     return (maxns + world - 1) / world + 1;
 }
 
-int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
-    HIPOK(c, hipSetDevice(c->device));
-    NEED(c, world >= 1 && rank >= 0 && rank < world, "bad (rank, world)");
-    HIPOK(c, hipStreamSynchronize(c->stream));
-    c->rank = rank;
-    c->world = world;
+static int partners_of(int kind) { return kind == EMX_MOVE_STRETCH ? 1 : kind == EMX_MOVE_DE ? 2 : 3; }
+
+// Pull exchange: records one rank may have to send another in one half-step.  Each of the ~N/(S G) walkers
+// a rank updates reads `npart` partners whose owner is uniform over the ranks: mean + 8 sigma + slack,
+// never more than every partner of every walker the destination could be updating.
+static int64_t pull_capacity(int64_t N, int G, int S, int npart) {
+    if (G <= 1) return 1;
+    const int64_t bmax = (N + G - 1) / G, nsmax = (N + S - 1) / S;
+    const int64_t hard = (int64_t)npart * std::min(bmax, nsmax);
+    const double mean = (double)npart * (double)N / S / G / G;
+    const int64_t cap = (int64_t)std::ceil(mean + 8.0 * std::sqrt(mean) + 64.0);
+    return std::max<int64_t>(1, std::min(cap, hard));
+}
+
+static int64_t pull_capacity_max(const emx_ctx* c) {
+    int64_t cap = 1;
+    for (const auto& m : c->moves) cap = std::max(cap, pull_capacity(c->N, c->world, m.nsplits, partners_of(m.kind)));
+    return cap;
+}
+
+static void exchange_free(emx_ctx* c) {
     if (c->own_shard_bufs) {
         if (c->sendbuf) hipFree(c->sendbuf);
         if (c->gathered) hipFree(c->gathered);
@@ -1445,6 +1532,80 @@ int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
     c->sendbuf = c->gathered = nullptr;
     c->own_shard_bufs = false;
     c->sendbuf_rows = c->gathered_rows = 0;
+    c->send_doubles = c->recv_doubles = 0;
+}
+
+static void pull_layout(const emx_ctx* c, int64_t& send, int64_t& recv) {
+    const int64_t G = c->world, bmax = (c->N + G - 1) / G;
+    const int64_t pairs = G * pull_capacity_max(c) * (c->D + 1);
+    send = std::max<int64_t>(pairs, bmax * (c->D + 3));
+    recv = std::max<int64_t>(pairs, G * bmax * (c->D + 3));
+}
+
+// (re)allocate what the pull exchange needs for the installed moves; own exchange buffers grow on demand,
+// caller-owned ones must already be large enough
+static int pull_ensure(emx_ctx* c) {
+    const int64_t G = c->world, bmax = (c->N + G - 1) / G;
+    if (c->cplan_rows < bmax) {
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        auto& p = c->cplan;
+        void* old[] = {p.order, p.p0, p.p1, p.p2, p.s0, p.uacc, p.logu, p.fac};
+        for (void* q : old)
+            if (q) hipFree(q);
+        HIPOK(c, hipMalloc((void**)&p.order, bmax * 4));
+        HIPOK(c, hipMalloc((void**)&p.p0, bmax * 4));
+        HIPOK(c, hipMalloc((void**)&p.p1, bmax * 4));
+        HIPOK(c, hipMalloc((void**)&p.p2, bmax * 4));
+        HIPOK(c, hipMalloc((void**)&p.s0, bmax * 8));
+        HIPOK(c, hipMalloc((void**)&p.uacc, bmax * 8));
+        HIPOK(c, hipMalloc((void**)&p.logu, bmax * 8));
+        HIPOK(c, hipMalloc((void**)&p.fac, bmax * 8));
+        c->cplan_rows = bmax;
+    }
+    const int64_t capmax = pull_capacity_max(c);
+    if (!c->pull_counts || c->pull_idx_cap < capmax) {
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        if (c->pull_counts) hipFree(c->pull_counts);
+        if (c->pull_sendidx) hipFree(c->pull_sendidx);
+        c->pull_counts = c->pull_sendidx = nullptr;
+        HIPOK(c, hipMalloc((void**)&c->pull_counts, (size_t)(1 + G) * 4));
+        HIPOK(c, hipMalloc((void**)&c->pull_sendidx, (size_t)G * capmax * 4));
+        c->pull_idx_cap = capmax;
+    }
+    int64_t send, recv;
+    pull_layout(c, send, recv);
+    if (c->send_doubles < send || c->recv_doubles < recv) {
+        NEED(c, c->own_shard_bufs || !c->sendbuf,
+             "pull exchange: caller-owned buffers too small for the installed moves (need %lld / %lld doubles)",
+             (long long)send, (long long)recv);
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        exchange_free(c);
+        HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)send * 8));
+        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)recv * 8));
+        c->own_shard_bufs = true;
+        c->send_doubles = send;
+        c->recv_doubles = recv;
+    }
+    return 0;
+}
+
+int emx_set_exchange(emx_ctx* c, int32_t kind) {
+    NEED(c, kind == EMX_EXCHANGE_ALLGATHER || kind == EMX_EXCHANGE_PULL, "unknown exchange kind %d", kind);
+    NEED(c, c->world == 1 && !c->comm && !c->sendbuf, "emx_set_exchange: call it before emx_set_shard / emx_comm_init");
+    c->exchange = kind;
+    return 0;
+}
+
+int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, world >= 1 && rank >= 0 && rank < world, "bad (rank, world)");
+    NEED(c, world <= c->N, "more ranks than walkers");
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    c->rank = rank;
+    c->world = world;
+    exchange_free(c);
+    c->pull_split = -1;
+    if (c->exchange == EMX_EXCHANGE_PULL) return world > 1 ? pull_ensure(c) : 0;
     if (world > 1) {
         const int64_t per = shard_rows_per_rank(c->N, world);
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));
@@ -1452,23 +1613,195 @@ int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
         c->own_shard_bufs = true;
         c->sendbuf_rows = per;
         c->gathered_rows = per * world;
+        c->send_doubles = per * (c->D + 2);
+        c->recv_doubles = per * world * (c->D + 2);
     }
     return 0;
 }
 
 int emx_set_shard_buffers(emx_ctx* c, void* sendbuf, void* gathered, int64_t rows_per_rank) {
     NEED(c, c->world >= 1, "emx_set_shard_buffers: call emx_set_shard first");
+    NEED(c, c->exchange == EMX_EXCHANGE_ALLGATHER, "pull exchange: use emx_set_exchange_buffers");
     NEED(c, rows_per_rank >= shard_rows_per_rank(c->N, c->world), "shard buffers too small");
     HIPOK(c, hipStreamSynchronize(c->stream));
-    if (c->own_shard_bufs) {
-        if (c->sendbuf) hipFree(c->sendbuf);
-        if (c->gathered) hipFree(c->gathered);
-        c->own_shard_bufs = false;
-    }
+    exchange_free(c);
     c->sendbuf = (double*)sendbuf;
     c->gathered = (double*)gathered;
     c->sendbuf_rows = rows_per_rank;
     c->gathered_rows = rows_per_rank * c->world;
+    c->send_doubles = rows_per_rank * (c->D + 2);
+    c->recv_doubles = c->gathered_rows * (c->D + 2);
+    return 0;
+}
+
+int emx_exchange_layout(emx_ctx* c, int64_t* send_doubles, int64_t* recv_doubles) {
+    if (c->exchange == EMX_EXCHANGE_PULL) {
+        pull_layout(c, *send_doubles, *recv_doubles);
+    } else {
+        const int64_t per = shard_rows_per_rank(c->N, c->world);
+        *send_doubles = per * (c->D + 2);
+        *recv_doubles = per * c->world * (c->D + 2);
+    }
+    return 0;
+}
+
+int emx_set_exchange_buffers(emx_ctx* c, void* send, int64_t send_doubles, void* recv, int64_t recv_doubles) {
+    NEED(c, c->exchange == EMX_EXCHANGE_PULL, "emx_set_exchange_buffers is for the pull exchange");
+    int64_t ns, nr;
+    pull_layout(c, ns, nr);
+    NEED(c, send && recv && send_doubles >= ns && recv_doubles >= nr, "exchange buffers too small (need %lld / %lld doubles)",
+         (long long)ns, (long long)nr);
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    exchange_free(c);
+    c->sendbuf = (double*)send;
+    c->gathered = (double*)recv;
+    c->send_doubles = send_doubles;
+    c->recv_doubles = recv_doubles;
+    return 0;
+}
+
+int emx_own_walkers(emx_ctx* c, int64_t* lo, int64_t* hi) {
+    *lo = c->N * c->rank / c->world;
+    *hi = c->N * (c->rank + 1) / c->world;
+    return 0;
+}
+
+int emx_pull_prepare(emx_ctx* c, int32_t split, int64_t* records_per_peer) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, c->exchange == EMX_EXCHANGE_PULL, "emx_pull_prepare needs emx_set_exchange(EMX_EXCHANGE_PULL)");
+    NEED(c, cur.active && cur.move >= 0 && cur.slot >= 0, "emx_pull_prepare outside a planned step");
+    NEED(c, split >= 0 && split < cur.S, "split out of range");
+    NEED(c, c->target != EMX_TARGET_HOST, "sharded stepping needs a device target");
+    int rc = pull_ensure(c);
+    if (rc) return rc;
+    const emx_move_desc& mv = c->moves[cur.move];
+    const auto& ps = c->ring[cur.slot];
+    const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
+    const int npart = partners_of(mv.kind);
+    const int64_t cap = pull_capacity(c->N, c->world, cur.S, npart);
+    HIPOK(c, hipMemsetAsync(c->pull_counts, 0, (size_t)(1 + c->world) * 4, c->stream));
+    if (ns > 0) {
+        PullPlanArgs a{};
+        a.order = ps.order + pos0;
+        a.p0 = ps.p0 + pos0;
+        a.p1 = ps.p1 + pos0;
+        a.p2 = ps.p2 + pos0;
+        a.s0 = ps.s0 + pos0;
+        a.uacc = ps.uacc + pos0;
+        a.logu = ps.logu + pos0;
+        a.fac = ps.fac + pos0;
+        a.corder = c->cplan.order;
+        a.cp0 = c->cplan.p0;
+        a.cp1 = c->cplan.p1;
+        a.cp2 = c->cplan.p2;
+        a.cs0 = c->cplan.s0;
+        a.cuacc = c->cplan.uacc;
+        a.clogu = c->cplan.logu;
+        a.cfac = c->cplan.fac;
+        a.counts = c->pull_counts;
+        a.sendidx = c->pull_sendidx;
+        a.status = c->status;
+        a.N = (int32_t)c->N;
+        a.G = c->world;
+        a.rank = c->rank;
+        a.ns = ns;
+        a.npart = npart;
+        a.cap = (int32_t)cap;
+        hipLaunchKernelGGL(k_pull_plan, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, a);
+        HIPOK(c, hipGetLastError());
+    }
+    if (c->world > 1) {
+        PullRowsArgs r{};
+        r.X = c->X;
+        r.rec = c->sendbuf;
+        r.counts = c->pull_counts;
+        r.sendidx = c->pull_sendidx;
+        r.N = (int32_t)c->N;
+        r.D = c->D;
+        r.G = c->world;
+        r.rank = c->rank;
+        r.cap = (int32_t)cap;
+        const int64_t nrec = (int64_t)c->world * cap;
+        hipLaunchKernelGGL(k_pull_pack, dim3((unsigned)((nrec + 15) / 16)), dim3(256), 0, c->stream, r);
+        HIPOK(c, hipGetLastError());
+    }
+    c->pull_cap_cur = cap;
+    c->pull_split = split;
+    if (records_per_peer) *records_per_peer = cap;
+    return 0;
+}
+
+int emx_pull_apply(emx_ctx* c, int32_t split) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, cur.active && c->pull_split == split, "emx_pull_apply: emx_pull_prepare(%d) has not run", split);
+    const emx_move_desc& mv = c->moves[cur.move];
+    const int ns = cur.off[split + 1] - cur.off[split];
+    c->pull_split = -1;
+    if (c->world > 1) {
+        PullRowsArgs r{};
+        r.X = c->X;
+        r.rec = c->gathered;
+        r.N = (int32_t)c->N;
+        r.D = c->D;
+        r.G = c->world;
+        r.rank = c->rank;
+        r.cap = (int32_t)c->pull_cap_cur;
+        const int64_t nrec = (int64_t)c->world * c->pull_cap_cur;
+        hipLaunchKernelGGL(k_pull_scatter, dim3((unsigned)((nrec + 15) / 16)), dim3(256), 0, c->stream, r);
+        HIPOK(c, hipGetLastError());
+    }
+    if (ns <= 0) return 0;
+    // the grid is sized for the expected number of owned slots (the kernel's batch loop covers any count;
+    // the count itself is read on the device)
+    const int64_t G = c->world, bmax = (c->N + G - 1) / G;
+    const double mean = (double)ns / G;
+    int64_t bound = (int64_t)std::ceil(mean + 8.0 * std::sqrt(mean) + 64.0);
+    bound = std::max<int64_t>(1, std::min<int64_t>(bound, std::min<int64_t>(bmax, ns)));
+    double *chain = nullptr, *chain_lp = nullptr;
+    if (cur.store) {
+        chain = c->chain + (size_t)c->stored * c->N * c->D;
+        chain_lp = c->chain_lp + (size_t)c->stored * c->N;
+    }
+    return launch_split(c, mv.kind, c->target, cur.S, split, 0, (int)bound, 0, (int)bound, &mv, &c->cplan, nullptr, c->X,
+                        c->lp, chain, chain_lp, nullptr, nullptr, c->pull_counts);
+}
+
+static void block_args(emx_ctx* c, BlockArgs& a, double* rec) {
+    a.X = c->X;
+    a.lp = c->lp;
+    a.acc = c->acc;
+    a.acc_count = c->acc_count;
+    a.rec = rec;
+    a.N = (int32_t)c->N;
+    a.D = c->D;
+    a.G = c->world;
+    a.rank = c->rank;
+    a.bmax = (int32_t)((c->N + c->world - 1) / c->world);
+}
+
+int emx_replica_pack(emx_ctx* c, int64_t* records_per_rank) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, c->exchange == EMX_EXCHANGE_PULL, "emx_replica_pack is for the pull exchange");
+    int rc = pull_ensure(c);
+    if (rc) return rc;
+    BlockArgs a{};
+    block_args(c, a, c->sendbuf);
+    hipLaunchKernelGGL(k_block_pack, dim3((unsigned)((a.bmax + 15) / 16)), dim3(256), 0, c->stream, a);
+    HIPOK(c, hipGetLastError());
+    if (records_per_rank) *records_per_rank = a.bmax;
+    return 0;
+}
+
+int emx_replica_unpack(emx_ctx* c) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, c->exchange == EMX_EXCHANGE_PULL && c->gathered, "emx_replica_unpack is for the pull exchange");
+    BlockArgs a{};
+    block_args(c, a, c->gathered);
+    const int64_t nrec = (int64_t)a.G * a.bmax;
+    hipLaunchKernelGGL(k_block_unpack, dim3((unsigned)((nrec + 15) / 16)), dim3(256), 0, c->stream, a);
+    HIPOK(c, hipGetLastError());
     return 0;
 }
 
@@ -1476,8 +1809,8 @@ int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
     switch (which) {
         case 0: *ptr = c->X; *nbytes = c->N * c->D * 8; return 0;
         case 1: *ptr = c->lp; *nbytes = c->N * 8; return 0;
-        case 2: *ptr = c->sendbuf; *nbytes = c->sendbuf_rows * (c->D + 2) * 8; return 0;
-        case 3: *ptr = c->gathered; *nbytes = c->gathered_rows * (c->D + 2) * 8; return 0;
+        case 2: *ptr = c->sendbuf; *nbytes = c->send_doubles * 8; return 0;
+        case 3: *ptr = c->gathered; *nbytes = c->recv_doubles * 8; return 0;
         case 4: *ptr = c->chain; *nbytes = c->stored * c->N * c->D * 8; return 0;
         case 5: *ptr = c->chain_lp; *nbytes = c->stored * c->N * 8; return 0;
     }
@@ -1561,13 +1894,17 @@ int emx_comm_init(emx_ctx* c, int32_t rank, int32_t world, const uint8_t id[128]
     NEED(c, !c->comm, "communicator already initialised");
     int rc = emx_set_shard(c, rank, world);
     if (rc) return rc;
-    if (!c->sendbuf) {   // world == 1: still exercise the exchange buffers
+    if (c->exchange == EMX_EXCHANGE_PULL) {
+        rc = pull_ensure(c);
+        if (rc) return rc;
+    } else if (!c->sendbuf) {   // world == 1: still exercise the exchange buffers
         const int64_t per = (c->N + 1) / 2 + 2;
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));
         HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * (c->D + 2) * 8));
         c->own_shard_bufs = true;
         c->sendbuf_rows = per;
         c->gathered_rows = per;
+        c->send_doubles = c->recv_doubles = per * (c->D + 2);
     }
     RcclId u;
     memcpy(u.internal, id, 128);
@@ -1681,6 +2018,10 @@ int emx_host_plan_philox(uint64_t seed, uint64_t step, int64_t N, const emx_move
 
 int32_t emx_host_move_choice_philox(uint64_t seed, uint64_t step, const double* cdf, int32_t n) {
     return philox_move_choice(seed, step, cdf, n);
+}
+
+int64_t emx_host_pull_capacity(int64_t nwalkers, int32_t world, int32_t nsplits, int32_t partners_per_walker) {
+    return pull_capacity(nwalkers, world, nsplits, partners_per_walker);
 }
 
 }  // extern "C"

@@ -30,7 +30,7 @@ namespace emx {
 
 enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_EVAL = 3 };
 enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5 };
-enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u };
+enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u };
 
 struct NativeArgs {
     uint64_t seed;
@@ -91,6 +91,8 @@ struct HalfStepArgs {
     const StepDesc* desc;
     double* chain_all;
     double* chain_lp_all;
+    // pull exchange: the slot count of the (compacted) plan is only known on the device
+    const int32_t* t_hi_dev;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -532,12 +534,13 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
             stage_pending = false;                                                                  \
         }                                                                                           \
     } while (0)
-    if (A.t_lo + wave * spw >= A.t_hi) {      // idle wave: publish its share, meet the barrier, leave
+    const int t_hi = A.t_hi_dev ? *A.t_hi_dev : A.t_hi;
+    if (A.t_lo + wave * spw >= t_hi) {        // idle wave: publish its share, meet the barrier, leave
         EMX_STAGE_PUBLISH();
         return;
     }
-    for (int t0 = A.t_lo + wave * spw; t0 < A.t_hi; t0 += nwaves * spw) {   // wave-uniform batch loop
-        const int nslot = min(spw, A.t_hi - t0);
+    for (int t0 = A.t_lo + wave * spw; t0 < t_hi; t0 += nwaves * spw) {     // wave-uniform batch loop
+        const int nslot = min(spw, t_hi - t0);
         const int npass = (nslot + WPW - 1) / WPW;
         const int pbase = A.pos0 + t0;          // plan position of the wave's first slot
 
@@ -956,6 +959,173 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const ScatterArgs A) {
             A.chain_lp[i] = l;
             if (ac) A.acc_count[i] += 1u;
         }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// Pull exchange (walker-block ownership).  Rank r owns walkers [N r / G, N (r+1) / G); the RNG
+// plan is replicated, so every rank can tell, without asking, which of ITS rows the walkers
+// other ranks update in this half-step will read.  Per half-step:
+//   k_pull_plan    -> compact plan of the slots whose walker this rank owns (+ device-side count),
+//                     and, per destination rank, the list of own rows it needs
+//   k_pull_pack    -> [global row index | row] records, `cap` per destination (index -1: unused)
+//   (all-to-all, cap records per pair)
+//   k_pull_scatter -> received rows into the local replica at their global index
+//   k_halfstep     -> over the compact plan
+// ----------------------------------------------------------------------------------------
+__host__ __device__ inline int block_owner(int w, int N, int G) {     // r with N r / G <= w < N (r+1) / G
+    return (int)((((long long)w + 1) * G - 1) / N);
+}
+
+struct PullPlanArgs {
+    const int32_t *order, *p0, *p1, *p2;      // this step's plan (slot-indexed), already offset to the split
+    const double *s0, *uacc, *logu, *fac;
+    int32_t *corder, *cp0, *cp1, *cp2;        // compact plan of this rank's active walkers
+    double *cs0, *cuacc, *clogu, *cfac;
+    int32_t* counts;                          // [0]: own active slots; [1 + q]: records for rank q
+    int32_t* sendidx;                         // [G][cap]: own rows rank q needs
+    uint32_t* status;
+    int32_t N, G, rank, ns, npart, cap;
+};
+
+__global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = t < A.ns;
+    int i = 0, pj[3] = {0, 0, 0}, oi = -1;
+    if (live) {
+        i = A.order[t];
+        pj[0] = A.p0[t];
+        pj[1] = A.p1[t];
+        pj[2] = A.p2[t];
+        oi = block_owner(i, A.N, A.G);
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // (a) slots of walkers this rank owns -> compact plan, one atomic per wave
+    {
+        const bool mine = live && oi == A.rank;
+        const unsigned long long m = __ballot(mine);
+        if (m) {
+            int base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(&A.counts[0], __popcll(m));
+            base = __shfl(base, leader);
+            if (mine) {
+                const int e = base + __popcll(m & below);
+                A.corder[e] = i;
+                A.cp0[e] = pj[0];
+                A.cp1[e] = pj[1];
+                A.cp2[e] = pj[2];
+                A.cs0[e] = A.s0[t];
+                A.cuacc[e] = A.uacc[t];
+                A.clogu[e] = A.logu[t];
+                A.cfac[e] = A.fac[t];
+            }
+        }
+    }
+    // (b) partners owned here of walkers updated elsewhere -> the owner's request list
+    for (int j = 0; j < A.npart; ++j) {
+        const bool here = live && oi != A.rank && block_owner(pj[j], A.N, A.G) == A.rank;
+        unsigned long long any = __ballot(here);
+        if (!any) continue;
+        for (int q = 0; q < A.G; ++q) {                         // wave-uniform
+            const bool hit = here && oi == q;
+            const unsigned long long m = __ballot(hit);
+            if (!m) continue;
+            int base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(&A.counts[1 + q], __popcll(m));
+            base = __shfl(base, leader);
+            if (hit) {
+                const int e = base + __popcll(m & below);
+                if (e < A.cap)
+                    A.sendidx[(size_t)q * A.cap + e] = pj[j];
+                else
+                    atomicOr(A.status, ST_EXCHANGE_OVERFLOW);
+            }
+        }
+    }
+}
+
+struct PullRowsArgs {
+    double* X;
+    double* rec;                 // [G][cap][D + 1]
+    const int32_t* counts;       // pack: counts[1 + q]
+    const int32_t* sendidx;
+    int32_t N, D, G, rank, cap;
+};
+
+// 16 lanes per record
+__global__ __launch_bounds__(256) void k_pull_pack(const PullRowsArgs A) {
+    const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    if (r >= A.G * A.cap) return;
+    const int q = r / A.cap, e = r - q * A.cap;
+    if (q == A.rank) return;
+    double* dst = A.rec + (size_t)r * (A.D + 1);
+    const int cnt = min(A.counts[1 + q], A.cap);
+    if (e >= cnt) {
+        if (l == 0) dst[0] = -1.0;
+        return;
+    }
+    const int idx = A.sendidx[(size_t)q * A.cap + e];
+    const double* src = A.X + (size_t)idx * A.D;
+    if (l == 0) dst[0] = (double)idx;
+    for (int d = l; d < A.D; d += 16) dst[1 + d] = src[d];
+}
+
+__global__ __launch_bounds__(256) void k_pull_scatter(const PullRowsArgs A) {
+    const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    if (r >= A.G * A.cap) return;
+    if (r / A.cap == A.rank) return;
+    const double* src = A.rec + (size_t)r * (A.D + 1);
+    const double h = src[0];
+    if (!(h >= 0.0)) return;
+    double* dst = A.X + (size_t)(long long)h * A.D;
+    for (int d = l; d < A.D; d += 16) dst[d] = src[1 + d];
+}
+
+// Replica sync of the pull exchange: every rank's block as [row | log_prob | accepted | accepted count] records
+struct BlockArgs {
+    double* X;
+    double* lp;
+    uint8_t* acc;
+    uint32_t* acc_count;
+    double* rec;          // pack: own block -> rec[0 .. bmax); unpack: rec[G][bmax] -> replica
+    int32_t N, D, G, rank, bmax;
+};
+
+__global__ __launch_bounds__(256) void k_block_pack(const BlockArgs A) {
+    const int e = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    const int lo = (int)((long long)A.N * A.rank / A.G), hi = (int)((long long)A.N * (A.rank + 1) / A.G);
+    if (e >= hi - lo) return;
+    const int w = lo + e;
+    double* dst = A.rec + (size_t)e * (A.D + 3);
+    for (int d = l; d < A.D; d += 16) dst[d] = A.X[(size_t)w * A.D + d];
+    if (l == 0) {
+        dst[A.D] = A.lp[w];
+        dst[A.D + 1] = (double)A.acc[w];
+        dst[A.D + 2] = (double)A.acc_count[w];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_block_unpack(const BlockArgs A) {
+    const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    if (r >= A.G * A.bmax) return;
+    const int q = r / A.bmax, e = r - q * A.bmax;
+    if (q == A.rank) return;
+    const int lo = (int)((long long)A.N * q / A.G), hi = (int)((long long)A.N * (q + 1) / A.G);
+    if (e >= hi - lo) return;
+    const int w = lo + e;
+    const double* src = A.rec + (size_t)r * (A.D + 3);
+    for (int d = l; d < A.D; d += 16) A.X[(size_t)w * A.D + d] = src[d];
+    if (l == 0) {
+        A.lp[w] = src[A.D];
+        A.acc[w] = src[A.D + 1] != 0.0 ? 1 : 0;
+        A.acc_count[w] = (uint32_t)src[A.D + 2];
     }
 }
 

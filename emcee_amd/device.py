@@ -15,6 +15,7 @@ __all__ = ["DeviceEnsemble", "EmxError"]
 
 _STATUS_NAN_LOGP = 1
 _STATUS_BAD_COORD = 2
+_STATUS_EXCHANGE_OVERFLOW = 4
 
 
 def _as_f64(a, shape=None):
@@ -77,6 +78,8 @@ class DeviceEnsemble:
     def raise_on_status(self):
         """Mirror the reference's ValueErrors (ensemble.py:476-479, 550-551)."""
         bits = self.status()
+        if bits & _STATUS_EXCHANGE_OVERFLOW:
+            raise EmxError("pull exchange: record capacity exceeded; the sharded run is invalid")
         if bits & _STATUS_BAD_COORD:
             raise ValueError("At least one parameter value was infinite or NaN")
         if bits & _STATUS_NAN_LOGP:
@@ -240,6 +243,41 @@ class DeviceEnsemble:
 
     def scatter_gathered(self, split):
         self._ck(self.lib.emx_scatter_gathered(self.ctx, int(split)))
+
+    # ---- pull exchange (walker-block ownership; include/emx.h) ----
+    def set_exchange(self, kind):
+        """'allgather' (every updated row to every rank) or 'pull' (only the partner rows read)."""
+        k = {"allgather": _lib.EXCHANGE_ALLGATHER, "pull": _lib.EXCHANGE_PULL}.get(kind, kind)
+        self._ck(self.lib.emx_set_exchange(self.ctx, int(k)))
+
+    def exchange_layout(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.emx_exchange_layout(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_exchange_buffers(self, send_ptr, send_doubles, recv_ptr, recv_doubles):
+        self._ck(self.lib.emx_set_exchange_buffers(self.ctx, send_ptr, int(send_doubles), recv_ptr, int(recv_doubles)))
+
+    def own_walkers(self):
+        lo, hi = C.c_int64(), C.c_int64()
+        self._ck(self.lib.emx_own_walkers(self.ctx, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def pull_prepare(self, split):
+        n = C.c_int64()
+        self._ck(self.lib.emx_pull_prepare(self.ctx, int(split), C.byref(n)))
+        return n.value
+
+    def pull_apply(self, split):
+        self._ck(self.lib.emx_pull_apply(self.ctx, int(split)))
+
+    def replica_pack(self):
+        n = C.c_int64()
+        self._ck(self.lib.emx_replica_pack(self.ctx, C.byref(n)))
+        return n.value
+
+    def replica_unpack(self):
+        self._ck(self.lib.emx_replica_unpack(self.ctx))
 
     # ---- library-driven RCCL ----
     @staticmethod

@@ -9,12 +9,20 @@ all-gather per half-step (RCCL over xGMI via torch.distributed) brings every ran
 every rank, where a scatter kernel folds them into the local replica before the next split --
 the ordering red_blue.py:85,104 requires.  No other collective sits on the data path.
 
+A second protocol, the *pull* exchange (`PullStepper`, include/emx.h "pull exchange"), moves only
+the rows a half-step reads: rank r owns the walker block [N r / G, N (r+1) / G); because the RNG
+plan is replicated each rank knows which of its rows its peers' walkers picked as partners, packs
+them as [index | row] records, and ONE all-to-all per half-step delivers them (1/G of the
+all-gather's volume per rank).  Replicas are re-synchronised (one all-gather of the blocks) only
+when somebody needs the whole ensemble.
+
 The engine is abstract (`DeviceEngine` drives libemx; the CPU test-suite supplies a NumPy
-double) so the protocol itself is covered by world_size-2 gloo tests without a GPU.
+double) so the protocols themselves are covered by world_size-2 gloo tests without a GPU.
 """
 import numpy as np
 
-__all__ = ["shard_range", "rows_per_rank", "ShardedStepper", "DeviceEngine", "LocalGroup"]
+__all__ = ["shard_range", "rows_per_rank", "ShardedStepper", "PullStepper", "DeviceEngine", "LocalGroup",
+           "block_range", "block_owner", "pull_capacity"]
 
 
 def shard_range(ns, rank, world):
@@ -64,20 +72,111 @@ class ShardedStepper:
             hint(1)
 
 
+def block_range(nwalkers, rank, world):
+    """Walkers owned by `rank` under the pull exchange (mirrors emx_own_walkers)."""
+    return nwalkers * rank // world, nwalkers * (rank + 1) // world
+
+
+def block_owner(w, nwalkers, world):
+    """Rank owning walker(s) `w` (mirrors block_owner in emx_kernels.hpp)."""
+    return ((np.asarray(w, dtype=np.int64) + 1) * world - 1) // nwalkers
+
+
+def pull_capacity(nwalkers, world, nsplits, npart):
+    """Records per (source, destination) pair of one half-step (mirrors pull_capacity in emx.hip):
+    mean + 8 sigma + 64 of the partner rows one rank's walkers pick inside another rank's block."""
+    import math
+    if world <= 1:
+        return 1
+    bmax = -(-nwalkers // world)
+    nsmax = -(-nwalkers // nsplits)
+    hard = npart * min(bmax, nsmax)
+    mean = float(npart) * float(nwalkers) / nsplits / world / world
+    cap = int(math.ceil(mean + 8.0 * math.sqrt(mean) + 64.0))
+    return max(1, min(cap, hard))
+
+
+class PullStepper:
+    """Drives one engine per rank through sharded steps of the pull exchange.
+
+    engine API: step_begin(store) -> (move, nsplits); pull_prepare(split) -> records per peer;
+    pull_apply(split); step_end(); replica_pack() -> records per rank; replica_unpack();
+    attributes sendbuf / gathered (flat float64 buffers), world, ndim.
+    all_to_all(out, inp): equal blocks, block q of `inp` to rank q, landing in block `rank` of its `out`.
+    all_gather(out, inp): every rank's `inp`, concatenated in rank order.
+    """
+
+    def __init__(self, engine, all_to_all, all_gather):
+        self.engine = engine
+        self.all_to_all = all_to_all
+        self.all_gather = all_gather
+
+    def step(self, store=False):
+        e = self.engine
+        move, nsplits = e.step_begin(store)
+        for split in range(nsplits):
+            n = e.world * e.pull_prepare(split) * (e.ndim + 1)     # own rows the peers will read
+            self.all_to_all(e.gathered[:n], e.sendbuf[:n])         # the one exchange per half-step
+            e.pull_apply(split)                                    # fold in, update the walkers owned here
+        e.step_end()
+        return move
+
+    def sync_replicas(self):
+        e = self.engine
+        n = e.replica_pack() * (e.ndim + 3)
+        self.all_gather(e.gathered[:e.world * n], e.sendbuf[:n])
+        e.replica_unpack()
+
+    def run(self, nsteps, thin_by=1, store=False):
+        i = 0
+        total = nsteps * thin_by
+        hint = getattr(self.engine, "set_prep_hint", None)
+        for _ in range(nsteps):
+            for _ in range(thin_by):
+                if hint is not None:
+                    hint(total - i)
+                self.step(store and (i + 1) % thin_by == 0)
+                i += 1
+        if hint is not None:
+            hint(1)
+        self.sync_replicas()
+
+
 class DeviceEngine:
     """libemx context as a sharded engine; exchange buffers are torch tensors (RCCL-ready)."""
 
-    def __init__(self, ens, rank, world, torch_device=None):
+    def __init__(self, ens, rank, world, torch_device=None, exchange="allgather"):
         import torch
         self.ens = ens
         self.rank, self.world = rank, world
+        self.ndim = ens.ndim
+        dev = torch_device if torch_device is not None else torch.device("cuda", torch.cuda.current_device())
+        if exchange == "pull":
+            ens.set_exchange("pull")
+            ens.set_shard(rank, world)
+            ns, nr = ens.exchange_layout()
+            self.sendbuf = torch.zeros(ns, dtype=torch.float64, device=dev)
+            self.gathered = torch.zeros(nr, dtype=torch.float64, device=dev)
+            ens.set_exchange_buffers(self.sendbuf.data_ptr(), ns, self.gathered.data_ptr(), nr)
+            return
         ens.set_shard(rank, world)
         rows = rows_per_rank(ens.nwalkers, world)
-        dev = torch_device if torch_device is not None else torch.device("cuda", torch.cuda.current_device())
         rec = ens.ndim + 2
         self.sendbuf = torch.zeros(rows * rec, dtype=torch.float64, device=dev)
         self.gathered = torch.zeros(world * rows * rec, dtype=torch.float64, device=dev)
         ens.set_shard_buffers(self.sendbuf.data_ptr(), self.gathered.data_ptr(), rows)
+
+    def pull_prepare(self, split):
+        return self.ens.pull_prepare(split)
+
+    def pull_apply(self, split):
+        self.ens.pull_apply(split)
+
+    def replica_pack(self):
+        return self.ens.replica_pack()
+
+    def replica_unpack(self):
+        self.ens.replica_unpack()
 
     def set_prep_hint(self, n):
         self.ens.set_tuning("prep_hint", n)
@@ -118,6 +217,19 @@ class LocalGroup:
         for e in engines:
             e.step_end()
         return res[0][0]
+
+    @staticmethod
+    def _all_to_all(engines, n):
+        """block q (n doubles) of rank r's sendbuf -> block r of rank q's gathered"""
+        for r, src in enumerate(engines):
+            for q, dst in enumerate(engines):
+                dst.gathered[r * n:(r + 1) * n] = src.sendbuf[q * n:(q + 1) * n]
+
+    @staticmethod
+    def _all_gather_n(engines, n):
+        for e in engines:
+            for r, src in enumerate(engines):
+                e.gathered[r * n:(r + 1) * n] = src.sendbuf[:n]
 
     @staticmethod
     def _all_gather(engines):

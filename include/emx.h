@@ -63,7 +63,8 @@ int emx_destroy(emx_ctx* ctx);
 int emx_set_stream(emx_ctx* ctx, void* hip_stream);
 int emx_sync(emx_ctx* ctx);
 /* sticky device status: bit0 NaN log-prob (ensemble.py:550-551), bit1 non-finite coordinate
- * (ensemble.py:476-479).  Reading clears it. */
+ * (ensemble.py:476-479), bit2 pull-exchange record capacity exceeded (a >8 sigma event: the run is
+ * invalid, never silently wrong).  Reading clears it. */
 int emx_status(emx_ctx* ctx, uint32_t* bits);
 int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value); /* "spw", "blocks_per_cu" */
 
@@ -142,6 +143,32 @@ int emx_shard_slots(emx_ctx* ctx, int32_t split, int64_t* t_lo, int64_t* t_hi, i
 /* after the all-gather of `sendbuf`s into `gathered`: write the other ranks' rows into X */
 int emx_scatter_gathered(emx_ctx* ctx, int32_t split);
 
+/* ---- pull exchange: walker-block ownership, only the partner rows that are read travel -----
+ * The all-gather above replicates every updated row on every rank: (G-1)/G of the ensemble crosses
+ * xGMI per step.  A half-step reads ONE partner row per updated walker (stretch.py:32; two / three for
+ * DE / snooker), so with rank r owning walkers [N r / G, N (r+1) / G) it is enough to move exactly those
+ * rows.  The RNG plan is replicated, hence every rank knows which of its rows the others will read:
+ *   emx_pull_prepare(split)  -> records [row index | row] for every peer in the send buffer
+ *                               (world blocks of *records_per_peer records of D+1 doubles)
+ *   all-to-all, records_per_peer * (D+1) doubles per pair (host layer, or emx_run when emx_comm_init ran)
+ *   emx_pull_apply(split)    -> received rows into the local replica, then the half-step over the
+ *                               slots whose walker this rank owns
+ * Only a rank's own block of X / log_prob / accepted / chain is current until emx_replica_pack ->
+ * all-gather (bmax records of D+3 doubles per rank) -> emx_replica_unpack re-synchronises the replicas
+ * (emx_run does it before it returns).  Results are bit-identical to the single-rank run. */
+#define EMX_EXCHANGE_ALLGATHER 0
+#define EMX_EXCHANGE_PULL 1
+int emx_set_exchange(emx_ctx* ctx, int32_t kind);          /* before emx_set_shard / emx_comm_init */
+/* doubles the send / receive buffers must hold for the moves installed (pull exchange) */
+int emx_exchange_layout(emx_ctx* ctx, int64_t* send_doubles, int64_t* recv_doubles);
+/* caller-owned exchange buffers (pull exchange), e.g. torch tensors handed to RCCL */
+int emx_set_exchange_buffers(emx_ctx* ctx, void* send, int64_t send_doubles, void* recv, int64_t recv_doubles);
+int emx_own_walkers(emx_ctx* ctx, int64_t* lo, int64_t* hi);
+int emx_pull_prepare(emx_ctx* ctx, int32_t split, int64_t* records_per_peer);
+int emx_pull_apply(emx_ctx* ctx, int32_t split);
+int emx_replica_pack(emx_ctx* ctx, int64_t* records_per_rank);
+int emx_replica_unpack(emx_ctx* ctx);
+
 /* RCCL driven by the library itself (ncclAllGather enqueued on the context stream between the
  * half-step kernels, so that emx_run covers sharded runs with no host round trip per step).
  * librccl is resolved with dlopen (path, $EMX_RCCL_LIB, librccl.so.1): pass PyTorch's copy when
@@ -179,6 +206,8 @@ int emx_host_split_draws(emx_mt* m, int64_t nwalkers, const emx_move_desc* mv, c
 int emx_host_plan_philox(uint64_t seed, uint64_t step, int64_t nwalkers, const emx_move_desc* mv, int32_t* off,
                          int32_t* order, int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc);
 int32_t emx_host_move_choice_philox(uint64_t seed, uint64_t step, const double* cdf, int32_t n);
+/* pull exchange: records per (source, destination) pair of one half-step (what emx_pull_prepare returns) */
+int64_t emx_host_pull_capacity(int64_t nwalkers, int32_t world, int32_t nsplits, int32_t partners_per_walker);
 
 #ifdef __cplusplus
 }

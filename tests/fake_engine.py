@@ -7,7 +7,7 @@ exchange logic can be checked against a single-rank oracle run without a GPU.
 """
 import numpy as np
 
-from emcee_amd.parallel import rows_per_rank, shard_range
+from emcee_amd.parallel import block_owner, block_range, pull_capacity, rows_per_rank, shard_range
 from oracle import sampler_oracle as so
 
 from emx_testlib import HostMT, cdf_of, move_desc
@@ -74,3 +74,82 @@ class FakeEngine:
             self.chain.append(self.X.copy())
             self.chain_lp.append(self.lp.copy())
             self.acc_count += self.acc
+
+
+class FakePullEngine(FakeEngine):
+    """The pull exchange (emcee_amd.parallel.PullStepper) on the same NumPy double: walker-block
+    ownership, [index | row] records for the peers, block all-gather at the end."""
+
+    NPART = {"stretch": 1, "de": 2, "snooker": 3}
+
+    def __init__(self, *a, **kw):
+        make_buffer = kw.get("make_buffer", np.zeros)
+        super().__init__(*a, **kw)
+        self.ndim = self.D
+        self.bmax = -(-self.N // self.world)
+        capmax = max(pull_capacity(self.N, self.world, m.nsplits, self.NPART[m.kind]) for m in self.moves)
+        pairs = self.world * capmax * (self.D + 1)
+        self.sendbuf = make_buffer(max(pairs, self.bmax * (self.D + 3)))
+        self.gathered = make_buffer(max(pairs, self.world * self.bmax * (self.D + 3)))
+        self.lo, self.hi = block_range(self.N, self.rank, self.world)
+
+    def pull_prepare(self, split):
+        off = self.plan["off"]
+        sl = slice(off[split], off[split + 1])
+        npart = self.NPART[self.move.kind]
+        cap = pull_capacity(self.N, self.world, self.move.nsplits, npart)
+        oi = block_owner(self.plan["order"][sl], self.N, self.world)
+        self._mine = np.nonzero(oi == self.rank)[0] + off[split]
+        sb = self._np(self.sendbuf)[: self.world * cap * (self.D + 1)].reshape(self.world, cap, self.D + 1)
+        sb[:, :, 0] = -1.0
+        fill = np.zeros(self.world, dtype=int)
+        for j in range(npart):
+            pj = self.plan["p%d" % j][sl]
+            here = (oi != self.rank) & (block_owner(pj, self.N, self.world) == self.rank)
+            for q, row in zip(oi[here], pj[here]):
+                assert fill[q] < cap, "pull capacity exceeded"
+                sb[q, fill[q], 0] = row
+                sb[q, fill[q], 1:] = self.X[row]
+                fill[q] += 1
+        self._cap = cap
+        return cap
+
+    def pull_apply(self, split):
+        ga = self._np(self.gathered)[: self.world * self._cap * (self.D + 1)].reshape(self.world, self._cap, self.D + 1)
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            ok = ga[r, :, 0] >= 0
+            self.X[ga[r, ok, 0].astype(np.int64)] = ga[r, ok, 1:]
+        sub = {k: v[self._mine] for k, v in self.plan.items() if k != "off"}
+        sub["off"] = np.array([0, len(self._mine)])
+        idx = sub["order"]
+        acc = so.propose_planned(self.X, self.lp, self.lp_fn, sub, self.move)
+        self.acc[idx] = acc[idx]
+
+    def replica_pack(self):
+        sb = self._np(self.sendbuf)[: self.bmax * (self.D + 3)].reshape(self.bmax, self.D + 3)
+        n = self.hi - self.lo
+        sb[:n, : self.D] = self.X[self.lo: self.hi]
+        sb[:n, self.D] = self.lp[self.lo: self.hi]
+        sb[:n, self.D + 1] = self.acc[self.lo: self.hi]
+        sb[:n, self.D + 2] = self.acc_count[self.lo: self.hi]
+        return self.bmax
+
+    def replica_unpack(self):
+        ga = self._np(self.gathered)[: self.world * self.bmax * (self.D + 3)].reshape(self.world, self.bmax, self.D + 3)
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            lo, hi = block_range(self.N, r, self.world)
+            self.X[lo:hi] = ga[r, : hi - lo, : self.D]
+            self.lp[lo:hi] = ga[r, : hi - lo, self.D]
+            self.acc[lo:hi] = ga[r, : hi - lo, self.D + 1] != 0
+            self.acc_count[lo:hi] = ga[r, : hi - lo, self.D + 2]
+
+    def step_end(self):
+        # only the own block of a stored step is meaningful before the replicas are synchronised
+        if self.store:
+            self.chain.append(self.X.copy())
+            self.chain_lp.append(self.lp.copy())
+            self.acc_count[self.lo: self.hi] += self.acc[self.lo: self.hi]

@@ -84,6 +84,83 @@ def _run_step(group, steppers):
         e.step_end()
 
 
+@pytest.mark.parametrize("name,world,rng", [
+    ("c1_stretch_32x5_iso", 2, "mt"), ("stretch_50x3_iso", 3, "mt"), ("stretch_128x64_dense", 2, "mt"),
+    ("stretch_128x64_dense", 4, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt"),
+    ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
+    ("stretch_nsplits3_45x2", 2, "mt"), ("stretch_50x3_iso", 7, "philox"),
+])
+def test_pull_exchange_equals_single_rank(name, world, rng):
+    """Pull exchange (walker-block ownership, partner rows only): each logical rank's block of the chain,
+    and every replica after the block all-gather, must equal the single-rank run bit for bit."""
+    import torch
+    from emcee_amd.parallel import block_range
+    g = load_golden(name)
+    spec = cases.build(name)
+    nst = min(8, spec["nsteps"])
+
+    def setup(ens):
+        if rng == "mt":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(rng_from_fixture(g).get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(777, 0)
+        ens.chain_config(nst)
+
+    ref = make_ens(spec, g["p0"])
+    setup(ref)
+    ref.run(nst, 1, True)
+    ref_chain, ref_lp, ref_acc = ref.chain_read(0, 0, nst), ref.chain_read(1, 0, nst), ref.accepted_counts()
+    ref.close()
+
+    engines = []
+    for r in range(world):
+        ens = make_ens(spec, g["p0"])
+        setup(ens)
+        engines.append(DeviceEngine(ens, r, world, torch.device("cuda", 0), exchange="pull"))
+    nd = engines[0].ndim
+
+    def sync():
+        for e in engines:
+            e.ens.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(nst):
+        res = [e.step_begin(True) for e in engines]
+        assert all(r == res[0] for r in res)
+        for split in range(res[0][1]):
+            caps = [e.pull_prepare(split) for e in engines]
+            assert len(set(caps)) == 1
+            sync()
+            LocalGroup._all_to_all(engines, caps[0] * (nd + 1))
+            sync()
+            for e in engines:
+                e.pull_apply(split)
+        for e in engines:
+            e.step_end()
+    # blocks first (replicas are not synchronised yet) ...
+    for r, e in enumerate(engines):
+        lo, hi = block_range(ref_chain.shape[1], r, world)
+        assert e.ens.own_walkers() == (lo, hi)
+        assert e.ens.status() == 0
+        assert np.array_equal(e.ens.chain_read(0, 0, nst)[:, lo:hi], ref_chain[:, lo:hi])
+        assert np.array_equal(e.ens.chain_read(1, 0, nst)[:, lo:hi], ref_lp[:, lo:hi])
+        assert np.array_equal(e.ens.accepted_counts()[lo:hi], ref_acc[lo:hi])
+    # ... then the block all-gather
+    per = [e.replica_pack() for e in engines]
+    assert len(set(per)) == 1
+    sync()
+    LocalGroup._all_gather_n(engines, per[0] * (nd + 3))
+    sync()
+    for e in engines:
+        e.replica_unpack()
+        x, lp = e.ens.get_state()
+        assert np.array_equal(x, ref_chain[-1]) and np.array_equal(lp, ref_lp[-1])
+        assert np.array_equal(e.ens.accepted_counts(), ref_acc)
+        e.ens.close()
+
+
 def test_library_driven_rccl_world1():
     """emx_comm_init + sharded emx_run (ncclAllGather enqueued by libemx) at world size 1:
     exercises the RCCL linkage and the exchange buffers; the chain must equal the plain run."""
@@ -92,12 +169,13 @@ def test_library_driven_rccl_world1():
     g = load_golden(name)
     spec = cases.build(name)
     chains = []
-    for use_comm in (False, True):
+    for use_comm in (False, "allgather", "pull"):
         ens = make_ens(spec, g["p0"])
         ens.set_rng_mode(_lib.RNG_PHILOX)
         ens.set_philox(4242, 0)
         ens.chain_config(10)
         if use_comm:
+            ens.set_exchange(use_comm)
             ens.comm_init(0, 1, DeviceEnsemble.rccl_unique_id())
         ens.run(10, 1, True)
         assert ens.status() == 0
@@ -105,5 +183,6 @@ def test_library_driven_rccl_world1():
         if use_comm:
             ens.comm_destroy()
         ens.close()
-    for a, b in zip(*chains):
-        assert np.array_equal(a, b)
+    for other in chains[1:]:
+        for a, b in zip(chains[0], other):
+            assert np.array_equal(a, b)

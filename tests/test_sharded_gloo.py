@@ -63,6 +63,104 @@ def test_sharded_protocol_over_gloo(name, world):
         np.testing.assert_allclose(lp, g["log_prob"][:nst], rtol=1e-12)
 
 
+def _pull_worker(rank, world, port, name, nst, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    from emcee_amd.parallel import PullStepper
+    from fake_engine import FakePullEngine
+    from helpers import load_golden, rng_from_fixture
+    from oracle import cases
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden(name)
+    spec = cases.build(name)
+    eng = FakePullEngine(g["p0"], cases.make_target(spec["desc"]), spec["moves"], spec["weights"],
+                         rng_from_fixture(g).get_state(), rank, world,
+                         make_buffer=lambda n: torch.zeros(n, dtype=torch.float64))
+    st = PullStepper(eng, lambda out, inp: dist.all_to_all_single(out, inp),
+                     lambda out, inp: dist.all_gather_into_tensor(out, inp))
+    st.run(nst, 1, True)      # ends with the block all-gather
+    q.put((rank, eng.lo, eng.hi, np.stack(eng.chain), np.stack(eng.chain_lp), eng.X.copy(), eng.lp.copy(), eng.acc_count.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("stretch_50x3_iso", 2), ("mix_de_snooker_128x8_dense", 2),
+                                        ("stretch_nsplits3_45x2", 3)])
+def test_pull_protocol_over_gloo(name, world):
+    """Pull exchange over a real all-to-all: every rank's block of the chain, and every replica after the
+    final block all-gather, equal the single-rank oracle chain."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    from helpers import load_golden
+    g = load_golden(name)
+    nst = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_pull_worker, args=(r, world, port, name, nst, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exact = "snooker" not in name
+    acc_total = (np.diff(g["chain"][: nst], axis=0, prepend=g["p0"][None]) != 0).any(axis=2).sum(axis=0)
+    for rank, lo, hi, chain, lp, x, lpf, acc in res:
+        if exact:
+            assert np.array_equal(chain[:, lo:hi], g["chain"][:nst, lo:hi]), "rank %d diverged" % rank
+            assert np.array_equal(x, g["chain"][nst - 1])
+        else:
+            np.testing.assert_allclose(chain[:, lo:hi], g["chain"][:nst, lo:hi], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(x, g["chain"][nst - 1], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(lp[:, lo:hi], g["log_prob"][:nst, lo:hi], rtol=1e-12)
+        np.testing.assert_allclose(lpf, g["log_prob"][nst - 1], rtol=1e-12)
+        assert np.array_equal(acc, acc_total)
+
+
+def test_pull_capacity_mirror_and_bounds():
+    """The Python mirror equals the library's capacity; the capacity never exceeds what a pair can need and
+    stays within ~15 % of the mean at bench scale."""
+    from emcee_amd import _lib
+    from emcee_amd.parallel import pull_capacity
+    lib = _lib.load()
+    for N in (32, 45, 128, 4096, 65536, 8 * 65536):
+        for world in (1, 2, 3, 4, 8):
+            for S, npart in ((2, 1), (2, 2), (4, 3), (3, 1)):
+                c = pull_capacity(N, world, S, npart)
+                assert c == lib.emx_host_pull_capacity(N, world, S, npart)
+                assert 1 <= c <= max(1, npart * min(-(-N // world), -(-N // S)))
+    assert pull_capacity(8 * 65536, 8, 2, 1) < 1.2 * (8 * 65536 / 2 / 64)
+
+
+def test_pull_requests_fit_the_capacity():
+    """Native plans at a realistic size: the per-pair request counts stay far below the capacity."""
+    from emcee_amd.parallel import block_owner, pull_capacity
+    from emx_testlib import philox_plan, move_desc
+    from oracle import sampler_oracle as so
+    N, world = 16384, 8
+    mv = so.MoveSpec("stretch")
+    cap = pull_capacity(N, world, 2, 1)
+    worst = 0
+    for step in range(6):
+        plan = philox_plan(99, step, N, move_desc(mv, 8))
+        for split in range(2):
+            sl = slice(plan["off"][split], plan["off"][split + 1])
+            oi = block_owner(plan["order"][sl], N, world)
+            oj = block_owner(plan["p0"][sl], N, world)
+            cnt = np.zeros((world, world), dtype=int)
+            np.add.at(cnt, (oj, oi), 1)
+            np.fill_diagonal(cnt, 0)
+            worst = max(worst, cnt.max())
+    mean = N / 2 / world / world
+    assert worst < mean + 5 * np.sqrt(mean) < cap
+
+
 def test_shard_ranges_tile_the_slots():
     from emcee_amd.parallel import rows_per_rank, shard_range
     for ns in (1, 2, 7, 16, 32768, 131073):
