@@ -67,6 +67,22 @@ CASES = {
     "mix_stretch_de_64x5": dict(N=64, D=5, target="iso", moves=[_S("stretch"), _S("de")], nsteps=20, seed=302),
 }
 
+# SURVEY.md 8(f) widening: moves whose proposal is host code in the reference and in the product
+# (MHMove/GaussianMove: whole ensemble at once; WalkMove/KDEMove: split-ensemble with a custom get_proposal).
+HOST_MOVE_CASES = {
+    "gauss_iso_vector_40x3": dict(N=40, D=3, target="iso", moves=[_S("gaussian", cov=0.25)], nsteps=20, seed=501),
+    "gauss_diag_random_factor_30x4": dict(N=30, D=4, target="diag", nsteps=20, seed=502,
+                                          moves=[_S("gaussian", cov=[0.1, 0.2, 0.3, 0.4], mode="random", factor=2.0)]),
+    "gauss_iso_sequential_24x3": dict(N=24, D=3, target="iso", moves=[_S("gaussian", cov=0.5, mode="sequential")], nsteps=14, seed=503),
+    "gauss_full_32x3_dense": dict(N=32, D=3, target="dense", nsteps=15, seed=504,
+                                  moves=[_S("gaussian", cov=[[0.3, 0.1, 0.0], [0.1, 0.2, 0.05], [0.0, 0.05, 0.4]])]),
+    # unit/test_sampler.py:26-28 mixes Stretch + Gaussian
+    "mix_stretch_gauss_32x3": dict(N=32, D=3, target="iso", moves=[_S("stretch"), _S("gaussian", cov=0.3)], weights=[0.6, 0.4], nsteps=25, seed=505),
+    "walk_24x2_iso": dict(N=24, D=2, target="iso", moves=[_S("walk")], nsteps=8, seed=511),
+    "walk_s5_30x3_diag": dict(N=30, D=3, target="diag", moves=[_S("walk", s=5)], nsteps=8, seed=512),
+    "kde_40x2_iso": dict(N=40, D=2, target="iso", moves=[_S("kde")], nsteps=8, seed=521),
+}
+
 # Larger cases: only a digest of the reference output is committed.
 DIGEST_CASES = {
     "stretch_4096x64_dense": dict(N=4096, D=64, target="dense", moves=[_S("stretch")], nsteps=3, seed=401),
@@ -77,7 +93,7 @@ DIGEST_CASES = {
 
 
 def build(name):
-    spec = dict(CASES.get(name) or DIGEST_CASES[name])
+    spec = dict(CASES.get(name) or HOST_MOVE_CASES.get(name) or DIGEST_CASES[name])
     N, D, seed = spec["N"], spec["D"], spec["seed"]
     kind = spec["target"]
     desc = {"kind": kind}

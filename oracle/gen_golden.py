@@ -61,6 +61,12 @@ def _ref_moves(emcee, specs, weights):
         elif m.kind == "snooker":
             kw.pop("nsplits")
             out.append(emcee.moves.DESnookerMove(gammas=m.gammas, **kw))
+        elif m.kind == "gaussian":
+            out.append(emcee.moves.GaussianMove(m.cov, mode=m.mode, factor=m.factor))
+        elif m.kind == "walk":
+            out.append(emcee.moves.WalkMove(s=m.s, **kw))
+        elif m.kind == "kde":
+            out.append(emcee.moves.KDEMove(bw_method=m.bw_method, **kw))
     if weights is not None:
         return list(zip(out, weights))
     return out
@@ -79,8 +85,11 @@ def run_reference(name):
     sampler = emcee.EnsembleSampler(N, D, lp, moves=_ref_moves(emcee, spec["moves"], spec["weights"]), vectorize=vec)
     sampler._random.seed(spec["rng_seed"])
     state0 = sampler._random.get_state()
-    rec = RecordingRandom(sampler._random)
-    sampler._random = rec
+    if any(m.kind == "kde" for m in spec["moves"]):
+        rec = sampler._random          # scipy's gaussian_kde.resample insists on a real RandomState
+    else:
+        rec = RecordingRandom(sampler._random)
+        sampler._random = rec
     sampler.run_mcmc(spec["p0"], spec["nsteps"], thin_by=spec["thin_by"], skip_initial_state_check=True)
     st1 = rec.get_state()
     out = dict(
@@ -88,9 +97,9 @@ def run_reference(name):
         chain=sampler.get_chain(), log_prob=sampler.get_log_prob(), accepted_count=sampler.backend.accepted,
         rng_key1=st1[1], rng_pos1=st1[2], rng_has_gauss1=st1[3], rng_cached1=st1[4],
     )
-    if rec.labels:
+    if getattr(rec, "labels", None):
         out["labels"] = np.stack(rec.labels)
-    if rec.ints:
+    if getattr(rec, "ints", None):
         out["ints"] = np.concatenate(rec.ints)
     return out
 
@@ -101,14 +110,14 @@ def digest(a):
 
 def main(argv):
     os.makedirs(GOLDEN, exist_ok=True)
-    names = argv or (list(cases.CASES) + list(cases.DIGEST_CASES))
+    names = argv or (list(cases.CASES) + list(cases.HOST_MOVE_CASES) + list(cases.DIGEST_CASES))
     digests = {}
     dpath = os.path.join(GOLDEN, "digests.json")
     if os.path.exists(dpath):
         digests = json.load(open(dpath))
     for name in names:
         out = run_reference(name)
-        if name in cases.CASES:
+        if name in cases.CASES or name in cases.HOST_MOVE_CASES:
             np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
             print("wrote", name, out["chain"].shape)
         else:

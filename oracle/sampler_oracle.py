@@ -61,8 +61,17 @@ class MoveSpec:
 
     def __init__(self, kind="stretch", a=2.0, sigma=1.0e-5, gamma0=None,
                  gammas=1.7, nsplits=2, randomize_split=True,
-                 live_dangerously=False):
+                 live_dangerously=False, cov=None, mode="vector", factor=None,
+                 s=None, bw_method=None):
         self.kind = kind
+        # 'gaussian' (moves/gaussian.py + moves/mh.py), 'walk' (moves/walk.py), 'kde' (moves/kde.py):
+        # the SURVEY.md 8(f) widening; host-side proposals in the reference and in the product
+        self.cov = cov
+        self.mode = mode
+        self.factor = factor
+        self.index = 0          # gaussian.py:66,97: the sequential mode's cursor lives in the move
+        self.s = s
+        self.bw_method = bw_method
         self.a = a
         self.sigma = sigma
         self.gamma0 = gamma0
@@ -168,6 +177,73 @@ def _same_state(a, b):
             and a[3] == b[3] and a[4] == b[4])
 
 
+def _gaussian_proposal(x0, random, move):
+    """moves/gaussian.py:78-103 (+ :110-117 for a matrix ``cov``)."""
+    nw, nd = x0.shape
+    try:
+        float(move.cov)
+        scale, full = np.sqrt(move.cov), False                     # gaussian.py:54-56
+    except TypeError:
+        cov = np.atleast_1d(move.cov)
+        full = cov.ndim == 2
+        scale = cov if full else np.sqrt(cov)                        # gaussian.py:42,47
+    f = 1.0
+    if move.factor is not None:                                      # gaussian.py:81-84, drawn first
+        lf = np.log(move.factor)
+        f = np.exp(random.uniform(-lf, lf))
+    if full:
+        xnew = x0 + f * random.multivariate_normal(np.zeros(len(scale)), scale)
+    else:
+        xnew = x0 + f * scale * random.randn(*(x0.shape))            # gaussian.py:87
+    if move.mode == "vector":
+        return xnew, np.zeros(nw)
+    if move.mode == "random":
+        cols = random.randint(nd, size=nw)                           # gaussian.py:93
+    else:
+        cols = move.index % nd + np.zeros(nw, dtype=int)             # gaussian.py:95-96
+        move.index = (move.index + 1) % nd
+    x = np.array(x0)
+    x[np.arange(nw), cols] = xnew[np.arange(nw), cols]
+    return x, np.zeros(nw)
+
+
+def _propose_mh(coords, log_prob, lp_fn, random, move):
+    """moves/mh.py:35-65: all walkers at once; ``log(rand) < lnpdiff`` (strict, uniforms drawn last)."""
+    q, factors = _gaussian_proposal(coords, random, move)
+    new_lp = np.asarray(lp_fn(q), dtype=np.float64)
+    if np.any(np.isnan(new_lp)):
+        raise ValueError("Probability function returned NaN")
+    lnpdiff = new_lp - log_prob + factors
+    with np.errstate(divide="ignore"):
+        accepted = np.log(random.rand(len(coords))) < lnpdiff
+    coords[accepted] = q[accepted]
+    log_prob[accepted] = new_lp[accepted]
+    return accepted
+
+
+def _walk(s, c, random, nhelp):
+    """moves/walk.py:28-42."""
+    c = np.concatenate(c, axis=0)
+    Ns, Nc = len(s), len(c)
+    q = np.empty_like(s)
+    s0 = Nc if nhelp is None else nhelp
+    for i in range(Ns):
+        inds = random.choice(Nc, s0, replace=False)
+        cov = np.atleast_2d(np.cov(c[inds], rowvar=0))
+        q[i] = random.multivariate_normal(s[i], cov)
+    return q, np.zeros(Ns, dtype=np.float64)
+
+
+def _kde(s, c, random, bw_method):
+    """moves/kde.py:40-45 (scipy.stats.gaussian_kde is the reference's own dependency)."""
+    from scipy.stats import gaussian_kde
+    c = np.concatenate(c, axis=0)
+    kde = gaussian_kde(c.T, bw_method=bw_method)
+    q = kde.resample(len(s), random)
+    factor = kde.logpdf(s.T) - kde.logpdf(q)
+    return q.T, factor
+
+
 def propose(coords, log_prob, lp_fn, random, move, trace=None):
     """moves/red_blue.py:52-106 + moves/move.py:29-45, in place.
 
@@ -175,6 +251,8 @@ def propose(coords, log_prob, lp_fn, random, move, trace=None):
     accepted mask (bool[N]).  ``trace`` (a list) receives one dict per split.
     """
     nwalkers, ndim = coords.shape
+    if move.kind == "gaussian":
+        return _propose_mh(coords, log_prob, lp_fn, random, move)
     if nwalkers < 2 * ndim and not move.live_dangerously:
         raise RuntimeError("It is unadvisable to use a red-blue move with fewer "
                            "walkers than twice the number of dimensions.")
@@ -200,6 +278,10 @@ def propose(coords, log_prob, lp_fn, random, move, trace=None):
             q, factors = _de(s, c, random, move.sigma, g0, tr)
         elif move.kind == "snooker":
             q, factors = _snooker(s, c, random, move.gammas, tr)
+        elif move.kind == "walk":
+            q, factors = _walk(s, c, random, move.s)
+        elif move.kind == "kde":
+            q, factors = _kde(s, c, random, move.bw_method)
         else:
             raise ValueError(move.kind)
         if np.any(np.isinf(q)):                 # ensemble.py:476-479

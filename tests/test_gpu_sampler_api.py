@@ -31,6 +31,12 @@ def target_of(desc):
 
 def move_of(m):
     kw = dict(nsplits=m.nsplits, randomize_split=m.randomize_split, live_dangerously=m.live_dangerously)
+    if m.kind == "gaussian":
+        return moves.GaussianMove(m.cov, mode=m.mode, factor=m.factor)
+    if m.kind == "walk":
+        return moves.WalkMove(s=m.s, **kw)
+    if m.kind == "kde":
+        return moves.KDEMove(bw_method=m.bw_method, **kw)
     if m.kind == "stretch":
         return moves.StretchMove(a=m.a, **kw)
     if m.kind == "de":
@@ -68,6 +74,21 @@ def test_run_mcmc_same_seed_same_chain_as_reference(name):
     assert np.array_equal(st[1], g["rng_key1"]) and st[2] == int(g["rng_pos1"])
     assert np.array_equal(last.coords, g["chain"][-1])
     assert s.iteration == spec["nsteps"]
+
+
+@pytest.mark.parametrize("name", list(cases.HOST_MOVE_CASES))
+def test_host_proposal_moves_same_chain_as_reference(name):
+    """MHMove/GaussianMove (log-probs from the device evaluator), WalkMove/KDEMove (host get_proposal,
+    device accept/commit) and the Stretch+Gaussian mixture of the reference's own unit tests."""
+    g = load_golden(name)
+    spec = cases.build(name)
+    s = make_sampler(spec, g)
+    s.run_mcmc(g["p0"], spec["nsteps"], skip_initial_state_check=True)
+    assert np.array_equal(s.get_chain(), g["chain"])
+    np.testing.assert_allclose(s.get_log_prob(), g["log_prob"], rtol=1e-11)
+    assert np.array_equal(s.backend.accepted, g["accepted_count"])
+    st = s.random_state
+    assert np.array_equal(st[1], g["rng_key1"]) and st[2] == int(g["rng_pos1"])
 
 
 @pytest.mark.parametrize("name", ["c1_stretch_32x5_iso", "mix_stretch_de_64x5", "snooker_64x4_iso"])

@@ -47,6 +47,21 @@ def test_oracle_reproduces_reference_fixture(name):
         assert np.array_equal(np.concatenate(ints), g["ints"])
 
 
+@pytest.mark.parametrize("name", list(cases.HOST_MOVE_CASES))
+def test_oracle_reproduces_host_move_fixture(name):
+    """MHMove/GaussianMove, WalkMove, KDEMove: same pinning as the hot-path moves."""
+    g = load_golden(name)
+    spec = cases.build(name)
+    rs = rng_from_fixture(g)
+    out = run_oracle(spec, g["p0"], rs)
+    assert np.array_equal(out["chain"], g["chain"]), "coords differ from reference"
+    assert np.array_equal(out["accepted_count"], g["accepted_count"])
+    np.testing.assert_allclose(out["log_prob"], g["log_prob"], rtol=1e-12, atol=0)
+    st = rs.get_state()
+    assert np.array_equal(st[1], g["rng_key1"]) and st[2] == int(g["rng_pos1"])
+    assert st[3] == int(g["rng_has_gauss1"]) and st[4] == float(g["rng_cached1"])
+
+
 @pytest.mark.parametrize("name", list(cases.DIGEST_CASES))
 def test_oracle_digest_cases(name):
     d = load_digests()[name]
