@@ -8,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libemx.so")
 
 TARGET_HOST, TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_ROSENBROCK, TARGET_BOX = range(6)
-MOVE_STRETCH, MOVE_DE, MOVE_SNOOKER = range(3)
+MOVE_STRETCH, MOVE_DE, MOVE_SNOOKER, MOVE_GAUSS = range(4)
+GAUSS_VECTOR, GAUSS_RANDOM, GAUSS_SEQUENTIAL = range(3)
 RNG_INPUTS, RNG_MT19937, RNG_PHILOX = range(3)
 EXCHANGE_ALLGATHER, EXCHANGE_PULL = range(2)
 
@@ -76,6 +77,9 @@ SIGNATURES = {
     "emx_device_ptr": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "emx_shard_slots": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "emx_scatter_gathered": (C.c_int, [_P, C.c_int32]),
+    "emx_set_move_scale": (C.c_int, [_P, C.c_int32, C.c_void_p, C.c_int32]),
+    "emx_get_move": (C.c_int, [_P, C.c_int32, C.POINTER(MoveDesc)]),
+    "emx_plan_set_noise": (C.c_int, [_P, _dp, C.c_double]),
     "emx_set_exchange": (C.c_int, [_P, C.c_int32]),
     "emx_exchange_layout": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "emx_set_exchange_buffers": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),

@@ -134,6 +134,34 @@ int make_exact_plan(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc
     return 0;
 }
 
+// One Gaussian Metropolis step's draws in the reference's order (gaussian.py:81-97, mh.py:50-57):
+// [factor uniform] -> randn(N, D) row-major -> [randint(D) per walker] -> (log-prob) -> rand(N).
+// `cursor` is the sequential mode's coordinate counter (advanced here).
+static double make_exact_gauss(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc& mv, double& cursor,
+                               int32_t* off, int32_t* order, int32_t* p0, int32_t* p1, int32_t* p2, double* s0,
+                               double* uacc, double* normals) {
+    double f = 1.0;
+    if (mv.a != 0.0) {
+        const double u = mt.next_double();
+        f = std::exp(-mv.g0 + (mv.g0 - (-mv.g0)) * u);        // legacy uniform: low + (high - low) * u
+    }
+    for (int64_t k = 0; k < N * (int64_t)D; ++k) normals[k] = mt.next_gauss();
+    int col = -1;
+    if (mv.reserved == EMX_GAUSS_SEQUENTIAL) {
+        col = (int)((int64_t)cursor % D);
+        cursor = (double)(((int64_t)cursor + 1) % D);
+    }
+    off[0] = 0;
+    off[1] = (int32_t)N;
+    for (int64_t i = 0; i < N; ++i) {
+        order[i] = p1[i] = p2[i] = (int32_t)i;
+        s0[i] = 0.0;
+        p0[i] = mv.reserved == EMX_GAUSS_RANDOM ? (int32_t)mt.randint((uint64_t)D) : col;
+    }
+    for (int64_t i = 0; i < N; ++i) uacc[i] = mt.next_double();
+    return f;
+}
+
 template <int MOVE>
 void host_native_plan(const NativeArgs& na, int64_t N, const emx_move_desc& mv, int32_t* off, int32_t* order,
                       int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc) {
@@ -263,6 +291,12 @@ struct emx_ctx {
     // moves
     std::vector<emx_move_desc> moves;
     std::vector<double> cdf;
+    // Gaussian Metropolis move: per-move coordinate scales, the displacement rows, exact-mode staging
+    std::vector<double*> mscale;          // device (D) or nullptr, one per move
+    double* disp = nullptr;               // (N, D)
+    double* noise_host = nullptr;         // pinned (N, D)
+    hipEvent_t noise_ev = nullptr;
+    bool noise_busy = false;
     // rng
     int rng_mode = EMX_RNG_PHILOX;
     MT19937Legacy mt;
@@ -280,6 +314,7 @@ struct emx_ctx {
         int move, S, slot;
         uint64_t step;
         NativeArgs nat;
+        double cursor_before;   // Gaussian sequential mode: the move's cursor before this step was planned
     };
     std::deque<Prepared> prepared;
     int64_t prep_hint = 1;   // upcoming steps the caller will take (emx_run sets it): batch size of the native prep
@@ -344,6 +379,13 @@ struct emx_ctx {
 
 static void graph_invalidate(emx_ctx* c);
 
+// forget native plans evaluated ahead of time; the Gaussian sequential cursors they advanced go back
+static void drop_prepared(emx_ctx* c) {
+    for (auto it = c->prepared.rbegin(); it != c->prepared.rend(); ++it)
+        if (it->move < (int)c->moves.size() && c->moves[it->move].kind == EMX_MOVE_GAUSS) c->moves[it->move].gammas = it->cursor_before;
+    c->prepared.clear();
+}
+
 #define FAIL(ctx, code, ...)                         \
     do {                                             \
         char _b[512];                                \
@@ -389,7 +431,7 @@ hipError_t launch_valu(const Shape& sh, dim3 grid, dim3 block, hipStream_t st, c
     EMX_CASE(64, 1, 4) EMX_CASE(64, 1, 8)
     EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
     EMX_CASE(64, 2, 4) EMX_CASE(64, 2, 8)
-    if constexpr (MOVE == MOVE_STRETCH || MOVE == MOVE_EVAL) {
+    if constexpr (MOVE == MOVE_STRETCH || MOVE == MOVE_EVAL || MOVE == MOVE_GAUSS) {
         EMX_CASE(64, 1, 16) EMX_CASE(64, 2, 16)
     }
 #undef EMX_CASE
@@ -421,6 +463,8 @@ hipError_t dispatch_halfstep(int move, bool dense, int dpb, const Shape& sh, dim
         case MOVE_SNOOKER:
             return dense ? launch_dense<MOVE_SNOOKER>(dpb, sh.V, grid, block, lds, st, a)
                          : launch_valu<MOVE_SNOOKER>(sh, grid, block, st, a);
+        case MOVE_GAUSS:
+            return dense ? launch_dense<MOVE_GAUSS>(dpb, sh.V, grid, block, lds, st, a) : launch_valu<MOVE_GAUSS>(sh, grid, block, st, a);
         case MOVE_EVAL:
             return dense ? launch_dense<MOVE_EVAL>(dpb, sh.V, grid, block, lds, st, a) : launch_valu<MOVE_EVAL>(sh, grid, block, st, a);
     }
@@ -434,7 +478,7 @@ size_t dense_lds_bytes(int Dp, int waves) {
 
 int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
     const int WPW = 64 / G;
-    const int nr = move == MOVE_STRETCH ? 2 : move == MOVE_DE ? 3 : move == MOVE_SNOOKER ? 4 : 1;
+    const int nr = (move == MOVE_STRETCH || move == MOVE_GAUSS) ? 2 : move == MOVE_DE ? 3 : move == MOVE_SNOOKER ? 4 : 1;
     int pf = 48 / (nr * CH * V);
     pf = pf < 1 ? 1 : (pf > 8 ? 8 : pf);
     int p2 = 1;
@@ -522,6 +566,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.chain_all = c->chain;
     a.chain_lp_all = c->chain_lp;
     a.t_hi_dev = t_hi_dev;
+    a.disp = c->disp;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;
     if (prof) {
@@ -685,6 +730,11 @@ int emx_destroy(emx_ctx* c) {
         for (void* x : q)
             if (x) hipFree(x);
     }
+    for (double* q : c->mscale)
+        if (q) hipFree(q);
+    if (c->disp) hipFree(c->disp);
+    if (c->noise_host) hipHostFree(c->noise_host);
+    if (c->noise_ev) hipEventDestroy(c->noise_ev);
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_ctr) hipFree(c->d_ctr);
     if (c->h_ctr) hipHostFree(c->h_ctr);
@@ -856,13 +906,27 @@ int emx_eval_log_prob(emx_ctx* c, const double* coords, int64_t n, double* out) 
 int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const double* cdf) {
     NEED(c, nmoves >= 1, "need at least one move");
     for (int i = 0; i < nmoves; ++i) {
-        NEED(c, moves[i].kind >= 0 && moves[i].kind <= 2, "unknown move kind");
+        NEED(c, moves[i].kind >= 0 && moves[i].kind <= EMX_MOVE_GAUSS, "unknown move kind");
+        if (moves[i].kind == EMX_MOVE_GAUSS) {
+            NEED(c, moves[i].nsplits == 1, "the Gaussian move updates the whole ensemble at once (nsplits must be 1)");
+            NEED(c, moves[i].reserved >= EMX_GAUSS_VECTOR && moves[i].reserved <= EMX_GAUSS_SEQUENTIAL, "unknown Gaussian mode");
+            NEED(c, moves[i].a == 0.0 || moves[i].g0 >= 0.0, "'factor' must be >= 1.0");
+            continue;
+        }
         NEED(c, moves[i].nsplits >= 2 && moves[i].nsplits <= 64, "nsplits must be in [2, 64]");
         NEED(c, moves[i].kind != EMX_MOVE_SNOOKER || moves[i].nsplits >= 4, "snooker needs nsplits >= 4");
         NEED(c, moves[i].nsplits <= c->N, "more splits than walkers");
     }
     c->moves.assign(moves, moves + nmoves);
     c->cdf.assign(cdf, cdf + nmoves);
+    for (double* p : c->mscale)
+        if (p) {
+            hipStreamSynchronize(c->stream);
+            hipFree(p);
+        }
+    c->mscale.assign(nmoves, nullptr);
+    for (int i = 0; i < nmoves; ++i)
+        if (moves[i].kind == EMX_MOVE_GAUSS && !c->disp) HIPOK(c, hipMalloc((void**)&c->disp, (size_t)c->N * c->D * 8));
     c->prepared.clear();
     graph_invalidate(c);
     c->graph_warm = false;
@@ -872,7 +936,27 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
 int emx_set_rng_mode(emx_ctx* c, int32_t mode) {
     NEED(c, mode >= 0 && mode <= 2, "unknown rng mode");
     c->rng_mode = mode;
-    c->prepared.clear();
+    drop_prepared(c);
+    return 0;
+}
+
+int emx_set_move_scale(emx_ctx* c, int32_t mi, const double* sd, int32_t n) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, mi >= 0 && mi < (int)c->moves.size() && c->moves[mi].kind == EMX_MOVE_GAUSS, "emx_set_move_scale: not a Gaussian move");
+    NEED(c, (sd == nullptr && n == 0) || n == c->D, "scale vector must have ndim entries");
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (c->mscale[mi]) hipFree(c->mscale[mi]), c->mscale[mi] = nullptr;
+    if (sd) {
+        HIPOK(c, hipMalloc((void**)&c->mscale[mi], (size_t)n * 8));
+        HIPOK(c, hipMemcpy(c->mscale[mi], sd, (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int emx_get_move(emx_ctx* c, int32_t mi, emx_move_desc* out) {
+    NEED(c, mi >= 0 && mi < (int)c->moves.size(), "bad move index");
+    drop_prepared(c);          // plans made ahead of time advanced the sequential cursor: take that back
+    *out = c->moves[mi];
     return 0;
 }
 
@@ -893,7 +977,7 @@ int emx_rng_get_mt19937(emx_ctx* c, uint32_t key[624], int32_t* pos, int32_t* hg
 int emx_rng_set_philox(emx_ctx* c, uint64_t seed, uint64_t step) {
     c->ph_seed = seed;
     c->ph_step = step;
-    c->prepared.clear();
+    drop_prepared(c);
     graph_invalidate(c);   // the seed is baked into the captured advance kernel
     return 0;
 }
@@ -1012,6 +1096,55 @@ static int acquire_slot(emx_ctx* c, emx_ctx::PlanSlot** out, bool host_written) 
     return 0;
 }
 
+// ---- Gaussian Metropolis move: the displacement rows of one step -------------------------------
+static void gauss_args(emx_ctx* c, int mi, GaussDispArgs& a, double f) {
+    const emx_move_desc& mv = c->moves[mi];
+    a.disp = c->disp;
+    a.scale = c->mscale[mi];
+    a.sigma = mv.sigma;
+    a.f = f;
+    a.N = (int32_t)c->N;
+    a.D = c->D;
+    a.mode = mv.reserved;
+}
+
+// host normals (exact / inputs modes) -> disp = (f * scale) * n
+static int gauss_upload_normals(emx_ctx* c, int mi, const double* normals, double f, bool pinned_staging) {
+    const size_t n = (size_t)c->N * c->D;
+    HIPOK(c, hipMemcpyAsync(c->disp, normals, n * 8, hipMemcpyHostToDevice, c->stream));
+    if (pinned_staging) {
+        HIPOK(c, hipEventRecord(c->noise_ev, c->stream));
+        c->noise_busy = true;
+    } else {
+        HIPOK(c, hipStreamSynchronize(c->stream));       // the caller's buffer may be pageable and short-lived
+    }
+    GaussDispArgs a{};
+    gauss_args(c, mi, a, f);
+    hipLaunchKernelGGL(k_gauss_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a);
+    HIPOK(c, hipGetLastError());
+    return 0;
+}
+
+// native mode: the factor is one Philox draw per step, the normals are generated where they are stored
+static int gauss_native_disp(emx_ctx* c, int mi, uint64_t step, const int32_t* col) {
+    const emx_move_desc& mv = c->moves[mi];
+    double f = 1.0;
+    if (mv.a != 0.0) {
+        const Philox4 r = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), 0x46414354u /*'FACT'*/, 0, (uint32_t)c->ph_seed,
+                                        (uint32_t)(c->ph_seed >> 32));
+        f = std::exp(-mv.g0 + 2.0 * mv.g0 * u53(r.v[0], r.v[1]));
+    }
+    GaussDispArgs a{};
+    gauss_args(c, mi, a, f);
+    a.col = col;
+    a.seed = c->ph_seed;
+    a.step = step;
+    const int64_t nthreads = mv.reserved == EMX_GAUSS_VECTOR ? c->N * (int64_t)((c->D + 1) / 2) : c->N;
+    hipLaunchKernelGGL(k_gauss_disp, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, a);
+    HIPOK(c, hipGetLastError());
+    return 0;
+}
+
 static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32_t* move_out, int32_t* S_out);
 
 int emx_step_begin(emx_ctx* c, int32_t store, int32_t* move_out, int32_t* S_out) {
@@ -1045,14 +1178,32 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         const size_t N = (size_t)c->N;
         int32_t* hi = (int32_t*)ps->host;
         double* hd = (double*)(ps->host + N * 16);
-        rc = make_exact_plan(c->mt, c->N, c->D, mv, c->labels_scratch, cur.off.data(), hi, hi + N, hi + 2 * N, hi + 3 * N,
-                             hd, hd + N);
-        NEED(c, rc == 0, "plan generation failed");
-        rc = upload_plan(c, *ps);
-        if (rc) return rc;
+        if (mv.kind == EMX_MOVE_GAUSS) {
+            // the normals go through one pinned buffer: wait until the previous step's copy has left it
+            if (!c->noise_host) {
+                HIPOK(c, hipHostMalloc((void**)&c->noise_host, N * (size_t)c->D * 8, hipHostMallocDefault));
+                HIPOK(c, hipEventCreateWithFlags(&c->noise_ev, hipEventDisableTiming));
+            }
+            if (c->noise_busy) {
+                HIPOK(c, hipEventSynchronize(c->noise_ev));
+                c->noise_busy = false;
+            }
+            const double f = make_exact_gauss(c->mt, c->N, c->D, mv, c->moves[cur.move].gammas, cur.off.data(), hi, hi + N,
+                                              hi + 2 * N, hi + 3 * N, hd, hd + N, c->noise_host);
+            rc = upload_plan(c, *ps);
+            if (rc) return rc;
+            rc = gauss_upload_normals(c, cur.move, c->noise_host, f, true);
+            if (rc) return rc;
+        } else {
+            rc = make_exact_plan(c->mt, c->N, c->D, mv, c->labels_scratch, cur.off.data(), hi, hi + N, hi + 2 * N, hi + 3 * N,
+                                 hd, hd + N);
+            NEED(c, rc == 0, "plan generation failed");
+            rc = upload_plan(c, *ps);
+            if (rc) return rc;
+        }
     } else if (c->rng_mode == EMX_RNG_PHILOX) {
-        if (forced_move >= 0) c->prepared.clear();
-        if (!c->prepared.empty() && c->prepared.front().step != c->ph_step) c->prepared.clear();
+        if (forced_move >= 0) drop_prepared(c);
+        if (!c->prepared.empty() && c->prepared.front().step != c->ph_step) drop_prepared(c);
         if (c->prepared.empty()) {
             // evaluate the plans of the next nb steps (both splits each) in one full-width launch
             int64_t nbw = forced_move >= 0 ? 1 : c->prep_hint;
@@ -1076,6 +1227,12 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
                 pr.nat.seed = c->ph_seed;
                 pr.nat.step = step;
                 pr.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, step);
+                pr.cursor_before = m.gammas;
+                if (m.kind == EMX_MOVE_GAUSS) {
+                    B.gmode[b] = m.reserved;
+                    B.gcol[b] = (int32_t)((int64_t)m.gammas % c->D);
+                    if (m.reserved == EMX_GAUSS_SEQUENTIAL) c->moves[mi].gammas = (double)(((int64_t)m.gammas + 1) % c->D);
+                }
                 c->prepared.push_back(pr);
                 B.nat[b] = pr.nat;
                 B.order[b] = ps->order;
@@ -1104,6 +1261,10 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         cur.slot = pr.slot;
         cur.off.assign(cur.S + 1, 0);
         for (int s = 0; s < cur.S; ++s) cur.off[s + 1] = cur.off[s] + (int32_t)((c->N - s + cur.S - 1) / cur.S);
+        if (c->moves[cur.move].kind == EMX_MOVE_GAUSS) {
+            int rc = gauss_native_disp(c, cur.move, pr.step, c->ring[pr.slot].p0);
+            if (rc) return rc;
+        }
     } else {
         // INPUTS: emx_plan_set must follow
         cur.move = -1;
@@ -1174,6 +1335,14 @@ int emx_plan_get(emx_ctx* c, int32_t* off, int32_t* order, int32_t* p0, int32_t*
     return 0;
 }
 
+int emx_plan_set_noise(emx_ctx* c, const double* normals, double factor) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, cur.active && cur.move >= 0 && c->moves[cur.move].kind == EMX_MOVE_GAUSS,
+         "emx_plan_set_noise follows emx_plan_set of a Gaussian move");
+    return gauss_upload_normals(c, cur.move, normals, factor, false);
+}
+
 static int do_halfstep(emx_ctx* c, int split, int target) {
     auto& cur = c->cur;
     NEED(c, cur.active && cur.move >= 0, "half-step outside a planned step");
@@ -1192,6 +1361,7 @@ static int do_halfstep(emx_ctx* c, int split, int target) {
          "pull exchange: use emx_pull_prepare / emx_pull_apply");
     double* sb = nullptr;
     if (c->sendbuf && target != EMX_TARGET_HOST && c->exchange == EMX_EXCHANGE_ALLGATHER) sb = c->sendbuf;
+    NEED(c, !sb || hi - lo <= c->sendbuf_rows, "exchange buffers too small for this move: call emx_set_shard after emx_set_moves");
     return launch_split(c, mv.kind, target, cur.S, split, pos0, ns, (int)lo, (int)hi, &mv, ps,
                         nullptr, c->X, c->lp, chain, chain_lp, sb);
 }
@@ -1302,6 +1472,7 @@ static emx_ctx::GraphSlot* graph_ready(emx_ctx* c, int store) {
     if (store && c->stored + NB > c->cap) return nullptr;
     auto& g = c->gslot[store ? 1 : 0];
     const emx_move_desc& mv = c->moves[0];
+    if (mv.kind == EMX_MOVE_GAUSS) return nullptr;
     if (g.valid && (g.spw != c->tune_spw || g.wpb != c->tune_wpb || g.bpc != c->tune_bpc || g.target != c->target)) graph_invalidate(c);
     if (!c->d_desc) {
         if (hipMalloc((void**)&c->d_desc, sizeof(StepDesc) * NB) != hipSuccess ||
@@ -1377,6 +1548,8 @@ static emx_ctx::GraphSlot* graph_ready(emx_ctx* c, int store) {
     }
     return &g;
 }
+
+static int scatter_gathered(emx_ctx* c, int32_t split, int64_t block_rows);
 
 // `count` doubles per pair from sendbuf block q to rank q's gathered block `rank` (RCCL's all-to-all when the
 // library has it, grouped send/recv otherwise)
@@ -1464,13 +1637,16 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
                 rc = do_halfstep(c, s, c->target);
                 if (!rc && c->comm) {
                     // the one exchange per half-step: every rank's [row | log_prob | accepted] records to every rank
-                    const int e = g_rccl.AllGather(c->sendbuf, c->gathered, (size_t)c->sendbuf_rows * (c->D + 2), RCCL_FLOAT64,
+                    // only the records this half-step filled travel: a rank's share of the sub-ensemble
+                    const int64_t ns_cur = c->cur.off[s + 1] - c->cur.off[s];
+                    const int64_t rows = std::min<int64_t>(c->sendbuf_rows, (ns_cur + c->world - 1) / c->world);
+                    const int e = g_rccl.AllGather(c->sendbuf, c->gathered, (size_t)rows * (c->D + 2), RCCL_FLOAT64,
                                                    c->comm, c->stream);
                     if (e != 0) {
                         c->err = std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
                         rc = -6;
                     }
-                    if (!rc && c->world > 1) rc = emx_scatter_gathered(c, s);
+                    if (!rc && c->world > 1) rc = scatter_gathered(c, s, rows);
                 }
                 if (rc) {
                     c->cur.active = false;
@@ -1499,12 +1675,22 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
 }
 
 // ---- sharding ----------------------------------------------------------------------------
-static int64_t shard_rows_per_rank(int64_t N, int world) {
-    const int64_t maxns = (N + 1) / 2 + 1;   // largest sub-ensemble (nsplits >= 2)
+// records one rank contributes to the all-gather of a half-step: its share of the largest sub-ensemble
+// (ceil(N / nsplits) walkers; the Gaussian move's single "split" is the whole ensemble)
+static int64_t shard_rows_per_rank(int64_t N, int world, int min_nsplits = 2) {
+    const int64_t maxns = (N + min_nsplits - 1) / min_nsplits + 1;
     return (maxns + world - 1) / world + 1;
 }
 
-static int partners_of(int kind) { return kind == EMX_MOVE_STRETCH ? 1 : kind == EMX_MOVE_DE ? 2 : 3; }
+static int min_nsplits_of(const emx_ctx* c) {
+    int m = 2;
+    for (const auto& mv : c->moves) m = std::min(m, (int)mv.nsplits);
+    return std::max(1, m);
+}
+
+static int partners_of(int kind) {
+    return kind == EMX_MOVE_GAUSS ? 0 : kind == EMX_MOVE_STRETCH ? 1 : kind == EMX_MOVE_DE ? 2 : 3;
+}
 
 // Pull exchange: records one rank may have to send another in one half-step.  Each of the ~N/(S G) walkers
 // a rank updates reads `npart` partners whose owner is uniform over the ranks: mean + 8 sigma + slack,
@@ -1607,7 +1793,7 @@ int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
     c->pull_split = -1;
     if (c->exchange == EMX_EXCHANGE_PULL) return world > 1 ? pull_ensure(c) : 0;
     if (world > 1) {
-        const int64_t per = shard_rows_per_rank(c->N, world);
+        const int64_t per = shard_rows_per_rank(c->N, world, min_nsplits_of(c));
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));
         HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * world * (c->D + 2) * 8));
         c->own_shard_bufs = true;
@@ -1622,7 +1808,7 @@ int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
 int emx_set_shard_buffers(emx_ctx* c, void* sendbuf, void* gathered, int64_t rows_per_rank) {
     NEED(c, c->world >= 1, "emx_set_shard_buffers: call emx_set_shard first");
     NEED(c, c->exchange == EMX_EXCHANGE_ALLGATHER, "pull exchange: use emx_set_exchange_buffers");
-    NEED(c, rows_per_rank >= shard_rows_per_rank(c->N, c->world), "shard buffers too small");
+    NEED(c, rows_per_rank >= shard_rows_per_rank(c->N, c->world, min_nsplits_of(c)), "shard buffers too small");
     HIPOK(c, hipStreamSynchronize(c->stream));
     exchange_free(c);
     c->sendbuf = (double*)sendbuf;
@@ -1638,7 +1824,7 @@ int emx_exchange_layout(emx_ctx* c, int64_t* send_doubles, int64_t* recv_doubles
     if (c->exchange == EMX_EXCHANGE_PULL) {
         pull_layout(c, *send_doubles, *recv_doubles);
     } else {
-        const int64_t per = shard_rows_per_rank(c->N, c->world);
+        const int64_t per = shard_rows_per_rank(c->N, c->world, min_nsplits_of(c));
         *send_doubles = per * (c->D + 2);
         *recv_doubles = per * c->world * (c->D + 2);
     }
@@ -1813,6 +1999,7 @@ int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
         case 3: *ptr = c->gathered; *nbytes = c->recv_doubles * 8; return 0;
         case 4: *ptr = c->chain; *nbytes = c->stored * c->N * c->D * 8; return 0;
         case 5: *ptr = c->chain_lp; *nbytes = c->stored * c->N * 8; return 0;
+        case 6: *ptr = c->disp; *nbytes = c->disp ? c->N * c->D * 8 : 0; return 0;
     }
     FAIL(c, -1, "unknown device pointer id %d", which);
 }
@@ -1825,8 +2012,10 @@ int emx_shard_slots(emx_ctx* c, int32_t split, int64_t* lo, int64_t* hi, int64_t
     return 0;
 }
 
-int emx_scatter_gathered(emx_ctx* c, int32_t split) {
-    // `gathered` holds `world` blocks of `sendbuf_rows` records; block r carries rank r's slots.
+int emx_scatter_gathered(emx_ctx* c, int32_t split) { return scatter_gathered(c, split, c->sendbuf_rows); }
+
+static int scatter_gathered(emx_ctx* c, int32_t split, int64_t block_rows) {
+    // `gathered` holds `world` blocks of `block_rows` records; block r carries rank r's slots.
     HIPOK(c, hipSetDevice(c->device));
     auto& cur = c->cur;
     NEED(c, cur.active && c->gathered, "emx_scatter_gathered needs an active sharded step");
@@ -1848,7 +2037,7 @@ int emx_scatter_gathered(emx_ctx* c, int32_t split) {
             a.chain_lp = c->chain_lp + (size_t)c->stored * c->N;
         }
         // block r starts at record r * sendbuf_rows and holds slot lo first: shift so that slot t indexes directly
-        a.gathered = c->gathered + ((int64_t)r * c->sendbuf_rows - lo) * rec;
+        a.gathered = c->gathered + ((int64_t)r * block_rows - lo) * rec;
         a.order = cur.slot >= 0 ? c->ring[cur.slot].order : nullptr;
         a.N = (int32_t)c->N;
         a.D = c->D;
@@ -1898,7 +2087,7 @@ int emx_comm_init(emx_ctx* c, int32_t rank, int32_t world, const uint8_t id[128]
         rc = pull_ensure(c);
         if (rc) return rc;
     } else if (!c->sendbuf) {   // world == 1: still exercise the exchange buffers
-        const int64_t per = (c->N + 1) / 2 + 2;
+        const int64_t per = c->N + 2;
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));
         HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * (c->D + 2) * 8));
         c->own_shard_bufs = true;

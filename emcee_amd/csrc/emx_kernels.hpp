@@ -28,7 +28,8 @@
 
 namespace emx {
 
-enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_EVAL = 3 };
+enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_GAUSS = 3, MOVE_EVAL = 4 };
+enum : int { GAUSS_VECTOR = 0, GAUSS_RANDOM = 1, GAUSS_SEQUENTIAL = 2 };
 enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5 };
 enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u };
 
@@ -93,6 +94,8 @@ struct HalfStepArgs {
     double* chain_lp_all;
     // pull exchange: the slot count of the (compacted) plan is only known on the device
     const int32_t* t_hi_dev;
+    // Gaussian Metropolis move: (N, D) displacement rows, indexed by walker (k_gauss_*)
+    const double* disp;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -368,7 +371,7 @@ __device__ __forceinline__ double eval_valu_target(const Row<G, V, CH>& q, const
 
 template <int MOVE>
 constexpr int rows_per_pass() {
-    return MOVE == MOVE_STRETCH ? 2 : MOVE == MOVE_DE ? 3 : MOVE == MOVE_SNOOKER ? 4 : 1;
+    return (MOVE == MOVE_STRETCH || MOVE == MOVE_GAUSS) ? 2 : MOVE == MOVE_DE ? 3 : MOVE == MOVE_SNOOKER ? 4 : 1;
 }
 
 template <int G, int V, int CH, int MOVE, int DPB>
@@ -386,8 +389,20 @@ constexpr int prefetch_depth() {
 template <int G, int V, int CH, int MOVE>
 __device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row<G, V, CH>& xa,
                                               const Row<G, V, CH>& xb, const Row<G, V, CH>& xc, double s0,
-                                              double gammas, int D, int gl, Row<G, V, CH>& q, double& factor) {
-    if constexpr (MOVE == MOVE_STRETCH) {
+                                              double gammas, int D, int gl, Row<G, V, CH>& q, double& factor,
+                                              int col = -1) {
+    if constexpr (MOVE == MOVE_GAUSS) {
+        // xa = this walker's displacement row (factor * scale * normal, gaussian.py:87); col >= 0: only
+        // that coordinate moves (gaussian.py:92-101), the others keep their exact value
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int d = (c * G + gl) * V + v;
+                const double moved = xi.x[c][v] + xa.x[c][v];   // x0 + ...
+                q.x[c][v] = (col < 0 || d == col) ? moved : xi.x[c][v];
+            }
+    } else if constexpr (MOVE == MOVE_STRETCH) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -565,7 +580,8 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                 const int srow = (pb + k) * WPW + sub;
                 const int pos = pbase + (srow < nslot ? srow : 0);
                 if (!(A.ablate & 32)) load_row<G, V, CH>(xi[k], A.X + (size_t)wi[k] * D, D, gl);
-                if constexpr (NR >= 2) if (!(A.ablate & 32)) load_row<G, V, CH>(xa[k], A.X + (size_t)ja[k] * D, D, gl);
+                if constexpr (NR >= 2) if (!(A.ablate & 32))
+                    load_row<G, V, CH>(xa[k], MOVE == MOVE_GAUSS ? A.disp + (size_t)wi[k] * D : A.X + (size_t)ja[k] * D, D, gl);
                 if constexpr (NR >= 3) load_row<G, V, CH>(xb[k], A.X + (size_t)jb[k] * D, D, gl);
                 if constexpr (NR >= 4) load_row<G, V, CH>(xc[k], A.X + (size_t)jc[k] * D, D, gl);
                 if constexpr (MOVE != MOVE_EVAL) {
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 
                     Row<G, V, CH> q;
                     make_proposal<G, V, CH, MOVE>(xi[k], xa[NR >= 2 ? k : 0], xb[NR >= 3 ? k : 0], xc[NR >= 4 ? k : 0],
-                                                  s0v[k], A.gammas, D, gl, q, factor);
+                                                  s0v[k], A.gammas, D, gl, q, factor, NR >= 2 ? ja[k] : -1);
 
                     // non-finite proposal -> sticky error (ensemble.py:476-479); the proposal is rejected
                     bool badq = false;
@@ -849,6 +865,81 @@ __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
     }
 }
 
+// Gaussian Metropolis move (moves/gaussian.py, moves/mh.py): every walker is its own slot; p0 carries the
+// coordinate that moves (-1: all of them), uacc the accept uniform.  Same Philox streams as native_slot.
+__host__ __device__ inline void native_gauss_slot(const NativeArgs& na, int D, int mode, int seqcol, int t, int& i,
+                                                  int& p0, int& p1, int& p2, double& s0, double& uacc) {
+    const uint32_t k0 = (uint32_t)na.seed, k1 = (uint32_t)(na.seed >> 32);
+    const uint32_t sl = (uint32_t)na.step, sh = (uint32_t)(na.step >> 32);
+    i = t;
+    p1 = p2 = t;
+    s0 = 0.0;
+    const Philox4 A = philox4x32_10((uint32_t)t, 0u, sl, sh, k0, k1);
+    uacc = u53(A.v[2], A.v[3]);
+    if (mode == GAUSS_RANDOM)
+        p0 = (int)bounded64(A.v[0], A.v[1], (uint64_t)D);
+    else
+        p0 = mode == GAUSS_SEQUENTIAL ? seqcol : -1;
+}
+
+// Box-Muller pair from one Philox block of the (walker, pair) counter; streams 2.. are the noise pairs
+__host__ __device__ inline void native_gauss_pair(uint64_t seed, uint64_t step, int w, int pair, double& n0, double& n1) {
+    const Philox4 R = philox4x32_10((uint32_t)w, 2u + (uint32_t)pair, (uint32_t)step, (uint32_t)(step >> 32),
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u1 = 1.0 - u53(R.v[0], R.v[1]);            // (0, 1]
+    const double u2 = u53(R.v[2], R.v[3]);
+    const double r = sqrt(-2.0 * log(u1));
+    const double th = 6.283185307179586476925 * u2;
+    n0 = r * cos(th);
+    n1 = r * sin(th);
+}
+
+struct GaussDispArgs {
+    double* disp;             // (N, D)
+    const double* scale;      // (D) standard deviations, or nullptr: isotropic `sigma`
+    const int32_t* col;       // plan p0 (slot == walker), used when mode != GAUSS_VECTOR
+    double sigma, f;          // f: this step's step-size factor (gaussian.py:81-84), 1 when unused
+    uint64_t seed, step;
+    int32_t N, D, mode;
+};
+
+// native draws: disp[w][d] = (f * scale_d) * n(w, d).  One thread per (walker, coordinate pair) in the
+// vector mode; in the one-coordinate modes one thread per walker writes just the coordinate that moves.
+__global__ __launch_bounds__(256) void k_gauss_disp(const GaussDispArgs A) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int npair = (A.D + 1) / 2;
+    if (A.mode == GAUSS_VECTOR) {
+        if (tid >= (long long)A.N * npair) return;
+        const int w = (int)(tid / npair), pr = (int)(tid - (long long)w * npair);
+        double n0, n1;
+        native_gauss_pair(A.seed, A.step, w, pr, n0, n1);
+        const int d0 = 2 * pr, d1 = d0 + 1;
+        const double s0 = A.f * (A.scale ? A.scale[d0] : A.sigma);
+        A.disp[(size_t)w * A.D + d0] = s0 * n0;
+        if (d1 < A.D) {
+            const double s1 = A.f * (A.scale ? A.scale[d1] : A.sigma);
+            A.disp[(size_t)w * A.D + d1] = s1 * n1;
+        }
+    } else {
+        if (tid >= A.N) return;
+        const int w = (int)tid, d = A.col[w];
+        double n0, n1;
+        native_gauss_pair(A.seed, A.step, w, d >> 1, n0, n1);
+        const double sc = A.f * (A.scale ? A.scale[d] : A.sigma);
+        A.disp[(size_t)w * A.D + d] = sc * ((d & 1) ? n1 : n0);
+    }
+}
+
+// host-supplied normals (exact / inputs modes): in place, disp = (f * scale_d) * n -- gaussian.py:87's
+// left-to-right product
+__global__ __launch_bounds__(256) void k_gauss_scale(const GaussDispArgs A) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long long)A.N * A.D) return;
+    const int d = (int)(tid % A.D);
+    const double sc = A.f * (A.scale ? A.scale[d] : A.sigma);
+    A.disp[tid] = sc * A.disp[tid];
+}
+
 // Native-mode plans, evaluated full width (one lane per walker and step): the Philox rounds, the keyed-
 // permutation inversions and the two f64 logs are paid once per walker here, not on the few lanes a
 // half-step group would spare.  Up to 8 consecutive steps per launch (grid.y = step): one step is only N
@@ -867,6 +958,7 @@ struct NativeBatchArgs {
     double* fac[NATIVE_BATCH_MAX];
     double a[NATIVE_BATCH_MAX], sigma[NATIVE_BATCH_MAX], g0[NATIVE_BATCH_MAX];
     int32_t move[NATIVE_BATCH_MAX], S[NATIVE_BATCH_MAX];
+    int32_t gmode[NATIVE_BATCH_MAX], gcol[NATIVE_BATCH_MAX];   // Gaussian move: mode, the sequential mode's column
     int32_t N, D, nb;
     const StepDesc* desc;   // graph replay: per-step NativeArgs from device memory instead of nat[]
 };
@@ -886,7 +978,9 @@ __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs
     double z, u;
     const int mv = B.move[b];
     const NativeArgs nat = B.desc ? B.desc[b].nat : B.nat[b];
-    if (mv == MOVE_STRETCH)
+    if (mv == MOVE_GAUSS)
+        native_gauss_slot(nat, B.D, B.gmode[b], B.gcol[b], pos, i, a0, a1, a2, z, u);
+    else if (mv == MOVE_STRETCH)
         native_slot<MOVE_STRETCH>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
     else if (mv == MOVE_DE)
         native_slot<MOVE_DE>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);

@@ -124,6 +124,22 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_set_moves(self.ctx, len(descs), arr, cdf))
         self._moves = list(descs)
 
+    def set_move_scale(self, move_index, std):
+        """Per-coordinate standard deviations of a Gaussian move (None: back to the isotropic sigma)."""
+        if std is None:
+            self._ck(self.lib.emx_set_move_scale(self.ctx, int(move_index), None, 0))
+            return
+        std = _as_f64(std)
+        self._ck(self.lib.emx_set_move_scale(self.ctx, int(move_index), std.ctypes.data, len(std)))
+
+    def get_move(self, move_index):
+        d = MoveDesc()
+        self._ck(self.lib.emx_get_move(self.ctx, int(move_index), C.byref(d)))
+        return d
+
+    def plan_set_noise(self, normals, factor=1.0):
+        self._ck(self.lib.emx_plan_set_noise(self.ctx, _as_f64(normals), float(factor)))
+
     def set_rng_mode(self, mode):
         self._ck(self.lib.emx_set_rng_mode(self.ctx, int(mode)))
 

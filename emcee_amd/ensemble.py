@@ -42,9 +42,12 @@ except ImportError:  # pragma: no cover
     from numpy import VisibleDeprecationWarning
 
 
-def _native_desc(move, ndim):
+def _native_desc(move, ndim, can_fuse=True):
     """MoveDesc of a built-in move (ours, or a reference emcee instance of the same class name
-    with an un-overridden get_proposal); None for anything else."""
+    with an un-overridden get_proposal); None for anything else.  Whole-ensemble Metropolis moves
+    (``_fused_only``) are only worth a device step when the log-prob is evaluated there too."""
+    if getattr(move, "_fused_only", False) and not can_fuse:
+        return None
     if hasattr(move, "_is_native"):
         return move._desc(ndim) if move._is_native() else None
     for klass in type(move).__mro__:
@@ -192,6 +195,10 @@ class EnsembleSampler(object):
         cdf = np.cumsum(self._weights)
         cdf /= cdf[-1]
         ens.set_moves(descs, cdf)
+        for i, m in enumerate(self._moves):
+            vec = getattr(m, "_scale_vector", None)
+            if vec is not None and descs[i].kind == _lib.MOVE_GAUSS:
+                ens.set_move_scale(i, vec())
         if self.rng == "mt19937":
             ens.set_rng_mode(_lib.RNG_MT19937)
             ens.set_mt19937(self._random.get_state())
@@ -201,6 +208,10 @@ class EnsembleSampler(object):
         return ens
 
     def _sync_rng_from_device(self, ens):
+        for i, m in enumerate(self._moves):          # the sequential Gaussian mode's cursor lives in the move
+            step = getattr(m, "get_proposal", None)
+            if hasattr(m, "_scale_vector") and getattr(step, "mode", None) == "sequential" and m._is_native():
+                step.index = int(ens.get_move(i).gammas)
         if self.rng == "mt19937":
             self._random.set_state(ens.get_mt19937())
         else:
@@ -242,12 +253,13 @@ class EnsembleSampler(object):
             raise ValueError("The initial log_prob was NaN")
 
         # which execution path
-        descs = [_native_desc(m, self.ndim) for m in self._moves]
+        can_fuse = self._device_target is not None and state.blobs is None
+        descs = [_native_desc(m, self.ndim, can_fuse) for m in self._moves]
         native = all(d is not None for d in descs)
-        fused = native and self._device_target is not None and state.blobs is None
+        fused = native and can_fuse
         own_backend = isinstance(self.backend, Backend)
         for m in self._moves:
-            live = getattr(m, "live_dangerously", False)
+            live = getattr(m, "live_dangerously", False) or not hasattr(m, "nsplits")   # MH moves have no such guard
             if native and self.nwalkers < 2 * self.ndim and not live:       # reference red_blue.py:64-70
                 raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice "
                                    "the number of dimensions.")
@@ -373,7 +385,7 @@ class EnsembleSampler(object):
             return None
         if not isinstance(self.backend, Backend) or nsteps is None or nsteps < 1:
             return None
-        descs = [_native_desc(m, self.ndim) for m in self._moves]
+        descs = [_native_desc(m, self.ndim, True) for m in self._moves]
         if any(d is None for d in descs):
             return None
         thin_by = int(kw.get("thin_by", 1))
@@ -389,7 +401,7 @@ class EnsembleSampler(object):
             raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
                              "linearly independent for the best performance")
         for m in self._moves:
-            if self.nwalkers < 2 * self.ndim and not getattr(m, "live_dangerously", False):
+            if self.nwalkers < 2 * self.ndim and hasattr(m, "nsplits") and not getattr(m, "live_dangerously", False):
                 raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice "
                                    "the number of dimensions.")
         self.random_state = state.random_state

@@ -64,7 +64,30 @@ class _GaussianStep(object):
 
 class GaussianMove(MHMove):
     """:param cov: scalar, vector or square matrix.  :param mode: ``"vector"`` | ``"random"`` |
-    ``"sequential"``.  :param factor: optional step-size jitter (>= 1)."""
+    ``"sequential"``.  :param factor: optional step-size jitter (>= 1).
+
+    With a device target the scalar and vector forms run fused on the GPU (``EMX_MOVE_GAUSS``:
+    displacement rows from ``k_gauss_disp`` / ``k_gauss_scale``, proposal + log-prob + accept + commit
+    in ``emx::k_halfstep<..., MOVE_GAUSS, ...>``); the matrix form keeps its host proposal."""
+
+    _fused_only = True       # with a host log_prob_fn the proposal stays on the host as well
+
+    def _is_native(self):
+        step = self.get_proposal
+        return isinstance(step, _GaussianStep) and step.kind in ("iso", "diag")
+
+    def _desc(self, ndim):
+        from .. import _lib
+        step = self.get_proposal
+        mode = {"vector": _lib.GAUSS_VECTOR, "random": _lib.GAUSS_RANDOM, "sequential": _lib.GAUSS_SEQUENTIAL}[step.mode]
+        jitter = step._log_factor is not None
+        sigma = float(step.scale) if step.kind == "iso" else 0.0
+        return _lib.MoveDesc(_lib.MOVE_GAUSS, 1, 0, mode, 1.0 if jitter else 0.0, sigma,
+                             float(step._log_factor) if jitter else 0.0, float(step.index))
+
+    def _scale_vector(self):
+        step = self.get_proposal
+        return np.asarray(step.scale, dtype=np.float64) if step.kind == "diag" else None
 
     def __init__(self, cov, mode="vector", factor=None):
         try:

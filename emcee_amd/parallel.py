@@ -30,9 +30,11 @@ def shard_range(ns, rank, world):
     return ns * rank // world, ns * (rank + 1) // world
 
 
-def rows_per_rank(nwalkers, world):
-    """Records per rank in the exchange buffers (mirrors shard_rows_per_rank in emx.hip)."""
-    maxns = (nwalkers + 1) // 2 + 1
+def rows_per_rank(nwalkers, world, min_nsplits=2):
+    """Records per rank in the exchange buffers (mirrors shard_rows_per_rank in emx.hip):
+    a rank's share of the largest sub-ensemble; ``min_nsplits=1`` when a Gaussian move is installed
+    (its single split is the whole ensemble)."""
+    maxns = -(-nwalkers // min_nsplits) + 1
     return (maxns + world - 1) // world + 1
 
 
@@ -160,7 +162,7 @@ class DeviceEngine:
             ens.set_exchange_buffers(self.sendbuf.data_ptr(), ns, self.gathered.data_ptr(), nr)
             return
         ens.set_shard(rank, world)
-        rows = rows_per_rank(ens.nwalkers, world)
+        rows = rows_per_rank(ens.nwalkers, world, min([2] + [int(m.nsplits) for m in getattr(ens, "_moves", [])]))
         rec = ens.ndim + 2
         self.sendbuf = torch.zeros(rows * rec, dtype=torch.float64, device=dev)
         self.gathered = torch.zeros(world * rows * rec, dtype=torch.float64, device=dev)

@@ -32,7 +32,17 @@ enum emx_target_kind {
     EMX_TARGET_BOX = 5         /* 0 inside [0,1]^D else -inf   test_proposal.py:25-28           */
 };
 
-enum emx_move_kind { EMX_MOVE_STRETCH = 0, EMX_MOVE_DE = 1, EMX_MOVE_SNOOKER = 2 };
+enum emx_move_kind {
+    EMX_MOVE_STRETCH = 0, EMX_MOVE_DE = 1, EMX_MOVE_SNOOKER = 2,
+    /* moves/gaussian.py + moves/mh.py: Metropolis step with an isotropic / axis-aligned Gaussian proposal,
+     * every walker at once from its own position (nsplits must be 1).  Fields: reserved = mode
+     * (emx_gauss_mode), sigma = isotropic standard deviation (emx_set_move_scale installs a per-coordinate
+     * vector instead), a != 0 enables the step-size factor exp(U(-g0, g0)) with g0 = ln(factor)
+     * (gaussian.py:81-84), gammas = the sequential mode's coordinate cursor (gaussian.py:96-97; the library
+     * advances it, emx_get_move reads it back). */
+    EMX_MOVE_GAUSS = 3
+};
+enum emx_gauss_mode { EMX_GAUSS_VECTOR = 0, EMX_GAUSS_RANDOM = 1, EMX_GAUSS_SEQUENTIAL = 2 };
 
 enum emx_rng_mode {
     EMX_RNG_INPUTS = 0,  /* every step's plan is supplied with emx_plan_set                     */
@@ -86,6 +96,10 @@ int emx_eval_log_prob(emx_ctx* ctx, const double* coords, int64_t n, double* out
 /* ensemble.py:115-129: move list + normalised cumulative weights (cdf[nmoves-1] == 1) */
 int emx_set_moves(emx_ctx* ctx, int32_t nmoves, const emx_move_desc* moves, const double* cdf);
 int emx_set_rng_mode(emx_ctx* ctx, int32_t mode);
+/* EMX_MOVE_GAUSS: per-coordinate standard deviations (n == ndim; NULL / 0 restores the isotropic sigma) */
+int emx_set_move_scale(emx_ctx* ctx, int32_t move_index, const double* std, int32_t n);
+/* current descriptor of a move (the sequential Gaussian cursor lives in it) */
+int emx_get_move(emx_ctx* ctx, int32_t move_index, emx_move_desc* out);
 /* numpy RandomState.get_state()/set_state() tuple round trip (ensemble.py:216-238) */
 int emx_rng_set_mt19937(emx_ctx* ctx, const uint32_t key[624], int32_t pos, int32_t has_gauss, double cached);
 int emx_rng_get_mt19937(emx_ctx* ctx, uint32_t key[624], int32_t* pos, int32_t* has_gauss, double* cached);
@@ -129,6 +143,10 @@ int emx_plan_set(emx_ctx* ctx, int32_t move_index, const int32_t* off, const int
                  const int32_t* p1, const int32_t* p2, const double* s0, const double* uacc);
 int emx_plan_get(emx_ctx* ctx, int32_t* off, int32_t* order, int32_t* p0, int32_t* p1, int32_t* p2, double* s0,
                  double* uacc);
+/* INPUTS mode, EMX_MOVE_GAUSS: after emx_plan_set (off = {0, N}, order = walker of each slot, p0 = coordinate
+ * that moves or -1, uacc), the (N, D) standard normals rng.randn(N, D) and the step-size factor (1 if unused);
+ * the library forms (factor * scale_d) * n on the device (gaussian.py:87) */
+int emx_plan_set_noise(emx_ctx* ctx, const double* normals, double factor);
 
 /* ---- walker-sharded multi-GPU (one process per GPU; collectives stay in the host layer) -- */
 int emx_set_shard(emx_ctx* ctx, int32_t rank, int32_t world);
@@ -137,7 +155,7 @@ int emx_set_shard(emx_ctx* ctx, int32_t rank, int32_t world);
 int emx_set_shard_buffers(emx_ctx* ctx, void* sendbuf, void* gathered, int64_t rows_per_rank);
 /* raw device pointers for zero-copy wrapping (torch.distributed all-gather buffers):
  * which: 0 coords (N,D), 1 log_prob (N), 2 sendbuf (rows/rank, D+2), 3 gathered (world*rows/rank, D+2),
- *        4 chain (stored, N, D), 5 chain log_prob (stored, N) */
+ *        4 chain (stored, N, D), 5 chain log_prob (stored, N), 6 Gaussian-move displacements (N, D) */
 int emx_device_ptr(emx_ctx* ctx, int32_t which, void** ptr, int64_t* nbytes);
 int emx_shard_slots(emx_ctx* ctx, int32_t split, int64_t* t_lo, int64_t* t_hi, int64_t* ns);
 /* after the all-gather of `sendbuf`s into `gathered`: write the other ranks' rows into X */

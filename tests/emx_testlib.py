@@ -8,6 +8,12 @@ from emcee_amd import _lib
 
 def move_desc(m, ndim):
     """oracle MoveSpec -> C struct (g0 resolved like moves/de.py:33-38)."""
+    if m.kind == "gaussian":
+        mode = {"vector": 0, "random": 1, "sequential": 2}[m.mode]
+        iso = np.ndim(m.cov) == 0
+        lf = 0.0 if m.factor is None else float(np.log(m.factor))
+        return _lib.MoveDesc(_lib.MOVE_GAUSS, 1, 0, mode, 0.0 if m.factor is None else 1.0,
+                             float(np.sqrt(m.cov)) if iso else 0.0, lf, float(m.index))
     kind = {"stretch": 0, "de": 1, "snooker": 2}[m.kind]
     g0 = m.gamma0 if m.gamma0 is not None else 2.38 / np.sqrt(2 * ndim)
     return _lib.MoveDesc(kind, m.nsplits, int(bool(m.randomize_split)), 0, float(m.a), float(m.sigma), float(g0),

@@ -51,6 +51,9 @@ def make_ens(spec, p0):
     set_target(ens, spec["desc"])
     descs = [move_desc(m, spec["D"]) for m in spec["moves"]]
     ens.set_moves(descs, cdf_of(spec["weights"], len(descs)))
+    for i, m in enumerate(spec["moves"]):
+        if m.kind == "gaussian" and np.ndim(m.cov) == 1:
+            ens.set_move_scale(i, np.sqrt(np.asarray(m.cov, dtype=np.float64)))
     ens.set_state(p0)
     ens.eval_state_log_prob()
     return ens

@@ -320,7 +320,12 @@ def test_get_proposal_hook_and_user_subclass():
 @pytest.mark.parametrize("mv,ndim,nsteps", [(lambda: moves.StretchMove(), 1, 2000), (lambda: moves.StretchMove(), 3, 2000),
                                             (lambda: moves.DEMove(), 2, 2000), (lambda: moves.DEMove(gamma0=1.0), 1, 2000),
                                             (lambda: moves.DESnookerMove(), 2, 4000),
-                                            (lambda: moves.StretchMove(nsplits=5), 2, 2000)])
+                                            (lambda: moves.StretchMove(nsplits=5), 2, 2000),
+                                            # reference integration/test_gaussian.py: every mode, with and without factor
+                                            (lambda: moves.GaussianMove(0.5), 1, 4000),
+                                            (lambda: moves.GaussianMove([0.5, 0.3], mode="random"), 2, 6000),
+                                            (lambda: moves.GaussianMove(0.5, mode="sequential", factor=2.0), 2, 6000),
+                                            (lambda: [(moves.StretchMove(), 0.5), (moves.GaussianMove(0.4, factor=1.5), 0.5)], 2, 3000)])
 def test_normal_target_statistics_philox(mv, ndim, nsteps):
     """reference integration/test_proposal.py:31-76 (_test_normal), run in the native RNG mode."""
     from scipy import stats
@@ -338,6 +343,21 @@ def test_normal_target_statistics_philox(mv, ndim, nsteps):
     if ndim == 1:
         ks, _ = stats.kstest(samps[:, 0], "norm")
         assert ks < 0.05
+
+
+def test_gaussian_sequential_cursor_survives_runs():
+    """The sequential mode's coordinate cursor is state of the move (gaussian.py:66,97): two runs of 5 + 9
+    steps must equal the reference's single 14-step run, and the move object must show the cursor."""
+    name = "gauss_iso_sequential_24x3"
+    g = load_golden(name)
+    spec = cases.build(name)
+    s = make_sampler(spec, g)
+    st = s.run_mcmc(g["p0"], 5, skip_initial_state_check=True)
+    assert s._moves[0].get_proposal.index == 5 % 3
+    s.run_mcmc(st, 9, skip_initial_state_check=True)
+    assert s._moves[0].get_proposal.index == 14 % 3
+    assert np.array_equal(s.get_chain(), g["chain"])
+    assert np.array_equal(s.backend.accepted, g["accepted_count"])
 
 
 def test_uniform_start_leaves_its_initialisation():

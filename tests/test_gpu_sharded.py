@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
     ("c1_stretch_32x5_iso", 2, "mt"), ("stretch_50x3_iso", 3, "mt"), ("stretch_128x64_dense", 2, "mt"),
     ("stretch_128x64_dense", 4, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt"),
     ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
-    ("stretch_nsplits3_45x2", 2, "mt"),
+    ("stretch_nsplits3_45x2", 2, "mt"), ("mix_stretch_gauss_32x3", 2, "mt"), ("gauss_diag_random_factor_30x4", 3, "philox"),
 ])
 def test_logical_ranks_equal_single_rank(name, world, rng):
     import torch
@@ -89,6 +89,7 @@ def _run_step(group, steppers):
     ("stretch_128x64_dense", 4, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt"),
     ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
     ("stretch_nsplits3_45x2", 2, "mt"), ("stretch_50x3_iso", 7, "philox"),
+    ("mix_stretch_gauss_32x3", 2, "mt"), ("gauss_diag_random_factor_30x4", 3, "philox"),
 ])
 def test_pull_exchange_equals_single_rank(name, world, rng):
     """Pull exchange (walker-block ownership, partner rows only): each logical rank's block of the chain,
