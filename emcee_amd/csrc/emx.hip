@@ -297,6 +297,9 @@ struct emx_ctx {
     double* noise_host = nullptr;         // pinned (N, D)
     hipEvent_t noise_ev = nullptr;
     bool noise_busy = false;
+    int64_t tune_gauss_materialize = 0;   // native mode: write the displacement rows to HBM (k_gauss_disp) instead of
+                                          // generating them inside the half-step kernel (verification / tests)
+    double gfac = 1.0;                    // step-size factor of the Gaussian step begun
     // rng
     int rng_mode = EMX_RNG_PHILOX;
     MT19937Legacy mt;
@@ -566,7 +569,15 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.chain_all = c->chain;
     a.chain_lp_all = c->chain_lp;
     a.t_hi_dev = t_hi_dev;
-    a.disp = c->disp;
+    if (move == MOVE_GAUSS && mv) {
+        const bool in_registers = c->cur.active && c->cur.native && !c->tune_gauss_materialize;
+        a.disp = in_registers ? nullptr : c->disp;
+        a.gscale = c->cur.move >= 0 ? c->mscale[c->cur.move] : nullptr;
+        a.gsigma = mv->sigma;
+        a.gfac = c->gfac;
+        a.gseed = c->ph_seed;
+        a.gstep = c->cur.nat.step;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;
     if (prof) {
@@ -771,6 +782,10 @@ int emx_status(emx_ctx* c, uint32_t* bits) {
 int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "spw")) {
         c->tune_spw = v;
+        return 0;
+    }
+    if (!strcmp(key, "gauss_materialize")) {
+        c->tune_gauss_materialize = v;
         return 0;
     }
     if (!strcmp(key, "throttle")) {
@@ -1134,6 +1149,8 @@ static int gauss_native_disp(emx_ctx* c, int mi, uint64_t step, const int32_t* c
                                         (uint32_t)(c->ph_seed >> 32));
         f = std::exp(-mv.g0 + 2.0 * mv.g0 * u53(r.v[0], r.v[1]));
     }
+    c->gfac = f;
+    if (!c->tune_gauss_materialize) return 0;      // the half-step kernel generates the rows in registers
     GaussDispArgs a{};
     gauss_args(c, mi, a, f);
     a.col = col;

@@ -94,8 +94,12 @@ struct HalfStepArgs {
     double* chain_lp_all;
     // pull exchange: the slot count of the (compacted) plan is only known on the device
     const int32_t* t_hi_dev;
-    // Gaussian Metropolis move: (N, D) displacement rows, indexed by walker (k_gauss_*)
+    // Gaussian Metropolis move: (N, D) displacement rows, indexed by walker (k_gauss_*); nullptr in the
+    // native mode, where the rows are generated in registers from (gseed, gstep, walker, coordinate pair)
     const double* disp;
+    const double* gscale;          // (D) standard deviations or nullptr: isotropic gsigma
+    double gsigma, gfac;           // gfac: this step's step-size factor
+    unsigned long long gseed, gstep;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -369,6 +373,37 @@ __device__ __forceinline__ double eval_valu_target(const Row<G, V, CH>& q, const
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+// Gaussian Metropolis move (moves/gaussian.py, moves/mh.py): every walker is its own slot; p0 carries the
+// coordinate that moves (-1: all of them), uacc the accept uniform.  Same Philox streams as native_slot.
+__host__ __device__ inline void native_gauss_slot(const NativeArgs& na, int D, int mode, int seqcol, int t, int& i,
+                                                  int& p0, int& p1, int& p2, double& s0, double& uacc) {
+    const uint32_t k0 = (uint32_t)na.seed, k1 = (uint32_t)(na.seed >> 32);
+    const uint32_t sl = (uint32_t)na.step, sh = (uint32_t)(na.step >> 32);
+    i = t;
+    p1 = p2 = t;
+    s0 = 0.0;
+    const Philox4 A = philox4x32_10((uint32_t)t, 0u, sl, sh, k0, k1);
+    uacc = u53(A.v[2], A.v[3]);
+    if (mode == GAUSS_RANDOM)
+        p0 = (int)bounded64(A.v[0], A.v[1], (uint64_t)D);
+    else
+        p0 = mode == GAUSS_SEQUENTIAL ? seqcol : -1;
+}
+
+// Box-Muller pair from one Philox block of the (walker, pair) counter; streams 2.. are the noise pairs.
+// The radius is computed in f64 (53-bit uniform: tails to 8.5 sigma), the direction with the hardware
+// v_sin_f32 / v_cos_f32 (argument in revolutions, 32-bit uniform): absolute error ~1e-6 * radius, which a
+// symmetric Metropolis proposal does not care about.  One definition for every path that needs a normal.
+__device__ __forceinline__ void native_gauss_pair(uint64_t seed, uint64_t step, int w, int pair, double& n0, double& n1) {
+    const Philox4 R = philox4x32_10((uint32_t)w, 2u + (uint32_t)pair, (uint32_t)step, (uint32_t)(step >> 32),
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u1 = 1.0 - u53(R.v[0], R.v[1]);            // (0, 1]
+    const double r = sqrt(-2.0 * log(u1));
+    const float rev = (float)(R.v[2] >> 8) * 5.9604644775390625e-8f;   // [0, 1) revolutions, 24 bits: exact in f32
+    n0 = r * (double)__builtin_amdgcn_cosf(rev);
+    n1 = r * (double)__builtin_amdgcn_sinf(rev);
+}
+
 template <int MOVE>
 constexpr int rows_per_pass() {
     return (MOVE == MOVE_STRETCH || MOVE == MOVE_GAUSS) ? 2 : MOVE == MOVE_DE ? 3 : MOVE == MOVE_SNOOKER ? 4 : 1;
@@ -383,6 +418,44 @@ constexpr int prefetch_depth() {
     while (p2 * 2 <= pf) p2 *= 2;
     if (DPB > 0 && p2 > 16 / WPW) p2 = 16 / WPW;           // dense: a batch never spans two 16-row MFMA tiles
     return p2 < G ? p2 : G;                                // at most 64 slots per batch
+}
+
+// native Gaussian move: this lane's part of walker w's displacement row, (f * scale_d) * n(w, d)
+template <int G, int V, int CH>
+__device__ __forceinline__ void gauss_disp_row(Row<G, V, CH>& t, const HalfStepArgs& A, int w, int col, int D, int gl) {
+    if (col >= 0) {
+        // one-coordinate modes (launch-uniform branch): a single normal per walker, computed once by every lane
+        // of the walker's group instead of once per chunk
+        double n0, n1;
+        native_gauss_pair(A.gseed, A.gstep, w, col >> 1, n0, n1);
+        const double val = (A.gfac * (A.gscale ? A.gscale[col] : A.gsigma)) * ((col & 1) ? n1 : n0);
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int v = 0; v < V; ++v) t.x[c][v] = ((c * G + gl) * V + v == col) ? val : 0.0;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if constexpr (V == 2) {
+            const int pr = c * G + gl, d0 = 2 * pr;
+            t.x[c][0] = t.x[c][1] = 0.0;
+            if (d0 < D) {
+                double n0, n1;
+                native_gauss_pair(A.gseed, A.gstep, w, pr, n0, n1);
+                t.x[c][0] = (A.gfac * (A.gscale ? A.gscale[d0] : A.gsigma)) * n0;
+                if (d0 + 1 < D) t.x[c][1] = (A.gfac * (A.gscale ? A.gscale[d0 + 1] : A.gsigma)) * n1;
+            }
+        } else {
+            const int d = c * G + gl;
+            t.x[c][0] = 0.0;
+            if (d < D) {
+                double n0, n1;
+                native_gauss_pair(A.gseed, A.gstep, w, d >> 1, n0, n1);
+                t.x[c][0] = (A.gfac * (A.gscale ? A.gscale[d] : A.gsigma)) * ((d & 1) ? n1 : n0);
+            }
+        }
+    }
 }
 
 // proposal from the prefetched rows; rounding order as in stretch.py:33 / de.py:53-62 / de_snooker.py:41-46
@@ -580,8 +653,11 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                 const int srow = (pb + k) * WPW + sub;
                 const int pos = pbase + (srow < nslot ? srow : 0);
                 if (!(A.ablate & 32)) load_row<G, V, CH>(xi[k], A.X + (size_t)wi[k] * D, D, gl);
-                if constexpr (NR >= 2) if (!(A.ablate & 32))
-                    load_row<G, V, CH>(xa[k], MOVE == MOVE_GAUSS ? A.disp + (size_t)wi[k] * D : A.X + (size_t)ja[k] * D, D, gl);
+                if constexpr (MOVE == MOVE_GAUSS) {
+                    if (A.disp) load_row<G, V, CH>(xa[k], A.disp + (size_t)wi[k] * D, D, gl);
+                } else if constexpr (NR >= 2) {
+                    if (!(A.ablate & 32)) load_row<G, V, CH>(xa[k], A.X + (size_t)ja[k] * D, D, gl);
+                }
                 if constexpr (NR >= 3) load_row<G, V, CH>(xb[k], A.X + (size_t)jb[k] * D, D, gl);
                 if constexpr (NR >= 4) load_row<G, V, CH>(xc[k], A.X + (size_t)jc[k] * D, D, gl);
                 if constexpr (MOVE != MOVE_EVAL) {
@@ -619,6 +695,8 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                     double factor = facv[k];
 
                     Row<G, V, CH> q;
+                    if constexpr (MOVE == MOVE_GAUSS)
+                        if (!A.disp) gauss_disp_row<G, V, CH>(xa[k], A, i, ja[k], D, gl);
                     make_proposal<G, V, CH, MOVE>(xi[k], xa[NR >= 2 ? k : 0], xb[NR >= 3 ? k : 0], xc[NR >= 4 ? k : 0],
                                                   s0v[k], A.gammas, D, gl, q, factor, NR >= 2 ? ja[k] : -1);
 
@@ -863,35 +941,6 @@ __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
             if (accept) A.acc_count[i] += 1u;
         }
     }
-}
-
-// Gaussian Metropolis move (moves/gaussian.py, moves/mh.py): every walker is its own slot; p0 carries the
-// coordinate that moves (-1: all of them), uacc the accept uniform.  Same Philox streams as native_slot.
-__host__ __device__ inline void native_gauss_slot(const NativeArgs& na, int D, int mode, int seqcol, int t, int& i,
-                                                  int& p0, int& p1, int& p2, double& s0, double& uacc) {
-    const uint32_t k0 = (uint32_t)na.seed, k1 = (uint32_t)(na.seed >> 32);
-    const uint32_t sl = (uint32_t)na.step, sh = (uint32_t)(na.step >> 32);
-    i = t;
-    p1 = p2 = t;
-    s0 = 0.0;
-    const Philox4 A = philox4x32_10((uint32_t)t, 0u, sl, sh, k0, k1);
-    uacc = u53(A.v[2], A.v[3]);
-    if (mode == GAUSS_RANDOM)
-        p0 = (int)bounded64(A.v[0], A.v[1], (uint64_t)D);
-    else
-        p0 = mode == GAUSS_SEQUENTIAL ? seqcol : -1;
-}
-
-// Box-Muller pair from one Philox block of the (walker, pair) counter; streams 2.. are the noise pairs
-__host__ __device__ inline void native_gauss_pair(uint64_t seed, uint64_t step, int w, int pair, double& n0, double& n1) {
-    const Philox4 R = philox4x32_10((uint32_t)w, 2u + (uint32_t)pair, (uint32_t)step, (uint32_t)(step >> 32),
-                                    (uint32_t)seed, (uint32_t)(seed >> 32));
-    const double u1 = 1.0 - u53(R.v[0], R.v[1]);            // (0, 1]
-    const double u2 = u53(R.v[2], R.v[3]);
-    const double r = sqrt(-2.0 * log(u1));
-    const double th = 6.283185307179586476925 * u2;
-    n0 = r * cos(th);
-    n1 = r * sin(th);
 }
 
 struct GaussDispArgs {

@@ -76,7 +76,8 @@ int emx_sync(emx_ctx* ctx);
  * (ensemble.py:476-479), bit2 pull-exchange record capacity exceeded (a >8 sigma event: the run is
  * invalid, never silently wrong).  Reading clears it. */
 int emx_status(emx_ctx* ctx, uint32_t* bits);
-int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value); /* "spw", "blocks_per_cu" */
+/* keys: "spw", "blocks_per_cu", "waves_per_block", "prep_hint", "graph", "throttle", "gauss_materialize" */
+int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value);
 
 /* ---- state: State(coords, log_prob) (state.py:10-45) ---------------------------------- */
 int emx_set_state(emx_ctx* ctx, const double* coords, const double* log_prob /* or NULL */);

@@ -118,6 +118,7 @@ def test_native_step_replays_from_its_own_draws(mode, factor):
     ens = make_ens(spec, p0)
     ens.set_rng_mode(_lib.RNG_PHILOX)
     ens.set_philox(99, 0)
+    ens.set_tuning("gauss_materialize", 1)        # rows to HBM (k_gauss_disp) so that the test can read them
     x, lp = p0.copy(), so.iso_gauss(p0)
     for step in range(6):
         k, S = ens.step_begin(False)
@@ -153,6 +154,7 @@ def test_native_normals_are_standard_normal():
     ens = make_ens(spec, np.zeros((N, D)))
     ens.set_rng_mode(_lib.RNG_PHILOX)
     ens.set_philox(7, 0)
+    ens.set_tuning("gauss_materialize", 1)
     blocks = []
     for _ in range(4):
         ens.step_begin(False)
@@ -167,6 +169,41 @@ def test_native_normals_are_standard_normal():
     assert not np.array_equal(blocks[0], blocks[1])
     assert abs(np.mean(np.abs(z) > 3) - 0.0027) < 0.001
     ens.close()
+
+
+@pytest.mark.parametrize("N,D,target,mode,factor", [
+    (64, 5, "iso", "vector", None), (200, 64, "dense", "vector", 1.3), (96, 7, "diag", "random", None),
+    (50, 2, "iso", "sequential", 2.0), (40, 130, "diag", "vector", None), (333, 33, "rosenbrock", "random", 1.1),
+    (128, 1024, "diag", "vector", None),
+])
+def test_rows_generated_in_registers_equal_the_materialised_rows(N, D, target, mode, factor):
+    """Default native path (normals generated inside k_halfstep, no HBM round trip) vs the same draws written
+    by k_gauss_disp and read back as rows: same chain, bit for bit, in every row layout (V = 1 and 2)."""
+    rs = np.random.RandomState(D)
+    mv = so.MoveSpec("gaussian", cov=((0.5 + rs.rand(D)) / D) if D != 5 else 0.1, mode=mode, factor=factor)
+    desc = {"kind": target}
+    if target == "diag":
+        desc.update(mu=rs.randn(D), ivar=1.0 / (0.1 + rs.rand(D)))
+    elif target == "dense":
+        mu, cov_, icov = cases._dense_params(D, 5)
+        desc.update(mu=mu, cov=cov_, icov=icov)
+    spec = dict(N=N, D=D, moves=[mv], weights=None, desc=desc)
+    p0 = (1.0 if target == "rosenbrock" else 0.0) + 0.1 * rs.randn(N, D) + desc.get("mu", 0.0)
+    out = []
+    for materialise in (0, 1):
+        ens = make_ens(spec, p0)
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(2024, 3)
+        ens.set_tuning("gauss_materialize", materialise)
+        ens.chain_config(12)
+        ens.run(12, 1, True)
+        assert ens.status() == 0
+        out.append((ens.chain_read(0, 0, 12), ens.chain_read(1, 0, 12), ens.accepted_counts()))
+        ens.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    acc = out[0][2].sum() / (12 * N)
+    assert 0.0 < acc < 1.0, acc
 
 
 def test_gaussian_move_validation_is_loud():

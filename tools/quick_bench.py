@@ -19,7 +19,7 @@ def dense_params(D, seed=0):
     return mu, cov, 0.5 * (icov + icov.T)
 
 
-def run(N, D, target, move=0, S=2, steps=200, spw=0, store=False, rng=_lib.RNG_PHILOX, bpc=2):
+def run(N, D, target, move=0, S=2, steps=200, spw=0, store=False, rng=_lib.RNG_PHILOX, bpc=2, gsigma=0.05, gmode=0):
     ens = DeviceEnsemble(N, D)
     rs = np.random.RandomState(1)
     if target == "dense":
@@ -36,7 +36,10 @@ def run(N, D, target, move=0, S=2, steps=200, spw=0, store=False, rng=_lib.RNG_P
     else:
         ens.set_target(_lib.TARGET_ROSENBROCK, scale=20.0)
         p0 = 1 + 0.1 * rs.randn(N, D)
-    md = _lib.MoveDesc(move, 4 if move == 2 else S, 1, 0, 2.0, 1e-5, 2.38 / np.sqrt(2 * D), 1.7)
+    if move == 3:      # Gaussian Metropolis move, vector mode, step sized for ~25 % acceptance
+        md = _lib.MoveDesc(3, 1, 0, gmode, 0.0, gsigma, 0.0, 0.0)
+    else:
+        md = _lib.MoveDesc(move, 4 if move == 2 else S, 1, 0, 2.0, 1e-5, 2.38 / np.sqrt(2 * D), 1.7)
     ens.set_moves([md], np.array([1.0]))
     ens.set_rng_mode(rng)
     if rng == _lib.RNG_MT19937:
@@ -64,7 +67,7 @@ def run(N, D, target, move=0, S=2, steps=200, spw=0, store=False, rng=_lib.RNG_P
     ens.run(32, 1, False)
     pl = ens.profile_read(64)
     ens.close()
-    part = {0: 1, 1: 2, 2: 3}[move]
+    part = {0: 1, 1: 2, 2: 3, 3: 0}[move]
     B = (16 + 8 * part) * D + 17 + (8 * D + 8 if store else 0)
     wups = N * steps / (ms * 1e-3)
     return dict(N=N, D=D, target=target, move=move, spw=spw, store=store, rng=rng, ms_per_step=ms / steps,
@@ -76,6 +79,7 @@ def run(N, D, target, move=0, S=2, steps=200, spw=0, store=False, rng=_lib.RNG_P
 if __name__ == "__main__":
     out = []
     cfgs = []
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     for spw in (0, 16, 32, 64):
         cfgs.append(dict(N=65536, D=64, target="dense", spw=spw))
     for spw in (0, 4, 8, 16, 32, 64):
@@ -86,8 +90,14 @@ if __name__ == "__main__":
              dict(N=16384, D=1024, target="diag"),
              dict(N=65536, D=64, target="dense", move=1),
              dict(N=65536, D=64, target="dense", move=2),
+             dict(N=65536, D=64, target="dense", move=3, gsigma=0.03),
+             dict(N=65536, D=64, target="iso", move=3, gsigma=0.25),
+             dict(N=65536, D=64, target="iso", move=3, gsigma=1.0, gmode=1),
+             dict(N=65536, D=64, target="dense", move=3, gsigma=0.03, rng=_lib.RNG_MT19937, steps=10),
              dict(N=32, D=5, target="iso", steps=2000),
              dict(N=1024, D=16, target="iso", steps=2000)]
+    if only == "gauss":
+        cfgs = [c for c in cfgs if c.get("move") == 3]
     for c in cfgs:
         try:
             r = run(**c)
@@ -95,4 +105,4 @@ if __name__ == "__main__":
             r = dict(cfg=c, error=str(e))
         print(json.dumps(r), flush=True)
         out.append(r)
-    json.dump(out, open("gpurun_out/quick_bench.json", "w"), indent=1)
+    json.dump(out, open("gpurun_out/quick_bench%s.json" % ("_" + only if only else ""), "w"), indent=1)
