@@ -612,9 +612,22 @@ def _split_log_prob_and_blobs(results, blobs_dtype):
     return log_prob, blob
 
 
+_DEVICE_CHECK_MIN_SIZE = 1 << 21      # elements; below this the host SVD is quicker than the PCIe round trip
+
+
 def walkers_independent(coords):
     """Initial-state conditioning check (reference ``ensemble.py:653-663``): the scaled, centred
-    walker matrix must have condition number <= 1e8.  One-off host check outside the step loop."""
+    walker matrix must have condition number <= 1e8.  One-off check outside the step loop.
+
+    Large ensembles (>= 2^21 coordinates) on a machine with a GPU are checked there: the same
+    centring / scaling passes, then the (ndim, ndim) triangular factor of a Householder QR (rocSOLVER
+    through ``torch.linalg.qr``) whose singular values are those of the tall matrix -- backward stable
+    like the SVD the reference takes, so the verdict is the same (a Gram matrix
+    would square the condition number and could not resolve the 1e8 threshold in float64)."""
+    if np.size(coords) >= _DEVICE_CHECK_MIN_SIZE and np.asarray(coords).dtype == np.float64:
+        verdict = _walkers_independent_device(coords)
+        if verdict is not None:
+            return verdict
     if not np.all(np.isfinite(coords)):
         return False
     C = coords - np.mean(coords, axis=0)[None, :]
@@ -624,6 +637,31 @@ def walkers_independent(coords):
     C /= colmax
     C /= np.sqrt(np.sum(C ** 2, axis=0))
     return np.linalg.cond(C.astype(float)) <= 1e8
+
+
+def _walkers_independent_device(coords):
+    """The check on the GPU; None when no GPU / no QR is available (the caller then uses the host)."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None
+        x = torch.as_tensor(np.ascontiguousarray(coords), device="cuda")
+        if not bool(torch.isfinite(x).all()):
+            return False
+        x = x - x.mean(dim=0, keepdim=True)
+        colmax = x.abs().amax(dim=0)
+        if bool((colmax == 0).any()):
+            return False
+        x = x / colmax
+        x = x / torch.sqrt((x * x).sum(dim=0))
+        if x.shape[0] < x.shape[1]:
+            return False                      # fewer walkers than dimensions: rank deficient by construction
+        r = torch.linalg.qr(x, mode="r").R.cpu().numpy()
+    except Exception:  # noqa: BLE001
+        return None
+    if not np.all(np.isfinite(r)):
+        return False
+    return bool(np.linalg.cond(r) <= 1e8)
 
 
 def ndarray_to_list_of_dicts(x, key_map):

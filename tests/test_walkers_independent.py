@@ -1,0 +1,58 @@
+"""walkers_independent: the reference's cases (unit/test_sampler.py:237-321) on the host path, and --
+on a GPU -- the device path (QR on the GPU) against the host verdict at sizes where it is used."""
+import numpy as np
+import pytest
+
+from emcee_amd import walkers_independent
+from emcee_amd import ensemble as ens_mod
+
+
+def _cases(nw, nd, rs):
+    """(name, matrix, expected) scaled-up versions of the reference's independence tests."""
+    w = rs.randn(nw, nd)
+    p = rs.randn(nd)
+    p /= np.sqrt(p @ p)
+    proj = (w @ p)[:, None] * p[None, :]
+    scales = np.resize(np.array([1, 1e10, 1e100, 1e200, 1e-10, 1e-100, 1e-200]), nd)
+    return [
+        ("ones", np.ones((nw, nd)), False),
+        ("randn", w, True),
+        ("offset 1e5", w + 1e5, True),
+        ("offset 1e10", w + 1e10, True),
+        ("offset 10/eps", w + 10 / np.finfo(float).eps, False),
+        ("projected", w - proj, False),
+        ("projected shifted", w - proj + p[None, :], False),
+        ("squashed 1e-10", w - proj + 1e-10 * proj, False),
+        ("squashed 1e-5", w - proj + 1e-5 * proj, True),
+        ("scaled", w * scales[None, :], True),
+        ("duplicate column", np.column_stack([w[:, :-1], w[:, 0]]), False),
+        ("nan", np.where(np.arange(nw * nd).reshape(nw, nd) == 7, np.nan, w), False),
+    ]
+
+
+@pytest.mark.parametrize("nw,nd", [(10, 2), (20, 5), (30, 10)])
+def test_reference_cases_host(nw, nd):
+    rs = np.random.RandomState(nw)
+    for name, m, expect in _cases(nw, nd, rs):
+        assert walkers_independent(m) == expect, name
+    assert not walkers_independent(rs.randn(nd, nd + 1))          # too few walkers
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw,nd", [(65536, 64), (4096, 600), (262144, 8)])
+def test_device_path_agrees_with_host(nw, nd):
+    rs = np.random.RandomState(nd)
+    assert nw * nd >= ens_mod._DEVICE_CHECK_MIN_SIZE
+    saved = ens_mod._DEVICE_CHECK_MIN_SIZE
+    for name, m, expect in _cases(nw, nd, rs):
+        dev = ens_mod._walkers_independent_device(m)
+        assert dev is not None, "device path unavailable on a GPU box"
+        try:
+            ens_mod._DEVICE_CHECK_MIN_SIZE = 1 << 62          # force the reference's host algorithm
+            host = walkers_independent(m)
+        finally:
+            ens_mod._DEVICE_CHECK_MIN_SIZE = saved
+        assert dev == host, name
+        if name not in ("offset 10/eps",):                   # quantised to multiples of 8: full rank again when nw is large
+            assert dev == expect, name
+        assert walkers_independent(m) == host, name          # the public entry point takes the device path here
