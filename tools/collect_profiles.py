@@ -1,0 +1,49 @@
+"""Copy the summaries of one tools/gpu_session.sh run from gpurun_out/ into profiles/<round>/ (tracked)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import statistics
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = "gpurun_out/prof_%s" % R, "profiles/%s" % R
+os.makedirs(dst, exist_ok=True)
+for name in ("c2_kernel_stats.csv", "c2_domain_stats.csv"):
+    shutil.copy(os.path.join(src, "trace", name), os.path.join(dst, name))
+tr = os.path.join(src, "trace", "c2_kernel_trace.csv")
+tr = tr if os.path.exists(tr) else tr + ".head"
+with open(tr) as f, open(os.path.join(dst, "c2_kernel_trace.head.csv"), "w") as g:
+    for i, line in enumerate(f):
+        if i >= 200:
+            break
+        g.write(line)
+summ = {}
+for which in ("pmc_fetch", "pmc_write"):
+    p = os.path.join(src, which, "c2_counter_collection.csv")
+    p = p if os.path.exists(p) else p + ".head"
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        agg["%s | %s" % (r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        summ[k] = dict(n=len(v), median=statistics.median(v), mean=statistics.mean(v), min=min(v), max=max(v))
+json.dump(summ, open(os.path.join(dst, "c2_pmc_summary.json"), "w"), indent=1)
+kern = "void emx::k_halfstep<8, 2, 4, 0, 4>(emx::HalfStepArgs)"
+fetch, write = summ[kern + " | FETCH_SIZE"]["median"], summ[kern + " | WRITE_SIZE"]["median"]
+json.dump({
+    "c2_stretch_dense_bytes_per_launch": (2 * fetch + write) * 1024,
+    "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s/c2_pmc_summary.json); "
+           "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section "
+           "(gfx950 counts 128-B requests at 64 B); WRITE_SIZE uncalibrated" % R,
+    "fetch_kb_median": fetch, "write_kb_median": write, "kernel": kern}, open("profiles/pmc_traffic.json", "w"), indent=1)
+shutil.copy("gpurun_out/bench_%s.json" % R, os.path.join(dst, "bench_n1.json"))
+if os.path.exists("gpurun_out/bench_%s_forcedist.json" % R):
+    shutil.copy("gpurun_out/bench_%s_forcedist.json" % R, os.path.join(dst, "bench_forcedist_world1.json"))
+with open("gpurun_out/pmc_%s.txt" % R) as f, open(os.path.join(dst, "c2_sq_counters.txt"), "w") as g:
+    g.write("rocprofv3 --pmc (tools/pmc_session.sh), medians over the k_halfstep<8,2,4,STRETCH,4> launches of bench.py\n")
+    for line in f:
+        if line.startswith(("sq1 ", "sq2 ", "grbm ")):
+            g.write(line)
+print(open(os.path.join(dst, "c2_kernel_stats.csv")).read()[:700])
+print(json.load(open("profiles/pmc_traffic.json"))["c2_stretch_dense_bytes_per_launch"])
