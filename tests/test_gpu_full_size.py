@@ -102,3 +102,66 @@ def test_native_mode_invariants_at_full_size(name):
     lo, hi = {"c2": (0.10, 0.25), "c3": (0.10, 0.45), "c4": (0.10, 0.45), "c5": (0.005, 0.12)}[name[:2]]
     assert lo < frac < hi, frac                                                    # (iv)
     ens.close()
+
+
+@pytest.mark.parametrize("name,world", [("c2_65536x64_dense_stretch", 4), ("c4_65536x64_dense_de_snooker", 2)])
+def test_pull_exchange_at_full_size(name, world):
+    """Pull exchange at a BASELINE size with `world` logical ranks on the one GPU: the per-pair record
+    capacity (mean + 8 sigma) must hold, every rank's block and the re-synchronised replicas must equal
+    the single-rank run bit for bit."""
+    import torch
+    from emcee_amd.parallel import DeviceEngine, LocalGroup, block_range, pull_capacity
+    spec = FULL[name]()
+    nst = 3
+
+    def setup(ens):
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(31337, 0)
+        ens.chain_config(nst)
+
+    ref = make_ens(spec, spec["p0"])
+    setup(ref)
+    ref.run(nst, 1, True)
+    ref_chain, ref_lp, ref_acc = ref.chain_read(0, 0, nst), ref.chain_read(1, 0, nst), ref.accepted_counts()
+    ref.close()
+    engines = []
+    for r in range(world):
+        ens = make_ens(spec, spec["p0"])
+        setup(ens)
+        engines.append(DeviceEngine(ens, r, world, torch.device("cuda", 0), exchange="pull"))
+    nd = spec["D"]
+
+    def sync():
+        for e in engines:
+            e.ens.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(nst):
+        res = [e.step_begin(True) for e in engines]
+        assert all(r == res[0] for r in res)
+        npart = {"stretch": 1, "de": 2, "snooker": 3}[spec["moves"][res[0][0]].kind]
+        for split in range(res[0][1]):
+            caps = [e.pull_prepare(split) for e in engines]
+            assert set(caps) == {pull_capacity(spec["N"], world, res[0][1], npart)}
+            sync()
+            LocalGroup._all_to_all(engines, caps[0] * (nd + 1))
+            sync()
+            for e in engines:
+                e.pull_apply(split)
+        for e in engines:
+            e.step_end()
+    for r, e in enumerate(engines):
+        lo, hi = block_range(spec["N"], r, world)
+        assert e.ens.status() == 0, "exchange capacity exceeded"
+        assert np.array_equal(e.ens.chain_read(0, 0, nst)[:, lo:hi], ref_chain[:, lo:hi])
+        assert np.array_equal(e.ens.chain_read(1, 0, nst)[:, lo:hi], ref_lp[:, lo:hi])
+    per = [e.replica_pack() for e in engines]
+    sync()
+    LocalGroup._all_gather_n(engines, per[0] * (nd + 3))
+    sync()
+    for e in engines:
+        e.replica_unpack()
+        x, lp = e.ens.get_state()
+        assert np.array_equal(x, ref_chain[-1]) and np.array_equal(lp, ref_lp[-1])
+        assert np.array_equal(e.ens.accepted_counts(), ref_acc)
+        e.ens.close()
