@@ -126,10 +126,11 @@ def load():
             import torch  # noqa: F401
         except Exception:  # noqa: BLE001
             pass
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("EMX_LIB") or LIB_PATH          # EMX_LIB: an alternative build (A/B measurements)
+    if not os.path.exists(path):
         raise EmxError("libemx.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`. "
-                       "There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                       "There is no CPU fallback." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -297,6 +297,8 @@ struct emx_ctx {
     double* noise_host = nullptr;         // pinned (N, D)
     hipEvent_t noise_ev = nullptr;
     bool noise_busy = false;
+    unsigned long long* dbg = nullptr;    // phase timestamps of the last half-step launch (tuning key "phase_clock")
+    int64_t dbg_blocks = 0;
     int64_t tune_gauss_materialize = 0;   // native mode: write the displacement rows to HBM (k_gauss_disp) instead of
                                           // generating them inside the half-step kernel (verification / tests)
     double gfac = 1.0;                    // step-size factor of the Gaussian step begun
@@ -578,6 +580,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         a.gseed = c->ph_seed;
         a.gstep = c->cur.nat.step;
     }
+    a.dbg = (c->dbg && nblocks <= c->dbg_blocks && move != MOVE_EVAL) ? c->dbg : nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;
     if (prof) {
@@ -744,6 +747,7 @@ int emx_destroy(emx_ctx* c) {
     for (double* q : c->mscale)
         if (q) hipFree(q);
     if (c->disp) hipFree(c->disp);
+    if (c->dbg) hipFree(c->dbg);
     if (c->noise_host) hipHostFree(c->noise_host);
     if (c->noise_ev) hipEventDestroy(c->noise_ev);
     if (c->d_desc) hipFree(c->d_desc);
@@ -782,6 +786,19 @@ int emx_status(emx_ctx* c, uint32_t* bits) {
 int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "spw")) {
         c->tune_spw = v;
+        return 0;
+    }
+    if (!strcmp(key, "phase_clock")) {     // v != 0: record s_memtime at the phase boundaries of every launch
+        if (v && !c->dbg) {
+            c->dbg_blocks = 4096;
+            HIPOK(c, hipMalloc((void**)&c->dbg, (size_t)c->dbg_blocks * 16 * 8));
+            HIPOK(c, hipMemset(c->dbg, 0, (size_t)c->dbg_blocks * 16 * 8));
+        }
+        if (!v && c->dbg) {
+            hipStreamSynchronize(c->stream);
+            hipFree(c->dbg);
+            c->dbg = nullptr;
+        }
         return 0;
     }
     if (!strcmp(key, "gauss_materialize")) {
@@ -2017,6 +2034,7 @@ int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
         case 4: *ptr = c->chain; *nbytes = c->stored * c->N * c->D * 8; return 0;
         case 5: *ptr = c->chain_lp; *nbytes = c->stored * c->N * 8; return 0;
         case 6: *ptr = c->disp; *nbytes = c->disp ? c->N * c->D * 8 : 0; return 0;
+        case 7: *ptr = c->dbg; *nbytes = c->dbg ? c->dbg_blocks * 16 * 8 : 0; return 0;
     }
     FAIL(c, -1, "unknown device pointer id %d", which);
 }

@@ -26,6 +26,18 @@
 
 #include "emx_rng.hpp"
 
+// build-time experiment switches (tools/ab_variants.sh builds variants, tools/ab_bench.sh alternates them on one
+// box); the defaults are the shipped configuration.  Measured on MI355X at C2 (27.9 us/step baseline):
+// RED4 +1.2 %; timestamps -1 %.  Tried and dropped: mean fragments held in registers (16 more loads at kernel
+// start) -4 %; plan-entry loads issued before the image loads -2.2 %; commit as a wave-wide copy of one accepted
+// row per iteration -2 % (profiles/r01/ab_variants.txt).
+#ifndef EMX_OPT_RED4
+#define EMX_OPT_RED4 1
+#endif
+#ifndef EMX_OPT_STAMPS
+#define EMX_OPT_STAMPS 0      // phase timestamps (tools/phase_clock.py builds its own copy with -DEMX_OPT_STAMPS=1: they cost 1 %)
+#endif
+
 namespace emx {
 
 enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_GAUSS = 3, MOVE_EVAL = 4 };
@@ -100,6 +112,8 @@ struct HalfStepArgs {
     const double* gscale;          // (D) standard deviations or nullptr: isotropic gsigma
     double gsigma, gfac;           // gfac: this step's step-size factor
     unsigned long long gseed, gstep;
+    // phase timestamps (tools/phase_clock.py): [block][16] s_memtime samples of wave 0, or nullptr
+    unsigned long long* dbg;
 };
 
 // ----------------------------------------------------------------------------------------
@@ -138,6 +152,19 @@ __device__ __forceinline__ double group_sum(double x) {
     if constexpr (G >= 32) x = sum_swap16(x);
     if constexpr (G >= 64) x = sum_swap32(x);
     return x;
+}
+
+// Four values summed over the 16 lanes of a DPP row at once ("transpose-reduce"): the first two steps halve
+// the number of live values instead of carrying all four through four butterfly steps.  On return every lane
+// holds the row total of value (lane & 3): 5 adds instead of 16.
+__device__ __forceinline__ double row16_sum4(double v0, double v1, double v2, double v3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const double x = (b0 ? v1 : v0) + dpp_f64<0xB1>(b0 ? v0 : v1);    // value (lane & 1) over {l, l ^ 1}
+    const double y = (b0 ? v3 : v2) + dpp_f64<0xB1>(b0 ? v2 : v3);    // value 2 + (lane & 1)
+    double z = (b1 ? y : x) + dpp_f64<0x4E>(b1 ? x : y);              // value (lane & 3) over the quad
+    z += dpp_f64<0x124>(z);                                           // row_ror:4  -- lanes with the same (lane & 3)
+    z += dpp_f64<0x128>(z);                                           // row_ror:8
+    return z;
 }
 
 // any-lane-in-group predicate from one ballot (no data movement)
@@ -578,19 +605,22 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     constexpr int NSTG = 5;                                 // double2 per thread held in registers (first round)
     double2 stg0, stg1, stg2, stg3, stg4;
     stg0 = stg1 = stg2 = stg3 = stg4 = double2{0.0, 0.0};
+#define EMX_IMAGE_LOADS()                                                                          \
+    do {                                                                                           \
+        const double2* img_ = reinterpret_cast<const double2*>(A.tp1);                             \
+        const int bs_ = blockDim.x, tx_ = threadIdx.x;                                             \
+        if (tx_ < IMG2) stg0 = img_[tx_];                                                          \
+        if (tx_ + bs_ < IMG2) stg1 = img_[tx_ + bs_];                                              \
+        if (tx_ + 2 * bs_ < IMG2) stg2 = img_[tx_ + 2 * bs_];                                      \
+        if (tx_ + 3 * bs_ < IMG2) stg3 = img_[tx_ + 3 * bs_];                                      \
+        if (tx_ + 4 * bs_ < IMG2) stg4 = img_[tx_ + 4 * bs_];                                      \
+    } while (0)
     if constexpr (DENSE) {
         // The image loads are the FIRST memory operations of the kernel: vector-memory loads return in
         // order, so they land before the (slower, bandwidth-bound) row loads issued below and the
         // workgroup barrier that publishes the image does not wait for any row.
-        const double2* img = reinterpret_cast<const double2*>(A.tp1);
-        const int bs = blockDim.x, tx = threadIdx.x;
-        if (tx < IMG2) stg0 = img[tx];
-        if (tx + bs < IMG2) stg1 = img[tx + bs];
-        if (tx + 2 * bs < IMG2) stg2 = img[tx + 2 * bs];
-        if (tx + 3 * bs < IMG2) stg3 = img[tx + 3 * bs];
-        if (tx + 4 * bs < IMG2) stg4 = img[tx + 4 * bs];
+        EMX_IMAGE_LOADS();
     }
-
     // per-lane diag-Gaussian parameters (narrow rows): same columns for every walker of the wave
     Row<G, V, CH> mu, iv;
 #pragma unroll
@@ -604,6 +634,15 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 
     const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
     const int nwaves = gridDim.x * (blockDim.x >> 6);
+#define EMX_STAMP(k_)                                                                              \
+    do {                                                                                           \
+        if (EMX_OPT_STAMPS && A.dbg && wib == 0) {                                                                   \
+            const unsigned long long t_ = __builtin_readcyclecounter();                            \
+            if (lane == 0) A.dbg[(size_t)blockIdx.x * 16 + (k_)] = t_;                             \
+        }                                                                                          \
+    } while (0)
+    EMX_STAMP(0);
+    if (EMX_OPT_STAMPS && A.dbg && wib == 0 && lane == 0) A.dbg[(size_t)blockIdx.x * 16 + 11] = wall_clock64();   // 100 MHz reference
     const int spw = A.spw;
     bool stage_pending = DENSE;   // this wave still owes its share of the image and the workgroup barrier
 #define EMX_STAGE_PUBLISH()                                                                         \
@@ -645,6 +684,11 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                 if constexpr (NR >= 3) jb[k] = A.p1[pos];
                 if constexpr (NR >= 4) jc[k] = A.p2[pos];
             }
+            EMX_STAMP(1);      // plan loads issued
+            if (EMX_OPT_STAMPS && A.dbg) {       // instrumented runs only: when do the plan entries actually arrive?
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                EMX_STAMP(13);
+            }
             // -------- issue every row load of the batch (+ the per-walker scalars) --------
             Row<G, V, CH> xi[PF], xa[NR >= 2 ? PF : 1], xb[NR >= 3 ? PF : 1], xc[NR >= 4 ? PF : 1];
             double s0v[PF], facv[PF], lpov[PF], loguv[PF];
@@ -675,7 +719,9 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                 }
             }
 
+            EMX_STAMP(2);      // row loads issued (the plan entries have arrived)
             if (stage_pending) EMX_STAGE_PUBLISH();   // rows are in flight; the barrier only waits for the image
+            EMX_STAMP(3);      // image published, workgroup barrier passed
 
             if (A.ablate & 128) {          // timing experiments: consume the loads, skip everything else
                 double sink = 0.0;
@@ -771,6 +817,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                 }
             }
 
+            EMX_STAMP(4);      // proposals done, tile rows written (all row loads consumed)
             if constexpr (DENSE) {
                 const int plast = (pb + PF < npass ? pb + PF : npass) - 1;          // last pass of this batch
                 const bool tile_done = ((plast + 1) % PPT == 0) || (plast + 1 == npass);
@@ -801,6 +848,8 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         for (int kk = 0; kk < KK; ++kk)
                             afr[kk] = tile[am * RT + 4 * kk + ak] - muS[4 * kk + ak];           // A[i = lane&15][k = lane>>4]
                         double part[4] = {0.0, 0.0, 0.0, 0.0};
+                        if (EMX_OPT_STAMPS && A.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                        EMX_STAMP(5);      // A fragments in registers
                         if (!(A.ablate & 1))
 #pragma unroll
                         for (int nb = 0; nb < DPB; ++nb) {
@@ -812,12 +861,21 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
                         }
+                        if (EMX_OPT_STAMPS && A.dbg) { asm volatile("s_nop 0" ::: "memory"); }
+                        EMX_STAMP(6);      // MFMA chain + squares done
+                        // over the 16 columns held by this row of lanes: lane (am, ak) ends with the total of tile
+                        // row ak + 4 (am & 3), which is what the decision lanes (am < 4) need
+#if EMX_OPT_RED4
+                        my_qf = row16_sum4(part[0], part[1], part[2], part[3], lane);
+#else
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) part[r] = group_sum<16>(part[r]);   // over the 16 columns held by this row of lanes
+                        for (int r = 0; r < 4; ++r) part[r] = group_sum<16>(part[r]);
                         my_qf = part[0];
 #pragma unroll
                         for (int r = 1; r < 4; ++r) my_qf = (am == r) ? part[r] : my_qf;
+#endif
                     }
+                    EMX_STAMP(7);      // reductions done
                     // ---- decisions for the (up to) 16 rows of this tile ----
                     bool acc = false;
                     double lp_fin = my_lpo;
@@ -840,6 +898,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             }
                         }
                     }
+                    EMX_STAMP(8);      // decisions made, flag / log-prob stores issued
                     if constexpr (MOVE != MOVE_EVAL) {
                         const unsigned long long am64 = __ballot(acc);       // bit (row & 3) * 16 + (row >> 2) <-> tile row
                         if (A.sendbuf && (lane & 15) < 4) qfS[myrow] = lp_fin;
@@ -879,11 +938,15 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             if (A.sendbuf) store_row<G, V, CH>(rr, A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2), D, gl);
                         }
                     }
+                    EMX_STAMP(9);      // commit stores issued
                     EMX_WAVE_SYNC();
                 }
             }
         }
     }   // batch loop
+    if (EMX_OPT_STAMPS && A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    EMX_STAMP(10);             // every store of this wave acknowledged
+    if (EMX_OPT_STAMPS && A.dbg && wib == 0 && lane == 0) A.dbg[(size_t)blockIdx.x * 16 + 12] = wall_clock64();
 }
 
 // logs of a host-supplied plan (exact / inputs modes), full width: logu = ln(uacc),

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build experiment variants of libemx (compile-time switches in emx_kernels.hpp) next to the shipped one.
+#   usage: tools/ab_variants.sh name "-DEMX_OPT_X=0 ..." [name flags ...]
+cd "$(dirname "$0")/../emcee_amd/csrc" || exit 1
+while [ $# -ge 2 ]; do
+  name=$1; flags=$2; shift 2
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -fPIC -shared $flags emx.hip -o ../libemx_$name.so &
+done
+wait
+ls -la ../libemx_*.so
