@@ -345,6 +345,23 @@ def test_normal_target_statistics_philox(mv, ndim, nsteps):
         assert ks < 0.05
 
 
+@pytest.mark.parametrize("mv,nsteps", [(lambda: moves.WalkMove(s=3), 1500), (lambda: moves.WalkMove(), 600),
+                                       (lambda: moves.KDEMove(), 1500)])
+def test_normal_target_statistics_host_proposal_moves(mv, nsteps):
+    """reference integration/test_walk.py, test_kde.py (_test_normal): host get_proposal, device accept/commit."""
+    np.random.seed(1234)
+    nwalkers, ndim = 32, 2
+    coords = np.random.randn(nwalkers, ndim)
+    s = emcee_amd.EnsembleSampler(nwalkers, ndim, targets.IsoGaussian(), moves=mv())
+    s.run_mcmc(coords, nsteps)
+    acc = s.acceptance_fraction
+    assert np.all((acc < 0.95) * (acc > 0.1)), acc
+    samps = s.get_chain(flat=True, discard=100)
+    mu, sig = np.mean(samps, axis=0), np.std(samps, axis=0)
+    assert np.all(np.abs(mu) < 0.08), mu
+    assert np.all(np.abs(sig - 1) < 0.05), sig
+
+
 def test_gaussian_sequential_cursor_survives_runs():
     """The sequential mode's coordinate cursor is state of the move (gaussian.py:66,97): two runs of 5 + 9
     steps must equal the reference's single 14-step run, and the move object must show the cursor."""
