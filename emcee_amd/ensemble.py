@@ -11,6 +11,9 @@ accessors, errors and RNG-state semantics as reference emcee.  What runs where:
   the host, exactly where reference emcee calls it (``moves/red_blue.py:93``).
 * user-written moves  ->  their own ``propose(model, state)`` is called as in the reference.
 
+``distributed=True`` (one process per GPU under ``torchrun``) shards the fused path over the ranks'
+GPUs; ``torch.distributed`` only bootstraps RCCL and replicates rank 0's RNG state and inputs.
+
 ``rng="mt19937"`` (default) replays NumPy's legacy MT19937 stream: the same seed gives the same
 chain as reference emcee.  ``rng="philox"`` generates all draws inside the kernels (counter
 based), the throughput mode.  There is no CPU fallback: a missing GPU raises.
@@ -81,7 +84,7 @@ class EnsembleSampler(object):
                  # Deprecated...
                  a=None, postargs=None, threads=None, live_dangerously=None, runtime_sortingfn=None,
                  # emcee_amd extensions
-                 rng="mt19937", device=0):
+                 rng="mt19937", device=None, distributed=False, exchange="allgather"):
         for value, text in ((a, "The 'a' argument is deprecated, use 'moves' instead"),
                             (threads, "The 'threads' argument is deprecated"),
                             (runtime_sortingfn, "The 'runtime_sortingfn' argument is deprecated"),
@@ -108,6 +111,22 @@ class EnsembleSampler(object):
         if rng not in ("mt19937", "philox"):
             raise ValueError("rng must be 'mt19937' or 'philox'")
         self.rng = rng
+        # one process per GPU (torchrun): every rank builds the same sampler; the ensemble is sharded by walkers
+        # and RCCL moves the updated rows between the half-step kernels
+        self._dist = None
+        if distributed:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("distributed=True needs an initialised torch.distributed process group "
+                                   "(it is only used to bootstrap RCCL and to replicate the inputs)")
+            if exchange not in ("allgather", "pull"):
+                raise ValueError("exchange must be 'allgather' or 'pull'")
+            self._dist = dist
+            self._exchange = exchange
+            self._comm_ready = False
+        if device is None:
+            import os
+            device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
         self.device = int(device)
         self.pool = pool
         self.vectorize = vectorize
@@ -138,6 +157,8 @@ class EnsembleSampler(object):
         # private generator, seeded from the global NumPy state (reference ensemble.py:164-167)
         self._random = np.random.mtrand.RandomState()
         self._random.set_state(state)
+        if self._dist is not None:            # replicated decisions need ONE stream: rank 0's
+            self._random.set_state(self._replicate(self._random.get_state()))
 
         self._device_target = log_prob_fn if isinstance(log_prob_fn, DeviceTarget) else None
         self.log_prob_fn = _FunctionWrapper(log_prob_fn, args, kwargs)
@@ -173,7 +194,32 @@ class EnsembleSampler(object):
         d = dict(self.__dict__)
         d["pool"] = None
         d["_ens"] = None            # device contexts are not picklable; re-created on demand
+        d["_dist"] = None           # nor are process groups: an unpickled sampler is a single-GPU one
         return d
+
+    # ------------------------------------------------------------------ multi-GPU plumbing
+    def _replicate(self, obj):
+        """rank 0's copy of a (picklable) host object on every rank"""
+        box = [obj]
+        self._dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def _refuse_partial_chain(self, store):
+        if self._dist is not None and self._exchange == "pull" and store:
+            raise RuntimeError("exchange='pull' keeps only each rank's block of walkers current between steps, so a stored "
+                               "chain would be partial: run with store=False, or use exchange='allgather'")
+
+    def _join_communicator(self, ens):
+        """RCCL communicator for this ensemble (once, after the moves are installed: the exchange buffers are sized
+        for them); from here on emx_run exchanges the updated rows itself."""
+        if self._dist is None or self._comm_ready:
+            return
+        from .device import DeviceEnsemble
+        rank, world = self._dist.get_rank(), self._dist.get_world_size()
+        uid = self._replicate(DeviceEnsemble.rccl_unique_id() if rank == 0 else None)
+        ens.set_exchange(self._exchange)
+        ens.comm_init(rank, world, uid)
+        self._comm_ready = True
 
     # ------------------------------------------------------------------ device plumbing
     def _device_ensemble(self):
@@ -199,6 +245,10 @@ class EnsembleSampler(object):
             vec = getattr(m, "_scale_vector", None)
             if vec is not None and descs[i].kind == _lib.MOVE_GAUSS:
                 ens.set_move_scale(i, vec())
+        if self._dist is not None:
+            if not fused:
+                raise RuntimeError("distributed=True needs a DeviceTarget log_prob_fn (the sharded step is the fused one)")
+            self._join_communicator(ens)
         if self.rng == "mt19937":
             ens.set_rng_mode(_lib.RNG_MT19937)
             ens.set_mt19937(self._random.get_state())
@@ -227,6 +277,8 @@ class EnsembleSampler(object):
         if iterations is None and store:
             raise ValueError("'store' must be False when 'iterations' is None")
         state = State(initial_state, copy=True)
+        if self._dist is not None:
+            state = self._replicate(state)
         state_shape = np.shape(state.coords)
         if state_shape != (self.nwalkers, self.ndim):
             raise ValueError(f"incompatible input dimensions {state_shape}")
@@ -266,6 +318,10 @@ class EnsembleSampler(object):
 
         yield_step, checkpoint_step, nsaves = _thinning_plan(iterations, thin_by, thin)
 
+        if self._dist is not None and not fused:
+            raise RuntimeError("distributed=True needs a DeviceTarget log_prob_fn and built-in moves "
+                               "(the sharded step is the fused one)")
+        self._refuse_partial_chain(store)
         ens = None
         if native:
             ens = self._configure_device(descs, fused)
@@ -393,6 +449,8 @@ class EnsembleSampler(object):
         if thin_by <= 0:
             raise ValueError("Invalid thinning argument")
         state = State(initial_state, copy=True)
+        if self._dist is not None:
+            state = self._replicate(state)
         if state.blobs is not None:
             return None
         if np.shape(state.coords) != (self.nwalkers, self.ndim):
@@ -405,6 +463,7 @@ class EnsembleSampler(object):
                 raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice "
                                    "the number of dimensions.")
         self.random_state = state.random_state
+        self._refuse_partial_chain(store)
         ens = self._configure_device(descs, True)
         if state.log_prob is None:
             ens.set_state(state.coords)

@@ -485,3 +485,46 @@ def test_resume_reset_growth_and_thinned_acceptance():
     assert s.iteration == 0
     s.run_mcmc(p0, 4)
     assert s.get_chain().shape == (4, 64, 3)
+
+
+def test_distributed_front_end_world1():
+    """EnsembleSampler(distributed=True): RNG state, inputs and the RCCL id are replicated through
+    torch.distributed, the run itself is the library-driven sharded emx_run.  One rank here (one GPU);
+    the chain must equal the plain sampler's, for both exchanges."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        name = "mix_stretch_gauss_32x3"
+        g = load_golden(name)
+        spec = cases.build(name)
+        plain = make_sampler(spec, g)
+        plain.run_mcmc(g["p0"], spec["nsteps"], skip_initial_state_check=True)
+        assert np.array_equal(plain.get_chain(), g["chain"])
+        for how in ("run_mcmc", "sample"):
+            s = make_sampler(spec, g, distributed=True)
+            assert s.device == 0
+            if how == "run_mcmc":
+                s.run_mcmc(g["p0"], spec["nsteps"], skip_initial_state_check=True)
+            else:
+                for _ in s.sample(g["p0"], iterations=spec["nsteps"], skip_initial_state_check=True):
+                    pass
+            assert np.array_equal(s.get_chain(), g["chain"])
+            assert np.array_equal(s.backend.accepted, g["accepted_count"])
+        s = make_sampler(spec, g, distributed=True, exchange="pull", rng="philox")
+        with pytest.raises(RuntimeError, match="partial"):
+            s.run_mcmc(g["p0"], 3, skip_initial_state_check=True)
+        last = s.run_mcmc(g["p0"], 40, skip_initial_state_check=True, store=False)
+        ref = make_sampler(spec, g, rng="philox")
+        ref_last = ref.run_mcmc(g["p0"], 40, skip_initial_state_check=True, store=False)
+        assert np.array_equal(last.coords, ref_last.coords) and np.array_equal(last.log_prob, ref_last.log_prob)
+        with pytest.raises(RuntimeError, match="DeviceTarget"):
+            bad = emcee_amd.EnsembleSampler(32, 3, lambda x: -0.5 * np.sum(x * x), distributed=True)
+            bad.run_mcmc(g["p0"], 2)
+    finally:
+        if created:
+            dist.destroy_process_group()
