@@ -61,7 +61,7 @@ def cpu_baseline(mu, cov, icov, budget_s=15.0):
         t0 = time.perf_counter()
         out = so.run(p0, 1, fn, rs, store=False)
         t1 = time.perf_counter() - t0
-        nst = int(min(40, max(3, budget_s / max(t1, 1e-3))))
+        nst = int(min(400, max(3, budget_s / max(t1, 1e-3))))      # ~15 s of CPU work whatever the host
         t0 = time.perf_counter()
         so.run(out["coords"], nst, fn, rs, store=False, log_prob0=out["lp"])
         return nst, time.perf_counter() - t0
