@@ -299,6 +299,7 @@ struct emx_ctx {
     bool noise_busy = false;
     unsigned long long* dbg = nullptr;    // phase timestamps of the last half-step launch (tuning key "phase_clock")
     int64_t dbg_blocks = 0;
+    int64_t tune_small = 1;               // small ensembles: whole runs in one workgroup (k_small_run); 0: general path only
     int64_t tune_gauss_materialize = 0;   // native mode: write the displacement rows to HBM (k_gauss_disp) instead of
                                           // generating them inside the half-step kernel (verification / tests)
     double gfac = 1.0;                    // step-size factor of the Gaussian step begun
@@ -425,6 +426,19 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
         lds_granted = lds;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    return hipGetLastError();
+}
+
+template <int G, int V, int CH>
+hipError_t launch_small(int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
+    auto kern = k_small_run<G, V, CH>;
+    static size_t lds_granted = 0;
+    if (lds > 48 * 1024 && lds > lds_granted) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_granted = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, st, a);
     return hipGetLastError();
 }
 
@@ -799,6 +813,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
             hipFree(c->dbg);
             c->dbg = nullptr;
         }
+        return 0;
+    }
+    if (!strcmp(key, "small_kernel")) {
+        c->tune_small = v;
         return 0;
     }
     if (!strcmp(key, "gauss_materialize")) {
@@ -1585,6 +1603,77 @@ static emx_ctx::GraphSlot* graph_ready(emx_ctx* c, int store) {
 
 static int scatter_gathered(emx_ctx* c, int32_t split, int64_t block_rows);
 
+// ---- small ensembles: whole runs inside one workgroup (k_small_run) ------------------------
+// steps whose plans one pass evaluates: as many as give every thread of the workgroup an entry
+static int small_batch(int64_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / N)); }
+
+static size_t small_lds_bytes(int64_t N, int D) {
+    const size_t B = (size_t)small_batch(N);
+    return (size_t)N * ((size_t)D * 8 + 8 + 4 + 1) + B * (size_t)N * (3 * 8 + 2 * 4) + 64;
+}
+
+static bool small_eligible(const emx_ctx* c) {
+    if (!c->tune_small || c->rng_mode != EMX_RNG_PHILOX || c->moves.size() != 1) return false;
+    const emx_move_desc& mv = c->moves[0];
+    if (mv.kind != EMX_MOVE_STRETCH) return false;
+    if (c->target != EMX_TARGET_ISO_GAUSS && c->target != EMX_TARGET_DIAG_GAUSS && c->target != EMX_TARGET_ROSENBROCK &&
+        c->target != EMX_TARGET_BOX)
+        return false;
+    if (c->world != 1 || c->comm || c->sendbuf || c->prof_max > 0 || c->tune_ablate || c->cur.active) return false;
+    if (c->N > 4096 || c->D > 256) return false;
+    return small_lds_bytes(c->N, c->D) <= 150 * 1024;
+}
+
+// `nsteps` full steps starting at step index i0 of the current emx_run call
+static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, int32_t store) {
+    const emx_move_desc& mv = c->moves[0];
+    const Shape sh = pick_shape(c->D, c->D);
+    SmallRunArgs a{};
+    a.X = c->X;
+    a.lp = c->lp;
+    a.acc = c->acc;
+    a.acc_count = c->acc_count;
+    a.status = c->status;
+    if (store) {
+        a.chain = c->chain + (size_t)c->stored * c->N * c->D;
+        a.chain_lp = c->chain_lp + (size_t)c->stored * c->N;
+    }
+    a.tp0 = c->tp0;
+    a.tp1 = c->tp1;
+    a.tscale = c->tscale;
+    a.a = mv.a;
+    a.seed = c->ph_seed;
+    a.step0 = c->ph_step;
+    a.i0 = i0;
+    a.N = (int32_t)c->N;
+    a.D = c->D;
+    a.S = mv.nsplits;
+    a.target = c->target;
+    a.nsteps = (int32_t)nsteps;
+    a.thin_by = thin_by;
+    a.store = store;
+    a.batch = small_batch(c->N);
+    const int64_t nsmax = (c->N + mv.nsplits - 1) / mv.nsplits;
+    // enough threads for one half-step's lanes AND for one plan entry each across the batch
+    const int64_t want = std::max<int64_t>(nsmax * sh.G, (int64_t)a.batch * c->N);
+    int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, ((want + 63) / 64) * 64));
+    const size_t lds = small_lds_bytes(c->N, c->D);
+    hipError_t e = hipErrorInvalidValue;
+#define EMX_CASE(g, v, ch) \
+    if (sh.G == g && sh.V == v && sh.CH == ch) e = launch_small<g, v, ch>(threads, lds, c->stream, a);
+    EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4) EMX_CASE(16, 1, 4) EMX_CASE(32, 1, 4) EMX_CASE(64, 1, 4)
+    EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
+#undef EMX_CASE
+    if (e != hipSuccess) FAIL(c, -2, "k_small_run launch failed (G=%d V=%d CH=%d ndim=%d): %s", sh.G, sh.V, sh.CH, c->D, hipGetErrorString(e));
+    int64_t nstored = 0;
+    if (store)
+        for (int64_t s2 = 0; s2 < nsteps; ++s2) nstored += ((i0 + s2 + 1) % thin_by == 0) ? 1 : 0;
+    c->stored += nstored;
+    c->proposals += nsteps;
+    c->ph_step += (uint64_t)nsteps;
+    return 0;
+}
+
 // `count` doubles per pair from sendbuf block q to rank q's gathered block `rank` (RCCL's all-to-all when the
 // library has it, grouped send/recv otherwise)
 static int rccl_all_to_all(emx_ctx* c, size_t count) {
@@ -1631,6 +1720,16 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
             }
             ++marks;
             next_mark += c->tune_throttle;
+        }
+        if (small_eligible(c)) {
+            // the ensemble fits one CU's LDS: up to 4096 steps per launch inside one workgroup
+            drop_prepared(c);
+            const int64_t chunk = std::min<int64_t>(total - i, 4096);
+            const int rc = run_small(c, i, chunk, thin_by, store);
+            if (rc) return rc;
+            i += chunk;
+            ctr_synced = false;
+            continue;
         }
         if (thin_by == 1 && total - i >= NATIVE_BATCH_MAX) {
             emx_ctx::GraphSlot* g = graph_ready(c, store);

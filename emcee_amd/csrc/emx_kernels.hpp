@@ -949,6 +949,153 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     if (EMX_OPT_STAMPS && A.dbg && wib == 0 && lane == 0) A.dbg[(size_t)blockIdx.x * 16 + 12] = wall_clock64();
 }
 
+// ----------------------------------------------------------------------------------------
+// Small ensembles: the whole run in ONE workgroup.
+// When the ensemble (coordinates, log-probs, one step's plan) fits the 160 KB LDS of a CU, a step is two
+// launches of pure latency (~3.6 us each).  Here one workgroup keeps the ensemble in LDS and iterates
+// plan -> half-step -> ... -> half-step with workgroup barriers where the general path has kernel
+// boundaries: `nsteps` full steps per launch, HBM touched only for the stored chain rows.  Native RNG,
+// stretch move, element-wise targets; the same device functions as the general path (native_slot,
+// make_proposal, eval_valu_target), hence the same bits (tests/test_gpu_small_run.py).
+// ----------------------------------------------------------------------------------------
+struct SmallRunArgs {
+    double* X;
+    double* lp;
+    uint8_t* acc;
+    uint32_t* acc_count;
+    uint32_t* status;
+    double* chain;        // first chain row this launch may append to (nullptr: nothing stored)
+    double* chain_lp;
+    const double* tp0;
+    const double* tp1;
+    double tscale, a;
+    unsigned long long seed, step0;
+    long long i0;         // index of the first step inside the emx_run call (thinning phase, ensemble.py:416)
+    int32_t N, D, S, target, nsteps, thin_by, store;
+    int32_t batch;        // steps whose plans are evaluated in one pass (batch * N plan entries live in LDS)
+};
+
+template <int G, int V, int CH>
+__global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int WPW = 64 / G;
+    const int N = A.N, D = A.D, S = A.S, T = blockDim.x, tid = threadIdx.x, B = A.batch;
+    const int lane = tid & 63, wv = tid >> 6, nwave = T >> 6, sub = lane / G, gl = lane % G;
+    double* Xs = smem;
+    double* lps = Xs + (size_t)N * D;
+    double* s0s = lps + N;                               // plan arrays: B steps x N entries each
+    double* logus = s0s + (size_t)B * N;
+    double* facs = logus + (size_t)B * N;
+    int* orders = reinterpret_cast<int*>(facs + (size_t)B * N);
+    int* p0s = orders + (size_t)B * N;
+    uint32_t* acnt = reinterpret_cast<uint32_t*>(p0s + (size_t)B * N);
+    uint8_t* accs = reinterpret_cast<uint8_t*>(acnt + N);
+
+    for (int e = tid; e < N * D; e += T) Xs[e] = A.X[e];
+    for (int e = tid; e < N; e += T) {
+        lps[e] = A.lp[e];
+        acnt[e] = 0u;
+        accs[e] = 0;
+    }
+    Row<G, V, CH> mu, iv;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v) mu.x[c][v] = iv.x[c][v] = 0.0;
+    if (CH <= 4 && A.target == TGT_DIAG) {
+        load_row<G, V, CH>(mu, A.tp0, D, gl);
+        load_row<G, V, CH>(iv, A.tp1, D, gl);
+    }
+
+    int row = 0;                                     // stored rows appended by this launch
+    for (int sb = 0; sb < A.nsteps; sb += B) {
+        const int nb = min(B, A.nsteps - sb);
+        __syncthreads();                             // the previous batch's plans are no longer read
+        // ---- the plans of nb steps in one pass (k_native_plan_batch's arithmetic, one entry per thread):
+        //      plans do not depend on the state, so the Philox rounds, keyed-permutation inversions and logs
+        //      of many steps run side by side instead of sitting on every step's critical path ----
+        for (int e = tid; e < nb * N; e += T) {
+            const int b = e / N, pos = e - b * N;
+            NativeArgs na;
+            na.seed = A.seed;
+            na.step = A.step0 + (unsigned long long)(sb + b);
+            na.pk = make_perm_key((uint64_t)N, na.seed, na.step);
+            int split = 0, t = pos;
+            for (int k = 0; k < S; ++k) {
+                const int n = (N - k + S - 1) / S;
+                if (t < n) { split = k; break; }
+                t -= n;
+            }
+            int i, a0, a1, a2;
+            double z, u;
+            native_slot<MOVE_STRETCH>(na, N, S, split, t, A.a, 0.0, 0.0, i, a0, a1, a2, z, u);
+            orders[e] = i;
+            p0s[e] = a0;
+            s0s[e] = z;
+            logus[e] = log(u);
+            facs[e] = ((double)D - 1.0) * log(z);
+        }
+        __syncthreads();
+        for (int b = 0; b < nb; ++b) {
+            const int s = sb + b;
+            // ---- the half-steps: a barrier where the general path has a kernel boundary ----
+            int pos0 = b * N;
+            for (int split = 0; split < S; ++split) {
+                const int ns = (N - split + S - 1) / S;
+                for (int base = wv * WPW; base < ns; base += nwave * WPW) {      // wave-uniform
+                    const int t = base + sub;
+                    const bool live = t < ns;
+                    const int pos = pos0 + (live ? t : 0);
+                    const int i = orders[pos], j = p0s[pos];
+                    Row<G, V, CH> xi, xa, q;
+                    load_row<G, V, CH>(xi, Xs + (size_t)i * D, D, gl);
+                    load_row<G, V, CH>(xa, Xs + (size_t)j * D, D, gl);
+                    double factor = facs[pos];
+                    make_proposal<G, V, CH, MOVE_STRETCH>(xi, xa, xa, xa, s0s[pos], 0.0, D, gl, q, factor);
+                    bool bl = false;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+#pragma unroll
+                        for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
+                    const bool badq = group_any<G>(bl, sub);
+                    if (live && badq && gl == 0) atomicOr(A.status, ST_BAD_COORD);
+                    const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
+                    if (live && gl == 0 && (lp_new != lp_new)) atomicOr(A.status, ST_NAN_LOGP);
+                    const double lp_old = lps[i];
+                    const double lnpdiff = factor + lp_new - lp_old;                  // red_blue.py:99
+                    const bool accept = live && !badq && (lnpdiff > logus[pos]);      // red_blue.py:100
+                    if (accept) {
+                        store_row<G, V, CH>(q, Xs + (size_t)i * D, D, gl);
+                        if (gl == 0) lps[i] = lp_new;
+                    }
+                    if (live && gl == 0) accs[i] = accept ? 1 : 0;
+                }
+                __syncthreads();
+                pos0 += ns;
+            }
+            // ---- chain append (ensemble.py:416, backend.py:229) ----
+            if (A.store && ((A.i0 + s + 1) % A.thin_by == 0)) {
+                double* cr = A.chain + (size_t)row * N * D;
+                double* cl = A.chain_lp + (size_t)row * N;
+                for (int e = tid; e < N * D; e += T) cr[e] = Xs[e];
+                for (int e = tid; e < N; e += T) {
+                    cl[e] = lps[e];
+                    acnt[e] += accs[e];
+                }
+                ++row;
+                __syncthreads();                     // the next half-step overwrites what was just copied
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * D; e += T) A.X[e] = Xs[e];
+    for (int e = tid; e < N; e += T) {
+        A.lp[e] = lps[e];
+        A.acc[e] = accs[e];
+        A.acc_count[e] += acnt[e];
+    }
+}
+
 // logs of a host-supplied plan (exact / inputs modes), full width: logu = ln(uacc),
 // fac = (D-1) ln zz for the stretch move (stretch.py:31), 0 otherwise
 __global__ void k_plan_logs(int N, int D, int stretch, const double* __restrict__ s0, const double* __restrict__ uacc,

@@ -76,7 +76,9 @@ int emx_sync(emx_ctx* ctx);
  * (ensemble.py:476-479), bit2 pull-exchange record capacity exceeded (a >8 sigma event: the run is
  * invalid, never silently wrong).  Reading clears it. */
 int emx_status(emx_ctx* ctx, uint32_t* bits);
-/* keys: "spw", "blocks_per_cu", "waves_per_block", "prep_hint", "graph", "throttle", "gauss_materialize" */
+/* keys: "spw", "blocks_per_cu", "waves_per_block", "prep_hint", "graph", "throttle", "gauss_materialize",
+ * "small_kernel" (1: ensembles that fit one CU's LDS run whole emx_run calls in one workgroup; default),
+ * "phase_clock" (instrumented builds) */
 int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value);
 
 /* ---- state: State(coords, log_prob) (state.py:10-45) ---------------------------------- */

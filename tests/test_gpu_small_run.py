@@ -1,0 +1,94 @@
+"""k_small_run: whole runs of a small ensemble inside one workgroup (state in LDS, barriers instead of kernel
+boundaries) must give exactly the bits of the general launch-per-half-step path."""
+import time
+
+import numpy as np
+import pytest
+
+from emcee_amd import _lib
+from oracle import cases
+from oracle import sampler_oracle as so
+
+from test_gpu_parity import make_ens
+
+pytestmark = pytest.mark.gpu
+
+
+def build(N, D, target, nsplits, a, seed):
+    mv = so.MoveSpec("stretch", nsplits=nsplits, a=a, live_dangerously=True)
+    cases.DIGEST_CASES["_sm"] = dict(N=N, D=D, target=target, moves=[mv], nsteps=1, seed=seed,
+                                     p0={"rosenbrock": "rosen", "box": "uniform"}.get(target, "randn"))
+    spec = cases.build("_sm")
+    del cases.DIGEST_CASES["_sm"]
+    return spec
+
+
+def run(spec, small, nsteps, thin_by, store, seed=4242, step0=0, chunks=1):
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_PHILOX)
+    ens.set_philox(seed, step0)
+    ens.set_tuning("small_kernel", small)
+    if store:
+        ens.chain_config(nsteps * chunks)
+    for _ in range(chunks):
+        ens.run(nsteps, thin_by, store)
+    assert ens.status() == 0
+    out = dict(state=ens.get_state(), acc=ens.accepted_mask(), step=ens.get_philox()[1], it=ens.iteration())
+    if store:
+        out.update(chain=ens.chain_read(0, 0, nsteps * chunks), lp=ens.chain_read(1, 0, nsteps * chunks), cnt=ens.accepted_counts())
+    ens.close()
+    return out
+
+
+SHAPES = [(32, 5, "iso", 2, 2.0), (50, 3, "iso", 2, 2.0), (45, 2, "iso", 3, 2.0), (64, 8, "rosenbrock", 2, 2.0),
+          (66, 7, "diag", 2, 3.0), (32, 1, "box", 2, 2.0), (128, 16, "diag", 2, 2.0), (100, 33, "iso", 4, 2.0),
+          (256, 32, "rosenbrock", 2, 2.0), (40, 130, "diag", 5, 2.0), (1024, 8, "iso", 2, 2.0), (4096, 2, "iso", 2, 1.5),
+          (16, 256, "iso", 2, 2.0), (2, 1, "iso", 2, 2.0)]
+
+
+@pytest.mark.parametrize("N,D,target,nsplits,a", SHAPES)
+def test_small_run_equals_general_path(N, D, target, nsplits, a):
+    spec = build(N, D, target, nsplits, a, seed=N + D)
+    for nsteps, thin_by, store in ((7, 1, True), (4, 3, True), (9, 2, False)):
+        fast = run(spec, 1, nsteps, thin_by, store)
+        slow = run(spec, 0, nsteps, thin_by, store)
+        assert fast["step"] == slow["step"] == nsteps * thin_by and fast["it"] == slow["it"]
+        assert np.array_equal(fast["state"][0], slow["state"][0]) and np.array_equal(fast["state"][1], slow["state"][1])
+        assert np.array_equal(fast["acc"], slow["acc"])
+        if store:
+            assert np.array_equal(fast["chain"], slow["chain"]) and np.array_equal(fast["lp"], slow["lp"])
+            assert np.array_equal(fast["cnt"], slow["cnt"])
+            assert fast["cnt"].sum() > 0
+
+
+def test_small_run_chunks_and_resume():
+    """more steps than one launch takes (4096), and a second emx_run call continuing the chain"""
+    spec = build(32, 5, "iso", 2, 2.0, seed=3)
+    fast = run(spec, 1, 5000, 1, False)
+    slow = run(spec, 0, 5000, 1, False)
+    assert np.array_equal(fast["state"][0], slow["state"][0]) and fast["step"] == 5000
+    fast = run(spec, 1, 6, 2, True, chunks=3)
+    slow = run(spec, 0, 6, 2, True, chunks=3)
+    assert np.array_equal(fast["chain"], slow["chain"]) and np.array_equal(fast["cnt"], slow["cnt"])
+
+
+def test_small_run_is_faster_and_not_used_when_it_cannot_be():
+    spec = build(32, 5, "iso", 2, 2.0, seed=9)
+    t = {}
+    for small in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(1, 0)
+        ens.set_tuning("small_kernel", small)
+        ens.run(2000, 1, False)
+        ens.sync()
+        t0 = time.perf_counter()
+        ens.run(20000, 1, False)
+        ens.sync()
+        t[small] = (time.perf_counter() - t0) / 20000
+        ens.close()
+    assert t[1] < 0.5 * t[0], t
+    # too big for one CU's LDS: the general path must take over silently and still be right
+    big = build(8192, 4, "iso", 2, 2.0, seed=5)
+    a, b = run(big, 1, 3, 1, True), run(big, 0, 3, 1, True)
+    assert np.array_equal(a["chain"], b["chain"])
