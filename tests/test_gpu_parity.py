@@ -255,6 +255,7 @@ def test_graph_replay_equals_plain_launches(name, store):
         ens.set_rng_mode(_lib.RNG_PHILOX)
         ens.set_philox(31337, 0)
         ens.set_tuning("graph", graph)
+        ens.set_tuning("small_kernel", 0)     # these fixtures are small enough for k_small_run, which would take over
         ens.chain_config(64)
         ens.run(3, 1, store)          # plain
         ens.run(37, 1, store)         # 1 plain + 4 graph blocks + 4 plain
