@@ -1,0 +1,131 @@
+"""Host-side pieces of the drop-in surface that need no GPU: State (reference unit/test_state.py:14-60),
+Backend bookkeeping and errors (unit/test_backends.py:78-101,187-216), the sampler with a Python log_prob_fn and a
+whole-ensemble (non split-ensemble) move -- a path that never creates a device context."""
+import pickle
+
+import numpy as np
+import pytest
+
+import emcee_amd
+from emcee_amd import backends, moves
+from emcee_amd.state import State
+
+
+def check_rstate(a, b):
+    assert all(np.allclose(a_, b_) for a_, b_ in zip(a[1:], b[1:]))
+
+
+def test_state_back_compat_and_indexing():
+    np.random.seed(1234)
+    coords = np.random.randn(16, 3)
+    log_prob = np.random.randn(len(coords))
+    blobs = np.random.randn(len(coords))
+    rstate = np.random.get_state()
+    state = State(coords, log_prob, blobs, rstate)
+    c, l, r, b = state
+    assert np.allclose(coords, c) and np.allclose(log_prob, l) and np.allclose(blobs, b)
+    check_rstate(rstate, r)
+    c, l, r = State(coords, log_prob, None, rstate)
+    assert np.allclose(coords, c) and np.allclose(log_prob, l)
+    np.testing.assert_allclose(state[0], state.coords)
+    np.testing.assert_allclose(state[1], state.log_prob)
+    check_rstate(state[2], state.random_state)
+    np.testing.assert_allclose(state[3], state.blobs)
+    np.testing.assert_allclose(state[-1], state.blobs)
+    with pytest.raises(IndexError):
+        state[4]
+    copy = State(state, copy=True)
+    copy.coords[0, 0] += 1
+    assert state.coords[0, 0] != copy.coords[0, 0]
+
+
+def test_backend_uninitialised_errors():
+    be = backends.Backend()
+    with pytest.raises(AttributeError):
+        be.get_last_sample()
+    for k in ("chain", "log_prob", "blobs"):
+        with pytest.raises(AttributeError):
+            getattr(be, "get_" + k)()
+
+
+def lp_plain(x):
+    return -0.5 * np.sum(x ** 2, axis=1)
+
+
+def lp_blob(x):          # vectorised form: one row [log_prob, blob] per walker (reference ensemble.py:504-527)
+    return np.column_stack([-0.5 * np.sum(x ** 2, axis=1), np.sum(x, axis=1)])
+
+
+def run_sampler(be, nwalkers=16, ndim=3, nsteps=12, seed=1234, blobs=False, thin_by=1):
+    np.random.seed(seed)
+    coords = np.random.randn(nwalkers, ndim)
+    s = emcee_amd.EnsembleSampler(nwalkers, ndim, lp_blob if blobs else lp_plain, backend=be, vectorize=True,
+                                  moves=moves.GaussianMove(0.3))
+    s.run_mcmc(coords, nsteps, thin_by=thin_by)
+    return s
+
+
+def test_blob_usage_errors():
+    be = backends.Backend()
+    run_sampler(be, blobs=True)
+    with pytest.raises(ValueError):
+        run_sampler(be, blobs=False)
+    be = backends.Backend()
+    run_sampler(be, blobs=False)
+    with pytest.raises(ValueError):
+        run_sampler(be, blobs=True)
+
+
+def test_backend_contents_thinning_and_restart():
+    s1 = run_sampler(backends.Backend(), nsteps=12)
+    assert s1.get_chain().shape == (12, 16, 3) and s1.get_log_prob().shape == (12, 16) and s1.get_blobs() is None
+    assert s1.get_chain(flat=True).shape == (12 * 16, 3)
+    assert np.array_equal(s1.get_chain(discard=2, thin=3), s1.get_chain()[2 + 3 - 1::3])
+    assert s1.iteration == 12 and s1.backend.accepted.shape == (16,)
+    np.testing.assert_allclose(s1.get_log_prob(), lp_plain(s1.get_chain().reshape(-1, 3)).reshape(12, 16))
+    last = s1.get_last_sample()
+    assert np.array_equal(last.coords, s1.get_chain()[-1])
+    # restart: continue from the stored state with the stored RNG state == one uninterrupted run
+    s2 = run_sampler(backends.Backend(), nsteps=5)
+    s2.run_mcmc(None, 7)
+    assert np.array_equal(s2.get_chain(), s1.get_chain())
+    check_rstate(s2.get_last_sample().random_state, last.random_state)
+    # thin_by keeps every third step and counts acceptances of the kept steps only
+    s3 = run_sampler(backends.Backend(), nsteps=4, thin_by=3)
+    assert np.array_equal(s3.get_chain(), s1.get_chain()[2::3]) and s3.iteration == 4
+    # reset
+    s3.reset()
+    assert s3.iteration == 0
+    with pytest.raises(AttributeError):
+        s3.get_chain()
+
+
+def test_sampler_pickles_and_input_is_not_overwritten():
+    np.random.seed(3)
+    p0 = np.random.randn(16, 2)
+    keep = p0.copy()
+    s = emcee_amd.EnsembleSampler(16, 2, lp_plain, vectorize=True, moves=moves.GaussianMove([0.2, 0.4], mode="random"))
+    s.run_mcmc(p0, 6)
+    assert np.array_equal(p0, keep)
+    s2 = pickle.loads(pickle.dumps(s))
+    assert np.array_equal(s2.get_chain(), s.get_chain())
+    a, b = s.run_mcmc(None, 3), s2.run_mcmc(None, 3)
+    assert np.array_equal(a.coords, b.coords)
+
+
+def test_errors_of_the_generic_path():
+    s = emcee_amd.EnsembleSampler(16, 2, lp_plain, vectorize=True, moves=moves.GaussianMove(0.1))
+    p0 = np.random.RandomState(0).randn(16, 2)
+    with pytest.raises(ValueError, match="incompatible input dimensions"):
+        s.run_mcmc(p0[:, :1], 2)
+    with pytest.raises(ValueError, match="large condition number"):
+        s.run_mcmc(np.ones((16, 2)), 2)
+    with pytest.raises(ValueError, match="'store' must be False"):
+        next(s.sample(p0, iterations=None, store=True))
+    with pytest.raises(ValueError, match="Invalid thinning"):
+        s.run_mcmc(p0, 2, thin_by=0)
+    bad = emcee_amd.EnsembleSampler(16, 2, lambda x: np.full(len(x), np.nan), vectorize=True, moves=moves.GaussianMove(0.1))
+    with pytest.raises(ValueError, match="NaN"):
+        bad.run_mcmc(p0, 2)
+    with pytest.raises(ValueError, match="rng must be"):
+        emcee_amd.EnsembleSampler(16, 2, lp_plain, rng="xorshift")
