@@ -429,9 +429,9 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
     return hipGetLastError();
 }
 
-template <int G, int V, int CH>
-hipError_t launch_small(int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
-    auto kern = k_small_run<G, V, CH>;
+template <int G, int V, int CH, int MOVE>
+hipError_t launch_small_move(int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
+    auto kern = k_small_run<G, V, CH, MOVE>;
     static size_t lds_granted = 0;
     if (lds > 48 * 1024 && lds > lds_granted) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -440,6 +440,16 @@ hipError_t launch_small(int threads, size_t lds, hipStream_t st, const SmallRunA
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, st, a);
     return hipGetLastError();
+}
+
+template <int G, int V, int CH>
+hipError_t launch_small(int move, int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
+    switch (move) {
+        case MOVE_STRETCH: return launch_small_move<G, V, CH, MOVE_STRETCH>(threads, lds, st, a);
+        case MOVE_DE: return launch_small_move<G, V, CH, MOVE_DE>(threads, lds, st, a);
+        case MOVE_SNOOKER: return launch_small_move<G, V, CH, MOVE_SNOOKER>(threads, lds, st, a);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int MOVE>
@@ -1609,13 +1619,14 @@ static int small_batch(int64_t N) { return (int)std::max<int64_t>(1, std::min<in
 
 static size_t small_lds_bytes(int64_t N, int D) {
     const size_t B = (size_t)small_batch(N);
-    return (size_t)N * ((size_t)D * 8 + 8 + 4 + 1) + B * (size_t)N * (3 * 8 + 2 * 4) + 64;
+    return (size_t)N * ((size_t)D * 8 + 8 + 4 + 1) + B * (size_t)N * (3 * 8 + 4 * 4) + 64;
 }
 
 static bool small_eligible(const emx_ctx* c) {
     if (!c->tune_small || c->rng_mode != EMX_RNG_PHILOX || c->moves.size() != 1) return false;
     const emx_move_desc& mv = c->moves[0];
-    if (mv.kind != EMX_MOVE_STRETCH) return false;
+    if (mv.kind != EMX_MOVE_STRETCH && mv.kind != EMX_MOVE_DE && mv.kind != EMX_MOVE_SNOOKER) return false;
+    if (mv.kind == EMX_MOVE_DE && c->N - (c->N + mv.nsplits - 1) / mv.nsplits < 2) return false;
     if (c->target != EMX_TARGET_ISO_GAUSS && c->target != EMX_TARGET_DIAG_GAUSS && c->target != EMX_TARGET_ROSENBROCK &&
         c->target != EMX_TARGET_BOX)
         return false;
@@ -1642,6 +1653,9 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
     a.tp1 = c->tp1;
     a.tscale = c->tscale;
     a.a = mv.a;
+    a.sigma = mv.sigma;
+    a.g0 = mv.g0;
+    a.gammas = mv.gammas;
     a.seed = c->ph_seed;
     a.step0 = c->ph_step;
     a.i0 = i0;
@@ -1660,7 +1674,7 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
     const size_t lds = small_lds_bytes(c->N, c->D);
     hipError_t e = hipErrorInvalidValue;
 #define EMX_CASE(g, v, ch) \
-    if (sh.G == g && sh.V == v && sh.CH == ch) e = launch_small<g, v, ch>(threads, lds, c->stream, a);
+    if (sh.G == g && sh.V == v && sh.CH == ch) e = launch_small<g, v, ch>(mv.kind, threads, lds, c->stream, a);
     EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4) EMX_CASE(16, 1, 4) EMX_CASE(32, 1, 4) EMX_CASE(64, 1, 4)
     EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
 #undef EMX_CASE

@@ -954,8 +954,8 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 // When the ensemble (coordinates, log-probs, one step's plan) fits the 160 KB LDS of a CU, a step is two
 // launches of pure latency (~3.6 us each).  Here one workgroup keeps the ensemble in LDS and iterates
 // plan -> half-step -> ... -> half-step with workgroup barriers where the general path has kernel
-// boundaries: `nsteps` full steps per launch, HBM touched only for the stored chain rows.  Native RNG,
-// stretch move, element-wise targets; the same device functions as the general path (native_slot,
+// boundaries: `nsteps` full steps per launch, HBM touched only for the stored chain rows.  Native RNG, one
+// stretch / DE / snooker move, element-wise targets; the same device functions as the general path (native_slot,
 // make_proposal, eval_valu_target), hence the same bits (tests/test_gpu_small_run.py).
 // ----------------------------------------------------------------------------------------
 struct SmallRunArgs {
@@ -968,15 +968,16 @@ struct SmallRunArgs {
     double* chain_lp;
     const double* tp0;
     const double* tp1;
-    double tscale, a;
+    double tscale, a, sigma, g0, gammas;     // move parameters (stretch a | DE sigma, g0 | snooker gammas)
     unsigned long long seed, step0;
     long long i0;         // index of the first step inside the emx_run call (thinning phase, ensemble.py:416)
     int32_t N, D, S, target, nsteps, thin_by, store;
     int32_t batch;        // steps whose plans are evaluated in one pass (batch * N plan entries live in LDS)
 };
 
-template <int G, int V, int CH>
+template <int G, int V, int CH, int MOVE>
 __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
+    constexpr int NR = rows_per_pass<MOVE>();
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int WPW = 64 / G;
     const int N = A.N, D = A.D, S = A.S, T = blockDim.x, tid = threadIdx.x, B = A.batch;
@@ -988,7 +989,9 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
     double* facs = logus + (size_t)B * N;
     int* orders = reinterpret_cast<int*>(facs + (size_t)B * N);
     int* p0s = orders + (size_t)B * N;
-    uint32_t* acnt = reinterpret_cast<uint32_t*>(p0s + (size_t)B * N);
+    int* p1s = p0s + (size_t)B * N;
+    int* p2s = p1s + (size_t)B * N;
+    uint32_t* acnt = reinterpret_cast<uint32_t*>(p2s + (size_t)B * N);
     uint8_t* accs = reinterpret_cast<uint8_t*>(acnt + N);
 
     for (int e = tid; e < N * D; e += T) Xs[e] = A.X[e];
@@ -1028,12 +1031,14 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
             }
             int i, a0, a1, a2;
             double z, u;
-            native_slot<MOVE_STRETCH>(na, N, S, split, t, A.a, 0.0, 0.0, i, a0, a1, a2, z, u);
+            native_slot<MOVE>(na, N, S, split, t, A.a, A.sigma, A.g0, i, a0, a1, a2, z, u);
             orders[e] = i;
             p0s[e] = a0;
+            p1s[e] = a1;
+            p2s[e] = a2;
             s0s[e] = z;
             logus[e] = log(u);
-            facs[e] = ((double)D - 1.0) * log(z);
+            facs[e] = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
         }
         __syncthreads();
         for (int b = 0; b < nb; ++b) {
@@ -1046,12 +1051,15 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
                     const int t = base + sub;
                     const bool live = t < ns;
                     const int pos = pos0 + (live ? t : 0);
-                    const int i = orders[pos], j = p0s[pos];
-                    Row<G, V, CH> xi, xa, q;
+                    const int i = orders[pos];
+                    Row<G, V, CH> xi, xa, xb, xc, q;
                     load_row<G, V, CH>(xi, Xs + (size_t)i * D, D, gl);
-                    load_row<G, V, CH>(xa, Xs + (size_t)j * D, D, gl);
+                    load_row<G, V, CH>(xa, Xs + (size_t)p0s[pos] * D, D, gl);
+                    if constexpr (NR >= 3) load_row<G, V, CH>(xb, Xs + (size_t)p1s[pos] * D, D, gl);
+                    if constexpr (NR >= 4) load_row<G, V, CH>(xc, Xs + (size_t)p2s[pos] * D, D, gl);
                     double factor = facs[pos];
-                    make_proposal<G, V, CH, MOVE_STRETCH>(xi, xa, xa, xa, s0s[pos], 0.0, D, gl, q, factor);
+                    make_proposal<G, V, CH, MOVE>(xi, xa, NR >= 3 ? xb : xa, NR >= 4 ? xc : xa,
+                                                  (MOVE == MOVE_SNOOKER) ? 0.0 : s0s[pos], A.gammas, D, gl, q, factor);
                     bool bl = false;
 #pragma unroll
                     for (int c = 0; c < CH; ++c)

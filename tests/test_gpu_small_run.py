@@ -14,8 +14,8 @@ from test_gpu_parity import make_ens
 pytestmark = pytest.mark.gpu
 
 
-def build(N, D, target, nsplits, a, seed):
-    mv = so.MoveSpec("stretch", nsplits=nsplits, a=a, live_dangerously=True)
+def build(N, D, target, nsplits, a, seed, kind="stretch"):
+    mv = so.MoveSpec(kind, nsplits=nsplits, a=a, live_dangerously=True, sigma=0.05, gammas=1.4)
     cases.DIGEST_CASES["_sm"] = dict(N=N, D=D, target=target, moves=[mv], nsteps=1, seed=seed,
                                      p0={"rosenbrock": "rosen", "box": "uniform"}.get(target, "randn"))
     spec = cases.build("_sm")
@@ -59,6 +59,22 @@ def test_small_run_equals_general_path(N, D, target, nsplits, a):
             assert np.array_equal(fast["chain"], slow["chain"]) and np.array_equal(fast["lp"], slow["lp"])
             assert np.array_equal(fast["cnt"], slow["cnt"])
             assert fast["cnt"].sum() > 0
+
+
+@pytest.mark.parametrize("kind,N,D,target,nsplits", [
+    ("de", 64, 4, "iso", 2), ("de", 45, 7, "diag", 3), ("de", 256, 16, "rosenbrock", 2), ("de", 30, 33, "iso", 2),
+    ("snooker", 64, 4, "iso", 4), ("snooker", 38, 3, "diag", 4), ("snooker", 200, 16, "rosenbrock", 4),
+    ("snooker", 40, 65, "iso", 4),
+])
+def test_small_run_de_and_snooker_equal_general_path(kind, N, D, target, nsplits):
+    spec = build(N, D, target, nsplits, 2.0, seed=N * 3 + D, kind=kind)
+    for nsteps, thin_by, store in ((6, 1, True), (3, 2, True)):
+        fast = run(spec, 1, nsteps, thin_by, store)
+        slow = run(spec, 0, nsteps, thin_by, store)
+        assert np.array_equal(fast["chain"], slow["chain"]) and np.array_equal(fast["lp"], slow["lp"])
+        assert np.array_equal(fast["cnt"], slow["cnt"]) and np.array_equal(fast["acc"], slow["acc"])
+        assert np.array_equal(fast["state"][0], slow["state"][0]) and fast["step"] == slow["step"]
+        assert fast["cnt"].sum() > 0
 
 
 def test_small_run_chunks_and_resume():
