@@ -299,6 +299,15 @@ struct emx_ctx {
     bool noise_busy = false;
     unsigned long long* dbg = nullptr;    // phase timestamps of the last half-step launch (tuning key "phase_clock")
     int64_t dbg_blocks = 0;
+    // exact-mode small runs: host plans of many steps per launch, double buffered
+    struct BulkPlans {
+        char* host = nullptr;       // pinned
+        char* dev = nullptr;
+        size_t bytes = 0;
+        hipEvent_t done = nullptr;  // the launch that read this buffer has finished
+        bool busy = false;
+    } bulk[2];
+    int bulk_pos = 0;
     int64_t tune_small = 1;               // small ensembles: whole runs in one workgroup (k_small_run); 0: general path only
     int64_t tune_gauss_materialize = 0;   // native mode: write the displacement rows to HBM (k_gauss_disp) instead of
                                           // generating them inside the half-step kernel (verification / tests)
@@ -429,9 +438,9 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
     return hipGetLastError();
 }
 
-template <int G, int V, int CH, int MOVE>
+template <int G, int V, int CH, int MOVE, bool PLANNED>
 hipError_t launch_small_move(int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
-    auto kern = k_small_run<G, V, CH, MOVE>;
+    auto kern = k_small_run<G, V, CH, MOVE, PLANNED>;
     static size_t lds_granted = 0;
     if (lds > 48 * 1024 && lds > lds_granted) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -444,10 +453,17 @@ hipError_t launch_small_move(int threads, size_t lds, hipStream_t st, const Smal
 
 template <int G, int V, int CH>
 hipError_t launch_small(int move, int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
+    const bool planned = a.plans != nullptr;
     switch (move) {
-        case MOVE_STRETCH: return launch_small_move<G, V, CH, MOVE_STRETCH>(threads, lds, st, a);
-        case MOVE_DE: return launch_small_move<G, V, CH, MOVE_DE>(threads, lds, st, a);
-        case MOVE_SNOOKER: return launch_small_move<G, V, CH, MOVE_SNOOKER>(threads, lds, st, a);
+        case MOVE_STRETCH:
+            return planned ? launch_small_move<G, V, CH, MOVE_STRETCH, true>(threads, lds, st, a)
+                           : launch_small_move<G, V, CH, MOVE_STRETCH, false>(threads, lds, st, a);
+        case MOVE_DE:
+            return planned ? launch_small_move<G, V, CH, MOVE_DE, true>(threads, lds, st, a)
+                           : launch_small_move<G, V, CH, MOVE_DE, false>(threads, lds, st, a);
+        case MOVE_SNOOKER:
+            return planned ? launch_small_move<G, V, CH, MOVE_SNOOKER, true>(threads, lds, st, a)
+                           : launch_small_move<G, V, CH, MOVE_SNOOKER, false>(threads, lds, st, a);
     }
     return hipErrorInvalidValue;
 }
@@ -700,14 +716,18 @@ int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
     ALLOC(c->evallp, N * 8);
     for (int r = 0; r < PLAN_RING; ++r) {
         auto& s = c->ring[r];
-        ALLOC(s.order, N * 4);
-        ALLOC(s.p0, N * 4);
-        ALLOC(s.p1, N * 4);
-        ALLOC(s.p2, N * 4);
-        ALLOC(s.s0, N * 8);
-        ALLOC(s.uacc, N * 8);
-        ALLOC(s.logu, N * 8);
-        ALLOC(s.fac, N * 8);
+        // one block per slot, laid out like the pinned staging buffer ([order|p0|p1|p2] int32, [s0|uacc] f64) so that a
+        // host-made plan goes up in ONE copy; the device-computed logs follow
+        char* blk = nullptr;
+        ALLOC(blk, N * 48);
+        s.order = (int32_t*)blk;
+        s.p0 = s.order + N;
+        s.p1 = s.p0 + N;
+        s.p2 = s.p1 + N;
+        s.s0 = (double*)(blk + N * 16);
+        s.uacc = s.s0 + N;
+        s.logu = s.uacc + N;
+        s.fac = s.logu + N;
         if (hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming) != hipSuccess) {
             g_err = "plan event creation failed";
             emx_destroy(c);
@@ -752,9 +772,7 @@ int emx_destroy(emx_ctx* c) {
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (auto& s : c->ring) {
-        void* q[] = {s.order, s.p0, s.p1, s.p2, s.s0, s.uacc, s.logu, s.fac};
-        for (void* p : q)
-            if (p) hipFree(p);
+        if (s.order) hipFree(s.order);       // the slot's single block
         if (s.host) hipHostFree(s.host);
         if (s.consumed) hipEventDestroy(s.consumed);
     }
@@ -770,6 +788,11 @@ int emx_destroy(emx_ctx* c) {
     }
     for (double* q : c->mscale)
         if (q) hipFree(q);
+    for (auto& bp : c->bulk) {
+        if (bp.host) hipHostFree(bp.host);
+        if (bp.dev) hipFree(bp.dev);
+        if (bp.done) hipEventDestroy(bp.done);
+    }
     if (c->disp) hipFree(c->disp);
     if (c->dbg) hipFree(c->dbg);
     if (c->noise_host) hipHostFree(c->noise_host);
@@ -1125,14 +1148,7 @@ int emx_accepted_counts(emx_ctx* c, double* out) {
 // ---- stepping ----------------------------------------------------------------------------
 static int upload_plan(emx_ctx* c, emx_ctx::PlanSlot& s) {
     const size_t N = (size_t)c->N;
-    int32_t* hi = (int32_t*)s.host;
-    double* hd = (double*)(s.host + N * 16);
-    HIPOK(c, hipMemcpyAsync(s.order, hi, N * 4, hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemcpyAsync(s.p0, hi + N, N * 4, hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemcpyAsync(s.p1, hi + 2 * N, N * 4, hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemcpyAsync(s.p2, hi + 3 * N, N * 4, hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemcpyAsync(s.s0, hd, N * 8, hipMemcpyHostToDevice, c->stream));
-    HIPOK(c, hipMemcpyAsync(s.uacc, hd + N, N * 8, hipMemcpyHostToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(s.order, s.host, N * 32, hipMemcpyHostToDevice, c->stream));   // same layout on both sides
     const int stretch = c->cur.move >= 0 && c->moves[c->cur.move].kind == EMX_MOVE_STRETCH;
     hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (int)N, (int)c->D, stretch,
                        s.s0, s.uacc, s.logu, s.fac);
@@ -1623,7 +1639,7 @@ static size_t small_lds_bytes(int64_t N, int D) {
 }
 
 static bool small_eligible(const emx_ctx* c) {
-    if (!c->tune_small || c->rng_mode != EMX_RNG_PHILOX || c->moves.size() != 1) return false;
+    if (!c->tune_small || (c->rng_mode != EMX_RNG_PHILOX && c->rng_mode != EMX_RNG_MT19937) || c->moves.size() != 1) return false;
     const emx_move_desc& mv = c->moves[0];
     if (mv.kind != EMX_MOVE_STRETCH && mv.kind != EMX_MOVE_DE && mv.kind != EMX_MOVE_SNOOKER) return false;
     if (mv.kind == EMX_MOVE_DE && c->N - (c->N + mv.nsplits - 1) / mv.nsplits < 2) return false;
@@ -1667,6 +1683,39 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
     a.thin_by = thin_by;
     a.store = store;
     a.batch = small_batch(c->N);
+    if (c->rng_mode == EMX_RNG_MT19937) {
+        // the reference's MT19937 stream, consumed on the host exactly as step_begin would (move choice, then the
+        // step's draws), `nsteps` plans per copy; the other buffer may still be feeding the previous launch
+        auto& bp = c->bulk[c->bulk_pos];
+        c->bulk_pos ^= 1;
+        const size_t need = (size_t)nsteps * (size_t)c->N * 32;
+        if (bp.busy) {
+            HIPOK(c, hipEventSynchronize(bp.done));
+            bp.busy = false;
+        }
+        if (bp.bytes < need) {
+            if (bp.host) hipHostFree(bp.host);
+            if (bp.dev) hipFree(bp.dev);
+            bp.host = bp.dev = nullptr;
+            bp.bytes = 0;
+            HIPOK(c, hipHostMalloc((void**)&bp.host, need, hipHostMallocDefault));
+            HIPOK(c, hipMalloc((void**)&bp.dev, need));
+            bp.bytes = need;
+            if (!bp.done) HIPOK(c, hipEventCreateWithFlags(&bp.done, hipEventDisableTiming));
+        }
+        const size_t N = (size_t)c->N;
+        std::vector<int32_t> off(mv.nsplits + 1);
+        for (int64_t s2 = 0; s2 < nsteps; ++s2) {
+            (void)c->mt.choice_cdf(c->cdf.data(), 1);                       // ensemble.py:406, one move
+            int32_t* hi = (int32_t*)(bp.host + (size_t)s2 * N * 32);
+            double* hd = (double*)(bp.host + (size_t)s2 * N * 32 + N * 16);
+            const int rc = make_exact_plan(c->mt, c->N, c->D, mv, c->labels_scratch, off.data(), hi, hi + N, hi + 2 * N,
+                                           hi + 3 * N, hd, hd + N);
+            NEED(c, rc == 0, "plan generation failed");
+        }
+        HIPOK(c, hipMemcpyAsync(bp.dev, bp.host, need, hipMemcpyHostToDevice, c->stream));
+        a.plans = bp.dev;
+    }
     const int64_t nsmax = (c->N + mv.nsplits - 1) / mv.nsplits;
     // enough threads for one half-step's lanes AND for one plan entry each across the batch
     const int64_t want = std::max<int64_t>(nsmax * sh.G, (int64_t)a.batch * c->N);
@@ -1684,7 +1733,12 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
         for (int64_t s2 = 0; s2 < nsteps; ++s2) nstored += ((i0 + s2 + 1) % thin_by == 0) ? 1 : 0;
     c->stored += nstored;
     c->proposals += nsteps;
-    c->ph_step += (uint64_t)nsteps;
+    if (c->rng_mode == EMX_RNG_PHILOX) c->ph_step += (uint64_t)nsteps;
+    if (a.plans) {
+        auto& bp = c->bulk[c->bulk_pos ^ 1];
+        HIPOK(c, hipEventRecord(bp.done, c->stream));
+        bp.busy = true;
+    }
     return 0;
 }
 
@@ -1738,7 +1792,9 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
         if (small_eligible(c)) {
             // the ensemble fits one CU's LDS: up to 4096 steps per launch inside one workgroup
             drop_prepared(c);
-            const int64_t chunk = std::min<int64_t>(total - i, 4096);
+            int64_t chunk = std::min<int64_t>(total - i, 4096);
+            if (c->rng_mode == EMX_RNG_MT19937)      // plans travel: <= 4 MB per launch, short enough to overlap host and GPU
+                chunk = std::min<int64_t>(chunk, std::max<int64_t>(8, (4 << 20) / (32 * c->N)));
             const int rc = run_small(c, i, chunk, thin_by, store);
             if (rc) return rc;
             i += chunk;

@@ -973,9 +973,12 @@ struct SmallRunArgs {
     long long i0;         // index of the first step inside the emx_run call (thinning phase, ensemble.py:416)
     int32_t N, D, S, target, nsteps, thin_by, store;
     int32_t batch;        // steps whose plans are evaluated in one pass (batch * N plan entries live in LDS)
+    // PLANNED instantiations (exact MT19937 mode): the host-made plans of the launch's steps, 32 N bytes per step in
+    // the staging layout [order|p0|p1|p2] int32, [s0|uacc] f64
+    const char* plans;
 };
 
-template <int G, int V, int CH, int MOVE>
+template <int G, int V, int CH, int MOVE, bool PLANNED>
 __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
     constexpr int NR = rows_per_pass<MOVE>();
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1019,6 +1022,21 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
         //      of many steps run side by side instead of sitting on every step's critical path ----
         for (int e = tid; e < nb * N; e += T) {
             const int b = e / N, pos = e - b * N;
+            if constexpr (PLANNED) {
+                // exact mode: entries made by the host's MT19937 twin; the logs are k_plan_logs' arithmetic
+                const char* base = A.plans + (size_t)(sb + b) * N * 32;
+                const int32_t* hi = reinterpret_cast<const int32_t*>(base);
+                const double* hd = reinterpret_cast<const double*>(base + (size_t)N * 16);
+                const double z = hd[pos], u = hd[N + pos];
+                orders[e] = hi[pos];
+                p0s[e] = hi[N + pos];
+                p1s[e] = hi[2 * N + pos];
+                p2s[e] = hi[3 * N + pos];
+                s0s[e] = z;
+                logus[e] = log(u);
+                facs[e] = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
+                continue;
+            }
             NativeArgs na;
             na.seed = A.seed;
             na.step = A.step0 + (unsigned long long)(sb + b);

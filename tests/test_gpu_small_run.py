@@ -77,6 +77,44 @@ def test_small_run_de_and_snooker_equal_general_path(kind, N, D, target, nsplits
         assert fast["cnt"].sum() > 0
 
 
+def run_exact(spec, small, nsteps, thin_by, store, chunks=1):
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_MT19937)
+    ens.set_mt19937(np.random.RandomState(77).get_state())
+    ens.set_tuning("small_kernel", small)
+    if store:
+        ens.chain_config(nsteps * chunks)
+    for _ in range(chunks):
+        ens.run(nsteps, thin_by, store)
+    assert ens.status() == 0
+    st = ens.get_mt19937()
+    out = dict(state=ens.get_state(), acc=ens.accepted_mask(), mt=(st[1].copy(), st[2], st[3], st[4]))
+    if store:
+        out.update(chain=ens.chain_read(0, 0, nsteps * chunks), lp=ens.chain_read(1, 0, nsteps * chunks), cnt=ens.accepted_counts())
+    ens.close()
+    return out
+
+
+@pytest.mark.parametrize("kind,N,D,target,nsplits", [
+    ("stretch", 32, 5, "iso", 2), ("stretch", 50, 3, "iso", 2), ("stretch", 45, 2, "iso", 3), ("stretch", 66, 7, "diag", 2),
+    ("stretch", 256, 32, "rosenbrock", 2), ("stretch", 1024, 8, "iso", 2), ("de", 64, 4, "iso", 2), ("de", 30, 3, "diag", 3),
+    ("snooker", 64, 4, "iso", 4), ("snooker", 38, 3, "diag", 4),
+])
+def test_small_run_exact_mode_equals_general_path(kind, N, D, target, nsplits):
+    """MT19937 mode: plans of many steps made by the host twin in one go, consumed by the one-workgroup kernel --
+    same chain, same accept counts and the same final generator state as the per-step path."""
+    spec = build(N, D, target, nsplits, 2.0, seed=N + 7 * D, kind=kind)
+    for nsteps, thin_by, store, chunks in ((9, 1, True, 1), (4, 3, True, 2), (300, 1, False, 1)):
+        fast = run_exact(spec, 1, nsteps, thin_by, store, chunks)
+        slow = run_exact(spec, 0, nsteps, thin_by, store, chunks)
+        assert np.array_equal(fast["state"][0], slow["state"][0]) and np.array_equal(fast["state"][1], slow["state"][1])
+        assert np.array_equal(fast["acc"], slow["acc"])
+        assert np.array_equal(fast["mt"][0], slow["mt"][0]) and fast["mt"][1:] == slow["mt"][1:]
+        if store:
+            assert np.array_equal(fast["chain"], slow["chain"]) and np.array_equal(fast["lp"], slow["lp"])
+            assert np.array_equal(fast["cnt"], slow["cnt"])
+
+
 def test_small_run_chunks_and_resume():
     """more steps than one launch takes (4096), and a second emx_run call continuing the chain"""
     spec = build(32, 5, "iso", 2, 2.0, seed=3)
