@@ -227,6 +227,17 @@ class Backend(object):
         self.random_state = state.random_state
         self._iteration += 1
 
+    @property
+    def random_state(self):
+        """RNG state after the last stored step.  During a device run the sampler hands over a provider (the MT19937
+        state then lives in libemx and is only copied out when somebody asks)."""
+        v = self._rstate
+        return v() if callable(v) else v
+
+    @random_state.setter
+    def random_state(self, value):
+        self._rstate = value
+
     def _device_step_saved(self, state_blobs, random_state):
         """Book-keeping after the kernel appended a step to the device chain."""
         if state_blobs is not None:
@@ -236,6 +247,7 @@ class Backend(object):
     def __getstate__(self):
         """Pickling materialises the device chain on the host (contexts are process-local)."""
         d = dict(self.__dict__)
+        d["_rstate"] = self.random_state          # resolve a lazy provider
         if self._dev is not None:
             it = self.iteration
             d["_chain"] = self._dev.chain_read(0, 0, it)

@@ -157,6 +157,7 @@ class EnsembleSampler(object):
         # private generator, seeded from the global NumPy state (reference ensemble.py:164-167)
         self._random = np.random.mtrand.RandomState()
         self._random.set_state(state)
+        self._rng_on_device = None      # the DeviceEnsemble whose MT19937 state is newer than self._random's
         if self._dist is not None:            # replicated decisions need ONE stream: rank 0's
             self._random.set_state(self._replicate(self._random.get_state()))
 
@@ -172,15 +173,25 @@ class EnsembleSampler(object):
     @property
     def random_state(self):
         """``get_state()`` of the sampler's private ``numpy.random.RandomState``."""
+        self._flush_rng()
         return self._random.get_state()
 
     @random_state.setter  # NOQA
     def random_state(self, state):
         """Try to set the generator state; fails silently like the reference (ensemble.py:228-238)."""
+        self._rng_on_device = None
         try:
             self._random.set_state(state)
         except:  # noqa: E722
             pass
+
+    def _flush_rng(self):
+        """Bring self._random up to date with the MT19937 state a device run left in libemx (copied lazily: a
+        624-word get_state/set_state round trip per yielded step would cost more than the step)."""
+        ens = self._rng_on_device
+        if ens is not None:
+            self._rng_on_device = None
+            self._random.set_state(ens.get_mt19937())
 
     @property
     def iteration(self):
@@ -191,8 +202,10 @@ class EnsembleSampler(object):
         self.backend.reset(self.nwalkers, self.ndim)
 
     def __getstate__(self):
+        self._flush_rng()
         d = dict(self.__dict__)
         d["pool"] = None
+        d["_rng_on_device"] = None
         d["_ens"] = None            # device contexts are not picklable; re-created on demand
         d["_dist"] = None           # nor are process groups: an unpickled sampler is a single-GPU one
         return d
@@ -229,6 +242,7 @@ class EnsembleSampler(object):
         return self._ens
 
     def _philox_seed(self):
+        self._flush_rng()
         key = self._random.get_state()[1]
         return (int(key[0]) << 32 | int(key[1])) ^ (int(key[2]) << 16)
 
@@ -250,6 +264,7 @@ class EnsembleSampler(object):
                 raise RuntimeError("distributed=True needs a DeviceTarget log_prob_fn (the sharded step is the fused one)")
             self._join_communicator(ens)
         if self.rng == "mt19937":
+            self._flush_rng()
             ens.set_rng_mode(_lib.RNG_MT19937)
             ens.set_mt19937(self._random.get_state())
         else:
@@ -263,7 +278,7 @@ class EnsembleSampler(object):
             if hasattr(m, "_scale_vector") and getattr(step, "mode", None) == "sequential" and m._is_native():
                 step.index = int(ens.get_move(i).gammas)
         if self.rng == "mt19937":
-            self._random.set_state(ens.get_mt19937())
+            self._rng_on_device = ens
         else:
             self._philox_step = ens.get_philox()[1]
 
@@ -342,6 +357,7 @@ class EnsembleSampler(object):
             self.backend.grow(nsaves, state.blobs)
 
         map_fn = self.pool.map if self.pool is not None else map
+        self._flush_rng()
         model = Model(self.log_prob_fn, self.compute_log_prob, map_fn, self._random)
         if progress_kwargs is None:
             progress_kwargs = {}
@@ -349,7 +365,28 @@ class EnsembleSampler(object):
         total = None if iterations is None else iterations * yield_step
         with get_progress_bar(progress, total, **progress_kwargs) as pbar:
             i = 0
+            # fused path: the yield_step proposals between two yields are ONE native call (emx_run(1, yield_step, store)
+            # keeps the block's last step, which is the step the reference stores: ensemble.py:416)
+            block_call = fused and (not store or dev_store) and checkpoint_step == yield_step
+            lazy_rs = lambda: self.random_state  # noqa: E731
             for _ in count() if iterations is None else range(iterations):
+                if block_call:
+                    ens.run(1, yield_step, store)
+                    ens.raise_on_status()
+                    self._sync_rng_from_device(ens)
+                    state._invalidate()
+                    state.random_state = lazy_rs             # resolved when somebody reads it
+                    if store:
+                        self.backend._device_step_saved(None, lazy_rs)
+                    pbar.update(yield_step)
+                    i += yield_step
+                    try:
+                        yield state
+                    except GeneratorExit:
+                        if store:
+                            self.backend.random_state = self.random_state    # pin what the provider stood for
+                        raise
+                    continue
                 for _ in range(yield_step):
                     save = store and (i + 1) % checkpoint_step == 0
                     if native:
@@ -376,6 +413,8 @@ class EnsembleSampler(object):
                 if native and not isinstance(state, DeviceState):
                     state.coords, state.log_prob = ens.get_state()
                 yield state
+            if block_call and store:
+                self.backend.random_state = self.random_state            # pin what the provider stood for
 
     def _device_step(self, ens, state, fused, store, need_mask=True):
         """One full step of the built-in moves on the device; returns the accepted mask (None when

@@ -63,7 +63,17 @@ class DeviceState(State):
     loop that never looks at the coordinates never pays the (nwalkers x ndim) PCIe copy.
     Assigning to ``coords`` / ``log_prob`` detaches that field from the device."""
 
-    __slots__ = ("_ens", "_c", "_lp")
+    __slots__ = ("_ens", "_c", "_lp", "_rs")
+
+    @property
+    def random_state(self):
+        """The sampler's current generator state (a provider is resolved on access, like the coordinates)."""
+        v = self._rs
+        return v() if callable(v) else v
+
+    @random_state.setter
+    def random_state(self, value):
+        self._rs = value
 
     def __init__(self, ens, blobs=None, random_state=None):
         self._ens = ens

@@ -528,3 +528,36 @@ def test_distributed_front_end_world1():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_generator_rng_state_is_current_whenever_somebody_looks():
+    """The MT19937 state stays in libemx between yields and is copied out on demand: sampler.random_state, the
+    yielded state's random_state and the backend's must all be what reference emcee would hold at that point."""
+    name = "stretch_50x3_iso"
+    g = load_golden(name)
+    spec = cases.build(name)
+    k = 7
+    ref = make_sampler(spec, g)
+    ref.run_mcmc(g["p0"], k, skip_initial_state_check=True)          # one native call: the state after k steps
+    want = ref.random_state
+    s = make_sampler(spec, g)
+    for n, st in enumerate(s.sample(g["p0"], iterations=spec["nsteps"], skip_initial_state_check=True), 1):
+        if n == k:
+            for got in (st.random_state, s.random_state, s.backend.random_state, s.get_last_sample().random_state):
+                assert np.array_equal(got[1], want[1]) and got[2:] == want[2:]
+            assert np.array_equal(st.coords, g["chain"][k - 1])
+    end = s.random_state
+    assert np.array_equal(end[1], g["rng_key1"]) and end[2] == int(g["rng_pos1"])
+    assert np.array_equal(s.backend.random_state[1], g["rng_key1"])
+    assert np.array_equal(s.get_chain(), g["chain"])
+    # leaving the loop early pins the backend's state at the last stored step
+    s = make_sampler(spec, g)
+    for n, st in enumerate(s.sample(g["p0"], iterations=spec["nsteps"], skip_initial_state_check=True), 1):
+        if n == k:
+            break
+    s.run_mcmc(s.get_last_sample(), 3, store=False, skip_initial_state_check=True)   # unsaved steps must not leak into it
+    got = s.backend.random_state
+    assert np.array_equal(got[1], want[1]) and got[2:] == want[2:]
+    # setting the state by hand wins over whatever the device holds
+    s.random_state = want
+    assert np.array_equal(s.random_state[1], want[1])
