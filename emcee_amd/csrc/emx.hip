@@ -282,6 +282,8 @@ struct emx_ctx {
     double *X = nullptr, *lp = nullptr;
     uint8_t* acc = nullptr;
     uint32_t *acc_count = nullptr, *status = nullptr;
+    uint32_t* status_host = nullptr;   // `status` lives in mapped pinned host memory: kernels only touch it on errors
+                                       // (system-scope atomicOr), the host reads it without a device copy
     int32_t* iota = nullptr;
     // target
     int target = EMX_TARGET_HOST;
@@ -707,7 +709,13 @@ int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
     ALLOC(c->lp, N * 8);
     ALLOC(c->acc, N);
     ALLOC(c->acc_count, N * 4);
-    ALLOC(c->status, 4);
+    if (hipHostMalloc((void**)&c->status_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->status, c->status_host, 0) != hipSuccess) {
+        g_err = "status word allocation failed";
+        emx_destroy(c);
+        return -2;
+    }
+    for (int k = 0; k < 16; ++k) c->status_host[k] = 0u;
     ALLOC(c->iota, N * 4);
     ALLOC(c->qout, N * D * 8);
     ALLOC(c->fout, N * 8);
@@ -737,7 +745,6 @@ int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
 #undef ALLOC
     hipMemsetAsync(c->acc, 0, N, c->stream);
     hipMemsetAsync(c->acc_count, 0, N * 4, c->stream);
-    hipMemsetAsync(c->status, 0, 4, c->stream);
     hipMemsetAsync(c->lp, 0, N * 8, c->stream);
     {
         std::vector<int32_t> io(N);
@@ -766,7 +773,8 @@ int emx_destroy(emx_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm), c->comm = nullptr;
-    void* ptrs[] = {c->X, c->lp, c->acc, c->acc_count, c->status, c->iota, c->qout, c->fout, c->newlp, c->evalX,
+    if (c->status_host) hipHostFree(c->status_host);
+    void* ptrs[] = {c->X, c->lp, c->acc, c->acc_count, c->iota, c->qout, c->fout, c->newlp, c->evalX,
                     c->evallp, c->tp0, c->tp1, c->chain, c->chain_lp, c->own_shard_bufs ? c->sendbuf : nullptr,
                     c->own_shard_bufs ? c->gathered : nullptr};
     for (void* p : ptrs)
@@ -824,9 +832,11 @@ int emx_sync(emx_ctx* c) {
 }
 
 int emx_status(emx_ctx* c, uint32_t* bits) {
-    HIPOK(c, hipMemcpyAsync(bits, c->status, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(c, hipStreamSynchronize(c->stream));
-    if (*bits) HIPOK(c, hipMemsetAsync(c->status, 0, 4, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));      // every launch that could still raise a bit has finished
+    uint32_t b = 0;
+    for (int k = 0; k < 3; ++k)
+        if (__atomic_exchange_n(&c->status_host[k], 0u, __ATOMIC_ACQ_REL)) b |= 1u << k;
+    *bits = b;
     return 0;
 }
 

@@ -45,6 +45,12 @@ enum : int { GAUSS_VECTOR = 0, GAUSS_RANDOM = 1, GAUSS_SEQUENTIAL = 2 };
 enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5 };
 enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u };
 
+// The sticky status lives in mapped host memory, one 32-bit flag per condition (index = bit number): raising one is
+// a plain idempotent store -- no read-modify-write across PCIe -- and only error paths ever execute it.
+__device__ __forceinline__ void raise_status(uint32_t* flags, uint32_t bit) {
+    __hip_atomic_store(&flags[__builtin_ctz(bit)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct NativeArgs {
     uint64_t seed;
     uint64_t step;
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 #pragma unroll
                             for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
                         badq = group_any<G>(bl, sub);
-                        if (live && badq && gl == 0) atomicOr(A.status, ST_BAD_COORD);
+                        if (live && badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
                     }
 
                     if (A.target == TGT_NONE) {
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         }
                     } else if constexpr (!DENSE) {
                         const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
-                        if (live && gl == 0 && (lp_new != lp_new)) atomicOr(A.status, ST_NAN_LOGP);   // ensemble.py:550-551
+                        if (live && gl == 0 && (lp_new != lp_new)) raise_status(A.status, ST_NAN_LOGP);   // ensemble.py:550-551
                         if constexpr (MOVE == MOVE_EVAL) {
                             if (live && gl == 0) A.lp[i] = lp_new;
                         } else {
@@ -881,7 +887,7 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                     double lp_fin = my_lpo;
                     if (mine) {
                         const double lpn = -0.5 * my_qf;
-                        if (lpn != lpn) atomicOr(A.status, ST_NAN_LOGP);
+                        if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);
                         if constexpr (MOVE == MOVE_EVAL) {
                             A.lp[my_i] = lpn;
                         } else {
@@ -1084,9 +1090,9 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
 #pragma unroll
                         for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
                     const bool badq = group_any<G>(bl, sub);
-                    if (live && badq && gl == 0) atomicOr(A.status, ST_BAD_COORD);
+                    if (live && badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
                     const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
-                    if (live && gl == 0 && (lp_new != lp_new)) atomicOr(A.status, ST_NAN_LOGP);
+                    if (live && gl == 0 && (lp_new != lp_new)) raise_status(A.status, ST_NAN_LOGP);
                     const double lp_old = lps[i];
                     const double lnpdiff = factor + lp_new - lp_old;                  // red_blue.py:99
                     const bool accept = live && !badq && (lnpdiff > logus[pos]);      // red_blue.py:100
@@ -1160,7 +1166,7 @@ __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
     const double uacc = A.uacc[A.pos0 + t];
     const double nlp = A.new_lp[t];
     const double lp_old = A.lp[i];
-    if (nlp != nlp) atomicOr(A.status, ST_NAN_LOGP);
+    if (nlp != nlp) raise_status(A.status, ST_NAN_LOGP);
     const double lnpdiff = A.fout[t] + nlp - lp_old;
     const bool accept = lnpdiff > log(uacc);
     const double* q = A.qout + (size_t)t * A.D;
@@ -1420,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) {
                 if (e < A.cap)
                     A.sendidx[(size_t)q * A.cap + e] = pj[j];
                 else
-                    atomicOr(A.status, ST_EXCHANGE_OVERFLOW);
+                    raise_status(A.status, ST_EXCHANGE_OVERFLOW);
             }
         }
     }
