@@ -398,7 +398,8 @@ class EnsembleSampler(object):
                     else:
                         move = self._random.choice(self._moves, p=self._weights)     # ensemble.py:406
                         state, accepted = move.propose(model, state)
-                    state.random_state = self.random_state
+                    # device steps leave the MT19937 state in libemx; a DeviceState resolves it when it is read
+                    state.random_state = lazy_rs if isinstance(state, DeviceState) else self.random_state
                     if tune and move is not None:
                         move.tune(state, accepted)
                     if save:
@@ -412,8 +413,13 @@ class EnsembleSampler(object):
                     i += 1
                 if native and not isinstance(state, DeviceState):
                     state.coords, state.log_prob = ens.get_state()
-                yield state
-            if block_call and store:
+                try:
+                    yield state
+                except GeneratorExit:
+                    if store and dev_store:
+                        self.backend.random_state = self.random_state
+                    raise
+            if store and (block_call or dev_store):
                 self.backend.random_state = self.random_state            # pin what the provider stood for
 
     def _device_step(self, ens, state, fused, store, need_mask=True):
@@ -437,7 +443,8 @@ class EnsembleSampler(object):
         ens.step_end()
         ens.raise_on_status()
         self._sync_rng_from_device(ens)
-        accepted = ens.accepted_mask()
+        # the mask crosses PCIe only when somebody on the host consumes it (host backend, blobs)
+        accepted = ens.accepted_mask() if (need_mask or pending) else None
         for split, new_blobs in pending:
             if state.blobs is None:
                 raise ValueError("If you start sampling with a given log_prob, you also need to provide the "
