@@ -404,7 +404,8 @@ class EnsembleSampler(object):
                         move.tune(state, accepted)
                     if save:
                         if dev_store:
-                            self.backend._device_step_saved(state.blobs, state.random_state)
+                            self.backend._device_step_saved(state.blobs, lazy_rs if isinstance(state, DeviceState)
+                                                            else state.random_state)
                         else:
                             if native and not isinstance(state, DeviceState):
                                 state.coords, state.log_prob = ens.get_state()
@@ -545,9 +546,9 @@ class EnsembleSampler(object):
         Device targets are evaluated by the batched kernel; other callables as in reference
         ``ensemble.py:458-553`` (``vectorize``, ``pool.map``, blobs, NaN / inf guards)."""
         p = coords
-        if np.any(np.isinf(p)):
-            raise ValueError("At least one parameter value was infinite")
-        if np.any(np.isnan(p)):
+        if not np.isfinite(p).all():               # one pass; the reference's two messages on the rare failure
+            if np.any(np.isinf(p)):
+                raise ValueError("At least one parameter value was infinite")
             raise ValueError("At least one parameter value was NaN")
 
         if self._device_target is not None:
@@ -700,6 +701,8 @@ def _blob_dtype(first_blob):
 def _split_log_prob_and_blobs(results, blobs_dtype):
     """``log_prob_fn`` may return a scalar or ``(log_prob, blob, ...)`` per walker; separate the two
     (reference ``ensemble.py:498-547``).  Returns ``(log_prob array, blob array or None)``."""
+    if isinstance(results, np.ndarray) and results.ndim == 1 and results.dtype.kind == "f":
+        return results.astype(np.float64, copy=False), None      # a vectorised callable's plain log-prob vector
     try:
         blobs = [r[1:] for r in results if len(r) > 1]
         has_blobs = len(blobs) > 0
