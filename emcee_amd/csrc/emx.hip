@@ -282,6 +282,8 @@ struct emx_ctx {
     double *X = nullptr, *lp = nullptr;
     uint8_t* acc = nullptr;
     uint32_t *acc_count = nullptr, *status = nullptr;
+    char* xfer_host = nullptr;         // pinned bounce buffer for small split-phase transfers (a D2H copy into pageable
+    size_t xfer_bytes = 0;             // memory costs ~2x the latency of one into pinned memory + a host memcpy)
     uint32_t* status_host = nullptr;   // `status` lives in mapped pinned host memory: kernels only touch it on errors
                                        // (system-scope atomicOr), the host reads it without a device copy
     int32_t* iota = nullptr;
@@ -774,6 +776,7 @@ int emx_destroy(emx_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm), c->comm = nullptr;
     if (c->status_host) hipHostFree(c->status_host);
+    if (c->xfer_host) hipHostFree(c->xfer_host);
     void* ptrs[] = {c->X, c->lp, c->acc, c->acc_count, c->iota, c->qout, c->fout, c->newlp, c->evalX,
                     c->evallp, c->tp0, c->tp1, c->chain, c->chain_lp, c->own_shard_bufs ? c->sendbuf : nullptr,
                     c->own_shard_bufs ? c->gathered : nullptr};
@@ -1468,10 +1471,25 @@ int emx_propose(emx_ctx* c, int32_t split, double* q_out, double* factors_out, i
     const auto& cur = c->cur;
     const int64_t ns = cur.off[split + 1] - cur.off[split];
     if (ns_out) *ns_out = ns;
-    if (q_out && ns > 0)
-        HIPOK(c, hipMemcpyAsync(q_out, c->qout, (size_t)ns * c->D * 8, hipMemcpyDeviceToHost, c->stream));
-    if (factors_out && ns > 0)
-        HIPOK(c, hipMemcpyAsync(factors_out, c->fout, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    const size_t qb = q_out && ns > 0 ? (size_t)ns * c->D * 8 : 0, fb = factors_out && ns > 0 ? (size_t)ns * 8 : 0;
+    if (qb + fb > 0 && qb + fb <= (4u << 20)) {
+        if (c->xfer_bytes < qb + fb) {
+            if (c->xfer_host) hipHostFree(c->xfer_host);
+            c->xfer_host = nullptr;
+            c->xfer_bytes = 0;
+            const size_t want = std::max<size_t>(qb + fb, std::min<size_t>(4u << 20, (size_t)c->N * (c->D + 1) * 8));
+            HIPOK(c, hipHostMalloc((void**)&c->xfer_host, want, hipHostMallocDefault));
+            c->xfer_bytes = want;
+        }
+        if (qb) HIPOK(c, hipMemcpyAsync(c->xfer_host, c->qout, qb, hipMemcpyDeviceToHost, c->stream));
+        if (fb) HIPOK(c, hipMemcpyAsync(c->xfer_host + qb, c->fout, fb, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        if (qb) memcpy(q_out, c->xfer_host, qb);
+        if (fb) memcpy(factors_out, c->xfer_host + qb, fb);
+        return 0;
+    }
+    if (qb) HIPOK(c, hipMemcpyAsync(q_out, c->qout, qb, hipMemcpyDeviceToHost, c->stream));
+    if (fb) HIPOK(c, hipMemcpyAsync(factors_out, c->fout, fb, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
