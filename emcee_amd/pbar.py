@@ -33,14 +33,15 @@ class _Progress(object):
 
 
 def _tqdm_factory(flavour):
-    """tqdm.tqdm for True, tqdm.<flavour>.tqdm for a string; None when tqdm is not installed."""
+    """The ``tqdm`` class of the submodule ``tqdm.<flavour>`` (``tqdm.auto`` for ``True``), as the reference picks it
+    (``pbar.py:54-58``); None when tqdm is not installed."""
     try:
-        tqdm = importlib.import_module("tqdm")
-    except ImportError:
-        return None
-    if flavour is True:
-        return tqdm.tqdm
-    return getattr(tqdm, "tqdm_" + str(flavour))
+        module = importlib.import_module("tqdm." + ("auto" if flavour is True else str(flavour)))
+    except ImportError as exc:
+        if exc.name == "tqdm":
+            return None
+        raise
+    return module.tqdm
 
 
 def get_progress_bar(display, total, **kwargs):

@@ -129,3 +129,98 @@ def test_errors_of_the_generic_path():
         bad.run_mcmc(p0, 2)
     with pytest.raises(ValueError, match="rng must be"):
         emcee_amd.EnsembleSampler(16, 2, lp_plain, rng="xorshift")
+
+
+# ---- named parameters, scalar-likes, progress bar (reference unit/test_ensemble.py, unit/test_pbar.py) -----------
+def test_ndarray_to_list_of_dicts():
+    import string
+    from emcee_amd.ensemble import ndarray_to_list_of_dicts
+    for n_keys in (1, 2, 10, 26):
+        keys = list(string.ascii_lowercase[:n_keys])
+        key_dict = {key: i for i, key in enumerate(keys)}
+        for N in (1, 2, 3, 10, 100):
+            x = np.random.rand(N, n_keys)
+            lod = ndarray_to_list_of_dicts(x, key_dict)
+            assert len(lod) == N
+            for i, dct in enumerate(lod):
+                assert dct.keys() == set(keys)
+                for j, key in enumerate(keys):
+                    assert dct[key] == x[i, j]
+
+
+class _Data:
+    x = np.random.RandomState(0).randn(100)
+
+
+def _lnpdf(pars):
+    mean, var = pars["mean"], pars["var"]
+    if var <= 0:
+        return -np.inf
+    return -0.5 * ((mean - _Data.x) ** 2 / var + np.log(2 * np.pi * var)).sum()
+
+
+def _lnpdf_grouped(pars):
+    mean1, mean2 = pars["means"]
+    var1, var2 = pars["vars"]
+    if var1 <= 0 or var2 <= 0:
+        return -np.inf
+    return -0.5 * ((mean1 - _Data.x) ** 2 / var1 + np.log(2 * np.pi * var1) + (mean2 - _Data.x - 3) ** 2 / var2
+                   + np.log(2 * np.pi * var2)).sum() + pars["constant"]
+
+
+def test_named_parameters_construction_and_asserts():
+    names = ["mean", "var"]
+    s = emcee_amd.EnsembleSampler(10, 2, _lnpdf, parameter_names=names)
+    assert s.params_are_named and list(s.parameter_names.keys()) == names
+    with pytest.raises(AssertionError):
+        emcee_amd.EnsembleSampler(10, 1, _lnpdf, parameter_names=names)              # ndim / names mismatch
+    with pytest.raises(AssertionError):
+        emcee_amd.EnsembleSampler(10, 3, _lnpdf, parameter_names=["a", "b", "a"])    # duplicates
+    with pytest.raises(AssertionError):
+        emcee_amd.EnsembleSampler(10, 2, _lnpdf, parameter_names=names, vectorize=True)
+
+
+def test_named_parameters_compute_log_prob_and_run():
+    for N in (4, 8, 10):
+        s = emcee_amd.EnsembleSampler(N, 2, _lnpdf, parameter_names=["mean", "var"])
+        lnps, _ = s.compute_log_prob(np.random.rand(N, 2))
+        assert len(lnps) == N and lnps.dtype == np.float64
+    grouped = {"means": [0, 1], "vars": [2, 3], "constant": 4}
+    for N in (8, 10, 20):
+        s = emcee_amd.EnsembleSampler(N, 5, _lnpdf_grouped, parameter_names=grouped)
+        lnps, _ = s.compute_log_prob(np.random.rand(N, 5))
+        assert len(lnps) == N and lnps.dtype == np.float64
+    # sort of an integration test, on a move that needs no GPU
+    s = emcee_amd.EnsembleSampler(4, 2, _lnpdf, parameter_names=["mean", "var"], moves=moves.GaussianMove(0.01))
+    res = s.run_mcmc(np.random.rand(4, 2), 50)
+    assert res.coords.shape == (4, 2)
+    assert s.chain.shape == (4, 50, 2)            # deprecated (walker, step, dim) spelling
+
+
+def test_log_prob_fn_may_return_scalar_likes():
+    def base(x):
+        return float(np.log(np.sqrt(np.pi) * np.exp(-((x / 2.0) ** 2)))[0])
+
+    for fn in (base, lambda x: np.array([base(x)]), lambda x: np.float64(base(x)), lambda x: np.array(base(x))):
+        init = np.random.default_rng(1).random((50, 1))
+        s = emcee_amd.EnsembleSampler(50, 1, fn, moves=moves.GaussianMove(0.5))
+        s.run_mcmc(init, 20)
+        assert s.get_log_prob().shape == (20, 50)
+
+
+def test_progress_bar_modes():
+    from emcee_amd.pbar import get_progress_bar
+    with get_progress_bar(False, 100) as bar:
+        bar.update(3)                                   # the no-op bar swallows updates
+    pytest.importorskip("tqdm")
+    import tqdm.asyncio
+    import tqdm.std
+    for mode, cls in ((True, tqdm.asyncio.tqdm_asyncio), ("std", tqdm.std.tqdm), ("auto", tqdm.asyncio.tqdm_asyncio),
+                      ("autonotebook", tqdm.std.tqdm)):
+        with get_progress_bar(mode, 10, disable=True) as bar:
+            bar.update(1)
+            assert isinstance(bar._bar, cls), (mode, type(bar._bar))
+    with pytest.raises(ImportError):
+        get_progress_bar("no_such_flavour", 10)
+    s = emcee_amd.EnsembleSampler(8, 1, lambda x: -0.5 * np.sum(x * x), moves=moves.GaussianMove(0.5))
+    s.run_mcmc(np.random.RandomState(2).randn(8, 1), 5, progress=True, progress_kwargs={"disable": True})
