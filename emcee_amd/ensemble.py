@@ -297,6 +297,7 @@ class EnsembleSampler(object):
         state_shape = np.shape(state.coords)
         if state_shape != (self.nwalkers, self.ndim):
             raise ValueError(f"incompatible input dimensions {state_shape}")
+        _refuse_extended_precision(state.coords)
         if (not skip_initial_state_check) and (not walkers_independent(state.coords)):
             raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
                              "linearly independent for the best performance")
@@ -502,6 +503,7 @@ class EnsembleSampler(object):
             return None
         if np.shape(state.coords) != (self.nwalkers, self.ndim):
             raise ValueError(f"incompatible input dimensions {np.shape(state.coords)}")
+        _refuse_extended_precision(state.coords)
         if (not kw.get("skip_initial_state_check", False)) and (not walkers_independent(state.coords)):
             raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
                              "linearly independent for the best performance")
@@ -642,6 +644,15 @@ class _FunctionWrapper(object):
             print("  exception:")
             traceback.print_exc()
             raise
+
+
+def _refuse_extended_precision(coords):
+    """The ensemble lives in HBM as float64.  The reference carries ``np.longdouble`` coordinates through its host
+    arrays (tests/integration/test_longdouble.py); here they would be truncated silently, so they are refused."""
+    dt = np.asarray(coords).dtype
+    if dt.kind == "f" and dt.itemsize > 8:
+        raise TypeError("emcee_amd keeps the ensemble in float64 on the GPU; %s coordinates would lose precision "
+                        "(cast them explicitly if that is acceptable)" % dt)
 
 
 def _thinning_plan(iterations, thin_by, thin):

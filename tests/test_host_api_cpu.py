@@ -224,3 +224,17 @@ def test_progress_bar_modes():
         get_progress_bar("no_such_flavour", 10)
     s = emcee_amd.EnsembleSampler(8, 1, lambda x: -0.5 * np.sum(x * x), moves=moves.GaussianMove(0.5))
     s.run_mcmc(np.random.RandomState(2).randn(8, 1), 5, progress=True, progress_kwargs={"disable": True})
+
+
+def test_extended_precision_input_is_refused_not_truncated():
+    """reference integration/test_longdouble.py keeps np.longdouble end to end; a float64 device state cannot, and
+    says so instead of silently rounding an ensemble that only differs beyond the 16th digit"""
+    if np.dtype(np.longdouble).itemsize <= 8:
+        pytest.skip("longdouble is float64 on this platform")
+    mjd = np.longdouble(58000.0)
+    sigma = 100 * np.finfo(np.longdouble).eps * mjd
+    p0 = sigma * np.random.RandomState(0).randn(20, 1).astype(np.longdouble) + mjd
+    s = emcee_amd.EnsembleSampler(20, 1, lambda x: -0.5 * np.sum(((x - mjd) / sigma) ** 2), moves=moves.GaussianMove(0.5))
+    with pytest.raises(TypeError, match="float64"):
+        s.run_mcmc(p0, 5, skip_initial_state_check=True)
+    s.run_mcmc(np.asarray(p0 - mjd, dtype=np.float64), 5, skip_initial_state_check=True)     # an explicit cast is fine
