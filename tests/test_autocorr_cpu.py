@@ -42,3 +42,14 @@ def test_equals_reference():
     np.testing.assert_allclose(autocorr.integrated_time(x, quiet=True),
                                emcee.autocorr.integrated_time(x, quiet=True), rtol=1e-9)
     np.testing.assert_allclose(autocorr.function_1d(x[:, 0, 0]), emcee.autocorr.function_1d(x[:, 0, 0]), atol=1e-12)
+
+
+def test_nd_layouts_agree():
+    """reference unit/test_autocorr.py:31-54: (steps, dims) with has_walkers=False == (steps, 1, dims); a multi-dimension
+    estimate equals the per-dimension ones"""
+    x = ar1(N=10000)
+    np.testing.assert_allclose(autocorr.integrated_time(x[:, np.newaxis]), autocorr.integrated_time(x, has_walkers=False))
+    xs = np.random.RandomState(42).randn(16384, 2)
+    multi = autocorr.integrated_time(xs[:, np.newaxis])
+    single = np.array([autocorr.integrated_time(xs[:, i]) for i in range(2)]).squeeze()
+    np.testing.assert_allclose(multi, single)
