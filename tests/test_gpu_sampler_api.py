@@ -377,12 +377,17 @@ def test_gaussian_sequential_cursor_survives_runs():
     assert np.array_equal(s.backend.accepted, g["accepted_count"])
 
 
-def test_uniform_start_leaves_its_initialisation():
-    """reference integration/test_proposal.py:79-102 (_test_uniform)."""
+@pytest.mark.parametrize("mv,rng", [(lambda: None, "philox"), (lambda: None, "mt19937"), (lambda: moves.DEMove(), "philox"),
+                                    (lambda: moves.DESnookerMove(), "philox"), (lambda: moves.GaussianMove(0.5), "philox"),
+                                    (lambda: moves.GaussianMove(0.5, mode="random", factor=2.0), "mt19937"),
+                                    (lambda: moves.StretchMove(randomize_split=False), "philox")])
+def test_uniform_start_leaves_its_initialisation(mv, rng):
+    """reference integration/test_proposal.py:79-102 (_test_uniform) for every move family
+    (test_stretch.py:22, test_de.py:18, test_de_snooker.py:15, test_gaussian.py:78)."""
     from scipy import stats
     np.random.seed(1234)
     coords = np.random.rand(32, 1)
-    s = emcee_amd.EnsembleSampler(32, 1, targets.IsoGaussian(), rng="philox")
+    s = emcee_amd.EnsembleSampler(32, 1, targets.IsoGaussian(), rng=rng, moves=mv())
     s.run_mcmc(coords, 2000)
     acc = s.acceptance_fraction
     assert np.all((acc < 0.9) * (acc > 0.1))
@@ -561,3 +566,17 @@ def test_generator_rng_state_is_current_whenever_somebody_looks():
     # setting the state by hand wins over whatever the device holds
     s.random_state = want
     assert np.array_equal(s.random_state[1], want[1])
+
+
+def test_normal_stretch_with_blobs_on_the_host_callable_path():
+    """reference integration/test_stretch.py:17-19 with blobs=True (test_proposal.py:21-23: the blob is a Python
+    object per walker)"""
+    np.random.seed(1234)
+    coords = np.random.randn(32, 2)
+    s = emcee_amd.EnsembleSampler(32, 2, lambda x: (-0.5 * np.sum(x ** 2), "blob"))
+    s.run_mcmc(coords, 1500)
+    acc = s.acceptance_fraction
+    assert np.all((acc < 0.9) * (acc > 0.1))
+    samps = s.get_chain(flat=True)
+    assert np.all(np.abs(np.mean(samps, axis=0)) < 0.08) and np.all(np.abs(np.std(samps, axis=0) - 1) < 0.05)
+    assert s.get_blobs().shape == (1500, 32) and s.get_blobs()[3, 4] == "blob"
