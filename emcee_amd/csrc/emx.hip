@@ -183,14 +183,7 @@ void host_native_plan(const NativeArgs& na, int64_t N, const emx_move_desc& mv, 
         }
 }
 
-int philox_move_choice(uint64_t seed, uint64_t step, const double* cdf, int n) {
-    const Philox4 r = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), 0x4d4f5645u /*'MOVE'*/, 0, (uint32_t)seed,
-                                    (uint32_t)(seed >> 32));
-    const double u = u53(r.v[0], r.v[1]);
-    int k = 0;
-    while (k < n - 1 && u >= cdf[k]) ++k;
-    return k;
-}
+int philox_move_choice(uint64_t seed, uint64_t step, const double* cdf, int n) { return native_move_choice(seed, step, cdf, n); }
 
 // ---- RCCL, resolved at run time (the process may already hold PyTorch's copy) ----------------
 struct RcclId {
@@ -442,9 +435,9 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
     return hipGetLastError();
 }
 
-template <int G, int V, int CH, int MOVE, bool PLANNED>
+template <int G, int V, int CH, int MOVESEL, bool PLANNED>
 hipError_t launch_small_move(int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
-    auto kern = k_small_run<G, V, CH, MOVE, PLANNED>;
+    auto kern = k_small_run<G, V, CH, MOVESEL, PLANNED>;
     static size_t lds_granted = 0;
     if (lds > 48 * 1024 && lds > lds_granted) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -468,6 +461,9 @@ hipError_t launch_small(int move, int threads, size_t lds, hipStream_t st, const
         case MOVE_SNOOKER:
             return planned ? launch_small_move<G, V, CH, MOVE_SNOOKER, true>(threads, lds, st, a)
                            : launch_small_move<G, V, CH, MOVE_SNOOKER, false>(threads, lds, st, a);
+        case SMALL_ANY_MOVE:
+            return planned ? launch_small_move<G, V, CH, SMALL_ANY_MOVE, true>(threads, lds, st, a)
+                           : launch_small_move<G, V, CH, SMALL_ANY_MOVE, false>(threads, lds, st, a);
     }
     return hipErrorInvalidValue;
 }
@@ -1667,10 +1663,12 @@ static size_t small_lds_bytes(int64_t N, int D) {
 }
 
 static bool small_eligible(const emx_ctx* c) {
-    if (!c->tune_small || (c->rng_mode != EMX_RNG_PHILOX && c->rng_mode != EMX_RNG_MT19937) || c->moves.size() != 1) return false;
-    const emx_move_desc& mv = c->moves[0];
-    if (mv.kind != EMX_MOVE_STRETCH && mv.kind != EMX_MOVE_DE && mv.kind != EMX_MOVE_SNOOKER) return false;
-    if (mv.kind == EMX_MOVE_DE && c->N - (c->N + mv.nsplits - 1) / mv.nsplits < 2) return false;
+    if (!c->tune_small || (c->rng_mode != EMX_RNG_PHILOX && c->rng_mode != EMX_RNG_MT19937)) return false;
+    if (c->moves.empty() || (int)c->moves.size() > SMALL_MAX_MOVES) return false;
+    for (const auto& mv : c->moves) {
+        if (mv.kind != EMX_MOVE_STRETCH && mv.kind != EMX_MOVE_DE && mv.kind != EMX_MOVE_SNOOKER) return false;
+        if (mv.kind == EMX_MOVE_DE && c->N - (c->N + mv.nsplits - 1) / mv.nsplits < 2) return false;
+    }
     if (c->target != EMX_TARGET_ISO_GAUSS && c->target != EMX_TARGET_DIAG_GAUSS && c->target != EMX_TARGET_ROSENBROCK &&
         c->target != EMX_TARGET_BOX)
         return false;
@@ -1681,9 +1679,23 @@ static bool small_eligible(const emx_ctx* c) {
 
 // `nsteps` full steps starting at step index i0 of the current emx_run call
 static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, int32_t store) {
-    const emx_move_desc& mv = c->moves[0];
+    const int nm = (int)c->moves.size();
     const Shape sh = pick_shape(c->D, c->D);
     SmallRunArgs a{};
+    int maxsplits = 2, minsplits = 64;
+    for (int m = 0; m < nm; ++m) {
+        const emx_move_desc& mv = c->moves[m];
+        a.kind[m] = mv.kind;
+        a.nsplits[m] = mv.nsplits;
+        a.a[m] = mv.a;
+        a.sigma[m] = mv.sigma;
+        a.g0[m] = mv.g0;
+        a.gammas[m] = mv.gammas;
+        a.cdf[m] = c->cdf[m];
+        maxsplits = std::max(maxsplits, (int)mv.nsplits);
+        minsplits = std::min(minsplits, (int)mv.nsplits);
+    }
+    a.nmoves = nm;
     a.X = c->X;
     a.lp = c->lp;
     a.acc = c->acc;
@@ -1696,16 +1708,11 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
     a.tp0 = c->tp0;
     a.tp1 = c->tp1;
     a.tscale = c->tscale;
-    a.a = mv.a;
-    a.sigma = mv.sigma;
-    a.g0 = mv.g0;
-    a.gammas = mv.gammas;
     a.seed = c->ph_seed;
     a.step0 = c->ph_step;
     a.i0 = i0;
     a.N = (int32_t)c->N;
     a.D = c->D;
-    a.S = mv.nsplits;
     a.target = c->target;
     a.nsteps = (int32_t)nsteps;
     a.thin_by = thin_by;
@@ -1716,7 +1723,8 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
         // step's draws), `nsteps` plans per copy; the other buffer may still be feeding the previous launch
         auto& bp = c->bulk[c->bulk_pos];
         c->bulk_pos ^= 1;
-        const size_t need = (size_t)nsteps * (size_t)c->N * 32;
+        const size_t plan_bytes = (size_t)nsteps * (size_t)c->N * 32;
+        const size_t need = plan_bytes + (size_t)nsteps * 4;          // + the move index of every step
         if (bp.busy) {
             HIPOK(c, hipEventSynchronize(bp.done));
             bp.busy = false;
@@ -1732,9 +1740,12 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
             if (!bp.done) HIPOK(c, hipEventCreateWithFlags(&bp.done, hipEventDisableTiming));
         }
         const size_t N = (size_t)c->N;
-        std::vector<int32_t> off(mv.nsplits + 1);
+        std::vector<int32_t> off(maxsplits + 1);
+        int32_t* step_moves = (int32_t*)(bp.host + plan_bytes);
         for (int64_t s2 = 0; s2 < nsteps; ++s2) {
-            (void)c->mt.choice_cdf(c->cdf.data(), 1);                       // ensemble.py:406, one move
+            const int mi = c->mt.choice_cdf(c->cdf.data(), nm);             // ensemble.py:406
+            step_moves[s2] = mi;
+            const emx_move_desc& mv = c->moves[mi];
             int32_t* hi = (int32_t*)(bp.host + (size_t)s2 * N * 32);
             double* hd = (double*)(bp.host + (size_t)s2 * N * 32 + N * 16);
             const int rc = make_exact_plan(c->mt, c->N, c->D, mv, c->labels_scratch, off.data(), hi, hi + N, hi + 2 * N,
@@ -1743,15 +1754,17 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
         }
         HIPOK(c, hipMemcpyAsync(bp.dev, bp.host, need, hipMemcpyHostToDevice, c->stream));
         a.plans = bp.dev;
+        a.step_moves = (const int32_t*)(bp.dev + plan_bytes);
     }
-    const int64_t nsmax = (c->N + mv.nsplits - 1) / mv.nsplits;
+    const int64_t nsmax = (c->N + minsplits - 1) / minsplits;
     // enough threads for one half-step's lanes AND for one plan entry each across the batch
     const int64_t want = std::max<int64_t>(nsmax * sh.G, (int64_t)a.batch * c->N);
     int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, ((want + 63) / 64) * 64));
     const size_t lds = small_lds_bytes(c->N, c->D);
     hipError_t e = hipErrorInvalidValue;
+    const int movesel = nm == 1 ? (int)c->moves[0].kind : SMALL_ANY_MOVE;
 #define EMX_CASE(g, v, ch) \
-    if (sh.G == g && sh.V == v && sh.CH == ch) e = launch_small<g, v, ch>(mv.kind, threads, lds, c->stream, a);
+    if (sh.G == g && sh.V == v && sh.CH == ch) e = launch_small<g, v, ch>(movesel, threads, lds, c->stream, a);
     EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4) EMX_CASE(16, 1, 4) EMX_CASE(32, 1, 4) EMX_CASE(64, 1, 4)
     EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
 #undef EMX_CASE

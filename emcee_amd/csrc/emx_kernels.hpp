@@ -960,10 +960,23 @@ __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 // When the ensemble (coordinates, log-probs, one step's plan) fits the 160 KB LDS of a CU, a step is two
 // launches of pure latency (~3.6 us each).  Here one workgroup keeps the ensemble in LDS and iterates
 // plan -> half-step -> ... -> half-step with workgroup barriers where the general path has kernel
-// boundaries: `nsteps` full steps per launch, HBM touched only for the stored chain rows.  Native RNG, one
-// stretch / DE / snooker move, element-wise targets; the same device functions as the general path (native_slot,
+// boundaries: `nsteps` full steps per launch, HBM touched only for the stored chain rows.  Either RNG mode, any
+// schedule of stretch / DE / snooker moves, element-wise targets; the same device functions as the general path (native_slot,
 // make_proposal, eval_valu_target), hence the same bits (tests/test_gpu_small_run.py).
 // ----------------------------------------------------------------------------------------
+constexpr int SMALL_MAX_MOVES = 8;
+constexpr int SMALL_ANY_MOVE = 7;      // MOVESEL: the kernel carries all three split-ensemble moves and picks per step
+
+// move of a native-mode step: one Philox draw against the cdf (the host's philox_move_choice)
+__host__ __device__ inline int native_move_choice(uint64_t seed, uint64_t step, const double* cdf, int n) {
+    const Philox4 r = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), 0x4d4f5645u /*'MOVE'*/, 0, (uint32_t)seed,
+                                    (uint32_t)(seed >> 32));
+    const double u = u53(r.v[0], r.v[1]);
+    int k = 0;
+    while (k < n - 1 && u >= cdf[k]) ++k;
+    return k;
+}
+
 struct SmallRunArgs {
     double* X;
     double* lp;
@@ -974,22 +987,75 @@ struct SmallRunArgs {
     double* chain_lp;
     const double* tp0;
     const double* tp1;
-    double tscale, a, sigma, g0, gammas;     // move parameters (stretch a | DE sigma, g0 | snooker gammas)
+    double tscale;
+    // the move schedule (ensemble.py:115-129): up to SMALL_MAX_MOVES stretch / DE / snooker moves and their cdf
+    double a[SMALL_MAX_MOVES], sigma[SMALL_MAX_MOVES], g0[SMALL_MAX_MOVES], gammas[SMALL_MAX_MOVES], cdf[SMALL_MAX_MOVES];
+    int32_t kind[SMALL_MAX_MOVES], nsplits[SMALL_MAX_MOVES];
+    int32_t nmoves;
     unsigned long long seed, step0;
     long long i0;         // index of the first step inside the emx_run call (thinning phase, ensemble.py:416)
-    int32_t N, D, S, target, nsteps, thin_by, store;
+    int32_t N, D, target, nsteps, thin_by, store;
     int32_t batch;        // steps whose plans are evaluated in one pass (batch * N plan entries live in LDS)
     // PLANNED instantiations (exact MT19937 mode): the host-made plans of the launch's steps, 32 N bytes per step in
-    // the staging layout [order|p0|p1|p2] int32, [s0|uacc] f64
+    // the staging layout [order|p0|p1|p2] int32, [s0|uacc] f64, and the move the host's choice() picked for each step
     const char* plans;
+    const int32_t* step_moves;
 };
 
-template <int G, int V, int CH, int MOVE, bool PLANNED>
-__global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
+// one entry of a step's plan (k_native_plan_batch's arithmetic for this move)
+template <int MOVE>
+__device__ __forceinline__ void small_plan_entry(const NativeArgs& na, int N, int D, int S, int pos, double a, double sigma,
+                                                 double g0, int& i, int& a0, int& a1, int& a2, double& z, double& lu, double& fc) {
+    int split = 0, t = pos;
+    for (int k = 0; k < S; ++k) {
+        const int n = (N - k + S - 1) / S;
+        if (t < n) { split = k; break; }
+        t -= n;
+    }
+    double u;
+    native_slot<MOVE>(na, N, S, split, t, a, sigma, g0, i, a0, a1, a2, z, u);
+    lu = log(u);
+    fc = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
+}
+
+// one group's (walker's) update inside a half-step: the general kernel's element-wise-target branch
+template <int G, int V, int CH, int MOVE>
+__device__ __forceinline__ void small_update(const SmallRunArgs& A, double* Xs, double* lps, uint8_t* accs, bool live, int i,
+                                             int j0, int j1, int j2, double s0, double fac, double logu, double gammas,
+                                             const Row<G, V, CH>& mu, const Row<G, V, CH>& iv, int D, int gl, int sub, int lane) {
     constexpr int NR = rows_per_pass<MOVE>();
+    Row<G, V, CH> xi, xa, xb, xc, q;
+    load_row<G, V, CH>(xi, Xs + (size_t)i * D, D, gl);
+    load_row<G, V, CH>(xa, Xs + (size_t)j0 * D, D, gl);
+    if constexpr (NR >= 3) load_row<G, V, CH>(xb, Xs + (size_t)j1 * D, D, gl);
+    if constexpr (NR >= 4) load_row<G, V, CH>(xc, Xs + (size_t)j2 * D, D, gl);
+    double factor = fac;
+    make_proposal<G, V, CH, MOVE>(xi, xa, NR >= 3 ? xb : xa, NR >= 4 ? xc : xa, (MOVE == MOVE_SNOOKER) ? 0.0 : s0, gammas, D,
+                                  gl, q, factor);
+    bool bl = false;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
+    const bool badq = group_any<G>(bl, sub);
+    if (live && badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
+    const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
+    if (live && gl == 0 && (lp_new != lp_new)) raise_status(A.status, ST_NAN_LOGP);
+    const double lp_old = lps[i];
+    const double lnpdiff = factor + lp_new - lp_old;                  // red_blue.py:99
+    const bool accept = live && !badq && (lnpdiff > logu);            // red_blue.py:100
+    if (accept) {
+        store_row<G, V, CH>(q, Xs + (size_t)i * D, D, gl);
+        if (gl == 0) lps[i] = lp_new;
+    }
+    if (live && gl == 0) accs[i] = accept ? 1 : 0;
+}
+
+template <int G, int V, int CH, int MOVESEL, bool PLANNED>
+__global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int WPW = 64 / G;
-    const int N = A.N, D = A.D, S = A.S, T = blockDim.x, tid = threadIdx.x, B = A.batch;
+    const int N = A.N, D = A.D, T = blockDim.x, tid = threadIdx.x, B = A.batch;
     const int lane = tid & 63, wv = tid >> 6, nwave = T >> 6, sub = lane / G, gl = lane % G;
     double* Xs = smem;
     double* lps = Xs + (size_t)N * D;
@@ -1018,16 +1084,24 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
         load_row<G, V, CH>(mu, A.tp0, D, gl);
         load_row<G, V, CH>(iv, A.tp1, D, gl);
     }
+    // the move of step s: the host's choice() (exact mode) or one Philox draw against the cdf (native mode)
+    auto move_of = [&](int s) -> int {
+        if (A.nmoves == 1) return 0;
+        if constexpr (PLANNED) return A.step_moves[s];
+        return native_move_choice(A.seed, A.step0 + (unsigned long long)s, A.cdf, A.nmoves);
+    };
 
     int row = 0;                                     // stored rows appended by this launch
     for (int sb = 0; sb < A.nsteps; sb += B) {
         const int nb = min(B, A.nsteps - sb);
         __syncthreads();                             // the previous batch's plans are no longer read
-        // ---- the plans of nb steps in one pass (k_native_plan_batch's arithmetic, one entry per thread):
-        //      plans do not depend on the state, so the Philox rounds, keyed-permutation inversions and logs
-        //      of many steps run side by side instead of sitting on every step's critical path ----
+        // ---- the plans of nb steps in one pass, one entry per thread: plans do not depend on the state, so the
+        //      Philox rounds, keyed-permutation inversions and logs of many steps run side by side instead of sitting
+        //      on every step's critical path ----
         for (int e = tid; e < nb * N; e += T) {
             const int b = e / N, pos = e - b * N;
+            const int m = move_of(sb + b);
+            const int kind = MOVESEL == SMALL_ANY_MOVE ? A.kind[m] : MOVESEL;
             if constexpr (PLANNED) {
                 // exact mode: entries made by the host's MT19937 twin; the logs are k_plan_logs' arithmetic
                 const char* base = A.plans + (size_t)(sb + b) * N * 32;
@@ -1040,33 +1114,37 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
                 p2s[e] = hi[3 * N + pos];
                 s0s[e] = z;
                 logus[e] = log(u);
-                facs[e] = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
+                facs[e] = (kind == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
                 continue;
             }
             NativeArgs na;
             na.seed = A.seed;
             na.step = A.step0 + (unsigned long long)(sb + b);
             na.pk = make_perm_key((uint64_t)N, na.seed, na.step);
-            int split = 0, t = pos;
-            for (int k = 0; k < S; ++k) {
-                const int n = (N - k + S - 1) / S;
-                if (t < n) { split = k; break; }
-                t -= n;
-            }
-            int i, a0, a1, a2;
-            double z, u;
-            native_slot<MOVE>(na, N, S, split, t, A.a, A.sigma, A.g0, i, a0, a1, a2, z, u);
+            int i = 0, a0 = 0, a1 = 0, a2 = 0;
+            double z = 0.0, lu = 0.0, fc = 0.0;
+            const int S = A.nsplits[m];
+            if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
+                small_plan_entry<MOVE_STRETCH>(na, N, D, S, pos, A.a[m], A.sigma[m], A.g0[m], i, a0, a1, a2, z, lu, fc);
+            else if (MOVESEL == MOVE_DE || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_DE))
+                small_plan_entry<MOVE_DE>(na, N, D, S, pos, A.a[m], A.sigma[m], A.g0[m], i, a0, a1, a2, z, lu, fc);
+            else
+                small_plan_entry<MOVE_SNOOKER>(na, N, D, S, pos, A.a[m], A.sigma[m], A.g0[m], i, a0, a1, a2, z, lu, fc);
             orders[e] = i;
             p0s[e] = a0;
             p1s[e] = a1;
             p2s[e] = a2;
             s0s[e] = z;
-            logus[e] = log(u);
-            facs[e] = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
+            logus[e] = lu;
+            facs[e] = fc;
         }
         __syncthreads();
         for (int b = 0; b < nb; ++b) {
             const int s = sb + b;
+            const int m = move_of(s);                                            // workgroup-uniform
+            const int kind = MOVESEL == SMALL_ANY_MOVE ? A.kind[m] : MOVESEL;
+            const int S = A.nsplits[m];
+            const double gam = A.gammas[m];
             // ---- the half-steps: a barrier where the general path has a kernel boundary ----
             int pos0 = b * N;
             for (int split = 0; split < S; ++split) {
@@ -1075,32 +1153,14 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
                     const int t = base + sub;
                     const bool live = t < ns;
                     const int pos = pos0 + (live ? t : 0);
-                    const int i = orders[pos];
-                    Row<G, V, CH> xi, xa, xb, xc, q;
-                    load_row<G, V, CH>(xi, Xs + (size_t)i * D, D, gl);
-                    load_row<G, V, CH>(xa, Xs + (size_t)p0s[pos] * D, D, gl);
-                    if constexpr (NR >= 3) load_row<G, V, CH>(xb, Xs + (size_t)p1s[pos] * D, D, gl);
-                    if constexpr (NR >= 4) load_row<G, V, CH>(xc, Xs + (size_t)p2s[pos] * D, D, gl);
-                    double factor = facs[pos];
-                    make_proposal<G, V, CH, MOVE>(xi, xa, NR >= 3 ? xb : xa, NR >= 4 ? xc : xa,
-                                                  (MOVE == MOVE_SNOOKER) ? 0.0 : s0s[pos], A.gammas, D, gl, q, factor);
-                    bool bl = false;
-#pragma unroll
-                    for (int c = 0; c < CH; ++c)
-#pragma unroll
-                        for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
-                    const bool badq = group_any<G>(bl, sub);
-                    if (live && badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
-                    const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
-                    if (live && gl == 0 && (lp_new != lp_new)) raise_status(A.status, ST_NAN_LOGP);
-                    const double lp_old = lps[i];
-                    const double lnpdiff = factor + lp_new - lp_old;                  // red_blue.py:99
-                    const bool accept = live && !badq && (lnpdiff > logus[pos]);      // red_blue.py:100
-                    if (accept) {
-                        store_row<G, V, CH>(q, Xs + (size_t)i * D, D, gl);
-                        if (gl == 0) lps[i] = lp_new;
-                    }
-                    if (live && gl == 0) accs[i] = accept ? 1 : 0;
+                    const int i = orders[pos], j0 = p0s[pos], j1 = p1s[pos], j2 = p2s[pos];
+                    const double s0 = s0s[pos], fac = facs[pos], logu = logus[pos];
+                    if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
+                        small_update<G, V, CH, MOVE_STRETCH>(A, Xs, lps, accs, live, i, j0, j1, j2, s0, fac, logu, gam, mu, iv, D, gl, sub, lane);
+                    else if (MOVESEL == MOVE_DE || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_DE))
+                        small_update<G, V, CH, MOVE_DE>(A, Xs, lps, accs, live, i, j0, j1, j2, s0, fac, logu, gam, mu, iv, D, gl, sub, lane);
+                    else
+                        small_update<G, V, CH, MOVE_SNOOKER>(A, Xs, lps, accs, live, i, j0, j1, j2, s0, fac, logu, gam, mu, iv, D, gl, sub, lane);
                 }
                 __syncthreads();
                 pos0 += ns;

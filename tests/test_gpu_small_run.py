@@ -115,6 +115,42 @@ def test_small_run_exact_mode_equals_general_path(kind, N, D, target, nsplits):
             assert np.array_equal(fast["cnt"], slow["cnt"])
 
 
+@pytest.mark.parametrize("rng", ["philox", "mt"])
+@pytest.mark.parametrize("N,D,target,kinds,weights", [
+    (64, 5, "iso", ["stretch", "de"], [0.5, 0.5]), (128, 8, "diag", ["de", "snooker"], [0.8, 0.2]),
+    (48, 3, "rosenbrock", ["stretch", "de", "snooker"], [0.2, 0.5, 0.3]), (40, 17, "iso", ["snooker", "stretch"], [0.3, 0.7]),
+])
+def test_small_run_move_schedules_equal_general_path(N, D, target, kinds, weights, rng):
+    """weighted mixtures: the move of each step comes from the same draw as on the general path (the host's MT19937
+    choice() in exact mode, one Philox draw against the cdf in native mode)"""
+    from emx_testlib import cdf_of
+    mvs = [so.MoveSpec(k, nsplits=2, live_dangerously=True, sigma=0.05, gammas=1.4) for k in kinds]
+    cases.DIGEST_CASES["_sm"] = dict(N=N, D=D, target=target, moves=mvs, weights=weights, nsteps=1, seed=N + D,
+                                     p0="rosen" if target == "rosenbrock" else "randn")
+    spec = cases.build("_sm")
+    del cases.DIGEST_CASES["_sm"]
+    outs = []
+    for small in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        if rng == "mt":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(np.random.RandomState(5).get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(2718, 0)
+        ens.set_tuning("small_kernel", small)
+        ens.chain_config(40)
+        ens.run(25, 1, True)
+        ens.run(5, 3, True)
+        assert ens.status() == 0
+        outs.append((ens.chain_read(0, 0, 30), ens.chain_read(1, 0, 30), ens.accepted_counts(), ens.get_state()[0],
+                     ens.get_mt19937()[1] if rng == "mt" else np.array(ens.get_philox())))
+        ens.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][2].sum() > 0
+
+
 def test_small_run_chunks_and_resume():
     """more steps than one launch takes (4096), and a second emx_run call continuing the chain"""
     spec = build(32, 5, "iso", 2, 2.0, seed=3)
