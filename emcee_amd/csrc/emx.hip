@@ -422,14 +422,17 @@ static void drop_prepared(emx_ctx* c) {
 // ------------------------------------------------------------------------------------------
 namespace {
 
+constexpr int MAX_DEVICES = 64;      // function attributes are per device: one process may drive several GPUs
+
 template <int G, int V, int CH, int MOVE, int DPB>
 hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
     auto kern = k_halfstep<G, V, CH, MOVE, DPB>;
-    static size_t lds_granted = 0;      // per instantiation: raise the dynamic-LDS limit once, not per launch
-    if (lds > 48 * 1024 && lds > lds_granted) {
+    static size_t lds_granted[MAX_DEVICES] = {};      // per instantiation and device: raise the dynamic-LDS limit once
+    int dev = 0;
+    if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        lds_granted = lds;
+        lds_granted[dev] = lds;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     return hipGetLastError();
@@ -438,11 +441,12 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
 template <int G, int V, int CH, int MOVESEL, bool PLANNED>
 hipError_t launch_small_move(int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
     auto kern = k_small_run<G, V, CH, MOVESEL, PLANNED>;
-    static size_t lds_granted = 0;
-    if (lds > 48 * 1024 && lds > lds_granted) {
+    static size_t lds_granted[MAX_DEVICES] = {};
+    int dev = 0;
+    if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        lds_granted = lds;
+        lds_granted[dev] = lds;
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, st, a);
     return hipGetLastError();
