@@ -438,9 +438,9 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
     return hipGetLastError();
 }
 
-template <int G, int V, int CH, int MOVESEL, bool PLANNED>
+template <int G, int V, int CH, int MOVESEL, bool PLANNED, int DPB = 0>
 hipError_t launch_small_move(int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
-    auto kern = k_small_run<G, V, CH, MOVESEL, PLANNED>;
+    auto kern = k_small_run<G, V, CH, MOVESEL, PLANNED, DPB>;
     static size_t lds_granted[MAX_DEVICES] = {};
     int dev = 0;
     if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
@@ -470,6 +470,19 @@ hipError_t launch_small(int move, int threads, size_t lds, hipStream_t st, const
                            : launch_small_move<G, V, CH, SMALL_ANY_MOVE, false>(threads, lds, st, a);
     }
     return hipErrorInvalidValue;
+}
+
+// dense target in the one-workgroup kernel: a single stretch move, or any schedule (the kernel then carries all three)
+template <int DPB, int V>
+hipError_t launch_small_dense(int move, int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
+    constexpr int cols = DPB * 16 / V;
+    constexpr int G = shape_g(cols), CH = shape_ch(cols);
+    const bool planned = a.plans != nullptr;
+    if (move == MOVE_STRETCH)
+        return planned ? launch_small_move<G, V, CH, MOVE_STRETCH, true, DPB>(threads, lds, st, a)
+                       : launch_small_move<G, V, CH, MOVE_STRETCH, false, DPB>(threads, lds, st, a);
+    return planned ? launch_small_move<G, V, CH, SMALL_ANY_MOVE, true, DPB>(threads, lds, st, a)
+                   : launch_small_move<G, V, CH, SMALL_ANY_MOVE, false, DPB>(threads, lds, st, a);
 }
 
 template <int MOVE>
@@ -1661,9 +1674,26 @@ static int scatter_gathered(emx_ctx* c, int32_t split, int64_t block_rows);
 // steps whose plans one pass evaluates: as many as give every thread of the workgroup an entry
 static int small_batch(int64_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / N)); }
 
-static size_t small_lds_bytes(int64_t N, int D) {
+// dense_dp > 0: + the Cholesky image and one 16-row tile per wave
+static size_t small_lds_bytes(int64_t N, int D, int dense_dp = 0, int waves = 0) {
     const size_t B = (size_t)small_batch(N);
-    return (size_t)N * ((size_t)D * 8 + 8 + 4 + 1) + B * (size_t)N * (3 * 8 + 4 * 4) + 64;
+    size_t b = (size_t)N * ((size_t)D * 8 + 8 + 4 + 1) + B * (size_t)N * (3 * 8 + 4 * 4) + 64;
+    if (dense_dp > 0) b += 16 + ((size_t)dense_dp * dense_dp + dense_dp + (size_t)waves * (16 * (dense_dp + 2) + 16)) * 8;
+    return b;
+}
+
+// threads of the one workgroup: enough for one half-step's lanes and one plan entry each across the batch; the dense
+// variant keeps one LDS tile per wave, so it takes the largest power-of-two wave count that still fits
+static int small_threads(const emx_ctx* c, int G, int minsplits, bool dense) {
+    const int64_t nsmax = (c->N + minsplits - 1) / minsplits;
+    const int64_t want = std::max<int64_t>(dense ? ((nsmax + 15) / 16) * 64 : nsmax * G, (int64_t)small_batch(c->N) * c->N);
+    int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, ((want + 63) / 64) * 64));
+    if (dense) {
+        int waves = threads / 64;
+        while (waves > 1 && small_lds_bytes(c->N, c->D, c->Dp, waves) > 150 * 1024) waves = (waves + 1) / 2;
+        threads = waves * 64;
+    }
+    return threads;
 }
 
 static bool small_eligible(const emx_ctx* c) {
@@ -1674,17 +1704,20 @@ static bool small_eligible(const emx_ctx* c) {
         if (mv.kind == EMX_MOVE_DE && c->N - (c->N + mv.nsplits - 1) / mv.nsplits < 2) return false;
     }
     if (c->target != EMX_TARGET_ISO_GAUSS && c->target != EMX_TARGET_DIAG_GAUSS && c->target != EMX_TARGET_ROSENBROCK &&
-        c->target != EMX_TARGET_BOX)
+        c->target != EMX_TARGET_BOX && c->target != EMX_TARGET_DENSE_GAUSS)
         return false;
     if (c->world != 1 || c->comm || c->sendbuf || c->prof_max > 0 || c->tune_ablate || c->cur.active) return false;
     if (c->N > 4096 || c->D > 256) return false;
+    if (c->target == EMX_TARGET_DENSE_GAUSS)     // one CU's matrix pipe: worth it only while the contraction is small
+        return c->N * (int64_t)c->Dp * c->Dp <= 65536 && small_lds_bytes(c->N, c->D, c->Dp, 1) <= 150 * 1024;
     return small_lds_bytes(c->N, c->D) <= 150 * 1024;
 }
 
 // `nsteps` full steps starting at step index i0 of the current emx_run call
 static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, int32_t store) {
     const int nm = (int)c->moves.size();
-    const Shape sh = pick_shape(c->D, c->D);
+    const bool dense = c->target == EMX_TARGET_DENSE_GAUSS;
+    const Shape sh = pick_shape(c->D, dense ? c->Dp : c->D);
     SmallRunArgs a{};
     int maxsplits = 2, minsplits = 64;
     for (int m = 0; m < nm; ++m) {
@@ -1760,18 +1793,24 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
         a.plans = bp.dev;
         a.step_moves = (const int32_t*)(bp.dev + plan_bytes);
     }
-    const int64_t nsmax = (c->N + minsplits - 1) / minsplits;
-    // enough threads for one half-step's lanes AND for one plan entry each across the batch
-    const int64_t want = std::max<int64_t>(nsmax * sh.G, (int64_t)a.batch * c->N);
-    int threads = (int)std::min<int64_t>(1024, std::max<int64_t>(64, ((want + 63) / 64) * 64));
-    const size_t lds = small_lds_bytes(c->N, c->D);
+    const int threads = small_threads(c, sh.G, minsplits, dense);
+    const size_t lds = dense ? small_lds_bytes(c->N, c->D, c->Dp, threads / 64) : small_lds_bytes(c->N, c->D);
     hipError_t e = hipErrorInvalidValue;
-    const int movesel = nm == 1 ? (int)c->moves[0].kind : SMALL_ANY_MOVE;
+    const int movesel = (nm == 1 && (!dense || c->moves[0].kind == EMX_MOVE_STRETCH)) ? (int)c->moves[0].kind : SMALL_ANY_MOVE;
+    if (dense) {
+        const int dpb = c->Dp / 16;
+#define EMX_DCASE(b, v) \
+    if (dpb == b && sh.V == v) e = launch_small_dense<b, v>(movesel, threads, lds, c->stream, a);
+        EMX_DCASE(1, 1) EMX_DCASE(2, 1) EMX_DCASE(3, 1) EMX_DCASE(4, 1) EMX_DCASE(5, 1) EMX_DCASE(6, 1) EMX_DCASE(7, 1)
+        EMX_DCASE(1, 2) EMX_DCASE(2, 2) EMX_DCASE(3, 2) EMX_DCASE(4, 2) EMX_DCASE(5, 2) EMX_DCASE(6, 2) EMX_DCASE(7, 2)
+#undef EMX_DCASE
+    } else {
 #define EMX_CASE(g, v, ch) \
     if (sh.G == g && sh.V == v && sh.CH == ch) e = launch_small<g, v, ch>(movesel, threads, lds, c->stream, a);
-    EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4) EMX_CASE(16, 1, 4) EMX_CASE(32, 1, 4) EMX_CASE(64, 1, 4)
-    EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
+        EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4) EMX_CASE(16, 1, 4) EMX_CASE(32, 1, 4) EMX_CASE(64, 1, 4)
+        EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
 #undef EMX_CASE
+    }
     if (e != hipSuccess) FAIL(c, -2, "k_small_run launch failed (G=%d V=%d CH=%d ndim=%d): %s", sh.G, sh.V, sh.CH, c->D, hipGetErrorString(e));
     int64_t nstored = 0;
     if (store)

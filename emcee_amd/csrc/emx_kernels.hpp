@@ -1019,17 +1019,18 @@ __device__ __forceinline__ void small_plan_entry(const NativeArgs& na, int N, in
 }
 
 // one group's (walker's) update inside a half-step: the general kernel's element-wise-target branch
+// the proposal of one walker from the LDS-resident ensemble (+ the non-finite check of ensemble.py:476-479)
 template <int G, int V, int CH, int MOVE>
-__device__ __forceinline__ void small_update(const SmallRunArgs& A, double* Xs, double* lps, uint8_t* accs, bool live, int i,
-                                             int j0, int j1, int j2, double s0, double fac, double logu, double gammas,
-                                             const Row<G, V, CH>& mu, const Row<G, V, CH>& iv, int D, int gl, int sub, int lane) {
+__device__ __forceinline__ void small_propose(const SmallRunArgs& A, const double* Xs, bool live, int i, int j0, int j1, int j2,
+                                              double s0, double fac, double gammas, int D, int gl, int sub, Row<G, V, CH>& q,
+                                              double& factor, bool& badq) {
     constexpr int NR = rows_per_pass<MOVE>();
-    Row<G, V, CH> xi, xa, xb, xc, q;
+    Row<G, V, CH> xi, xa, xb, xc;
     load_row<G, V, CH>(xi, Xs + (size_t)i * D, D, gl);
     load_row<G, V, CH>(xa, Xs + (size_t)j0 * D, D, gl);
     if constexpr (NR >= 3) load_row<G, V, CH>(xb, Xs + (size_t)j1 * D, D, gl);
     if constexpr (NR >= 4) load_row<G, V, CH>(xc, Xs + (size_t)j2 * D, D, gl);
-    double factor = fac;
+    factor = fac;
     make_proposal<G, V, CH, MOVE>(xi, xa, NR >= 3 ? xb : xa, NR >= 4 ? xc : xa, (MOVE == MOVE_SNOOKER) ? 0.0 : s0, gammas, D,
                                   gl, q, factor);
     bool bl = false;
@@ -1037,8 +1038,18 @@ __device__ __forceinline__ void small_update(const SmallRunArgs& A, double* Xs, 
     for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
-    const bool badq = group_any<G>(bl, sub);
+    badq = group_any<G>(bl, sub);
     if (live && badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
+}
+
+template <int G, int V, int CH, int MOVE>
+__device__ __forceinline__ void small_update(const SmallRunArgs& A, double* Xs, double* lps, uint8_t* accs, bool live, int i,
+                                             int j0, int j1, int j2, double s0, double fac, double logu, double gammas,
+                                             const Row<G, V, CH>& mu, const Row<G, V, CH>& iv, int D, int gl, int sub, int lane) {
+    Row<G, V, CH> q;
+    double factor;
+    bool badq;
+    small_propose<G, V, CH, MOVE>(A, Xs, live, i, j0, j1, j2, s0, fac, gammas, D, gl, sub, q, factor, badq);
     const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
     if (live && gl == 0 && (lp_new != lp_new)) raise_status(A.status, ST_NAN_LOGP);
     const double lp_old = lps[i];
@@ -1051,10 +1062,12 @@ __device__ __forceinline__ void small_update(const SmallRunArgs& A, double* Xs, 
     if (live && gl == 0) accs[i] = accept ? 1 : 0;
 }
 
-template <int G, int V, int CH, int MOVESEL, bool PLANNED>
+template <int G, int V, int CH, int MOVESEL, bool PLANNED, int DPB = 0>
 __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int WPW = 64 / G;
+    constexpr bool DENSE = DPB > 0;
+    constexpr int Dp = DENSE ? DPB * 16 : 16, KK = Dp / 4, RT = Dp + 2, PPT = 16 / WPW;
     const int N = A.N, D = A.D, T = blockDim.x, tid = threadIdx.x, B = A.batch;
     const int lane = tid & 63, wv = tid >> 6, nwave = T >> 6, sub = lane / G, gl = lane % G;
     double* Xs = smem;
@@ -1068,6 +1081,13 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
     int* p2s = p1s + (size_t)B * N;
     uint32_t* acnt = reinterpret_cast<uint32_t*>(p2s + (size_t)B * N);
     uint8_t* accs = reinterpret_cast<uint8_t*>(acnt + N);
+    // dense target: the Cholesky image (as in k_halfstep) and one 16-row tile per wave, 16-byte aligned behind the rest
+    double* Sfrag = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(accs + N) + 15) & ~(uintptr_t)15);
+    double* muS = Sfrag + (size_t)Dp * Dp;
+    double* tile = muS + Dp + (size_t)wv * (16 * RT + 16);
+    double* facS = tile + 16 * RT;
+    if constexpr (DENSE)
+        for (int e = tid; e < Dp * Dp + Dp; e += T) Sfrag[e] = A.tp1[e];
 
     for (int e = tid; e < N * D; e += T) Xs[e] = A.X[e];
     for (int e = tid; e < N; e += T) {
@@ -1149,6 +1169,95 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
             int pos0 = b * N;
             for (int split = 0; split < S; ++split) {
                 const int ns = (N - split + S - 1) / S;
+                if constexpr (DENSE) {
+                    // dense Gaussian target: a wave takes 16 slots at a time -- proposals into its LDS tile, the f64 MFMA
+                    // contraction and the decisions exactly as k_halfstep does them (same instructions, same order)
+                    for (int base = wv * 16; base < ns; base += nwave * 16) {       // wave-uniform
+                        const int nslot = min(16, ns - base);
+#pragma unroll
+                        for (int pp = 0; pp < PPT; ++pp) {
+                            const int trow = pp * WPW + sub;
+                            const bool live = trow < nslot;
+                            const int pos = pos0 + base + (live ? trow : 0);
+                            Row<G, V, CH> q;
+                            double factor = 0.0;
+                            bool badq = false;
+                            const int i = orders[pos], j0 = p0s[pos], j1 = p1s[pos], j2 = p2s[pos];
+                            if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
+                                small_propose<G, V, CH, MOVE_STRETCH>(A, Xs, live, i, j0, j1, j2, s0s[pos], facs[pos], gam, D, gl, sub, q, factor, badq);
+                            else if (MOVESEL == MOVE_DE || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_DE))
+                                small_propose<G, V, CH, MOVE_DE>(A, Xs, live, i, j0, j1, j2, s0s[pos], facs[pos], gam, D, gl, sub, q, factor, badq);
+                            else
+                                small_propose<G, V, CH, MOVE_SNOOKER>(A, Xs, live, i, j0, j1, j2, s0s[pos], facs[pos], gam, D, gl, sub, q, factor, badq);
+#pragma unroll
+                            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                                for (int v = 0; v < V; ++v) {
+                                    const int d = (c * G + gl) * V + v;
+                                    if (d < Dp) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] : muS[d];     // dead row: zero residual
+                                }
+                            if (gl == 0) facS[trow] = badq ? -__builtin_inf() : factor;
+                        }
+                        const int myrow = (lane >> 4) + 4 * (lane & 3);
+                        const bool mine = (lane & 15) < 4 && myrow < nslot;
+                        const int mypos = pos0 + base + (myrow < nslot ? myrow : 0);
+                        const int my_i = orders[mypos];
+                        const double my_lpo = lps[my_i], my_logu = logus[mypos];
+                        EMX_WAVE_SYNC();
+                        double my_qf;
+                        {
+                            const int am = lane & 15, ak = lane >> 4;
+                            typedef double d4 __attribute__((ext_vector_type(4)));
+                            double afr[KK];
+#pragma unroll
+                            for (int kk = 0; kk < KK; ++kk) afr[kk] = tile[am * RT + 4 * kk + ak] - muS[4 * kk + ak];
+                            double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int nb = 0; nb < DPB; ++nb) {
+                                d4 accv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                                for (int kk = 4 * nb; kk < KK; ++kk)
+                                    accv = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], Sfrag[(nb * KK + kk) * 64 + lane], accv, 0, 0, 0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
+                            }
+#if EMX_OPT_RED4
+                            my_qf = row16_sum4(part[0], part[1], part[2], part[3], lane);
+#else
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) part[r] = group_sum<16>(part[r]);
+                            my_qf = part[0];
+#pragma unroll
+                            for (int r = 1; r < 4; ++r) my_qf = (am == r) ? part[r] : my_qf;
+#endif
+                        }
+                        bool acc = false;
+                        if (mine) {
+                            const double lpn = -0.5 * my_qf;
+                            if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);
+                            const double lnpdiff = facS[myrow] + lpn - my_lpo;
+                            acc = lnpdiff > my_logu;
+                            accs[my_i] = acc ? 1 : 0;
+                            if (acc) lps[my_i] = lpn;
+                        }
+                        const unsigned long long am64 = __ballot(acc);       // bit (row & 3) * 16 + (row >> 2) <-> tile row
+#pragma unroll
+                        for (int pp = 0; pp < PPT; ++pp) {
+                            const int row = pp * WPW + sub;
+                            if (row < nslot && ((am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull)) {
+                                const int wrow = orders[pos0 + base + row];
+#pragma unroll
+                                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                                    for (int v = 0; v < V; ++v) {
+                                        const int d = (c * G + gl) * V + v;
+                                        if (d < D) Xs[(size_t)wrow * D + d] = tile[row * RT + d];
+                                    }
+                            }
+                        }
+                        EMX_WAVE_SYNC();
+                    }
+                } else
                 for (int base = wv * WPW; base < ns; base += nwave * WPW) {      // wave-uniform
                     const int t = base + sub;
                     const bool live = t < ns;

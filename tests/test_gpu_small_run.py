@@ -151,6 +151,40 @@ def test_small_run_move_schedules_equal_general_path(N, D, target, kinds, weight
     assert outs[0][2].sum() > 0
 
 
+@pytest.mark.parametrize("rng", ["philox", "mt"])
+@pytest.mark.parametrize("N,D,kinds", [
+    (32, 5, ["stretch"]), (16, 64, ["stretch"]), (64, 16, ["stretch"]), (50, 17, ["stretch"]), (60, 33, ["stretch"]),
+    (5, 100, ["stretch"]), (64, 8, ["de"]), (128, 8, ["de", "snooker"]), (24, 48, ["stretch", "de"]), (4, 112, ["stretch"]),
+    (128, 64, ["stretch"]),       # too much contraction for one CU: both runs take the general path
+])
+def test_small_run_dense_target_equals_general_path(N, D, kinds, rng):
+    """dense Gaussian target inside the one-workgroup kernel: the tile / MFMA / reduction sequence is k_halfstep's, so the
+    log-probs, and with them every decision, are the same bits"""
+    mvs = [so.MoveSpec(k, live_dangerously=True, sigma=0.05, gammas=1.4) for k in kinds]
+    cases.DIGEST_CASES["_sm"] = dict(N=N, D=D, target="dense", moves=mvs, weights=None, nsteps=1, seed=N + D)
+    spec = cases.build("_sm")
+    del cases.DIGEST_CASES["_sm"]
+    outs = []
+    for small in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        if rng == "mt":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(np.random.RandomState(5).get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(31, 0)
+        ens.set_tuning("small_kernel", small)
+        ens.chain_config(20)
+        ens.run(14, 1, True)
+        ens.run(2, 3, True)
+        assert ens.status() == 0
+        outs.append((ens.chain_read(0, 0, 16), ens.chain_read(1, 0, 16), ens.accepted_counts(), ens.get_state()[0], ens.get_state()[1]))
+        ens.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][2].sum() > 0
+
+
 def test_small_run_chunks_and_resume():
     """more steps than one launch takes (4096), and a second emx_run call continuing the chain"""
     spec = build(32, 5, "iso", 2, 2.0, seed=3)

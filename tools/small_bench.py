@@ -20,6 +20,12 @@ def run(N, D, target, small, steps):
         iv = 1.0 / (0.1 + rs.rand(D))
         ens.set_target(_lib.TARGET_DIAG, np.zeros(D), iv)
         p0 = rs.randn(N, D) / np.sqrt(iv)
+    elif target == "dense":
+        A = rs.randn(D, D)
+        cov = A @ A.T / D + 0.1 * np.eye(D)
+        icov = np.linalg.inv(cov)
+        ens.set_target(_lib.TARGET_DENSE, np.zeros(D), 0.5 * (icov + icov.T))
+        p0 = rs.randn(N, D) @ np.linalg.cholesky(cov).T
     else:
         ens.set_target(_lib.TARGET_ROSENBROCK, scale=20.0)
         p0 = 1 + 0.1 * rs.randn(N, D)
@@ -41,7 +47,7 @@ def run(N, D, target, small, steps):
 
 if __name__ == "__main__":
     out = []
-    for N, D, target in [(32, 5, "iso"), (64, 8, "rosen"), (128, 16, "diag"), (256, 32, "iso"), (1024, 8, "iso"),
+    for N, D, target in [(32, 5, "iso"), (32, 5, "dense"), (128, 64, "dense"), (512, 16, "dense"), (64, 8, "rosen"), (128, 16, "diag"), (256, 32, "iso"), (1024, 8, "iso"),
                          (1024, 16, "rosen"), (4096, 2, "iso"), (2048, 4, "diag")]:
         steps = 40000 if N <= 256 else 8000
         fast, slow = run(N, D, target, 1, steps), run(N, D, target, 0, steps)
