@@ -4,12 +4,13 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "emx.hip")
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip")]     # two translation units, built in parallel
+SRC = SRCS[0]
 LIB = os.path.join(HERE, "libemx.so")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_rng.hpp", "mt19937_legacy.hpp")] + [
+DEPS = SRCS + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_rng.hpp", "mt19937_legacy.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "emx.h")]
 # -ffp-contract=off: the proposal arithmetic must round like NumPy's separate multiply/subtract.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-fPIC"]
 
 
 HASHFILE = LIB + ".srchash"
@@ -39,12 +40,27 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + [SRC, "-o", LIB]
+    objs, procs = [], []
+    for src in SRCS:
+        obj = os.path.join(HERE, os.path.basename(src) + ".o")
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        _, err = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + err[-4000:])
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl"]
     if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(link))
+    r = subprocess.run(link, capture_output=True, text=True)
+    for obj in objs:
+        if os.path.exists(obj):
+            os.remove(obj)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+        raise RuntimeError("hipcc link failed:\n" + r.stderr[-4000:])
     with open(HASHFILE, "w") as f:
         f.write(_source_hash() + "\n")
     return LIB

@@ -438,53 +438,6 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
     return hipGetLastError();
 }
 
-template <int G, int V, int CH, int MOVESEL, bool PLANNED, int DPB = 0>
-hipError_t launch_small_move(int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
-    auto kern = k_small_run<G, V, CH, MOVESEL, PLANNED, DPB>;
-    static size_t lds_granted[MAX_DEVICES] = {};
-    int dev = 0;
-    if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_granted[dev] = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, st, a);
-    return hipGetLastError();
-}
-
-template <int G, int V, int CH>
-hipError_t launch_small(int move, int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
-    const bool planned = a.plans != nullptr;
-    switch (move) {
-        case MOVE_STRETCH:
-            return planned ? launch_small_move<G, V, CH, MOVE_STRETCH, true>(threads, lds, st, a)
-                           : launch_small_move<G, V, CH, MOVE_STRETCH, false>(threads, lds, st, a);
-        case MOVE_DE:
-            return planned ? launch_small_move<G, V, CH, MOVE_DE, true>(threads, lds, st, a)
-                           : launch_small_move<G, V, CH, MOVE_DE, false>(threads, lds, st, a);
-        case MOVE_SNOOKER:
-            return planned ? launch_small_move<G, V, CH, MOVE_SNOOKER, true>(threads, lds, st, a)
-                           : launch_small_move<G, V, CH, MOVE_SNOOKER, false>(threads, lds, st, a);
-        case SMALL_ANY_MOVE:
-            return planned ? launch_small_move<G, V, CH, SMALL_ANY_MOVE, true>(threads, lds, st, a)
-                           : launch_small_move<G, V, CH, SMALL_ANY_MOVE, false>(threads, lds, st, a);
-    }
-    return hipErrorInvalidValue;
-}
-
-// dense target in the one-workgroup kernel: a single stretch move, or any schedule (the kernel then carries all three)
-template <int DPB, int V>
-hipError_t launch_small_dense(int move, int threads, size_t lds, hipStream_t st, const SmallRunArgs& a) {
-    constexpr int cols = DPB * 16 / V;
-    constexpr int G = shape_g(cols), CH = shape_ch(cols);
-    const bool planned = a.plans != nullptr;
-    if (move == MOVE_STRETCH)
-        return planned ? launch_small_move<G, V, CH, MOVE_STRETCH, true, DPB>(threads, lds, st, a)
-                       : launch_small_move<G, V, CH, MOVE_STRETCH, false, DPB>(threads, lds, st, a);
-    return planned ? launch_small_move<G, V, CH, SMALL_ANY_MOVE, true, DPB>(threads, lds, st, a)
-                   : launch_small_move<G, V, CH, SMALL_ANY_MOVE, false, DPB>(threads, lds, st, a);
-}
-
 template <int MOVE>
 hipError_t launch_valu(const Shape& sh, dim3 grid, dim3 block, hipStream_t st, const HalfStepArgs& a) {
 #define EMX_CASE(g, v, c) \
@@ -1670,6 +1623,10 @@ static emx_ctx::GraphSlot* graph_ready(emx_ctx* c, int store) {
 
 static int scatter_gathered(emx_ctx* c, int32_t split, int64_t block_rows);
 
+// emx_small.hip: the k_small_run instantiations live in their own translation unit (compiled in parallel with this one)
+hipError_t emx_small_dispatch(int G, int V, int CH, int dpb, int movesel, int threads, size_t lds, hipStream_t st,
+                              const emx::SmallRunArgs& a);
+
 // ---- small ensembles: whole runs inside one workgroup (k_small_run) ------------------------
 // steps whose plans one pass evaluates: as many as give every thread of the workgroup an entry
 static int small_batch(int64_t N) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / N)); }
@@ -1797,20 +1754,7 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
     const size_t lds = dense ? small_lds_bytes(c->N, c->D, c->Dp, threads / 64) : small_lds_bytes(c->N, c->D);
     hipError_t e = hipErrorInvalidValue;
     const int movesel = (nm == 1 && (!dense || c->moves[0].kind == EMX_MOVE_STRETCH)) ? (int)c->moves[0].kind : SMALL_ANY_MOVE;
-    if (dense) {
-        const int dpb = c->Dp / 16;
-#define EMX_DCASE(b, v) \
-    if (dpb == b && sh.V == v) e = launch_small_dense<b, v>(movesel, threads, lds, c->stream, a);
-        EMX_DCASE(1, 1) EMX_DCASE(2, 1) EMX_DCASE(3, 1) EMX_DCASE(4, 1) EMX_DCASE(5, 1) EMX_DCASE(6, 1) EMX_DCASE(7, 1)
-        EMX_DCASE(1, 2) EMX_DCASE(2, 2) EMX_DCASE(3, 2) EMX_DCASE(4, 2) EMX_DCASE(5, 2) EMX_DCASE(6, 2) EMX_DCASE(7, 2)
-#undef EMX_DCASE
-    } else {
-#define EMX_CASE(g, v, ch) \
-    if (sh.G == g && sh.V == v && sh.CH == ch) e = launch_small<g, v, ch>(movesel, threads, lds, c->stream, a);
-        EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4) EMX_CASE(16, 1, 4) EMX_CASE(32, 1, 4) EMX_CASE(64, 1, 4)
-        EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
-#undef EMX_CASE
-    }
+    e = emx_small_dispatch(sh.G, sh.V, sh.CH, dense ? c->Dp / 16 : 0, movesel, threads, lds, c->stream, a);
     if (e != hipSuccess) FAIL(c, -2, "k_small_run launch failed (G=%d V=%d CH=%d ndim=%d): %s", sh.G, sh.V, sh.CH, c->D, hipGetErrorString(e));
     int64_t nstored = 0;
     if (store)

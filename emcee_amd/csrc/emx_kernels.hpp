@@ -570,7 +570,7 @@ __device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row
 }
 
 template <int G, int V, int CH, int MOVE, int DPB>
-__global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
+static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     static_assert(G >= 4 && G <= 64 && (64 % G) == 0, "G lanes per walker");
     constexpr bool DENSE = DPB > 0;
     constexpr int WPW = 64 / G;       // walkers per pass (<= 16)
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void small_update(const SmallRunArgs& A, double* Xs, 
 }
 
 template <int G, int V, int CH, int MOVESEL, bool PLANNED, int DPB = 0>
-__global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
+static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int WPW = 64 / G;
     constexpr bool DENSE = DPB > 0;
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A) {
 
 // logs of a host-supplied plan (exact / inputs modes), full width: logu = ln(uacc),
 // fac = (D-1) ln zz for the stretch move (stretch.py:31), 0 otherwise
-__global__ void k_plan_logs(int N, int D, int stretch, const double* __restrict__ s0, const double* __restrict__ uacc,
+static __global__ void k_plan_logs(int N, int D, int stretch, const double* __restrict__ s0, const double* __restrict__ uacc,
                             double* __restrict__ logu, double* __restrict__ fac) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= N) return;
@@ -1327,7 +1327,7 @@ struct AcceptArgs {
     int32_t N, D, S, split, pos0, ns, move;
 };
 
-__global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
+static __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= A.ns) return;
@@ -1365,7 +1365,7 @@ struct GaussDispArgs {
 
 // native draws: disp[w][d] = (f * scale_d) * n(w, d).  One thread per (walker, coordinate pair) in the
 // vector mode; in the one-coordinate modes one thread per walker writes just the coordinate that moves.
-__global__ __launch_bounds__(256) void k_gauss_disp(const GaussDispArgs A) {
+static __global__ __launch_bounds__(256) void k_gauss_disp(const GaussDispArgs A) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int npair = (A.D + 1) / 2;
     if (A.mode == GAUSS_VECTOR) {
@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(256) void k_gauss_disp(const GaussDispArgs A) {
 
 // host-supplied normals (exact / inputs modes): in place, disp = (f * scale_d) * n -- gaussian.py:87's
 // left-to-right product
-__global__ __launch_bounds__(256) void k_gauss_scale(const GaussDispArgs A) {
+static __global__ __launch_bounds__(256) void k_gauss_scale(const GaussDispArgs A) {
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= (long long)A.N * A.D) return;
     const int d = (int)(tid % A.D);
@@ -1423,7 +1423,7 @@ struct NativeBatchArgs {
     const StepDesc* desc;   // graph replay: per-step NativeArgs from device memory instead of nat[]
 };
 
-__global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs B) {
+static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs B) {
     const int b = blockIdx.y;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= B.N) return;
@@ -1456,14 +1456,14 @@ __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs
     B.fac[b][pos] = (mv == MOVE_STRETCH) ? ((double)B.D - 1.0) * log(z) : 0.0;
 }
 
-__global__ void k_graph_set(GraphCounters* ctr, unsigned long long step_base, long long stored_base) {
+static __global__ void k_graph_set(GraphCounters* ctr, unsigned long long step_base, long long stored_base) {
     ctr->step_base = step_base;
     ctr->stored_base = stored_base;
 }
 
 // First node of the captured 8-step graph: derive this replay's per-step descriptors from the device
 // counters and advance them (one block; every lane reads the counters before lane 0 updates them).
-__global__ void k_graph_advance(GraphCounters* ctr, StepDesc* desc, unsigned long long seed, int N, int nb, int store) {
+static __global__ void k_graph_advance(GraphCounters* ctr, StepDesc* desc, unsigned long long seed, int N, int nb, int store) {
     const int b = threadIdx.x;
     const unsigned long long base = ctr->step_base;
     const long long sb = ctr->stored_base;
@@ -1494,7 +1494,7 @@ struct ScatterArgs {
     int32_t N, D, S, split, pos0, t_lo, t_hi;
 };
 
-__global__ __launch_bounds__(256) void k_scatter_rows(const ScatterArgs A) {
+static __global__ __launch_bounds__(256) void k_scatter_rows(const ScatterArgs A) {
     const int lane = threadIdx.x & 63;
     const int t = A.t_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= A.t_hi) return;
@@ -1542,7 +1542,7 @@ struct PullPlanArgs {
     int32_t N, G, rank, ns, npart, cap;
 };
 
-__global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) {
+static __global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool live = t < A.ns;
@@ -1610,7 +1610,7 @@ struct PullRowsArgs {
 };
 
 // 16 lanes per record
-__global__ __launch_bounds__(256) void k_pull_pack(const PullRowsArgs A) {
+static __global__ __launch_bounds__(256) void k_pull_pack(const PullRowsArgs A) {
     const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     if (r >= A.G * A.cap) return;
@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(256) void k_pull_pack(const PullRowsArgs A) {
     for (int d = l; d < A.D; d += 16) dst[1 + d] = src[d];
 }
 
-__global__ __launch_bounds__(256) void k_pull_scatter(const PullRowsArgs A) {
+static __global__ __launch_bounds__(256) void k_pull_scatter(const PullRowsArgs A) {
     const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     if (r >= A.G * A.cap) return;
@@ -1650,7 +1650,7 @@ struct BlockArgs {
     int32_t N, D, G, rank, bmax;
 };
 
-__global__ __launch_bounds__(256) void k_block_pack(const BlockArgs A) {
+static __global__ __launch_bounds__(256) void k_block_pack(const BlockArgs A) {
     const int e = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     const int lo = (int)((long long)A.N * A.rank / A.G), hi = (int)((long long)A.N * (A.rank + 1) / A.G);
@@ -1665,7 +1665,7 @@ __global__ __launch_bounds__(256) void k_block_pack(const BlockArgs A) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_block_unpack(const BlockArgs A) {
+static __global__ __launch_bounds__(256) void k_block_unpack(const BlockArgs A) {
     const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     if (r >= A.G * A.bmax) return;

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../emcee_amd/csrc" || exit 1
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -fPIC -shared $flags emx.hip -o ../libemx_$name.so &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -fPIC -shared $flags emx.hip emx_small.hip -o ../libemx_$name.so &
 done
 wait
 ls -la ../libemx_*.so
