@@ -216,3 +216,41 @@ def test_small_run_is_faster_and_not_used_when_it_cannot_be():
     big = build(8192, 4, "iso", 2, 2.0, seed=5)
     a, b = run(big, 1, 3, 1, True), run(big, 0, 3, 1, True)
     assert np.array_equal(a["chain"], b["chain"])
+
+
+def _random_small_configs():
+    rs = np.random.RandomState(4321)
+    out = []
+    for _ in range(40):
+        kind = ["stretch", "de", "snooker"][rs.randint(3)]
+        nsplits = 4 if kind == "snooker" else int(rs.randint(2, 6))
+        D = int(rs.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 32, 33, 40]))
+        N = int(rs.randint(max(2 * nsplits, 4), 70))
+        target = ["iso", "diag", "rosenbrock", "dense"][rs.randint(4)]
+        if target == "rosenbrock" and D < 2:
+            target = "iso"
+        out.append((kind, N, D, target, nsplits, ["mt", "philox"][rs.randint(2)], int(rs.randint(1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("kind,N,D,target,nsplits,rng,thin_by", _random_small_configs())
+def test_small_run_random_configs_equal_general_path(kind, N, D, target, nsplits, rng, thin_by):
+    spec = build(N, D, target, nsplits, 2.0, seed=N * 41 + D, kind=kind)
+    outs = []
+    for small in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        if rng == "mt":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(np.random.RandomState(N).get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(N * 7 + D, 2)
+        ens.set_tuning("small_kernel", small)
+        ens.chain_config(12)
+        ens.run(7, thin_by, True)
+        ens.run(5, 1, True)
+        assert ens.status() == 0
+        outs.append((ens.chain_read(0, 0, 12), ens.chain_read(1, 0, 12), ens.accepted_counts(), ens.accepted_mask()))
+        ens.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
