@@ -274,3 +274,29 @@ def test_graph_replay_equals_plain_launches(name, store):
         ens.close()
     for a, b in zip(*outs):
         assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_dense_target_keeps_precision_next_to_a_large_mean():
+    """(q - mu) is formed before the contraction, so walkers that sit 1e-4 away from a mean of 2.45e6 (Julian dates)
+    keep full relative precision in their log-prob -- the reason the faster `Q L - mu^T L` form was not adopted
+    (profiles/r01/ab_variants.txt)"""
+    from emcee_amd.device import DeviceEnsemble
+    rs = np.random.RandomState(8)
+    N, D = 64, 6
+    mu = 2.45e6 + rs.rand(D)
+    A = rs.randn(D, D)
+    cov = (A @ A.T / D + 0.1 * np.eye(D)) * 1e-8
+    icov = np.linalg.inv(cov)
+    icov = 0.5 * (icov + icov.T)
+    x = mu + rs.randn(N, D) @ np.linalg.cholesky(cov).T
+    ens = DeviceEnsemble(N, D)
+    ens.set_target(_lib.TARGET_DENSE, mu, icov)
+    got = ens.eval_log_prob(x)
+    ens.close()
+    r = (x.astype(np.longdouble) - mu.astype(np.longdouble))
+    want = np.asarray(-0.5 * np.einsum("ij,jk,ik->i", r, icov.astype(np.longdouble), r), dtype=np.float64)
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    # the folded form would be off by ~|mu| / spread * eps ~ 1e-6 here
+    L = np.linalg.cholesky(icov)
+    folded = -0.5 * np.sum((x @ L - mu @ L) ** 2, axis=1)
+    assert np.max(np.abs(folded - want) / np.abs(want)) > 100 * np.max(np.abs(got - want) / np.abs(want))
