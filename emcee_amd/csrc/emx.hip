@@ -11,6 +11,7 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/emx.h"
@@ -58,15 +59,21 @@ int draw_split_proposal(MT19937Legacy& mt, int64_t N, const emx_move_desc& mv, c
             return (int64_t)r < base ? order[r] : order[r + ns];
         };
         if (mv.kind == EMX_MOVE_STRETCH) {
-            for (int64_t t = 0; t < ns; ++t) {                              // stretch.py:30
-                const double u = mt.next_double();
-                const double tt = (mv.a - 1.0) * u + 1.0;
-                s0[base + t] = tt * tt / mv.a;
+            if constexpr (std::is_same<F64, double>::value) {
+                mt.fill_doubles(&s0[base], ns);                             // stretch.py:30
+                for (int64_t t = 0; t < ns; ++t) {
+                    const double tt = (mv.a - 1.0) * s0[base + t] + 1.0;
+                    s0[base + t] = tt * tt / mv.a;
+                }
+            } else {
+                for (int64_t t = 0; t < ns; ++t) {
+                    const double u = mt.next_double();
+                    const double tt = (mv.a - 1.0) * u + 1.0;
+                    s0[base + t] = tt * tt / mv.a;
+                }
             }
-            for (int64_t t = 0; t < ns; ++t) {                              // stretch.py:32
-                p0[base + t] = comp(mt.randint((uint64_t)nc));
-                p1[base + t] = p2[base + t] = order[base + t];
-            }
+            mt.fill_randint(ns, (uint64_t)nc, [&](int64_t t, uint64_t r) { p0[base + t] = comp(r); });   // stretch.py:32
+            for (int64_t t = 0; t < ns; ++t) p1[base + t] = p2[base + t] = order[base + t];
         } else if (mv.kind == EMX_MOVE_DE) {
             const uint64_t pop = (uint64_t)nc * (uint64_t)(nc - 1);
             for (int64_t t = 0; t < ns; ++t) {                              // de.py:49-50
@@ -128,7 +135,10 @@ int make_exact_plan(MT19937Legacy& mt, int64_t N, int32_t D, const emx_move_desc
     for (int split = 0; split < S; ++split) {
         const int64_t base = off[split], ns = off[split + 1] - off[split];
         if (draw_split_proposal(mt, N, mv, off, order, split, p0, p1, p2, s0) != 0) return -1;
-        for (int64_t t = 0; t < ns; ++t) uacc[base + t] = mt.next_double();  // red_blue.py:100
+        if constexpr (std::is_same<F64, double>::value)
+            mt.fill_doubles(&uacc[base], ns);                                 // red_blue.py:100
+        else
+            for (int64_t t = 0; t < ns; ++t) uacc[base + t] = mt.next_double();
     }
     (void)D;
     return 0;

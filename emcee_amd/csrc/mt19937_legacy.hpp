@@ -165,13 +165,87 @@ struct MT19937Legacy {
     }
 
     // RandomState.shuffle on a 1-d array of n items: for i = n-1..1: j = random_interval(i); swap.
+    // Same draws as the loop above them in NumPy, restructured: all i that share a rejection mask are served from
+    // the tempered block in one tight loop (no per-element call, no mask recomputation).
     template <typename T>
     inline void shuffle(T* x, int64_t n) {
-        for (int64_t i = n - 1; i > 0; --i) {
+        int64_t i = n - 1;
+        while (i > 0 && (uint64_t)i > 0xffffffffull) {           // 64-bit draws: astronomically large arrays only
             const int64_t j = (int64_t)random_interval((uint64_t)i);
             const T t = x[i];
             x[i] = x[j];
             x[j] = t;
+            --i;
+        }
+        while (i > 0) {
+            uint32_t mask = (uint32_t)i;
+            mask |= mask >> 1;
+            mask |= mask >> 2;
+            mask |= mask >> 4;
+            mask |= mask >> 8;
+            mask |= mask >> 16;
+            const int64_t lo = (int64_t)(mask >> 1);             // i in (lo, mask] share this mask
+            while (i > lo) {
+                if (pos == 624) twist();
+                int p = pos;
+                const uint32_t* w = out;
+                while (p < 624 && i > lo) {
+                    // branch-free: a rejected draw (one in four on average, unpredictable) swaps x[i] with itself
+                    const uint32_t v = w[p++] & mask;
+                    const bool ok = v <= (uint32_t)i;
+                    const int64_t j = ok ? (int64_t)v : i;
+                    const T t = x[i];
+                    x[i] = x[j];
+                    x[j] = t;
+                    i -= (int64_t)ok;
+                }
+                pos = p;
+            }
+        }
+    }
+
+    // n consecutive randint(0, bound) values (RandomState.randint(bound, size=n)), into `dst` through `map`
+    template <typename F>
+    inline void fill_randint(int64_t n, uint64_t bound, F&& put) {
+        const uint64_t rng = bound - 1;
+        if (rng == 0 || rng >= 0xffffffffull) {                  // no draw / whole words / 64-bit: the scalar routine
+            for (int64_t k = 0; k < n; ++k) put(k, randint(bound));
+            return;
+        }
+        uint32_t mask = (uint32_t)rng;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        int64_t k = 0;
+        while (k < n) {
+            if (pos == 624) twist();
+            int p = pos;
+            while (p < 624 && k < n) {
+                const uint32_t v = out[p++] & mask;
+                if (v <= (uint32_t)rng) put(k++, (uint64_t)v);
+            }
+            pos = p;
+        }
+    }
+
+    // n consecutive random_sample() values (RandomState.rand(n))
+    inline void fill_doubles(double* dst, int64_t n) {
+        int64_t k = 0;
+        while (k < n) {
+            if (pos >= 623) {                    // fewer than two words left in the block: the slow path handles the seam
+                dst[k++] = next_double();
+                continue;
+            }
+            int p = pos;
+            const int64_t take = (int64_t)((624 - p) / 2) < n - k ? (int64_t)((624 - p) / 2) : n - k;
+            for (int64_t e = 0; e < take; ++e, p += 2) {
+                const int32_t a = (int32_t)(out[p] >> 5), b = (int32_t)(out[p + 1] >> 6);
+                dst[k + e] = (a * 67108864.0 + b) / 9007199254740992.0;
+            }
+            pos = p;
+            k += take;
         }
     }
 
