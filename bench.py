@@ -80,7 +80,23 @@ def cpu_baseline(mu, cov, icov, budget_s=15.0):
                       % (nst, dt, cores, os.cpu_count())}
 
 
+# The contract is ONE JSON line on stdout.  Libraries in the process write there too (gloo announces its mesh, RCCL its
+# version ...), so file descriptor 1 is pointed at stderr for the whole run and the line goes to a private copy of the
+# original stdout.
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _REAL_STDOUT
+
+
 def main():
+    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
@@ -281,7 +297,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(mu, cov, icov)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        out = _claim_stdout()
+        out.write(json.dumps(line) + "\n")
+        out.flush()
 
     def summary(r):
         return {"ms_per_step": r["wall"] * 1e3 / K, "value": n * K / r["wall"], "comm": r["comm"], "device_status": r["status"],
