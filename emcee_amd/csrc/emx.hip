@@ -1667,6 +1667,10 @@ static bool small_eligible(const emx_ctx* c) {
     if (!c->tune_small || (c->rng_mode != EMX_RNG_PHILOX && c->rng_mode != EMX_RNG_MT19937)) return false;
     if (c->moves.empty() || (int)c->moves.size() > SMALL_MAX_MOVES) return false;
     for (const auto& mv : c->moves) {
+        if (mv.kind == EMX_MOVE_GAUSS) {
+            if (c->rng_mode != EMX_RNG_PHILOX) return false;      // exact mode: N x D host normals per step, general path
+            continue;
+        }
         if (mv.kind != EMX_MOVE_STRETCH && mv.kind != EMX_MOVE_DE && mv.kind != EMX_MOVE_SNOOKER) return false;
         if (mv.kind == EMX_MOVE_DE && c->N - (c->N + mv.nsplits - 1) / mv.nsplits < 2) return false;
     }
@@ -1683,10 +1687,12 @@ static bool small_eligible(const emx_ctx* c) {
 // `nsteps` full steps starting at step index i0 of the current emx_run call
 static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, int32_t store) {
     const int nm = (int)c->moves.size();
+    emx_ctx::BulkPlans* gauss_bulk = nullptr;
     const bool dense = c->target == EMX_TARGET_DENSE_GAUSS;
     const Shape sh = pick_shape(c->D, dense ? c->Dp : c->D);
     SmallRunArgs a{};
     int maxsplits = 2, minsplits = 64;
+    bool any_gauss = false;
     for (int m = 0; m < nm; ++m) {
         const emx_move_desc& mv = c->moves[m];
         a.kind[m] = mv.kind;
@@ -1696,6 +1702,10 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
         a.g0[m] = mv.g0;
         a.gammas[m] = mv.gammas;
         a.cdf[m] = c->cdf[m];
+        a.gmode[m] = mv.reserved;
+        a.gsigma[m] = mv.sigma;
+        a.gscale[m] = m < (int)c->mscale.size() ? c->mscale[m] : nullptr;
+        any_gauss = any_gauss || mv.kind == EMX_MOVE_GAUSS;
         maxsplits = std::max(maxsplits, (int)mv.nsplits);
         minsplits = std::min(minsplits, (int)mv.nsplits);
     }
@@ -1760,10 +1770,55 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
         a.plans = bp.dev;
         a.step_moves = (const int32_t*)(bp.dev + plan_bytes);
     }
+    if (any_gauss) {
+        // per step of the launch: the step-size factor (one Philox draw, as gauss_native_disp) and the sequential mode's
+        // column; both follow from the step number, so the host lists them and advances the move's cursor
+        auto& bp = c->bulk[c->bulk_pos];
+        c->bulk_pos ^= 1;
+        const size_t need = (size_t)nsteps * 16;
+        if (bp.busy) {
+            HIPOK(c, hipEventSynchronize(bp.done));
+            bp.busy = false;
+        }
+        if (bp.bytes < need) {
+            if (bp.host) hipHostFree(bp.host);
+            if (bp.dev) hipFree(bp.dev);
+            bp.host = bp.dev = nullptr;
+            bp.bytes = 0;
+            HIPOK(c, hipHostMalloc((void**)&bp.host, need, hipHostMallocDefault));
+            HIPOK(c, hipMalloc((void**)&bp.dev, need));
+            bp.bytes = need;
+            if (!bp.done) HIPOK(c, hipEventCreateWithFlags(&bp.done, hipEventDisableTiming));
+        }
+        double* facs = (double*)bp.host;
+        int32_t* cols = (int32_t*)(bp.host + (size_t)nsteps * 8);
+        for (int64_t s2 = 0; s2 < nsteps; ++s2) {
+            const uint64_t step = c->ph_step + (uint64_t)s2;
+            const int mi = nm == 1 ? 0 : philox_move_choice(c->ph_seed, step, c->cdf.data(), nm);
+            emx_move_desc& mv = c->moves[mi];
+            facs[s2] = 1.0;
+            cols[s2] = 0;
+            if (mv.kind != EMX_MOVE_GAUSS) continue;
+            if (mv.a != 0.0) {
+                const Philox4 r = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), 0x46414354u /*'FACT'*/, 0,
+                                                (uint32_t)c->ph_seed, (uint32_t)(c->ph_seed >> 32));
+                facs[s2] = std::exp(-mv.g0 + 2.0 * mv.g0 * u53(r.v[0], r.v[1]));
+            }
+            if (mv.reserved == EMX_GAUSS_SEQUENTIAL) {
+                cols[s2] = (int32_t)((int64_t)mv.gammas % c->D);
+                mv.gammas = (double)(((int64_t)mv.gammas + 1) % c->D);
+            }
+        }
+        HIPOK(c, hipMemcpyAsync(bp.dev, bp.host, need, hipMemcpyHostToDevice, c->stream));
+        a.step_fac = (const double*)bp.dev;
+        a.step_col = (const int32_t*)(bp.dev + (size_t)nsteps * 8);
+        gauss_bulk = &bp;
+    }
     const int threads = small_threads(c, sh.G, minsplits, dense);
     const size_t lds = dense ? small_lds_bytes(c->N, c->D, c->Dp, threads / 64) : small_lds_bytes(c->N, c->D);
     hipError_t e = hipErrorInvalidValue;
     const int movesel = (nm == 1 && (!dense || c->moves[0].kind == EMX_MOVE_STRETCH)) ? (int)c->moves[0].kind : SMALL_ANY_MOVE;
+    // (MOVE_GAUSS == 3 is a valid single selector for the element-wise targets; the dense variant carries it under ANY)
     e = emx_small_dispatch(sh.G, sh.V, sh.CH, dense ? c->Dp / 16 : 0, movesel, threads, lds, c->stream, a);
     if (e != hipSuccess) FAIL(c, -2, "k_small_run launch failed (G=%d V=%d CH=%d ndim=%d): %s", sh.G, sh.V, sh.CH, c->D, hipGetErrorString(e));
     int64_t nstored = 0;
@@ -1776,6 +1831,10 @@ static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, in
         auto& bp = c->bulk[c->bulk_pos ^ 1];
         HIPOK(c, hipEventRecord(bp.done, c->stream));
         bp.busy = true;
+    }
+    if (gauss_bulk) {
+        HIPOK(c, hipEventRecord(gauss_bulk->done, c->stream));
+        gauss_bulk->busy = true;
     }
     return 0;
 }

@@ -454,8 +454,9 @@ constexpr int prefetch_depth() {
 }
 
 // native Gaussian move: this lane's part of walker w's displacement row, (f * scale_d) * n(w, d)
-template <int G, int V, int CH>
-__device__ __forceinline__ void gauss_disp_row(Row<G, V, CH>& t, const HalfStepArgs& A, int w, int col, int D, int gl) {
+// ARGS: anything with gseed, gstep, gfac, gsigma, gscale (HalfStepArgs; GaussGen in the one-workgroup kernel)
+template <int G, int V, int CH, typename ARGS>
+__device__ __forceinline__ void gauss_disp_row(Row<G, V, CH>& t, const ARGS& A, int w, int col, int D, int gl) {
     if (col >= 0) {
         // one-coordinate modes (launch-uniform branch): a single normal per walker, computed once by every lane
         // of the walker's group instead of once per chunk
@@ -965,6 +966,11 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 // make_proposal, eval_valu_target), hence the same bits (tests/test_gpu_small_run.py).
 // ----------------------------------------------------------------------------------------
 constexpr int SMALL_MAX_MOVES = 8;
+struct GaussGen {          // what gauss_disp_row needs to generate a walker's displacement row in registers
+    unsigned long long gseed, gstep;
+    double gfac, gsigma;
+    const double* gscale;
+};
 constexpr int SMALL_ANY_MOVE = 7;      // MOVESEL: the kernel carries all three split-ensemble moves and picks per step
 
 // move of a native-mode step: one Philox draw against the cdf (the host's philox_move_choice)
@@ -991,6 +997,13 @@ struct SmallRunArgs {
     // the move schedule (ensemble.py:115-129): up to SMALL_MAX_MOVES stretch / DE / snooker moves and their cdf
     double a[SMALL_MAX_MOVES], sigma[SMALL_MAX_MOVES], g0[SMALL_MAX_MOVES], gammas[SMALL_MAX_MOVES], cdf[SMALL_MAX_MOVES];
     int32_t kind[SMALL_MAX_MOVES], nsplits[SMALL_MAX_MOVES];
+    // Gaussian Metropolis moves (native mode): mode, isotropic sigma / per-coordinate scale; per step of the launch the
+    // step-size factor and the sequential mode's column (host-computed: both are functions of the step number alone)
+    int32_t gmode[SMALL_MAX_MOVES];
+    double gsigma[SMALL_MAX_MOVES];
+    const double* gscale[SMALL_MAX_MOVES];
+    const double* step_fac;
+    const int32_t* step_col;
     int32_t nmoves;
     unsigned long long seed, step0;
     long long i0;         // index of the first step inside the emx_run call (thinning phase, ensemble.py:416)
@@ -1023,16 +1036,19 @@ __device__ __forceinline__ void small_plan_entry(const NativeArgs& na, int N, in
 template <int G, int V, int CH, int MOVE>
 __device__ __forceinline__ void small_propose(const SmallRunArgs& A, const double* Xs, bool live, int i, int j0, int j1, int j2,
                                               double s0, double fac, double gammas, int D, int gl, int sub, Row<G, V, CH>& q,
-                                              double& factor, bool& badq) {
+                                              double& factor, bool& badq, const GaussGen* gg = nullptr) {
     constexpr int NR = rows_per_pass<MOVE>();
     Row<G, V, CH> xi, xa, xb, xc;
     load_row<G, V, CH>(xi, Xs + (size_t)i * D, D, gl);
-    load_row<G, V, CH>(xa, Xs + (size_t)j0 * D, D, gl);
+    if constexpr (MOVE == MOVE_GAUSS)
+        gauss_disp_row<G, V, CH>(xa, *gg, i, j0, D, gl);                 // j0: the coordinate that moves, or -1
+    else
+        load_row<G, V, CH>(xa, Xs + (size_t)j0 * D, D, gl);
     if constexpr (NR >= 3) load_row<G, V, CH>(xb, Xs + (size_t)j1 * D, D, gl);
     if constexpr (NR >= 4) load_row<G, V, CH>(xc, Xs + (size_t)j2 * D, D, gl);
     factor = fac;
     make_proposal<G, V, CH, MOVE>(xi, xa, NR >= 3 ? xb : xa, NR >= 4 ? xc : xa, (MOVE == MOVE_SNOOKER) ? 0.0 : s0, gammas, D,
-                                  gl, q, factor);
+                                  gl, q, factor, MOVE == MOVE_GAUSS ? j0 : -1);
     bool bl = false;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -1045,11 +1061,12 @@ __device__ __forceinline__ void small_propose(const SmallRunArgs& A, const doubl
 template <int G, int V, int CH, int MOVE>
 __device__ __forceinline__ void small_update(const SmallRunArgs& A, double* Xs, double* lps, uint8_t* accs, bool live, int i,
                                              int j0, int j1, int j2, double s0, double fac, double logu, double gammas,
-                                             const Row<G, V, CH>& mu, const Row<G, V, CH>& iv, int D, int gl, int sub, int lane) {
+                                             const Row<G, V, CH>& mu, const Row<G, V, CH>& iv, int D, int gl, int sub, int lane,
+                                             const GaussGen* gg = nullptr) {
     Row<G, V, CH> q;
     double factor;
     bool badq;
-    small_propose<G, V, CH, MOVE>(A, Xs, live, i, j0, j1, j2, s0, fac, gammas, D, gl, sub, q, factor, badq);
+    small_propose<G, V, CH, MOVE>(A, Xs, live, i, j0, j1, j2, s0, fac, gammas, D, gl, sub, q, factor, badq, gg);
     const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
     if (live && gl == 0 && (lp_new != lp_new)) raise_status(A.status, ST_NAN_LOGP);
     const double lp_old = lps[i];
@@ -1144,6 +1161,11 @@ static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A)
             int i = 0, a0 = 0, a1 = 0, a2 = 0;
             double z = 0.0, lu = 0.0, fc = 0.0;
             const int S = A.nsplits[m];
+            if (MOVESEL == MOVE_GAUSS || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_GAUSS)) {
+                double u;
+                native_gauss_slot(na, D, A.gmode[m], A.step_col ? A.step_col[sb + b] : 0, pos, i, a0, a1, a2, z, u);
+                lu = log(u);
+            } else
             if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
                 small_plan_entry<MOVE_STRETCH>(na, N, D, S, pos, A.a[m], A.sigma[m], A.g0[m], i, a0, a1, a2, z, lu, fc);
             else if (MOVESEL == MOVE_DE || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_DE))
@@ -1165,6 +1187,12 @@ static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A)
             const int kind = MOVESEL == SMALL_ANY_MOVE ? A.kind[m] : MOVESEL;
             const int S = A.nsplits[m];
             const double gam = A.gammas[m];
+            GaussGen gg;
+            gg.gseed = A.seed;
+            gg.gstep = A.step0 + (unsigned long long)s;
+            gg.gfac = A.step_fac ? A.step_fac[s] : 1.0;
+            gg.gsigma = A.gsigma[m];
+            gg.gscale = A.gscale[m];
             // ---- the half-steps: a barrier where the general path has a kernel boundary ----
             int pos0 = b * N;
             for (int split = 0; split < S; ++split) {
@@ -1183,7 +1211,9 @@ static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A)
                             double factor = 0.0;
                             bool badq = false;
                             const int i = orders[pos], j0 = p0s[pos], j1 = p1s[pos], j2 = p2s[pos];
-                            if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
+                            if (!PLANNED && (MOVESEL == MOVE_GAUSS || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_GAUSS)))
+                                small_propose<G, V, CH, MOVE_GAUSS>(A, Xs, live, i, j0, j1, j2, s0s[pos], facs[pos], gam, D, gl, sub, q, factor, badq, &gg);
+                            else if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
                                 small_propose<G, V, CH, MOVE_STRETCH>(A, Xs, live, i, j0, j1, j2, s0s[pos], facs[pos], gam, D, gl, sub, q, factor, badq);
                             else if (MOVESEL == MOVE_DE || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_DE))
                                 small_propose<G, V, CH, MOVE_DE>(A, Xs, live, i, j0, j1, j2, s0s[pos], facs[pos], gam, D, gl, sub, q, factor, badq);
@@ -1264,7 +1294,9 @@ static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A)
                     const int pos = pos0 + (live ? t : 0);
                     const int i = orders[pos], j0 = p0s[pos], j1 = p1s[pos], j2 = p2s[pos];
                     const double s0 = s0s[pos], fac = facs[pos], logu = logus[pos];
-                    if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
+                    if (!PLANNED && (MOVESEL == MOVE_GAUSS || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_GAUSS)))
+                        small_update<G, V, CH, MOVE_GAUSS>(A, Xs, lps, accs, live, i, j0, j1, j2, s0, fac, logu, gam, mu, iv, D, gl, sub, lane, &gg);
+                    else if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
                         small_update<G, V, CH, MOVE_STRETCH>(A, Xs, lps, accs, live, i, j0, j1, j2, s0, fac, logu, gam, mu, iv, D, gl, sub, lane);
                     else if (MOVESEL == MOVE_DE || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_DE))
                         small_update<G, V, CH, MOVE_DE>(A, Xs, lps, accs, live, i, j0, j1, j2, s0, fac, logu, gam, mu, iv, D, gl, sub, lane);

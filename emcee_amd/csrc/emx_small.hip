@@ -41,6 +41,8 @@ hipError_t launch_small(int move, int threads, size_t lds, hipStream_t st, const
         case MOVE_SNOOKER:
             return planned ? launch_small_move<G, V, CH, MOVE_SNOOKER, true>(threads, lds, st, a)
                            : launch_small_move<G, V, CH, MOVE_SNOOKER, false>(threads, lds, st, a);
+        case MOVE_GAUSS:       // native mode only: the exact mode's normals come from the host
+            return planned ? hipErrorInvalidValue : launch_small_move<G, V, CH, MOVE_GAUSS, false>(threads, lds, st, a);
         case SMALL_ANY_MOVE:
             return planned ? launch_small_move<G, V, CH, SMALL_ANY_MOVE, true>(threads, lds, st, a)
                            : launch_small_move<G, V, CH, SMALL_ANY_MOVE, false>(threads, lds, st, a);

@@ -254,3 +254,41 @@ def test_small_run_random_configs_equal_general_path(kind, N, D, target, nsplits
         ens.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("N,D,target,mode,factor,diag,mix", [
+    (32, 5, "iso", "vector", None, False, False), (40, 3, "iso", "random", 2.0, False, False),
+    (24, 3, "iso", "sequential", None, False, False), (48, 6, "diag", "vector", 1.5, True, False),
+    (32, 5, "dense", "vector", None, False, False), (64, 8, "rosenbrock", "random", None, True, False),
+    (32, 3, "iso", "vector", None, False, True), (30, 4, "dense", "sequential", 1.3, True, True),
+])
+def test_small_run_gaussian_move_equals_general_path(N, D, target, mode, factor, diag, mix):
+    """Gaussian Metropolis move (native mode) inside the one-workgroup kernel: same normals (generated in registers
+    from the same counters), same factor and sequential cursor as the general path; alone and mixed with the stretch move"""
+    rs = np.random.RandomState(D)
+    cov = (0.05 + 0.1 * rs.rand(D)) if diag else 0.08
+    mvs = [so.MoveSpec("gaussian", cov=cov, mode=mode, factor=factor)]
+    weights = None
+    if mix:
+        mvs = [so.MoveSpec("stretch", live_dangerously=True)] + mvs
+        weights = [0.6, 0.4]
+    cases.DIGEST_CASES["_sm"] = dict(N=N, D=D, target=target, moves=mvs, weights=weights, nsteps=1, seed=N + D,
+                                     p0="rosen" if target == "rosenbrock" else "randn")
+    spec = cases.build("_sm")
+    del cases.DIGEST_CASES["_sm"]
+    outs = []
+    for small in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(1618, 0)
+        ens.set_tuning("small_kernel", small)
+        ens.chain_config(30)
+        ens.run(17, 1, True)
+        ens.run(4, 2, True)
+        assert ens.status() == 0
+        cursor = int(ens.get_move(len(mvs) - 1).gammas)
+        outs.append((ens.chain_read(0, 0, 21), ens.chain_read(1, 0, 21), ens.accepted_counts(), ens.get_state()[0], np.array([cursor])))
+        ens.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert 0 < outs[0][2].sum() < 21 * N
