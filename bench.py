@@ -1,18 +1,27 @@
 #!/usr/bin/env python
-"""Contract bench: walker-updates/sec of the fused red/blue stretch-move step on MI355X.
+"""Contract bench: walker-updates/sec of the fused red/blue half-step path on MI355X.
 
-`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one
-rank per GPU).  A "step" is one full ensemble step = both half-steps of the stretch move over
-one ensemble of synthetic walkers resident in HBM (BASELINE.json configs[1]:
-nwalkers=65536 per GPU, ndim=64, correlated Gaussian with dense precision matrix, a=2.0).
-Weak scaling: the ensemble grows with N (65536 walkers per GPU).  Two exchange protocols exist
-(emcee_amd/parallel.py): every rank updates a slot range and one all-gather per half-step replicates
-all updated rows; or every rank owns a walker block and one all-to-all per half-step moves only the
-partner rows that are read.  At N>1 both are measured (same seed: their final states must agree) and
-the faster is reported; `exchange` in the JSON line carries both.
+`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run, one rank per GPU).
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields, incl. `roofline` and
-`cpu_baseline`).
+A "step" is one full ensemble step (every half-step of the move chosen for it) over an ensemble of synthetic
+walkers resident in HBM.  The HEADLINE (`metric`, `value`, `ms_per_step`, `roofline`) is BASELINE.json configs[1]:
+nwalkers=65536 per GPU, ndim=64, correlated Gaussian with a dense precision matrix, StretchMove a=2.0, counter-based
+RNG, float64 -- weak-scaled over the GPUs.  The same JSON line also carries (rank 0, N=1):
+
+  configs     C3 262144x32 Rosenbrock, C4 65536x64 DE+snooker mixture, C5 16384x1024 diagonal Gaussian and C2 with
+              the chain stored every step: ms_per_step, wu_per_s, roofline fraction (SURVEY.md 8d bytes formulas)
+  exact_mode  C2 under rng=mt19937 (the mode that reproduces reference emcee's chain for a seed)
+  quality     acceptance fraction and integrated autocorrelation time of a 2048x64 run >= 50 tau long, next to the
+              reference's numbers for the same configuration (profiles/r02/quality_ref.json, build container)
+  cpu_baseline reference emcee itself when /root/reference is importable (build container), otherwise the NumPy
+              port (oracle/) timed here + the committed reference timings (profiles/r02/cpu_reference.json)
+
+and at N>1 `multi_gpu`: C2 weak, C3 (262144 walkers sharded) and C5 (16384x1024, strong scaling), each under every
+exchange protocol (emcee_amd/parallel.py), the fastest valid one reported per config.
+
+Timing: after W warm-up steps, blocks of EXACTLY K steps are timed, each bracketed by barrier + synchronize, until
+>= 50 ms have been measured; the MEDIAN block is reported (max over ranks per block).  `--single-block` restores the
+one-block protocol.  stdout carries exactly one JSON line.
 """
 import argparse
 import json
@@ -25,11 +34,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WALKERS_PER_GPU = 65536
-NDIM = 64
 HBM_PEAK_GBPS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
+MIN_TIMED_MS = 50.0
+MAX_BLOCKS = 400
 
 
+# ------------------------------------------------------------------------------------------------ workloads
 def dense_gaussian(ndim, seed=0):
     """Sigma = A A^T / D + 0.1 I, dense Sigma^-1."""
     rs = np.random.RandomState(seed)
@@ -40,46 +50,79 @@ def dense_gaussian(ndim, seed=0):
     return mu, cov, 0.5 * (icov + icov.T)
 
 
-def initial_walkers(n, mu, cov, seed=1):
-    rs = np.random.RandomState(seed)
-    return mu + rs.randn(n, len(mu)) @ np.linalg.cholesky(cov).T   # equilibrium start
+def partner_rows(kind):
+    return {"stretch": 1, "de": 2, "snooker": 3}[kind]
 
 
-def cpu_baseline(mu, cov, icov, budget_s=15.0):
-    """NumPy oracle (port of reference emcee's vectorised path) on the host cores, bounded sample."""
-    from oracle import sampler_oracle as so
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # noqa: BLE001
-        threadpool_limits = None
-    n = WALKERS_PER_GPU
-    p0 = initial_walkers(n, mu, cov)
-    fn = lambda x: so.dense_gauss(x, mu, icov)  # noqa: E731
-    rs = np.random.RandomState(7)
-
-    def go():
-        out = so.run(p0, 1, fn, rs, store=False)                  # warm-up (page faults, BLAS initialisation)
-        t0 = time.perf_counter()
-        out = so.run(out["coords"], 2, fn, rs, store=False, log_prob0=out["lp"])
-        t1 = (time.perf_counter() - t0) / 2
-        nst = int(min(1000, max(3, budget_s / max(t1, 1e-3))))     # ~15 s of CPU work whatever the host
-        t0 = time.perf_counter()
-        so.run(out["coords"], nst, fn, rs, store=False, log_prob0=out["lp"])
-        return nst, time.perf_counter() - t0
-
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            nst, dt = go()
-        cores = 1
-    else:
-        nst, dt = go()
-        cores = os.cpu_count()
-    return {"value": n * nst / dt, "unit": "walker-updates/s", "cores": cores, "kind": "port",
-            "sample": "oracle/sampler_oracle.py (NumPy restatement of emcee's vectorize=True path), "
-                      "%d steps of the same 65536x64 dense-Gaussian stretch workload, %.1f s, BLAS threads=%d, host has %d cores"
-                      % (nst, dt, cores, os.cpu_count())}
+def algorithmic_bytes(ndim, kind, store):
+    """read x_k + partner rows, write x_k', log-prob in/out, accepted flag (+ chain row and log-prob)."""
+    return (16 + 8 * partner_rows(kind)) * ndim + 17 + ((8 * ndim + 8) if store else 0)
 
 
+class Workload(object):
+    """One BASELINE.json configuration: synthetic inputs + how to install it on a DeviceEnsemble."""
+
+    def __init__(self, key, nwalkers):
+        from emcee_amd import _lib
+        self.key = key
+        self.N = int(nwalkers)
+        std = lambda kind, D, S=2: _lib.MoveDesc({"stretch": 0, "de": 1, "snooker": 2}[kind], 4 if kind == "snooker" else S, 1, 0,  # noqa: E731
+                                                 2.0, 1e-5, 2.38 / np.sqrt(2 * D), 1.7)
+        rs = np.random.RandomState(1)
+        if key in ("c2", "c4"):
+            self.D = 64
+            mu, cov, icov = dense_gaussian(self.D)
+            self.params = (mu, cov, icov)
+            self.target = (_lib.TARGET_DENSE, mu, icov, 0.0)
+            self.p0 = mu + rs.randn(self.N, self.D) @ np.linalg.cholesky(cov).T      # equilibrium start
+            if key == "c2":
+                self.moves, self.weights = [("stretch", std("stretch", 64))], [1.0]
+                self.label = "configs[1]: nwalkers=%d, ndim=64, dense-precision Gaussian, StretchMove a=2.0, nsplits=2" % self.N
+            else:
+                self.moves = [("de", std("de", 64)), ("snooker", std("snooker", 64))]
+                self.weights = [0.8, 0.2]
+                self.label = "configs[3]: nwalkers=%d, ndim=64, dense-precision Gaussian, DEMove 0.8 + DESnookerMove 0.2" % self.N
+        elif key == "c3":
+            self.D = 32
+            self.target = (_lib.TARGET_ROSENBROCK, None, None, 20.0)
+            self.p0 = 1.0 + 0.1 * rs.randn(self.N, self.D)
+            self.moves, self.weights = [("stretch", std("stretch", 32))], [1.0]
+            self.label = "configs[2]: nwalkers=%d, ndim=32, Rosenbrock/20, StretchMove a=2.0" % self.N
+        elif key == "c5":
+            self.D = 1024
+            ivar = 1.0 / np.random.RandomState(0).rand(self.D)                        # docs/index.rst:41-45
+            self.target = (_lib.TARGET_DIAG, np.zeros(self.D), ivar, 0.0)
+            self.p0 = rs.randn(self.N, self.D) / np.sqrt(ivar)
+            self.moves, self.weights = [("stretch", std("stretch", 1024))], [1.0]
+            self.label = "configs[4]: nwalkers=%d, ndim=1024, diagonal Gaussian, StretchMove a=2.0" % self.N
+        else:
+            raise ValueError(key)
+
+    def bytes_per_update(self, store):
+        w = np.asarray(self.weights) / np.sum(self.weights)
+        return float(sum(wi * algorithmic_bytes(self.D, kind, store) for wi, (kind, _) in zip(w, self.moves)))
+
+    def launches_per_step(self):
+        w = np.asarray(self.weights) / np.sum(self.weights)
+        return float(sum(wi * d.nsplits for wi, (_, d) in zip(w, self.moves)))
+
+    def install(self, ens, rng, seed=20260923):
+        from emcee_amd import _lib
+        kind, p0, p1, scale = self.target
+        ens.set_target(kind, p0, p1, scale)
+        cdf = np.cumsum(self.weights) / np.sum(self.weights)
+        ens.set_moves([d for _, d in self.moves], cdf)
+        if rng == "philox":
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(seed, 0)
+        else:
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(np.random.RandomState(seed).get_state())
+        ens.set_state(self.p0)
+        ens.eval_state_log_prob()
+
+
+# ------------------------------------------------------------------------------------------------ stdout
 # The contract is ONE JSON line on stdout.  Libraries in the process write there too (gloo announces its mesh, RCCL its
 # version ...), so file descriptor 1 is pointed at stderr for the whole run and the line goes to a private copy of the
 # original stdout.
@@ -95,23 +138,449 @@ def _claim_stdout():
     return _REAL_STDOUT
 
 
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _port_leg(so, wl, fn, budget_s, label, cores):
+    rs = np.random.RandomState(7)
+    out = so.run(wl.p0, 1, fn, rs, store=False)                  # warm-up (page faults, BLAS initialisation)
+    t0 = time.perf_counter()
+    out = so.run(out["coords"], 1, fn, rs, store=False, log_prob0=out["lp"])
+    t1 = time.perf_counter() - t0
+    nst = int(min(1000, max(2, budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    so.run(out["coords"], nst, fn, rs, store=False, log_prob0=out["lp"])
+    dt = time.perf_counter() - t0
+    return {"mode": label, "wu_per_s": wl.N * nst / dt, "ms_per_step": dt * 1e3 / nst, "steps": nst, "seconds": dt, "cores": cores}
+
+
+_POOL_MU = _POOL_ICOV = None
+
+
+def _pool_init(mu, icov):
+    global _POOL_MU, _POOL_ICOV
+    _POOL_MU, _POOL_ICOV = mu, icov
+
+
+def _pool_lp(x):
+    d = x - _POOL_MU
+    return -0.5 * float(np.dot(d, _POOL_ICOV @ d))
+
+
+def cpu_baseline(wl, budget_s=14.0):
+    """The host-core baseline of the headline workload (a reported number, not the optimisation target).
+
+    Build container (/root/reference importable): reference emcee ITSELF, kind "reference".  GPU box: the NumPy port of
+    its vectorize=True path (oracle/sampler_oracle.py, pinned to the reference by tests/golden), kind "port", in the
+    reference's three documented modes, plus the committed reference timings from the build container."""
+    from oracle import ref_shim
+    from oracle import sampler_oracle as so
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # noqa: BLE001
+        threadpool_limits = None
+    mu, cov, icov = wl.params
+    ncores = os.cpu_count()
+    embedded = None
+    path = os.path.join(ROOT, "profiles", "r02", "cpu_reference.json")
+    if os.path.exists(path):
+        try:
+            embedded = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            embedded = None
+
+    if ref_shim.available():
+        emcee = ref_shim.import_reference()
+
+        def ref_leg(label, cores, **kw):
+            s = emcee.EnsembleSampler(wl.N, wl.D, kw.pop("fn"), **kw)
+            s._random.seed(7)
+            st = s.run_mcmc(wl.p0, 1, skip_initial_state_check=True, store=False)
+            t0 = time.perf_counter()
+            st = s.run_mcmc(st, 1, skip_initial_state_check=True, store=False)
+            t1 = time.perf_counter() - t0
+            nst = int(min(1000, max(2, budget_s / max(t1, 1e-3))))
+            t0 = time.perf_counter()
+            s.run_mcmc(st, nst, skip_initial_state_check=True, store=False)
+            dt = time.perf_counter() - t0
+            return {"mode": label, "wu_per_s": wl.N * nst / dt, "ms_per_step": dt * 1e3 / nst, "steps": nst, "seconds": dt, "cores": cores}
+
+        vec = lambda x: -0.5 * np.einsum("ij,ij->i", (x - mu) @ icov, x - mu)  # noqa: E731
+        legs = []
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=1):
+                legs.append(ref_leg("vectorize=True, 1 BLAS thread", 1, fn=vec, vectorize=True))
+        else:
+            legs.append(ref_leg("vectorize=True, default BLAS threads", ncores, fn=vec, vectorize=True))
+        import multiprocessing
+        _pool_init(mu, icov)
+        with multiprocessing.Pool(ncores, initializer=_pool_init, initargs=(mu, icov)) as pool:
+            legs.append(ref_leg("per-walker log_prob_fn, multiprocessing.Pool(%d)" % ncores, ncores, fn=_pool_lp, pool=pool))
+        best = max(legs, key=lambda r: r["wu_per_s"])
+        return {"value": best["wu_per_s"], "unit": "walker-updates/s", "cores": best["cores"], "kind": "reference",
+                "sample": "reference emcee (/root/reference/src) run_mcmc on %s; best mode '%s': %d steps, %.1f s; host has %d cores"
+                          % (wl.label, best["mode"], best["steps"], best["seconds"], ncores),
+                "modes": legs}
+
+    fn = lambda x: so.dense_gauss(x, mu, icov)  # noqa: E731
+    legs = []
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            legs.append(_port_leg(so, wl, fn, budget_s, "port of vectorize=True, 1 BLAS thread", 1))
+        legs.append(_port_leg(so, wl, fn, budget_s / 2, "port of vectorize=True, BLAS threads = all cores", ncores))
+    else:
+        legs.append(_port_leg(so, wl, fn, budget_s, "port of vectorize=True, default BLAS threads", ncores))
+    # the reference's documented parallel path: per-walker log_prob_fn through pool.map (ensemble.py:492-496)
+    try:
+        import multiprocessing
+        nproc = min(ncores, 32)
+        with multiprocessing.Pool(nproc, initializer=_pool_init, initargs=(mu, icov)) as pool:
+            chunk = max(1, wl.N // 2 // (4 * nproc))
+            pfn = lambda x: np.asarray(pool.map(_pool_lp, x, chunksize=chunk))  # noqa: E731
+            if threadpool_limits is not None:
+                with threadpool_limits(limits=1):
+                    legs.append(_port_leg(so, wl, pfn, budget_s / 2, "port, per-walker log_prob_fn via multiprocessing.Pool(%d)" % nproc, nproc))
+            else:
+                legs.append(_port_leg(so, wl, pfn, budget_s / 2, "port, per-walker log_prob_fn via multiprocessing.Pool(%d)" % nproc, nproc))
+    except Exception as e:  # noqa: BLE001
+        legs.append({"mode": "port, multiprocessing.Pool", "error": repr(e)})
+    head = legs[0]
+    out = {"value": head["wu_per_s"], "unit": "walker-updates/s", "cores": head["cores"], "kind": "port",
+           "sample": "oracle/sampler_oracle.py (NumPy restatement of emcee's vectorize=True path; /root/reference is absent on this "
+                     "box), %d steps of %s, %.1f s, BLAS threads=%d, host has %d cores"
+                     % (head["steps"], wl.label, head["seconds"], head["cores"], ncores),
+           "modes": legs}
+    if embedded is not None:
+        out["reference_build_container"] = {"source": "profiles/r02/cpu_reference.json (tools/cpu_reference.py; static: measured in the "
+                                                      "build container, not on this box)",
+                                            "host": embedded.get("host"),
+                                            "modes": {k: {"wu_per_s": v["wu_per_s"], "ms_per_step": v["ms_per_step"], "cores": v["cores"]}
+                                                      for k, v in embedded.get("modes", {}).items()}}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ single-GPU measurement
+def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=False, want_kernel=True, spin_s=0.15):
+    """W warm-up steps, then K-step blocks (each: sync, hipEvent + wall clock around emx_run(K), sync) until >= 50 ms;
+    median block.  Returns per-step times, per-launch event duration of the half-step kernel, accept fraction."""
+    from emcee_amd.device import DeviceEnsemble
+    ens = DeviceEnsemble(wl.N, wl.D, device=device)
+    wl.install(ens, rng)
+    if store:
+        ens.chain_config(max(K, W))
+    # untimed spin-up: the first ~50 ms on a fresh context run slower (clock ramp, first touch of the plan ring, lazy
+    # code-object loading); tools/stall_probe.py
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < spin_s:
+        ens.run(min(50, max(1, K)), 1, False)
+        ens.sync()
+    if store:
+        ens.chain_reset()
+    ens.run(W, 1, store)
+    ens.sync()
+    walls, gpus = [], []
+    total = 0.0
+    while True:
+        if store:
+            ens.chain_reset()
+        ens.sync()
+        ens.timer_start()
+        t0 = time.perf_counter()
+        ens.run(K, 1, store)
+        gpu_ms = ens.timer_stop()          # hipEvents on the stream the kernels are launched on; synchronises
+        ens.sync()
+        wall = time.perf_counter() - t0
+        walls.append(wall)
+        gpus.append(gpu_ms)
+        total += wall * 1e3
+        if single_block or (total >= MIN_TIMED_MS and len(walls) >= 3) or len(walls) >= MAX_BLOCKS:
+            break
+    wall = float(np.median(walls))
+    gpu_ms = float(np.median(gpus))
+    res = {"wall_s": wall, "gpu_ms": gpu_ms, "blocks": len(walls), "wall_min_s": float(np.min(walls)),
+           "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(), "per_launch_us": None}
+    if want_kernel:
+        # per-launch hipEvent durations of the half-step kernel (separate pass: event records perturb)
+        ens.profile_enable(128)
+        ens.run(48, 1, False)
+        pl = ens.profile_read(128)
+        if len(pl):
+            res["per_launch_us"] = float(np.median(pl) * 1e3)
+    ens.close()
+    return res
+
+
+def config_entry(wl, res, K, store):
+    B = wl.bytes_per_update(store)
+    lps = wl.launches_per_step()
+    ms = res["wall_s"] * 1e3 / K
+    wu = wl.N * K / res["wall_s"]
+    ev_ms = res["gpu_ms"] / K
+    out = {"workload": wl.label + (", chain stored every step" if store else ""), "nwalkers": wl.N, "ndim": wl.D,
+           "ms_per_step": ms, "wu_per_s": wu, "steps_per_s": K / res["wall_s"], "blocks_timed": res["blocks"],
+           "accept_frac": res["accept_frac"], "device_status": res["status"],
+           "roofline": {"bound": "hbm", "algorithmic_bytes_per_walker_update": B,
+                        "achieved": wl.N * B / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": wl.N * B / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS,
+                        "avg_launch_us": ev_ms * 1e3 / lps, "per_launch_event_us": res["per_launch_us"],
+                        "launches_per_step": lps}}
+    return out
+
+
+def exact_mode_entry(wl, K, W, device):
+    """C2 under rng=mt19937 (same seed => reference emcee's chain).  The host produces every draw of the step from the
+    serial NumPy-legacy stream; host_plan_ms times that producer alone (no GPU involved)."""
+    from emcee_amd import _lib
+    Kx = max(10, min(K, 100))
+    res = measure_single(wl, Kx, max(W, 10), device=device, rng="mt19937", spin_s=0.05)
+    lib = _lib.load()
+    host_ms = None
+    try:
+        st = np.random.RandomState(5).get_state()
+        key = np.ascontiguousarray(st[1], dtype=np.uint32)
+        m = lib.emx_mt_create(key, int(st[2]), int(st[3]), float(st[4]))
+        N = wl.N
+        off = np.zeros(3, dtype=np.int32)
+        order, p0, p1, p2 = (np.empty(N, dtype=np.int32) for _ in range(4))
+        s0, ua = np.empty(N), np.empty(N)
+        mv = wl.moves[0][1]
+        import ctypes as C
+        lib.emx_host_plan_mt(m, N, wl.D, C.byref(mv), off, order, p0, p1, p2, s0, ua)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            lib.emx_host_plan_mt(m, N, wl.D, C.byref(mv), off, order, p0, p1, p2, s0, ua)
+        host_ms = (time.perf_counter() - t0) * 1e3 / 20
+        lib.emx_mt_destroy(m)
+    except Exception as e:  # noqa: BLE001
+        log("host plan timing failed:", e)
+    B = wl.bytes_per_update(False)
+    wu = wl.N * Kx / res["wall_s"]
+    return {"workload": wl.label + ", rng=mt19937 (NumPy legacy stream, chain identical to reference emcee's)",
+            "steps": Kx, "blocks_timed": res["blocks"], "ms_per_step": res["wall_s"] * 1e3 / Kx, "wu_per_s": wu,
+            "best_block_ms_per_step": res["wall_min_s"] * 1e3 / Kx,
+            "host_plan_ms": host_ms, "kernel_us": res["per_launch_us"], "accept_frac": res["accept_frac"],
+            "roofline_frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS,
+            "note": "host_plan_ms = one step's plan from the serial MT19937 stream by a single host thread (emx_host_plan_mt, no GPU); "
+                    "emx_run overlaps plan production with the device through its plan pipeline"}
+
+
+def quality_entry(device, rng="philox", nwalkers=2048, nsteps=2000, thin_by=25, burn=2000):
+    """Acceptance fraction and integrated autocorrelation time (reference estimator, c=5) of the 64-dim correlated
+    Gaussian, StretchMove a=2: 2048 walkers, 2000 burn-in + 50 000 steps (>= 50 tau), next to the reference's own
+    numbers for the same configuration (static file from the build container)."""
+    import emcee_amd
+    D = 64
+    mu, cov, icov = dense_gaussian(D)
+    p0 = mu + np.random.RandomState(1).randn(nwalkers, D) @ np.linalg.cholesky(cov).T
+    s = emcee_amd.EnsembleSampler(nwalkers, D, emcee_amd.targets.DenseGaussian(mu, icov), rng=rng, device=device)
+    s._random.seed(12)
+    t0 = time.perf_counter()
+    st = s.run_mcmc(p0, burn, skip_initial_state_check=True, store=False)
+    s.run_mcmc(st, nsteps, thin_by=thin_by, skip_initial_state_check=True)
+    t_run = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tau = s.get_autocorr_time(quiet=True)             # in steps (thin_by accounted for by the backend? no: stored units)
+    t_tau = time.perf_counter() - t0
+    tau = np.asarray(tau) * thin_by
+    acc = float(np.mean(s.acceptance_fraction))
+    out = {"workload": "%d walkers x 64-dim correlated Gaussian, StretchMove a=2, %d burn-in + %d steps, thin_by=%d, rng=%s"
+                       % (nwalkers, burn, nsteps * thin_by, thin_by, rng),
+           "accept": acc, "tau_mean": float(np.mean(tau)), "tau_min": float(np.min(tau)), "tau_max": float(np.max(tau)),
+           "nsteps_over_tau": float(nsteps * thin_by / np.mean(tau)), "run_seconds": t_run, "tau_seconds": t_tau}
+    path = os.path.join(ROOT, "profiles", "r02", "quality_ref.json")
+    if os.path.exists(path):
+        try:
+            ref = json.load(open(path))
+            cfg, r = ref["config"], ref["results"][0]
+            same = (cfg["nwalkers"], cfg["nsteps"], cfg["thin_by"], cfg["burn"]) == (nwalkers, nsteps, thin_by, burn)
+            out["reference"] = {"source": "profiles/r02/quality_ref.json (reference emcee in the build container; static)",
+                                "same_configuration": bool(same), "accept": r["accept_mean"], "tau_mean": r["tau_mean"],
+                                "nsteps_over_tau": r["chain_over_tau"], "seconds": r["seconds"]}
+            out["accept_rel_diff"] = acc / r["accept_mean"] - 1.0
+            out["tau_rel_diff"] = float(np.mean(tau)) / r["tau_mean"] - 1.0
+            out["within_2pct"] = bool(abs(out["accept_rel_diff"]) < 0.02 and abs(out["tau_rel_diff"]) < 0.02)
+        except Exception as e:  # noqa: BLE001
+            out["reference"] = "unreadable: %r" % (e,)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ multi-GPU measurement
+EXCHANGES = ("allgather", "pull")
+
+
+def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode, single_block=False):
+    """One sharded measurement (fresh context): spin-up, W warm-up steps, K-step blocks."""
+    import torch
+    from emcee_amd.device import DeviceEnsemble
+    ens = DeviceEnsemble(wl.N, wl.D, device=local_rank)
+    wl.install(ens, "philox")
+    ens.set_exchange(exchange)
+    comm_used = None
+    if comm_mode == "torch":
+        from emcee_amd.parallel import DeviceEngine, PullStepper, ShardedStepper
+        ens.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels + RCCL ordered on one stream
+        eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank), exchange=exchange)
+        gather = lambda out, inp: dist.all_gather_into_tensor(out, inp)  # noqa: E731
+        if exchange == "pull":
+            stepper = PullStepper(eng, lambda out, inp: dist.all_to_all_single(out, inp), gather)
+        else:
+            stepper = ShardedStepper(eng, gather)
+        run = lambda k: stepper.run(k, 1, False)  # noqa: E731
+        comm_used = "torch.distributed(nccl)"
+    else:
+        uid = [DeviceEnsemble.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ens.comm_init(rank, world, uid[0])      # ncclCommInitRank; emx_run now exchanges per half-step
+        run = lambda k: ens.run(k, 1, False)  # noqa: E731
+        comm_used = "libemx->RCCL"
+
+    def fence():
+        ens.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(6):            # a FIXED count: every rank must issue the same collectives
+        run(5)
+        ens.sync()
+    run(W)
+    fence()
+    walls, gpus = [], []
+    total, nblk = 0.0, 0
+    while True:
+        fence()
+        ens.timer_start()
+        t0 = time.perf_counter()
+        run(K)
+        gpu_ms = ens.timer_stop()
+        fence()
+        wall = time.perf_counter() - t0
+        t = torch.tensor([wall, gpu_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # gloo (bootstrap group) or nccl: both fine for 2 doubles
+        walls.append(float(t[0]))
+        gpus.append(float(t[1]))
+        total += float(t[0]) * 1e3
+        nblk += 1
+        if single_block or (total >= MIN_TIMED_MS and nblk >= 3) or nblk >= 60:     # same decision on every rank: t is reduced
+            break
+    x, lp = ens.get_state()
+    digest = "%.17g/%.17g" % (float(np.sum(x * np.arange(1, wl.D + 1))), float(np.sum(lp)))
+    every = [None] * world
+    dist.all_gather_object(every, digest)
+    res = {"wall_s": float(np.median(walls)), "gpu_ms": float(np.median(gpus)), "blocks": nblk, "comm": comm_used,
+           "exchange": exchange, "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(),
+           "digest": digest, "replicas_agree": len(set(every)) == 1}
+    if comm_mode != "torch":
+        ens.comm_destroy()
+    ens.close()
+    return res
+
+
+def sharded_config(key, world, K, W, rank, local_rank, dist, args):
+    """Every exchange protocol on one workload; the fastest whose final ensemble agrees on all ranks (and with the
+    first protocol's) is reported."""
+    import threading
+    scaling = {"c2": "weak", "c3": "strong", "c5": "strong"}[key] if args.scaling == "auto" else args.scaling
+    base = {"c2": 65536, "c3": 262144, "c5": 16384}[key]
+    wl = Workload(key, base * world if scaling == "weak" else base)
+    results, errors = {}, {}
+    exchanges = EXCHANGES if args.exchange == "all" else (args.exchange,)
+    for ex in exchanges:
+        done = threading.Event()
+
+        def bail(ex=ex):
+            if done.is_set():
+                return
+            # a protocol that hangs must not take the contract line with it: report what is in hand and leave
+            log("rank %d: exchange '%s' on %s did not return within %.0f s" % (rank, ex, key, args.exchange_timeout))
+            _emergency_emit(args, "exchange '%s' on %s hung" % (ex, key))
+            os._exit(3)
+
+        timer = threading.Timer(args.exchange_timeout, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            results[ex] = measure_sharded(wl, K, W, ex, rank, world, local_rank, dist, args.comm, args.single_block)
+        except Exception as e:  # noqa: BLE001
+            errors[ex] = repr(e)
+            log("rank %d: exchange '%s' on %s failed: %r" % (rank, ex, key, e))
+        done.set()
+        timer.cancel()
+        ok = torch_all_ok(dist, ex in results)
+        if not ok:
+            results.pop(ex, None)
+            errors.setdefault(ex, "failed on another rank")
+    ref_digest = None
+    best = None
+    summary = {}
+    for ex in exchanges:
+        r = results.get(ex)
+        if r is None:
+            summary[ex] = {"error": errors.get(ex, "?")}
+            continue
+        if ref_digest is None:
+            ref_digest = r["digest"]
+        valid = r["status"] == 0 and r["replicas_agree"] and r["digest"] == ref_digest
+        summary[ex] = {"ms_per_step": r["wall_s"] * 1e3 / K, "wu_per_s": wl.N * K / r["wall_s"], "comm": r["comm"],
+                       "device_status": r["status"], "replicas_agree": r["replicas_agree"],
+                       "same_final_state_as_first": r["digest"] == ref_digest, "blocks_timed": r["blocks"]}
+        if valid and (best is None or r["wall_s"] < best["wall_s"]):
+            best = r
+    entry = {"workload": wl.label, "nwalkers": wl.N, "ndim": wl.D, "scaling": scaling, "exchange": summary}
+    if best is not None:
+        B = wl.bytes_per_update(False)
+        wu = wl.N * K / best["wall_s"]
+        entry.update({"reported": best["exchange"], "ms_per_step": best["wall_s"] * 1e3 / K, "wu_per_s": wu,
+                      "steps_per_s": K / best["wall_s"], "accept_frac": best["accept_frac"],
+                      "roofline_frac_per_gpu": wu * B / 1e9 / HBM_PEAK_GBPS / world})
+    return wl, best, entry
+
+
+def torch_all_ok(dist, ok):
+    import torch
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag[0]) == 1
+
+
+_PARTIAL = {}
+
+
+def _emergency_emit(args, why):
+    if int(os.environ.get("RANK", "0")) != 0 or not _PARTIAL.get("line"):
+        return
+    line = dict(_PARTIAL["line"])
+    line["incomplete"] = why
+    out = _claim_stdout()
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--store", action="store_true", help="append every step to the device chain")
+    ap.add_argument("--config", default="all", choices=["all", "c2", "c3", "c4", "c5"],
+                    help="which BASELINE configuration(s) to measure beside the C2 headline (N>1: c2, c3, c5)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="N>1: auto = C2 weak (65536 walkers per GPU), C3 / C5 strong (BASELINE's fixed totals)")
+    ap.add_argument("--store", action="store_true", help="headline with the chain appended every step (32D+25 bytes)")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (no configs / exact_mode / quality)")
+    ap.add_argument("--single-block", action="store_true", help="time one K-step block instead of the median of >= 50 ms of blocks")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded RCCL path even at world size 1 (testing)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="sharded runs: collectives enqueued by libemx itself (default) or torch.distributed")
-    ap.add_argument("--exchange", default="both", choices=["both", "allgather", "pull"],
-                    help="sharded runs: all-gather of every updated row, all-to-all of the partner rows read "
-                         "(emcee_amd/parallel.py), or measure both and report the faster (default)")
-    ap.add_argument("--pull-timeout", type=float, default=150.0,
-                    help="'both': seconds after which a stuck pull measurement is abandoned for the all-gather result")
+    ap.add_argument("--exchange", default="all", choices=["all"] + list(EXCHANGES))
+    ap.add_argument("--exchange-timeout", type=float, default=150.0,
+                    help="seconds after which a stuck exchange measurement is abandoned (the line so far is emitted)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,242 +591,126 @@ def main():
     K, W = args.steps, args.warmup
 
     import torch
-    from emcee_amd import _lib
-    from emcee_amd.device import DeviceEnsemble
-
     torch.cuda.set_device(local_rank)
-    dist = None
     sharded = world > 1 or args.force_dist
-    if sharded:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.comm == "torch":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")      # bootstrap / barriers only; the data path is libemx -> RCCL
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("c2_stretch_dense_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
 
-    n = WALKERS_PER_GPU * world
-    mu, cov, icov = dense_gaussian(NDIM)
-    p0 = initial_walkers(n, mu, cov)
-
-    def measure(exchange):
-        """One full measurement (fresh context): spin-up, W warm-up steps, K timed steps."""
-        ens = DeviceEnsemble(n, NDIM, device=local_rank)
-        ens.set_target(_lib.TARGET_DENSE, mu, icov)
-        ens.set_moves([_lib.MoveDesc(_lib.MOVE_STRETCH, 2, 1, 0, 2.0, 1e-5, 2.38 / np.sqrt(2 * NDIM), 1.7)], np.array([1.0]))
-        if args.rng == "philox":
-            ens.set_rng_mode(_lib.RNG_PHILOX)
-            ens.set_philox(20260923, 0)
-        else:
-            ens.set_rng_mode(_lib.RNG_MT19937)
-            ens.set_mt19937(np.random.RandomState(20260923).get_state())
-        ens.set_state(p0)
-        ens.eval_state_log_prob()
-        if args.store:
-            ens.chain_config(K + W)
-        if sharded:
-            ens.set_exchange(exchange)
-
-        def torch_path(group=None):
-            from emcee_amd.parallel import DeviceEngine, PullStepper, ShardedStepper
-            ens.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels + RCCL ordered on one stream
-            eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank), exchange=exchange)
-            gather = lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group)  # noqa: E731
-            if exchange == "pull":
-                stepper = PullStepper(eng, lambda out, inp: dist.all_to_all_single(out, inp, group=group), gather)
-            else:
-                stepper = ShardedStepper(eng, gather)
-            return lambda k, st=None: stepper.run(k, 1, args.store if st is None else st)
-
-        comm_used = None
-        if sharded and args.comm == "torch":
-            run = torch_path()
-            comm_used = "torch.distributed(nccl)"
-        elif sharded:
-            ok = 1
-            try:
-                uid = [DeviceEnsemble.rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                ens.comm_init(rank, world, uid[0])      # ncclCommInitRank; emx_run now exchanges per half-step
-            except Exception as e:  # noqa: BLE001
-                ok = 0
-                print("[bench] library-driven RCCL unavailable on rank %d (%s); falling back to torch.distributed" % (rank, e),
-                      file=sys.stderr)
-            flag = torch.tensor([ok])
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]) == 1:
-                run = lambda k, st=None: ens.run(k, 1, args.store if st is None else st)  # noqa: E731
-                comm_used = "libemx->RCCL"
-            else:
-                try:
-                    ens.comm_destroy()
-                except Exception:  # noqa: BLE001
-                    pass
-                run = torch_path(dist.new_group(backend="nccl"))
-                comm_used = "torch.distributed(nccl) [fallback]"
-        else:
-            run = lambda k, st=None: ens.run(k, 1, args.store if st is None else st)  # noqa: E731
-
-        def fence():
-            ens.sync()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        # Untimed spin-up before the contract's W warm-up steps: the first ~50 ms of work on a fresh context run
-        # slower (clock ramp, first touch of the plan ring, lazy code-object loading); tools/stall_probe.py.
-        if sharded:
-            for _ in range(10):            # a FIXED count: every rank must issue the same collectives
-                run(5, False)
-                ens.sync()
-        else:
-            t_spin = time.perf_counter()
-            while time.perf_counter() - t_spin < 0.15:
-                run(50, False)
-                ens.sync()
-        run(W)
-        fence()
-        ens.timer_start()
-        t0 = time.perf_counter()
-        run(K)
-        gpu_ms = ens.timer_stop()          # hipEvents on the stream the kernels are launched on
-        fence()
-        wall = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device="cuda" if args.comm == "torch" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall, gpu_ms = float(t[0]), float(t[1])
-
-        res = {"wall": wall, "gpu_ms": gpu_ms, "comm": comm_used, "exchange": exchange if sharded else None,
-               "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(), "per_launch_us": None, "digest": None}
-        if sharded:
-            # every rank must hold the same ensemble, whatever the exchange: a checksum of the state
-            x, lp = ens.get_state()
-            res["digest"] = "%.17g/%.17g" % (float(np.sum(x * np.arange(1, NDIM + 1))), float(np.sum(lp)))
-            every = [None] * world
-            dist.all_gather_object(every, res["digest"])
-            res["replicas_agree"] = len(set(every)) == 1
-        else:
-            # per-launch hipEvent durations of the half-step kernel (separate pass: event records perturb)
-            ens.profile_enable(128)
-            ens.run(64, 1, False)
-            pl = ens.profile_read(128)
-            if len(pl):
-                res["per_launch_us"] = float(np.median(pl) * 1e3)
-        if sharded and comm_used == "libemx->RCCL":
-            ens.comm_destroy()
-        ens.close()
-        return res
-
-    def emit(res, extra=None):
-        nsplits = 2
-        wall, gpu_ms = res["wall"], res["gpu_ms"]
-        launches = K * nsplits
-        slots_per_launch = WALKERS_PER_GPU // nsplits                 # per GPU
-        B = 24 * NDIM + 17 + ((8 * NDIM + 8) if args.store else 0)    # algorithmic bytes / walker-update
-        avg_launch_s = gpu_ms * 1e-3 / launches                        # timed-region events / launches
+    def headline(wl, wall_s, gpu_ms, per_launch_us, accept, status, how, extra):
+        B = wl.bytes_per_update(args.store)
+        lps = wl.launches_per_step()
+        slots_per_launch = (wl.N // world) / lps                      # per GPU
+        avg_launch_s = gpu_ms * 1e-3 / (K * lps)                       # timed-region events / launches
         achieved = slots_per_launch * B / avg_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("c2_stretch_dense_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        how = ""
-        if sharded:
-            how = ", %s via %s" % ("all-to-all of the partner rows (pull exchange)" if res["exchange"] == "pull"
-                                   else "all-gather of the updated rows", res["comm"])
         line = {
             "metric": "walker-updates/sec (whole node), 64-dim correlated Gaussian, StretchMove a=2",
-            "value": n * K / wall, "unit": "walker-updates/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": wl.N * K / wall_s, "unit": "walker-updates/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall_s * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: nwalkers=%d (65536/GPU), ndim=64, dense-precision Gaussian, "
-                                   "StretchMove a=2.0, nsplits=2, rng=%s, store=%s" % (n, args.rng, args.store),
-                       "nwalkers": n, "ndim": NDIM, "parallelism": "walker-sharded x%d%s" % (world, how)},
-            "steps_per_s": K / wall, "accept_frac": res["accept_frac"], "device_status": res["status"],
+            "config": {"workload": wl.label + ", rng=%s, store=%s" % (args.rng, args.store),
+                       "nwalkers": wl.N, "ndim": wl.D, "parallelism": "walker-sharded x%d%s" % (world, how)},
+            "timing": "median of K-step blocks, each bracketed by barrier + synchronize, >= %.0f ms measured" % MIN_TIMED_MS
+                      if not args.single_block else "one K-step block",
+            "steps_per_s": K / wall_s, "accept_frac": accept, "device_status": status,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 PMC passes of an earlier run of this command, "
+                                           "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; not re-measured here)",
                          "kernel": "emx::k_halfstep<8,2,4,STRETCH,DPB=4> (G=8 lanes/walker, V=2, CH=4; f64 MFMA dense target)",
                          "algorithmic_bytes_per_walker_update": B, "walker_updates_per_launch": slots_per_launch,
-                         "avg_launch_us": avg_launch_s * 1e6, "per_launch_event_us": res["per_launch_us"],
+                         "avg_launch_us": avg_launch_s * 1e6, "per_launch_event_us": per_launch_us,
                          "note": "avg_launch_us = hipEvent time of the timed region / half-step launches: it includes the "
                                  "inter-kernel gaps and the batched plan kernel (k_native_plan_batch, 1 launch per 8 steps)"
                                  + (" and, on sharded runs, the exchange" if sharded else "") +
                                  "; per_launch_event_us brackets single half-step launches with hipEvents"},
         }
-        if extra:
-            line["exchange"] = extra
-        if world == 1 and not sharded and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(mu, cov, icov)
-        else:
-            line["cpu_baseline"] = None
+        line.update(extra)
+        return line
+
+    def emit(line):
         out = _claim_stdout()
         out.write(json.dumps(line) + "\n")
         out.flush()
 
-    def summary(r):
-        return {"ms_per_step": r["wall"] * 1e3 / K, "value": n * K / r["wall"], "comm": r["comm"], "device_status": r["status"],
-                "replicas_agree": r.get("replicas_agree")}
-
     if not sharded:
-        res = measure(None)
-        emit(res)
-    elif args.exchange != "both":
-        res = measure(args.exchange)
-        if rank == 0:
-            emit(res)
+        wl = Workload("c2", 65536)
+        res = measure_single(wl, K, W, device=local_rank, rng=args.rng, store=args.store, single_block=args.single_block)
+        extra = {"timed_blocks": res["blocks"], "best_block_ms_per_step": res["wall_min_s"] * 1e3 / K}
+        line = headline(wl, res["wall_s"], res["gpu_ms"], res["per_launch_us"], res["accept_frac"], res["status"], "", extra)
+        _PARTIAL["line"] = line
+        if not args.no_extras:
+            cfgs = {}
+            plan = [("c3", 262144, False), ("c4", 65536, False), ("c5", 16384, False), ("c2", 65536, True)]
+            for key, n, st in plan:
+                if args.config not in ("all", key):
+                    continue
+                name = {"c3": "c3_262144x32_rosen", "c4": "c4_de_snooker", "c5": "c5_16384x1024_diag", "c2": "c2_store"}[key]
+                try:
+                    w2 = wl if key == "c2" else Workload(key, n)
+                    Ks = K if not st else min(K, 200)          # stored chain: 33.5 MB per step
+                    r2 = measure_single(w2, Ks, min(W, Ks), device=local_rank, rng="philox", store=st, single_block=args.single_block)
+                    cfgs[name] = config_entry(w2, r2, Ks, st)
+                except Exception as e:  # noqa: BLE001
+                    cfgs[name] = {"error": repr(e)}
+                    log("config %s failed: %r" % (name, e))
+            line["configs"] = cfgs
+            try:
+                line["exact_mode"] = exact_mode_entry(wl, K, W, local_rank)
+            except Exception as e:  # noqa: BLE001
+                line["exact_mode"] = {"error": repr(e)}
+            try:
+                line["quality"] = quality_entry(local_rank)
+            except Exception as e:  # noqa: BLE001
+                line["quality"] = {"error": repr(e)}
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(wl)
+        emit(line)
+        return
+
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.comm == "torch":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
-        # Both protocols, identical seed and step count: the all-gather result is in hand before the pull
-        # exchange is tried, and a watchdog falls back to it if that attempt does not come back.
-        res_ag = measure("allgather")
-        import threading
-        done = threading.Event()
+        dist.init_process_group("gloo")      # bootstrap / barriers only; the data path is libemx -> RCCL
 
-        def bail():
-            if done.is_set():
+    keys = ["c2", "c3", "c5"] if args.config == "all" else [args.config if args.config != "c4" else "c2"]
+    if "c2" not in keys:
+        keys = ["c2"] + keys                 # the headline is always C2
+    multi = {}
+    line = None
+    for key in keys:
+        wl, best, entry = sharded_config(key, world, K, W, rank, local_rank, dist, args)
+        multi[{"c2": "c2_weak_65536_per_gpu", "c3": "c3_262144x32_rosen_sharded", "c5": "c5_16384x1024_strong"}[key]
+              if args.scaling == "auto" else "%s_%s" % (key, entry["scaling"])] = entry
+        if key == "c2":
+            if best is None:
+                if rank == 0:
+                    emit({"metric": "walker-updates/sec (whole node), 64-dim correlated Gaussian, StretchMove a=2", "value": None,
+                          "unit": "walker-updates/s", "n_gpus": world, "steps": K, "warmup": W, "error": entry["exchange"]})
+                dist.barrier()
+                dist.destroy_process_group()
                 return
-            if rank == 0:
-                emit(res_ag, {"allgather": summary(res_ag), "pull": "no result after %.0f s" % args.pull_timeout,
-                              "reported": "allgather"})
-            sys.stdout.flush()
-            os._exit(0)
-
-        timer = threading.Timer(args.pull_timeout, bail)
-        timer.daemon = True
-        timer.start()
-        res_pull, err = None, None
-        try:
-            res_pull = measure("pull")
-        except Exception as e:  # noqa: BLE001
-            err = repr(e)
-        done.set()
-        timer.cancel()
-        if rank == 0:
-            extra = {"allgather": summary(res_ag)}
-            best = res_ag
-            if res_pull is None:
-                extra["pull"] = "failed: %s" % err
-            else:
-                extra["pull"] = summary(res_pull)
-                same = res_pull["digest"] == res_ag["digest"] and res_pull["status"] == 0 and bool(res_pull.get("replicas_agree"))
-                extra["same_final_state"] = same
-                if same and res_pull["wall"] < res_ag["wall"]:
-                    best = res_pull
-            extra["reported"] = best["exchange"]
-            emit(best, extra)
-        if res_pull is None:          # a rank that failed must not leave the others in a collective
-            sys.stdout.flush()
-            os._exit(0 if rank == 0 else 1)
-
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            how = ", %s via %s" % ({"pull": "all-to-all of the partner rows (pull exchange)",
+                                    "allgather": "all-gather of the updated rows"}.get(best["exchange"], best["exchange"]), best["comm"])
+            line = headline(wl, best["wall_s"], best["gpu_ms"], None, best["accept_frac"], best["status"], how,
+                            {"timed_blocks": best["blocks"]})
+            line["scaling"] = entry["scaling"]
+            line["cpu_baseline"] = None
+            line["multi_gpu"] = multi
+            _PARTIAL["line"] = line
+    if rank == 0 and line is not None:
+        line["multi_gpu"] = multi
+        emit(line)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -7,8 +7,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip")]     # two translation units, built in parallel
 SRC = SRCS[0]
 LIB = os.path.join(HERE, "libemx.so")
-DEPS = SRCS + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_rng.hpp", "mt19937_legacy.hpp")] + [
+HOST_SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx_mtpipe.cpp",)]       # plain host C++ (threads, SIMD clones): no device pass
+DEPS = SRCS + HOST_SRCS + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_rng.hpp", "mt19937_legacy.hpp",
+                                                                  "emx_mtpipe.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "emx.h")]
+HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread"]
 # -ffp-contract=off: the proposal arithmetic must round like NumPy's separate multiply/subtract.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-fPIC"]
 
@@ -18,7 +21,7 @@ HASHFILE = LIB + ".srchash"
 
 def _source_hash():
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256(" ".join(FLAGS + HOST_FLAGS).encode())
     for d in DEPS:
         with open(d, "rb") as f:
             h.update(f.read())
@@ -48,11 +51,21 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
         objs.append(obj)
+    hostcxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(hostcxx):
+        hostcxx = shutil.which("amdclang++") or shutil.which("clang++") or shutil.which("g++")
+    for src in HOST_SRCS:
+        obj = os.path.join(HERE, os.path.basename(src) + ".o")
+        cmd = [hostcxx] + HOST_FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        objs.append(obj)
     for cmd, pr in procs:
         _, err = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + err[-4000:])
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl"]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl", "-pthread"]
     if verbose:
         print(" ".join(link))
     r = subprocess.run(link, capture_output=True, text=True)

@@ -106,6 +106,8 @@ SIGNATURES = {
     "emx_mt_shuffle_labels": (None, [_P, C.c_int64, C.c_int32, _ip]),
     "emx_mt_choice_cdf": (C.c_int32, [_P, _dp, C.c_int32]),
     "emx_host_plan_mt": (C.c_int, [_P, C.c_int64, C.c_int32, C.POINTER(MoveDesc), _ip, _ip, _ip, _ip, _ip, _dp, _dp]),
+    "emx_host_plan_mt_stream": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(MoveDesc), _dp, C.c_int64, C.c_int32, C.c_int32,
+                                          _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_double)]),
     "emx_host_split_draws": (C.c_int, [_P, C.c_int64, C.POINTER(MoveDesc), _ip, _ip, C.c_int32, _ip, _ip, _ip, _dp]),
     "emx_host_plan_philox": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(MoveDesc), _ip, _ip, _ip, _ip, _ip, _dp, _dp]),
     "emx_host_move_choice_philox": (C.c_int32, [C.c_uint64, C.c_uint64, _dp, C.c_int32]),

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -16,6 +17,7 @@
 
 #include "../../include/emx.h"
 #include "emx_kernels.hpp"
+#include "emx_mtpipe.hpp"
 #include "emx_rng.hpp"
 #include "mt19937_legacy.hpp"
 
@@ -31,23 +33,6 @@ constexpr int PLAN_RING = 16;
 // exact (NumPy-stream) plan of one step: every draw red_blue.py / stretch.py / de.py /
 // de_snooker.py make for one propose(), in their order.
 // ------------------------------------------------------------------------------------------
-inline void de_pair(uint64_t k, uint64_t nc, uint64_t& first, uint64_t& second) {
-    // moves/de.py:67-77 in closed form
-    const uint64_t T = nc * (nc - 1) / 2;
-    const uint64_t kk = k < T ? k : k - T;
-    uint64_t i = (uint64_t)((1.0 + std::sqrt(1.0 + 8.0 * (double)kk)) / 2.0);
-    while (i * (i - 1) / 2 > kk) --i;
-    while ((i + 1) * i / 2 <= kk) ++i;
-    const uint64_t j = kk - i * (i - 1) / 2;
-    if (k < T) {
-        first = i;
-        second = j;
-    } else {
-        first = j;
-        second = i;
-    }
-}
-
 // proposal draws of ONE get_proposal call (stretch.py:30-32 | de.py:49-56 | de_snooker.py:37-40)
 template <typename I32, typename F64>
 int draw_split_proposal(MT19937Legacy& mt, int64_t N, const emx_move_desc& mv, const int32_t* off, const I32* order,
@@ -329,8 +314,16 @@ struct emx_ctx {
         double *s0 = nullptr, *uacc = nullptr, *logu = nullptr, *fac = nullptr;
         char* host = nullptr;  // pinned: [order|p0|p1|p2](int32 N each) [s0|uacc](double N each)
         hipEvent_t consumed = nullptr;
+        hipEvent_t uploaded = nullptr;     // pipeline uploads: copy + logs done on the upload stream
         bool busy = false, host_written = false;
     } ring[PLAN_RING];
+    // exact-mode plan pipeline (emx_mtpipe.hpp): alive only inside emx_run
+    MtPlanPipeline* pipe = nullptr;
+    int64_t pipe_taken = 0;              // steps whose plan emx_step_begin has taken
+    int pipe_ring0 = 0;                  // ring slot of pipeline step 0
+    std::deque<int64_t> pipe_uploads;    // steps whose upload is enqueued and not yet known to be complete
+    hipStream_t up_stream = nullptr;     // plan uploads overlap the previous step's kernels
+    int64_t tune_mt_pipeline = -1;       // -1: on, finisher threads chosen from the core count; 0: off; k > 0: k finishers
     int ring_pos = 0;
     struct Prepared {   // native plans already evaluated on the device, in step order
         int move, S, slot;
@@ -761,6 +754,7 @@ int emx_destroy(emx_ctx* c) {
     for (auto& s : c->ring) {
         if (s.order) hipFree(s.order);       // the slot's single block
         if (s.host) hipHostFree(s.host);
+        if (s.uploaded) hipEventDestroy(s.uploaded);
         if (s.consumed) hipEventDestroy(s.consumed);
     }
     for (auto& g : c->gslot) {
@@ -792,6 +786,8 @@ int emx_destroy(emx_ctx* c) {
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (auto e : c->prof) hipEventDestroy(e);
+    if (c->pipe) delete c->pipe, c->pipe = nullptr;
+    if (c->up_stream) hipStreamDestroy(c->up_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -843,6 +839,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "gauss_materialize")) {
         c->tune_gauss_materialize = v;
+        return 0;
+    }
+    if (!strcmp(key, "mt_pipeline")) {   // exact mode: -1 auto, 0 plans made inline by the calling thread, k > 0 finisher threads
+        c->tune_mt_pipeline = v;
         return 0;
     }
     if (!strcmp(key, "throttle")) {
@@ -897,24 +897,30 @@ int emx_get_accepted(emx_ctx* c, uint8_t* mask) {
 int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1, double scale) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, kind >= EMX_TARGET_HOST && kind <= EMX_TARGET_BOX, "unknown target kind %d", kind);
-    HIPOK(c, hipStreamSynchronize(c->stream));
-    if (c->tp0) hipFree(c->tp0), c->tp0 = nullptr;
-    if (c->tp1) hipFree(c->tp1), c->tp1 = nullptr;
+    // Everything that can fail (argument checks, the Cholesky factorisation, allocations, uploads) happens on
+    // fresh buffers; the context's target is replaced only once the new one is complete, so a refused target
+    // leaves the previous one fully usable.
     const size_t D = (size_t)c->D;
+    double *ntp0 = nullptr, *ntp1 = nullptr;
+    int nDp = c->Dp;
+    struct Guard {          // frees the new buffers on every early return
+        double*& a;
+        double*& b;
+        ~Guard() {
+            if (a) hipFree(a);
+            if (b) hipFree(b);
+        }
+    } guard{ntp0, ntp1};
     if (kind == EMX_TARGET_DIAG_GAUSS || kind == EMX_TARGET_DENSE_GAUSS) {
         NEED(c, p0 && p1, "target needs (mu, ivar|icov)");
-        const size_t n1 = kind == EMX_TARGET_DENSE_GAUSS ? D * D : D;
+        std::vector<double> img;
         if (kind == EMX_TARGET_DENSE_GAUSS) {
-            c->Dp = (int)((D + 15) / 16 * 16);
-            NEED(c, c->Dp <= 112 && dense_lds_bytes(c->Dp, 1) <= 160 * 1024,
+            nDp = (int)((D + 15) / 16 * 16);
+            NEED(c, nDp <= 112 && dense_lds_bytes(nDp, 1) <= 160 * 1024,
                  "dense Gaussian target supports ndim <= 112 (LDS-resident precision matrix); got %d", c->D);
-        }
-        HIPOK(c, hipMalloc((void**)&c->tp0, D * 8));
-        HIPOK(c, hipMemcpy(c->tp0, p0, D * 8, hipMemcpyHostToDevice));
-        if (kind == EMX_TARGET_DENSE_GAUSS) {
             // -0.5 d^T A d with A = sym(icov) = L L^T  ==  -0.5 |L^T d|^2.  Factor once on the host and upload the
             // image the kernel stages into LDS: L in MFMA B-fragment order (zero padded) followed by the mean.
-            const int Dp = c->Dp, KK = Dp / 4, n = (int)D;
+            const int Dp = nDp, KK = Dp / 4, n = (int)D;
             std::vector<double> Lm((size_t)n * n, 0.0);
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j <= i; ++j) {
@@ -928,7 +934,7 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
                         Lm[(size_t)i * n + j] = sum / Lm[(size_t)j * n + j];
                     }
                 }
-            std::vector<double> img((size_t)Dp * Dp + Dp, 0.0);
+            img.assign((size_t)Dp * Dp + Dp, 0.0);
             for (int nb = 0; nb < Dp / 16; ++nb)
                 for (int kk = 0; kk < KK; ++kk)
                     for (int l = 0; l < 64; ++l) {
@@ -936,13 +942,18 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
                         if (k < n && col < n && k >= col) img[((size_t)nb * KK + kk) * 64 + l] = Lm[(size_t)k * n + col];
                     }
             for (int d = 0; d < n; ++d) img[(size_t)Dp * Dp + d] = p0[d];
-            HIPOK(c, hipMalloc((void**)&c->tp1, img.size() * 8));
-            HIPOK(c, hipMemcpy(c->tp1, img.data(), img.size() * 8, hipMemcpyHostToDevice));
-        } else {
-            HIPOK(c, hipMalloc((void**)&c->tp1, n1 * 8));
-            HIPOK(c, hipMemcpy(c->tp1, p1, n1 * 8, hipMemcpyHostToDevice));
         }
+        HIPOK(c, hipMalloc((void**)&ntp0, D * 8));
+        HIPOK(c, hipMemcpy(ntp0, p0, D * 8, hipMemcpyHostToDevice));
+        const double* src1 = kind == EMX_TARGET_DENSE_GAUSS ? img.data() : p1;
+        const size_t n1 = kind == EMX_TARGET_DENSE_GAUSS ? img.size() : D;
+        HIPOK(c, hipMalloc((void**)&ntp1, n1 * 8));
+        HIPOK(c, hipMemcpy(ntp1, src1, n1 * 8, hipMemcpyHostToDevice));
     }
+    HIPOK(c, hipStreamSynchronize(c->stream));      // no kernel still reads the old parameters
+    std::swap(c->tp0, ntp0);                        // the guard now frees the OLD buffers
+    std::swap(c->tp1, ntp1);
+    c->Dp = nDp;
     graph_invalidate(c);
     c->graph_warm = false;
     c->target = kind;
@@ -988,6 +999,10 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
         NEED(c, moves[i].nsplits >= 2 && moves[i].nsplits <= 64, "nsplits must be in [2, 64]");
         NEED(c, moves[i].kind != EMX_MOVE_SNOOKER || moves[i].nsplits >= 4, "snooker needs nsplits >= 4");
         NEED(c, moves[i].nsplits <= c->N, "more splits than walkers");
+        // DE draws two distinct complement members (de.py:49): refuse a complement of one in every RNG mode
+        // (the native slot function would reduce modulo zero)
+        NEED(c, moves[i].kind != EMX_MOVE_DE || c->N - (c->N + moves[i].nsplits - 1) / moves[i].nsplits >= 2,
+             "complement too small for this move");
     }
     c->moves.assign(moves, moves + nmoves);
     c->cdf.assign(cdf, cdf + nmoves);
@@ -1213,6 +1228,86 @@ static int gauss_native_disp(emx_ctx* c, int mi, uint64_t step, const int32_t* c
 }
 
 static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32_t* move_out, int32_t* S_out);
+static bool small_eligible(const emx_ctx* c);
+
+// ---- exact-mode plan pipeline (emx_mtpipe.hpp) -----------------------------------------------------------------
+// retire completed uploads: the pinned staging buffer of such a step may be rewritten by the tokenizer
+static void pipe_poll(void* arg) {
+    emx_ctx* c = (emx_ctx*)arg;
+    while (!c->pipe_uploads.empty()) {
+        const int64_t n = c->pipe_uploads.front();
+        auto& s = c->ring[(c->pipe_ring0 + n) % PLAN_RING];
+        if (hipEventQuery(s.uploaded) != hipSuccess) break;
+        c->pipe->release(n);
+        c->pipe_uploads.pop_front();
+    }
+}
+
+static int pipe_start(emx_ctx* c, int64_t nsteps) {
+    const size_t N = (size_t)c->N;
+    if (!c->up_stream) HIPOK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    HIPOK(c, hipStreamSynchronize(c->stream));          // no earlier copy still reads a staging buffer
+    PlanSink sinks[PLAN_RING];
+    c->pipe_ring0 = (c->ring_pos + 1) % PLAN_RING;
+    for (int r = 0; r < PLAN_RING; ++r) {
+        auto& s = c->ring[(c->pipe_ring0 + r) % PLAN_RING];
+        s.busy = false;
+        if (!s.host) HIPOK(c, hipHostMalloc((void**)&s.host, N * 32, hipHostMallocDefault));
+        if (!s.uploaded) HIPOK(c, hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+        int32_t* hi = (int32_t*)s.host;
+        double* hd = (double*)(s.host + N * 16);
+        sinks[r].order = hi;
+        sinks[r].p0 = hi + N;
+        sinks[r].p1 = hi + 2 * N;
+        sinks[r].p2 = hi + 3 * N;
+        sinks[r].s0 = hd;
+        sinks[r].uacc = hd + N;
+    }
+    c->pipe_taken = 0;
+    c->pipe_uploads.clear();
+    c->pipe = new MtPlanPipeline(c->mt, c->N, c->D, (int32_t)c->moves.size(), c->moves.data(), c->cdf.data(), nsteps, sinks,
+                                 PLAN_RING, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0));
+    return 0;
+}
+
+// stop the threads; the context's generator continues from the end of the last step taken
+static void pipe_stop(emx_ctx* c) {
+    if (!c->pipe) return;
+    c->pipe->finish(c->pipe_taken, c->mt);
+    delete c->pipe;
+    c->pipe = nullptr;
+    c->pipe_uploads.clear();
+}
+
+// emx_step_begin's part: wait for the next plan, send it up on the upload stream, order the kernels behind it
+static int pipe_take(emx_ctx* c) {
+    auto& cur = c->cur;
+    const int64_t n = c->pipe_taken;
+    PipeStepInfo info;
+    pipe_poll(c);
+    if (!c->pipe->wait_ready(n, info, pipe_poll, c)) FAIL(c, -7, "exact-mode plan pipeline stopped before step %lld", (long long)n);
+    const int slot = (int)((c->pipe_ring0 + n) % PLAN_RING);
+    auto& s = c->ring[slot];
+    cur.move = info.move;
+    cur.S = info.S;
+    cur.slot = slot;
+    cur.off.assign(info.off, info.off + info.S + 1);
+    const size_t N = (size_t)c->N;
+    // the device copy of this slot was last read by the kernels of step n - PLAN_RING
+    if (s.busy) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed, 0));
+    HIPOK(c, hipMemcpyAsync(s.order, s.host, N * 32, hipMemcpyHostToDevice, c->up_stream));
+    const int stretch = c->moves[cur.move].kind == EMX_MOVE_STRETCH;
+    hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->up_stream, (int)N, (int)c->D, stretch, s.s0,
+                       s.uacc, s.logu, s.fac);
+    HIPOK(c, hipGetLastError());
+    HIPOK(c, hipEventRecord(s.uploaded, c->up_stream));
+    HIPOK(c, hipStreamWaitEvent(c->stream, s.uploaded, 0));
+    s.host_written = true;
+    c->pipe_uploads.push_back(n);
+    c->pipe_taken = n + 1;
+    c->ring_pos = slot;
+    return 0;
+}
 
 int emx_step_begin(emx_ctx* c, int32_t store, int32_t* move_out, int32_t* S_out) {
     return step_begin_impl(c, store, -1, move_out, S_out);
@@ -1231,7 +1326,12 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
     cur.store = store != 0;
     cur.native = false;
     const int nm = (int)c->moves.size();
-    if (c->rng_mode == EMX_RNG_MT19937) {
+    if (c->rng_mode == EMX_RNG_MT19937 && c->pipe) {
+        // emx_run in exact mode: the plan of this step was made by the pipeline threads (same draws, same order)
+        NEED(c, forced_move < 0, "a forced move cannot be taken from the plan pipeline");
+        int rc = pipe_take(c);
+        if (rc) return rc;
+    } else if (c->rng_mode == EMX_RNG_MT19937) {
         cur.move = forced_move >= 0 ? forced_move : c->mt.choice_cdf(c->cdf.data(), nm);   // ensemble.py:406
         const emx_move_desc& mv = c->moves[cur.move];
         cur.S = mv.nsplits;
@@ -1474,6 +1574,7 @@ int emx_accept(emx_ctx* c, int32_t split, const double* new_lp) {
     HIPOK(c, hipSetDevice(c->device));
     auto& cur = c->cur;
     NEED(c, cur.active && cur.move >= 0, "emx_accept outside a planned step");
+    NEED(c, split >= 0 && split < cur.S, "emx_accept: split %d out of range (the step has %d)", split, cur.S);
     const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
     if (ns <= 0) return 0;
     HIPOK(c, hipMemcpyAsync(c->newlp, new_lp, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
@@ -1860,8 +1961,27 @@ static int rccl_all_to_all(emx_ctx* c, size_t count) {
     return 0;
 }
 
+static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store);
+
 int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     HIPOK(c, hipSetDevice(c->device));
+    NEED(c, thin_by >= 1, "Invalid thinning argument");
+    NEED(c, !c->cur.active, "emx_run: a step begun with emx_step_begin is still open");
+    const int64_t total = nsteps * thin_by;
+    // exact mode, general path: the plans of the whole call come from the host pipeline (generator / tokenizer /
+    // finisher threads) instead of being made inline, one step at a time, by this thread
+    const bool piped = c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_pipeline != 0 && total >= 2 && c->target != EMX_TARGET_HOST &&
+                       !small_eligible(c) && MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
+    if (piped) {
+        const int rc = pipe_start(c, total);
+        if (rc) return rc;
+    }
+    const int rc = run_impl(c, nsteps, thin_by, store);
+    if (piped) pipe_stop(c);
+    return rc;
+}
+
+static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     NEED(c, thin_by >= 1, "Invalid thinning argument");
     NEED(c, c->rng_mode != EMX_RNG_INPUTS, "emx_run needs an RNG mode that generates plans");
     NEED(c, c->target != EMX_TARGET_HOST, "emx_run needs a device target");
@@ -2483,6 +2603,47 @@ int emx_host_plan_mt(emx_mt* m, int64_t N, int32_t D, const emx_move_desc* mv, i
                      int32_t* p1, int32_t* p2, double* s0, double* uacc) {
     std::vector<uint8_t> labels;
     return make_exact_plan(m->mt, N, D, *mv, labels, off, order, p0, p1, p2, s0, uacc);
+}
+
+int emx_host_plan_mt_stream(emx_mt* m, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves, const double* cdf,
+                            int64_t nsteps, int32_t nworkers, int32_t nsinks, int32_t* moves_out, int32_t* order, int32_t* p0,
+                            int32_t* p1, int32_t* p2, double* s0, double* uacc, double* seconds_out) {
+    if (!m || N < 2 || nsteps < 1 || nsinks < 1 || !MtPlanPipeline::supports(nmoves, moves)) return -1;
+    for (int i = 0; i < nmoves; ++i)
+        if (moves[i].kind == EMX_MOVE_DE && N - (N + moves[i].nsplits - 1) / moves[i].nsplits < 2) return -1;
+    // staging buffers laid out like a plan slot's pinned block; the consumer below plays emx_run's part
+    std::vector<std::vector<char>> stage((size_t)nsinks, std::vector<char>((size_t)N * 32));
+    std::vector<PlanSink> sinks((size_t)nsinks);
+    for (int r = 0; r < nsinks; ++r) {
+        int32_t* hi = (int32_t*)stage[r].data();
+        double* hd = (double*)(stage[r].data() + (size_t)N * 16);
+        sinks[r].order = hi;
+        sinks[r].p0 = hi + N;
+        sinks[r].p1 = hi + 2 * N;
+        sinks[r].p2 = hi + 3 * N;
+        sinks[r].s0 = hd;
+        sinks[r].uacc = hd + N;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    MtPlanPipeline pipe(m->mt, N, D, nmoves, moves, cdf, nsteps, sinks.data(), nsinks, nworkers);
+    int64_t n = 0;
+    for (; n < nsteps; ++n) {
+        PipeStepInfo info;
+        if (!pipe.wait_ready(n, info)) break;
+        if (moves_out) moves_out[n] = info.move;
+        const PlanSink& sk = sinks[n % nsinks];
+        const size_t o = (size_t)n * (size_t)N;
+        if (order) memcpy(order + o, sk.order, (size_t)N * 4);
+        if (p0) memcpy(p0 + o, sk.p0, (size_t)N * 4);
+        if (p1) memcpy(p1 + o, sk.p1, (size_t)N * 4);
+        if (p2) memcpy(p2 + o, sk.p2, (size_t)N * 4);
+        if (s0) memcpy(s0 + o, sk.s0, (size_t)N * 8);
+        if (uacc) memcpy(uacc + o, sk.uacc, (size_t)N * 8);
+        pipe.release(n);
+    }
+    pipe.finish(n, m->mt);
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return n == nsteps ? pipe.workers() : -7;
 }
 
 int emx_host_split_draws(emx_mt* m, int64_t N, const emx_move_desc* mv, const int32_t* off, const int32_t* order,

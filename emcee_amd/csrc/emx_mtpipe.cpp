@@ -1,0 +1,648 @@
+// Exact-mode plan pipeline (see emx_mtpipe.hpp).  Plain host C++: compiled with -ffp-contract=off so that the few
+// floating-point expressions (zz, polar radius, gamma) round exactly like NumPy's separate operations.
+#include "emx_mtpipe.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace emx {
+namespace {
+
+#if defined(__x86_64__) && defined(__clang__)
+#define EMX_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define EMX_CLONES
+#endif
+
+constexpr int BLK = 624;
+constexpr uint64_t NBLK = 2048;          // generator ring: 2048 blocks = 1.28 M words (5 MB) + the same for the raw keys
+constexpr int MAX_SPLITS = 64;
+
+struct Backoff {
+    int n = 0;
+    inline void pause() {
+        if (n < 256) {
+            ++n;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        } else if (n < 512) {
+            ++n;
+            std::this_thread::yield();
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(40));
+        }
+    }
+};
+
+// ---- the MT19937 recurrence, out of place so that every loop is a plain vectorisable map -------------------------
+EMX_CLONES void twist_block(const uint32_t* __restrict o, uint32_t* __restrict n) {
+    constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX = 0x9908b0dfu;
+    for (int kk = 0; kk < 227; ++kk) {
+        const uint32_t y = (o[kk] & UPPER) | (o[kk + 1] & LOWER);
+        n[kk] = o[kk + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX);
+    }
+    for (int kk = 227; kk < 454; ++kk) {                     // reads n[0, 227): written above
+        const uint32_t y = (o[kk] & UPPER) | (o[kk + 1] & LOWER);
+        n[kk] = n[kk - 227] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX);
+    }
+    for (int kk = 454; kk < 623; ++kk) {                     // reads n[227, 396)
+        const uint32_t y = (o[kk] & UPPER) | (o[kk + 1] & LOWER);
+        n[kk] = n[kk - 227] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX);
+    }
+    const uint32_t y = (o[623] & UPPER) | (n[0] & LOWER);
+    n[623] = n[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX);
+}
+
+EMX_CLONES void temper_block(const uint32_t* __restrict k, uint32_t* __restrict out) {
+    for (int i = 0; i < BLK; ++i) {
+        uint32_t y = k[i];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        out[i] = y;
+    }
+}
+
+// random_sample() of consecutive word pairs
+EMX_CLONES void convert_pairs(const uint32_t* __restrict w, double* __restrict dst, int64_t n) {
+    for (int64_t e = 0; e < n; ++e) {
+        const int32_t a = (int32_t)(w[2 * e] >> 5), b = (int32_t)(w[2 * e + 1] >> 6);
+        dst[e] = (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+}
+
+// stretch.py:30  zz = ((a - 1) * u + 1) ** 2 / a
+EMX_CLONES void stretch_zz(double* __restrict s, int64_t n, double a) {
+    for (int64_t t = 0; t < n; ++t) {
+        const double tt = (a - 1.0) * s[t] + 1.0;
+        s[t] = tt * tt / a;
+    }
+}
+
+struct WordStream {
+    std::vector<uint32_t> ring;      // tempered words, NBLK blocks
+    std::vector<uint32_t> kring;     // the matching untempered state words (generator state after each twist)
+    alignas(64) std::atomic<uint64_t> produced{0};     // blocks produced
+    alignas(64) std::atomic<uint64_t> keep{0};         // lowest block the reader may still touch
+    std::atomic<bool> stop{false};
+};
+
+void generator_main(WordStream* ws, const uint32_t* start_key) {
+    // block 0 is the block the caller's generator currently stands in (no twist)
+    std::memcpy(&ws->kring[0], start_key, BLK * 4);
+    temper_block(&ws->kring[0], &ws->ring[0]);
+    ws->produced.store(1, std::memory_order_release);
+    Backoff bo;
+    for (uint64_t b = 1; !ws->stop.load(std::memory_order_relaxed);) {
+        if (b - ws->keep.load(std::memory_order_acquire) >= NBLK - 1) {
+            bo.pause();
+            continue;
+        }
+        bo.n = 0;
+        const uint32_t* prev = &ws->kring[((b - 1) % NBLK) * BLK];
+        uint32_t* cur = &ws->kring[(b % NBLK) * BLK];
+        twist_block(prev, cur);
+        temper_block(cur, &ws->ring[(b % NBLK) * BLK]);
+        ws->produced.store(b + 1, std::memory_order_release);
+        ++b;
+    }
+}
+
+// the tokenizer's view of the stream
+struct Reader {
+    WordStream* ws;
+    const uint32_t *base = nullptr, *cur = nullptr, *end = nullptr;
+    uint64_t a_base = 0;          // absolute index of *base
+    const std::atomic<bool>* stop;
+    bool dead = false;
+
+    uint64_t pos() const { return a_base + (uint64_t)(cur - base); }
+
+    void seek(uint64_t a) {
+        a_base = a;
+        base = cur = end = nullptr;
+    }
+
+    // make at least one word available at the current position (waits for the generator)
+    void refill() {
+        const uint64_t a = pos();
+        ws->keep.store(a > 0 ? (a - 1) / BLK : 0, std::memory_order_release);
+        Backoff bo;
+        uint64_t prod;
+        while ((prod = ws->produced.load(std::memory_order_acquire)) * BLK <= a) {
+            if (stop->load(std::memory_order_relaxed)) {
+                dead = true;
+                static const uint32_t zeros[2] = {0, 0};
+                base = cur = zeros;
+                end = zeros + 2;
+                a_base = a;
+                return;
+            }
+            bo.pause();
+        }
+        const uint64_t ring_words = NBLK * BLK;
+        const uint64_t off = a % ring_words;
+        const uint64_t n = std::min<uint64_t>(prod * BLK - a, ring_words - off);
+        base = cur = &ws->ring[off];
+        end = cur + n;
+        a_base = a;
+    }
+    inline size_t avail() {
+        if (cur == end) refill();
+        return (size_t)(end - cur);
+    }
+    inline uint32_t next32() {
+        if (__builtin_expect(cur == end, 0)) refill();
+        return *cur++;
+    }
+    inline uint64_t next64() {
+        const uint64_t hi = next32();
+        const uint64_t lo = next32();
+        return (hi << 32) | lo;
+    }
+    inline double next_double() {
+        const int32_t a = (int32_t)(next32() >> 5), b = (int32_t)(next32() >> 6);
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    // distributions.c random_interval(): masked rejection in [0, max]
+    inline uint64_t random_interval(uint64_t max) {
+        if (max == 0) return 0;
+        uint64_t mask = max, value;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        mask |= mask >> 32;
+        if (max <= 0xffffffffull) {
+            while ((value = (next32() & mask)) > max && !dead) {
+            }
+        } else {
+            while ((value = (next64() & mask)) > max && !dead) {
+            }
+        }
+        return value;
+    }
+    // RandomState.randint(0, n) element
+    inline uint64_t randint(uint64_t n) {
+        const uint64_t rng = n - 1;
+        if (rng == 0) return 0;
+        if (rng <= 0xffffffffull) {
+            if (rng == 0xffffffffull) return next32();
+            uint64_t mask = rng;
+            mask |= mask >> 1;
+            mask |= mask >> 2;
+            mask |= mask >> 4;
+            mask |= mask >> 8;
+            mask |= mask >> 16;
+            uint32_t val;
+            do {
+                val = next32() & (uint32_t)mask;
+            } while (val > rng && !dead);
+            return val;
+        }
+        if (rng == 0xffffffffffffffffull) return next64();
+        uint64_t mask = rng, val;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        mask |= mask >> 32;
+        do {
+            val = next64() & mask;
+        } while (val > rng && !dead);
+        return val;
+    }
+    // n consecutive random_sample() values
+    void fill_doubles(double* dst, int64_t n) {
+        int64_t k = 0;
+        while (k < n && !dead) {
+            const size_t av = avail();
+            if (av < 2) {                    // the window ends in the middle of a pair
+                dst[k++] = next_double();
+                continue;
+            }
+            const int64_t take = std::min<int64_t>((int64_t)(av / 2), n - k);
+            convert_pairs(cur, dst + k, take);
+            cur += 2 * take;
+            k += take;
+        }
+    }
+    // n consecutive randint(0, bound) values (32-bit results: bound <= 2^32)
+    void fill_randint32(int32_t* dst, int64_t n, uint64_t bound) {
+        const uint64_t rng = bound - 1;
+        if (rng == 0) {
+            for (int64_t k = 0; k < n; ++k) dst[k] = 0;
+            return;
+        }
+        if (rng >= 0xffffffffull) {
+            for (int64_t k = 0; k < n; ++k) dst[k] = (int32_t)randint(bound);
+            return;
+        }
+        uint32_t mask = (uint32_t)rng;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        mask |= mask >> 8;
+        mask |= mask >> 16;
+        int64_t k = 0;
+        if (mask == (uint32_t)rng) {         // power-of-two bound: no rejection, a masked copy
+            while (k < n && !dead) {
+                const int64_t take = std::min<int64_t>((int64_t)avail(), n - k);
+                for (int64_t e = 0; e < take; ++e) dst[k + e] = (int32_t)(cur[e] & mask);
+                cur += take;
+                k += take;
+            }
+            return;
+        }
+        while (k < n && !dead) {
+            const size_t av = avail();
+            const uint32_t* p = cur;
+            const uint32_t* pe = cur + av;
+            while (p < pe && k < n) {
+                const uint32_t v = *p++ & mask;
+                dst[k] = (int32_t)v;          // branch-free compaction: a rejected value is overwritten by the next
+                k += (v <= (uint32_t)rng);
+            }
+            cur = p;
+        }
+    }
+    // RandomState.shuffle of n items: the accepted swap target of every i = n-1 .. 1
+    void shuffle_targets(uint32_t* j, int64_t n) {
+        int64_t i = n - 1;
+        while (i > 0 && (uint64_t)i > 0xffffffffull) {
+            j[i] = (uint32_t)random_interval((uint64_t)i);     // unreachable for int32 walker counts
+            --i;
+        }
+        while (i > 0 && !dead) {
+            uint32_t mask = (uint32_t)i;
+            mask |= mask >> 1;
+            mask |= mask >> 2;
+            mask |= mask >> 4;
+            mask |= mask >> 8;
+            mask |= mask >> 16;
+            const int64_t lo = (int64_t)(mask >> 1);           // i in (lo, mask] share this mask
+            while (i > lo && !dead) {
+                const size_t av = avail();
+                const uint32_t* p = cur;
+                const uint32_t* pe = cur + av;
+                while (p < pe && i > lo) {
+                    const uint32_t v = *p++ & mask;
+                    j[i] = v;                                   // a rejected draw is overwritten by the next one
+                    i -= (int64_t)(v <= (uint32_t)i);
+                }
+                cur = p;
+            }
+        }
+    }
+};
+
+struct RawStep {               // tokens of one step that do not already sit in the plan sink
+    std::vector<uint32_t> j;   // Fisher-Yates targets
+    std::vector<uint64_t> k64; // DE: pair codes (de.py:49)
+    std::vector<double> gx, gr2;  // DE: polar-method tokens of randn (de.py:56): normal = gx * sqrt(-2 ln r2 / r2), r2 < 0: gx itself
+    std::vector<uint8_t> perm; // snooker: shuffle(w) draws, j2 | j1 << 2
+};
+
+}  // namespace
+
+struct MtPlanPipeline::Impl {
+    int64_t N = 0, nsteps = 0;
+    int32_t D = 0;
+    std::vector<emx_move_desc> moves;
+    std::vector<double> cdf;
+    std::vector<PlanSink> sinks;
+    int nsinks = 0, K = 1, NR = 0, NSNAP = 0;
+    MT19937Legacy start;
+    WordStream ws;
+    std::vector<RawStep> raws;
+    std::vector<PipeStepInfo> infos;               // [nsinks]
+    std::vector<MT19937Legacy> snaps;              // [NSNAP]
+    // sequence flags (step numbers), one cache line each
+    struct alignas(64) Seq {
+        std::atomic<int64_t> v{0};
+    };
+    std::vector<Seq> raw_ready, raw_done, sink_ready;
+    alignas(64) std::atomic<int64_t> released{0};  // steps whose sink may be rewritten: [0, released)
+    std::atomic<bool> stop{false};
+    std::atomic<bool> failed{false};
+    std::thread gen, tok;
+    std::vector<std::thread> fin;
+    bool joined = false;
+
+    void tokenizer_main();
+    void finisher_main(int id);
+    void tokenize(Reader& rd, int64_t n, int& has_gauss, double& gauss);
+    void finish_step(int64_t n, std::vector<uint8_t>& labels);
+    void join_all();
+};
+
+bool MtPlanPipeline::supports(int32_t nmoves, const emx_move_desc* moves) {
+    for (int i = 0; i < nmoves; ++i) {
+        const int k = moves[i].kind;
+        if (k != EMX_MOVE_STRETCH && k != EMX_MOVE_DE && k != EMX_MOVE_SNOOKER) return false;
+        if (moves[i].nsplits < 2 || moves[i].nsplits > MAX_SPLITS) return false;
+    }
+    return nmoves >= 1;
+}
+
+MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves,
+                               const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers)
+    : impl_(new Impl()) {
+    Impl& m = *impl_;
+    m.N = N;
+    m.D = D;
+    m.nsteps = nsteps;
+    m.moves.assign(moves, moves + nmoves);
+    m.cdf.assign(cdf, cdf + nmoves);
+    m.sinks.assign(sinks, sinks + nsinks);
+    m.nsinks = nsinks;
+    int K = nworkers;
+    if (K <= 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        K = hw >= 32 ? 6 : hw >= 16 ? 4 : hw >= 8 ? 3 : hw >= 4 ? 2 : 1;
+    }
+    K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(K, nsinks), nsteps));
+    m.K = K;
+    m.NR = K + 2;
+    m.NSNAP = nsinks + 4;
+    m.start = start;
+    m.ws.ring.resize(NBLK * BLK);
+    m.ws.kring.resize(NBLK * BLK);
+    m.raws.resize(m.NR);
+    bool any_shuffle = false, any_de = false, any_sn = false;
+    for (auto& mv : m.moves) {
+        any_shuffle |= mv.randomize_split != 0;
+        any_de |= mv.kind == EMX_MOVE_DE;
+        any_sn |= mv.kind == EMX_MOVE_SNOOKER;
+    }
+    for (auto& r : m.raws) {
+        if (any_shuffle) r.j.resize((size_t)N);
+        if (any_de) {
+            r.k64.resize((size_t)N);
+            r.gx.resize((size_t)N);
+            r.gr2.resize((size_t)N);
+        }
+        if (any_sn) r.perm.resize((size_t)N);
+    }
+    m.infos.resize(nsinks);
+    m.snaps.resize(m.NSNAP);
+    m.raw_ready = std::vector<Impl::Seq>(m.NR);
+    m.raw_done = std::vector<Impl::Seq>(m.NR);
+    m.sink_ready = std::vector<Impl::Seq>(nsinks);
+    for (int s = 0; s < m.NR; ++s) {
+        m.raw_ready[s].v.store(-1);
+        m.raw_done[s].v.store((int64_t)s - m.NR);     // "step s - NR is done": slot s is free for step s
+    }
+    for (int s = 0; s < nsinks; ++s) m.sink_ready[s].v.store(-1);
+    m.gen = std::thread(generator_main, &m.ws, m.start.key);
+    m.tok = std::thread([&m] { m.tokenizer_main(); });
+    for (int k = 0; k < K; ++k) m.fin.emplace_back([&m, k] { m.finisher_main(k); });
+}
+
+int MtPlanPipeline::workers() const { return impl_->K; }
+
+void MtPlanPipeline::Impl::join_all() {
+    if (joined) return;
+    stop.store(true);
+    ws.stop.store(true);
+    if (gen.joinable()) gen.join();
+    if (tok.joinable()) tok.join();
+    for (auto& t : fin)
+        if (t.joinable()) t.join();
+    joined = true;
+}
+
+MtPlanPipeline::~MtPlanPipeline() {
+    impl_->join_all();
+    delete impl_;
+}
+
+// ---- tokenizer: one pass over the stream in the reference's draw order --------------------------------------------
+void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, double& gauss) {
+    const int nm = (int)moves.size();
+    // ensemble.py:406  move = self._random.choice(self._moves, p=self._weights): one uniform against the cdf
+    int mi;
+    {
+        const double u = rd.next_double();
+        int lo = 0, hi = nm;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (u < cdf[mid])
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        mi = lo < nm ? lo : nm - 1;
+    }
+    const emx_move_desc& mv = moves[mi];
+    const int S = mv.nsplits;
+    PipeStepInfo& info = infos[n % nsinks];
+    info.move = mi;
+    info.S = S;
+    info.off[0] = 0;
+    for (int s = 0; s < S; ++s) info.off[s + 1] = info.off[s] + (int32_t)((N - s + S - 1) / S);   // label counts survive the shuffle
+    RawStep& raw = raws[n % NR];
+    const PlanSink& sk = sinks[n % nsinks];
+    if (mv.randomize_split) rd.shuffle_targets(raw.j.data(), N);                                  // red_blue.py:80
+    for (int split = 0; split < S && !rd.dead; ++split) {
+        const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
+        if (mv.kind == EMX_MOVE_STRETCH) {
+            rd.fill_doubles(sk.s0 + base, ns);                                                     // stretch.py:30
+            stretch_zz(sk.s0 + base, ns, mv.a);
+            rd.fill_randint32(sk.p0 + base, ns, (uint64_t)nc);                                     // stretch.py:32 (complement index)
+        } else if (mv.kind == EMX_MOVE_DE) {
+            const uint64_t pop = (uint64_t)nc * (uint64_t)(nc - 1);
+            for (int64_t t = 0; t < ns; ++t) raw.k64[base + t] = rd.randint(pop);                  // de.py:49
+            // de.py:56 randn(ns, 1): legacy polar method, the second value of a pair is cached for the next call
+            int64_t t = 0;
+            while (t < ns && !rd.dead) {
+                if (has_gauss) {
+                    raw.gx[base + t] = gauss;
+                    raw.gr2[base + t] = -1.0;
+                    has_gauss = 0;
+                    gauss = 0.0;
+                    ++t;
+                    continue;
+                }
+                double x1, x2, r2;
+                do {
+                    x1 = 2.0 * rd.next_double() - 1.0;
+                    x2 = 2.0 * rd.next_double() - 1.0;
+                    r2 = x1 * x1 + x2 * x2;
+                } while ((r2 >= 1.0 || r2 == 0.0) && !rd.dead);
+                raw.gx[base + t] = x2;                       // this call returns f * x2 ...
+                raw.gr2[base + t] = r2;
+                ++t;
+                if (t < ns) {                                // ... and the next one the cached f * x1
+                    raw.gx[base + t] = x1;
+                    raw.gr2[base + t] = r2;
+                    ++t;
+                } else {
+                    const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+                    gauss = f * x1;
+                    has_gauss = 1;
+                }
+            }
+        } else {   // snooker: de_snooker.py:37-40 per walker
+            int cs[3], q = 0;
+            for (int s = 0; s < S && q < 3; ++s)
+                if (s != split) cs[q++] = s;
+            const uint64_t nj[3] = {(uint64_t)(info.off[cs[0] + 1] - info.off[cs[0]]), (uint64_t)(info.off[cs[1] + 1] - info.off[cs[1]]),
+                                    (uint64_t)(info.off[cs[2] + 1] - info.off[cs[2]])};
+            for (int64_t t = 0; t < ns && !rd.dead; ++t) {
+                sk.p0[base + t] = (int32_t)rd.randint(nj[0]);
+                sk.p1[base + t] = (int32_t)rd.randint(nj[1]);
+                sk.p2[base + t] = (int32_t)rd.randint(nj[2]);
+                const uint32_t j2 = (uint32_t)rd.random_interval(2);
+                const uint32_t j1 = (uint32_t)rd.random_interval(1);
+                raw.perm[base + t] = (uint8_t)(j2 | (j1 << 2));
+            }
+        }
+        rd.fill_doubles(sk.uacc + base, ns);                                                       // red_blue.py:100
+    }
+}
+
+void MtPlanPipeline::Impl::tokenizer_main() {
+    Reader rd;
+    rd.ws = &ws;
+    rd.stop = &stop;
+    rd.seek((uint64_t)start.pos);
+    int has_gauss = start.has_gauss;
+    double gauss = start.gauss;
+    for (int64_t n = 0; n < nsteps; ++n) {
+        Backoff bo;
+        // the sink of step n is free once step n - nsinks has been uploaded; the raw slot once its finisher is done
+        while ((n >= released.load(std::memory_order_acquire) + nsinks || raw_done[n % NR].v.load(std::memory_order_acquire) != n - NR) &&
+               !stop.load(std::memory_order_relaxed))
+            bo.pause();
+        if (stop.load(std::memory_order_relaxed)) return;
+        tokenize(rd, n, has_gauss, gauss);
+        if (rd.dead) return;
+        // generator state after this step (NumPy get_state() semantics: a block consumed to its end reports pos = 624)
+        {
+            const uint64_t a = rd.pos();
+            const uint64_t blk = a > 0 ? (a - 1) / BLK : 0;
+            MT19937Legacy& sn = snaps[n % NSNAP];
+            // the block is still retained: keep <= (a - 1) / BLK and the generator never overwrites blocks >= keep
+            sn.set_state(&ws.kring[(blk % NBLK) * BLK], (int)(a - blk * BLK), has_gauss, gauss);
+        }
+        raw_ready[n % NR].v.store(n, std::memory_order_release);
+    }
+}
+
+// ---- finisher: one whole step, independent of every other step ----------------------------------------------------
+void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) {
+    const PipeStepInfo& info = infos[n % nsinks];
+    const emx_move_desc& mv = moves[info.move];
+    const int S = info.S;
+    const RawStep& raw = raws[n % NR];
+    const PlanSink& sk = sinks[n % nsinks];
+    uint8_t* x = labels.data();
+    for (int64_t i = 0; i < N; ++i) x[i] = (uint8_t)(i % S);                 // red_blue.py:78
+    if (mv.randomize_split) {
+        const uint32_t* j = raw.j.data();
+        for (int64_t i = N - 1; i > 0; --i) {                               // red_blue.py:80 (the swaps of RandomState.shuffle)
+            const uint32_t jj = j[i];
+            const uint8_t t = x[i];
+            x[i] = x[jj];
+            x[jj] = t;
+        }
+    }
+    // boolean-mask gather order (red_blue.py:85): ascending walker index inside each set
+    int32_t cur[MAX_SPLITS + 1];
+    for (int s = 0; s < S; ++s) cur[s] = info.off[s];
+    int32_t* order = sk.order;
+    for (int64_t i = 0; i < N; ++i) order[cur[x[i]]++] = (int32_t)i;
+    for (int split = 0; split < S; ++split) {
+        const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
+        auto comp = [&](uint64_t r) -> int32_t { return (int64_t)r < base ? order[r] : order[r + ns]; };   // stretch.py:27
+        if (mv.kind == EMX_MOVE_STRETCH) {
+            for (int64_t t = 0; t < ns; ++t) {
+                sk.p0[base + t] = comp((uint32_t)sk.p0[base + t]);
+                sk.p1[base + t] = sk.p2[base + t] = order[base + t];
+            }
+        } else if (mv.kind == EMX_MOVE_DE) {
+            for (int64_t t = 0; t < ns; ++t) {
+                uint64_t f, s;
+                de_pair(raw.k64[base + t], (uint64_t)nc, f, s);
+                sk.p0[base + t] = comp(f);
+                sk.p1[base + t] = comp(s);
+                sk.p2[base + t] = order[base + t];
+                const double r2 = raw.gr2[base + t];
+                double g = raw.gx[base + t];
+                if (r2 >= 0.0) {
+                    const double fac = std::sqrt(-2.0 * std::log(r2) / r2);
+                    g = fac * g;
+                }
+                sk.s0[base + t] = mv.g0 * (1.0 + mv.sigma * g);
+            }
+        } else {
+            int cs[3], q = 0;
+            for (int s = 0; s < S && q < 3; ++s)
+                if (s != split) cs[q++] = s;
+            for (int64_t t = 0; t < ns; ++t) {
+                int32_t w[3] = {order[info.off[cs[0]] + sk.p0[base + t]], order[info.off[cs[1]] + sk.p1[base + t]],
+                                order[info.off[cs[2]] + sk.p2[base + t]]};
+                const int j2 = raw.perm[base + t] & 3, j1 = (raw.perm[base + t] >> 2) & 1;
+                std::swap(w[2], w[j2]);
+                std::swap(w[1], w[j1]);
+                sk.p0[base + t] = w[0];
+                sk.p1[base + t] = w[1];
+                sk.p2[base + t] = w[2];
+                sk.s0[base + t] = 0.0;
+            }
+        }
+    }
+}
+
+void MtPlanPipeline::Impl::finisher_main(int id) {
+    std::vector<uint8_t> labels((size_t)N);
+    for (int64_t n = id; n < nsteps; n += K) {
+        Backoff bo;
+        while (raw_ready[n % NR].v.load(std::memory_order_acquire) != n && !stop.load(std::memory_order_relaxed)) bo.pause();
+        if (stop.load(std::memory_order_relaxed)) return;
+        finish_step(n, labels);
+        raw_done[n % NR].v.store(n, std::memory_order_release);
+        sink_ready[n % nsinks].v.store(n, std::memory_order_release);
+    }
+}
+
+bool MtPlanPipeline::wait_ready(int64_t n, PipeStepInfo& info, void (*poll)(void*), void* poll_arg) {
+    Impl& m = *impl_;
+    if (n < 0 || n >= m.nsteps) return false;
+    Backoff bo;
+    int spins = 0;
+    while (m.sink_ready[n % m.nsinks].v.load(std::memory_order_acquire) != n) {
+        if (m.failed.load() || m.stop.load()) return false;
+        if (poll && ((++spins & 15) == 0)) poll(poll_arg);
+        bo.pause();
+    }
+    info = m.infos[n % m.nsinks];
+    return true;
+}
+
+void MtPlanPipeline::release(int64_t n) {
+    Impl& m = *impl_;
+    int64_t cur = m.released.load(std::memory_order_relaxed);
+    if (n + 1 > cur) m.released.store(n + 1, std::memory_order_release);
+}
+
+void MtPlanPipeline::finish(int64_t steps_consumed, MT19937Legacy& out) {
+    Impl& m = *impl_;
+    m.join_all();
+    if (steps_consumed <= 0)
+        out = m.start;
+    else
+        out = m.snaps[(steps_consumed - 1) % m.NSNAP];
+}
+
+}  // namespace emx

@@ -205,8 +205,14 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_step_begin_with(self.ctx, int(bool(store)), int(move_index), C.byref(S)))
         return S.value
 
+    def _split_size(self, split):
+        """number of walkers `split` of the step begun updates (the library copies exactly that many values)"""
+        return self.shard_slots(split)[2]
+
     def accept_proposals(self, split, q, factors, new_log_prob):
-        self._ck(self.lib.emx_accept_proposals(self.ctx, int(split), _as_f64(q), _as_f64(factors), _as_f64(new_log_prob)))
+        ns = self._split_size(split)
+        self._ck(self.lib.emx_accept_proposals(self.ctx, int(split), _as_f64(q, (ns, self.ndim)), _as_f64(factors, (ns,)),
+                                               _as_f64(new_log_prob, (ns,))))
 
     def halfstep(self, split):
         self._ck(self.lib.emx_halfstep(self.ctx, int(split)))
@@ -222,7 +228,8 @@ class DeviceEnsemble:
         return q[: ns.value]
 
     def accept(self, split, new_log_prob):
-        self._ck(self.lib.emx_accept(self.ctx, int(split), _as_f64(new_log_prob)))
+        # a log_prob_fn returning the wrong number of values is a ValueError here, not a host over-read in the library
+        self._ck(self.lib.emx_accept(self.ctx, int(split), _as_f64(new_log_prob, (self._split_size(split),))))
 
     def step_end(self):
         self._ck(self.lib.emx_step_end(self.ctx))

@@ -92,21 +92,9 @@ class EnsembleSampler(object):
             if value is not None:
                 deprecation_warning(text)
 
-        # move schedule (reference ensemble.py:115-129)
-        if moves is None:
-            self._moves = [StretchMove()]
-            self._weights = [1.0]
-        elif isinstance(moves, Iterable):
-            try:
-                self._moves, self._weights = zip(*moves)
-            except TypeError:
-                self._moves = moves
-                self._weights = np.ones(len(moves))
-        else:
-            self._moves = [moves]
-            self._weights = [1.0]
-        self._weights = np.atleast_1d(self._weights).astype(float)
-        self._weights /= np.sum(self._weights)
+        # move schedule (reference ensemble.py:115-129): a single move, a sequence of moves (equal weights), or a
+        # sequence of (move, weight) pairs; the weights are normalised to probabilities
+        self._moves, self._weights = _parse_move_schedule(moves)
 
         if rng not in ("mt19937", "philox"):
             raise ValueError("rng must be 'mt19937' or 'philox'")
@@ -178,11 +166,13 @@ class EnsembleSampler(object):
 
     @random_state.setter  # NOQA
     def random_state(self, state):
-        """Try to set the generator state; fails silently like the reference (ensemble.py:228-238)."""
-        self._rng_on_device = None
+        """Try to set the generator state; fails silently like the reference (ensemble.py:228-238): a state that
+        NumPy refuses (None included) leaves the stream where it is -- which, after a device run, is wherever
+        libemx left it, so that copy is brought home first."""
+        self._flush_rng()
         try:
             self._random.set_state(state)
-        except:  # noqa: E722
+        except Exception:  # noqa: BLE001
             pass
 
     def _flush_rng(self):
@@ -282,6 +272,21 @@ class EnsembleSampler(object):
         else:
             self._philox_step = ens.get_philox()[1]
 
+    def _raise_on_device_status(self, ens, store):
+        """The reference's ValueErrors for a NaN log-prob / non-finite proposal (ensemble.py:476-479, 550-551).
+
+        Divergence from the reference, by design: it stops AT the offending step; a native call covers a block of
+        steps (the ``thin_by`` proposals between two yields, or a whole ``run_mcmc``), the offending proposals are
+        rejected on the device, the block completes, and the error is raised when the block returns -- so
+        ``backend.iteration`` may stand past the step that misbehaved.  The backend's ``random_state`` is pinned
+        to the generator's real position before the exception leaves."""
+        try:
+            ens.raise_on_status()
+        except Exception:
+            if store:
+                self.backend.random_state = self.random_state
+            raise
+
     # ------------------------------------------------------------------ sampling
     def sample(self, initial_state, log_prob0=None, rstate0=None, blobs0=None, iterations=1, tune=False,
                skip_initial_state_check=False, thin_by=1, thin=None, store=True, progress=False,
@@ -373,8 +378,8 @@ class EnsembleSampler(object):
             for _ in count() if iterations is None else range(iterations):
                 if block_call:
                     ens.run(1, yield_step, store)
-                    ens.raise_on_status()
                     self._sync_rng_from_device(ens)
+                    self._raise_on_device_status(ens, store)
                     state._invalidate()
                     state.random_state = lazy_rs             # resolved when somebody reads it
                     if store:
@@ -429,8 +434,8 @@ class EnsembleSampler(object):
         nobody on the host needs it: the device chain keeps its own accept counters)."""
         if fused:
             ens.run(1, 1, store)
-            ens.raise_on_status()
             self._sync_rng_from_device(ens)
+            self._raise_on_device_status(ens, store)
             return ens.accepted_mask() if need_mask else None
         # split-phase: the callable runs on the host between propose and accept (red_blue.py:90-104)
         k, nsplits = ens.step_begin(store)
@@ -533,8 +538,8 @@ class EnsembleSampler(object):
                 self.backend._attach(ens)
             self.backend.grow(nsteps, None)
         ens.run(nsteps, thin_by, store and self.backend._dev is ens)
-        ens.raise_on_status()
         self._sync_rng_from_device(ens)
+        self._raise_on_device_status(ens, store)
         coords, lp = ens.get_state()
         out = State(coords, log_prob=lp, random_state=self.random_state)
         if store:
@@ -625,25 +630,44 @@ class EnsembleSampler(object):
 
 
 class _FunctionWrapper(object):
-    """Bundle ``args`` / ``kwargs`` with the callable so that it pickles for ``pool.map``."""
+    """The user's callable with its extra positional / keyword arguments bound.  A plain class (not a closure or a
+    functools.partial holding a lambda) so that ``pool.map`` can pickle it.  When the callable raises, the walker
+    position and the bound arguments are reported before the exception continues (reference ``ensemble.py:632-652``
+    prints the same facts; the wording is ours)."""
 
     def __init__(self, f, args, kwargs):
         self.f = f
-        self.args = args or []
-        self.kwargs = kwargs or {}
+        self.args = [] if args is None else args
+        self.kwargs = {} if kwargs is None else kwargs
 
     def __call__(self, x):
         try:
             return self.f(x, *self.args, **self.kwargs)
-        except:  # pragma: no cover  # noqa: E722
+        except BaseException:  # pragma: no cover
+            import sys
             import traceback
-            print("emcee: Exception while calling your likelihood function:")
-            print("  params:", x)
-            print("  args:", self.args)
-            print("  kwargs:", self.kwargs)
-            print("  exception:")
-            traceback.print_exc()
+            report = ["emcee: Exception while calling your likelihood function:",
+                      "  params: %s" % (x,), "  args: %s" % (self.args,), "  kwargs: %s" % (self.kwargs,), "  exception:"]
+            print("\n".join(report))
+            traceback.print_exception(*sys.exc_info(), file=sys.stdout)
             raise
+
+
+def _parse_move_schedule(moves):
+    """-> (list of moves, weight vector summing to one) from the ``moves`` constructor argument."""
+    if moves is None:
+        seq, w = [StretchMove()], [1.0]
+    elif not isinstance(moves, Iterable):
+        seq, w = [moves], [1.0]
+    else:
+        items = list(moves)
+        pairs = [it for it in items if isinstance(it, (tuple, list)) and len(it) == 2]
+        if len(pairs) == len(items) and items:
+            seq, w = [m for m, _ in items], [wt for _, wt in items]
+        else:
+            seq, w = items, [1.0] * len(items)
+    w = np.asarray(w, dtype=float).reshape(-1)
+    return seq, w / w.sum()
 
 
 def _refuse_extended_precision(coords):
@@ -789,10 +813,14 @@ def ndarray_to_list_of_dicts(x, key_map):
 
 
 def _scalar(fx):
-    """Coerce a log-prob return value to a Python float (reference ``ensemble.py:703-713``)."""
-    if not np.isscalar(fx):
-        try:
-            fx = np.asarray(fx).item()
-        except (TypeError, ValueError) as e:
-            raise ValueError("log_prob_fn should return scalar") from e
-    return float(fx)
+    """One walker's log-prob as a Python float: NumPy / Python scalars directly, size-one arrays through ``item()``;
+    anything longer is the user returning a vector where a number is expected (reference ``ensemble.py:703-713``)."""
+    if np.isscalar(fx):
+        return float(fx)
+    arr = np.asarray(fx)
+    if arr.size != 1:
+        raise ValueError("log_prob_fn should return scalar")
+    try:
+        return float(arr.reshape(()).item())
+    except (TypeError, ValueError) as err:
+        raise ValueError("log_prob_fn should return scalar") from err

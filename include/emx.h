@@ -78,6 +78,8 @@ int emx_sync(emx_ctx* ctx);
 int emx_status(emx_ctx* ctx, uint32_t* bits);
 /* keys: "spw", "blocks_per_cu", "waves_per_block", "prep_hint", "graph", "throttle", "gauss_materialize",
  * "small_kernel" (1: ensembles that fit one CU's LDS run whole emx_run calls in one workgroup; default),
+ * "mt_pipeline" (MT19937 mode, emx_run: -1 plans from the threaded host pipeline, finisher threads chosen from the core
+ * count (default); k > 0: k finisher threads; 0: plans made inline by the calling thread),
  * "phase_clock" (instrumented builds) */
 int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value);
 
@@ -220,6 +222,15 @@ int32_t emx_mt_choice_cdf(emx_mt* m, const double* cdf, int32_t n);
 /* one step's exact plan on the host (the producer emx_run uses in MT19937 mode) */
 int emx_host_plan_mt(emx_mt* m, int64_t nwalkers, int32_t ndim, const emx_move_desc* mv, int32_t* off, int32_t* order,
                      int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc);
+/* The same plans for `nsteps` consecutive steps (move choice included, ensemble.py:406) made by the threaded pipeline emx_run
+ * uses in MT19937 mode (csrc/emx_mtpipe.hpp: generator / tokenizer / `nworkers` finisher threads, `nsinks` staging buffers used
+ * round-robin).  Output arrays hold nsteps * nwalkers entries (step-major; any may be NULL), moves_out nsteps.  Advances `m`
+ * exactly like nsteps calls of emx_mt_choice_cdf + emx_host_plan_mt.  Returns the number of finisher threads used (> 0) or a
+ * negative code; *seconds_out: wall time of the whole production. */
+int emx_host_plan_mt_stream(emx_mt* m, int64_t nwalkers, int32_t ndim, int32_t nmoves, const emx_move_desc* moves,
+                            const double* cdf, int64_t nsteps, int32_t nworkers, int32_t nsinks, int32_t* moves_out,
+                            int32_t* order, int32_t* p0, int32_t* p1, int32_t* p2, double* s0, double* uacc,
+                            double* seconds_out);
 /* the draws of ONE RedBlueMove.get_proposal(s, c, random) call for `split` of a given partition */
 int emx_host_split_draws(emx_mt* m, int64_t nwalkers, const emx_move_desc* mv, const int32_t* off,
                          const int32_t* order, int32_t split, int32_t* p0, int32_t* p1, int32_t* p2, double* s0);

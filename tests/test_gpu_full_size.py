@@ -7,7 +7,7 @@ from emcee_amd import _lib
 from oracle import cases
 from oracle import sampler_oracle as so
 
-from emx_testlib import cdf_of, move_desc
+from emx_testlib import cdf_of, move_desc, philox_plan
 from test_gpu_parity import assert_lp_close, make_ens, set_target
 
 pytestmark = pytest.mark.gpu
@@ -101,6 +101,59 @@ def test_native_mode_invariants_at_full_size(name):
     frac = changed_total.mean() / nst
     lo, hi = {"c2": (0.10, 0.25), "c3": (0.10, 0.45), "c4": (0.10, 0.45), "c5": (0.005, 0.12)}[name[:2]]
     assert lo < frac < hi, frac                                                    # (iv)
+    ens.close()
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_native_mode_teacher_forced_at_full_size(name):
+    """Philox mode -- the mode the bench headline is measured in -- replayed through the oracle AT the BASELINE size.
+    For 3 steps: the plan the device evaluated (k_native_plan_batch, read back with emx_plan_get) must equal the host
+    twin of the keyed permutation / Philox draws (emx_host_plan_philox) entry for entry, and the oracle's arithmetic
+    (stretch.py:33, de.py:53-62, de_snooker.py:41-46, red_blue.py:96-104) applied to the device's pre-step state with
+    that plan must give the same accept mask (bit-exact) and the same post-step state (coordinates bit-identical for
+    stretch / DE, 1e-9 for snooker whose norms and dots are reductions)."""
+    spec = FULL[name]()
+    fn = cases.make_target(spec["desc"])
+    N, D = spec["N"], spec["D"]
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_PHILOX)
+    seed = 0xBEEF03 + spec["seed"]          # c4: steps 0..2 draw DE, snooker, DE
+    ens.set_philox(seed, 0)
+    cdf = cdf_of(spec["weights"], len(spec["moves"]))
+    nst = 3
+    used = set()
+    nacc = 0
+    for step in range(nst):
+        x0, lp0 = ens.get_state()
+        k, S = ens.step_begin(store=False)
+        assert k == ens.lib.emx_host_move_choice_philox(seed, step, cdf, len(cdf))
+        mv = spec["moves"][k]
+        used.add(mv.kind)
+        plan = ens.plan_get(S)
+        host = philox_plan(seed, step, N, move_desc(mv, D))
+        for key in ("off", "order", "p0", "p1", "p2"):
+            assert np.array_equal(plan[key], host[key]), (step, key)
+        np.testing.assert_allclose(plan["s0"], host["s0"], rtol=1e-14)
+        assert np.array_equal(plan["uacc"], host["uacc"])
+        assert np.array_equal(np.sort(plan["order"]), np.arange(N))          # the split is a partition
+        for s in range(S):
+            ens.halfstep(s)
+        ens.step_end()
+        assert ens.status() == 0
+        x1, lp1 = ens.get_state()
+        acc_dev = ens.accepted_mask()
+        xo, lpo = x0.copy(), lp0.copy()
+        acc_or = so.propose_planned(xo, lpo, fn, plan, mv)
+        assert np.array_equal(acc_dev, acc_or), "accept mask differs at step %d (%d walkers)" % (step, int(np.sum(acc_dev != acc_or)))
+        if mv.kind == "snooker":
+            np.testing.assert_allclose(x1, xo, rtol=1e-9, atol=1e-10)
+        else:
+            assert np.array_equal(x1, xo), "coordinates differ at step %d" % step
+        assert_lp_close(lp1, lpo, 1e-9 if mv.kind == "snooker" else 1e-11)
+        nacc += int(acc_dev.sum())
+    assert nacc > 0
+    if len(spec["moves"]) > 1:
+        assert used == {m.kind for m in spec["moves"]}, "the seed must exercise every move of the mixture: %s" % used
     ens.close()
 
 

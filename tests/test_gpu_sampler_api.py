@@ -568,6 +568,55 @@ def test_generator_rng_state_is_current_whenever_somebody_looks():
     assert np.array_equal(s.random_state[1], want[1])
 
 
+def test_consecutive_unstored_runs_from_plain_arrays_continue_the_stream():
+    """Two runs started from bare ndarrays (whose State carries random_state=None) with nobody reading the generator
+    state in between: the second run must continue the MT19937 stream where the first left it in libemx, exactly
+    as the reference's silently-failing setter leaves its RandomState alone (ensemble.py:228-238).  (Round-1 advisor
+    finding: the setter dropped the device-held state before the failing set_state.)"""
+    name = "stretch_50x3_iso"
+    g = load_golden(name)
+    spec = cases.build(name)
+    k = 4
+    # the oracle, one generator across both runs
+    rs = rng_from_fixture(g)
+    fn = cases.make_target(spec["desc"])
+    a = so.run(g["p0"], k, fn, rs, moves=spec["moves"], weights=spec["weights"], store=False)
+    b = so.run(a["coords"], spec["nsteps"] - k, fn, rs, moves=spec["moves"], weights=spec["weights"], store=False,
+               log_prob0=a["lp"])
+    assert np.array_equal(b["coords"], g["chain"][-1])          # the oracle itself reproduces the reference run
+    for runner in ("sample", "run_mcmc"):
+        s = make_sampler(spec, g)
+        if runner == "sample":
+            for st in s.sample(g["p0"], iterations=k, store=False, skip_initial_state_check=True):
+                pass
+            mid = np.array(st.coords)
+            for st in s.sample(mid, iterations=spec["nsteps"] - k, store=False, skip_initial_state_check=True):
+                pass
+            end = np.array(st.coords)
+        else:
+            mid = s.run_mcmc(g["p0"], k, store=False, skip_initial_state_check=True).coords
+            end = s.run_mcmc(np.array(mid), spec["nsteps"] - k, store=False, skip_initial_state_check=True).coords
+        assert np.array_equal(mid, a["coords"]), runner
+        assert np.array_equal(end, g["chain"][-1]), runner
+        fin = s.random_state
+        assert np.array_equal(fin[1], g["rng_key1"]) and fin[2] == int(g["rng_pos1"]), runner
+    # an invalid state is ignored without losing the stream position either
+    s = make_sampler(spec, g)
+    s.run_mcmc(g["p0"], k, store=False, skip_initial_state_check=True)
+    s.random_state = "not a state"
+    end = s.run_mcmc(None, spec["nsteps"] - k, store=False, skip_initial_state_check=True).coords
+    assert np.array_equal(end, g["chain"][-1])
+
+
+def test_wrong_length_log_prob_vector_is_a_value_error():
+    """A vectorised log_prob_fn that returns the wrong number of values must raise, not be read past its end."""
+    s, p0 = _mk(32, 3)
+    bad = emcee_amd.EnsembleSampler(32, 3, lambda x: -0.5 * np.sum(x ** 2, axis=1)[:-1] if len(x) < 32 else
+                                    -0.5 * np.sum(x ** 2, axis=1), vectorize=True)
+    with pytest.raises(ValueError):
+        bad.run_mcmc(p0, 2, skip_initial_state_check=True)
+
+
 def test_normal_stretch_with_blobs_on_the_host_callable_path():
     """reference integration/test_stretch.py:17-19 with blobs=True (test_proposal.py:21-23: the blob is a Python
     object per walker)"""

@@ -1,0 +1,102 @@
+"""The exact-mode plan pipeline (emcee_amd/csrc/emx_mtpipe.cpp: generator / tokenizer / finisher threads) must
+produce, step for step, the plans and the final MT19937 state of the serial host twin (emx_mt_choice_cdf +
+emx_host_plan_mt), which tests/test_mt19937_exact.py pins word-for-word to NumPy's legacy RandomState and to the
+oracle's draws.  Host only: no GPU needed."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from emcee_amd import _lib
+
+from emx_testlib import HostMT
+
+
+def md(kind, S=2, rs=1, a=2.0, sigma=1e-5, g0=0.3, gammas=1.7):
+    return _lib.MoveDesc({"stretch": 0, "de": 1, "snooker": 2}[kind], 4 if kind == "snooker" and S < 4 else S, rs, 0, a, sigma, g0,
+                         gammas)
+
+
+def serial(state, N, D, moves, cdf, nsteps):
+    m = HostMT(state)
+    out = []
+    for _ in range(nsteps):
+        k = m.choice_cdf(cdf)
+        out.append((k, m.plan(N, D, moves[k])))
+    return out, m.get_state()
+
+
+def stream(state, N, D, moves, cdf, nsteps, workers, nsinks):
+    lib = _lib.load()
+    m = HostMT(state)
+    arr = (_lib.MoveDesc * len(moves))(*moves)
+    mv = np.empty(nsteps, dtype=np.int32)
+    order, p0, p1, p2 = (np.empty(nsteps * N, dtype=np.int32) for _ in range(4))
+    s0, ua = np.empty(nsteps * N), np.empty(nsteps * N)
+    sec = C.c_double()
+    rc = lib.emx_host_plan_mt_stream(m.h, N, D, len(moves), arr, np.ascontiguousarray(cdf, dtype=np.float64), nsteps, workers, nsinks,
+                                     mv.ctypes.data, order.ctypes.data, p0.ctypes.data, p1.ctypes.data, p2.ctypes.data,
+                                     s0.ctypes.data, ua.ctypes.data, C.byref(sec))
+    assert rc > 0, rc
+    plans = [(int(mv[n]), dict(order=order[n * N:(n + 1) * N], p0=p0[n * N:(n + 1) * N], p1=p1[n * N:(n + 1) * N],
+                               p2=p2[n * N:(n + 1) * N], s0=s0[n * N:(n + 1) * N], uacc=ua[n * N:(n + 1) * N])) for n in range(nsteps)]
+    return plans, m.get_state(), sec.value
+
+
+def same_state(a, b):
+    return np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] and a[4] == b[4]
+
+
+CASES = [
+    # name, N, D, moves, weights, nsteps, start position in the block, cached normal
+    ("stretch_pow2", 4096, 8, [md("stretch")], None, 12, None, False),
+    ("stretch_odd", 1001, 3, [md("stretch")], None, 9, 623, False),
+    ("stretch_nsplits5", 333, 2, [md("stretch", S=5)], None, 7, 624, False),
+    ("stretch_fixed_split", 64, 2, [md("stretch", rs=0)], None, 5, 1, False),
+    ("de", 512, 4, [md("de")], None, 9, None, False),
+    ("de_odd_with_cached_normal", 203, 4, [md("de", S=3)], None, 11, 17, True),
+    ("snooker", 256, 4, [md("snooker")], None, 9, None, False),
+    ("snooker_odd", 131, 3, [md("snooker", S=5)], None, 6, 300, False),
+    ("mixture", 300, 5, [md("stretch"), md("de"), md("snooker")], [0.5, 0.3, 0.2], 24, 5, True),
+    ("tiny", 4, 1, [md("stretch")], None, 40, None, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("workers,nsinks", [(1, 2), (3, 4), (2, 16)])
+def test_pipeline_plans_equal_the_serial_twin(case, workers, nsinks):
+    name, N, D, moves, w, nsteps, pos, cached = case
+    rs = np.random.RandomState(zlib.crc32(name.encode()))
+    if cached:
+        rs.randn(1)                          # leaves a cached second normal in the state
+    st = list(rs.get_state())
+    if pos is not None:
+        st[2] = pos
+    st = tuple(st)
+    w = np.ones(len(moves)) if w is None else np.asarray(w, dtype=float)
+    cdf = np.cumsum(w / w.sum())
+    cdf /= cdf[-1]
+    want, want_state = serial(st, N, D, moves, cdf, nsteps)
+    got, got_state, _ = stream(st, N, D, moves, cdf, nsteps, workers, nsinks)
+    for n, ((ka, pa), (kb, pb)) in enumerate(zip(want, got)):
+        assert ka == kb, (n, ka, kb)
+        kind = moves[ka].kind
+        keys = ["order", "p0", "uacc", "s0"] + (["p1", "p2"] if kind != 0 else [])
+        for key in keys:
+            assert np.array_equal(pa[key], pb[key]), (name, n, key)
+    assert same_state(want_state, got_state)
+
+
+def test_pipeline_at_the_headline_size_and_its_throughput():
+    """65 536 walkers (BASELINE configs[1]): a few steps, bit-identical; prints the host-side production rate."""
+    N, D, nsteps = 65536, 64, 6
+    moves = [md("stretch")]
+    st = np.random.RandomState(11).get_state()
+    want, want_state = serial(st, N, D, moves, np.array([1.0]), nsteps)
+    got, got_state, sec = stream(st, N, D, moves, np.array([1.0]), nsteps, 0, 16)
+    for (ka, pa), (kb, pb) in zip(want, got):
+        for key in ("order", "p0", "s0", "uacc"):
+            assert np.array_equal(pa[key], pb[key]), key
+    assert same_state(want_state, got_state)
+    print("pipeline: %.3f ms per step of 65536 walkers (thread start-up included)" % (sec * 1e3 / nsteps))
