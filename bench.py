@@ -12,7 +12,7 @@ RNG, float64 -- weak-scaled over the GPUs.  The same JSON line also carries (ran
               the chain stored every step: ms_per_step, wu_per_s, roofline fraction (SURVEY.md 8d bytes formulas)
   exact_mode  C2 under rng=mt19937 (the mode that reproduces reference emcee's chain for a seed)
   quality     acceptance fraction and integrated autocorrelation time of a 2048x64 run >= 50 tau long, next to the
-              reference's numbers for the same configuration (profiles/r02/quality_ref.json, build container)
+              reference's numbers for the same configuration (tests/golden/quality_ref.json, build container)
   cpu_baseline reference emcee itself when /root/reference is importable (build container), otherwise the NumPy
               port (oracle/) timed here + the committed reference timings (profiles/r02/cpu_reference.json)
 
@@ -363,16 +363,26 @@ def exact_mode_entry(wl, K, W, device):
             "best_block_ms_per_step": res["wall_min_s"] * 1e3 / Kx,
             "host_plan_ms": host_ms, "kernel_us": res["per_launch_us"], "accept_frac": res["accept_frac"],
             "roofline_frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS,
-            "note": "host_plan_ms = one step's plan from the serial MT19937 stream by a single host thread (emx_host_plan_mt, no GPU); "
-                    "emx_run overlaps plan production with the device through its plan pipeline"}
+            "note": "host_plan_ms = one step's plan made inline by ONE host thread (emx_host_plan_mt, no GPU) -- round 1's path; emx_run "
+                    "now takes its plans from the host pipeline (csrc/emx_mtpipe.cpp: MT19937 generator thread, tokenizer thread, "
+                    "3 finisher threads confined to one L3 domain, uploads on a side stream), so ms_per_step is the pipeline's rate"}
 
 
-def quality_entry(device, rng="philox", nwalkers=2048, nsteps=2000, thin_by=25, burn=2000):
+def quality_entry(device, rng="philox"):
     """Acceptance fraction and integrated autocorrelation time (reference estimator, c=5) of the 64-dim correlated
-    Gaussian, StretchMove a=2: 2048 walkers, 2000 burn-in + 50 000 steps (>= 50 tau), next to the reference's own
-    numbers for the same configuration (static file from the build container)."""
+    Gaussian, StretchMove a=2, in the configuration the reference itself was run in (tests/golden/quality_ref.json, made by
+    `tools/quality.py --ref` in the build container: 1024 walkers, 2000 burn-in + 100 000 steps = 68 tau, thin_by 25), next to
+    the reference's numbers.  Different random streams: the comparison is statistical (2 % bar, BASELINE.json)."""
     import emcee_amd
     D = 64
+    ref = None
+    path = os.path.join(ROOT, "tests", "golden", "quality_ref.json")
+    try:
+        ref = json.load(open(path))
+        cfg = ref["config"]
+        nwalkers, nsteps, thin_by, burn = cfg["nwalkers"], cfg["nsteps"], cfg["thin_by"], cfg["burn"]
+    except Exception:  # noqa: BLE001
+        nwalkers, nsteps, thin_by, burn = 1024, 4000, 25, 2000
     mu, cov, icov = dense_gaussian(D)
     p0 = mu + np.random.RandomState(1).randn(nwalkers, D) @ np.linalg.cholesky(cov).T
     s = emcee_amd.EnsembleSampler(nwalkers, D, emcee_amd.targets.DenseGaussian(mu, icov), rng=rng, device=device)
@@ -382,28 +392,21 @@ def quality_entry(device, rng="philox", nwalkers=2048, nsteps=2000, thin_by=25, 
     s.run_mcmc(st, nsteps, thin_by=thin_by, skip_initial_state_check=True)
     t_run = time.perf_counter() - t0
     t0 = time.perf_counter()
-    tau = s.get_autocorr_time(quiet=True)             # in steps (thin_by accounted for by the backend? no: stored units)
+    tau = np.asarray(s.get_autocorr_time(quiet=True)) * thin_by          # the backend counts in stored samples
     t_tau = time.perf_counter() - t0
-    tau = np.asarray(tau) * thin_by
     acc = float(np.mean(s.acceptance_fraction))
     out = {"workload": "%d walkers x 64-dim correlated Gaussian, StretchMove a=2, %d burn-in + %d steps, thin_by=%d, rng=%s"
                        % (nwalkers, burn, nsteps * thin_by, thin_by, rng),
            "accept": acc, "tau_mean": float(np.mean(tau)), "tau_min": float(np.min(tau)), "tau_max": float(np.max(tau)),
            "nsteps_over_tau": float(nsteps * thin_by / np.mean(tau)), "run_seconds": t_run, "tau_seconds": t_tau}
-    path = os.path.join(ROOT, "profiles", "r02", "quality_ref.json")
-    if os.path.exists(path):
-        try:
-            ref = json.load(open(path))
-            cfg, r = ref["config"], ref["results"][0]
-            same = (cfg["nwalkers"], cfg["nsteps"], cfg["thin_by"], cfg["burn"]) == (nwalkers, nsteps, thin_by, burn)
-            out["reference"] = {"source": "profiles/r02/quality_ref.json (reference emcee in the build container; static)",
-                                "same_configuration": bool(same), "accept": r["accept_mean"], "tau_mean": r["tau_mean"],
-                                "nsteps_over_tau": r["chain_over_tau"], "seconds": r["seconds"]}
-            out["accept_rel_diff"] = acc / r["accept_mean"] - 1.0
-            out["tau_rel_diff"] = float(np.mean(tau)) / r["tau_mean"] - 1.0
-            out["within_2pct"] = bool(abs(out["accept_rel_diff"]) < 0.02 and abs(out["tau_rel_diff"]) < 0.02)
-        except Exception as e:  # noqa: BLE001
-            out["reference"] = "unreadable: %r" % (e,)
+    if ref is not None:
+        r = ref["results"][0]
+        out["reference"] = {"source": "tests/golden/quality_ref.json (reference emcee in the build container, tools/quality.py --ref; static)",
+                            "accept": r["accept_mean"], "tau_mean": r["tau_mean"], "nsteps_over_tau": r["chain_over_tau"],
+                            "seconds": r["seconds"]}
+        out["accept_rel_diff"] = acc / r["accept_mean"] - 1.0
+        out["tau_rel_diff"] = float(np.mean(tau)) / r["tau_mean"] - 1.0
+        out["within_2pct"] = bool(abs(out["accept_rel_diff"]) < 0.02 and abs(out["tau_rel_diff"]) < 0.02)
     return out
 
 

@@ -6,9 +6,16 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
+
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 namespace emx {
 namespace {
@@ -20,8 +27,85 @@ namespace {
 #endif
 
 constexpr int BLK = 624;
-constexpr uint64_t NBLK = 2048;          // generator ring: 2048 blocks = 1.28 M words (5 MB) + the same for the raw keys
+constexpr uint64_t NBLK = 256;           // generator ring: 256 blocks = 160 k words (640 KB): stays cache resident between the two threads
 constexpr int MAX_SPLITS = 64;
+
+inline uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// The threads hand each other megabytes per step through the cache hierarchy (the word ring, the token and staging
+// buffers).  Spread over the CCDs / sockets of a large host by the scheduler they run 6x slower than the calling thread
+// alone (measured on a 2 x EPYC 9575F: 0.66 ms/step against 0.105 ms/step inside one L3 domain), so they are confined
+// to the CPUs that share the last-level cache with the CPU the caller runs on (within the process's own affinity
+// mask).  EMX_PIPE_AFFINITY=off disables it, EMX_PIPE_AFFINITY=<cpu list, e.g. 0-7,128-135> overrides it.
+#if defined(__linux__)
+struct CpuSet {
+    cpu_set_t set;
+    bool valid = false;
+};
+
+bool parse_cpu_list(const char* txt, cpu_set_t& out) {
+    CPU_ZERO(&out);
+    int count = 0;
+    const char* p = txt;
+    while (*p) {
+        while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+        if (!*p) break;
+        char* e = nullptr;
+        const long a = strtol(p, &e, 10);
+        if (e == p) return false;
+        long b = a;
+        p = e;
+        if (*p == '-') {
+            b = strtol(p + 1, &e, 10);
+            if (e == p + 1) return false;
+            p = e;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+            CPU_SET((int)c, &out);
+            ++count;
+        }
+    }
+    return count > 0;
+}
+
+CpuSet pipeline_cpus() {
+    CpuSet r;
+    const char* env = getenv("EMX_PIPE_AFFINITY");
+    if (env && (!strcmp(env, "off") || !strcmp(env, "0") || !*env)) return r;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return r;
+    cpu_set_t want;
+    if (env) {
+        if (!parse_cpu_list(env, want)) return r;
+    } else {
+        const int cpu = sched_getcpu();
+        if (cpu < 0) return r;
+        char path[128], buf[512];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+        FILE* f = fopen(path, "r");
+        if (!f) return r;
+        const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+        buf[n] = 0;
+        if (!parse_cpu_list(buf, want)) return r;
+    }
+    CPU_AND(&r.set, &want, &allowed);
+    r.valid = CPU_COUNT(&r.set) >= 2;        // a single CPU for five busy threads would be worse than no pinning
+    return r;
+}
+
+void confine(std::thread& t, const CpuSet& cs) {
+    if (cs.valid) pthread_setaffinity_np(t.native_handle(), sizeof(cs.set), &cs.set);
+}
+#else
+struct CpuSet {
+    bool valid = false;
+};
+CpuSet pipeline_cpus() { return CpuSet(); }
+void confine(std::thread&, const CpuSet&) {}
+#endif
 
 struct Backoff {
     int n = 0;
@@ -78,36 +162,57 @@ EMX_CLONES void convert_pairs(const uint32_t* __restrict w, double* __restrict d
     }
 }
 
-// stretch.py:30  zz = ((a - 1) * u + 1) ** 2 / a
-EMX_CLONES void stretch_zz(double* __restrict s, int64_t n, double a) {
-    for (int64_t t = 0; t < n; ++t) {
-        const double tt = (a - 1.0) * s[t] + 1.0;
-        s[t] = tt * tt / a;
+// stretch.py:30  zz = ((a - 1) * rand(Ns) + 1) ** 2 / a, straight from the word pairs
+EMX_CLONES void convert_pairs_zz(const uint32_t* __restrict w, double* __restrict dst, int64_t n, double a) {
+    for (int64_t e = 0; e < n; ++e) {
+        const int32_t hi = (int32_t)(w[2 * e] >> 5), lo = (int32_t)(w[2 * e + 1] >> 6);
+        const double u = (hi * 67108864.0 + lo) / 9007199254740992.0;
+        const double tt = (a - 1.0) * u + 1.0;
+        dst[e] = tt * tt / a;
     }
+}
+
+// inverse of MT19937's output tempering: the generator state words behind a block of outputs
+inline uint32_t untemper(uint32_t y) {
+    y ^= y >> 18;                                   // an involution: 2 * 18 >= 32
+    y ^= (y << 15) & 0xefc60000u;                   // an involution: the mask shifted by 15 again has no bit left in it
+    uint32_t t = y;                                 // y ^= (y << 7) & B: each round recovers 7 more low bits
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    y = t;
+    y ^= y >> 11;                                   // y ^= y >> 11: y1 ^ y1 >> 11 ^ y1 >> 22
+    y ^= y >> 22;
+    return y;
 }
 
 struct WordStream {
     std::vector<uint32_t> ring;      // tempered words, NBLK blocks
-    std::vector<uint32_t> kring;     // the matching untempered state words (generator state after each twist)
     alignas(64) std::atomic<uint64_t> produced{0};     // blocks produced
     alignas(64) std::atomic<uint64_t> keep{0};         // lowest block the reader may still touch
     std::atomic<bool> stop{false};
+    uint64_t gen_wait_ns = 0, gen_blocks = 0, rd_wait_ns = 0;
 };
 
 void generator_main(WordStream* ws, const uint32_t* start_key) {
     // block 0 is the block the caller's generator currently stands in (no twist)
-    std::memcpy(&ws->kring[0], start_key, BLK * 4);
-    temper_block(&ws->kring[0], &ws->ring[0]);
+    alignas(64) uint32_t key[2][BLK];
+    std::memcpy(key[0], start_key, BLK * 4);
+    temper_block(key[0], &ws->ring[0]);
     ws->produced.store(1, std::memory_order_release);
     Backoff bo;
     for (uint64_t b = 1; !ws->stop.load(std::memory_order_relaxed);) {
         if (b - ws->keep.load(std::memory_order_acquire) >= NBLK - 1) {
+            const uint64_t t0 = now_ns();
             bo.pause();
+            ws->gen_wait_ns += now_ns() - t0;
             continue;
         }
         bo.n = 0;
-        const uint32_t* prev = &ws->kring[((b - 1) % NBLK) * BLK];
-        uint32_t* cur = &ws->kring[(b % NBLK) * BLK];
+        ws->gen_blocks = b;
+        const uint32_t* prev = key[(b - 1) & 1];
+        uint32_t* cur = key[b & 1];
         twist_block(prev, cur);
         temper_block(cur, &ws->ring[(b % NBLK) * BLK]);
         ws->produced.store(b + 1, std::memory_order_release);
@@ -136,6 +241,11 @@ struct Reader {
         ws->keep.store(a > 0 ? (a - 1) / BLK : 0, std::memory_order_release);
         Backoff bo;
         uint64_t prod;
+        if (ws->produced.load(std::memory_order_acquire) * BLK <= a) {
+            const uint64_t t0 = now_ns();
+            while (ws->produced.load(std::memory_order_acquire) * BLK <= a && !stop->load(std::memory_order_relaxed)) bo.pause();
+            ws->rd_wait_ns += now_ns() - t0;
+        }
         while ((prod = ws->produced.load(std::memory_order_acquire)) * BLK <= a) {
             if (stop->load(std::memory_order_relaxed)) {
                 dead = true;
@@ -221,17 +331,26 @@ struct Reader {
         } while (val > rng && !dead);
         return val;
     }
-    // n consecutive random_sample() values
-    void fill_doubles(double* dst, int64_t n) {
+    // n consecutive random_sample() values; zz_a != 0: transformed to the stretch factor on the fly
+    void fill_doubles(double* dst, int64_t n, double zz_a = 0.0) {
         int64_t k = 0;
         while (k < n && !dead) {
             const size_t av = avail();
             if (av < 2) {                    // the window ends in the middle of a pair
-                dst[k++] = next_double();
+                const double u = next_double();
+                if (zz_a != 0.0) {
+                    const double tt = (zz_a - 1.0) * u + 1.0;
+                    dst[k++] = tt * tt / zz_a;
+                } else {
+                    dst[k++] = u;
+                }
                 continue;
             }
             const int64_t take = std::min<int64_t>((int64_t)(av / 2), n - k);
-            convert_pairs(cur, dst + k, take);
+            if (zz_a != 0.0)
+                convert_pairs_zz(cur, dst + k, take, zz_a);
+            else
+                convert_pairs(cur, dst + k, take);
             cur += 2 * take;
             k += take;
         }
@@ -337,6 +456,8 @@ struct MtPlanPipeline::Impl {
     std::thread gen, tok;
     std::vector<std::thread> fin;
     bool joined = false;
+    uint64_t t_start = 0, tok_wait_sink_ns = 0, tok_done_ns = 0;
+    std::vector<uint64_t> fin_wait_ns, fin_busy_ns;
 
     void tokenizer_main();
     void finisher_main(int id);
@@ -368,7 +489,7 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     int K = nworkers;
     if (K <= 0) {
         const unsigned hw = std::thread::hardware_concurrency();
-        K = hw >= 32 ? 6 : hw >= 16 ? 4 : hw >= 8 ? 3 : hw >= 4 ? 2 : 1;
+        K = hw >= 8 ? 3 : hw >= 4 ? 2 : 1;       // three finishers keep up with the tokenizer (tools/mt_pipe_bench.py)
     }
     K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(K, nsinks), nsteps));
     m.K = K;
@@ -376,7 +497,6 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     m.NSNAP = nsinks + 4;
     m.start = start;
     m.ws.ring.resize(NBLK * BLK);
-    m.ws.kring.resize(NBLK * BLK);
     m.raws.resize(m.NR);
     bool any_shuffle = false, any_de = false, any_sn = false;
     for (auto& mv : m.moves) {
@@ -403,9 +523,18 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
         m.raw_done[s].v.store((int64_t)s - m.NR);     // "step s - NR is done": slot s is free for step s
     }
     for (int s = 0; s < nsinks; ++s) m.sink_ready[s].v.store(-1);
+    m.fin_wait_ns.assign(K, 0);
+    m.fin_busy_ns.assign(K, 0);
+    m.t_start = now_ns();
+    const CpuSet cs = pipeline_cpus();
     m.gen = std::thread(generator_main, &m.ws, m.start.key);
+    confine(m.gen, cs);
     m.tok = std::thread([&m] { m.tokenizer_main(); });
-    for (int k = 0; k < K; ++k) m.fin.emplace_back([&m, k] { m.finisher_main(k); });
+    confine(m.tok, cs);
+    for (int k = 0; k < K; ++k) {
+        m.fin.emplace_back([&m, k] { m.finisher_main(k); });
+        confine(m.fin.back(), cs);
+    }
 }
 
 int MtPlanPipeline::workers() const { return impl_->K; }
@@ -419,6 +548,15 @@ void MtPlanPipeline::Impl::join_all() {
     for (auto& t : fin)
         if (t.joinable()) t.join();
     joined = true;
+    if (getenv("EMX_PIPE_STATS")) {
+        const double tot = (now_ns() - t_start) * 1e-6;
+        fprintf(stderr, "[emx pipe] N=%lld steps=%lld workers=%d: %.3f ms total; generator %llu blocks, waited %.3f ms for space; tokenizer finished at "
+                        "%.3f ms, waited %.3f ms for words and %.3f ms for sinks/raw slots;",
+                (long long)N, (long long)nsteps, K, tot, (unsigned long long)ws.gen_blocks, ws.gen_wait_ns * 1e-6, tok_done_ns * 1e-6,
+                ws.rd_wait_ns * 1e-6, tok_wait_sink_ns * 1e-6);
+        for (int k = 0; k < K; ++k) fprintf(stderr, " fin%d busy %.3f wait %.3f;", k, fin_busy_ns[k] * 1e-6, fin_wait_ns[k] * 1e-6);
+        fprintf(stderr, "\n");
+    }
 }
 
 MtPlanPipeline::~MtPlanPipeline() {
@@ -456,8 +594,7 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
     for (int split = 0; split < S && !rd.dead; ++split) {
         const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
         if (mv.kind == EMX_MOVE_STRETCH) {
-            rd.fill_doubles(sk.s0 + base, ns);                                                     // stretch.py:30
-            stretch_zz(sk.s0 + base, ns, mv.a);
+            rd.fill_doubles(sk.s0 + base, ns, mv.a);                                               // stretch.py:30
             rd.fill_randint32(sk.p0 + base, ns, (uint64_t)nc);                                     // stretch.py:32 (complement index)
         } else if (mv.kind == EMX_MOVE_DE) {
             const uint64_t pop = (uint64_t)nc * (uint64_t)(nc - 1);
@@ -521,9 +658,13 @@ void MtPlanPipeline::Impl::tokenizer_main() {
     for (int64_t n = 0; n < nsteps; ++n) {
         Backoff bo;
         // the sink of step n is free once step n - nsinks has been uploaded; the raw slot once its finisher is done
-        while ((n >= released.load(std::memory_order_acquire) + nsinks || raw_done[n % NR].v.load(std::memory_order_acquire) != n - NR) &&
-               !stop.load(std::memory_order_relaxed))
-            bo.pause();
+        if (n >= released.load(std::memory_order_acquire) + nsinks || raw_done[n % NR].v.load(std::memory_order_acquire) != n - NR) {
+            const uint64_t t0 = now_ns();
+            while ((n >= released.load(std::memory_order_acquire) + nsinks || raw_done[n % NR].v.load(std::memory_order_acquire) != n - NR) &&
+                   !stop.load(std::memory_order_relaxed))
+                bo.pause();
+            tok_wait_sink_ns += now_ns() - t0;
+        }
         if (stop.load(std::memory_order_relaxed)) return;
         tokenize(rd, n, has_gauss, gauss);
         if (rd.dead) return;
@@ -533,10 +674,14 @@ void MtPlanPipeline::Impl::tokenizer_main() {
             const uint64_t blk = a > 0 ? (a - 1) / BLK : 0;
             MT19937Legacy& sn = snaps[n % NSNAP];
             // the block is still retained: keep <= (a - 1) / BLK and the generator never overwrites blocks >= keep
-            sn.set_state(&ws.kring[(blk % NBLK) * BLK], (int)(a - blk * BLK), has_gauss, gauss);
+            uint32_t key[BLK];
+            const uint32_t* out = &ws.ring[(blk % NBLK) * BLK];
+            for (int i = 0; i < BLK; ++i) key[i] = untemper(out[i]);
+            sn.set_state(key, (int)(a - blk * BLK), has_gauss, gauss);
         }
         raw_ready[n % NR].v.store(n, std::memory_order_release);
     }
+    tok_done_ns = now_ns() - t_start;
 }
 
 // ---- finisher: one whole step, independent of every other step ----------------------------------------------------
@@ -608,9 +753,13 @@ void MtPlanPipeline::Impl::finisher_main(int id) {
     std::vector<uint8_t> labels((size_t)N);
     for (int64_t n = id; n < nsteps; n += K) {
         Backoff bo;
+        const uint64_t t0 = now_ns();
         while (raw_ready[n % NR].v.load(std::memory_order_acquire) != n && !stop.load(std::memory_order_relaxed)) bo.pause();
         if (stop.load(std::memory_order_relaxed)) return;
+        const uint64_t t1 = now_ns();
+        fin_wait_ns[id] += t1 - t0;
         finish_step(n, labels);
+        fin_busy_ns[id] += now_ns() - t1;
         raw_done[n % NR].v.store(n, std::memory_order_release);
         sink_ready[n % nsinks].v.store(n, std::memory_order_release);
     }
