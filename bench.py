@@ -11,7 +11,7 @@ RNG, float64 -- weak-scaled over the GPUs.  The same JSON line also carries (ran
   configs     C3 262144x32 Rosenbrock, C4 65536x64 DE+snooker mixture, C5 16384x1024 diagonal Gaussian and C2 with
               the chain stored every step: ms_per_step, wu_per_s, roofline fraction (SURVEY.md 8d bytes formulas)
   exact_mode  C2 under rng=mt19937 (the mode that reproduces reference emcee's chain for a seed)
-  quality     acceptance fraction and integrated autocorrelation time of a 2048x64 run >= 50 tau long, next to the
+  quality     acceptance fraction and integrated autocorrelation time of a 1024x64 run 68 tau long, next to the
               reference's numbers for the same configuration (tests/golden/quality_ref.json, build container)
   cpu_baseline reference emcee itself when /root/reference is importable (build container), otherwise the NumPy
               port (oracle/) timed here + the committed reference timings (profiles/r02/cpu_reference.json)
@@ -143,6 +143,25 @@ def log(*a):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+def usable_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a container on a 256-thread
+    host may be limited to a handful: oversubscribing it makes every parallel leg slower than the serial one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:  # noqa: BLE001
+            pass
+    return n
+
+
 def _port_leg(so, wl, fn, budget_s, label, cores):
     rs = np.random.RandomState(7)
     out = so.run(wl.p0, 1, fn, rs, store=False)                  # warm-up (page faults, BLAS initialisation)
@@ -182,7 +201,7 @@ def cpu_baseline(wl, budget_s=14.0):
     except Exception:  # noqa: BLE001
         threadpool_limits = None
     mu, cov, icov = wl.params
-    ncores = os.cpu_count()
+    ncores = usable_cores()
     embedded = None
     path = os.path.join(ROOT, "profiles", "r02", "cpu_reference.json")
     if os.path.exists(path):
@@ -229,7 +248,8 @@ def cpu_baseline(wl, budget_s=14.0):
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
             legs.append(_port_leg(so, wl, fn, budget_s, "port of vectorize=True, 1 BLAS thread", 1))
-        legs.append(_port_leg(so, wl, fn, budget_s / 2, "port of vectorize=True, BLAS threads = all cores", ncores))
+        with threadpool_limits(limits=ncores):
+            legs.append(_port_leg(so, wl, fn, budget_s / 2, "port of vectorize=True, %d BLAS threads" % ncores, ncores))
     else:
         legs.append(_port_leg(so, wl, fn, budget_s, "port of vectorize=True, default BLAS threads", ncores))
     # the reference's documented parallel path: per-walker log_prob_fn through pool.map (ensemble.py:492-496)
@@ -411,7 +431,7 @@ def quality_entry(device, rng="philox"):
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU measurement
-EXCHANGES = ("allgather", "pull")
+EXCHANGES = ("allgather", "pull", "direct")
 
 
 def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode, single_block=False):
@@ -423,6 +443,8 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
     ens.set_exchange(exchange)
     comm_used = None
     if comm_mode == "torch":
+        if exchange == "direct":
+            raise RuntimeError("the direct exchange is driven by libemx itself (--comm rccl)")
         from emcee_amd.parallel import DeviceEngine, PullStepper, ShardedStepper
         ens.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels + RCCL ordered on one stream
         eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank), exchange=exchange)
@@ -437,6 +459,9 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
         uid = [DeviceEnsemble.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ens.comm_init(rank, world, uid[0])      # ncclCommInitRank; emx_run now exchanges per half-step
+        if exchange == "direct":                # map the peers' coordinate arrays and barrier flags (IPC handles over gloo)
+            from emcee_amd.parallel import import_direct_peers
+            import_direct_peers(ens, dist)
         run = lambda k: ens.run(k, 1, False)  # noqa: E731
         comm_used = "libemx->RCCL"
 
@@ -702,7 +727,9 @@ def main():
                 dist.destroy_process_group()
                 return
             how = ", %s via %s" % ({"pull": "all-to-all of the partner rows (pull exchange)",
-                                    "allgather": "all-gather of the updated rows"}.get(best["exchange"], best["exchange"]), best["comm"])
+                                    "allgather": "all-gather of the updated rows",
+                                    "direct": "partner rows read in place from the peers' HBM (direct exchange)"}.get(
+                                        best["exchange"], best["exchange"]), best["comm"])
             line = headline(wl, best["wall_s"], best["gpu_ms"], None, best["accept_frac"], best["status"], how,
                             {"timed_blocks": best["blocks"]})
             line["scaling"] = entry["scaling"]

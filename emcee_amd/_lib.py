@@ -11,7 +11,7 @@ TARGET_HOST, TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_ROSENBROCK, TARGET_BO
 MOVE_STRETCH, MOVE_DE, MOVE_SNOOKER, MOVE_GAUSS = range(4)
 GAUSS_VECTOR, GAUSS_RANDOM, GAUSS_SEQUENTIAL = range(3)
 RNG_INPUTS, RNG_MT19937, RNG_PHILOX = range(3)
-EXCHANGE_ALLGATHER, EXCHANGE_PULL = range(2)
+EXCHANGE_ALLGATHER, EXCHANGE_PULL, EXCHANGE_DIRECT = range(3)
 
 
 class MoveDesc(C.Structure):
@@ -88,6 +88,10 @@ SIGNATURES = {
     "emx_pull_apply": (C.c_int, [_P, C.c_int32]),
     "emx_replica_pack": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "emx_replica_unpack": (C.c_int, [_P]),
+    "emx_direct_export": (C.c_int, [_P, _u8p]),
+    "emx_direct_import": (C.c_int, [_P, _u8p]),
+    "emx_direct_attach": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "emx_direct_halfstep": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "emx_host_pull_capacity": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "emx_comm_load": (C.c_int, [C.c_char_p]),
     "emx_comm_get_unique_id": (C.c_int, [_u8p]),

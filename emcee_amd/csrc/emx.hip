@@ -28,6 +28,7 @@ namespace {
 std::string g_err;
 
 constexpr int PLAN_RING = 16;
+constexpr int EMX_MAX_RANKS = 1024;      // pull / all-gather exchanges: counter storage
 
 // ------------------------------------------------------------------------------------------
 // exact (NumPy-stream) plan of one step: every draw red_blue.py / stretch.py / de.py /
@@ -360,11 +361,20 @@ struct emx_ctx {
     int exchange = EMX_EXCHANGE_ALLGATHER;
     PlanSlot cplan;                   // compact plan: the slots whose walker this rank owns
     int64_t cplan_rows = 0;
-    int32_t* pull_counts = nullptr;   // [1 + world]
-    int32_t* pull_sendidx = nullptr;  // [world][pull_idx_cap]
-    int64_t pull_idx_cap = 0;
+    int32_t* pull_counts = nullptr;   // [2][1 + world] + ticket: counters of the current / next half-step (k_pull_plan re-arms them)
+    int pull_parity = 0;
     int64_t pull_cap_cur = 0;         // records per pair of the prepared half-step
     int pull_split = -1;
+    // direct exchange: peers' coordinate arrays and barrier flags mapped into this process / device
+    double* peerX[EMX_MAX_PEERS] = {};
+    unsigned long long* peer_flags[EMX_MAX_PEERS] = {};
+    bool peer_ipc_x[EMX_MAX_PEERS] = {}, peer_ipc_f[EMX_MAX_PEERS] = {};   // opened with hipIpcOpenMemHandle (to be closed)
+    unsigned long long* my_flags = nullptr;   // [EMX_MAX_PEERS], fine-grained device memory when available
+    bool peers_ready = false;
+    unsigned long long direct_epoch = 0;
+    int32_t* direct_counts = nullptr;         // [64]: owned slots per split of the step begun
+    bool direct_planned = false;              // k_own_plan has run for the step begun
+    int64_t tune_direct_timeout_ms = 5000;
     // hipGraph replay of the native 8-step block (single move, thin_by 1, one rank)
     struct GraphSlot {
         hipGraph_t graph = nullptr;
@@ -393,6 +403,9 @@ struct emx_ctx {
 };
 
 static void graph_invalidate(emx_ctx* c);
+static void direct_detach(emx_ctx* c);
+static int direct_ensure(emx_ctx* c);
+static void exchange_free(emx_ctx* c);
 
 // forget native plans evaluated ahead of time; the Gaussian sequential cursors they advanced go back
 static void drop_prepared(emx_ctx* c) {
@@ -593,6 +606,13 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         a.gseed = c->ph_seed;
         a.gstep = c->cur.nat.step;
     }
+    if (c->exchange == EMX_EXCHANGE_DIRECT && c->peers_ready && c->world > 1 && move != MOVE_EVAL && X == c->X) {
+        a.npeer = c->world;
+        for (int q = 0; q < c->world; ++q) {
+            a.peerX[q] = c->peerX[q];
+            a.peer_lo[q] = (int32_t)(c->N * q / c->world);
+        }
+    }
     a.dbg = (c->dbg && nblocks <= c->dbg_blocks && move != MOVE_EVAL) ? c->dbg : nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;
@@ -763,7 +783,7 @@ int emx_destroy(emx_ctx* c) {
     }
     {
         auto& p = c->cplan;
-        void* q[] = {p.order, p.p0, p.p1, p.p2, p.s0, p.uacc, p.logu, p.fac, c->pull_counts, c->pull_sendidx};
+        void* q[] = {p.order, p.p0, p.p1, p.p2, p.s0, p.uacc, p.logu, p.fac, c->pull_counts};
         for (void* x : q)
             if (x) hipFree(x);
     }
@@ -786,6 +806,9 @@ int emx_destroy(emx_ctx* c) {
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (auto e : c->prof) hipEventDestroy(e);
+    direct_detach(c);
+    if (c->my_flags) hipFree(c->my_flags);
+    if (c->direct_counts) hipFree(c->direct_counts);
     if (c->pipe) delete c->pipe, c->pipe = nullptr;
     if (c->up_stream) hipStreamDestroy(c->up_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -809,7 +832,7 @@ int emx_sync(emx_ctx* c) {
 int emx_status(emx_ctx* c, uint32_t* bits) {
     HIPOK(c, hipStreamSynchronize(c->stream));      // every launch that could still raise a bit has finished
     uint32_t b = 0;
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 4; ++k)
         if (__atomic_exchange_n(&c->status_host[k], 0u, __ATOMIC_ACQ_REL)) b |= 1u << k;
     *bits = b;
     return 0;
@@ -839,6 +862,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "gauss_materialize")) {
         c->tune_gauss_materialize = v;
+        return 0;
+    }
+    if (!strcmp(key, "direct_timeout_ms")) {   // direct exchange: how long the device-side barrier waits for a peer
+        c->tune_direct_timeout_ms = v > 0 ? v : 5000;
         return 0;
     }
     if (!strcmp(key, "mt_pipeline")) {   // exact mode: -1 auto, 0 plans made inline by the calling thread, k > 0 finisher threads
@@ -1526,6 +1553,8 @@ static int do_halfstep(emx_ctx* c, int split, int target) {
     emx_ctx::PlanSlot* ps = cur.slot >= 0 ? &c->ring[cur.slot] : nullptr;
     NEED(c, c->exchange != EMX_EXCHANGE_PULL || c->world == 1 || target == EMX_TARGET_HOST,
          "pull exchange: use emx_pull_prepare / emx_pull_apply");
+    NEED(c, c->exchange != EMX_EXCHANGE_DIRECT || c->world == 1 || target == EMX_TARGET_HOST,
+         "direct exchange: use emx_direct_halfstep");
     double* sb = nullptr;
     if (c->sendbuf && target != EMX_TARGET_HOST && c->exchange == EMX_EXCHANGE_ALLGATHER) sb = c->sendbuf;
     NEED(c, !sb || hi - lo <= c->sendbuf_rows, "exchange buffers too small for this move: call emx_set_shard after emx_set_moves");
@@ -1627,6 +1656,7 @@ int emx_step_end(emx_ctx* c) {
             s.busy = true;
         }
     }
+    c->direct_planned = false;
     if (cur.store) c->stored++;
     c->proposals++;
     if (c->rng_mode == EMX_RNG_PHILOX) c->ph_step++;
@@ -1987,6 +2017,8 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
     NEED(c, c->target != EMX_TARGET_HOST, "emx_run needs a device target");
     NEED(c, (c->world == 1 && !c->sendbuf) || c->comm,
          "emx_run on a sharded context needs emx_comm_init (or drive emx_halfstep / the collective from the host layer)");
+    NEED(c, c->exchange != EMX_EXCHANGE_DIRECT || c->world == 1 || c->peers_ready,
+         "direct exchange: the peers' arrays are not mapped yet (emx_direct_export / emx_direct_import, or emx_direct_attach)");
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     const int64_t total = nsteps * thin_by;
     bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
@@ -2042,11 +2074,20 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
             int rc = emx_step_begin(c, st, &mvi, &S);
             if (rc) return rc;
             for (int s = 0; s < S; ++s) {
+                if (c->exchange == EMX_EXCHANGE_DIRECT && c->world > 1) {
+                    // partner rows are read in place from the peers' HBM: a device-side barrier, then the half-step
+                    rc = emx_direct_halfstep(c, s, 1);
+                    if (rc) {
+                        c->cur.active = false;
+                        return rc;
+                    }
+                    continue;
+                }
                 if (c->comm && c->exchange == EMX_EXCHANGE_PULL) {
                     // partner rows only: pack what the peers will read, all-to-all, fold in, update own walkers
                     int64_t cap = 0;
                     rc = emx_pull_prepare(c, s, &cap);
-                    if (!rc) rc = rccl_all_to_all(c, (size_t)cap * (c->D + 1));
+                    if (!rc) rc = rccl_all_to_all(c, (size_t)cap * (c->D + 1));      // cap counts the header record
                     if (!rc) rc = emx_pull_apply(c, s);
                     if (rc) {
                         c->cur.active = false;
@@ -2081,7 +2122,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
         }
     }
     c->prep_hint = 1;
-    if (c->comm && c->exchange == EMX_EXCHANGE_PULL) {
+    if (c->comm && c->exchange != EMX_EXCHANGE_ALLGATHER && c->world > 1) {
         // re-synchronise the replicas: every rank's block of (coords, log_prob, accepted) to every rank
         int64_t per = 0;
         int rc = emx_replica_pack(c, &per);
@@ -2143,7 +2184,7 @@ static void exchange_free(emx_ctx* c) {
 
 static void pull_layout(const emx_ctx* c, int64_t& send, int64_t& recv) {
     const int64_t G = c->world, bmax = (c->N + G - 1) / G;
-    const int64_t pairs = G * pull_capacity_max(c) * (c->D + 1);
+    const int64_t pairs = G * (pull_capacity_max(c) + 1) * (c->D + 1);       // per pair: [count] + cap records
     send = std::max<int64_t>(pairs, bmax * (c->D + 3));
     recv = std::max<int64_t>(pairs, G * bmax * (c->D + 3));
 }
@@ -2168,15 +2209,11 @@ static int pull_ensure(emx_ctx* c) {
         HIPOK(c, hipMalloc((void**)&p.fac, bmax * 8));
         c->cplan_rows = bmax;
     }
-    const int64_t capmax = pull_capacity_max(c);
-    if (!c->pull_counts || c->pull_idx_cap < capmax) {
-        HIPOK(c, hipStreamSynchronize(c->stream));
-        if (c->pull_counts) hipFree(c->pull_counts);
-        if (c->pull_sendidx) hipFree(c->pull_sendidx);
-        c->pull_counts = c->pull_sendidx = nullptr;
-        HIPOK(c, hipMalloc((void**)&c->pull_counts, (size_t)(1 + G) * 4));
-        HIPOK(c, hipMalloc((void**)&c->pull_sendidx, (size_t)G * capmax * 4));
-        c->pull_idx_cap = capmax;
+    if (!c->pull_counts) {
+        const size_t n = (size_t)(2 * (1 + EMX_MAX_RANKS) + 1) * 4;
+        HIPOK(c, hipMalloc((void**)&c->pull_counts, n));
+        HIPOK(c, hipMemset(c->pull_counts, 0, n));
+        c->pull_parity = 0;
     }
     int64_t send, recv;
     pull_layout(c, send, recv);
@@ -2196,7 +2233,7 @@ static int pull_ensure(emx_ctx* c) {
 }
 
 int emx_set_exchange(emx_ctx* c, int32_t kind) {
-    NEED(c, kind == EMX_EXCHANGE_ALLGATHER || kind == EMX_EXCHANGE_PULL, "unknown exchange kind %d", kind);
+    NEED(c, kind == EMX_EXCHANGE_ALLGATHER || kind == EMX_EXCHANGE_PULL || kind == EMX_EXCHANGE_DIRECT, "unknown exchange kind %d", kind);
     NEED(c, c->world == 1 && !c->comm && !c->sendbuf, "emx_set_exchange: call it before emx_set_shard / emx_comm_init");
     c->exchange = kind;
     return 0;
@@ -2212,6 +2249,11 @@ int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
     exchange_free(c);
     c->pull_split = -1;
     if (c->exchange == EMX_EXCHANGE_PULL) return world > 1 ? pull_ensure(c) : 0;
+    if (c->exchange == EMX_EXCHANGE_DIRECT) {
+        NEED(c, world <= EMX_MAX_PEERS, "direct exchange: at most %d ranks (the GPUs of one node)", EMX_MAX_PEERS);
+        direct_detach(c);
+        return direct_ensure(c);
+    }
     if (world > 1) {
         const int64_t per = shard_rows_per_rank(c->N, world, min_nsplits_of(c));
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));
@@ -2286,7 +2328,9 @@ int emx_pull_prepare(emx_ctx* c, int32_t split, int64_t* records_per_peer) {
     const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
     const int npart = partners_of(mv.kind);
     const int64_t cap = pull_capacity(c->N, c->world, cur.S, npart);
-    HIPOK(c, hipMemsetAsync(c->pull_counts, 0, (size_t)(1 + c->world) * 4, c->stream));
+    NEED(c, c->world <= EMX_MAX_RANKS, "pull exchange: at most %d ranks", EMX_MAX_RANKS);
+    int32_t* counts = c->pull_counts + (size_t)c->pull_parity * (1 + EMX_MAX_RANKS);
+    int32_t* counts_next = c->pull_counts + (size_t)(c->pull_parity ^ 1) * (1 + EMX_MAX_RANKS);
     if (ns > 0) {
         PullPlanArgs a{};
         a.order = ps.order + pos0;
@@ -2305,10 +2349,14 @@ int emx_pull_prepare(emx_ctx* c, int32_t split, int64_t* records_per_peer) {
         a.cuacc = c->cplan.uacc;
         a.clogu = c->cplan.logu;
         a.cfac = c->cplan.fac;
-        a.counts = c->pull_counts;
-        a.sendidx = c->pull_sendidx;
+        a.counts = counts;
+        a.counts_next = counts_next;
+        a.ticket = c->pull_counts + 2 * (1 + EMX_MAX_RANKS);
+        a.X = c->X;
+        a.rec = c->sendbuf;
         a.status = c->status;
         a.N = (int32_t)c->N;
+        a.D = c->D;
         a.G = c->world;
         a.rank = c->rank;
         a.ns = ns;
@@ -2316,25 +2364,14 @@ int emx_pull_prepare(emx_ctx* c, int32_t split, int64_t* records_per_peer) {
         a.cap = (int32_t)cap;
         hipLaunchKernelGGL(k_pull_plan, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, a);
         HIPOK(c, hipGetLastError());
-    }
-    if (c->world > 1) {
-        PullRowsArgs r{};
-        r.X = c->X;
-        r.rec = c->sendbuf;
-        r.counts = c->pull_counts;
-        r.sendidx = c->pull_sendidx;
-        r.N = (int32_t)c->N;
-        r.D = c->D;
-        r.G = c->world;
-        r.rank = c->rank;
-        r.cap = (int32_t)cap;
-        const int64_t nrec = (int64_t)c->world * cap;
-        hipLaunchKernelGGL(k_pull_pack, dim3((unsigned)((nrec + 15) / 16)), dim3(256), 0, c->stream, r);
-        HIPOK(c, hipGetLastError());
+    } else {
+        HIPOK(c, hipMemsetAsync(counts, 0, (size_t)(1 + c->world) * 4, c->stream));
+        HIPOK(c, hipMemsetAsync(counts_next, 0, (size_t)(1 + c->world) * 4, c->stream));
+        HIPOK(c, hipMemsetAsync(c->sendbuf, 0, (size_t)c->world * (cap + 1) * (c->D + 1) * 8, c->stream));
     }
     c->pull_cap_cur = cap;
     c->pull_split = split;
-    if (records_per_peer) *records_per_peer = cap;
+    if (records_per_peer) *records_per_peer = cap + 1;         // what travels per pair: the count record + cap row records
     return 0;
 }
 
@@ -2358,6 +2395,8 @@ int emx_pull_apply(emx_ctx* c, int32_t split) {
         hipLaunchKernelGGL(k_pull_scatter, dim3((unsigned)((nrec + 15) / 16)), dim3(256), 0, c->stream, r);
         HIPOK(c, hipGetLastError());
     }
+    const int32_t* counts_now = c->pull_counts + (size_t)c->pull_parity * (1 + EMX_MAX_RANKS);
+    c->pull_parity ^= 1;              // the plan kernel re-armed the other buffer for the next half-step
     if (ns <= 0) return 0;
     // the grid is sized for the expected number of owned slots (the kernel's batch loop covers any count;
     // the count itself is read on the device)
@@ -2371,7 +2410,195 @@ int emx_pull_apply(emx_ctx* c, int32_t split) {
         chain_lp = c->chain_lp + (size_t)c->stored * c->N;
     }
     return launch_split(c, mv.kind, c->target, cur.S, split, 0, (int)bound, 0, (int)bound, &mv, &c->cplan, nullptr, c->X,
-                        c->lp, chain, chain_lp, nullptr, nullptr, c->pull_counts);
+                        c->lp, chain, chain_lp, nullptr, nullptr, counts_now);
+}
+
+// ---- direct exchange ---------------------------------------------------------------------------------------------
+static void direct_detach(emx_ctx* c) {
+    for (int q = 0; q < EMX_MAX_PEERS; ++q) {
+        if (c->peer_ipc_x[q] && c->peerX[q]) hipIpcCloseMemHandle(c->peerX[q]);
+        if (c->peer_ipc_f[q] && c->peer_flags[q]) hipIpcCloseMemHandle(c->peer_flags[q]);
+        c->peerX[q] = nullptr;
+        c->peer_flags[q] = nullptr;
+        c->peer_ipc_x[q] = c->peer_ipc_f[q] = false;
+    }
+    c->peers_ready = false;
+}
+
+static int direct_ensure(emx_ctx* c) {
+    const int64_t G = c->world, N = c->N, bmax = (N + G - 1) / G;
+    if (c->cplan_rows < N) {          // the compact plans of all splits of a step, split s at offset off[s]
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        auto& p = c->cplan;
+        void* old[] = {p.order, p.p0, p.p1, p.p2, p.s0, p.uacc, p.logu, p.fac};
+        for (void* q : old)
+            if (q) hipFree(q);
+        HIPOK(c, hipMalloc((void**)&p.order, N * 4));
+        HIPOK(c, hipMalloc((void**)&p.p0, N * 4));
+        HIPOK(c, hipMalloc((void**)&p.p1, N * 4));
+        HIPOK(c, hipMalloc((void**)&p.p2, N * 4));
+        HIPOK(c, hipMalloc((void**)&p.s0, N * 8));
+        HIPOK(c, hipMalloc((void**)&p.uacc, N * 8));
+        HIPOK(c, hipMalloc((void**)&p.logu, N * 8));
+        HIPOK(c, hipMalloc((void**)&p.fac, N * 8));
+        c->cplan_rows = N;
+    }
+    if (!c->direct_counts) {
+        HIPOK(c, hipMalloc((void**)&c->direct_counts, 65 * 4));       // [64]: "a barrier timed out" (later barriers do not wait again)
+        HIPOK(c, hipMemset(c->direct_counts, 0, 65 * 4));
+    }
+    if (!c->my_flags) {
+        // the barrier flags are written by the peers while this device polls them: fine-grained (uncached) device memory
+        // where the runtime offers it, ordinary device memory otherwise (the polls are system-scope atomics either way)
+        void* f = nullptr;
+        if (hipExtMallocWithFlags(&f, EMX_MAX_PEERS * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPOK(c, hipMalloc(&f, EMX_MAX_PEERS * 8));
+        }
+        c->my_flags = (unsigned long long*)f;
+        HIPOK(c, hipMemset(c->my_flags, 0, EMX_MAX_PEERS * 8));
+        c->direct_epoch = 0;
+    }
+    // buffers of the replica re-synchronisation (one all-gather of the blocks when emx_run returns)
+    const int64_t send = bmax * (c->D + 3), recv = G * bmax * (c->D + 3);
+    if (c->send_doubles < send || c->recv_doubles < recv) {
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        exchange_free(c);
+        HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)send * 8));
+        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)recv * 8));
+        c->own_shard_bufs = true;
+        c->send_doubles = send;
+        c->recv_doubles = recv;
+    }
+    return 0;
+}
+
+int emx_direct_export(emx_ctx* c, uint8_t handles[128]) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, c->exchange == EMX_EXCHANGE_DIRECT, "emx_direct_export needs emx_set_exchange(EMX_EXCHANGE_DIRECT)");
+    int rc = direct_ensure(c);
+    if (rc) return rc;
+    static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle size");
+    hipIpcMemHandle_t hx, hf;
+    HIPOK(c, hipIpcGetMemHandle(&hx, c->X));
+    HIPOK(c, hipIpcGetMemHandle(&hf, c->my_flags));
+    memset(handles, 0, 128);
+    memcpy(handles, &hx, sizeof(hx));
+    memcpy(handles + 64, &hf, sizeof(hf));
+    return 0;
+}
+
+int emx_direct_import(emx_ctx* c, const uint8_t* handles) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, c->exchange == EMX_EXCHANGE_DIRECT && c->world >= 1, "emx_direct_import needs the direct exchange and emx_set_shard");
+    int rc = direct_ensure(c);
+    if (rc) return rc;
+    direct_detach(c);
+    for (int q = 0; q < c->world; ++q) {
+        if (q == c->rank) {
+            c->peerX[q] = c->X;
+            c->peer_flags[q] = c->my_flags;
+            continue;
+        }
+        hipIpcMemHandle_t hx, hf;
+        memcpy(&hx, handles + (size_t)q * 128, sizeof(hx));
+        memcpy(&hf, handles + (size_t)q * 128 + 64, sizeof(hf));
+        void *px = nullptr, *pf = nullptr;
+        HIPOK(c, hipIpcOpenMemHandle(&px, hx, hipIpcMemLazyEnablePeerAccess));
+        c->peerX[q] = (double*)px;
+        c->peer_ipc_x[q] = true;
+        HIPOK(c, hipIpcOpenMemHandle(&pf, hf, hipIpcMemLazyEnablePeerAccess));
+        c->peer_flags[q] = (unsigned long long*)pf;
+        c->peer_ipc_f[q] = true;
+    }
+    c->peers_ready = true;
+    return 0;
+}
+
+int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_flags) {
+    NEED(c, c->exchange == EMX_EXCHANGE_DIRECT && c->world >= 1, "emx_direct_attach needs the direct exchange and emx_set_shard");
+    int rc = direct_ensure(c);
+    if (rc) return rc;
+    direct_detach(c);
+    for (int q = 0; q < c->world; ++q) {
+        c->peerX[q] = q == c->rank ? c->X : (double*)peer_coords[q];
+        c->peer_flags[q] = q == c->rank ? c->my_flags : (unsigned long long*)(peer_flags ? peer_flags[q] : nullptr);
+        NEED(c, c->peerX[q], "emx_direct_attach: no coordinate array for rank %d", q);
+    }
+    c->peers_ready = true;
+    return 0;
+}
+
+int emx_direct_halfstep(emx_ctx* c, int32_t split, int32_t barrier) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, c->exchange == EMX_EXCHANGE_DIRECT, "emx_direct_halfstep needs emx_set_exchange(EMX_EXCHANGE_DIRECT)");
+    NEED(c, cur.active && cur.move >= 0 && cur.slot >= 0, "emx_direct_halfstep outside a planned step");
+    NEED(c, split >= 0 && split < cur.S && cur.S <= 64, "split out of range");
+    NEED(c, c->target != EMX_TARGET_HOST, "sharded stepping needs a device target");
+    NEED(c, c->peers_ready || c->world == 1, "direct exchange: peers not mapped");
+    const emx_move_desc& mv = c->moves[cur.move];
+    const auto& ps = c->ring[cur.slot];
+    const int64_t G = c->world, N = c->N;
+    if (!c->direct_planned) {
+        // once per step: the slots of every split whose walker this rank owns
+        HIPOK(c, hipMemsetAsync(c->direct_counts, 0, 64 * 4, c->stream));
+        OwnPlanArgs a{};
+        a.order = ps.order;
+        a.p0 = ps.p0;
+        a.p1 = ps.p1;
+        a.p2 = ps.p2;
+        a.s0 = ps.s0;
+        a.uacc = ps.uacc;
+        a.logu = ps.logu;
+        a.fac = ps.fac;
+        a.corder = c->cplan.order;
+        a.cp0 = c->cplan.p0;
+        a.cp1 = c->cplan.p1;
+        a.cp2 = c->cplan.p2;
+        a.cs0 = c->cplan.s0;
+        a.cuacc = c->cplan.uacc;
+        a.clogu = c->cplan.logu;
+        a.cfac = c->cplan.fac;
+        a.counts = c->direct_counts;
+        for (int s = 0; s <= cur.S; ++s) a.off[s] = cur.off[s];
+        a.N = (int32_t)N;
+        a.G = (int32_t)G;
+        a.rank = c->rank;
+        a.S = cur.S;
+        hipLaunchKernelGGL(k_own_plan, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, a);
+        HIPOK(c, hipGetLastError());
+        c->direct_planned = true;
+    }
+    if (barrier && G > 1) {
+        PeerBarrierArgs b{};
+        for (int q = 0; q < G; ++q) {
+            NEED(c, c->peer_flags[q], "direct exchange: no barrier flags for rank %d", q);
+            b.peer_flags[q] = c->peer_flags[q];
+        }
+        b.my_flags = c->my_flags;
+        b.dead = c->direct_counts + 64;
+        b.status = c->status;
+        b.epoch = ++c->direct_epoch;
+        b.timeout_ticks = (unsigned long long)c->tune_direct_timeout_ms * 100000ull;      // wall_clock64: 100 MHz
+        b.rank = c->rank;
+        b.npeer = (int32_t)G;
+        hipLaunchKernelGGL(k_peer_barrier, dim3(1), dim3(64), 0, c->stream, b);
+        HIPOK(c, hipGetLastError());
+    }
+    const int ns = cur.off[split + 1] - cur.off[split];
+    if (ns <= 0) return 0;
+    const int64_t bmax = (N + G - 1) / G;
+    const double mean = (double)ns / G;
+    int64_t bound = (int64_t)std::ceil(mean + 8.0 * std::sqrt(mean) + 64.0);      // grid size only: the count is read on the device
+    bound = std::max<int64_t>(1, std::min<int64_t>(bound, std::min<int64_t>(bmax, ns)));
+    double *chain = nullptr, *chain_lp = nullptr;
+    if (cur.store) {
+        chain = c->chain + (size_t)c->stored * N * c->D;
+        chain_lp = c->chain_lp + (size_t)c->stored * N;
+    }
+    return launch_split(c, mv.kind, c->target, cur.S, split, cur.off[split], (int)bound, 0, (int)bound, &mv, &c->cplan, nullptr, c->X,
+                        c->lp, chain, chain_lp, nullptr, nullptr, c->direct_counts + split);
 }
 
 static void block_args(emx_ctx* c, BlockArgs& a, double* rec) {
@@ -2389,8 +2616,8 @@ static void block_args(emx_ctx* c, BlockArgs& a, double* rec) {
 
 int emx_replica_pack(emx_ctx* c, int64_t* records_per_rank) {
     HIPOK(c, hipSetDevice(c->device));
-    NEED(c, c->exchange == EMX_EXCHANGE_PULL, "emx_replica_pack is for the pull exchange");
-    int rc = pull_ensure(c);
+    NEED(c, c->exchange != EMX_EXCHANGE_ALLGATHER, "emx_replica_pack is for the block-ownership exchanges (pull, direct)");
+    int rc = c->exchange == EMX_EXCHANGE_PULL ? pull_ensure(c) : direct_ensure(c);
     if (rc) return rc;
     BlockArgs a{};
     block_args(c, a, c->sendbuf);
@@ -2402,7 +2629,7 @@ int emx_replica_pack(emx_ctx* c, int64_t* records_per_rank) {
 
 int emx_replica_unpack(emx_ctx* c) {
     HIPOK(c, hipSetDevice(c->device));
-    NEED(c, c->exchange == EMX_EXCHANGE_PULL && c->gathered, "emx_replica_unpack is for the pull exchange");
+    NEED(c, c->exchange != EMX_EXCHANGE_ALLGATHER && c->gathered, "emx_replica_unpack is for the block-ownership exchanges (pull, direct)");
     BlockArgs a{};
     block_args(c, a, c->gathered);
     const int64_t nrec = (int64_t)a.G * a.bmax;
@@ -2421,6 +2648,7 @@ int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
         case 5: *ptr = c->chain_lp; *nbytes = c->stored * c->N * 8; return 0;
         case 6: *ptr = c->disp; *nbytes = c->disp ? c->N * c->D * 8 : 0; return 0;
         case 7: *ptr = c->dbg; *nbytes = c->dbg ? c->dbg_blocks * 16 * 8 : 0; return 0;
+        case 8: *ptr = c->my_flags; *nbytes = c->my_flags ? EMX_MAX_PEERS * 8 : 0; return 0;
     }
     FAIL(c, -1, "unknown device pointer id %d", which);
 }
@@ -2506,6 +2734,9 @@ int emx_comm_init(emx_ctx* c, int32_t rank, int32_t world, const uint8_t id[128]
     if (rc) return rc;
     if (c->exchange == EMX_EXCHANGE_PULL) {
         rc = pull_ensure(c);
+        if (rc) return rc;
+    } else if (c->exchange == EMX_EXCHANGE_DIRECT) {
+        rc = direct_ensure(c);
         if (rc) return rc;
     } else if (!c->sendbuf) {   // world == 1: still exercise the exchange buffers
         const int64_t per = c->N + 2;

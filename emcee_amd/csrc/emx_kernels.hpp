@@ -43,7 +43,8 @@ namespace emx {
 enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_GAUSS = 3, MOVE_EVAL = 4 };
 enum : int { GAUSS_VECTOR = 0, GAUSS_RANDOM = 1, GAUSS_SEQUENTIAL = 2 };
 enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5 };
-enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u };
+enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u, ST_EXCHANGE_TIMEOUT = 8u };
+constexpr int EMX_MAX_PEERS = 8;       // direct exchange: GPUs of one node
 
 // The sticky status lives in mapped host memory, one 32-bit flag per condition (index = bit number): raising one is
 // a plain idempotent store -- no read-modify-write across PCIe -- and only error paths ever execute it.
@@ -120,7 +121,22 @@ struct HalfStepArgs {
     unsigned long long gseed, gstep;
     // phase timestamps (tools/phase_clock.py): [block][16] s_memtime samples of wave 0, or nullptr
     unsigned long long* dbg;
+    // direct exchange (walker-block ownership, the peers' coordinate arrays mapped into this device's address space):
+    // a partner row is read from the replica of the rank that owns it, i.e. over xGMI from that GPU's HBM.  npeer = 0:
+    // one replica (everything else).  peer_lo is ascending; own entry of peerX == X.
+    const double* peerX[EMX_MAX_PEERS];
+    int32_t peer_lo[EMX_MAX_PEERS];
+    int32_t npeer;
 };
+
+// coordinate array holding the current row of walker j (block ownership: rank q owns [peer_lo[q], peer_lo[q + 1]))
+__device__ __forceinline__ const double* partner_base(const HalfStepArgs& A, int j) {
+    if (A.npeer == 0) return A.X;                   // launch-uniform
+    const double* b = A.peerX[0];
+#pragma unroll
+    for (int q = 1; q < EMX_MAX_PEERS; ++q) b = (q < A.npeer && j >= A.peer_lo[q]) ? A.peerX[q] : b;
+    return b;
+}
 
 // ----------------------------------------------------------------------------------------
 // group helpers
@@ -707,10 +723,10 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                 if constexpr (MOVE == MOVE_GAUSS) {
                     if (A.disp) load_row<G, V, CH>(xa[k], A.disp + (size_t)wi[k] * D, D, gl);
                 } else if constexpr (NR >= 2) {
-                    if (!(A.ablate & 32)) load_row<G, V, CH>(xa[k], A.X + (size_t)ja[k] * D, D, gl);
+                    if (!(A.ablate & 32)) load_row<G, V, CH>(xa[k], partner_base(A, ja[k]) + (size_t)ja[k] * D, D, gl);
                 }
-                if constexpr (NR >= 3) load_row<G, V, CH>(xb[k], A.X + (size_t)jb[k] * D, D, gl);
-                if constexpr (NR >= 4) load_row<G, V, CH>(xc[k], A.X + (size_t)jc[k] * D, D, gl);
+                if constexpr (NR >= 3) load_row<G, V, CH>(xb[k], partner_base(A, jb[k]) + (size_t)jb[k] * D, D, gl);
+                if constexpr (NR >= 4) load_row<G, V, CH>(xc[k], partner_base(A, jc[k]) + (size_t)jc[k] * D, D, gl);
                 if constexpr (MOVE != MOVE_EVAL) {
                     s0v[k] = (MOVE == MOVE_SNOOKER) ? 0.0 : A.s0[pos];
                     facv[k] = A.fac[pos];
@@ -1552,10 +1568,9 @@ static __global__ __launch_bounds__(256) void k_scatter_rows(const ScatterArgs A
 // Pull exchange (walker-block ownership).  Rank r owns walkers [N r / G, N (r+1) / G); the RNG
 // plan is replicated, so every rank can tell, without asking, which of ITS rows the walkers
 // other ranks update in this half-step will read.  Per half-step:
-//   k_pull_plan    -> compact plan of the slots whose walker this rank owns (+ device-side count),
-//                     and, per destination rank, the list of own rows it needs
-//   k_pull_pack    -> [global row index | row] records, `cap` per destination (index -1: unused)
-//   (all-to-all, cap records per pair)
+//   k_pull_plan    -> compact plan of the slots whose walker this rank owns (+ device-side count) and, per
+//                     destination rank, a block [count | up to cap records of [global row index | row]]
+//   (all-to-all, 1 + cap records per pair)
 //   k_pull_scatter -> received rows into the local replica at their global index
 //   k_halfstep     -> over the compact plan
 // ----------------------------------------------------------------------------------------
@@ -1568,12 +1583,18 @@ struct PullPlanArgs {
     const double *s0, *uacc, *logu, *fac;
     int32_t *corder, *cp0, *cp1, *cp2;        // compact plan of this rank's active walkers
     double *cs0, *cuacc, *clogu, *cfac;
-    int32_t* counts;                          // [0]: own active slots; [1 + q]: records for rank q
-    int32_t* sendidx;                         // [G][cap]: own rows rank q needs
+    int32_t* counts;                          // this half-step's counters: [0] own active slots; [1 + q] records for rank q
+    int32_t* counts_next;                     // the other buffer: zeroed here for the next half-step (no memset on the stream)
+    int32_t* ticket;                          // blocks finished (the last one writes the headers)
+    const double* X;                          // own rows are copied straight into the send records
+    double* rec;                              // [G] blocks of (1 + cap) records of D + 1 doubles: [count | ...], then [row index | row]
     uint32_t* status;
-    int32_t N, G, rank, ns, npart, cap;
+    int32_t N, D, G, rank, ns, npart, cap;
 };
 
+// One launch per half-step does what k_pull_plan + k_pull_pack + two memsets used to: the compact plan of the own slots,
+// the records of the rows the peers will read (copied by the whole wave, one row per iteration), and -- by the last
+// block to finish -- the record count at the head of every destination's block.
 static __global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1587,6 +1608,7 @@ static __global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) 
         oi = block_owner(i, A.N, A.G);
     }
     const unsigned long long below = (1ull << lane) - 1ull;
+    const size_t recw = (size_t)A.D + 1;
     // (a) slots of walkers this rank owns -> compact plan, one atomic per wave
     {
         const bool mine = live && oi == A.rank;
@@ -1609,67 +1631,153 @@ static __global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) 
             }
         }
     }
-    // (b) partners owned here of walkers updated elsewhere -> the owner's request list
+    // (b) partners owned here of walkers updated elsewhere -> a [row index | row] record in the owner's block
     for (int j = 0; j < A.npart; ++j) {
         const bool here = live && oi != A.rank && block_owner(pj[j], A.N, A.G) == A.rank;
         unsigned long long any = __ballot(here);
         if (!any) continue;
         for (int q = 0; q < A.G; ++q) {                         // wave-uniform
             const bool hit = here && oi == q;
-            const unsigned long long m = __ballot(hit);
+            unsigned long long m = __ballot(hit);
             if (!m) continue;
             int base = 0;
             const int leader = __ffsll((long long)m) - 1;
             if (lane == leader) base = atomicAdd(&A.counts[1 + q], __popcll(m));
             base = __shfl(base, leader);
-            if (hit) {
-                const int e = base + __popcll(m & below);
-                if (e < A.cap)
-                    A.sendidx[(size_t)q * A.cap + e] = pj[j];
-                else
-                    raise_status(A.status, ST_EXCHANGE_OVERFLOW);
+            const int e = base + __popcll(m & below);
+            if (hit && e >= A.cap) raise_status(A.status, ST_EXCHANGE_OVERFLOW);
+            while (m) {                                         // one requested row per iteration, copied by the whole wave
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int eb = __shfl(e, b), idx = __shfl(pj[j], b);
+                if (eb >= A.cap) continue;
+                double* dst = A.rec + ((size_t)q * (A.cap + 1) + 1 + eb) * recw;
+                const double* src = A.X + (size_t)idx * A.D;
+                if (lane == 0) dst[0] = (double)idx;
+                for (int d = lane; d < A.D; d += 64) dst[1 + d] = src[d];
             }
         }
     }
+    // (c) the last block to finish publishes the record counts and re-arms the other counter buffer
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(A.ticket, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    for (int q = threadIdx.x; q < A.G; q += blockDim.x) {
+        const int cnt = min(__hip_atomic_load(&A.counts[1 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), A.cap);
+        A.rec[(size_t)q * (A.cap + 1) * recw] = (double)(q == A.rank ? 0 : cnt);
+    }
+    for (int q = threadIdx.x; q < 1 + A.G; q += blockDim.x) A.counts_next[q] = 0;
+    if (threadIdx.x == 0) *A.ticket = 0;
 }
 
 struct PullRowsArgs {
     double* X;
-    double* rec;                 // [G][cap][D + 1]
-    const int32_t* counts;       // pack: counts[1 + q]
-    const int32_t* sendidx;
+    const double* rec;           // [G] blocks of (1 + cap) records: the peers' rows this rank's walkers will read
     int32_t N, D, G, rank, cap;
 };
 
 // 16 lanes per record
-static __global__ __launch_bounds__(256) void k_pull_pack(const PullRowsArgs A) {
+static __global__ __launch_bounds__(256) void k_pull_scatter(const PullRowsArgs A) {
     const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     if (r >= A.G * A.cap) return;
     const int q = r / A.cap, e = r - q * A.cap;
     if (q == A.rank) return;
-    double* dst = A.rec + (size_t)r * (A.D + 1);
-    const int cnt = min(A.counts[1 + q], A.cap);
-    if (e >= cnt) {
-        if (l == 0) dst[0] = -1.0;
-        return;
-    }
-    const int idx = A.sendidx[(size_t)q * A.cap + e];
-    const double* src = A.X + (size_t)idx * A.D;
-    if (l == 0) dst[0] = (double)idx;
-    for (int d = l; d < A.D; d += 16) dst[1 + d] = src[d];
+    const double* blk = A.rec + (size_t)q * (A.cap + 1) * (A.D + 1);
+    if (e >= (int)blk[0]) return;
+    const double* src = blk + (size_t)(1 + e) * (A.D + 1);
+    double* dst = A.X + (size_t)(long long)src[0] * A.D;
+    for (int d = l; d < A.D; d += 16) dst[d] = src[1 + d];
 }
 
-static __global__ __launch_bounds__(256) void k_pull_scatter(const PullRowsArgs A) {
-    const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-    const int l = threadIdx.x & 15;
-    if (r >= A.G * A.cap) return;
-    if (r / A.cap == A.rank) return;
-    const double* src = A.rec + (size_t)r * (A.D + 1);
-    const double h = src[0];
-    if (!(h >= 0.0)) return;
-    double* dst = A.X + (size_t)(long long)h * A.D;
-    for (int d = l; d < A.D; d += 16) dst[d] = src[1 + d];
+// ----------------------------------------------------------------------------------------
+// Direct exchange: nothing is packed or sent.  Every rank owns a walker block; the half-step kernel reads partner rows
+// straight from the owner's HBM (HalfStepArgs::peerX).  What remains per step is
+//   k_own_plan      -> per split, the compact plan of the slots whose walker this rank owns (counts on the device)
+//   k_peer_barrier  -> before every half-step: "my previous half-step is complete and visible" to every peer, then wait for
+//                      the same from every peer.  It orders both hazards: a partner row must carry its owner's last
+//                      update, and nobody may start writing split k+1 rows while a peer still reads them as partners.
+// ----------------------------------------------------------------------------------------
+struct OwnPlanArgs {
+    const int32_t *order, *p0, *p1, *p2;      // this step's full plan
+    const double *s0, *uacc, *logu, *fac;
+    int32_t *corder, *cp0, *cp1, *cp2;        // compact plan: split s at offset off[s], counts[s] entries
+    double *cs0, *cuacc, *clogu, *cfac;
+    int32_t* counts;                          // [S]
+    int32_t off[66];
+    int32_t N, G, rank, S;
+};
+
+static __global__ __launch_bounds__(256) void k_own_plan(const OwnPlanArgs A) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = t < A.N;
+    int i = 0, s = -1;
+    if (live) {
+        i = A.order[t];
+        if (block_owner(i, A.N, A.G) == A.rank) {
+            s = 0;
+            while (s + 1 < A.S && t >= A.off[s + 1]) ++s;
+        }
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long todo = __ballot(s >= 0);
+    while (todo) {                                                  // wave-uniform: one pass per split present in the wave
+        const int leader = __ffsll((long long)todo) - 1;
+        const int sp = __shfl(s, leader);
+        const bool hit = s == sp;
+        const unsigned long long m = __ballot(hit);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&A.counts[sp], __popcll(m));
+        base = __shfl(base, leader);
+        if (hit) {
+            const int e = A.off[sp] + base + __popcll(m & below);
+            A.corder[e] = i;
+            A.cp0[e] = A.p0[t];
+            A.cp1[e] = A.p1[t];
+            A.cp2[e] = A.p2[t];
+            A.cs0[e] = A.s0[t];
+            A.cuacc[e] = A.uacc[t];
+            A.clogu[e] = A.logu[t];
+            A.cfac[e] = A.fac[t];
+        }
+        todo &= ~m;
+    }
+}
+
+struct PeerBarrierArgs {
+    unsigned long long* peer_flags[EMX_MAX_PEERS];   // [q]: rank q's flag array (one slot per rank) as mapped here
+    unsigned long long* my_flags;                     // this rank's own array: slot q is written by rank q
+    int32_t* dead;                                    // set once a wait timed out: the run is invalid, later barriers return at once
+    uint32_t* status;
+    unsigned long long epoch, timeout_ticks;          // wall_clock64 ticks (100 MHz)
+    int32_t rank, npeer;
+};
+
+// one wave; lane q talks to rank q
+static __global__ __launch_bounds__(64) void k_peer_barrier(const PeerBarrierArgs A) {
+    const int q = threadIdx.x;
+    // everything this device wrote in earlier kernels (the previous half-step's commits) leaves its L2
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (q < A.npeer && q != A.rank) {
+        __hip_atomic_store(&A.peer_flags[q][A.rank], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = wall_clock64();
+        const bool dead = *A.dead != 0;
+        while (!dead && __hip_atomic_load(&A.my_flags[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.epoch) {
+            if (wall_clock64() - t0 > A.timeout_ticks) {           // a peer never arrived: never hang the GPU
+                raise_status(A.status, ST_EXCHANGE_TIMEOUT);
+                *A.dead = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    // stale copies of the peers' rows in this device's caches are dropped before the half-step reads them
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 // Replica sync of the pull exchange: every rank's block as [row | log_prob | accepted | accepted count] records

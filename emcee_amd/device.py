@@ -16,6 +16,7 @@ __all__ = ["DeviceEnsemble", "EmxError"]
 _STATUS_NAN_LOGP = 1
 _STATUS_BAD_COORD = 2
 _STATUS_EXCHANGE_OVERFLOW = 4
+_STATUS_EXCHANGE_TIMEOUT = 8
 
 
 def _as_f64(a, shape=None):
@@ -80,6 +81,8 @@ class DeviceEnsemble:
         bits = self.status()
         if bits & _STATUS_EXCHANGE_OVERFLOW:
             raise EmxError("pull exchange: record capacity exceeded; the sharded run is invalid")
+        if bits & _STATUS_EXCHANGE_TIMEOUT:
+            raise EmxError("direct exchange: a peer did not reach the device-side barrier in time; the sharded run is invalid")
         if bits & _STATUS_BAD_COORD:
             raise ValueError("At least one parameter value was infinite or NaN")
         if bits & _STATUS_NAN_LOGP:
@@ -270,7 +273,7 @@ class DeviceEnsemble:
     # ---- pull exchange (walker-block ownership; include/emx.h) ----
     def set_exchange(self, kind):
         """'allgather' (every updated row to every rank) or 'pull' (only the partner rows read)."""
-        k = {"allgather": _lib.EXCHANGE_ALLGATHER, "pull": _lib.EXCHANGE_PULL}.get(kind, kind)
+        k = {"allgather": _lib.EXCHANGE_ALLGATHER, "pull": _lib.EXCHANGE_PULL, "direct": _lib.EXCHANGE_DIRECT}.get(kind, kind)
         self._ck(self.lib.emx_set_exchange(self.ctx, int(k)))
 
     def exchange_layout(self):
@@ -293,6 +296,28 @@ class DeviceEnsemble:
 
     def pull_apply(self, split):
         self._ck(self.lib.emx_pull_apply(self.ctx, int(split)))
+
+    # ---- direct exchange (partner rows read in place from the peers' HBM; include/emx.h) ----
+    def direct_export(self):
+        """128 bytes (IPC handles of the coordinate array and the barrier flags) for the peers' direct_import."""
+        h = np.zeros(128, dtype=np.uint8)
+        self._ck(self.lib.emx_direct_export(self.ctx, h))
+        return h
+
+    def direct_import(self, handles):
+        """handles: (world, 128) uint8, every rank's direct_export in rank order (multi-process runs)."""
+        h = np.ascontiguousarray(handles, dtype=np.uint8).reshape(-1)
+        self._ck(self.lib.emx_direct_import(self.ctx, h))
+
+    def direct_attach(self, coords_ptrs, flags_ptrs=None):
+        """Same-process peers: raw device pointers (device_ptr(0) / device_ptr(8) of every rank's context)."""
+        n = len(coords_ptrs)
+        a = (C.c_void_p * n)(*[C.c_void_p(p) for p in coords_ptrs])
+        f = None if flags_ptrs is None else (C.c_void_p * n)(*[C.c_void_p(p) for p in flags_ptrs])
+        self._ck(self.lib.emx_direct_attach(self.ctx, a, f))
+
+    def direct_halfstep(self, split, barrier=False):
+        self._ck(self.lib.emx_direct_halfstep(self.ctx, int(split), int(bool(barrier))))
 
     def replica_pack(self):
         n = C.c_int64()

@@ -9,6 +9,11 @@ all-gather per half-step (RCCL over xGMI via torch.distributed) brings every ran
 every rank, where a scatter kernel folds them into the local replica before the next split --
 the ordering red_blue.py:85,104 requires.  No other collective sits on the data path.
 
+A third protocol, the *direct* exchange (include/emx.h "direct exchange"), keeps the pull exchange's walker-block
+ownership but sends nothing: the peers' coordinate arrays are mapped (IPC) and the half-step kernel reads each partner
+row from its owner's HBM over xGMI, with a one-wave device-side barrier between half-steps (`attach_direct_peers`,
+`import_direct_peers`; `emx_run` drives it).
+
 A second protocol, the *pull* exchange (`PullStepper`, include/emx.h "pull exchange"), moves only
 the rows a half-step reads: rank r owns the walker block [N r / G, N (r+1) / G); because the RNG
 plan is replicated each rank knows which of its rows its peers' walkers picked as partners, packs
@@ -22,7 +27,7 @@ double) so the protocols themselves are covered by world_size-2 gloo tests witho
 import numpy as np
 
 __all__ = ["shard_range", "rows_per_rank", "ShardedStepper", "PullStepper", "DeviceEngine", "LocalGroup",
-           "block_range", "block_owner", "pull_capacity"]
+           "block_range", "block_owner", "pull_capacity", "attach_direct_peers", "import_direct_peers"]
 
 
 def shard_range(ns, rank, world):
@@ -144,6 +149,38 @@ class PullStepper:
         self.sync_replicas()
 
 
+class _DevView(object):
+    """__cuda_array_interface__ carrier for a library-owned device buffer of float64"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
+def _wrap_device_buffer(ens, which, dev):
+    import torch
+    ptr, nbytes = ens.device_ptr(which)
+    return torch.as_tensor(_DevView(ptr, nbytes // 8), device=dev)
+
+
+def attach_direct_peers(ensembles):
+    """Logical ranks of ONE process (tests, several contexts on one GPU): hand every context the others' coordinate
+    arrays and barrier flags as plain device pointers.  Between processes the same is done with IPC handles:
+    ``handles = all_gather(ens.direct_export()); ens.direct_import(handles)``."""
+    xs = [e.device_ptr(0)[0] for e in ensembles]
+    fs = [e.device_ptr(8)[0] for e in ensembles]
+    for e in ensembles:
+        e.direct_attach(xs, fs)
+
+
+def import_direct_peers(ens, dist):
+    """One process per GPU: all-gather the 128-byte IPC handles over the (host) process group and map the peers."""
+    mine = ens.direct_export()
+    every = [None] * dist.get_world_size()
+    dist.all_gather_object(every, mine.tobytes())
+    ens.direct_import(np.frombuffer(b"".join(every), dtype=np.uint8))
+
+
 class DeviceEngine:
     """libemx context as a sharded engine; exchange buffers are torch tensors (RCCL-ready)."""
 
@@ -153,6 +190,14 @@ class DeviceEngine:
         self.rank, self.world = rank, world
         self.ndim = ens.ndim
         dev = torch_device if torch_device is not None else torch.device("cuda", torch.cuda.current_device())
+        if exchange == "direct":
+            # partner rows are read in place from the peers' HBM; the only buffers are the library's own for the replica
+            # re-synchronisation, wrapped here (zero copy) so that a torch collective can move them
+            ens.set_exchange("direct")
+            ens.set_shard(rank, world)
+            self.sendbuf = _wrap_device_buffer(ens, 2, dev)
+            self.gathered = _wrap_device_buffer(ens, 3, dev)
+            return
         if exchange == "pull":
             ens.set_exchange("pull")
             ens.set_shard(rank, world)

@@ -74,7 +74,8 @@ int emx_set_stream(emx_ctx* ctx, void* hip_stream);
 int emx_sync(emx_ctx* ctx);
 /* sticky device status: bit0 NaN log-prob (ensemble.py:550-551), bit1 non-finite coordinate
  * (ensemble.py:476-479), bit2 pull-exchange record capacity exceeded (a >8 sigma event: the run is
- * invalid, never silently wrong).  Reading clears it. */
+ * invalid, never silently wrong), bit3 direct exchange: a peer did not reach the device-side barrier in time.
+ * Reading clears it. */
 int emx_status(emx_ctx* ctx, uint32_t* bits);
 /* keys: "spw", "blocks_per_cu", "waves_per_block", "prep_hint", "graph", "throttle", "gauss_materialize",
  * "small_kernel" (1: ensembles that fit one CU's LDS run whole emx_run calls in one workgroup; default),
@@ -160,7 +161,8 @@ int emx_set_shard(emx_ctx* ctx, int32_t rank, int32_t world);
 int emx_set_shard_buffers(emx_ctx* ctx, void* sendbuf, void* gathered, int64_t rows_per_rank);
 /* raw device pointers for zero-copy wrapping (torch.distributed all-gather buffers):
  * which: 0 coords (N,D), 1 log_prob (N), 2 sendbuf (rows/rank, D+2), 3 gathered (world*rows/rank, D+2),
- *        4 chain (stored, N, D), 5 chain log_prob (stored, N), 6 Gaussian-move displacements (N, D) */
+ *        4 chain (stored, N, D), 5 chain log_prob (stored, N), 6 Gaussian-move displacements (N, D),
+ *        8 direct-exchange barrier flags (one uint64 per rank) */
 int emx_device_ptr(emx_ctx* ctx, int32_t which, void** ptr, int64_t* nbytes);
 int emx_shard_slots(emx_ctx* ctx, int32_t split, int64_t* t_lo, int64_t* t_hi, int64_t* ns);
 /* after the all-gather of `sendbuf`s into `gathered`: write the other ranks' rows into X */
@@ -181,6 +183,7 @@ int emx_scatter_gathered(emx_ctx* ctx, int32_t split);
  * (emx_run does it before it returns).  Results are bit-identical to the single-rank run. */
 #define EMX_EXCHANGE_ALLGATHER 0
 #define EMX_EXCHANGE_PULL 1
+#define EMX_EXCHANGE_DIRECT 2      /* see "direct exchange" below */
 int emx_set_exchange(emx_ctx* ctx, int32_t kind);          /* before emx_set_shard / emx_comm_init */
 /* doubles the send / receive buffers must hold for the moves installed (pull exchange) */
 int emx_exchange_layout(emx_ctx* ctx, int64_t* send_doubles, int64_t* recv_doubles);
@@ -191,6 +194,28 @@ int emx_pull_prepare(emx_ctx* ctx, int32_t split, int64_t* records_per_peer);
 int emx_pull_apply(emx_ctx* ctx, int32_t split);
 int emx_replica_pack(emx_ctx* ctx, int64_t* records_per_rank);
 int emx_replica_unpack(emx_ctx* ctx);
+
+/* ---- direct exchange: partner rows read in place from the owner's HBM over xGMI ----------------------------------
+ * Same walker-block ownership as the pull exchange, but nothing is packed, sent or scattered: every rank maps the other
+ * ranks' coordinate arrays (hipIpc handles between processes, plain pointers between contexts of one process) and the
+ * half-step kernel loads a partner row from the replica of the rank that owns it (stretch.py:32 reads ONE row per updated
+ * walker, de.py:53 two, de_snooker.py:41-46 three) -- the only bytes that cross xGMI are the (G-1)/G of those rows that
+ * live on another GPU.  Between half-steps a one-wave device-side barrier (a flag store into every peer's flag array, a
+ * spin on the own array; bounded by tuning key "direct_timeout_ms", status bit 3 on expiry) orders the two hazards of
+ * red_blue.py:85,104: a partner row must carry its owner's last commit, and nobody may start committing split k+1 while a
+ * peer still reads those rows as partners of split k.
+ *   emx_set_exchange(EMX_EXCHANGE_DIRECT); emx_set_shard / emx_comm_init; then
+ *   multi-process: emx_direct_export -> 128 bytes per rank, all-gathered by the host layer -> emx_direct_import
+ *   one process:   emx_direct_attach(coordinate arrays, flag arrays) of all ranks (emx_device_ptr which = 0 / 8)
+ *   per step:      emx_step_begin; emx_direct_halfstep(split, barrier) for every split; emx_step_end   (emx_run does it)
+ * Only a rank's own block is current until the replica re-synchronisation (emx_replica_pack / all-gather / unpack; emx_run
+ * runs it before it returns when emx_comm_init was called).  Results are bit-identical to the single-rank run.  World size
+ * <= 8 (one node). */
+int emx_direct_export(emx_ctx* ctx, uint8_t handles[128]);
+int emx_direct_import(emx_ctx* ctx, const uint8_t* handles /* world * 128 bytes, rank order */);
+int emx_direct_attach(emx_ctx* ctx, void* const* peer_coords /* [world] */, void* const* peer_flags /* [world] or NULL */);
+/* barrier != 0: device-side barrier with the peers first (needs their flag arrays); 0: the caller orders the ranks itself */
+int emx_direct_halfstep(emx_ctx* ctx, int32_t split, int32_t barrier);
 
 /* RCCL driven by the library itself (ncclAllGather enqueued on the context stream between the
  * half-step kernels, so that emx_run covers sharded runs with no host round trip per step).

@@ -162,6 +162,113 @@ def test_pull_exchange_equals_single_rank(name, world, rng):
         e.ens.close()
 
 
+DIRECT_CASES = [
+    ("c1_stretch_32x5_iso", 2, "mt"), ("stretch_50x3_iso", 3, "mt"), ("stretch_128x64_dense", 2, "mt"),
+    ("stretch_128x64_dense", 4, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt"),
+    ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
+    ("stretch_nsplits3_45x2", 2, "mt"), ("stretch_50x3_iso", 7, "philox"),
+    ("mix_stretch_gauss_32x3", 2, "mt"), ("gauss_diag_random_factor_30x4", 3, "philox"),
+]
+
+
+def _direct_setup(name, world, rng, nst):
+    import torch
+    from emcee_amd.parallel import attach_direct_peers
+    g = load_golden(name)
+    spec = cases.build(name)
+
+    def setup(ens):
+        if rng == "mt":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(rng_from_fixture(g).get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(777, 0)
+        ens.chain_config(nst)
+
+    ref = make_ens(spec, g["p0"])
+    setup(ref)
+    ref.run(nst, 1, True)
+    out = (ref.chain_read(0, 0, nst), ref.chain_read(1, 0, nst), ref.accepted_counts())
+    ref.close()
+    engines = []
+    for r in range(world):
+        ens = make_ens(spec, g["p0"])
+        setup(ens)
+        engines.append(DeviceEngine(ens, r, world, torch.device("cuda", 0), exchange="direct"))
+    attach_direct_peers([e.ens for e in engines])
+    return engines, out
+
+
+def _direct_check(engines, out, nst, world):
+    import torch
+    from emcee_amd.parallel import block_range
+    ref_chain, ref_lp, ref_acc = out
+    nd = engines[0].ndim
+    for r, e in enumerate(engines):
+        lo, hi = block_range(ref_chain.shape[1], r, world)
+        assert e.ens.status() == 0
+        assert np.array_equal(e.ens.chain_read(0, 0, nst)[:, lo:hi], ref_chain[:, lo:hi])
+        assert np.array_equal(e.ens.chain_read(1, 0, nst)[:, lo:hi], ref_lp[:, lo:hi])
+        assert np.array_equal(e.ens.accepted_counts()[lo:hi], ref_acc[lo:hi])
+    per = [e.replica_pack() for e in engines]
+    assert len(set(per)) == 1
+    for e in engines:
+        e.ens.sync()
+    torch.cuda.synchronize()
+    LocalGroup._all_gather_n(engines, per[0] * (nd + 3))
+    torch.cuda.synchronize()
+    for e in engines:
+        e.replica_unpack()
+        x, lp = e.ens.get_state()
+        assert np.array_equal(x, ref_chain[-1]) and np.array_equal(lp, ref_lp[-1])
+        assert np.array_equal(e.ens.accepted_counts(), ref_acc)
+        e.ens.close()
+
+
+@pytest.mark.parametrize("name,world,rng", DIRECT_CASES)
+def test_direct_exchange_equals_single_rank(name, world, rng):
+    """Direct exchange: every logical rank owns a walker block and its half-step kernel reads partner rows straight from
+    the other contexts' coordinate arrays (between GPUs: the peers' HBM over xGMI).  Host-ordered here (stream syncs
+    between half-steps stand in for the device-side barrier).  Each rank's block of the chain, and every replica after the
+    block all-gather, must equal the single-rank run bit for bit."""
+    nst = min(8, cases.build(name)["nsteps"])
+    engines, out = _direct_setup(name, world, rng, nst)
+    for _ in range(nst):
+        res = [e.step_begin(True) for e in engines]
+        assert all(r == res[0] for r in res)
+        for split in range(res[0][1]):
+            for e in engines:
+                e.ens.direct_halfstep(split, barrier=False)
+            for e in engines:
+                e.ens.sync()
+        for e in engines:
+            e.step_end()
+    _direct_check(engines, out, nst, world)
+
+
+@pytest.mark.parametrize("name,world,rng", [("stretch_128x64_dense", 2, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt")])
+def test_direct_exchange_device_side_barrier(name, world, rng):
+    """The same with the ranks ordered by the one-wave barrier kernel alone: no host synchronisation between half-steps;
+    each context runs on its own stream, the barrier kernels of the two contexts meet on the device (flag store into the
+    peer's array, spin on the own one).  Bounded: a barrier that is never met raises status bit 3 instead of hanging."""
+    nst = min(6, cases.build(name)["nsteps"])
+    engines, out = _direct_setup(name, world, rng, nst)
+    for e in engines:
+        e.ens.set_tuning("direct_timeout_ms", 3000)
+    for _ in range(nst):
+        res = [e.step_begin(True) for e in engines]
+        assert all(r == res[0] for r in res)
+        for split in range(res[0][1]):
+            for e in engines:
+                e.ens.direct_halfstep(split, barrier=True)
+        for e in engines:
+            e.step_end()
+    for e in engines:
+        e.ens.sync()
+    _direct_check(engines, out, nst, world)
+
+
 def test_library_driven_rccl_world1():
     """emx_comm_init + sharded emx_run (ncclAllGather enqueued by libemx) at world size 1:
     exercises the RCCL linkage and the exchange buffers; the chain must equal the plain run."""
@@ -170,7 +277,7 @@ def test_library_driven_rccl_world1():
     g = load_golden(name)
     spec = cases.build(name)
     chains = []
-    for use_comm in (False, "allgather", "pull"):
+    for use_comm in (False, "allgather", "pull", "direct"):
         ens = make_ens(spec, g["p0"])
         ens.set_rng_mode(_lib.RNG_PHILOX)
         ens.set_philox(4242, 0)

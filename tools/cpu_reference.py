@@ -77,7 +77,8 @@ def main():
     N, D = a.nwalkers, a.ndim
     MU, cov, ICOV = dense_gaussian(D)
     p0 = MU + np.random.RandomState(1).randn(N, D) @ np.linalg.cholesky(cov).T
-    ncores = os.cpu_count()
+    from bench import usable_cores
+    ncores = usable_cores()
     modes = {}
     with threadpool_limits(limits=1):
         modes["vectorize_1thread"] = dict(time_mode(emcee, N, D, p0, a.budget, fn=lp_vector, vectorize=True), cores=1)
