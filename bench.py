@@ -478,6 +478,7 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
     fence()
     walls, gpus = [], []
     total, nblk = 0.0, 0
+    digest, every = None, None
     while True:
         fence()
         ens.timer_start()
@@ -492,12 +493,15 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
         gpus.append(float(t[1]))
         total += float(t[0]) * 1e3
         nblk += 1
+        if digest is None:
+            # checksum of the ensemble after a FIXED number of steps (spin-up + W + K): every rank and every exchange
+            # protocol must arrive at the same state
+            x, lp = ens.get_state()
+            digest = "%.17g/%.17g" % (float(np.sum(x * np.arange(1, wl.D + 1))), float(np.sum(lp)))
+            every = [None] * world
+            dist.all_gather_object(every, digest)
         if single_block or (total >= MIN_TIMED_MS and nblk >= 3) or nblk >= 60:     # same decision on every rank: t is reduced
             break
-    x, lp = ens.get_state()
-    digest = "%.17g/%.17g" % (float(np.sum(x * np.arange(1, wl.D + 1))), float(np.sum(lp)))
-    every = [None] * world
-    dist.all_gather_object(every, digest)
     res = {"wall_s": float(np.median(walls)), "gpu_ms": float(np.median(gpus)), "blocks": nblk, "comm": comm_used,
            "exchange": exchange, "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(),
            "digest": digest, "replicas_agree": len(set(every)) == 1}

@@ -361,8 +361,10 @@ struct emx_ctx {
     int exchange = EMX_EXCHANGE_ALLGATHER;
     PlanSlot cplan;                   // compact plan: the slots whose walker this rank owns
     int64_t cplan_rows = 0;
-    int32_t* pull_counts = nullptr;   // [2][1 + world] + ticket: counters of the current / next half-step (k_pull_plan re-arms them)
+    int32_t* pull_counts = nullptr;   // [2][1 + world]: counters of the current / next half-step (k_pull_scatter re-arms them)
     int pull_parity = 0;
+    int64_t pull_cap_armed = 0;       // capacity (records per pair) the send records' NaN indices were laid out for
+    double* pull_armed_buf = nullptr;
     int64_t pull_cap_cur = 0;         // records per pair of the prepared half-step
     int pull_split = -1;
     // direct exchange: peers' coordinate arrays and barrier flags mapped into this process / device
@@ -2087,7 +2089,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
                     // partner rows only: pack what the peers will read, all-to-all, fold in, update own walkers
                     int64_t cap = 0;
                     rc = emx_pull_prepare(c, s, &cap);
-                    if (!rc) rc = rccl_all_to_all(c, (size_t)cap * (c->D + 1));      // cap counts the header record
+                    if (!rc) rc = rccl_all_to_all(c, (size_t)cap * (c->D + 1));
                     if (!rc) rc = emx_pull_apply(c, s);
                     if (rc) {
                         c->cur.active = false;
@@ -2184,7 +2186,7 @@ static void exchange_free(emx_ctx* c) {
 
 static void pull_layout(const emx_ctx* c, int64_t& send, int64_t& recv) {
     const int64_t G = c->world, bmax = (c->N + G - 1) / G;
-    const int64_t pairs = G * (pull_capacity_max(c) + 1) * (c->D + 1);       // per pair: [count] + cap records
+    const int64_t pairs = G * pull_capacity_max(c) * (c->D + 1);
     send = std::max<int64_t>(pairs, bmax * (c->D + 3));
     recv = std::max<int64_t>(pairs, G * bmax * (c->D + 3));
 }
@@ -2210,7 +2212,7 @@ static int pull_ensure(emx_ctx* c) {
         c->cplan_rows = bmax;
     }
     if (!c->pull_counts) {
-        const size_t n = (size_t)(2 * (1 + EMX_MAX_RANKS) + 1) * 4;
+        const size_t n = (size_t)(2 * (1 + EMX_MAX_RANKS)) * 4;
         HIPOK(c, hipMalloc((void**)&c->pull_counts, n));
         HIPOK(c, hipMemset(c->pull_counts, 0, n));
         c->pull_parity = 0;
@@ -2327,10 +2329,19 @@ int emx_pull_prepare(emx_ctx* c, int32_t split, int64_t* records_per_peer) {
     const auto& ps = c->ring[cur.slot];
     const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
     const int npart = partners_of(mv.kind);
-    const int64_t cap = pull_capacity(c->N, c->world, cur.S, npart);
+    // one capacity for every half-step of the context (the largest an installed move needs): records keep their address
+    const int64_t cap = pull_capacity_max(c);
+    NEED(c, pull_capacity(c->N, c->world, cur.S, npart) <= cap, "pull exchange: capacity below this move's need");
     NEED(c, c->world <= EMX_MAX_RANKS, "pull exchange: at most %d ranks", EMX_MAX_RANKS);
     int32_t* counts = c->pull_counts + (size_t)c->pull_parity * (1 + EMX_MAX_RANKS);
-    int32_t* counts_next = c->pull_counts + (size_t)(c->pull_parity ^ 1) * (1 + EMX_MAX_RANKS);
+    if (c->pull_cap_armed != cap || c->pull_armed_buf != c->sendbuf) {
+        const int nrec = (int)(c->world * cap);
+        hipLaunchKernelGGL(k_pull_reset, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, c->sendbuf, nrec, c->D);
+        HIPOK(c, hipGetLastError());
+        HIPOK(c, hipMemsetAsync(c->pull_counts, 0, (size_t)(2 * (1 + EMX_MAX_RANKS)) * 4, c->stream));
+        c->pull_cap_armed = cap;
+        c->pull_armed_buf = c->sendbuf;
+    }
     if (ns > 0) {
         PullPlanArgs a{};
         a.order = ps.order + pos0;
@@ -2350,8 +2361,6 @@ int emx_pull_prepare(emx_ctx* c, int32_t split, int64_t* records_per_peer) {
         a.clogu = c->cplan.logu;
         a.cfac = c->cplan.fac;
         a.counts = counts;
-        a.counts_next = counts_next;
-        a.ticket = c->pull_counts + 2 * (1 + EMX_MAX_RANKS);
         a.X = c->X;
         a.rec = c->sendbuf;
         a.status = c->status;
@@ -2364,14 +2373,10 @@ int emx_pull_prepare(emx_ctx* c, int32_t split, int64_t* records_per_peer) {
         a.cap = (int32_t)cap;
         hipLaunchKernelGGL(k_pull_plan, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, a);
         HIPOK(c, hipGetLastError());
-    } else {
-        HIPOK(c, hipMemsetAsync(counts, 0, (size_t)(1 + c->world) * 4, c->stream));
-        HIPOK(c, hipMemsetAsync(counts_next, 0, (size_t)(1 + c->world) * 4, c->stream));
-        HIPOK(c, hipMemsetAsync(c->sendbuf, 0, (size_t)c->world * (cap + 1) * (c->D + 1) * 8, c->stream));
     }
     c->pull_cap_cur = cap;
     c->pull_split = split;
-    if (records_per_peer) *records_per_peer = cap + 1;         // what travels per pair: the count record + cap row records
+    if (records_per_peer) *records_per_peer = cap;
     return 0;
 }
 
@@ -2382,16 +2387,19 @@ int emx_pull_apply(emx_ctx* c, int32_t split) {
     const emx_move_desc& mv = c->moves[cur.move];
     const int ns = cur.off[split + 1] - cur.off[split];
     c->pull_split = -1;
-    if (c->world > 1) {
+    {
+        // received rows into the replica; the send records and the other counter buffer are re-armed for the next half-step
         PullRowsArgs r{};
         r.X = c->X;
         r.rec = c->gathered;
+        r.sent = c->sendbuf;
+        r.counts_next = c->pull_counts + (size_t)(c->pull_parity ^ 1) * (1 + EMX_MAX_RANKS);
         r.N = (int32_t)c->N;
         r.D = c->D;
         r.G = c->world;
         r.rank = c->rank;
         r.cap = (int32_t)c->pull_cap_cur;
-        const int64_t nrec = (int64_t)c->world * c->pull_cap_cur;
+        const int64_t nrec = std::max<int64_t>(1, (int64_t)c->world * c->pull_cap_cur);
         hipLaunchKernelGGL(k_pull_scatter, dim3((unsigned)((nrec + 15) / 16)), dim3(256), 0, c->stream, r);
         HIPOK(c, hipGetLastError());
     }

@@ -1569,9 +1569,9 @@ static __global__ __launch_bounds__(256) void k_scatter_rows(const ScatterArgs A
 // plan is replicated, so every rank can tell, without asking, which of ITS rows the walkers
 // other ranks update in this half-step will read.  Per half-step:
 //   k_pull_plan    -> compact plan of the slots whose walker this rank owns (+ device-side count) and, per
-//                     destination rank, a block [count | up to cap records of [global row index | row]]
-//   (all-to-all, 1 + cap records per pair)
-//   k_pull_scatter -> received rows into the local replica at their global index
+//                     destination rank, up to cap records [global row index | row] (unused records: NaN index)
+//   (all-to-all, cap records per pair)
+//   k_pull_scatter -> received rows into the local replica at their global index; re-arms the send records and counters
 //   k_halfstep     -> over the compact plan
 // ----------------------------------------------------------------------------------------
 __host__ __device__ inline int block_owner(int w, int N, int G) {     // r with N r / G <= w < N (r+1) / G
@@ -1584,17 +1584,16 @@ struct PullPlanArgs {
     int32_t *corder, *cp0, *cp1, *cp2;        // compact plan of this rank's active walkers
     double *cs0, *cuacc, *clogu, *cfac;
     int32_t* counts;                          // this half-step's counters: [0] own active slots; [1 + q] records for rank q
-    int32_t* counts_next;                     // the other buffer: zeroed here for the next half-step (no memset on the stream)
-    int32_t* ticket;                          // blocks finished (the last one writes the headers)
     const double* X;                          // own rows are copied straight into the send records
-    double* rec;                              // [G] blocks of (1 + cap) records of D + 1 doubles: [count | ...], then [row index | row]
+    double* rec;                              // [G][cap] records of D + 1 doubles: [row index | row]; unused records keep a NaN index
     uint32_t* status;
     int32_t N, D, G, rank, ns, npart, cap;
 };
 
-// One launch per half-step does what k_pull_plan + k_pull_pack + two memsets used to: the compact plan of the own slots,
-// the records of the rows the peers will read (copied by the whole wave, one row per iteration), and -- by the last
-// block to finish -- the record count at the head of every destination's block.
+// One launch per half-step does what k_pull_plan + k_pull_pack used to: the compact plan of the own slots and the records
+// of the rows the peers will read, copied by the whole wave, one row per iteration.  `cap` is the same for every
+// half-step of a context (the largest any installed move needs), so a record always sits at the same address: unused
+// records carry a NaN index, which k_pull_scatter restores after the exchange (no memset on the stream).
 static __global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1651,32 +1650,20 @@ static __global__ __launch_bounds__(256) void k_pull_plan(const PullPlanArgs A) 
                 m &= m - 1;
                 const int eb = __shfl(e, b), idx = __shfl(pj[j], b);
                 if (eb >= A.cap) continue;
-                double* dst = A.rec + ((size_t)q * (A.cap + 1) + 1 + eb) * recw;
+                double* dst = A.rec + ((size_t)q * A.cap + eb) * recw;
                 const double* src = A.X + (size_t)idx * A.D;
                 if (lane == 0) dst[0] = (double)idx;
                 for (int d = lane; d < A.D; d += 64) dst[1 + d] = src[d];
             }
         }
     }
-    // (c) the last block to finish publishes the record counts and re-arms the other counter buffer
-    __shared__ int last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = (atomicAdd(A.ticket, 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    for (int q = threadIdx.x; q < A.G; q += blockDim.x) {
-        const int cnt = min(__hip_atomic_load(&A.counts[1 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), A.cap);
-        A.rec[(size_t)q * (A.cap + 1) * recw] = (double)(q == A.rank ? 0 : cnt);
-    }
-    for (int q = threadIdx.x; q < 1 + A.G; q += blockDim.x) A.counts_next[q] = 0;
-    if (threadIdx.x == 0) *A.ticket = 0;
 }
 
 struct PullRowsArgs {
     double* X;
-    const double* rec;           // [G] blocks of (1 + cap) records: the peers' rows this rank's walkers will read
+    const double* rec;           // received: [G][cap] records, the peers' rows this rank's walkers will read
+    double* sent;                // this rank's send records: their index fields go back to NaN for the next half-step
+    int32_t* counts_next;        // the other counter buffer: zeroed here for the next half-step
     int32_t N, D, G, rank, cap;
 };
 
@@ -1684,14 +1671,23 @@ struct PullRowsArgs {
 static __global__ __launch_bounds__(256) void k_pull_scatter(const PullRowsArgs A) {
     const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
+    if (blockIdx.x == 0 && threadIdx.x <= A.G) A.counts_next[threadIdx.x] = 0;
     if (r >= A.G * A.cap) return;
-    const int q = r / A.cap, e = r - q * A.cap;
-    if (q == A.rank) return;
-    const double* blk = A.rec + (size_t)q * (A.cap + 1) * (A.D + 1);
-    if (e >= (int)blk[0]) return;
-    const double* src = blk + (size_t)(1 + e) * (A.D + 1);
-    double* dst = A.X + (size_t)(long long)src[0] * A.D;
-    for (int d = l; d < A.D; d += 16) dst[d] = src[1 + d];
+    const size_t o = (size_t)r * (A.D + 1);
+    if (r / A.cap != A.rank) {
+        const double h = A.rec[o];
+        if (h >= 0.0) {                                       // NaN: unused record
+            double* dst = A.X + (size_t)(long long)h * A.D;
+            for (int d = l; d < A.D; d += 16) dst[d] = A.rec[o + 1 + d];
+        }
+    }
+    if (l == 0) A.sent[o] = __builtin_nan("");
+}
+
+// initial state of the send records (and after the installed moves changed the capacity)
+static __global__ __launch_bounds__(256) void k_pull_reset(double* sent, int nrec, int D) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrec) sent[(size_t)r * (D + 1)] = __builtin_nan("");
 }
 
 // ----------------------------------------------------------------------------------------
