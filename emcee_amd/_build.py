@@ -4,12 +4,12 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip")]     # two translation units, built in parallel
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip")]     # translation units, built in parallel
 SRC = SRCS[0]
 LIB = os.path.join(HERE, "libemx.so")
 HOST_SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx_mtpipe.cpp",)]       # plain host C++ (threads, SIMD clones): no device pass
 DEPS = SRCS + HOST_SRCS + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_rng.hpp", "mt19937_legacy.hpp",
-                                                                  "emx_mtpipe.hpp")] + [
+                                                                  "emx_mtpipe.hpp", "emx_internal.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "emx.h")]
 HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread"]
 # -ffp-contract=off: the proposal arithmetic must round like NumPy's separate multiply/subtract.

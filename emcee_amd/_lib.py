@@ -92,6 +92,9 @@ SIGNATURES = {
     "emx_direct_import": (C.c_int, [_P, _u8p]),
     "emx_direct_attach": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "emx_direct_halfstep": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "emx_fft_load": (C.c_int, [C.c_char_p]),
+    "emx_autocorr": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_double, _dp, _ip, C.POINTER(C.c_int64)]),
+    "emx_walkers_independent": (C.c_int, [C.c_int32, _dp, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "emx_host_pull_capacity": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "emx_comm_load": (C.c_int, [C.c_char_p]),
     "emx_comm_get_unique_id": (C.c_int, [_u8p]),

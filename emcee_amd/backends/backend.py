@@ -148,17 +148,24 @@ class Backend(object):
                      blobs=blobs, random_state=self.random_state)
 
     def get_autocorr_time(self, discard=0, thin=1, **kwargs):
-        """Integrated autocorrelation time per parameter, in steps (reference backend.py:130-150)."""
-        if self._dev is not None and kwargs.get("has_walkers", True):
-            try:    # chain is in HBM: batched FFTs next to it, only the mean ACF comes back
-                from .._devfft import integrated_time_device
-                kw = {k: v for k, v in kwargs.items() if k in ("c", "tol", "quiet")}
-                if len(kw) == len(kwargs):
-                    return thin * integrated_time_device(self._dev, self.iteration, discard=discard, thin=thin, **kw)
-            except autocorr.AutocorrError:
-                raise
-            except Exception as e:  # noqa: BLE001  (torch missing / view unsupported): host estimator below
-                autocorr.logger.debug("device autocorr unavailable (%s); using the host estimator", e)
+        """Integrated autocorrelation time per parameter, in steps (reference backend.py:130-150).
+
+        A device-resident chain is analysed where it lives (``emx_autocorr``: batched FFTs next to the chain, Sokal window,
+        only ``ndim`` numbers come back); the reference's ``tol`` / ``quiet`` handling (autocorr.py:110-121) is applied here.
+        Host-side chains (custom moves, blobs) go through :func:`emcee_amd.autocorr.integrated_time`."""
+        only = {k: v for k, v in kwargs.items() if k in ("c", "tol", "quiet")}
+        if self._dev is not None and kwargs.get("has_walkers", True) and len(only) == len(kwargs):
+            c, tol, quiet = only.get("c", 5), only.get("tol", 50), only.get("quiet", False)
+            tau_est, _, n_t = self._dev.autocorr(discard=discard, thin=thin, c=c)
+            flag = tol * tau_est > n_t
+            if np.any(flag):
+                msg = ("The chain is shorter than {0} times the integrated autocorrelation time for {1} parameter(s). "
+                       "Use this estimate with caution and run a longer chain!\n").format(tol, np.sum(flag))
+                msg += "N/{0} = {1:.0f};\ntau: {2}".format(tol, n_t / tol, tau_est)
+                if not quiet:
+                    raise autocorr.AutocorrError(tau_est, msg)
+                autocorr.logger.warning(msg)
+            return thin * tau_est
         x = self.get_chain(discard=discard, thin=thin)
         return thin * autocorr.integrated_time(x, **kwargs)
 

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/emx.h"
+#include "emx_internal.hpp"
 #include "emx_kernels.hpp"
 #include "emx_mtpipe.hpp"
 #include "emx_rng.hpp"
@@ -645,6 +646,30 @@ void shard_range(int64_t ns, int rank, int world, int64_t& lo, int64_t& hi) {
 }
 
 }  // namespace
+
+// ---- glue for the other translation units (emx_internal.hpp) -------------------------------------------------------
+int emx_internal_chain_view(emx_ctx* c, EmxChainView* v) {
+    if (!c) {
+        g_err = "null context";
+        return -1;
+    }
+    v->chain = c->chain;
+    v->chain_lp = c->chain_lp;
+    v->N = c->N;
+    v->D = c->D;
+    v->stored = c->stored;
+    v->stream = c->stream;
+    v->device = c->device;
+    return 0;
+}
+
+int emx_internal_fail(emx_ctx* c, int code, const char* msg) {
+    if (c)
+        c->err = msg;
+    else
+        g_err = msg;
+    return code;
+}
 
 // ------------------------------------------------------------------------------------------
 // C ABI

@@ -34,6 +34,9 @@
 #ifndef EMX_OPT_RED4
 #define EMX_OPT_RED4 1
 #endif
+#ifndef EMX_OPT_RTILE
+#define EMX_OPT_RTILE 1       // dense target, batch == tile: the LDS tile holds R = Q - mu (no mean reads at the A fragments), accepted
+#endif                        // rows are committed from the registers that made them (no tile re-read)
 #ifndef EMX_OPT_STAMPS
 #define EMX_OPT_STAMPS 0      // phase timestamps (tools/phase_clock.py builds its own copy with -DEMX_OPT_STAMPS=1: they cost 1 %)
 #endif
@@ -439,18 +442,30 @@ __host__ __device__ inline void native_gauss_slot(const NativeArgs& na, int D, i
         p0 = mode == GAUSS_SEQUENTIAL ? seqcol : -1;
 }
 
-// Box-Muller pair from one Philox block of the (walker, pair) counter; streams 2.. are the noise pairs.
-// The radius is computed in f64 (53-bit uniform: tails to 8.5 sigma), the direction with the hardware
-// v_sin_f32 / v_cos_f32 (argument in revolutions, 32-bit uniform): absolute error ~1e-6 * radius, which a
-// symmetric Metropolis proposal does not care about.  One definition for every path that needs a normal.
+// Noise of the native Gaussian Metropolis proposal.  Pair p (coordinates 2p, 2p + 1) of walker w is one Box-Muller pair
+// made from HALF a Philox4x32-7 block: block (w, 2 + (p >> 1)), words (2h, 2h + 1) with h = p & 1 -- a 32-bit uniform for
+// the radius (converted to f32: small values keep all their bits, so the tail reaches 6.7 sigma) and a 24-bit one for the
+// direction, all in f32 hardware transcendentals (v_log / v_sqrt / v_sin / v_cos).  A Metropolis proposal only has to be
+// symmetric for the chain to be exact, which any Box-Muller pair is (the direction is uniform); round count and
+// precision affect nothing but the cost: 7 instead of 10 rounds, two pairs per block, no f64 logarithm.
+// One definition for every path that needs a normal.
+__device__ __forceinline__ void gauss_from_words(uint32_t a, uint32_t b, double& n0, double& n1) {
+    const float u = ((float)a + 0.5f) * 2.3283064365386963e-10f;            // (0, 1]
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));   // sqrt(-2 ln u), ln u = ln 2 * log2 u
+    const float rev = (float)(b >> 8) * 5.9604644775390625e-8f;             // [0, 1) revolutions, 24 bits: exact in f32
+    n0 = (double)(r * __builtin_amdgcn_cosf(rev));
+    n1 = (double)(r * __builtin_amdgcn_sinf(rev));
+}
+
+__device__ __forceinline__ Philox4 gauss_block(uint64_t seed, uint64_t step, int w, int blk) {
+    return philox4x32<7>((uint32_t)w, 2u + (uint32_t)blk, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                         (uint32_t)(seed >> 32));
+}
+
 __device__ __forceinline__ void native_gauss_pair(uint64_t seed, uint64_t step, int w, int pair, double& n0, double& n1) {
-    const Philox4 R = philox4x32_10((uint32_t)w, 2u + (uint32_t)pair, (uint32_t)step, (uint32_t)(step >> 32),
-                                    (uint32_t)seed, (uint32_t)(seed >> 32));
-    const double u1 = 1.0 - u53(R.v[0], R.v[1]);            // (0, 1]
-    const double r = sqrt(-2.0 * log(u1));
-    const float rev = (float)(R.v[2] >> 8) * 5.9604644775390625e-8f;   // [0, 1) revolutions, 24 bits: exact in f32
-    n0 = r * (double)__builtin_amdgcn_cosf(rev);
-    n1 = r * (double)__builtin_amdgcn_sinf(rev);
+    const Philox4 R = gauss_block(seed, step, w, pair >> 1);
+    const int h = pair & 1;
+    gauss_from_words(h ? R.v[2] : R.v[0], h ? R.v[3] : R.v[1], n0, n1);
 }
 
 template <int MOVE>
@@ -483,6 +498,34 @@ __device__ __forceinline__ void gauss_disp_row(Row<G, V, CH>& t, const ARGS& A, 
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int v = 0; v < V; ++v) t.x[c][v] = ((c * G + gl) * V + v == col) ? val : 0.0;
+        return;
+    }
+    if constexpr (V == 2 && (CH % 2) == 0) {
+        // Lanes gl and gl ^ 1 hold pairs c G + gl and c G + (gl ^ 1): the two halves of ONE block.  Of every two chunks the
+        // even lane computes the block of the first, the odd lane the block of the second, and they swap the halves they
+        // do not need (DPP quad_perm [1,0,3,2]): one Philox block per lane per two chunks instead of two.
+        const int b = gl & 1;
+#pragma unroll
+        for (int c2 = 0; c2 < CH; c2 += 2) {
+            const int cm = c2 + b;                                 // the chunk whose block this lane computes
+            const Philox4 R = gauss_block(A.gseed, A.gstep, w, (cm * G + gl) >> 1);
+            // my half of my block serves chunk cm; the other half is the neighbour's for the same chunk
+            const uint32_t keep0 = b ? R.v[2] : R.v[0], keep1 = b ? R.v[3] : R.v[1];
+            const uint32_t give0 = b ? R.v[0] : R.v[2], give1 = b ? R.v[1] : R.v[3];
+            const uint32_t got0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give0, 0xB1, 0xf, 0xf, false);
+            const uint32_t got1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give1, 0xB1, 0xf, 0xf, false);
+            // chunk c2 + b from the kept words, chunk c2 + (1 - b) from the received ones
+            double k0, k1, r0, r1;
+            gauss_from_words(keep0, keep1, k0, k1);
+            gauss_from_words(got0, got1, r0, r1);
+            const double e0 = b ? r0 : k0, e1 = b ? r1 : k1;       // chunk c2     (even chunk of the pair)
+            const double o0 = b ? k0 : r0, o1 = b ? k1 : r1;       // chunk c2 + 1
+            const int de = 2 * (c2 * G + gl), dod = 2 * ((c2 + 1) * G + gl);
+            t.x[c2][0] = de < D ? (A.gfac * (A.gscale ? A.gscale[de] : A.gsigma)) * e0 : 0.0;
+            t.x[c2][1] = de + 1 < D ? (A.gfac * (A.gscale ? A.gscale[de + 1] : A.gsigma)) * e1 : 0.0;
+            t.x[c2 + 1][0] = dod < D ? (A.gfac * (A.gscale ? A.gscale[dod] : A.gsigma)) * o0 : 0.0;
+            t.x[c2 + 1][1] = dod + 1 < D ? (A.gfac * (A.gscale ? A.gscale[dod + 1] : A.gsigma)) * o1 : 0.0;
+        }
         return;
     }
 #pragma unroll
@@ -597,6 +640,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     constexpr int Dp = DPB * 16;      // dense: padded dimension
     constexpr int KK = Dp / 4;        // MFMA k-steps
     constexpr int RT = Dp + 2;        // tile row stride (doubles): conflict-free A-fragment reads
+    constexpr bool RTILE = EMX_OPT_RTILE && DENSE && PF == PPT && MOVE != MOVE_EVAL;
     static_assert(!DENSE || G * V * CH >= Dp, "row layout must cover the padded dimension");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (A.ablate & 64) return;     // timing experiments: launch + dispatch floor
@@ -654,6 +698,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
         load_row<G, V, CH>(mu, A.tp0, D, gl);
         load_row<G, V, CH>(iv, A.tp1, D, gl);
     }
+    if constexpr (RTILE) load_row<G, V, CH>(mu, A.tp0, D, gl);        // the mean in the row layout: the tile receives q - mu
 
     const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -714,6 +759,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
             }
             // -------- issue every row load of the batch (+ the per-walker scalars) --------
             Row<G, V, CH> xi[PF], xa[NR >= 2 ? PF : 1], xb[NR >= 3 ? PF : 1], xc[NR >= 4 ? PF : 1];
+            Row<G, V, CH> qk[RTILE ? PF : 1];          // RTILE: the proposals stay in registers until the commit
             double s0v[PF], facv[PF], lpov[PF], loguv[PF];
 #pragma unroll
             for (int k = 0; k < PF; ++k) {
@@ -826,8 +872,13 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 #pragma unroll
                             for (int v = 0; v < V; ++v) {
                                 const int d = (c * G + gl) * V + v;
-                                if (d < Dp && !(A.ablate & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] : muS[d];   // dead row: zero residual
+                                if constexpr (RTILE) {
+                                    if (d < Dp && !(A.ablate & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] - mu.x[c][v] : 0.0;
+                                } else {
+                                    if (d < Dp && !(A.ablate & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] : muS[d];   // dead row: zero residual
+                                }
                             }
+                        if constexpr (RTILE) qk[k] = q;
                         if (gl == 0) facS[trow] = badq ? -__builtin_inf() : factor;
                         // stored step / sharded run: the current row goes out now (fire and forget); an accepted
                         // proposal overwrites it after the decision -- no reload of rejected rows in the commit
@@ -868,8 +919,12 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         typedef double d4 __attribute__((ext_vector_type(4)));
                         double afr[KK];
 #pragma unroll
-                        for (int kk = 0; kk < KK; ++kk)
-                            afr[kk] = tile[am * RT + 4 * kk + ak] - muS[4 * kk + ak];           // A[i = lane&15][k = lane>>4]
+                        for (int kk = 0; kk < KK; ++kk) {                                        // A[i = lane&15][k = lane>>4]
+                            if constexpr (RTILE)
+                                afr[kk] = tile[am * RT + 4 * kk + ak];
+                            else
+                                afr[kk] = tile[am * RT + 4 * kk + ak] - muS[4 * kk + ak];
+                        }
                         double part[4] = {0.0, 0.0, 0.0, 0.0};
                         if (EMX_OPT_STAMPS && A.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                         EMX_STAMP(5);      // A fragments in registers
@@ -927,7 +982,9 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         if (A.sendbuf && (lane & 15) < 4) qfS[myrow] = lp_fin;
                         if (A.sendbuf) EMX_WAVE_SYNC();
                         // commit the tile's rows in the (G, V, CH) row layout: accepted rows come from LDS
-                        for (int pp = 0; pp < ((A.ablate & 8) ? 0 : PPT); ++pp) {
+#pragma unroll
+                        for (int pp = 0; pp < PPT; ++pp) {
+                            if (A.ablate & 8) break;
                             const int row = pp * WPW + sub;              // 0..15
                             const int sidx = tb + row;
                             const bool lv = sidx < nslot;
@@ -949,13 +1006,17 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                 wi2 = A.order[pbase + sidx];
                             }
                             Row<G, V, CH> rr;
+                            if constexpr (RTILE) {
+                                rr = qk[pp < PF ? pp : 0];               // batch == tile: pass pp of the tile is pass pp of the batch
+                            } else {
 #pragma unroll
-                            for (int c = 0; c < CH; ++c)
+                                for (int c = 0; c < CH; ++c)
 #pragma unroll
-                                for (int v = 0; v < V; ++v) {
-                                    const int d = (c * G + gl) * V + v;
-                                    rr.x[c][v] = d < D ? tile[row * RT + d] : 0.0;
-                                }
+                                    for (int v = 0; v < V; ++v) {
+                                        const int d = (c * G + gl) * V + v;
+                                        rr.x[c][v] = d < D ? tile[row * RT + d] : 0.0;
+                                    }
+                            }
                             store_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
                             if (chain_) store_row<G, V, CH>(rr, chain_ + (size_t)wi2 * D, D, gl);
                             if (A.sendbuf) store_row<G, V, CH>(rr, A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2), D, gl);

@@ -22,11 +22,14 @@ struct Philox4 {
     uint32_t v[4];
 };
 
-// Philox4x32-10 (Salmon et al. 2011), key = 64-bit seed, counter = 128 bits.
-EMX_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// Philox4x32-R (Salmon et al. 2011), key = 64-bit seed, counter = 128 bits.  R = 10 is the recommended strength and what
+// every decision-bearing draw uses; R = 7 is the smallest round count that passes BigCrush (ibid., table 2) and serves the
+// bulk noise of the Gaussian Metropolis proposal, where the integer multiplies were the bottleneck.
+template <int ROUNDS>
+EMX_HD Philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
         const uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
         c0 = hi1 ^ c1 ^ k0;
@@ -42,6 +45,10 @@ EMX_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
     o.v[2] = c2;
     o.v[3] = c3;
     return o;
+}
+
+EMX_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    return philox4x32<10>(c0, c1, c2, c3, k0, k1);
 }
 
 // 53-bit uniform in [0,1) from two words (same construction as MT19937 random_sample).

@@ -197,6 +197,32 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_accepted_counts(self.ctx, out))
         return out
 
+    # ---- around the hot loop ----
+    def autocorr(self, discard=0, thin=1, c=5.0):
+        """-> (tau per parameter in units of the selected samples, windows, number of samples): emx_autocorr on the
+        device-resident chain (reference autocorr.integrated_time over get_chain(discard, thin))."""
+        DeviceEnsemble._load_hipfft(self.lib)
+        tau = np.empty(self.ndim)
+        win = np.empty(self.ndim, dtype=np.int32)
+        nt = C.c_int64()
+        self._ck(self.lib.emx_autocorr(self.ctx, int(discard), int(thin), float(c), tau, win, C.byref(nt)))
+        return tau, win, nt.value
+
+    @staticmethod
+    def _load_hipfft(lib):
+        import os
+        path = os.environ.get("EMX_HIPFFT_LIB")
+        if not path:
+            try:   # share PyTorch's hipFFT / rocFFT when torch is in the process
+                import torch
+                cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libhipfft.so")
+                path = cand if os.path.exists(cand) else None
+            except Exception:  # noqa: BLE001
+                path = None
+        rc = lib.emx_fft_load(path.encode() if path else None)
+        if rc != 0:
+            raise EmxError((lib.emx_last_error(None) or b"cannot load libhipfft").decode())
+
     # ---- split-phase ----
     def step_begin(self, store=False):
         mv, S = C.c_int32(), C.c_int32()

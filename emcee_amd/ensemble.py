@@ -762,9 +762,9 @@ def walkers_independent(coords):
     """Initial-state conditioning check (reference ``ensemble.py:653-663``): the scaled, centred
     walker matrix must have condition number <= 1e8.  One-off check outside the step loop.
 
-    Large ensembles (>= 2^21 coordinates) on a machine with a GPU are checked there: the same
-    centring / scaling passes, then the (ndim, ndim) triangular factor of a Householder QR (rocSOLVER
-    through ``torch.linalg.qr``) whose singular values are those of the tall matrix -- backward stable
+    Large ensembles (>= 2^21 coordinates) on a machine with a GPU are checked there
+    (``emx_walkers_independent`` in libemx): the same centring / scaling passes, then a Householder QR
+    whose (ndim, ndim) triangular factor has the singular values of the tall matrix -- backward stable
     like the SVD the reference takes, so the verdict is the same (a Gram matrix
     would square the condition number and could not resolve the 1e8 threshold in float64)."""
     if np.size(coords) >= _DEVICE_CHECK_MIN_SIZE and np.asarray(coords).dtype == np.float64:
@@ -783,28 +783,21 @@ def walkers_independent(coords):
 
 
 def _walkers_independent_device(coords):
-    """The check on the GPU; None when no GPU / no QR is available (the caller then uses the host)."""
+    """The check on the GPU (``emx_walkers_independent``: Householder QR there, extreme singular values of the small
+    triangular factor on the host); None when no GPU is available (the caller then uses the host)."""
+    import ctypes as C
     try:
-        import torch
-        if not torch.cuda.is_available():
+        lib = _lib.load()
+        if _lib.device_count() < 1:
             return None
-        x = torch.as_tensor(np.ascontiguousarray(coords), device="cuda")
-        if not bool(torch.isfinite(x).all()):
-            return False
-        x = x - x.mean(dim=0, keepdim=True)
-        colmax = x.abs().amax(dim=0)
-        if bool((colmax == 0).any()):
-            return False
-        x = x / colmax
-        x = x / torch.sqrt((x * x).sum(dim=0))
-        if x.shape[0] < x.shape[1]:
-            return False                      # fewer walkers than dimensions: rank deficient by construction
-        r = torch.linalg.qr(x, mode="r").R.cpu().numpy()
+        x = np.ascontiguousarray(coords, dtype=np.float64)
+        verdict = C.c_int32(0)
+        rc = lib.emx_walkers_independent(0, x, x.shape[0], x.shape[1], C.byref(verdict), None)
     except Exception:  # noqa: BLE001
         return None
-    if not np.all(np.isfinite(r)):
-        return False
-    return bool(np.linalg.cond(r) <= 1e8)
+    if rc != 0:
+        return None
+    return bool(verdict.value)
 
 
 def ndarray_to_list_of_dicts(x, key_map):

@@ -227,6 +227,24 @@ int emx_comm_get_unique_id(uint8_t id[128]);
 int emx_comm_init(emx_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[128]);
 int emx_comm_destroy(emx_ctx* ctx);
 
+/* ---- around the hot loop: autocorrelation time and the initial-state check ------------------------------------------ */
+/* Integrated autocorrelation time of the device-resident chain, per parameter (autocorr.py:49-123 integrated_time applied to
+ * Backend.get_value("chain", discard, thin), backend.py:42-58,130-150): normalised FFT autocorrelation function of every
+ * walker's series (batched hipFFT next to the chain), averaged over walkers, Sokal window with step size c.  tau_out[ndim] is
+ * in units of the SELECTED samples (the caller multiplies by thin, backend.py:150); window_out[ndim] (or NULL) the windows;
+ * *nsamples_out the series length, against which the caller applies the reference's "tol" check (autocorr.py:110-121).
+ * libhipfft is resolved with dlopen (emx_fft_load(path), $EMX_HIPFFT_LIB, libhipfft.so): pass PyTorch's copy when torch is
+ * in the process. */
+int emx_fft_load(const char* libhipfft_path /* or NULL */);
+int emx_autocorr(emx_ctx* ctx, int64_t discard, int64_t thin, double c, double* tau_out, int32_t* window_out,
+                 int64_t* nsamples_out);
+/* walkers_independent(coords) (ensemble.py:653-663): centre, scale by max |.| and by the 2-norm per coordinate, condition
+ * number <= 1e8.  The (n, ndim) host matrix goes to `device`; Householder QR there (one reflector per coordinate), then the
+ * extreme singular values of the ndim x ndim triangular factor by (inverse) power iteration on the host.  *independent: 0 / 1;
+ * *cond_out (or NULL): the condition number (inf for a constant coordinate, non-finite input, n < ndim or a singular factor). */
+int emx_walkers_independent(int32_t device, const double* coords, int64_t n, int32_t ndim, int32_t* independent,
+                            double* cond_out);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 int emx_timer_start(emx_ctx* ctx);                 /* hipEventRecord on the context stream */
 int emx_timer_stop(emx_ctx* ctx, float* ms);       /* record + synchronize + elapsed       */

@@ -412,7 +412,8 @@ def test_compute_log_prob_and_autocorr_time():
 
 
 def test_device_autocorr_equals_host_estimator():
-    """tau from batched FFTs on the HBM-resident chain == the host estimator."""
+    """tau from emx_autocorr (batched hipFFT on the HBM-resident chain, behind the C ABI) == the host
+    estimator (which tests/test_autocorr_cpu.py holds equal to the reference's) == the torch.fft cross-check."""
     from emcee_amd import autocorr
     from emcee_amd._devfft import integrated_time_device, mean_acf
     np.random.seed(5)
@@ -420,16 +421,31 @@ def test_device_autocorr_equals_host_estimator():
     s.run_mcmc(np.random.randn(96, 3), 1500)
     ens = s.backend._dev
     assert ens is not None
-    for discard, thin in ((0, 1), (100, 3)):
+    for discard, thin, c in ((0, 1, 5), (100, 3, 5), (7, 2, 3.5), (1499, 1, 5)):
         host_chain = s.get_chain(discard=discard, thin=thin)
-        tau_h = autocorr.integrated_time(host_chain, quiet=True)
-        tau_d = integrated_time_device(ens, s.iteration, discard=discard, thin=thin, quiet=True)
-        np.testing.assert_allclose(tau_d, tau_h, rtol=1e-8)
+        tau_lib, win, n_t = ens.autocorr(discard=discard, thin=thin, c=c)
+        assert n_t == host_chain.shape[0]
+        if n_t < 2:
+            continue
+        tau_h = autocorr.integrated_time(host_chain, c=c, quiet=True)
+        np.testing.assert_allclose(tau_lib, tau_h, rtol=1e-8)
+        for d in range(3):      # the window itself: auto_window on the walker-averaged ACF of the host chain
+            rho = autocorr._batched_acf(np.asarray(host_chain[:, :, d], dtype=float)).mean(axis=1)
+            assert win[d] == autocorr.tau_from_mean_acf(rho, c)[0]
+        tau_t = integrated_time_device(ens, s.iteration, discard=discard, thin=thin, c=c, quiet=True)    # torch.fft twin
+        np.testing.assert_allclose(tau_lib, tau_t, rtol=1e-8)
         f = mean_acf(ens, s.iteration, discard=discard, thin=thin)
         assert f.shape == (host_chain.shape[0], 3) and abs(f[0, 0] - 1.0) < 1e-12
     np.testing.assert_allclose(s.get_autocorr_time(quiet=True), autocorr.integrated_time(s.get_chain(), quiet=True), rtol=1e-8)
+    np.testing.assert_allclose(s.get_autocorr_time(quiet=True, discard=50, thin=4),
+                               4 * autocorr.integrated_time(s.get_chain(discard=50, thin=4), quiet=True), rtol=1e-8)
     with pytest.raises(autocorr.AutocorrError):
         s.get_autocorr_time(tol=1e6)
+    # several chunks of walkers (the chunk size follows from the padded length): a longer chain of a wider ensemble
+    np.random.seed(6)
+    s = emcee_amd.EnsembleSampler(4096, 8, targets.IsoGaussian(), rng="philox")
+    s.run_mcmc(np.random.randn(4096, 8), 600)
+    np.testing.assert_allclose(s.get_autocorr_time(quiet=True), autocorr.integrated_time(s.get_chain(), quiet=True), rtol=1e-8)
 
 
 def test_reference_move_instances_are_recognised_by_duck_typing():

@@ -1,5 +1,5 @@
 """walkers_independent: the reference's cases (unit/test_sampler.py:237-321) on the host path, and --
-on a GPU -- the device path (QR on the GPU) against the host verdict at sizes where it is used."""
+on a GPU -- the device path (emx_walkers_independent: Householder QR on the GPU) against the host verdict."""
 import numpy as np
 import pytest
 
@@ -36,6 +36,30 @@ def test_reference_cases_host(nw, nd):
     for name, m, expect in _cases(nw, nd, rs):
         assert walkers_independent(m) == expect, name
     assert not walkers_independent(rs.randn(nd, nd + 1))          # too few walkers
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw,nd", [(10, 2), (20, 5), (30, 10), (200, 33)])
+def test_reference_cases_through_the_c_abi(nw, nd):
+    """emx_walkers_independent itself (Householder QR kernels + extreme singular values of the triangular factor) on the
+    reference's own small cases, with the condition number next to NumPy's for the well-posed ones."""
+    import ctypes as C
+    from emcee_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(nw)
+    for name, m, expect in _cases(nw, nd, rs):
+        x = np.ascontiguousarray(m, dtype=np.float64)
+        verdict, cond = C.c_int32(-1), C.c_double()
+        assert lib.emx_walkers_independent(0, x, nw, nd, C.byref(verdict), C.byref(cond)) == 0
+        assert bool(verdict.value) == expect, (name, cond.value)
+        if expect:
+            Cm = x - x.mean(axis=0)
+            Cm /= np.abs(Cm).max(axis=0)
+            Cm /= np.sqrt((Cm ** 2).sum(axis=0))
+            np.testing.assert_allclose(cond.value, np.linalg.cond(Cm), rtol=1e-4)      # (inverse) power iteration: ample for a 1e8 threshold
+    verdict = C.c_int32(-1)
+    assert lib.emx_walkers_independent(0, np.ascontiguousarray(rs.randn(nd, nd + 1)), nd, nd + 1, C.byref(verdict), None) == 0
+    assert verdict.value == 0                                         # too few walkers
 
 
 @pytest.mark.gpu

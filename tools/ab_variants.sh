@@ -2,9 +2,11 @@
 # Build experiment variants of libemx (compile-time switches in emx_kernels.hpp) next to the shipped one.
 #   usage: tools/ab_variants.sh name "-DEMX_OPT_X=0 ..." [name flags ...]
 cd "$(dirname "$0")/../emcee_amd/csrc" || exit 1
+HOSTCXX=/opt/rocm/lib/llvm/bin/clang++
+$HOSTCXX -O3 -std=c++17 -ffp-contract=off -fPIC -pthread -c emx_mtpipe.cpp -o /tmp/emx_mtpipe_ab.o || exit 1
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -fPIC -shared $flags emx.hip emx_small.hip -o ../libemx_$name.so &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -fPIC -shared $flags /tmp/emx_mtpipe_ab.o emx.hip emx_small.hip -o ../libemx_$name.so -ldl -pthread &
 done
 wait
 ls -la ../libemx_*.so
