@@ -616,6 +616,10 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
             a.peer_lo[q] = (int32_t)(c->N * q / c->world);
         }
     }
+    {
+        static const int skew_sleep = getenv("EMX_SKEW_SLEEP") ? atoi(getenv("EMX_SKEW_SLEEP")) : 0;     // kernel experiments only
+        a.skew_sleep = skew_sleep;
+    }
     a.dbg = (c->dbg && nblocks <= c->dbg_blocks && move != MOVE_EVAL) ? c->dbg : nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max && move != MOVE_EVAL;

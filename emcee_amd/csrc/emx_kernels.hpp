@@ -37,6 +37,9 @@
 #ifndef EMX_OPT_RTILE
 #define EMX_OPT_RTILE 1       // dense target, batch == tile: the LDS tile holds R = Q - mu (no mean reads at the A fragments), accepted
 #endif                        // rows are committed from the registers that made them (no tile re-read)
+#ifndef EMX_OPT_SKEW
+#define EMX_OPT_SKEW 1        // dense target, 8-wave workgroups: the upper four waves stage the whole LDS image before they issue
+#endif                        // their row loads, so the two waves of a SIMD run out of phase (loads first for the lower four)
 #ifndef EMX_OPT_STAMPS
 #define EMX_OPT_STAMPS 0      // phase timestamps (tools/phase_clock.py builds its own copy with -DEMX_OPT_STAMPS=1: they cost 1 %)
 #endif
@@ -130,6 +133,7 @@ struct HalfStepArgs {
     const double* peerX[EMX_MAX_PEERS];
     int32_t peer_lo[EMX_MAX_PEERS];
     int32_t npeer;
+    int32_t skew_sleep;            // EMX_OPT_SKEW experiments: extra delay of the staging waves, in s_sleep(8) units (0 in production)
 };
 
 // coordinate array holding the current row of walker j (block ownership: rank q owns [peer_lo[q], peer_lo[q + 1]))
@@ -669,19 +673,32 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     // (built once by emx_set_target).  Its global loads are issued first and written to LDS only after
     // the first batch's row loads are in flight; one workgroup barrier precedes the first MFMA stage.
     constexpr int IMG2 = (Dp * Dp + Dp) / 2;                // image size in double2
-    constexpr int NSTG = 5;                                 // double2 per thread held in registers (first round)
-    double2 stg0, stg1, stg2, stg3, stg4;
-    stg0 = stg1 = stg2 = stg3 = stg4 = double2{0.0, 0.0};
+    constexpr int NSTG = 5;                                 // double2 per thread held in registers (first round; 9 = the whole image of a skewed stager in one round was measured 2.7 % slower)
+    double2 stg0, stg1, stg2, stg3, stg4, stg5, stg6, stg7, stg8;
+    stg0 = stg1 = stg2 = stg3 = stg4 = stg5 = stg6 = stg7 = stg8 = double2{0.0, 0.0};
 #define EMX_IMAGE_LOADS()                                                                          \
     do {                                                                                           \
         const double2* img_ = reinterpret_cast<const double2*>(A.tp1);                             \
-        const int bs_ = blockDim.x, tx_ = threadIdx.x;                                             \
+        const int bs_ = stg_bs, tx_ = stg_tx;                                                      \
         if (tx_ < IMG2) stg0 = img_[tx_];                                                          \
         if (tx_ + bs_ < IMG2) stg1 = img_[tx_ + bs_];                                              \
         if (tx_ + 2 * bs_ < IMG2) stg2 = img_[tx_ + 2 * bs_];                                      \
         if (tx_ + 3 * bs_ < IMG2) stg3 = img_[tx_ + 3 * bs_];                                      \
         if (tx_ + 4 * bs_ < IMG2) stg4 = img_[tx_ + 4 * bs_];                                      \
+        if constexpr (NSTG > 5) {                                                                  \
+            if (tx_ + 5 * bs_ < IMG2) stg5 = img_[tx_ + 5 * bs_];                                  \
+            if (tx_ + 6 * bs_ < IMG2) stg6 = img_[tx_ + 6 * bs_];                                  \
+            if (tx_ + 7 * bs_ < IMG2) stg7 = img_[tx_ + 7 * bs_];                                  \
+            if (tx_ + 8 * bs_ < IMG2) stg8 = img_[tx_ + 8 * bs_];                                  \
+        }                                                                                          \
     } while (0)
+    // EMX_OPT_SKEW: in an 8-wave workgroup the image is staged by waves 4-7 alone, BEFORE their own row loads; waves 0-3 go
+    // straight to their loads.  The two waves that share a SIMD (w, w + 4) then run about one image latency out of phase:
+    // while one is in its MFMA chain the other is still loading / proposing instead of queueing for the same pipe.
+    const bool skew = EMX_OPT_SKEW && DENSE && blockDim.x == 512;
+    const bool stager = !skew || (threadIdx.x >> 6) >= 4;
+    const int stg_bs = skew ? 256 : (int)blockDim.x;
+    const int stg_tx = skew ? (stager ? (int)threadIdx.x - 256 : (1 << 30)) : (int)threadIdx.x;      // non-stagers: beyond the image
     if constexpr (DENSE) {
         // The image loads are the FIRST memory operations of the kernel: vector-memory loads return in
         // order, so they land before the (slower, bandwidth-bound) row loads issued below and the
@@ -717,12 +734,18 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     do {                                                                                            \
         if constexpr (DENSE) {                                                                      \
             double2* dst_ = reinterpret_cast<double2*>(smem);                                       \
-            const int bs_ = blockDim.x, tx_ = threadIdx.x;                                          \
+            const int bs_ = stg_bs, tx_ = stg_tx;                                                   \
             if (tx_ < IMG2) dst_[tx_] = stg0;                                                       \
             if (tx_ + bs_ < IMG2) dst_[tx_ + bs_] = stg1;                                           \
             if (tx_ + 2 * bs_ < IMG2) dst_[tx_ + 2 * bs_] = stg2;                                   \
             if (tx_ + 3 * bs_ < IMG2) dst_[tx_ + 3 * bs_] = stg3;                                   \
             if (tx_ + 4 * bs_ < IMG2) dst_[tx_ + 4 * bs_] = stg4;                                   \
+            if constexpr (NSTG > 5) {                                                               \
+                if (tx_ + 5 * bs_ < IMG2) dst_[tx_ + 5 * bs_] = stg5;                               \
+                if (tx_ + 6 * bs_ < IMG2) dst_[tx_ + 6 * bs_] = stg6;                               \
+                if (tx_ + 7 * bs_ < IMG2) dst_[tx_ + 7 * bs_] = stg7;                               \
+                if (tx_ + 8 * bs_ < IMG2) dst_[tx_ + 8 * bs_] = stg8;                               \
+            }                                                                                       \
             for (int e_ = tx_ + NSTG * bs_; e_ < IMG2; e_ += bs_)                                   \
                 dst_[e_] = reinterpret_cast<const double2*>(A.tp1)[e_];   /* very wide targets */   \
             __syncthreads();                                                                        \
@@ -740,6 +763,10 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
         const int pbase = A.pos0 + t0;          // plan position of the wave's first slot
 
         for (int pb = 0; pb < npass; pb += PF) {
+            if (skew && stager && stage_pending) {                       // image first, own loads after the barrier
+                EMX_STAGE_PUBLISH();
+                for (int r_ = 0; r_ < A.skew_sleep; ++r_) __builtin_amdgcn_s_sleep(8);
+            }
             // -------- plan entries of the batch: every lane of a group reads its walker's entry
             //          (same address across the group: one request, broadcast) --------
             int wi[PF], ja[PF], jb[NR >= 3 ? PF : 1], jc[NR >= 4 ? PF : 1];

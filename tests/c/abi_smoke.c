@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
     SYM(emx_create) SYM(emx_destroy) SYM(emx_set_target) SYM(emx_set_moves) SYM(emx_set_rng_mode)
     SYM(emx_rng_set_philox) SYM(emx_set_state) SYM(emx_eval_state_log_prob) SYM(emx_chain_config)
     SYM(emx_run) SYM(emx_chain_read) SYM(emx_accepted_counts) SYM(emx_get_state) SYM(emx_status)
+    SYM(emx_autocorr) SYM(emx_walkers_independent)
     printf("version: %s\n", p_emx_version());
 
     /* host-only: MT19937 seeded with init_genrand(5489)-style key is not needed; use a fixed key */
@@ -91,6 +92,28 @@ int main(int argc, char** argv) {
     }
     printf("gpu run ok: acceptance %.3f, <x^2> %.3f\n", a, m2);
     if (!(a > 0.2 && a < 0.9 && m2 > 0.6 && m2 < 1.5)) return 11;
+    /* the two operations around the loop, from C: autocorrelation time of the device chain and the initial-state check */
+    double tau[D];
+    int32_t win[D];
+    int64_t nsel = 0;
+    if (p_emx_autocorr(ctx, 20, 1, 5.0, tau, win, &nsel) != 0) { fprintf(stderr, "emx_autocorr: %s\n", p_emx_last_error(ctx)); return 12; }
+    printf("autocorrelation time over %lld samples: %.2f %.2f %.2f %.2f steps\n", (long long)nsel, tau[0], tau[1], tau[2], tau[3]);
+    for (int d = 0; d < D; ++d)
+        if (!(nsel == 180 && tau[d] > 1.0 && tau[d] < 60.0 && win[d] > 0)) return 12;
+    int32_t indep = -1;
+    double cond = 0.0;
+    uint32_t lcg = 12345u;                                 /* the sinusoids above span two dimensions only: fresh pseudo-random rows */
+    for (int i = 0; i < N * D; ++i) {
+        lcg = lcg * 1664525u + 1013904223u;
+        x0[i] = (double)(lcg >> 8) / 16777216.0 - 0.5;
+    }
+    if (p_emx_walkers_independent(0, x0, N, D, &indep, &cond) != 0 || indep != 1 || !(cond >= 1.0 && cond < 1e3)) {
+        fprintf(stderr, "emx_walkers_independent: verdict %d, cond %g (%s)\n", indep, cond, p_emx_last_error(NULL));
+        return 13;
+    }
+    for (int i = 0; i < N; ++i) x0[i * D + 3] = 2.0 * x0[i * D + 1];          /* a linearly dependent coordinate */
+    if (p_emx_walkers_independent(0, x0, N, D, &indep, &cond) != 0 || indep != 0) { fprintf(stderr, "dependent walkers accepted\n"); return 13; }
+    printf("initial-state check ok\n");
     p_emx_destroy(ctx);
     return 0;
 }
