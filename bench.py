@@ -611,12 +611,17 @@ def main():
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="sharded runs: collectives enqueued by libemx itself (default) or torch.distributed")
     ap.add_argument("--exchange", default="all", choices=["all"] + list(EXCHANGES))
+    ap.add_argument("--all-on-device", type=int, default=None,
+                    help="testing on a one-GPU box: every rank uses this device (RCCL refuses duplicate devices, so only the "
+                         "control flow -- failure handling, watchdogs, the emitted line -- is exercised)")
     ap.add_argument("--exchange-timeout", type=float, default=150.0,
                     help="seconds after which a stuck exchange measurement is abandoned (the line so far is emitted)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.all_on_device is not None:
+        local_rank = args.all_on_device
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))

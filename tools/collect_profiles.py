@@ -7,11 +7,14 @@ import shutil
 import statistics
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = "gpurun_out/prof_%s" % R, "profiles/%s" % R
 os.makedirs(dst, exist_ok=True)
 for name in ("c2_kernel_stats.csv", "c2_domain_stats.csv"):
     shutil.copy(os.path.join(src, "trace", name), os.path.join(dst, name))
+allstats = os.path.join(src, "trace_all", "all_kernel_stats.csv")
+if os.path.exists(allstats):
+    shutil.copy(allstats, os.path.join(dst, "all_configs_kernel_stats.csv"))
 tr = os.path.join(src, "trace", "c2_kernel_trace.csv")
 tr = tr if os.path.exists(tr) else tr + ".head"
 with open(tr) as f, open(os.path.join(dst, "c2_kernel_trace.head.csv"), "w") as g:
