@@ -434,6 +434,16 @@ def quality_entry(device, rng="philox"):
 EXCHANGES = ("allgather", "pull", "direct")
 
 
+_NCCL_GROUP = {}
+
+
+def _torch_nccl_group(dist):
+    """torch.distributed's own RCCL communicator, next to the gloo bootstrap group (fallback data path)"""
+    if "g" not in _NCCL_GROUP:
+        _NCCL_GROUP["g"] = dist.new_group(backend="nccl")
+    return _NCCL_GROUP["g"]
+
+
 def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode, single_block=False):
     """One sharded measurement (fresh context): spin-up, W warm-up steps, K-step blocks."""
     import torch
@@ -448,9 +458,10 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
         from emcee_amd.parallel import DeviceEngine, PullStepper, ShardedStepper
         ens.set_stream(torch.cuda.current_stream().cuda_stream)   # kernels + RCCL ordered on one stream
         eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank), exchange=exchange)
-        gather = lambda out, inp: dist.all_gather_into_tensor(out, inp)  # noqa: E731
+        grp = None if dist.get_backend() == "nccl" else _torch_nccl_group(dist)
+        gather = lambda out, inp: dist.all_gather_into_tensor(out, inp, group=grp)  # noqa: E731
         if exchange == "pull":
-            stepper = PullStepper(eng, lambda out, inp: dist.all_to_all_single(out, inp), gather)
+            stepper = PullStepper(eng, lambda out, inp: dist.all_to_all_single(out, inp, group=grp), gather)
         else:
             stepper = ShardedStepper(eng, gather)
         run = lambda k: stepper.run(k, 1, False)  # noqa: E731
@@ -539,12 +550,23 @@ def sharded_config(key, world, K, W, rank, local_rank, dist, args):
         except Exception as e:  # noqa: BLE001
             errors[ex] = repr(e)
             log("rank %d: exchange '%s' on %s failed: %r" % (rank, ex, key, e))
-        done.set()
-        timer.cancel()
         ok = torch_all_ok(dist, ex in results)
         if not ok:
             results.pop(ex, None)
             errors.setdefault(ex, "failed on another rank")
+            if args.comm == "rccl" and ex != "direct":
+                # library-driven RCCL unavailable on some rank: the same protocol over torch.distributed's communicator
+                try:
+                    results[ex] = measure_sharded(wl, K, W, ex, rank, world, local_rank, dist, "torch", args.single_block)
+                except Exception as e:  # noqa: BLE001
+                    errors[ex] = errors[ex] + " | torch.distributed fallback: " + repr(e)
+                    log("rank %d: exchange '%s' on %s failed over torch.distributed too: %r" % (rank, ex, key, e))
+                if not torch_all_ok(dist, ex in results):
+                    results.pop(ex, None)
+                else:
+                    errors.pop(ex, None)
+        done.set()
+        timer.cancel()
     ref_digest = None
     best = None
     summary = {}
