@@ -522,51 +522,86 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
     return res
 
 
-def sharded_config(key, world, K, W, rank, local_rank, dist, args):
-    """Every exchange protocol on one workload; the fastest whose final ensemble agrees on all ranks (and with the
-    first protocol's) is reported."""
-    import threading
+def sharded_workload(key, world, args):
     scaling = {"c2": "weak", "c3": "strong", "c5": "strong"}[key] if args.scaling == "auto" else args.scaling
     base = {"c2": 65536, "c3": 262144, "c5": 16384}[key]
-    wl = Workload(key, base * world if scaling == "weak" else base)
+    return Workload(key, base * world if scaling == "weak" else base), scaling
+
+
+def child_main(args, rank, world, local_rank):
+    """One (configuration, exchange) measurement in a process of its own: a protocol that crashes the GPU runtime or hangs in a
+    collective takes this child with it, not the rank's orchestrating parent (which never touches the GPU at N > 1)."""
+    import torch
+    import torch.distributed as dist
+    key, ex = args.child.split(":")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % args.child_port, rank=rank, world_size=world)
+    wl, _ = sharded_workload(key, world, args)
+    out = {"error": None}
+    try:
+        out = measure_sharded(wl, args.steps, args.warmup, ex, rank, world, local_rank, dist, args.comm, args.single_block)
+    except Exception as e:  # noqa: BLE001
+        first = repr(e)
+        log("rank %d: exchange '%s' on %s failed: %s" % (rank, ex, key, first))
+        out = {"error": first}
+    if args.comm == "rccl" and ex != "direct":
+        # library-driven RCCL unavailable on some rank: the same protocol over torch.distributed's communicator
+        if not torch_all_ok(dist, out.get("error") is None):
+            try:
+                out = measure_sharded(wl, args.steps, args.warmup, ex, rank, world, local_rank, dist, "torch", args.single_block)
+            except Exception as e:  # noqa: BLE001
+                out = {"error": (out.get("error") or "failed on another rank") + " | torch.distributed fallback: " + repr(e)}
+    sys.stdout.flush()
+    _claim_stdout().write("EMX_CHILD_RESULT " + json.dumps(out) + "\n")
+    _claim_stdout().flush()
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def run_child(args, key, ex, port, timeout_s):
+    """-> the child's result dict, or {"error": ...} (non-zero exit, no result line, or the timeout)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--child", "%s:%s" % (key, ex), "--child-port", str(port), "--comm", args.comm, "--scaling", args.scaling]
+    if args.single_block:
+        cmd.append("--single-block")
+    if args.all_on_device is not None:
+        cmd += ["--all-on-device", str(args.all_on_device)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %.0f s (hung; child killed)" % timeout_s}
+    for line in (r.stdout or "").splitlines():
+        if line.startswith("EMX_CHILD_RESULT "):
+            try:
+                return json.loads(line[len("EMX_CHILD_RESULT "):])
+            except Exception as e:  # noqa: BLE001
+                return {"error": "unreadable child result: %r" % (e,)}
+    return {"error": "child exited with code %d and no result" % r.returncode}
+
+
+def sharded_config(key, world, K, rank, dist, args, port0, skip):
+    """Every exchange protocol on one workload, each in its own child process per rank; the fastest whose final ensemble
+    agrees on all ranks (and with the first protocol's) is reported.  `skip`: protocols that already failed on an earlier
+    configuration (not tried again)."""
+    wl, scaling = sharded_workload(key, world, args)
     results, errors = {}, {}
     exchanges = EXCHANGES if args.exchange == "all" else (args.exchange,)
-    for ex in exchanges:
-        done = threading.Event()
-
-        def bail(ex=ex):
-            if done.is_set():
-                return
-            # a protocol that hangs must not take the contract line with it: report what is in hand and leave
-            log("rank %d: exchange '%s' on %s did not return within %.0f s" % (rank, ex, key, args.exchange_timeout))
-            _emergency_emit(args, "exchange '%s' on %s hung" % (ex, key))
-            os._exit(3)
-
-        timer = threading.Timer(args.exchange_timeout, bail)
-        timer.daemon = True
-        timer.start()
-        try:
-            results[ex] = measure_sharded(wl, K, W, ex, rank, world, local_rank, dist, args.comm, args.single_block)
-        except Exception as e:  # noqa: BLE001
-            errors[ex] = repr(e)
-            log("rank %d: exchange '%s' on %s failed: %r" % (rank, ex, key, e))
-        ok = torch_all_ok(dist, ex in results)
-        if not ok:
-            results.pop(ex, None)
-            errors.setdefault(ex, "failed on another rank")
-            if args.comm == "rccl" and ex != "direct":
-                # library-driven RCCL unavailable on some rank: the same protocol over torch.distributed's communicator
-                try:
-                    results[ex] = measure_sharded(wl, K, W, ex, rank, world, local_rank, dist, "torch", args.single_block)
-                except Exception as e:  # noqa: BLE001
-                    errors[ex] = errors[ex] + " | torch.distributed fallback: " + repr(e)
-                    log("rank %d: exchange '%s' on %s failed over torch.distributed too: %r" % (rank, ex, key, e))
-                if not torch_all_ok(dist, ex in results):
-                    results.pop(ex, None)
-                else:
-                    errors.pop(ex, None)
-        done.set()
-        timer.cancel()
+    for n, ex in enumerate(exchanges):
+        if ex in skip:
+            errors[ex] = "skipped: failed on an earlier configuration (%s)" % skip[ex]
+            continue
+        r = run_child(args, key, ex, port0 + n, args.exchange_timeout)
+        ok = r.get("error") is None and "wall_s" in r
+        if not torch_all_ok(dist, ok):             # the parents' own gloo group: CPU only
+            errors[ex] = r.get("error") or "failed on another rank"
+            skip[ex] = "%s: %s" % (key, errors[ex][:200])
+            log("rank %d: exchange '%s' on %s: %s" % (rank, ex, key, errors[ex]))
+        else:
+            results[ex] = r
     ref_digest = None
     best = None
     summary = {}
@@ -600,19 +635,6 @@ def torch_all_ok(dist, ok):
     return int(flag[0]) == 1
 
 
-_PARTIAL = {}
-
-
-def _emergency_emit(args, why):
-    if int(os.environ.get("RANK", "0")) != 0 or not _PARTIAL.get("line"):
-        return
-    line = dict(_PARTIAL["line"])
-    line["incomplete"] = why
-    out = _claim_stdout()
-    out.write(json.dumps(line) + "\n")
-    out.flush()
-
-
 # ------------------------------------------------------------------------------------------------ main
 def main():
     _claim_stdout()
@@ -636,8 +658,10 @@ def main():
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="testing on a one-GPU box: every rank uses this device (RCCL refuses duplicate devices, so only the "
                          "control flow -- failure handling, watchdogs, the emitted line -- is exercised)")
-    ap.add_argument("--exchange-timeout", type=float, default=150.0,
-                    help="seconds after which a stuck exchange measurement is abandoned (the line so far is emitted)")
+    ap.add_argument("--exchange-timeout", type=float, default=120.0,
+                    help="seconds after which a stuck exchange measurement (a child process per rank) is killed")
+    ap.add_argument("--child", default=None, help=argparse.SUPPRESS)          # internal: "<config>:<exchange>"
+    ap.add_argument("--child-port", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -648,10 +672,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     K, W = args.steps, args.warmup
+    if args.child:
+        return child_main(args, rank, world, local_rank)
 
-    import torch
-    torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_dist
+    if not sharded:
+        import torch
+        torch.cuda.set_device(local_rank)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -701,7 +728,6 @@ def main():
         res = measure_single(wl, K, W, device=local_rank, rng=args.rng, store=args.store, single_block=args.single_block)
         extra = {"timed_blocks": res["blocks"], "best_block_ms_per_step": res["wall_min_s"] * 1e3 / K}
         line = headline(wl, res["wall_s"], res["gpu_ms"], res["per_launch_us"], res["accept_frac"], res["status"], "", extra)
-        _PARTIAL["line"] = line
         if not args.no_extras:
             cfgs = {}
             plan = [("c3", 262144, False), ("c4", 65536, False), ("c5", 16384, False), ("c2", 65536, True)]
@@ -730,23 +756,24 @@ def main():
         emit(line)
         return
 
+    # N > 1: this process only orchestrates (CPU; a gloo group of the parents for agreement on what failed).  Every
+    # (configuration, exchange) measurement is a child process per rank with a rendezvous of its own.
     import torch.distributed as dist
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if args.comm == "torch":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group("gloo")      # bootstrap / barriers only; the data path is libemx -> RCCL
+    dist.init_process_group("gloo")
+    port_base = int(os.environ["MASTER_PORT"]) + 17
 
     keys = ["c2", "c3", "c5"] if args.config == "all" else [args.config if args.config != "c4" else "c2"]
     if "c2" not in keys:
         keys = ["c2"] + keys                 # the headline is always C2
     multi = {}
     line = None
-    for key in keys:
-        wl, best, entry = sharded_config(key, world, K, W, rank, local_rank, dist, args)
+    skip = {}
+    for kn, key in enumerate(keys):
+        wl, best, entry = sharded_config(key, world, K, rank, dist, args, port_base + 8 * kn, skip)
         multi[{"c2": "c2_weak_65536_per_gpu", "c3": "c3_262144x32_rosen_sharded", "c5": "c5_16384x1024_strong"}[key]
               if args.scaling == "auto" else "%s_%s" % (key, entry["scaling"])] = entry
         if key == "c2":
@@ -766,7 +793,6 @@ def main():
             line["scaling"] = entry["scaling"]
             line["cpu_baseline"] = None
             line["multi_gpu"] = multi
-            _PARTIAL["line"] = line
     if rank == 0 and line is not None:
         line["multi_gpu"] = multi
         emit(line)
