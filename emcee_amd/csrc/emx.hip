@@ -28,7 +28,8 @@ namespace {
 
 std::string g_err;
 
-constexpr int PLAN_RING = 16;
+constexpr int PLAN_RING = 2 * NATIVE_BATCH_MAX;     // two native batches (the upper half serves the quarantined graph replay)
+constexpr int PIPE_SINKS = PLAN_RING < 16 ? PLAN_RING : 16;      // exact-mode plan pipeline: pinned staging buffers in flight
 constexpr int EMX_MAX_RANKS = 1024;      // pull / all-gather exchanges: counter storage
 
 // ------------------------------------------------------------------------------------------
@@ -1294,7 +1295,7 @@ static void pipe_poll(void* arg) {
     emx_ctx* c = (emx_ctx*)arg;
     while (!c->pipe_uploads.empty()) {
         const int64_t n = c->pipe_uploads.front();
-        auto& s = c->ring[(c->pipe_ring0 + n) % PLAN_RING];
+        auto& s = c->ring[(c->pipe_ring0 + n % PIPE_SINKS) % PLAN_RING];
         if (hipEventQuery(s.uploaded) != hipSuccess) break;
         c->pipe->release(n);
         c->pipe_uploads.pop_front();
@@ -1305,9 +1306,9 @@ static int pipe_start(emx_ctx* c, int64_t nsteps) {
     const size_t N = (size_t)c->N;
     if (!c->up_stream) HIPOK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     HIPOK(c, hipStreamSynchronize(c->stream));          // no earlier copy still reads a staging buffer
-    PlanSink sinks[PLAN_RING];
+    PlanSink sinks[PIPE_SINKS];
     c->pipe_ring0 = (c->ring_pos + 1) % PLAN_RING;
-    for (int r = 0; r < PLAN_RING; ++r) {
+    for (int r = 0; r < PIPE_SINKS; ++r) {
         auto& s = c->ring[(c->pipe_ring0 + r) % PLAN_RING];
         s.busy = false;
         if (!s.host) HIPOK(c, hipHostMalloc((void**)&s.host, N * 32, hipHostMallocDefault));
@@ -1324,7 +1325,7 @@ static int pipe_start(emx_ctx* c, int64_t nsteps) {
     c->pipe_taken = 0;
     c->pipe_uploads.clear();
     c->pipe = new MtPlanPipeline(c->mt, c->N, c->D, (int32_t)c->moves.size(), c->moves.data(), c->cdf.data(), nsteps, sinks,
-                                 PLAN_RING, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0));
+                                 PIPE_SINKS, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0));
     return 0;
 }
 
@@ -1344,14 +1345,14 @@ static int pipe_take(emx_ctx* c) {
     PipeStepInfo info;
     pipe_poll(c);
     if (!c->pipe->wait_ready(n, info, pipe_poll, c)) FAIL(c, -7, "exact-mode plan pipeline stopped before step %lld", (long long)n);
-    const int slot = (int)((c->pipe_ring0 + n) % PLAN_RING);
+    const int slot = (int)((c->pipe_ring0 + n % PIPE_SINKS) % PLAN_RING);
     auto& s = c->ring[slot];
     cur.move = info.move;
     cur.S = info.S;
     cur.slot = slot;
     cur.off.assign(info.off, info.off + info.S + 1);
     const size_t N = (size_t)c->N;
-    // the device copy of this slot was last read by the kernels of step n - PLAN_RING
+    // the device copy of this slot was last read by the kernels of step n - PIPE_SINKS
     if (s.busy) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed, 0));
     HIPOK(c, hipMemcpyAsync(s.order, s.host, N * 32, hipMemcpyHostToDevice, c->up_stream));
     const int stretch = c->moves[cur.move].kind == EMX_MOVE_STRETCH;

@@ -1541,7 +1541,10 @@ static __global__ __launch_bounds__(256) void k_gauss_scale(const GaussDispArgs 
 // half-step group would spare.  Up to 8 consecutive steps per launch (grid.y = step): one step is only N
 // lanes of latency-bound work, so batching fills the machine and amortises the launch.  emx_plan_get
 // returns these arrays to the parity tests.
-constexpr int NATIVE_BATCH_MAX = 8;
+#ifndef EMX_NATIVE_BATCH
+#define EMX_NATIVE_BATCH 16     // 8 -> 16: +0.9 % at C2 (the plan kernel's launch is amortised over twice the steps); 32: +0.6 % more for twice the ring memory
+#endif
+constexpr int NATIVE_BATCH_MAX = EMX_NATIVE_BATCH;      // native plans evaluated per k_native_plan_batch launch
 struct NativeBatchArgs {
     NativeArgs nat[NATIVE_BATCH_MAX];
     int32_t* order[NATIVE_BATCH_MAX];
