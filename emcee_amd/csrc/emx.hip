@@ -237,6 +237,18 @@ struct Shape {
     int G, V, CH;
 };
 
+// Layout of a plan slot, the same in the device block and in its pinned staging buffer: [order | p0] int32, [s0 | uacc]
+// f64, [p1 | p2] int32 -- what a stretch step needs (one partner, 24 bytes per walker) is a prefix, so its upload stops
+// there; DE / snooker / Gaussian plans go up whole (32 bytes per walker).  (The device block continues with logu | fac.)
+struct HostPlan {
+    int32_t *order, *p0, *p1, *p2;
+    double *s0, *uacc;
+    HostPlan(char* base, size_t N)
+        : order((int32_t*)base), p0((int32_t*)base + N), p1((int32_t*)(base + N * 24)), p2((int32_t*)(base + N * 24) + N),
+          s0((double*)(base + N * 8)), uacc((double*)(base + N * 8) + N) {}
+};
+inline size_t plan_upload_bytes(size_t N, int move_kind) { return N * (move_kind == EMX_MOVE_STRETCH ? 24 : 32); }
+
 // Row layout for a row of `Dcover` doubles: G lanes x CH chunks x V doubles, chosen to minimise
 // the instructions per walker (few lanes per walker -> short cross-lane reductions, many walkers per
 // pass) while every chunk of a row is still read as whole 128-byte lines (G*V*8 >= 128 B).
@@ -753,11 +765,11 @@ int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
         ALLOC(blk, N * 48);
         s.order = (int32_t*)blk;
         s.p0 = s.order + N;
-        s.p1 = s.p0 + N;
-        s.p2 = s.p1 + N;
-        s.s0 = (double*)(blk + N * 16);
+        s.s0 = (double*)(blk + N * 8);
         s.uacc = s.s0 + N;
-        s.logu = s.uacc + N;
+        s.p1 = (int32_t*)(blk + N * 24);
+        s.p2 = s.p1 + N;
+        s.logu = (double*)(blk + N * 32);
         s.fac = s.logu + N;
         if (hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming) != hipSuccess) {
             g_err = "plan event creation failed";
@@ -1211,8 +1223,9 @@ int emx_accepted_counts(emx_ctx* c, double* out) {
 // ---- stepping ----------------------------------------------------------------------------
 static int upload_plan(emx_ctx* c, emx_ctx::PlanSlot& s) {
     const size_t N = (size_t)c->N;
-    HIPOK(c, hipMemcpyAsync(s.order, s.host, N * 32, hipMemcpyHostToDevice, c->stream));   // same layout on both sides
     const int stretch = c->cur.move >= 0 && c->moves[c->cur.move].kind == EMX_MOVE_STRETCH;
+    HIPOK(c, hipMemcpyAsync(s.order, s.host, plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE),
+                            hipMemcpyHostToDevice, c->stream));   // same layout on both sides
     hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (int)N, (int)c->D, stretch,
                        s.s0, s.uacc, s.logu, s.fac);
     HIPOK(c, hipGetLastError());
@@ -1313,14 +1326,13 @@ static int pipe_start(emx_ctx* c, int64_t nsteps) {
         s.busy = false;
         if (!s.host) HIPOK(c, hipHostMalloc((void**)&s.host, N * 32, hipHostMallocDefault));
         if (!s.uploaded) HIPOK(c, hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
-        int32_t* hi = (int32_t*)s.host;
-        double* hd = (double*)(s.host + N * 16);
-        sinks[r].order = hi;
-        sinks[r].p0 = hi + N;
-        sinks[r].p1 = hi + 2 * N;
-        sinks[r].p2 = hi + 3 * N;
-        sinks[r].s0 = hd;
-        sinks[r].uacc = hd + N;
+        const HostPlan hp(s.host, N);
+        sinks[r].order = hp.order;
+        sinks[r].p0 = hp.p0;
+        sinks[r].p1 = hp.p1;
+        sinks[r].p2 = hp.p2;
+        sinks[r].s0 = hp.s0;
+        sinks[r].uacc = hp.uacc;
     }
     c->pipe_taken = 0;
     c->pipe_uploads.clear();
@@ -1354,8 +1366,9 @@ static int pipe_take(emx_ctx* c) {
     const size_t N = (size_t)c->N;
     // the device copy of this slot was last read by the kernels of step n - PIPE_SINKS
     if (s.busy) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed, 0));
-    HIPOK(c, hipMemcpyAsync(s.order, s.host, N * 32, hipMemcpyHostToDevice, c->up_stream));
     const int stretch = c->moves[cur.move].kind == EMX_MOVE_STRETCH;
+    HIPOK(c, hipMemcpyAsync(s.order, s.host, plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE),
+                            hipMemcpyHostToDevice, c->up_stream));
     hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->up_stream, (int)N, (int)c->D, stretch, s.s0,
                        s.uacc, s.logu, s.fac);
     HIPOK(c, hipGetLastError());
@@ -1402,8 +1415,7 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         cur.slot = c->ring_pos;
         cur.off.assign(cur.S + 1, 0);
         const size_t N = (size_t)c->N;
-        int32_t* hi = (int32_t*)ps->host;
-        double* hd = (double*)(ps->host + N * 16);
+        const HostPlan hp(ps->host, N);
         if (mv.kind == EMX_MOVE_GAUSS) {
             // the normals go through one pinned buffer: wait until the previous step's copy has left it
             if (!c->noise_host) {
@@ -1414,15 +1426,15 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
                 HIPOK(c, hipEventSynchronize(c->noise_ev));
                 c->noise_busy = false;
             }
-            const double f = make_exact_gauss(c->mt, c->N, c->D, mv, c->moves[cur.move].gammas, cur.off.data(), hi, hi + N,
-                                              hi + 2 * N, hi + 3 * N, hd, hd + N, c->noise_host);
+            const double f = make_exact_gauss(c->mt, c->N, c->D, mv, c->moves[cur.move].gammas, cur.off.data(), hp.order, hp.p0,
+                                              hp.p1, hp.p2, hp.s0, hp.uacc, c->noise_host);
             rc = upload_plan(c, *ps);
             if (rc) return rc;
             rc = gauss_upload_normals(c, cur.move, c->noise_host, f, true);
             if (rc) return rc;
         } else {
-            rc = make_exact_plan(c->mt, c->N, c->D, mv, c->labels_scratch, cur.off.data(), hi, hi + N, hi + 2 * N, hi + 3 * N,
-                                 hd, hd + N);
+            rc = make_exact_plan(c->mt, c->N, c->D, mv, c->labels_scratch, cur.off.data(), hp.order, hp.p0, hp.p1, hp.p2, hp.s0,
+                                 hp.uacc);
             NEED(c, rc == 0, "plan generation failed");
             rc = upload_plan(c, *ps);
             if (rc) return rc;
@@ -1518,14 +1530,13 @@ int emx_plan_set(emx_ctx* c, int32_t move_index, const int32_t* off, const int32
     if (rc) return rc;
     cur.slot = c->ring_pos;
     const size_t N = (size_t)c->N;
-    int32_t* hi = (int32_t*)ps->host;
-    double* hd = (double*)(ps->host + N * 16);
-    memcpy(hi, order, N * 4);
-    memcpy(hi + N, p0, N * 4);
-    memcpy(hi + 2 * N, p1 ? p1 : order, N * 4);
-    memcpy(hi + 3 * N, p2 ? p2 : order, N * 4);
-    if (s0) memcpy(hd, s0, N * 8); else memset(hd, 0, N * 8);
-    memcpy(hd + N, uacc, N * 8);
+    const HostPlan hp(ps->host, N);
+    memcpy(hp.order, order, N * 4);
+    memcpy(hp.p0, p0, N * 4);
+    memcpy(hp.p1, p1 ? p1 : order, N * 4);
+    memcpy(hp.p2, p2 ? p2 : order, N * 4);
+    if (s0) memcpy(hp.s0, s0, N * 8); else memset(hp.s0, 0, N * 8);
+    memcpy(hp.uacc, uacc, N * 8);
     return upload_plan(c, *ps);
 }
 
@@ -1550,14 +1561,13 @@ int emx_plan_get(emx_ctx* c, int32_t* off, int32_t* order, int32_t* p0, int32_t*
     }
     NEED(c, cur.slot >= 0, "no plan available");
     auto& ps = c->ring[cur.slot];
-    const int32_t* hi = (const int32_t*)ps.host;
-    const double* hd = (const double*)(ps.host + N * 16);
-    memcpy(order, hi, N * 4);
-    memcpy(p0, hi + N, N * 4);
-    memcpy(p1, hi + 2 * N, N * 4);
-    memcpy(p2, hi + 3 * N, N * 4);
-    memcpy(s0, hd, N * 8);
-    memcpy(uacc, hd + N, N * 8);
+    const HostPlan hp(ps.host, N);
+    memcpy(order, hp.order, N * 4);
+    memcpy(p0, hp.p0, N * 4);
+    memcpy(p1, hp.p1, N * 4);
+    memcpy(p2, hp.p2, N * 4);
+    memcpy(s0, hp.s0, N * 8);
+    memcpy(uacc, hp.uacc, N * 8);
     return 0;
 }
 
@@ -2884,14 +2894,13 @@ int emx_host_plan_mt_stream(emx_mt* m, int64_t N, int32_t D, int32_t nmoves, con
     std::vector<std::vector<char>> stage((size_t)nsinks, std::vector<char>((size_t)N * 32));
     std::vector<PlanSink> sinks((size_t)nsinks);
     for (int r = 0; r < nsinks; ++r) {
-        int32_t* hi = (int32_t*)stage[r].data();
-        double* hd = (double*)(stage[r].data() + (size_t)N * 16);
-        sinks[r].order = hi;
-        sinks[r].p0 = hi + N;
-        sinks[r].p1 = hi + 2 * N;
-        sinks[r].p2 = hi + 3 * N;
-        sinks[r].s0 = hd;
-        sinks[r].uacc = hd + N;
+        const HostPlan hp(stage[r].data(), (size_t)N);
+        sinks[r].order = hp.order;
+        sinks[r].p0 = hp.p0;
+        sinks[r].p1 = hp.p1;
+        sinks[r].p2 = hp.p2;
+        sinks[r].s0 = hp.s0;
+        sinks[r].uacc = hp.uacc;
     }
     const auto t0 = std::chrono::steady_clock::now();
     MtPlanPipeline pipe(m->mt, N, D, nmoves, moves, cdf, nsteps, sinks.data(), nsinks, nworkers);

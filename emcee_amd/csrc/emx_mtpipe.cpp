@@ -96,15 +96,62 @@ CpuSet pipeline_cpus() {
     return r;
 }
 
-void confine(std::thread& t, const CpuSet& cs) {
-    if (cs.valid) pthread_setaffinity_np(t.native_handle(), sizeof(cs.set), &cs.set);
+// One logical CPU per physical core of the set (the lowest SMT sibling), the caller's own core last: generator,
+// tokenizer and finishers each get a core of their own when there are enough -- two of them sharing a core through SMT
+// halves both (the generator and the tokenizer are the critical pair).
+std::vector<int> distinct_cores(const CpuSet& cs) {
+    std::vector<int> reps;
+    if (!cs.valid) return reps;
+    const int self = sched_getcpu();
+    int self_rep = -1;
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &cs.set)) continue;
+        char path[128], buf[256];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        int rep = c;
+        if (FILE* f = fopen(path, "r")) {
+            const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+            fclose(f);
+            buf[n] = 0;
+            cpu_set_t sib;
+            if (parse_cpu_list(buf, sib)) {
+                for (int k = 0; k < CPU_SETSIZE; ++k)
+                    if (CPU_ISSET(k, &sib) && CPU_ISSET(k, &cs.set)) {
+                        rep = k;
+                        break;
+                    }
+                if (self >= 0 && CPU_ISSET(self, &sib)) self_rep = rep;
+            }
+        }
+        if (std::find(reps.begin(), reps.end(), rep) == reps.end()) reps.push_back(rep);
+    }
+    if (self_rep >= 0) {                      // the caller keeps its core to itself as long as there are others
+        auto it = std::find(reps.begin(), reps.end(), self_rep);
+        if (it != reps.end()) {
+            reps.erase(it);
+            reps.push_back(self_rep);
+        }
+    }
+    return reps;
+}
+
+void confine(std::thread& t, const CpuSet& cs, const std::vector<int>& cores, int slot) {
+    if (!cs.valid) return;
+    if ((int)cores.size() >= 3 && slot >= 0) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(cores[(size_t)slot % cores.size()], &one);
+        if (pthread_setaffinity_np(t.native_handle(), sizeof(one), &one) == 0) return;
+    }
+    pthread_setaffinity_np(t.native_handle(), sizeof(cs.set), &cs.set);
 }
 #else
 struct CpuSet {
     bool valid = false;
 };
 CpuSet pipeline_cpus() { return CpuSet(); }
-void confine(std::thread&, const CpuSet&) {}
+std::vector<int> distinct_cores(const CpuSet&) { return {}; }
+void confine(std::thread&, const CpuSet&, const std::vector<int>&, int) {}
 #endif
 
 struct Backoff {
@@ -154,6 +201,79 @@ EMX_CLONES void temper_block(const uint32_t* __restrict k, uint32_t* __restrict 
     }
 }
 
+#if defined(__x86_64__) && defined(__clang__)
+#include <immintrin.h>
+#define EMX_HAVE_AVX512_GEN 1
+// The whole block in registers: 39 vectors of 16 words.  Word kk of the new block needs new word kk - 227 (for
+// kk >= 227), i.e. a vector that starts 13 words into new vector i - 15: instead of storing the new words and
+// re-loading them unaligned (a load that straddles two just-issued stores cannot be forwarded and waits for both to
+// retire -- the dependency that holds the auto-vectorised loops at 0.16 ns/word), the last 15 result vectors stay in
+// registers and the straddling vector is made with one valignd.  Tempering happens on the way out.
+__attribute__((target("avx512f"))) void twist_temper_avx512(const uint32_t* __restrict o, uint32_t* __restrict n,
+                                                            uint32_t* __restrict out) {
+    const __m512i UPPER = _mm512_set1_epi32((int)0x80000000u), ONE = _mm512_set1_epi32(1),
+                  MATRIX = _mm512_set1_epi32((int)0x9908b0dfu), TB = _mm512_set1_epi32((int)0x9d2c5680u),
+                  TC = _mm512_set1_epi32((int)0xefc60000u);
+    __m512i N[39];
+    const __m512i Olast = _mm512_loadu_si512(o + 608);
+#pragma unroll
+    for (int i = 0; i < 39; ++i) {
+        const __m512i cur = _mm512_loadu_si512(o + 16 * i);
+        __m512i nxt;
+        if (i < 38)
+            nxt = _mm512_loadu_si512(o + 16 * i + 1);
+        else
+            nxt = _mm512_alignr_epi32(N[0], cur, 1);                      // word 623 pairs with the NEW word 0
+        __m512i m;
+        if (i <= 13)
+            m = _mm512_loadu_si512(o + 16 * i + 397);                     // old words kk + 397
+        else if (i == 14)
+            m = _mm512_alignr_epi32(N[0], Olast, 13);                     // old 621..623, then new 0..12
+        else
+            m = _mm512_alignr_epi32(N[i - 14], N[i - 15], 13);            // new words kk - 227
+        // y = (cur & UPPER) | (nxt & LOWER);  r = m ^ (y >> 1) ^ (y & 1 ? MATRIX : 0)   (y & 1 == nxt & 1)
+        const __m512i y = _mm512_ternarylogic_epi32(UPPER, cur, nxt, 0xCA);    // UPPER ? cur : nxt, bitwise
+        __m512i r = _mm512_xor_si512(m, _mm512_srli_epi32(y, 1));
+        const __mmask16 odd = _mm512_test_epi32_mask(nxt, ONE);
+        r = _mm512_mask_xor_epi32(r, odd, r, MATRIX);
+        N[i] = r;
+        _mm512_storeu_si512(n + 16 * i, r);
+        __m512i t = _mm512_xor_si512(r, _mm512_srli_epi32(r, 11));
+        t = _mm512_xor_si512(t, _mm512_and_si512(_mm512_slli_epi32(t, 7), TB));
+        t = _mm512_xor_si512(t, _mm512_and_si512(_mm512_slli_epi32(t, 15), TC));
+        t = _mm512_xor_si512(t, _mm512_srli_epi32(t, 18));
+        _mm512_storeu_si512(out + 16 * i, t);
+    }
+}
+#endif
+
+// one generator step: new state words and their tempered outputs
+using TwistFn = void (*)(const uint32_t*, uint32_t*, uint32_t*);
+void twist_temper_generic(const uint32_t* o, uint32_t* n, uint32_t* out) {
+    twist_block(o, n);
+    temper_block(n, out);
+}
+
+// the register-resident AVX-512 version where the CPU has it and it reproduces the generic one on a test block
+TwistFn pick_twist() {
+#ifdef EMX_HAVE_AVX512_GEN
+    if (__builtin_cpu_supports("avx512f") && !getenv("EMX_PIPE_NO_AVX512")) {
+        alignas(64) uint32_t o[BLK + 16], a[BLK + 16], b[BLK + 16], ta[BLK], tb[BLK];
+        uint32_t x = 0x9e3779b9u;
+        for (int i = 0; i < BLK + 16; ++i) {
+            x ^= x << 13;
+            x ^= x >> 17;
+            x ^= x << 5;
+            o[i] = x;
+        }
+        twist_temper_generic(o, a, ta);
+        twist_temper_avx512(o, b, tb);
+        if (!std::memcmp(a, b, BLK * 4) && !std::memcmp(ta, tb, BLK * 4)) return twist_temper_avx512;
+    }
+#endif
+    return twist_temper_generic;
+}
+
 // random_sample() of consecutive word pairs
 EMX_CLONES void convert_pairs(const uint32_t* __restrict w, double* __restrict dst, int64_t n) {
     for (int64_t e = 0; e < n; ++e) {
@@ -171,6 +291,28 @@ EMX_CLONES void convert_pairs_zz(const uint32_t* __restrict w, double* __restric
         dst[e] = tt * tt / a;
     }
 }
+
+#ifdef EMX_HAVE_AVX512_GEN
+// Fisher-Yates targets, 16 stream words at a time.  Word k of a vector is accepted iff v_k <= i - (accepted before it): a
+// word <= i - 16 is accepted and a word > i rejected whatever the others do, and that is nearly every word (the rest,
+// 16 values out of the mask range, send the vector to the scalar loop).  Accepted values are compressed in stream order
+// into jr[(n - 1) - i ...]: the reversed layout makes their addresses ascend.  Returns the words consumed.
+__attribute__((target("avx512f"))) size_t shuffle_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i,
+                                                              int64_t lo, uint32_t* jr, int64_t nm1) {
+    const __m512i vmask = _mm512_set1_epi32((int)mask);
+    size_t used = 0;
+    while (navail - used >= 16 && i - 16 > lo) {
+        const __m512i v = _mm512_and_si512(_mm512_loadu_si512(p + used), vmask);
+        const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)(i - 16)));
+        const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)i));
+        if ((__mmask16)(acc | rej) != (__mmask16)0xffff) break;             // a word in (i - 16, i]: order matters, scalar
+        _mm512_storeu_si512(jr + (nm1 - i), _mm512_maskz_compress_epi32(acc, v));       // 16 slots of slack behind jr
+        i -= (int64_t)__builtin_popcount((unsigned)acc);
+        used += 16;
+    }
+    return used;
+}
+#endif
 
 // inverse of MT19937's output tempering: the generator state words behind a block of outputs
 inline uint32_t untemper(uint32_t y) {
@@ -197,8 +339,10 @@ struct WordStream {
 
 void generator_main(WordStream* ws, const uint32_t* start_key) {
     // block 0 is the block the caller's generator currently stands in (no twist)
-    alignas(64) uint32_t key[2][BLK];
+    alignas(64) uint32_t key[2][BLK + 16];          // + 16: the vector version reads one vector past word 607 + 1
+    std::memset(key, 0, sizeof(key));
     std::memcpy(key[0], start_key, BLK * 4);
+    const TwistFn twist_temper = pick_twist();
     temper_block(key[0], &ws->ring[0]);
     ws->produced.store(1, std::memory_order_release);
     Backoff bo;
@@ -213,8 +357,7 @@ void generator_main(WordStream* ws, const uint32_t* start_key) {
         ws->gen_blocks = b;
         const uint32_t* prev = key[(b - 1) & 1];
         uint32_t* cur = key[b & 1];
-        twist_block(prev, cur);
-        temper_block(cur, &ws->ring[(b % NBLK) * BLK]);
+        twist_temper(prev, cur, &ws->ring[(b % NBLK) * BLK]);
         ws->produced.store(b + 1, std::memory_order_release);
         ++b;
     }
@@ -394,11 +537,13 @@ struct Reader {
             cur = p;
         }
     }
-    // RandomState.shuffle of n items: the accepted swap target of every i = n-1 .. 1
-    void shuffle_targets(uint32_t* j, int64_t n) {
+    // RandomState.shuffle of n items: the accepted swap target of every i = n-1 .. 1, stored as jr[(n - 1) - i]
+    // (jr has 16 slots of slack)
+    void shuffle_targets(uint32_t* jr, int64_t n, bool vec) {
+        const int64_t nm1 = n - 1;
         int64_t i = n - 1;
         while (i > 0 && (uint64_t)i > 0xffffffffull) {
-            j[i] = (uint32_t)random_interval((uint64_t)i);     // unreachable for int32 walker counts
+            jr[nm1 - i] = (uint32_t)random_interval((uint64_t)i);     // unreachable for int32 walker counts
             --i;
         }
         while (i > 0 && !dead) {
@@ -413,19 +558,39 @@ struct Reader {
                 const size_t av = avail();
                 const uint32_t* p = cur;
                 const uint32_t* pe = cur + av;
-                while (p < pe && i > lo) {
+#ifdef EMX_HAVE_AVX512_GEN
+                if (vec) p += shuffle_scan_avx512(p, av, mask, i, lo, jr, nm1);
+#endif
+                int budget = 16;                                // one vector's worth, then the fast path is tried again
+                while (p < pe && i > lo && budget-- > 0) {
                     const uint32_t v = *p++ & mask;
-                    j[i] = v;                                   // a rejected draw is overwritten by the next one
+                    jr[nm1 - i] = v;                            // a rejected draw is overwritten by the next one
                     i -= (int64_t)(v <= (uint32_t)i);
                 }
                 cur = p;
             }
         }
+        (void)vec;
+    }
+    // n raw stream words, verbatim (fixed-length draws are converted by the finishers)
+    void copy_words(uint32_t* dst, int64_t n) {
+        int64_t k = 0;
+        while (k < n && !dead) {
+            const int64_t take = std::min<int64_t>((int64_t)avail(), n - k);
+            std::memcpy(dst + k, cur, (size_t)take * 4);
+            cur += take;
+            k += take;
+        }
     }
 };
 
+// randint(0, bound) draws exactly one word per value when bound is a power of two (the mask rejects nothing)
+inline bool pow2_bound(uint64_t bound) { return bound >= 2 && bound <= 0x80000000ull && (bound & (bound - 1)) == 0; }
+
 struct RawStep {               // tokens of one step that do not already sit in the plan sink
-    std::vector<uint32_t> j;   // Fisher-Yates targets
+    std::vector<uint32_t> j;   // Fisher-Yates targets, reversed: j[(N - 1) - i] for i = N-1 .. 1 (+ 16 slots of slack)
+    std::vector<uint32_t> wz, wr, wu;   // raw stream words of the fixed-length draws, converted by the finisher: rand(Ns) of the
+                                        // stretch factor (2 per walker), power-of-two randint (1), the accept uniforms (2)
     std::vector<uint64_t> k64; // DE: pair codes (de.py:49)
     std::vector<double> gx, gr2;  // DE: polar-method tokens of randn (de.py:56): normal = gx * sqrt(-2 ln r2 / r2), r2 < 0: gx itself
     std::vector<uint8_t> perm; // snooker: shuffle(w) draws, j2 | j1 << 2
@@ -457,6 +622,8 @@ struct MtPlanPipeline::Impl {
     std::vector<std::thread> fin;
     bool joined = false;
     uint64_t t_start = 0, tok_wait_sink_ns = 0, tok_done_ns = 0;
+    bool vec_scan = false, stats = false, fill_unused = false;
+    uint64_t tok_shuffle_ns = 0;
     std::vector<uint64_t> fin_wait_ns, fin_busy_ns;
 
     void tokenizer_main();
@@ -476,7 +643,8 @@ bool MtPlanPipeline::supports(int32_t nmoves, const emx_move_desc* moves) {
 }
 
 MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves,
-                               const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers)
+                               const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers,
+                               bool fill_unused_fields)
     : impl_(new Impl()) {
     Impl& m = *impl_;
     m.N = N;
@@ -489,7 +657,7 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     int K = nworkers;
     if (K <= 0) {
         const unsigned hw = std::thread::hardware_concurrency();
-        K = hw >= 8 ? 3 : hw >= 4 ? 2 : 1;       // three finishers keep up with the tokenizer (tools/mt_pipe_bench.py)
+        K = hw >= 16 ? 4 : hw >= 8 ? 3 : hw >= 4 ? 2 : 1;       // four finishers keep up with the tokenizer (tools/mt_pipe_bench.py)
     }
     K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(K, nsinks), nsteps));
     m.K = K;
@@ -498,14 +666,20 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     m.start = start;
     m.ws.ring.resize(NBLK * BLK);
     m.raws.resize(m.NR);
-    bool any_shuffle = false, any_de = false, any_sn = false;
+    bool any_shuffle = false, any_de = false, any_sn = false, any_stretch = false;
     for (auto& mv : m.moves) {
         any_shuffle |= mv.randomize_split != 0;
+        any_stretch |= mv.kind == EMX_MOVE_STRETCH;
         any_de |= mv.kind == EMX_MOVE_DE;
         any_sn |= mv.kind == EMX_MOVE_SNOOKER;
     }
     for (auto& r : m.raws) {
-        if (any_shuffle) r.j.resize((size_t)N);
+        if (any_shuffle) r.j.resize((size_t)N + 16);
+        r.wu.resize((size_t)2 * N);
+        if (any_stretch) {
+            r.wz.resize((size_t)2 * N);
+            r.wr.resize((size_t)N);
+        }
         if (any_de) {
             r.k64.resize((size_t)N);
             r.gx.resize((size_t)N);
@@ -523,17 +697,23 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
         m.raw_done[s].v.store((int64_t)s - m.NR);     // "step s - NR is done": slot s is free for step s
     }
     for (int s = 0; s < nsinks; ++s) m.sink_ready[s].v.store(-1);
+#ifdef EMX_HAVE_AVX512_GEN
+    m.vec_scan = __builtin_cpu_supports("avx512f") && !getenv("EMX_PIPE_NO_AVX512");
+#endif
+    m.stats = getenv("EMX_PIPE_STATS") != nullptr;
+    m.fill_unused = fill_unused_fields;
     m.fin_wait_ns.assign(K, 0);
     m.fin_busy_ns.assign(K, 0);
     m.t_start = now_ns();
     const CpuSet cs = pipeline_cpus();
+    const std::vector<int> cores = getenv("EMX_PIPE_NO_CORE_PINNING") ? std::vector<int>() : distinct_cores(cs);
     m.gen = std::thread(generator_main, &m.ws, m.start.key);
-    confine(m.gen, cs);
+    confine(m.gen, cs, cores, 0);
     m.tok = std::thread([&m] { m.tokenizer_main(); });
-    confine(m.tok, cs);
+    confine(m.tok, cs, cores, 1);
     for (int k = 0; k < K; ++k) {
         m.fin.emplace_back([&m, k] { m.finisher_main(k); });
-        confine(m.fin.back(), cs);
+        confine(m.fin.back(), cs, cores, (int)cores.size() >= 3 + k ? 2 + k : -1);     // out of cores: anywhere in the L3 domain
     }
 }
 
@@ -551,9 +731,9 @@ void MtPlanPipeline::Impl::join_all() {
     if (getenv("EMX_PIPE_STATS")) {
         const double tot = (now_ns() - t_start) * 1e-6;
         fprintf(stderr, "[emx pipe] N=%lld steps=%lld workers=%d: %.3f ms total; generator %llu blocks, waited %.3f ms for space; tokenizer finished at "
-                        "%.3f ms, waited %.3f ms for words and %.3f ms for sinks/raw slots;",
+                        "%.3f ms (shuffle scans %.3f ms), waited %.3f ms for words and %.3f ms for sinks/raw slots;",
                 (long long)N, (long long)nsteps, K, tot, (unsigned long long)ws.gen_blocks, ws.gen_wait_ns * 1e-6, tok_done_ns * 1e-6,
-                ws.rd_wait_ns * 1e-6, tok_wait_sink_ns * 1e-6);
+                tok_shuffle_ns * 1e-6, ws.rd_wait_ns * 1e-6, tok_wait_sink_ns * 1e-6);
         for (int k = 0; k < K; ++k) fprintf(stderr, " fin%d busy %.3f wait %.3f;", k, fin_busy_ns[k] * 1e-6, fin_wait_ns[k] * 1e-6);
         fprintf(stderr, "\n");
     }
@@ -590,12 +770,17 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
     for (int s = 0; s < S; ++s) info.off[s + 1] = info.off[s] + (int32_t)((N - s + S - 1) / S);   // label counts survive the shuffle
     RawStep& raw = raws[n % NR];
     const PlanSink& sk = sinks[n % nsinks];
-    if (mv.randomize_split) rd.shuffle_targets(raw.j.data(), N);                                  // red_blue.py:80
+    const uint64_t ts0 = stats ? now_ns() : 0;
+    if (mv.randomize_split) rd.shuffle_targets(raw.j.data(), N, vec_scan);                        // red_blue.py:80
+    if (stats) tok_shuffle_ns += now_ns() - ts0;
     for (int split = 0; split < S && !rd.dead; ++split) {
         const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
         if (mv.kind == EMX_MOVE_STRETCH) {
-            rd.fill_doubles(sk.s0 + base, ns, mv.a);                                               // stretch.py:30
-            rd.fill_randint32(sk.p0 + base, ns, (uint64_t)nc);                                     // stretch.py:32 (complement index)
+            rd.copy_words(raw.wz.data() + 2 * base, 2 * ns);                                       // stretch.py:30 rand(Ns): fixed length
+            if (pow2_bound((uint64_t)nc))                                                          // stretch.py:32 randint(Nc, Ns):
+                rd.copy_words(raw.wr.data() + base, ns);                                           //   no rejection: fixed length too
+            else
+                rd.fill_randint32(sk.p0 + base, ns, (uint64_t)nc);                                 //   rejection decides the position
         } else if (mv.kind == EMX_MOVE_DE) {
             const uint64_t pop = (uint64_t)nc * (uint64_t)(nc - 1);
             for (int64_t t = 0; t < ns; ++t) raw.k64[base + t] = rd.randint(pop);                  // de.py:49
@@ -644,7 +829,7 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
                 raw.perm[base + t] = (uint8_t)(j2 | (j1 << 2));
             }
         }
-        rd.fill_doubles(sk.uacc + base, ns);                                                       // red_blue.py:100
+        rd.copy_words(raw.wu.data() + 2 * base, 2 * ns);                                           // red_blue.py:100 rand() x Ns
     }
 }
 
@@ -694,9 +879,9 @@ void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) 
     uint8_t* x = labels.data();
     for (int64_t i = 0; i < N; ++i) x[i] = (uint8_t)(i % S);                 // red_blue.py:78
     if (mv.randomize_split) {
-        const uint32_t* j = raw.j.data();
+        const uint32_t* jr = raw.j.data();
         for (int64_t i = N - 1; i > 0; --i) {                               // red_blue.py:80 (the swaps of RandomState.shuffle)
-            const uint32_t jj = j[i];
+            const uint32_t jj = jr[(N - 1) - i];
             const uint8_t t = x[i];
             x[i] = x[jj];
             x[jj] = t;
@@ -710,11 +895,19 @@ void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) 
     for (int split = 0; split < S; ++split) {
         const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
         auto comp = [&](uint64_t r) -> int32_t { return (int64_t)r < base ? order[r] : order[r + ns]; };   // stretch.py:27
+        convert_pairs(raw.wu.data() + 2 * base, sk.uacc + base, ns);                             // red_blue.py:100
         if (mv.kind == EMX_MOVE_STRETCH) {
-            for (int64_t t = 0; t < ns; ++t) {
-                sk.p0[base + t] = comp((uint32_t)sk.p0[base + t]);
-                sk.p1[base + t] = sk.p2[base + t] = order[base + t];
+            convert_pairs_zz(raw.wz.data() + 2 * base, sk.s0 + base, ns, mv.a);                    // stretch.py:30
+            if (pow2_bound((uint64_t)nc)) {
+                const uint32_t msk = (uint32_t)(nc - 1);
+                const uint32_t* wr = raw.wr.data() + base;
+                for (int64_t t = 0; t < ns; ++t) sk.p0[base + t] = (int32_t)(wr[t] & msk);
             }
+            // p1 / p2 carry no information for a stretch step (one partner): the kernels never read them and the upload
+            // stops before them; they are filled only for consumers that compare whole plans (fill_unused)
+            if (fill_unused)
+                for (int64_t t = 0; t < ns; ++t) sk.p1[base + t] = sk.p2[base + t] = order[base + t];
+            for (int64_t t = 0; t < ns; ++t) sk.p0[base + t] = comp((uint32_t)sk.p0[base + t]);
         } else if (mv.kind == EMX_MOVE_DE) {
             for (int64_t t = 0; t < ns; ++t) {
                 uint64_t f, s;

@@ -61,7 +61,8 @@ class MtPlanPipeline {
     // `sinks`: nsinks staging buffers used round-robin (step n -> sinks[n % nsinks]); a sink is rewritten only after
     // release(n - nsinks).  moves must all be stretch / DE / snooker.  nworkers <= 0: chosen from the core count.
     MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves,
-                   const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers);
+                   const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers,
+                   bool fill_unused_fields = false);      // true: a stretch plan's p1 / p2 are set to the walker itself
     ~MtPlanPipeline();
     MtPlanPipeline(const MtPlanPipeline&) = delete;
     MtPlanPipeline& operator=(const MtPlanPipeline&) = delete;

@@ -11,6 +11,15 @@ int main(){
   for(int r=0;r<R;r+=2){ twist_block(a.data(),b.data()); temper_block(b.data(),o.data()); twist_block(b.data(),a.data()); temper_block(a.data(),o.data()); }
   double dt=std::chrono::duration<double>(std::chrono::steady_clock::now()-t0).count();
   printf("gen: %.3f ns/word (%u)\n", dt*1e9/(R*624.0), o[5]);
+  {
+    TwistFn f = pick_twist();
+    std::vector<uint32_t> ka(640, 1u), kb(640), oo(640);
+    for (int i = 0; i < 624; i++) ka[i] = i * 2654435761u;
+    t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < R; r += 2) { f(ka.data(), kb.data(), oo.data()); f(kb.data(), ka.data(), oo.data()); }
+    dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("gen (%s): %.3f ns/word (%u)\n", f == twist_temper_generic ? "generic" : "avx512 register window", dt * 1e9 / (R * 624.0), oo[5]);
+  }
   // tokenizer-like loops over a big static buffer
   std::vector<uint32_t> w(1<<22); for(size_t i=0;i<w.size();i++) w[i]=(uint32_t)(i*2654435761u ^ (i>>3)*40503u);
   std::vector<double> d(1<<21);
