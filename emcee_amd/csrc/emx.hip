@@ -558,7 +558,10 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         // 8-wave workgroups halve the number of LDS image copies; below ~2048 tiles 4-wave groups spread
         // the few tiles over more CUs (tools/nsweep.py)
         const int64_t ntiles = (nown + spw - 1) / spw;
-        waves_per_block = c->tune_wpb > 0 ? (int)c->tune_wpb : (ntiles >= 2048 ? 8 : 4);
+        // ... except for the Gaussian Metropolis move, whose single launch covers the whole ensemble (4 tiles per SIMD at
+        // 65 536 walkers): two co-resident 4-wave groups per CU, two tiles per wave, overlap better than one 8-wave group
+        // (24.0 vs 26.5 us/step, tools/wpb_sweep.py)
+        waves_per_block = c->tune_wpb > 0 ? (int)c->tune_wpb : (ntiles >= 2048 && move != MOVE_GAUSS ? 8 : 4);
         while (waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
         lds = dense_lds_bytes(c->Dp, waves_per_block);
         if (lds > 160 * 1024) {

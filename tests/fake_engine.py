@@ -153,3 +153,89 @@ class FakePullEngine(FakeEngine):
             self.chain.append(self.X.copy())
             self.chain_lp.append(self.lp.copy())
             self.acc_count[self.lo: self.hi] += self.acc[self.lo: self.hi]
+
+
+class FakeDirectEngine(FakePullEngine):
+    """The direct exchange on the NumPy double: every rank's coordinate array and barrier flags live in POSIX shared
+    memory (the CPU stand-in for hipIpc-mapped HBM); a half-step reads partner rows from the segment of the rank that
+    owns them, and a flag barrier (store the epoch into every peer's flag array, spin on the own one) is the only
+    synchronisation between the processes inside a step -- the protocol of emx_direct_halfstep / k_peer_barrier."""
+
+    def __init__(self, *a, **kw):
+        from multiprocessing import shared_memory
+        tag = kw.pop("tag")
+        super().__init__(*a, **kw)
+        self._shm_x = shared_memory.SharedMemory(create=True, size=self.N * self.D * 8, name="emx_%s_x%d" % (tag, self.rank))
+        self._shm_f = shared_memory.SharedMemory(create=True, size=8 * 8, name="emx_%s_f%d" % (tag, self.rank))
+        x = np.ndarray((self.N, self.D), dtype=np.float64, buffer=self._shm_x.buf)
+        x[:] = self.X
+        self.X = x                                            # the replica itself is what the peers map
+        self.flags = np.ndarray(8, dtype=np.int64, buffer=self._shm_f.buf)
+        self.flags[:] = 0
+        self.epoch = 0
+        self.peers, self._attached = {}, []
+
+    # the two calls emcee_amd.parallel.import_direct_peers makes on a DeviceEnsemble
+    def direct_export(self):
+        h = np.zeros(128, dtype=np.uint8)
+        for o, name in ((0, self._shm_x.name), (64, self._shm_f.name)):
+            b = name.encode()
+            h[o:o + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        return h
+
+    def direct_import(self, handles):
+        from multiprocessing import shared_memory
+        h = np.asarray(handles, dtype=np.uint8).reshape(self.world, 128)
+        for q in range(self.world):
+            if q == self.rank:
+                self.peers[q] = (self.X, self.flags)
+                continue
+            names = [bytes(h[q, o:o + 64]).rstrip(b"\0").decode() for o in (0, 64)]
+            sx, sf = shared_memory.SharedMemory(name=names[0]), shared_memory.SharedMemory(name=names[1])
+            self._attached += [sx, sf]
+            self.peers[q] = (np.ndarray((self.N, self.D), dtype=np.float64, buffer=sx.buf),
+                             np.ndarray(8, dtype=np.int64, buffer=sf.buf))
+
+    def _barrier(self, timeout=60.0):
+        import time
+        self.epoch += 1
+        for q in range(self.world):
+            if q != self.rank:
+                self.peers[q][1][self.rank] = self.epoch       # "my previous half-step is complete"
+        t0 = time.time()
+        while any(self.flags[q] < self.epoch for q in range(self.world) if q != self.rank):
+            if time.time() - t0 > timeout:
+                raise RuntimeError("direct exchange: a peer never reached the barrier")
+            time.sleep(0)
+
+    def direct_halfstep(self, split, barrier=True):
+        if barrier:
+            self._barrier()
+        off = self.plan["off"]
+        sl = slice(off[split], off[split + 1])
+        mine = np.nonzero(block_owner(self.plan["order"][sl], self.N, self.world) == self.rank)[0] + off[split]
+        sub = {k: v[mine] for k, v in self.plan.items() if k != "off"}
+        sub["off"] = np.array([0, len(mine)])
+        # partner rows come from the replica of the rank that owns them (own rows from the own replica)
+        view = np.array(self.X, copy=True)
+        for j in range(self.NPART[self.move.kind]):
+            pj = sub["p%d" % j]
+            own = block_owner(pj, self.N, self.world)
+            for q in range(self.world):
+                if q != self.rank:
+                    rows = pj[own == q]
+                    view[rows] = self.peers[q][0][rows]
+        idx = sub["order"]
+        acc = so.propose_planned(view, self.lp, self.lp_fn, sub, self.move)
+        self.X[idx] = view[idx]
+        self.acc[idx] = acc[idx]
+
+    def close(self):
+        self.peers = {}
+        x = np.array(self.X, copy=True)
+        self.X, self.flags = x, None
+        for s in self._attached:
+            s.close()
+        for s in (self._shm_x, self._shm_f):
+            s.close()
+            s.unlink()

@@ -123,6 +123,65 @@ def test_pull_protocol_over_gloo(name, world):
         assert np.array_equal(acc, acc_total)
 
 
+def _direct_worker(rank, world, port, name, nst, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from emcee_amd.parallel import import_direct_peers
+    from fake_engine import FakeDirectEngine
+    from helpers import load_golden, rng_from_fixture
+    from oracle import cases
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden(name)
+    spec = cases.build(name)
+    eng = FakeDirectEngine(g["p0"], cases.make_target(spec["desc"]), spec["moves"], spec["weights"],
+                           rng_from_fixture(g).get_state(), rank, world, tag="%d" % port)
+    import_direct_peers(eng, dist)             # the product's handle exchange: 128 bytes per rank over the host group
+    dist.barrier()
+    for _ in range(nst):
+        k, S = eng.step_begin(True)
+        for split in range(S):
+            eng.direct_halfstep(split, barrier=True)      # no collective inside the loop: flags in shared memory only
+        eng.step_end()
+    eng._barrier()                             # everybody has finished reading before anybody unmaps
+    q.put((rank, eng.lo, eng.hi, np.stack(eng.chain), np.stack(eng.chain_lp)))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("stretch_50x3_iso", 2), ("mix_de_snooker_128x8_dense", 2),
+                                        ("stretch_nsplits3_45x2", 3)])
+def test_direct_protocol_between_processes(name, world):
+    """Direct exchange, control plane and hazards, without a GPU: the ranks' replicas and barrier flags are shared-memory
+    segments mapped through emcee_amd.parallel.import_direct_peers; inside the step loop the processes meet only at the
+    flag barrier.  Every rank's block of the chain equals the single-rank oracle chain."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    from helpers import load_golden
+    g = load_golden(name)
+    nst = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, name, nst, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, lo, hi, chain, lp in res:
+        if "snooker" not in name:
+            assert np.array_equal(chain[:, lo:hi], g["chain"][:nst, lo:hi]), "rank %d diverged" % rank
+        else:
+            np.testing.assert_allclose(chain[:, lo:hi], g["chain"][:nst, lo:hi], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(lp[:, lo:hi], g["log_prob"][:nst, lo:hi], rtol=1e-12)
+
+
 def test_pull_capacity_mirror_and_bounds():
     """The Python mirror equals the library's capacity; the capacity never exceeds what a pair can need and
     stays within ~15 % of the mean at bench scale."""
