@@ -583,6 +583,9 @@ def run_child(args, key, ex, port, timeout_s):
     return {"error": "child exited with code %d and no result" % r.returncode}
 
 
+_CHILDREN_RUN = []
+
+
 def sharded_config(key, world, K, rank, dist, args, port0, skip):
     """Every exchange protocol on one workload, each in its own child process per rank; the fastest whose final ensemble
     agrees on all ranks (and with the first protocol's) is reported.  `skip`: protocols that already failed on an earlier
@@ -594,7 +597,10 @@ def sharded_config(key, world, K, rank, dist, args, port0, skip):
         if ex in skip:
             errors[ex] = "skipped: failed on an earlier configuration (%s)" % skip[ex]
             continue
-        r = run_child(args, key, ex, port0 + n, args.exchange_timeout)
+        # the very first child also pays for cold caches (kernel modules, code objects, a slower first torch import)
+        first = not _CHILDREN_RUN
+        _CHILDREN_RUN.append((key, ex))
+        r = run_child(args, key, ex, port0 + n, args.exchange_timeout + (180.0 if first else 0.0))
         ok = r.get("error") is None and "wall_s" in r
         if not torch_all_ok(dist, ok):             # the parents' own gloo group: CPU only
             errors[ex] = r.get("error") or "failed on another rank"
