@@ -387,6 +387,7 @@ struct emx_ctx {
     bool peer_ipc_x[EMX_MAX_PEERS] = {}, peer_ipc_f[EMX_MAX_PEERS] = {};   // opened with hipIpcOpenMemHandle (to be closed)
     unsigned long long* my_flags = nullptr;   // [EMX_MAX_PEERS], fine-grained device memory when available
     bool peers_ready = false;
+    PeerTable* peer_table = nullptr;          // device copy of (peerX, block starts) for the half-step kernel
     unsigned long long direct_epoch = 0;
     int32_t* direct_counts = nullptr;         // [64]: owned slots per split of the step begun
     bool direct_planned = false;              // k_own_plan has run for the step begun
@@ -627,10 +628,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     }
     if (c->exchange == EMX_EXCHANGE_DIRECT && c->peers_ready && c->world > 1 && move != MOVE_EVAL && X == c->X) {
         a.npeer = c->world;
-        for (int q = 0; q < c->world; ++q) {
-            a.peerX[q] = c->peerX[q];
-            a.peer_lo[q] = (int32_t)(c->N * q / c->world);
-        }
+        a.peers = c->peer_table;
     }
     {
         static const int skew_sleep = getenv("EMX_SKEW_SLEEP") ? atoi(getenv("EMX_SKEW_SLEEP")) : 0;     // kernel experiments only
@@ -855,6 +853,7 @@ int emx_destroy(emx_ctx* c) {
     for (auto e : c->prof) hipEventDestroy(e);
     direct_detach(c);
     if (c->my_flags) hipFree(c->my_flags);
+    if (c->peer_table) hipFree(c->peer_table);
     if (c->direct_counts) hipFree(c->direct_counts);
     if (c->pipe) delete c->pipe, c->pipe = nullptr;
     if (c->up_stream) hipStreamDestroy(c->up_stream);
@@ -2524,6 +2523,18 @@ static int direct_ensure(emx_ctx* c) {
     return 0;
 }
 
+static int direct_publish_table(emx_ctx* c) {
+    PeerTable t{};
+    for (int q = 0; q < c->world; ++q) {
+        t.X[q] = c->peerX[q];
+        t.lo[q] = (int32_t)(c->N * q / c->world);
+    }
+    if (!c->peer_table) HIPOK(c, hipMalloc((void**)&c->peer_table, sizeof(PeerTable)));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    HIPOK(c, hipMemcpy(c->peer_table, &t, sizeof(t), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int emx_direct_export(emx_ctx* c, uint8_t handles[128]) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, c->exchange == EMX_EXCHANGE_DIRECT, "emx_direct_export needs emx_set_exchange(EMX_EXCHANGE_DIRECT)");
@@ -2563,7 +2574,7 @@ int emx_direct_import(emx_ctx* c, const uint8_t* handles) {
         c->peer_ipc_f[q] = true;
     }
     c->peers_ready = true;
-    return 0;
+    return direct_publish_table(c);
 }
 
 int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_flags) {
@@ -2577,7 +2588,7 @@ int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_fl
         NEED(c, c->peerX[q], "emx_direct_attach: no coordinate array for rank %d", q);
     }
     c->peers_ready = true;
-    return 0;
+    return direct_publish_table(c);
 }
 
 int emx_direct_halfstep(emx_ctx* c, int32_t split, int32_t barrier) {

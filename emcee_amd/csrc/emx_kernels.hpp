@@ -130,18 +130,23 @@ struct HalfStepArgs {
     // direct exchange (walker-block ownership, the peers' coordinate arrays mapped into this device's address space):
     // a partner row is read from the replica of the rank that owns it, i.e. over xGMI from that GPU's HBM.  npeer = 0:
     // one replica (everything else).  peer_lo is ascending; own entry of peerX == X.
-    const double* peerX[EMX_MAX_PEERS];
-    int32_t peer_lo[EMX_MAX_PEERS];
+    const struct PeerTable* peers;     // device memory (not kernel arguments: 24 scalar registers the single-GPU path never needs)
     int32_t npeer;
     int32_t skew_sleep;            // EMX_OPT_SKEW experiments: extra delay of the staging waves, in s_sleep(8) units (0 in production)
 };
 
-// coordinate array holding the current row of walker j (block ownership: rank q owns [peer_lo[q], peer_lo[q + 1]))
+struct PeerTable {
+    const double* X[EMX_MAX_PEERS];
+    int32_t lo[EMX_MAX_PEERS];
+};
+
+// coordinate array holding the current row of walker j (block ownership: rank q owns [lo[q], lo[q + 1]))
 __device__ __forceinline__ const double* partner_base(const HalfStepArgs& A, int j) {
     if (A.npeer == 0) return A.X;                   // launch-uniform
-    const double* b = A.peerX[0];
+    const PeerTable* __restrict__ T = A.peers;      // uniform address: scalar loads
+    const double* b = T->X[0];
 #pragma unroll
-    for (int q = 1; q < EMX_MAX_PEERS; ++q) b = (q < A.npeer && j >= A.peer_lo[q]) ? A.peerX[q] : b;
+    for (int q = 1; q < EMX_MAX_PEERS; ++q) b = (q < A.npeer && j >= T->lo[q]) ? T->X[q] : b;
     return b;
 }
 
