@@ -141,8 +141,9 @@ struct PeerTable {
 };
 
 // coordinate array holding the current row of walker j (block ownership: rank q owns [lo[q], lo[q + 1]))
+template <bool LEAN>
 __device__ __forceinline__ const double* partner_base(const HalfStepArgs& A, int j) {
-    if (A.npeer == 0) return A.X;                   // launch-uniform
+    if (LEAN || A.npeer == 0) return A.X;           // launch-uniform
     const PeerTable* __restrict__ T = A.peers;      // uniform address: scalar loads
     const double* b = T->X[0];
 #pragma unroll
@@ -638,8 +639,19 @@ __device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row
     }
 }
 
-template <int G, int V, int CH, int MOVE, int DPB>
+// LEAN: the production instantiation of the shapes the bench configurations use.  The host selects it when none of the
+// occasional features is in play (sharded send buffers, device-side slot counts, graph replay descriptors, materialised
+// Gaussian displacements, peers, timing experiments): those kernel arguments then fold to constants instead of sitting in
+// scalar registers for the whole kernel -- the full kernel spills 66 SGPRs, and 25 fewer spills were worth 1.3 % at C2.
+template <int G, int V, int CH, int MOVE, int DPB, bool LEAN = false>
 static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
+    const int ablate_ = LEAN ? 0 : A.ablate;
+    const StepDesc* const desc_ = LEAN ? nullptr : A.desc;
+    double* const sendbuf_ = LEAN ? nullptr : A.sendbuf;
+    const int32_t* const thidev_ = LEAN ? nullptr : A.t_hi_dev;
+    const double* const disp_ = LEAN ? nullptr : A.disp;
+    const int skewsl_ = LEAN ? 0 : A.skew_sleep;
+    const int target_ = (LEAN && DPB > 0) ? (int)TGT_DENSE : A.target;
     static_assert(G >= 4 && G <= 64 && (64 % G) == 0, "G lanes per walker");
     constexpr bool DENSE = DPB > 0;
     constexpr int WPW = 64 / G;       // walkers per pass (<= 16)
@@ -652,7 +664,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     constexpr bool RTILE = EMX_OPT_RTILE && DENSE && PF == PPT && MOVE != MOVE_EVAL;
     static_assert(!DENSE || G * V * CH >= Dp, "row layout must cover the padded dimension");
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (A.ablate & 64) return;     // timing experiments: launch + dispatch floor
+    if (ablate_ & 64) return;     // timing experiments: launch + dispatch floor
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int sub = lane / G;
@@ -660,8 +672,8 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     const int D = A.D;
     double* chain_ = A.chain;
     double* chain_lp_ = A.chain_lp;
-    if (A.desc) {      // hipGraph replay: this step's chain row comes from the device-side descriptor
-        const long long sidx_ = A.desc->stored_idx;
+    if (desc_) {      // hipGraph replay: this step's chain row comes from the device-side descriptor
+        const long long sidx_ = desc_->stored_idx;
         chain_ = sidx_ >= 0 ? A.chain_all + (size_t)sidx_ * A.N * D : nullptr;
         chain_lp_ = sidx_ >= 0 ? A.chain_lp_all + (size_t)sidx_ * A.N : nullptr;
     }
@@ -716,7 +728,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int v = 0; v < V; ++v) mu.x[c][v] = iv.x[c][v] = 0.0;
-    if (!DENSE && CH <= 4 && A.target == TGT_DIAG) {
+    if (!DENSE && CH <= 4 && target_ == TGT_DIAG) {
         load_row<G, V, CH>(mu, A.tp0, D, gl);
         load_row<G, V, CH>(iv, A.tp1, D, gl);
     }
@@ -757,7 +769,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
             stage_pending = false;                                                                  \
         }                                                                                           \
     } while (0)
-    const int t_hi = A.t_hi_dev ? *A.t_hi_dev : A.t_hi;
+    const int t_hi = thidev_ ? *thidev_ : A.t_hi;
     if (A.t_lo + wave * spw >= t_hi) {        // idle wave: publish its share, meet the barrier, leave
         EMX_STAGE_PUBLISH();
         return;
@@ -770,7 +782,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
         for (int pb = 0; pb < npass; pb += PF) {
             if (skew && stager && stage_pending) {                       // image first, own loads after the barrier
                 EMX_STAGE_PUBLISH();
-                for (int r_ = 0; r_ < A.skew_sleep; ++r_) __builtin_amdgcn_s_sleep(8);
+                for (int r_ = 0; r_ < skewsl_; ++r_) __builtin_amdgcn_s_sleep(8);
             }
             // -------- plan entries of the batch: every lane of a group reads its walker's entry
             //          (same address across the group: one request, broadcast) --------
@@ -797,18 +809,18 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
             for (int k = 0; k < PF; ++k) {
                 const int srow = (pb + k) * WPW + sub;
                 const int pos = pbase + (srow < nslot ? srow : 0);
-                if (!(A.ablate & 32)) load_row<G, V, CH>(xi[k], A.X + (size_t)wi[k] * D, D, gl);
+                if (!(ablate_ & 32)) load_row<G, V, CH>(xi[k], A.X + (size_t)wi[k] * D, D, gl);
                 if constexpr (MOVE == MOVE_GAUSS) {
-                    if (A.disp) load_row<G, V, CH>(xa[k], A.disp + (size_t)wi[k] * D, D, gl);
+                    if (disp_) load_row<G, V, CH>(xa[k], disp_ + (size_t)wi[k] * D, D, gl);
                 } else if constexpr (NR >= 2) {
-                    if (!(A.ablate & 32)) load_row<G, V, CH>(xa[k], partner_base(A, ja[k]) + (size_t)ja[k] * D, D, gl);
+                    if (!(ablate_ & 32)) load_row<G, V, CH>(xa[k], partner_base<LEAN>(A, ja[k]) + (size_t)ja[k] * D, D, gl);
                 }
-                if constexpr (NR >= 3) load_row<G, V, CH>(xb[k], partner_base(A, jb[k]) + (size_t)jb[k] * D, D, gl);
-                if constexpr (NR >= 4) load_row<G, V, CH>(xc[k], partner_base(A, jc[k]) + (size_t)jc[k] * D, D, gl);
+                if constexpr (NR >= 3) load_row<G, V, CH>(xb[k], partner_base<LEAN>(A, jb[k]) + (size_t)jb[k] * D, D, gl);
+                if constexpr (NR >= 4) load_row<G, V, CH>(xc[k], partner_base<LEAN>(A, jc[k]) + (size_t)jc[k] * D, D, gl);
                 if constexpr (MOVE != MOVE_EVAL) {
                     s0v[k] = (MOVE == MOVE_SNOOKER) ? 0.0 : A.s0[pos];
                     facv[k] = A.fac[pos];
-                    if (!DENSE || A.target == TGT_NONE) {
+                    if (!DENSE || target_ == TGT_NONE) {
                         lpov[k] = A.lp[wi[k]];
                         loguv[k] = A.logu[pos];
                     } else {
@@ -824,7 +836,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
             if (stage_pending) EMX_STAGE_PUBLISH();   // rows are in flight; the barrier only waits for the image
             EMX_STAMP(3);      // image published, workgroup barrier passed
 
-            if (A.ablate & 128) {          // timing experiments: consume the loads, skip everything else
+            if (ablate_ & 128) {          // timing experiments: consume the loads, skip everything else
                 double sink = 0.0;
 #pragma unroll
                 for (int k = 0; k < PF; ++k) sink += xi[k].x[0][0] + xa[NR >= 2 ? k : 0].x[0][0] + lpov[k];
@@ -843,7 +855,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 
                     Row<G, V, CH> q;
                     if constexpr (MOVE == MOVE_GAUSS)
-                        if (!A.disp) gauss_disp_row<G, V, CH>(xa[k], A, i, ja[k], D, gl);
+                        if (!disp_) gauss_disp_row<G, V, CH>(xa[k], A, i, ja[k], D, gl);
                     make_proposal<G, V, CH, MOVE>(xi[k], xa[NR >= 2 ? k : 0], xb[NR >= 3 ? k : 0], xc[NR >= 4 ? k : 0],
                                                   s0v[k], A.gammas, D, gl, q, factor, NR >= 2 ? ja[k] : -1);
 
@@ -859,7 +871,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         if (live && badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
                     }
 
-                    if (A.target == TGT_NONE) {
+                    if (target_ == TGT_NONE) {
                         // split-phase: hand the proposal to the host log-prob (red_blue.py:90-93)
                         if (live) {
                             const int t = t0 + srow;
@@ -867,7 +879,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             if (gl == 0) A.fout[t] = factor;
                         }
                     } else if constexpr (!DENSE) {
-                        const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, A.target, A.tscale, D, gl, lane);
+                        const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, target_, A.tscale, D, gl, lane);
                         if (live && gl == 0 && (lp_new != lp_new)) raise_status(A.status, ST_NAN_LOGP);   // ensemble.py:550-551
                         if constexpr (MOVE == MOVE_EVAL) {
                             if (live && gl == 0) A.lp[i] = lp_new;
@@ -887,8 +899,8 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                 }
                             }
                             if (live && chain_) store_row<G, V, CH>(accept ? q : xi[k], chain_ + (size_t)i * D, D, gl);
-                            if (live && A.sendbuf) {
-                                double* sb = A.sendbuf + (size_t)(t0 + srow - A.t_lo) * (D + 2);
+                            if (live && sendbuf_) {
+                                double* sb = sendbuf_ + (size_t)(t0 + srow - A.t_lo) * (D + 2);
                                 store_row<G, V, CH>(accept ? q : xi[k], sb, D, gl);
                                 if (gl == 0) {
                                     sb[D] = accept ? lp_new : lp_old;
@@ -905,9 +917,9 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             for (int v = 0; v < V; ++v) {
                                 const int d = (c * G + gl) * V + v;
                                 if constexpr (RTILE) {
-                                    if (d < Dp && !(A.ablate & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] - mu.x[c][v] : 0.0;
+                                    if (d < Dp && !(ablate_ & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] - mu.x[c][v] : 0.0;
                                 } else {
-                                    if (d < Dp && !(A.ablate & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] : muS[d];   // dead row: zero residual
+                                    if (d < Dp && !(ablate_ & 4)) tile[trow * RT + d] = (live && !badq) ? q.x[c][v] : muS[d];   // dead row: zero residual
                                 }
                             }
                         if constexpr (RTILE) qk[k] = q;
@@ -916,8 +928,8 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         // proposal overwrites it after the decision -- no reload of rejected rows in the commit
                         if constexpr (MOVE != MOVE_EVAL) {
                             if (live && chain_) store_row<G, V, CH>(xi[k], chain_ + (size_t)i * D, D, gl);
-                            if (live && A.sendbuf)
-                                store_row<G, V, CH>(xi[k], A.sendbuf + (size_t)(t0 + srow - A.t_lo) * (D + 2), D, gl);
+                            if (live && sendbuf_)
+                                store_row<G, V, CH>(xi[k], sendbuf_ + (size_t)(t0 + srow - A.t_lo) * (D + 2), D, gl);
                         }
                     }
                 }
@@ -927,7 +939,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
             if constexpr (DENSE) {
                 const int plast = (pb + PF < npass ? pb + PF : npass) - 1;          // last pass of this batch
                 const bool tile_done = ((plast + 1) % PPT == 0) || (plast + 1 == npass);
-                if (A.target != TGT_NONE && tile_done && !(A.ablate & 16)) {
+                if (target_ != TGT_NONE && tile_done && !(ablate_ & 16)) {
                     // ---- one 16-row tile: Y = R Sinv by v_mfma_f64_16x16x4_f64 (R = Q - mu), qf[w] = sum_n Y[w][n] R[w][n] ----
                     const int tb = (plast / PPT) * 16;                  // first slot of the tile
                     // decision lanes: the 16 lanes with (lane & 15) < 4.  After the row reduction lane (am, ak) holds the
@@ -960,7 +972,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         double part[4] = {0.0, 0.0, 0.0, 0.0};
                         if (EMX_OPT_STAMPS && A.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
                         EMX_STAMP(5);      // A fragments in registers
-                        if (!(A.ablate & 1))
+                        if (!(ablate_ & 1))
 #pragma unroll
                         for (int nb = 0; nb < DPB; ++nb) {
                             d4 accv = {0.0, 0.0, 0.0, 0.0};
@@ -1011,19 +1023,19 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                     EMX_STAMP(8);      // decisions made, flag / log-prob stores issued
                     if constexpr (MOVE != MOVE_EVAL) {
                         const unsigned long long am64 = __ballot(acc);       // bit (row & 3) * 16 + (row >> 2) <-> tile row
-                        if (A.sendbuf && (lane & 15) < 4) qfS[myrow] = lp_fin;
-                        if (A.sendbuf) EMX_WAVE_SYNC();
+                        if (sendbuf_ && (lane & 15) < 4) qfS[myrow] = lp_fin;
+                        if (sendbuf_) EMX_WAVE_SYNC();
                         // commit the tile's rows in the (G, V, CH) row layout: accepted rows come from LDS
 #pragma unroll
                         for (int pp = 0; pp < PPT; ++pp) {
-                            if (A.ablate & 8) break;
+                            if (ablate_ & 8) break;
                             const int row = pp * WPW + sub;              // 0..15
                             const int sidx = tb + row;
                             const bool lv = sidx < nslot;
                             const bool ac = lv && ((am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull);
                             if (!lv) continue;
-                            if (A.sendbuf && gl == 0) {
-                                double* sb = A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2);
+                            if (sendbuf_ && gl == 0) {
+                                double* sb = sendbuf_ + (size_t)(t0 + sidx - A.t_lo) * (D + 2);
                                 sb[D] = qfS[row];
                                 sb[D + 1] = ac ? 1.0 : 0.0;
                             }
@@ -1051,7 +1063,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             }
                             store_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
                             if (chain_) store_row<G, V, CH>(rr, chain_ + (size_t)wi2 * D, D, gl);
-                            if (A.sendbuf) store_row<G, V, CH>(rr, A.sendbuf + (size_t)(t0 + sidx - A.t_lo) * (D + 2), D, gl);
+                            if (sendbuf_) store_row<G, V, CH>(rr, sendbuf_ + (size_t)(t0 + sidx - A.t_lo) * (D + 2), D, gl);
                         }
                     }
                     EMX_STAMP(9);      // commit stores issued
