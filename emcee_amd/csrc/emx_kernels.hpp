@@ -37,6 +37,12 @@
 #ifndef EMX_OPT_RTILE
 #define EMX_OPT_RTILE 1       // dense target, batch == tile: the LDS tile holds R = Q - mu (no mean reads at the A fragments), accepted
 #endif                        // rows are committed from the registers that made them (no tile re-read)
+#ifndef EMX_LEAN_FOLD_D
+#define EMX_LEAN_FOLD_D 0
+#endif
+#ifndef EMX_LEAN_FOLD_SPW
+#define EMX_LEAN_FOLD_SPW 1     // +0.7 % at C2
+#endif
 #ifndef EMX_OPT_SKEW
 #define EMX_OPT_SKEW 1        // dense target, 8-wave workgroups: the upper four waves stage the whole LDS image before they issue
 #endif                        // their row loads, so the two waves of a SIMD run out of phase (loads first for the lower four)
@@ -669,7 +675,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     const int wib = threadIdx.x >> 6;
     const int sub = lane / G;
     const int gl = lane % G;
-    const int D = A.D;
+    const int D = (LEAN && EMX_LEAN_FOLD_D) ? G * V * CH : A.D;          // folding the dimension too was measured 1.7 % SLOWER at C2 (scheduling)
     double* chain_ = A.chain;
     double* chain_lp_ = A.chain_lp;
     if (desc_) {      // hipGraph replay: this step's chain row comes from the device-side descriptor
@@ -745,7 +751,8 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     } while (0)
     EMX_STAMP(0);
     if (EMX_OPT_STAMPS && A.dbg && wib == 0 && lane == 0) A.dbg[(size_t)blockIdx.x * 16 + 11] = wall_clock64();   // 100 MHz reference
-    const int spw = A.spw;
+    const int spw = (LEAN && EMX_LEAN_FOLD_SPW) ? ((DENSE && PF * WPW < 16) ? 16 : PF * WPW) : A.spw;
+    const int tlo_ = (LEAN && EMX_LEAN_FOLD_SPW) ? 0 : A.t_lo;
     bool stage_pending = DENSE;   // this wave still owes its share of the image and the workgroup barrier
 #define EMX_STAGE_PUBLISH()                                                                         \
     do {                                                                                            \
@@ -770,11 +777,11 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
         }                                                                                           \
     } while (0)
     const int t_hi = thidev_ ? *thidev_ : A.t_hi;
-    if (A.t_lo + wave * spw >= t_hi) {        // idle wave: publish its share, meet the barrier, leave
+    if (tlo_ + wave * spw >= t_hi) {        // idle wave: publish its share, meet the barrier, leave
         EMX_STAGE_PUBLISH();
         return;
     }
-    for (int t0 = A.t_lo + wave * spw; t0 < t_hi; t0 += nwaves * spw) {     // wave-uniform batch loop
+    for (int t0 = tlo_ + wave * spw; t0 < t_hi; t0 += nwaves * spw) {     // wave-uniform batch loop
         const int nslot = min(spw, t_hi - t0);
         const int npass = (nslot + WPW - 1) / WPW;
         const int pbase = A.pos0 + t0;          // plan position of the wave's first slot
@@ -900,7 +907,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             }
                             if (live && chain_) store_row<G, V, CH>(accept ? q : xi[k], chain_ + (size_t)i * D, D, gl);
                             if (live && sendbuf_) {
-                                double* sb = sendbuf_ + (size_t)(t0 + srow - A.t_lo) * (D + 2);
+                                double* sb = sendbuf_ + (size_t)(t0 + srow - tlo_) * (D + 2);
                                 store_row<G, V, CH>(accept ? q : xi[k], sb, D, gl);
                                 if (gl == 0) {
                                     sb[D] = accept ? lp_new : lp_old;
@@ -929,7 +936,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         if constexpr (MOVE != MOVE_EVAL) {
                             if (live && chain_) store_row<G, V, CH>(xi[k], chain_ + (size_t)i * D, D, gl);
                             if (live && sendbuf_)
-                                store_row<G, V, CH>(xi[k], sendbuf_ + (size_t)(t0 + srow - A.t_lo) * (D + 2), D, gl);
+                                store_row<G, V, CH>(xi[k], sendbuf_ + (size_t)(t0 + srow - tlo_) * (D + 2), D, gl);
                         }
                     }
                 }
@@ -1035,7 +1042,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             const bool ac = lv && ((am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull);
                             if (!lv) continue;
                             if (sendbuf_ && gl == 0) {
-                                double* sb = sendbuf_ + (size_t)(t0 + sidx - A.t_lo) * (D + 2);
+                                double* sb = sendbuf_ + (size_t)(t0 + sidx - tlo_) * (D + 2);
                                 sb[D] = qfS[row];
                                 sb[D + 1] = ac ? 1.0 : 0.0;
                             }
@@ -1063,7 +1070,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             }
                             store_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
                             if (chain_) store_row<G, V, CH>(rr, chain_ + (size_t)wi2 * D, D, gl);
-                            if (sendbuf_) store_row<G, V, CH>(rr, sendbuf_ + (size_t)(t0 + sidx - A.t_lo) * (D + 2), D, gl);
+                            if (sendbuf_) store_row<G, V, CH>(rr, sendbuf_ + (size_t)(t0 + sidx - tlo_) * (D + 2), D, gl);
                         }
                     }
                     EMX_STAMP(9);      // commit stores issued
