@@ -713,7 +713,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 PMC passes of an earlier run of this command, "
                                            "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; not re-measured here)",
-                         "kernel": "emx::k_halfstep<8,2,4,STRETCH,DPB=4> (G=8 lanes/walker, V=2, CH=4; f64 MFMA dense target)",
+                         "kernel": "emx::k_halfstep<8,2,4,STRETCH,DPB=4,LEAN> (G=8 lanes/walker, V=2, CH=4; f64 MFMA dense target)",
                          "algorithmic_bytes_per_walker_update": B, "walker_updates_per_launch": slots_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "per_launch_event_us": per_launch_us,
                          "note": "avg_launch_us = hipEvent time of the timed region / half-step launches: it includes the "
