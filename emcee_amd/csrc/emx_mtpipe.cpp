@@ -706,7 +706,10 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     m.fin_busy_ns.assign(K, 0);
     m.t_start = now_ns();
     const CpuSet cs = pipeline_cpus();
-    const std::vector<int> cores = getenv("EMX_PIPE_NO_CORE_PINNING") ? std::vector<int>() : distinct_cores(cs);
+    // One physical core per thread is the fastest placement on an idle host (0.080 vs 0.100 ms/step at 65 536 walkers) and the
+    // slowest when another tenant of the machine occupies one of the chosen cores (0.19 seen): opt-in (EMX_PIPE_CORE_PINNING=1);
+    // by default the threads may move inside the L3 domain.
+    const std::vector<int> cores = getenv("EMX_PIPE_CORE_PINNING") ? distinct_cores(cs) : std::vector<int>();
     m.gen = std::thread(generator_main, &m.ws, m.start.key);
     confine(m.gen, cs, cores, 0);
     m.tok = std::thread([&m] { m.tokenizer_main(); });
