@@ -460,14 +460,17 @@ constexpr int MAX_DEVICES = 64;      // function attributes are per device: one 
 // the occasional features a LEAN instantiation compiles out
 int prefetch_depth_host(int G, int V, int CH, int move, bool dense);
 
-inline bool lean_ok(const HalfStepArgs& a, int G, int V, int CH, int move, bool dense) {
+// -> 0: the full kernel; 1: LEAN; 2: LEAN for the block-ownership exchanges (device-side slot count and / or peer table live)
+inline int lean_kind(const HalfStepArgs& a, int G, int V, int CH, int move, bool dense) {
     const int WPW = 64 / G, PF = prefetch_depth_host(G, V, CH, move, dense);
     const int spw = (dense && PF * WPW < 16) ? 16 : PF * WPW;
-    return !a.ablate && !a.desc && !a.sendbuf && !a.t_hi_dev && !a.disp && !a.skew_sleep && !a.npeer && !a.dbg && a.target != TGT_NONE &&
-           a.D == G * V * CH && a.spw == spw && a.t_lo == 0;
+    const bool common = !a.ablate && !a.desc && !a.sendbuf && !a.disp && !a.skew_sleep && !a.dbg && a.target != TGT_NONE &&
+                        a.D == G * V * CH && a.spw == spw && a.t_lo == 0;
+    if (!common) return 0;
+    return (a.t_hi_dev || a.npeer) ? 2 : 1;
 }
 
-template <int G, int V, int CH, int MOVE, int DPB, bool LEAN = false>
+template <int G, int V, int CH, int MOVE, int DPB, int LEAN = 0>
 hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
     auto kern = k_halfstep<G, V, CH, MOVE, DPB, LEAN>;
     static size_t lds_granted[MAX_DEVICES] = {};      // per instantiation and device: raise the dynamic-LDS limit once
@@ -484,8 +487,16 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
 template <int MOVE>
 hipError_t launch_valu(const Shape& sh, dim3 grid, dim3 block, hipStream_t st, const HalfStepArgs& a) {
     if constexpr (MOVE == MOVE_STRETCH) {          // C3 (D = 32) and C5 (D = 1024)
-        if (sh.G == 8 && sh.V == 2 && sh.CH == 2 && lean_ok(a, 8, 2, 2, MOVE, false)) return launch_one<8, 2, 2, MOVE, 0, true>(grid, block, 0, st, a);
-        if (sh.G == 64 && sh.V == 2 && sh.CH == 8 && lean_ok(a, 64, 2, 8, MOVE, false)) return launch_one<64, 2, 8, MOVE, 0, true>(grid, block, 0, st, a);
+        if (sh.G == 8 && sh.V == 2 && sh.CH == 2) {
+            const int lk = lean_kind(a, 8, 2, 2, MOVE, false);
+            if (lk == 1) return launch_one<8, 2, 2, MOVE, 0, 1>(grid, block, 0, st, a);
+            if (lk == 2) return launch_one<8, 2, 2, MOVE, 0, 2>(grid, block, 0, st, a);
+        }
+        if (sh.G == 64 && sh.V == 2 && sh.CH == 8) {
+            const int lk = lean_kind(a, 64, 2, 8, MOVE, false);
+            if (lk == 1) return launch_one<64, 2, 8, MOVE, 0, 1>(grid, block, 0, st, a);
+            if (lk == 2) return launch_one<64, 2, 8, MOVE, 0, 2>(grid, block, 0, st, a);
+        }
     }
 #define EMX_CASE(g, v, c) \
     if (sh.G == g && sh.V == v && sh.CH == c) return launch_one<g, v, c, MOVE, 0>(grid, block, 0, st, a);
@@ -507,7 +518,12 @@ constexpr int dense_ch(int dpb, int v) { return shape_ch(dpb * 16 / v); }
 template <int MOVE>
 hipError_t launch_dense(int dpb, int V, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
     if constexpr (MOVE != MOVE_EVAL) {             // C2 / C4 (D = 64)
-        if (dpb == 4 && V == 2 && lean_ok(a, dense_g(4, 2), 2, dense_ch(4, 2), MOVE, true)) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, true>(grid, block, lds, st, a);
+        if (dpb == 4 && V == 2) {
+            const int lk = lean_kind(a, dense_g(4, 2), 2, dense_ch(4, 2), MOVE, true);
+            if (lk == 1) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, 1>(grid, block, lds, st, a);
+            if constexpr (MOVE == MOVE_STRETCH)
+                if (lk == 2) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, 2>(grid, block, lds, st, a);
+        }
     }
 #define EMX_CASE(b, v) \
     if (dpb == b && V == v) return launch_one<dense_g(b, v), v, dense_ch(b, v), MOVE, b>(grid, block, lds, st, a);

@@ -147,9 +147,9 @@ struct PeerTable {
 };
 
 // coordinate array holding the current row of walker j (block ownership: rank q owns [lo[q], lo[q + 1]))
-template <bool LEAN>
+template <int LEAN>
 __device__ __forceinline__ const double* partner_base(const HalfStepArgs& A, int j) {
-    if (LEAN || A.npeer == 0) return A.X;           // launch-uniform
+    if (LEAN == 1 || A.npeer == 0) return A.X;      // launch-uniform
     const PeerTable* __restrict__ T = A.peers;      // uniform address: scalar loads
     const double* b = T->X[0];
 #pragma unroll
@@ -649,12 +649,14 @@ __device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row
 // occasional features is in play (sharded send buffers, device-side slot counts, graph replay descriptors, materialised
 // Gaussian displacements, peers, timing experiments): those kernel arguments then fold to constants instead of sitting in
 // scalar registers for the whole kernel -- the full kernel spills 66 SGPRs, and 25 fewer spills were worth 1.3 % at C2.
-template <int G, int V, int CH, int MOVE, int DPB, bool LEAN = false>
+// LEAN = 2 keeps what the block-ownership exchanges need (the device-side slot count of the compact plan, the peer
+// table of the direct exchange) and folds the rest: the sharded stretch runs of the same shapes.
+template <int G, int V, int CH, int MOVE, int DPB, int LEAN = 0>
 static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     const int ablate_ = LEAN ? 0 : A.ablate;
     const StepDesc* const desc_ = LEAN ? nullptr : A.desc;
     double* const sendbuf_ = LEAN ? nullptr : A.sendbuf;
-    const int32_t* const thidev_ = LEAN ? nullptr : A.t_hi_dev;
+    const int32_t* const thidev_ = LEAN == 1 ? nullptr : A.t_hi_dev;        // LEAN 2: the block-ownership exchanges (pull, direct)
     const double* const disp_ = LEAN ? nullptr : A.disp;
     const int skewsl_ = LEAN ? 0 : A.skew_sleep;
     const int target_ = (LEAN && DPB > 0) ? (int)TGT_DENSE : A.target;

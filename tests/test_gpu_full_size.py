@@ -221,3 +221,47 @@ def test_pull_exchange_at_full_size(name, world):
         assert np.array_equal(x, ref_chain[-1]) and np.array_equal(lp, ref_lp[-1])
         assert np.array_equal(e.ens.accepted_counts(), ref_acc)
         e.ens.close()
+
+
+@pytest.mark.parametrize("name,world", [("c2_65536x64_dense_stretch", 4), ("c3_262144x32_rosenbrock_stretch", 2)])
+def test_direct_exchange_at_full_size(name, world):
+    """Direct exchange at a BASELINE size with `world` logical ranks on the one GPU (host-ordered half-steps): the shapes
+    whose sharded runs take the LEAN = 2 instantiation of the half-step kernel.  Every rank's block of the chain must equal
+    the single-rank run bit for bit."""
+    import torch
+    from emcee_amd.parallel import DeviceEngine, attach_direct_peers, block_range
+    spec = FULL[name]()
+    nst = 3
+
+    def setup(ens):
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(271828, 0)
+        ens.chain_config(nst)
+
+    ref = make_ens(spec, spec["p0"])
+    setup(ref)
+    ref.run(nst, 1, True)
+    ref_chain, ref_lp = ref.chain_read(0, 0, nst), ref.chain_read(1, 0, nst)
+    ref.close()
+    engines = []
+    for r in range(world):
+        ens = make_ens(spec, spec["p0"])
+        setup(ens)
+        engines.append(DeviceEngine(ens, r, world, torch.device("cuda", 0), exchange="direct"))
+    attach_direct_peers([e.ens for e in engines])
+    for _ in range(nst):
+        res = [e.step_begin(True) for e in engines]
+        assert all(r == res[0] for r in res)
+        for split in range(res[0][1]):
+            for e in engines:
+                e.ens.direct_halfstep(split, barrier=False)
+            for e in engines:
+                e.ens.sync()
+        for e in engines:
+            e.step_end()
+    for r, e in enumerate(engines):
+        lo, hi = block_range(spec["N"], r, world)
+        assert e.ens.status() == 0
+        assert np.array_equal(e.ens.chain_read(0, 0, nst)[:, lo:hi], ref_chain[:, lo:hi])
+        assert np.array_equal(e.ens.chain_read(1, 0, nst)[:, lo:hi], ref_lp[:, lo:hi])
+        e.ens.close()
