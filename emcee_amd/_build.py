@@ -4,16 +4,18 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip")]     # translation units, built in parallel
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip", "emx_hot.hip")]     # translation units, built in parallel
 SRC = SRCS[0]
 LIB = os.path.join(HERE, "libemx.so")
 HOST_SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx_mtpipe.cpp",)]       # plain host C++ (threads, SIMD clones): no device pass
 DEPS = SRCS + HOST_SRCS + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_rng.hpp", "mt19937_legacy.hpp",
-                                                                  "emx_mtpipe.hpp", "emx_internal.hpp")] + [
+                                                                  "emx_mtpipe.hpp", "emx_internal.hpp", "emx_launch.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "emx.h")]
 HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread"]
 # -ffp-contract=off: the proposal arithmetic must round like NumPy's separate multiply/subtract.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-fPIC"]
+# emx_hot.hip (the headline kernel alone): the ILP instruction scheduler, +2.2 % there (csrc/emx_launch.hpp says why not everywhere)
+EXTRA_FLAGS = {"emx_hot.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 HASHFILE = LIB + ".srchash"
@@ -21,7 +23,7 @@ HASHFILE = LIB + ".srchash"
 
 def _source_hash():
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS + HOST_FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS + HOST_FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     for d in DEPS:
         with open(d, "rb") as f:
             h.update(f.read())
@@ -46,7 +48,7 @@ def build(force=False, verbose=False):
     objs, procs = [], []
     for src in SRCS:
         obj = os.path.join(HERE, os.path.basename(src) + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))

@@ -18,6 +18,7 @@
 #include "../../include/emx.h"
 #include "emx_internal.hpp"
 #include "emx_kernels.hpp"
+#include "emx_launch.hpp"
 #include "emx_mtpipe.hpp"
 #include "emx_rng.hpp"
 #include "mt19937_legacy.hpp"
@@ -455,8 +456,6 @@ static void drop_prepared(emx_ctx* c) {
 // ------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int MAX_DEVICES = 64;      // function attributes are per device: one process may drive several GPUs
-
 // the occasional features a LEAN instantiation compiles out
 int prefetch_depth_host(int G, int V, int CH, int move, bool dense);
 
@@ -468,20 +467,6 @@ inline int lean_kind(const HalfStepArgs& a, int G, int V, int CH, int move, bool
                         a.D == G * V * CH && a.spw == spw && a.t_lo == 0;
     if (!common) return 0;
     return (a.t_hi_dev || a.npeer) ? 2 : 1;
-}
-
-template <int G, int V, int CH, int MOVE, int DPB, int LEAN = 0>
-hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
-    auto kern = k_halfstep<G, V, CH, MOVE, DPB, LEAN>;
-    static size_t lds_granted[MAX_DEVICES] = {};      // per instantiation and device: raise the dynamic-LDS limit once
-    int dev = 0;
-    if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_granted[dev] = lds;
-    }
-    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
-    return hipGetLastError();
 }
 
 template <int MOVE>
@@ -520,9 +505,11 @@ hipError_t launch_dense(int dpb, int V, dim3 grid, dim3 block, size_t lds, hipSt
     if constexpr (MOVE != MOVE_EVAL) {             // C2 / C4 (D = 64)
         if (dpb == 4 && V == 2) {
             const int lk = lean_kind(a, dense_g(4, 2), 2, dense_ch(4, 2), MOVE, true);
-            if (lk == 1) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, 1>(grid, block, lds, st, a);
-            if constexpr (MOVE == MOVE_STRETCH)
-                if (lk == 2) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, 2>(grid, block, lds, st, a);
+            if constexpr (MOVE == MOVE_STRETCH) {
+                if (lk) return launch_hot_stretch_dense64(lk, grid, block, lds, st, a);       // emx_hot.hip (its own scheduler strategy)
+            } else {
+                if (lk == 1) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, 1>(grid, block, lds, st, a);
+            }
         }
     }
 #define EMX_CASE(b, v) \
