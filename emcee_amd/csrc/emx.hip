@@ -463,7 +463,7 @@ int prefetch_depth_host(int G, int V, int CH, int move, bool dense);
 inline int lean_kind(const HalfStepArgs& a, int G, int V, int CH, int move, bool dense) {
     const int WPW = 64 / G, PF = prefetch_depth_host(G, V, CH, move, dense);
     const int spw = (dense && PF * WPW < 16) ? 16 : PF * WPW;
-    const bool common = !a.ablate && !a.desc && !a.sendbuf && !a.disp && !a.skew_sleep && !a.dbg && a.target != TGT_NONE &&
+    const bool common = !a.ablate && !a.desc && !a.sendbuf && !a.disp && !a.skew_sleep && (EMX_OPT_STAMPS || !a.dbg) && a.target != TGT_NONE &&
                         a.D == G * V * CH && a.spw == spw && a.t_lo == 0;
     if (!common) return 0;
     return (a.t_hi_dev || a.npeer) ? 2 : 1;

@@ -300,3 +300,47 @@ def test_dense_target_keeps_precision_next_to_a_large_mean():
     L = np.linalg.cholesky(icov)
     folded = -0.5 * np.sum((x @ L - mu @ L) ** 2, axis=1)
     assert np.max(np.abs(folded - want) / np.abs(want)) > 100 * np.max(np.abs(got - want) / np.abs(want))
+
+
+@pytest.mark.parametrize("name", ["stretch_256x16_dense", "mix_de_snooker_128x8_dense", "stretch_nsplits3_45x2"])
+def test_exact_mode_pipeline_inline_and_single_steps_interleave(name):
+    """MT19937 mode: emx_run takes its plans from the threaded host pipeline (csrc/emx_mtpipe.cpp), single steps
+    (emx_step_begin) and `mt_pipeline = 0` make them inline.  Any interleaving must continue ONE stream: the chain, the
+    accept counts and the final generator state equal the reference fixture's."""
+    g = load_golden(name)
+    spec = cases.build(name)
+    if spec["thin_by"] != 1:
+        pytest.skip("thinned fixture")
+    nst = spec["nsteps"]
+    ens = make_ens(spec, g["p0"])
+    ens.set_rng_mode(_lib.RNG_MT19937)
+    ens.set_mt19937(rng_from_fixture(g).get_state())
+    ens.set_tuning("small_kernel", 0)          # the general path (the one-workgroup kernel has its own bulk plan producer)
+    ens.chain_config(nst)
+    done = 0
+    pattern = [("run", 3), ("step", 1), ("run", 2), ("inline", 2), ("step", 1)]
+    k = 0
+    while done < nst:
+        kind, n = pattern[k % len(pattern)]
+        n = min(n, nst - done)
+        k += 1
+        if kind == "step":
+            _, S = ens.step_begin(store=True)
+            for s in range(S):
+                ens.halfstep(s)
+            ens.step_end()
+        else:
+            ens.set_tuning("mt_pipeline", 0 if kind == "inline" else -1)
+            ens.run(n, 1, True)
+        done += n
+    assert ens.status() == 0
+    chain = ens.chain_read(0, 0, nst)
+    if has_snooker(spec):
+        np.testing.assert_allclose(chain, g["chain"], rtol=SNOOKER_RTOL, atol=SNOOKER_ATOL)
+    else:
+        assert np.array_equal(chain, g["chain"])
+    assert np.array_equal(ens.accepted_counts(), g["accepted_count"])
+    st = ens.get_mt19937()
+    assert np.array_equal(st[1], g["rng_key1"]) and st[2] == int(g["rng_pos1"])
+    assert st[3] == int(g["rng_has_gauss1"]) and st[4] == float(g["rng_cached1"])
+    ens.close()
