@@ -354,7 +354,7 @@ def exact_mode_entry(wl, K, W, device):
     """C2 under rng=mt19937 (same seed => reference emcee's chain).  The host produces every draw of the step from the
     serial NumPy-legacy stream; host_plan_ms times that producer alone (no GPU involved)."""
     from emcee_amd import _lib
-    Kx = max(10, min(K, 100))
+    Kx = max(100, min(K, 400))          # one emx_run per block: long enough that the pipeline's thread start-up (0.2 ms) is amortised
     res = measure_single(wl, Kx, max(W, 10), device=device, rng="mt19937", spin_s=0.05)
     lib = _lib.load()
     host_ms = None
