@@ -421,6 +421,7 @@ struct emx_ctx {
 };
 
 static void graph_invalidate(emx_ctx* c);
+static void pipe_stop(emx_ctx* c);
 static void direct_detach(emx_ctx* c);
 static int direct_ensure(emx_ctx* c);
 static void exchange_free(emx_ctx* c);
@@ -826,6 +827,7 @@ int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
 
 int emx_destroy(emx_ctx* c) {
     if (!c) return 0;
+    pipe_stop(c);                 // its threads write into the pinned staging buffers freed below
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm), c->comm = nullptr;
@@ -875,7 +877,6 @@ int emx_destroy(emx_ctx* c) {
     if (c->my_flags) hipFree(c->my_flags);
     if (c->peer_table) hipFree(c->peer_table);
     if (c->direct_counts) hipFree(c->direct_counts);
-    if (c->pipe) delete c->pipe, c->pipe = nullptr;
     if (c->up_stream) hipStreamDestroy(c->up_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -923,6 +924,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "small_kernel")) {
+        pipe_stop(c);
         c->tune_small = v;
         return 0;
     }
@@ -935,6 +937,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "mt_pipeline")) {   // exact mode: -1 auto, 0 plans made inline by the calling thread, k > 0 finisher threads
+        pipe_stop(c);
         c->tune_mt_pipeline = v;
         return 0;
     }
@@ -1081,6 +1084,7 @@ int emx_eval_log_prob(emx_ctx* c, const double* coords, int64_t n, double* out) 
 
 int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const double* cdf) {
     NEED(c, nmoves >= 1, "need at least one move");
+    pipe_stop(c);
     for (int i = 0; i < nmoves; ++i) {
         NEED(c, moves[i].kind >= 0 && moves[i].kind <= EMX_MOVE_GAUSS, "unknown move kind");
         if (moves[i].kind == EMX_MOVE_GAUSS) {
@@ -1115,6 +1119,7 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
 
 int emx_set_rng_mode(emx_ctx* c, int32_t mode) {
     NEED(c, mode >= 0 && mode <= 2, "unknown rng mode");
+    pipe_stop(c);
     c->rng_mode = mode;
     drop_prepared(c);
     return 0;
@@ -1141,12 +1146,14 @@ int emx_get_move(emx_ctx* c, int32_t mi, emx_move_desc* out) {
 }
 
 int emx_rng_set_mt19937(emx_ctx* c, const uint32_t key[624], int32_t pos, int32_t hg, double cached) {
+    pipe_stop(c);
     NEED(c, pos >= 0 && pos <= 624, "bad MT19937 position");
     c->mt.set_state(key, pos, hg, cached);
     return 0;
 }
 
 int emx_rng_get_mt19937(emx_ctx* c, uint32_t key[624], int32_t* pos, int32_t* hg, double* cached) {
+    pipe_stop(c);          // the state after the last step taken (what the pipeline produced ahead is dropped)
     memcpy(key, c->mt.key, sizeof(c->mt.key));
     *pos = c->mt.pos;
     *hg = c->mt.has_gauss;
@@ -1330,6 +1337,7 @@ static void pipe_poll(void* arg) {
     emx_ctx* c = (emx_ctx*)arg;
     while (!c->pipe_uploads.empty()) {
         const int64_t n = c->pipe_uploads.front();
+        if (c->cur.active && n == c->pipe_taken - 1) break;       // the open step's staging buffer may still be read (emx_plan_get)
         auto& s = c->ring[(c->pipe_ring0 + n % PIPE_SINKS) % PLAN_RING];
         if (hipEventQuery(s.uploaded) != hipSuccess) break;
         c->pipe->release(n);
@@ -1337,7 +1345,8 @@ static void pipe_poll(void* arg) {
     }
 }
 
-static int pipe_start(emx_ctx* c, int64_t nsteps) {
+static int pipe_start(emx_ctx* c) {
+    const int64_t nsteps = (int64_t)1 << 60;       // it runs ahead (16 plans at most) until something retires it
     const size_t N = (size_t)c->N;
     if (!c->up_stream) HIPOK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     HIPOK(c, hipStreamSynchronize(c->stream));          // no earlier copy still reads a staging buffer
@@ -1370,6 +1379,16 @@ static void pipe_stop(emx_ctx* c) {
     delete c->pipe;
     c->pipe = nullptr;
     c->pipe_uploads.clear();
+}
+
+// The pipeline is persistent: emx_run (or a single step of a large ensemble) starts it, it keeps running AHEAD of the steps
+// taken -- plans do not depend on the walkers -- and serves later emx_run / emx_step_begin calls (the sample() generator takes
+// one step per call) until something needs the generator state itself or changes what a plan is: emx_rng_get/set_mt19937,
+// emx_set_moves, emx_set_rng_mode, a forced move, the one-workgroup path, emx_destroy.  Those retire it (pipe_stop): the
+// context's generator is set to the state after the last step TAKEN, what was produced ahead is dropped.
+static bool pipe_eligible(const emx_ctx* c) {
+    return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_pipeline != 0 && !small_eligible(c) &&
+           MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
 }
 
 // emx_step_begin's part: wait for the next plan, send it up on the upload stream, order the kernels behind it
@@ -1420,9 +1439,13 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
     cur.store = store != 0;
     cur.native = false;
     const int nm = (int)c->moves.size();
-    if (c->rng_mode == EMX_RNG_MT19937 && c->pipe) {
-        // emx_run in exact mode: the plan of this step was made by the pipeline threads (same draws, same order)
-        NEED(c, forced_move < 0, "a forced move cannot be taken from the plan pipeline");
+    if (c->pipe && (forced_move >= 0 || !pipe_eligible(c))) pipe_stop(c);      // a forced move skips the choice draw: inline
+    if (c->rng_mode == EMX_RNG_MT19937 && forced_move < 0 && (c->pipe || (c->N >= 8192 && pipe_eligible(c)))) {
+        // exact mode: the plan of this step comes from the pipeline threads (same draws, same order as the inline producer)
+        if (!c->pipe) {
+            int rc0 = pipe_start(c);
+            if (rc0) return rc0;
+        }
         int rc = pipe_take(c);
         if (rc) return rc;
     } else if (c->rng_mode == EMX_RNG_MT19937) {
@@ -1586,8 +1609,13 @@ int emx_plan_get(emx_ctx* c, int32_t* off, int32_t* order, int32_t* p0, int32_t*
     const HostPlan hp(ps.host, N);
     memcpy(order, hp.order, N * 4);
     memcpy(p0, hp.p0, N * 4);
-    memcpy(p1, hp.p1, N * 4);
-    memcpy(p2, hp.p2, N * 4);
+    if (cur.move >= 0 && c->moves[cur.move].kind == EMX_MOVE_STRETCH) {     // one partner: the pipeline leaves these columns alone
+        memcpy(p1, hp.order, N * 4);
+        memcpy(p2, hp.order, N * 4);
+    } else {
+        memcpy(p1, hp.p1, N * 4);
+        memcpy(p2, hp.p2, N * 4);
+    }
     memcpy(s0, hp.s0, N * 8);
     memcpy(uacc, hp.uacc, N * 8);
     return 0;
@@ -1881,6 +1909,7 @@ static bool small_eligible(const emx_ctx* c) {
 
 // `nsteps` full steps starting at step index i0 of the current emx_run call
 static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, int32_t store) {
+    pipe_stop(c);                 // this path draws from the context's generator itself
     const int nm = (int)c->moves.size();
     emx_ctx::BulkPlans* gauss_bulk = nullptr;
     const bool dense = c->target == EMX_TARGET_DENSE_GAUSS;
@@ -2064,14 +2093,14 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     const int64_t total = nsteps * thin_by;
     // exact mode, general path: the plans of the whole call come from the host pipeline (generator / tokenizer /
     // finisher threads) instead of being made inline, one step at a time, by this thread
-    const bool piped = c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_pipeline != 0 && total >= 2 && c->target != EMX_TARGET_HOST &&
-                       !small_eligible(c) && MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
-    if (piped) {
-        const int rc = pipe_start(c, total);
+    const bool piped = pipe_eligible(c) && c->target != EMX_TARGET_HOST && (c->pipe || total >= 2);
+    if (c->pipe && !piped) pipe_stop(c);
+    if (piped && !c->pipe) {
+        const int rc = pipe_start(c);
         if (rc) return rc;
     }
     const int rc = run_impl(c, nsteps, thin_by, store);
-    if (piped) pipe_stop(c);
+    if (rc && c->pipe) pipe_stop(c);          // after an error the generator stands after the last plan taken
     return rc;
 }
 

@@ -165,8 +165,11 @@ struct Backoff {
         } else if (n < 512) {
             ++n;
             std::this_thread::yield();
-        } else {
+        } else if (n < 3000) {
+            ++n;
             std::this_thread::sleep_for(std::chrono::microseconds(40));
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(500));      // a pipeline left idle between calls costs next to nothing
         }
     }
 };

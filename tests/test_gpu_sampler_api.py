@@ -624,6 +624,35 @@ def test_consecutive_unstored_runs_from_plain_arrays_continue_the_stream():
     assert np.array_equal(end, g["chain"][-1])
 
 
+def test_generator_path_of_a_large_ensemble_runs_on_the_persistent_plan_pipeline():
+    """sample() takes one native step per yield.  For ensembles of >= 8192 walkers in MT19937 mode those single steps are
+    served by the plan pipeline that keeps running ahead between the calls; reading the generator state in the middle
+    retires and restarts it.  Chain and final state must equal the one-call run_mcmc (itself pinned to the oracle at full
+    size by test_gpu_full_size.py)."""
+    N, D, nst = 8192, 8, 14
+    rs = np.random.RandomState(21)
+    p0 = rs.randn(N, D)
+    mv = [(moves.StretchMove(), 0.6), (moves.DEMove(), 0.4)]
+    a = emcee_amd.EnsembleSampler(N, D, targets.IsoGaussian(), moves=mv)
+    a._random.seed(77)
+    a.run_mcmc(p0, nst, skip_initial_state_check=True)
+    b = emcee_amd.EnsembleSampler(N, D, targets.IsoGaussian(), moves=mv)
+    b._random.seed(77)
+    mid_state = None
+    for n, st in enumerate(b.sample(p0, iterations=nst, skip_initial_state_check=True), 1):
+        if n == 5:
+            mid_state = st.random_state            # copies the MT19937 state out of libemx: the pipeline is retired here
+    assert np.array_equal(a.get_chain(), b.get_chain())
+    assert np.array_equal(a.get_log_prob(), b.get_log_prob())
+    fa, fb = a.random_state, b.random_state
+    assert np.array_equal(fa[1], fb[1]) and fa[2:] == fb[2:]
+    c = emcee_amd.EnsembleSampler(N, D, targets.IsoGaussian(), moves=mv)
+    c._random.seed(77)
+    c.run_mcmc(p0, 5, skip_initial_state_check=True)
+    want = c.random_state
+    assert np.array_equal(mid_state[1], want[1]) and mid_state[2:] == want[2:]
+
+
 def test_wrong_length_log_prob_vector_is_a_value_error():
     """A vectorised log_prob_fn that returns the wrong number of values must raise, not be read past its end."""
     s, p0 = _mk(32, 3)
