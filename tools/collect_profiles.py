@@ -32,7 +32,7 @@ for which in ("pmc_fetch", "pmc_write"):
     for k, v in agg.items():
         summ[k] = dict(n=len(v), median=statistics.median(v), mean=statistics.mean(v), min=min(v), max=max(v))
 json.dump(summ, open(os.path.join(dst, "c2_pmc_summary.json"), "w"), indent=1)
-kern = "void emx::k_halfstep<8, 2, 4, 0, 4, true>(emx::HalfStepArgs)"
+kern = "void emx::k_halfstep<8, 2, 4, 0, 4, 1>(emx::HalfStepArgs)"
 fetch, write = summ[kern + " | FETCH_SIZE"]["median"], summ[kern + " | WRITE_SIZE"]["median"]
 json.dump({
     "c2_stretch_dense_bytes_per_launch": (2 * fetch + write) * 1024,
