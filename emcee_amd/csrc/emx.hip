@@ -412,7 +412,7 @@ struct emx_ctx {
     bool graph_warm = false;         // one ordinary step has run (function attributes set, kernels loaded)
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
-    int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0;
+    int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof;
@@ -556,6 +556,9 @@ int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
     return p2 < G ? p2 : G;
 }
 
+// dense Gaussian targets whose Cholesky image does not fit LDS next to the MFMA tiles (or tuning "dense_wide" = 1, for tests)
+inline bool dense_is_wide(const emx_ctx* c) { return c->Dp > 112 || c->tune_dense_wide; }
+
 // launch one fused (or propose-only) half-step over the slots [t_lo, t_hi) of `split`
 int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, int ns, int t_lo, int t_hi,
                  const emx_move_desc* mv, const emx_ctx::PlanSlot* ps, const int32_t* order,
@@ -564,6 +567,71 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     if (t_hi <= t_lo) return 0;
     const bool dense = target == EMX_TARGET_DENSE_GAUSS;
     const int D = c->D;
+    if (dense && dense_is_wide(c)) {
+        // precision matrix too wide for LDS: propose -> k_wide_lp (MFMA, L streamed through LDS) -> k_wide_commit, all on the
+        // stream (emx_wide.hip); the reference's compute_log_prob between get_proposal and the accept loop (red_blue.py:90-101)
+        if (step_desc) {
+            c->err = "wide dense target: not replayable from a step graph";
+            return -1;
+        }
+        WideLpArgs w{};
+        w.order = order ? order : (ps ? ps->order : nullptr);
+        w.img = c->tp1;
+        w.status = c->status;
+        w.t_hi_dev = t_hi_dev;
+        w.D = D;
+        w.Dp = c->Dp;
+        w.pos0 = pos0;
+        w.t_lo = t_lo;
+        w.t_hi = t_hi;
+        if (move == MOVE_EVAL) {
+            w.rows = X;
+            w.out = lp;
+            w.scatter = 1;
+            w.check_bad = 0;
+            if (launch_wide_lp(w, t_hi - t_lo, c->num_cu, c->stream) != hipSuccess) {
+                c->err = "wide dense target: log-prob kernel launch failed";
+                return -2;
+            }
+            return 0;
+        }
+        if (!ps) {
+            c->err = "wide dense target: half-step without a plan";
+            return -1;
+        }
+        int rc = launch_split(c, move, EMX_TARGET_HOST, S, split, pos0, ns, t_lo, t_hi, mv, ps, order, X, lp, nullptr, nullptr,
+                              nullptr, nullptr, t_hi_dev);
+        if (rc) return rc;
+        w.rows = c->qout;
+        w.order = nullptr;
+        w.out = c->newlp;
+        w.scatter = 0;
+        w.check_bad = 1;
+        WideCommitArgs k{};
+        k.X = X;
+        k.lp = lp;
+        k.acc = c->acc;
+        k.acc_count = c->acc_count;
+        k.chain = chain;
+        k.chain_lp = chain_lp;
+        k.sendbuf = sendbuf;
+        k.qout = c->qout;
+        k.fout = c->fout;
+        k.newlp = c->newlp;
+        k.order = order ? order : ps->order;
+        k.logu = ps->logu;
+        k.t_hi_dev = t_hi_dev;
+        k.D = D;
+        k.pos0 = pos0;
+        k.t_lo = t_lo;
+        k.t_hi = t_hi;
+        if (launch_wide_lp(w, t_hi - t_lo, c->num_cu, c->stream) != hipSuccess ||
+            launch_wide_commit(k, t_hi - t_lo, c->num_cu, c->stream) != hipSuccess) {
+            c->err = "wide dense target: kernel launch failed";
+            return -2;
+        }
+        return 0;
+    }
     const Shape sh = pick_shape(D, dense ? c->Dp : D);
     const int WPW = 64 / sh.G;
     const int nown = t_hi - t_lo;
@@ -961,6 +1029,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_wpb = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;   // 0: automatic
         return 0;
     }
+    if (!strcmp(key, "dense_wide")) {      // 1: take the wide-target path (emx_wide.hip) whatever the ndim -- parity tests against the fused kernel
+        c->tune_dense_wide = v ? 1 : 0;
+        graph_invalidate(c);
+        return 0;
+    }
     if (!strcmp(key, "blocks_per_cu")) {
         c->tune_bpc = v > 0 ? v : 2;
         return 0;
@@ -1012,8 +1085,7 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
         std::vector<double> img;
         if (kind == EMX_TARGET_DENSE_GAUSS) {
             nDp = (int)((D + 15) / 16 * 16);
-            NEED(c, nDp <= 112 && dense_lds_bytes(nDp, 1) <= 160 * 1024,
-                 "dense Gaussian target supports ndim <= 112 (LDS-resident precision matrix); got %d", c->D);
+            NEED(c, nDp <= 2048, "dense Gaussian target supports ndim <= 2048; got %d", c->D);
             // -0.5 d^T A d with A = sym(icov) = L L^T  ==  -0.5 |L^T d|^2.  Factor once on the host and upload the
             // image the kernel stages into LDS: L in MFMA B-fragment order (zero padded) followed by the mean.
             const int Dp = nDp, KK = Dp / 4, n = (int)D;
@@ -1903,7 +1975,7 @@ static bool small_eligible(const emx_ctx* c) {
     if (c->world != 1 || c->comm || c->sendbuf || c->prof_max > 0 || c->tune_ablate || c->cur.active) return false;
     if (c->N > 4096 || c->D > 256) return false;
     if (c->target == EMX_TARGET_DENSE_GAUSS)     // one CU's matrix pipe: worth it only while the contraction is small
-        return c->N * (int64_t)c->Dp * c->Dp <= 65536 && small_lds_bytes(c->N, c->D, c->Dp, 1) <= 150 * 1024;
+        return !dense_is_wide(c) && c->N * (int64_t)c->Dp * c->Dp <= 65536 && small_lds_bytes(c->N, c->D, c->Dp, 1) <= 150 * 1024;
     return small_lds_bytes(c->N, c->D) <= 150 * 1024;
 }
 

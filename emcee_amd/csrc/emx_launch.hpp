@@ -28,4 +28,34 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
 // while the same flag costs the element-wise kernels up to 6 % (C3), so it is not a global build flag.
 hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a);
 
+// Wide dense Gaussian targets (padded ndim > 112, emx_wide.hip): log-probs of a block of rows, and the decision + commit
+// of a half-step whose proposals sit in qout / fout.
+struct WideLpArgs {
+    const double* rows;          // row of slot t: rows + (order ? order[pos0 + t] : t) * D
+    const int32_t* order;
+    const double* img;           // the target image of emx_set_target: L in B-fragment order, then the padded mean
+    double* out;                 // out[t], or out[order[pos0 + t]] with `scatter`
+    uint32_t* status;
+    const int32_t* t_hi_dev;     // device-side slot count (block-ownership exchanges), or nullptr
+    int32_t D, Dp, pos0, t_lo, t_hi, scatter, check_bad;
+};
+struct WideCommitArgs {
+    double* X;
+    double* lp;
+    uint8_t* acc;
+    uint32_t* acc_count;
+    double* chain;
+    double* chain_lp;
+    double* sendbuf;
+    const double* qout;
+    const double* fout;
+    const double* newlp;
+    const int32_t* order;
+    const double* logu;
+    const int32_t* t_hi_dev;
+    int32_t D, pos0, t_lo, t_hi;
+};
+hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipStream_t st);
+hipError_t launch_wide_commit(const WideCommitArgs& a, int nrows_bound, int num_cu, hipStream_t st);
+
 }  // namespace emx

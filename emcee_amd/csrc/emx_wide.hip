@@ -1,0 +1,308 @@
+// Dense Gaussian targets too wide for the LDS-resident precision matrix (padded ndim > 112): the half-step is
+//   k_halfstep (propose only: q, factor -> qout / fout)  ->  k_wide_lp  ->  k_wide_commit
+// all on the device, on the context's stream.  The reference evaluates the same thing as one vectorised log_prob_fn
+// call on the proposal block (ensemble.py:486-501, compute_log_prob) between get_proposal and the accept loop
+// (red_blue.py:90-101).
+//
+// k_wide_lp is f64-MFMA-bound (D^2 flop against 8 D bytes per row):  Y = R L with R = Q - mu (rows x Dp) and L the lower
+// Cholesky factor of the precision matrix, log-prob = -0.5 * rowsum(Y^2) -- the contraction of k_halfstep's dense stage, in
+// the same association order (column blocks ascending, k ascending from the diagonal block, squares folded per column
+// block), so the two paths agree bit for bit on an ndim both can take.  One wave owns a 16-row tile and walks the
+// non-zero 16x16 blocks of L in 128-column macro blocks (8 accumulators); the workgroup's waves share each 16 x 128 slab of L
+// through LDS (double-buffered, one barrier per slab = 32 MFMAs per wave); a wave's rows arrive as 128-byte pieces (four
+// lanes per row), pass through a 16 x 16 LDS tile of its own and come back as A fragments.  Every load is issued a whole
+// slab before its first use, and nothing touches a loaded register in between (a select or a compare on a loaded value
+// there cost a vmcnt(0) in the issue phase: 23 % of the kernel, measured).
+#include <algorithm>
+
+#include "emx_launch.hpp"
+
+namespace emx {
+
+namespace {
+
+constexpr int SLAB = 32 * 64;        // doubles per slab: 4 k-steps x 8 column blocks x 64 lanes (B-fragment order)
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// one slab against the first NC column blocks of the macro block
+template <int NC, int I0, int I1>
+__device__ __forceinline__ void slab_mfma(double4_t (&acc)[8], const double (&afr)[4], const double* bs, int lane) {
+    double b[2][NC];          // the B fragments of k-step i + 1 are read while the MFMAs of k-step i are issued
+#pragma unroll
+    for (int j = 0; j < NC; ++j) b[I0 & 1][j] = bs[(j * 4 + I0) * 64 + lane];
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        if (i + 1 < I1) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) b[(i + 1) & 1][j] = bs[(j * 4 + i + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[i], b[i & 1][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+constexpr int ART = 18;              // A-tile row stride (doubles): conflict-free fragment reads, 16-byte aligned rows
+typedef double double2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+__host__ __device__ constexpr size_t wide_lds_bytes(int Dp, int W) {
+    return ((size_t)2 * SLAB + (size_t)Dp + (size_t)W * 16 * ART) * sizeof(double);
+}
+
+// Staging at the end of the slab costs the matrix pipe about 1 100 of every 5 300 cycles at ndim 512 (MFMA issue is in order
+// and blocks its wave; the two waves of a SIMD stage at the same time).  Three ways of hiding it were measured on MI355X and
+// dropped (profiles/r02/wide_dense.txt): two four-wave groups half an iteration apart on two barriers per slab (+18 %
+// time: a single wave issues f64 MFMAs at 70, not 64, cycles and both barriers are exposed), staging skewed into the MFMA
+// stream after k-step 1 / 3 (+-1 %), two co-resident 4-wave workgroups (they are not co-scheduled: +40 %).
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
+    constexpr int NT = 64 * W;
+    constexpr int NTG = NT;
+    constexpr int NLD = SLAB / 2 / NTG;           // double2 per thread and slab
+    extern __shared__ __attribute__((aligned(16))) double dsm[];      // slab[2][SLAB] | mu[Dp] | per wave: A tile [16][ART]
+    typedef double4_t d4;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, tx = threadIdx.x;
+    const int gtx = tx;
+    double* Bs = dsm;
+    const int am = lane & 15, ak = lane >> 4;             // MFMA A-fragment coordinates
+    const int arow = lane >> 2, aseg = lane & 3;          // row loads: four lanes cover one 128-byte piece of a row
+    const int D = A.D, Dp = A.Dp, DPB = Dp / 16, KK = Dp / 4;
+    const int t_hi = A.t_hi_dev ? *A.t_hi_dev : A.t_hi;
+    const int ntiles = (t_hi - A.t_lo + 15) / 16;
+    const double2* img2 = reinterpret_cast<const double2*>(A.img);
+    const int nmacro = (DPB + 7) / 8;
+    double* muS = dsm + (size_t)2 * SLAB;
+    double* At = muS + Dp + wib * 16 * ART;
+    for (int d = tx; d < Dp; d += NT) muS[d] = A.img[(size_t)Dp * Dp + d];      // zero padded beyond D
+    __syncthreads();
+    // this thread's pieces of a slab: double2 number e = gtx + r NTG of the 32 chunks (column block j, k-step i) x 32
+    int boff[NLD], bj[NLD];
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+        const int e = gtx + r * NTG, chunk = e >> 5, within = e & 31;
+        bj[r] = chunk >> 2;
+        boff[r] = ((chunk >> 2) * KK + (chunk & 3)) * 32 + within;
+    }
+
+    for (int base = blockIdx.x * W; base < ntiles; base += gridDim.x * W) {      // workgroup-uniform
+        const int tile = base + wib;
+        const int t = A.t_lo + tile * 16 + arow;
+        const bool rowlive = tile < ntiles && t < t_hi;
+        const double* rowp = A.rows + (size_t)(rowlive ? (A.order ? A.order[A.pos0 + t] : t) : 0) * D;
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+        bool bad = false;
+        d4 acc[8];
+        double2 bn[NLD];
+        double afr[4], araw[4], mraw[4], xn[4];
+        int kn = 0;
+
+        // slab (nbb, sp): k rows 16 (8 nbb + sp) ..+16, columns 128 nbb ..+128.  Raw loads only: their first use
+        // (consume) comes after the current slab's MFMAs.
+        auto issue = [&](int nbb, int sp) {
+            const int ncb = min(8, DPB - 8 * nbb), kk0 = 4 * (8 * nbb + sp);
+            const double2* src = img2 + ((size_t)(8 * nbb) * KK + kk0) * 32;           // wave-uniform
+#pragma unroll
+            for (int r = 0; r < NLD; ++r) bn[r] = bj[r] < ncb ? src[boff[r]] : double2{0.0, 0.0};
+            kn = 4 * kk0 + 4 * aseg;
+            if (16 * (8 * nbb + sp) + 16 <= D) {               // wave-uniform: the whole k block lies inside the row
+                const double* rp = rowlive ? rowp + kn : A.rows;        // dead rows read row 0 (finite or not, never used)
+                const double2_a8 lo = *reinterpret_cast<const double2_a8*>(rp);
+                const double2_a8 hi = *reinterpret_cast<const double2_a8*>(rp + 2);
+                xn[0] = lo.x;                                  // raw: masked in consume (no use of a loaded value here)
+                xn[1] = lo.y;
+                xn[2] = hi.x;
+                xn[3] = hi.y;
+            } else {                                           // the ragged last k block of a row (ndim not a multiple of 16)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xn[e] = rowp[min(kn + e, D - 1)];
+            }
+        };
+        // Staging half: the raw row values go into the wave's A tile and come back as this lane's four A fragments, with the
+        // matching pieces of the mean.  No f64 arithmetic here: the f64 VALU shares the pipe the OTHER group's MFMAs are
+        // queued on (measured: four v_add_f64 + four v_cmp_f64 in this place cost 1 900 cycles per slab) -- the mask and the
+        // finiteness test are integer operations, the subtraction waits for this group's own turn (finish).
+        auto consume = [&]() {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xn[e] = (rowlive && kn + e < D) ? xn[e] : 0.0;
+                bad |= (__double2hiint(xn[e]) & 0x7ff00000) == 0x7ff00000;
+            }
+            double2* dst = reinterpret_cast<double2*>(At + arow * ART + 4 * aseg);
+            dst[0] = double2{xn[0], xn[1]};
+            dst[1] = double2{xn[2], xn[3]};
+            EMX_WAVE_SYNC();
+            const int kf = kn - 4 * aseg + ak;                 // first k of this lane's fragments
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                araw[i] = At[am * ART + 4 * i + ak];
+                mraw[i] = muS[kf + 4 * i];
+            }
+            EMX_WAVE_SYNC();
+        };
+        auto finish = [&]() {                                  // R = Q - mu: the A fragments of the slab about to be multiplied
+#pragma unroll
+            for (int i = 0; i < 4; ++i) afr[i] = araw[i] - mraw[i];
+        };
+        auto publish = [&](int buf) {
+            double2* dst = reinterpret_cast<double2*>(Bs + (size_t)buf * SLAB);
+#pragma unroll
+            for (int r = 0; r < NLD; ++r) dst[gtx + r * NTG] = bn[r];
+        };
+
+        // slab order: macro block by macro block, k blocks from the diagonal down
+        auto next_of = [&](int& nb_, int& sp_) {
+            if (++sp_ == DPB - 8 * nb_) {
+                ++nb_;
+                sp_ = 0;
+            }
+        };
+        int nbb = 0, sp = 0, buf = 0;
+        int nbl = 0, spl = 0;                                  // the slab whose loads are in flight
+        issue(0, 0);
+        publish(0);
+        consume();
+        next_of(nbl, spl);
+        if (nbl < nmacro) issue(nbl, spl);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+        __syncthreads();
+        for (;;) {
+            const int ncb = min(8, DPB - 8 * nbb), nsl = DPB - 8 * nbb;
+            const bool last = (sp == nsl - 1) && nbb + 1 >= nmacro;
+            finish();
+            const int jlim = min(ncb - 1, sp);                 // column block j starts at its diagonal block: k block >= j
+            const double* bs = Bs + (size_t)buf * SLAB;
+#define EMX_SLAB_STEPS(I0, I1)                                                  \
+    switch (jlim) {                                                            \
+        case 7: slab_mfma<8, I0, I1>(acc, afr, bs, lane); break;               \
+        case 6: slab_mfma<7, I0, I1>(acc, afr, bs, lane); break;               \
+        case 5: slab_mfma<6, I0, I1>(acc, afr, bs, lane); break;               \
+        case 4: slab_mfma<5, I0, I1>(acc, afr, bs, lane); break;               \
+        case 3: slab_mfma<4, I0, I1>(acc, afr, bs, lane); break;               \
+        case 2: slab_mfma<3, I0, I1>(acc, afr, bs, lane); break;               \
+        case 1: slab_mfma<2, I0, I1>(acc, afr, bs, lane); break;               \
+        default: slab_mfma<1, I0, I1>(acc, afr, bs, lane); break;              \
+    }
+            // the next slab's operands: loaded during the previous slab, to LDS now, and the loads of the slab after issued
+            auto stage = [&]() {
+                if (last) return;
+                __builtin_amdgcn_sched_barrier(0);
+                publish(buf ^ 1);
+                consume();
+                next_of(nbl, spl);
+                if (nbl < nmacro) issue(nbl, spl);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            EMX_SLAB_STEPS(0, 4);
+            stage();
+#undef EMX_SLAB_STEPS
+            if (sp == nsl - 1) {                               // macro block complete: fold the squares, column blocks ascending
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < ncb) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[r] = fma(acc[j][r], acc[j][r], part[r]);
+                    }
+                    acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+                }
+            }
+            __syncthreads();                                   // slab s + 1 is published; nobody reads slab s any more
+            if (last) break;
+            next_of(nbb, sp);
+            buf ^= 1;
+        }
+
+        // lane (am, ak) ends with the total of tile row ak + 4 (am & 3)
+        const double qf = row16_sum4(part[0], part[1], part[2], part[3], lane);
+        const int myrow = (lane >> 4) + 4 * (lane & 3);
+        const int tt = A.t_lo + tile * 16 + myrow;
+        const unsigned long long bm = __ballot(bad);          // lanes 4 r .. 4 r + 3 loaded row r
+        const bool rowbad = A.check_bad && ((bm >> (4 * myrow)) & 0xFull);
+        if ((lane & 15) < 4 && tile < ntiles && tt < t_hi) {
+            const double lpn = rowbad ? -__builtin_inf() : -0.5 * qf;        // a non-finite proposal is rejected (ensemble.py:476-479 raised already)
+            if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);             // ensemble.py:550-551
+            A.out[A.scatter ? (A.order ? A.order[A.pos0 + tt] : tt) : tt] = lpn;
+        }
+    }
+}
+
+// decision + commit of one half-step from (qout, fout, newlp): red_blue.py:96-101, move.py:33-34; one wave per slot
+__global__ __launch_bounds__(256) void k_wide_commit(const WideCommitArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int t_hi = A.t_hi_dev ? *A.t_hi_dev : A.t_hi;
+    const int D = A.D;
+    for (int t = A.t_lo + blockIdx.x * 4 + (threadIdx.x >> 6); t < t_hi; t += gridDim.x * 4) {
+        const int pos = A.pos0 + t;
+        const int i = A.order[pos];
+        const double nlp = A.newlp[t], lp_old = A.lp[i];
+        const double lnpdiff = A.fout[t] + nlp - lp_old;                     // red_blue.py:99
+        const bool accept = lnpdiff > A.logu[pos];                          // red_blue.py:100
+        const double* q = A.qout + (size_t)t * D;
+        double* xr = A.X + (size_t)i * D;
+        double* ch = A.chain ? A.chain + (size_t)i * D : nullptr;
+        double* sb = A.sendbuf ? A.sendbuf + (size_t)(t - A.t_lo) * (D + 2) : nullptr;
+        for (int d = lane; d < D; d += 64) {
+            const double v = accept ? q[d] : xr[d];
+            if (accept) xr[d] = v;
+            if (ch) ch[d] = v;
+            if (sb) sb[d] = v;
+        }
+        if (lane == 0) {
+            const double lp_fin = accept ? nlp : lp_old;
+            if (accept) A.lp[i] = nlp;
+            A.acc[i] = accept ? 1 : 0;
+            if (A.chain_lp) {
+                A.chain_lp[i] = lp_fin;
+                if (accept) A.acc_count[i] += 1u;
+            }
+            if (sb) {
+                sb[D] = lp_fin;
+                sb[D + 1] = accept ? 1.0 : 0.0;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace {
+
+template <int W>
+hipError_t launch_lp(const WideLpArgs& a, dim3 grid, hipStream_t st) {
+    const size_t lds = wide_lds_bytes(a.Dp, W);               // up to 66 KB: above the 64 KB a kernel gets without asking
+    static size_t lds_granted[MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)k_wide_lp<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_granted[dev] = lds;
+    }
+    hipLaunchKernelGGL(k_wide_lp<W>, grid, dim3(64 * W), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipStream_t st) {
+    if (nrows_bound <= 0) return hipSuccess;
+    const int ntiles = (nrows_bound + 15) / 16;
+    // wide workgroups share each slab of L among more rows; few tiles spread over more CUs instead
+    const int W = ntiles >= 8 * num_cu ? 8 : ntiles >= 4 * num_cu ? 4 : ntiles >= 2 * num_cu ? 2 : 1;
+    const int nblocks = (ntiles + W - 1) / W;
+    const dim3 grid((unsigned)std::min(nblocks, 4 * num_cu));
+    switch (W) {
+        case 8: return launch_lp<8>(a, grid, st);
+        case 4: return launch_lp<4>(a, grid, st);
+        case 2: return launch_lp<2>(a, grid, st);
+        default: return launch_lp<1>(a, grid, st);
+    }
+}
+
+hipError_t launch_wide_commit(const WideCommitArgs& a, int nrows_bound, int num_cu, hipStream_t st) {
+    if (nrows_bound <= 0) return hipSuccess;
+    const int nblocks = (nrows_bound + 3) / 4;
+    hipLaunchKernelGGL(k_wide_commit, dim3((unsigned)std::min(nblocks, 64 * num_cu)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace emx

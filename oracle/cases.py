@@ -58,6 +58,10 @@ CASES = {
     "stretch_box_32x1": dict(N=32, D=1, target="box", moves=[_S("stretch")], nsteps=40, seed=51, p0="uniform"),
     "stretch_thin3_32x2": dict(N=32, D=2, target="iso", moves=[_S("stretch")], nsteps=8, thin_by=3, seed=61),
     "stretch_wide_16x130_live": dict(N=16, D=130, target="diag", moves=[_S("stretch", live_dangerously=True)], nsteps=6, seed=71),
+    # dense precision matrices wider than LDS (padded ndim > 112): the propose -> MFMA log-prob -> commit path of emx_wide.hip
+    "stretch_48x130_dense": dict(N=48, D=130, target="dense", moves=[_S("stretch", live_dangerously=True)], nsteps=5, seed=81),
+    "mix_de_snooker_40x113_dense": dict(N=40, D=113, target="dense", nsteps=8, seed=82, weights=[0.7, 0.3],
+                                        moves=[_S("de", live_dangerously=True), _S("snooker", live_dangerously=True)]),
     "de_64x4_iso": dict(N=64, D=4, target="iso", moves=[_S("de")], nsteps=20, seed=101),
     "de_g1_s01_30x3": dict(N=30, D=3, target="iso", moves=[_S("de", gamma0=1.0, sigma=0.1)], nsteps=20, seed=102),
     "snooker_64x4_iso": dict(N=64, D=4, target="iso", moves=[_S("snooker")], nsteps=20, seed=201),
@@ -88,6 +92,8 @@ DIGEST_CASES = {
     "stretch_4096x64_dense": dict(N=4096, D=64, target="dense", moves=[_S("stretch")], nsteps=3, seed=401),
     "stretch_2048x32_rosen": dict(N=2048, D=32, target="rosenbrock", moves=[_S("stretch")], nsteps=3, seed=402, p0="rosen"),
     "stretch_2048x1024_diag": dict(N=2048, D=1024, target="diag", moves=[_S("stretch")], nsteps=2, seed=403),
+    "stretch_1024x256_dense": dict(N=1024, D=256, target="dense", moves=[_S("stretch")], nsteps=2, seed=405),
+    "stretch_1100x520_dense": dict(N=1100, D=520, target="dense", moves=[_S("stretch")], nsteps=2, seed=406),
     "mix_de_snooker_1024x64_dense": dict(N=1024, D=64, target="dense", moves=[_S("de"), _S("snooker")], weights=[0.8, 0.2], nsteps=6, seed=404),
 }
 

@@ -24,7 +24,7 @@ def configs():
             kind = ["stretch", "de", "snooker"][rs.randint(3)] if D <= 256 else "stretch"
             if kind == "snooker" and D > 128:
                 kind = "de"
-            targets = ["iso", "diag", "rosenbrock"] + (["dense"] if D <= 112 else [])
+            targets = ["iso", "diag", "rosenbrock"] + (["dense"] if D <= 1030 else [])
             target = targets[rs.randint(len(targets))]
             nsplits = 4 if kind == "snooker" else int(rs.randint(2, 5))
             N = int(2 * D + rs.randint(nsplits * 2 + 2, 40)) if D <= 300 else int(nsplits * 3 + rs.randint(0, 9))
@@ -66,7 +66,7 @@ def sharded_configs():
         kind = ["stretch", "de", "snooker", "gaussian"][rs.randint(4)]
         if D > 128 and kind == "snooker":
             kind = "stretch"
-        targets = ["iso", "diag", "rosenbrock"] + (["dense"] if D <= 112 else [])
+        targets = ["iso", "diag", "rosenbrock"] + (["dense"] if D <= 1030 else [])
         target = targets[rs.randint(len(targets))]
         nsplits = 4 if kind == "snooker" else int(rs.randint(2, 4))
         world = int(rs.randint(2, 9))

@@ -124,7 +124,8 @@ def test_exact_mode_mid_size_against_oracle(name):
 
 NATIVE_CASES = ["c1_stretch_32x5_iso", "stretch_50x3_iso", "stretch_128x64_dense", "stretch_128x8_rosen",
                 "stretch_nsplits3_45x2", "stretch_wide_16x130_live", "de_64x4_iso", "de_g1_s01_30x3",
-                "snooker_64x4_iso", "snooker_38x3_diag", "mix_de_snooker_128x8_dense", "stretch_box_32x1"]
+                "snooker_64x4_iso", "snooker_38x3_diag", "mix_de_snooker_128x8_dense", "stretch_box_32x1",
+                "stretch_48x130_dense", "mix_de_snooker_40x113_dense"]
 
 
 @pytest.mark.parametrize("name", NATIVE_CASES)
@@ -198,7 +199,8 @@ def test_host_target_split_phase_equals_fused(name):
 @pytest.mark.parametrize("kind,D", [("iso", 1), ("iso", 5), ("iso", 64), ("iso", 129), ("diag", 7), ("diag", 1024),
                                     ("diag", 2048), ("rosenbrock", 2), ("rosenbrock", 32), ("rosenbrock", 33),
                                     ("rosenbrock", 300), ("dense", 3), ("dense", 16), ("dense", 17), ("dense", 64),
-                                    ("dense", 100), ("dense", 112), ("box", 3)])
+                                    ("dense", 100), ("dense", 112), ("dense", 113), ("dense", 128), ("dense", 129),
+                                    ("dense", 200), ("dense", 257), ("dense", 512), ("dense", 1000), ("dense", 2048), ("box", 3)])
 def test_batched_log_prob_eval(kind, D):
     rs = np.random.RandomState(D)
     N = 200
@@ -220,9 +222,9 @@ def test_batched_log_prob_eval(kind, D):
 
 
 def test_dense_ndim_limit_is_loud():
-    ens = _dev()(300, 128)
+    ens = _dev()(8, 2049)
     with pytest.raises(_lib.EmxError):
-        ens.set_target(_lib.TARGET_DENSE, np.zeros(128), np.eye(128))
+        ens.set_target(_lib.TARGET_DENSE, np.zeros(2049), np.eye(2049))
     ens.close()
 
 

@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
     ("stretch_128x64_dense", 4, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt"),
     ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
     ("stretch_nsplits3_45x2", 2, "mt"), ("mix_stretch_gauss_32x3", 2, "mt"), ("gauss_diag_random_factor_30x4", 3, "philox"),
+    ("stretch_48x130_dense", 2, "mt"), ("mix_de_snooker_40x113_dense", 3, "philox"),
 ])
 def test_logical_ranks_equal_single_rank(name, world, rng):
     import torch
@@ -90,6 +91,7 @@ def _run_step(group, steppers):
     ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
     ("stretch_nsplits3_45x2", 2, "mt"), ("stretch_50x3_iso", 7, "philox"),
     ("mix_stretch_gauss_32x3", 2, "mt"), ("gauss_diag_random_factor_30x4", 3, "philox"),
+    ("stretch_48x130_dense", 3, "philox"), ("mix_de_snooker_40x113_dense", 2, "mt"),
 ])
 def test_pull_exchange_equals_single_rank(name, world, rng):
     """Pull exchange (walker-block ownership, partner rows only): each logical rank's block of the chain,
@@ -168,6 +170,7 @@ DIRECT_CASES = [
     ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
     ("stretch_nsplits3_45x2", 2, "mt"), ("stretch_50x3_iso", 7, "philox"),
     ("mix_stretch_gauss_32x3", 2, "mt"), ("gauss_diag_random_factor_30x4", 3, "philox"),
+    ("stretch_48x130_dense", 2, "philox"), ("mix_de_snooker_40x113_dense", 2, "mt"),
 ]
 
 

@@ -1,0 +1,104 @@
+"""Dense Gaussian targets wider than the LDS-resident precision matrix (padded ndim > 112; emx_wide.hip):
+propose -> k_wide_lp (f64 MFMA, L streamed through LDS) -> k_wide_commit, all on the device.
+
+The reference fixtures of such targets (stretch_48x130_dense, mix_de_snooker_40x113_dense, the 256- and 520-dim digest
+cases) run through the generic parity tests (test_gpu_parity.py, test_gpu_sharded.py).  Here: the wide path against
+the FUSED kernel on dimensions both can take -- same contraction order, so the chains must agree bit for bit -- and
+ragged / multi-macro-block shapes against the oracle."""
+import numpy as np
+import pytest
+
+from emcee_amd import _lib
+from oracle import cases
+from oracle import sampler_oracle as so
+
+from emx_testlib import cdf_of, move_desc
+from test_gpu_parity import LP_RTOL, assert_lp_close, make_ens
+
+pytestmark = pytest.mark.gpu
+
+_S = so.MoveSpec
+
+
+def _spec(N, D, moves, weights=None, seed=3):
+    mu, cov, icov = cases._dense_params(D, seed + 1000)
+    rs = np.random.RandomState(seed)
+    p0 = mu + rs.randn(N, D) @ np.linalg.cholesky(cov).T
+    return dict(N=N, D=D, desc=dict(kind="dense", mu=mu, cov=cov, icov=icov), moves=moves, weights=weights, p0=p0, seed=seed)
+
+
+@pytest.mark.parametrize("N,D,moves,weights", [
+    (600, 64, [_S("stretch")], None),
+    (333, 100, [_S("stretch", nsplits=3)], None),
+    (512, 48, [_S("de"), _S("snooker")], [0.6, 0.4]),
+    (400, 17, [_S("stretch"), _S("gaussian", cov=0.01)], [0.5, 0.5]),
+    (4100, 112, [_S("stretch")], None),
+])
+@pytest.mark.parametrize("store", [True, False])
+def test_wide_path_equals_fused_kernel_bit_for_bit(N, D, moves, weights, store):
+    spec = _spec(N, D, moves, weights)
+    outs = []
+    for wide in (0, 1):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_tuning("dense_wide", wide)
+        ens.set_tuning("small_kernel", 0)
+        ens.set_tuning("graph", 0)
+        ens.eval_state_log_prob()
+        lp0 = ens.get_state()[1]
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(90210, 0)
+        nst = 12
+        ens.chain_config(nst)
+        ens.run(nst, 1, store)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(lp0=lp0, x=x, lp=lp, acc=ens.accepted_mask().copy())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, nst), clp=ens.chain_read(1, 0, nst), cnt=ens.accepted_counts())
+        outs.append(rec)
+        ens.close()
+    a, b = outs
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    if store:
+        assert a["cnt"].sum() > 0
+
+
+@pytest.mark.parametrize("N,D", [(64, 113), (300, 130), (1000, 160), (77, 257), (2100, 384), (40, 1000)])
+def test_wide_stretch_steps_against_oracle(N, D):
+    """Exact mode, free-running from a seeded generator: accept decisions and coordinates equal to the oracle's
+    (stretch proposals involve no reduction), log-probs within the dense-target tolerance."""
+    spec = _spec(N, D, [_S("stretch", live_dangerously=True)], seed=D)
+    fn = cases.make_target(spec["desc"])
+    nst = 3
+    rs = np.random.RandomState(1234 + D)
+    out = so.run(spec["p0"], nst, fn, np.random.RandomState(1234 + D), moves=spec["moves"], weights=None, thin_by=1)
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_MT19937)
+    ens.set_mt19937(rs.get_state())
+    ens.chain_config(nst)
+    ens.run(nst, 1, True)
+    assert ens.status() == 0
+    assert np.array_equal(ens.accepted_counts(), out["accepted_count"])
+    assert np.array_equal(ens.chain_read(0, 0, nst), out["chain"])
+    assert_lp_close(ens.chain_read(1, 0, nst), out["log_prob"], 1e-10)
+    ens.close()
+
+
+def test_wide_non_finite_proposal_is_rejected_and_reported():
+    """ensemble.py:476-479: a non-finite coordinate raises; on the device the proposal is rejected and the sticky status
+    bit is set, whichever path evaluates the target."""
+    N, D = 64, 130
+    spec = _spec(N, D, [_S("stretch", live_dangerously=True)])
+    p0 = np.full((N, D), 1.7e308)          # x_j - x_k overflows for every pair of opposite sign
+    p0[1::2] = -1.7e308
+    ens = make_ens(spec, spec["p0"])
+    ens.set_state(p0)
+    ens.eval_state_log_prob()
+    ens.set_rng_mode(_lib.RNG_PHILOX)
+    ens.set_philox(5, 0)
+    ens.run(2, 1, False)
+    assert ens.status() & 2, "bad-coordinate bit"
+    x, lp = ens.get_state()
+    assert np.all(np.isfinite(x))
+    ens.close()
