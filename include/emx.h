@@ -81,6 +81,7 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  * "small_kernel" (1: ensembles that fit one CU's LDS run whole emx_run calls in one workgroup; default),
  * "mt_pipeline" (MT19937 mode, emx_run: -1 plans from the threaded host pipeline, finisher threads chosen from the core
  * count (default); k > 0: k finisher threads; 0: plans made inline by the calling thread),
+ * "dense_wide" (1: dense targets take the propose / log-prob / commit path of wide targets whatever the ndim; parity tests),
  * "phase_clock" (instrumented builds) */
 int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value);
 
@@ -91,7 +92,9 @@ int emx_get_accepted(emx_ctx* ctx, uint8_t* mask /* N */); /* `accepted` of the 
 
 /* ---- target: the batched log-prob (ensemble.py:458-553, vectorised) -------------------- */
 /* p0/p1: DIAG (mu, ivar); DENSE (mu, icov[D*D], symmetric positive definite: factored once as
- * L L^T, the kernel evaluates -0.5 |L^T (x-mu)|^2); others NULL.  scale: Rosenbrock divisor. */
+ * L L^T, the kernel evaluates -0.5 |L^T (x-mu)|^2 with f64 MFMAs: fused into the half-step kernel up to
+ * ndim 112, as a log-prob kernel of its own between propose and commit up to ndim 2048); others NULL.
+ * scale: Rosenbrock divisor. */
 int emx_set_target(emx_ctx* ctx, int32_t kind, const double* p0, const double* p1, double scale);
 /* log-prob of the current state, stored as the state's log_prob (ensemble.py:350-351) */
 int emx_eval_state_log_prob(emx_ctx* ctx);
