@@ -98,6 +98,8 @@ if __name__ == "__main__":
              dict(N=1024, D=16, target="iso", steps=2000)]
     if only == "gauss":
         cfgs = [c for c in cfgs if c.get("move") == 3]
+    if only == "moves":      # the dense 64-dim shape under every move
+        cfgs = [c for c in cfgs if c.get("target") == "dense" and c.get("move", 0) in (1, 2, 3) and "rng" not in c]
     for c in cfgs:
         try:
             r = run(**c)
