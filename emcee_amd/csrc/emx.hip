@@ -286,6 +286,8 @@ struct emx_ctx {
     double *X = nullptr, *lp = nullptr;
     uint8_t* acc = nullptr;
     uint32_t *acc_count = nullptr, *status = nullptr;
+    char* bounce[2] = {nullptr, nullptr};      // pinned halves of the large-copy pipeline (big_copy_to_host)
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     char* xfer_host = nullptr;         // pinned bounce buffer for small split-phase transfers (a D2H copy into pageable
     size_t xfer_bytes = 0;             // memory costs ~2x the latency of one into pinned memory + a host memcpy)
     uint32_t* status_host = nullptr;   // `status` lives in mapped pinned host memory: kernels only touch it on errors
@@ -901,6 +903,10 @@ int emx_destroy(emx_ctx* c) {
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm), c->comm = nullptr;
     if (c->status_host) hipHostFree(c->status_host);
     if (c->xfer_host) hipHostFree(c->xfer_host);
+    for (int k = 0; k < 2; ++k) {
+        if (c->bounce[k]) hipHostFree(c->bounce[k]);
+        if (c->bounce_ev[k]) hipEventDestroy(c->bounce_ev[k]);
+    }
     void* ptrs[] = {c->X, c->lp, c->acc, c->acc_count, c->iota, c->qout, c->fout, c->newlp, c->evalX,
                     c->evallp, c->tp0, c->tp1, c->chain, c->chain_lp, c->own_shard_bufs ? c->sendbuf : nullptr,
                     c->own_shard_bufs ? c->gathered : nullptr};
@@ -1041,9 +1047,81 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     FAIL(c, -1, "unknown tuning key %s", key);
 }
 
+// Device -> host copies of more than a few MB into ordinary (pageable) memory: HIP's own path managed 1.6 GB/s into a fresh
+// NumPy array on the GPU box (21 ms for the 33.5 MB state at 65 536 x 64).  Here the data crosses PCIe into two pinned 8 MB
+// halves in turn and a host memcpy empties one while the DMA fills the other.  Synchronous; small copies and copies into
+// memory the caller pinned go straight through.  Returns with everything enqueued on the stream before it complete.
+static int big_copy_to_host(emx_ctx* c, void* dst, const void* src, size_t bytes) {
+    constexpr size_t CH = 8u << 20;
+    if (bytes == 0) return 0;
+    bool direct = bytes < (2u << 20);
+    if (!direct) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) == hipSuccess) direct = at.type == hipMemoryTypeHost;      // pinned by the caller
+        else (void)hipGetLastError();                                                                     // ordinary memory
+    }
+    if (direct) {
+        HIPOK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!c->bounce[k]) HIPOK(c, hipHostMalloc((void**)&c->bounce[k], CH, hipHostMallocDefault));
+        if (!c->bounce_ev[k]) HIPOK(c, hipEventCreateWithFlags(&c->bounce_ev[k], hipEventDisableTiming));
+    }
+    const size_t nch = (bytes + CH - 1) / CH;
+    auto issue = [&](size_t k) -> hipError_t {
+        const size_t off = k * CH, n = std::min(CH, bytes - off);
+        hipError_t e = hipMemcpyAsync(c->bounce[k & 1], (const char*)src + off, n, hipMemcpyDeviceToHost, c->stream);
+        return e != hipSuccess ? e : hipEventRecord(c->bounce_ev[k & 1], c->stream);
+    };
+    HIPOK(c, issue(0));
+    for (size_t k = 0; k < nch; ++k) {
+        if (k + 1 < nch) HIPOK(c, issue(k + 1));
+        HIPOK(c, hipEventSynchronize(c->bounce_ev[k & 1]));
+        const size_t off = k * CH;
+        memcpy((char*)dst + off, c->bounce[k & 1], std::min(CH, bytes - off));
+    }
+    return 0;
+}
+
+// the other direction: a host memcpy fills one pinned half while the DMA drains the other
+static int big_copy_to_device(emx_ctx* c, void* dst, const void* src, size_t bytes) {
+    constexpr size_t CH = 8u << 20;
+    if (bytes == 0) return 0;
+    bool direct = bytes < (2u << 20);
+    if (!direct) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, src) == hipSuccess) direct = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
+    if (direct) {
+        HIPOK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPOK(c, hipStreamSynchronize(c->stream));      // the caller may reuse src
+        return 0;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!c->bounce[k]) HIPOK(c, hipHostMalloc((void**)&c->bounce[k], CH, hipHostMallocDefault));
+        if (!c->bounce_ev[k]) HIPOK(c, hipEventCreateWithFlags(&c->bounce_ev[k], hipEventDisableTiming));
+    }
+    const size_t nch = (bytes + CH - 1) / CH;
+    for (size_t k = 0; k < nch; ++k) {
+        const size_t off = k * CH, n = std::min(CH, bytes - off);
+        if (k >= 2) HIPOK(c, hipEventSynchronize(c->bounce_ev[k & 1]));      // the DMA that last read this half is done
+        memcpy(c->bounce[k & 1], (const char*)src + off, n);
+        HIPOK(c, hipMemcpyAsync((char*)dst + off, c->bounce[k & 1], n, hipMemcpyHostToDevice, c->stream));
+        HIPOK(c, hipEventRecord(c->bounce_ev[k & 1], c->stream));
+    }
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int emx_set_state(emx_ctx* c, const double* coords, const double* log_prob) {
     HIPOK(c, hipSetDevice(c->device));
-    HIPOK(c, hipMemcpyAsync(c->X, coords, (size_t)c->N * c->D * 8, hipMemcpyHostToDevice, c->stream));
+    {
+        const int rc = big_copy_to_device(c, c->X, coords, (size_t)c->N * c->D * 8);
+        if (rc) return rc;
+    }
     if (log_prob) HIPOK(c, hipMemcpyAsync(c->lp, log_prob, (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1051,8 +1129,11 @@ int emx_set_state(emx_ctx* c, const double* coords, const double* log_prob) {
 
 int emx_get_state(emx_ctx* c, double* coords, double* log_prob) {
     HIPOK(c, hipSetDevice(c->device));
-    if (coords) HIPOK(c, hipMemcpyAsync(coords, c->X, (size_t)c->N * c->D * 8, hipMemcpyDeviceToHost, c->stream));
     if (log_prob) HIPOK(c, hipMemcpyAsync(log_prob, c->lp, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (coords) {
+        const int rc = big_copy_to_host(c, coords, c->X, (size_t)c->N * c->D * 8);
+        if (rc) return rc;
+    }
     HIPOK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1303,8 +1384,15 @@ int emx_chain_read(emx_ctx* c, int32_t what, int64_t start, int64_t stop, int64_
     const char* base = what == 0 ? (const char*)c->chain : (const char*)c->chain_lp;
     char* o = (char*)out;
     if (stride == 1) {
-        if (stop > start)
-            HIPOK(c, hipMemcpyAsync(o, base + row * start, row * (stop - start), hipMemcpyDeviceToHost, c->stream));
+        if (stop > start) {
+            const int rc = big_copy_to_host(c, o, base + row * start, row * (size_t)(stop - start));
+            if (rc) return rc;
+        }
+    } else if (row >= (2u << 20)) {
+        for (int64_t s = start; s < stop; s += stride, o += row) {
+            const int rc = big_copy_to_host(c, o, base + row * s, row);
+            if (rc) return rc;
+        }
     } else {
         for (int64_t s = start; s < stop; s += stride, o += row)
             HIPOK(c, hipMemcpyAsync(o, base + row * s, row, hipMemcpyDeviceToHost, c->stream));
@@ -1757,8 +1845,11 @@ int emx_propose(emx_ctx* c, int32_t split, double* q_out, double* factors_out, i
         if (fb) memcpy(factors_out, c->xfer_host + qb, fb);
         return 0;
     }
-    if (qb) HIPOK(c, hipMemcpyAsync(q_out, c->qout, qb, hipMemcpyDeviceToHost, c->stream));
     if (fb) HIPOK(c, hipMemcpyAsync(factors_out, c->fout, fb, hipMemcpyDeviceToHost, c->stream));
+    if (qb) {
+        const int rc2 = big_copy_to_host(c, q_out, c->qout, qb);
+        if (rc2) return rc2;
+    }
     HIPOK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1805,7 +1896,10 @@ int emx_accept_proposals(emx_ctx* c, int32_t split, const double* q, const doubl
     NEED(c, cur.active && cur.move >= 0 && split >= 0 && split < cur.S, "emx_accept_proposals outside a planned step");
     const int ns = cur.off[split + 1] - cur.off[split];
     if (ns <= 0) return 0;
-    HIPOK(c, hipMemcpyAsync(c->qout, q, (size_t)ns * c->D * 8, hipMemcpyHostToDevice, c->stream));
+    {
+        const int rc = big_copy_to_device(c, c->qout, q, (size_t)ns * c->D * 8);
+        if (rc) return rc;
+    }
     HIPOK(c, hipMemcpyAsync(c->fout, factors, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
     return emx_accept(c, split, new_lp);
 }

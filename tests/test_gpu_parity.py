@@ -346,3 +346,25 @@ def test_exact_mode_pipeline_inline_and_single_steps_interleave(name):
     assert np.array_equal(st[1], g["rng_key1"]) and st[2] == int(g["rng_pos1"])
     assert st[3] == int(g["rng_has_gauss1"]) and st[4] == float(g["rng_cached1"])
     ens.close()
+
+
+def test_large_device_to_host_copies_through_the_pinned_pipeline():
+    """Copies of more than 2 MB into ordinary memory cross PCIe through two pinned 8 MB halves (big_copy_to_host): a
+    30 MB chain read in one call (four pieces, the last one partial) equals the same chain read row by row (1 MB rows:
+    the direct path); rows of 4 MB read with a stride (one pipeline run per row) equal the contiguous read."""
+    for N, D, K in ((4096, 32, 30), (65536, 8, 5)):
+        ens = _dev()(N, D)
+        ens.set_target(_lib.TARGET_ISO)
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(11, 0)
+        ens.set_state(np.random.RandomState(0).randn(N, D))
+        ens.eval_state_log_prob()
+        ens.chain_config(K)
+        ens.run(K, 1, True)
+        full = ens.chain_read(0, 0, K)
+        for s in range(K):
+            assert np.array_equal(full[s], ens.chain_read(0, s, s + 1)[0]), s
+        assert np.array_equal(full[1::2], ens.chain_read(0, 1, K, 2))
+        assert np.array_equal(full[-1], ens.get_state()[0])
+        assert np.array_equal(ens.chain_read(1, 0, K)[-1], ens.get_state()[1])
+        ens.close()
