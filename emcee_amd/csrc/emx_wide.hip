@@ -57,12 +57,10 @@ __host__ __device__ constexpr size_t wide_lds_bytes(int Dp, int W) {
 template <int W>
 __global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
     constexpr int NT = 64 * W;
-    constexpr int NTG = NT;
-    constexpr int NLD = SLAB / 2 / NTG;           // double2 per thread and slab
+    constexpr int NLD = SLAB / 2 / NT;            // double2 per thread and slab
     extern __shared__ __attribute__((aligned(16))) double dsm[];      // slab[2][SLAB] | mu[Dp] | per wave: A tile [16][ART]
     typedef double4_t d4;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, tx = threadIdx.x;
-    const int gtx = tx;
     double* Bs = dsm;
     const int am = lane & 15, ak = lane >> 4;             // MFMA A-fragment coordinates
     const int arow = lane >> 2, aseg = lane & 3;          // row loads: four lanes cover one 128-byte piece of a row
@@ -75,11 +73,11 @@ __global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
     double* At = muS + Dp + wib * 16 * ART;
     for (int d = tx; d < Dp; d += NT) muS[d] = A.img[(size_t)Dp * Dp + d];      // zero padded beyond D
     __syncthreads();
-    // this thread's pieces of a slab: double2 number e = gtx + r NTG of the 32 chunks (column block j, k-step i) x 32
+    // this thread's pieces of a slab: double2 number e = tx + r NT of the 32 chunks (column block j, k-step i) x 32
     int boff[NLD], bj[NLD];
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
-        const int e = gtx + r * NTG, chunk = e >> 5, within = e & 31;
+        const int e = tx + r * NT, chunk = e >> 5, within = e & 31;
         bj[r] = chunk >> 2;
         boff[r] = ((chunk >> 2) * KK + (chunk & 3)) * 32 + within;
     }
@@ -93,7 +91,7 @@ __global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
         bool bad = false;
         d4 acc[8];
         double2 bn[NLD];
-        double afr[4], araw[4], mraw[4], xn[4];
+        double afr[4], xn[4];
         int kn = 0;
 
         // slab (nbb, sp): k rows 16 (8 nbb + sp) ..+16, columns 128 nbb ..+128.  Raw loads only: their first use
@@ -117,10 +115,9 @@ __global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
                 for (int e = 0; e < 4; ++e) xn[e] = rowp[min(kn + e, D - 1)];
             }
         };
-        // Staging half: the raw row values go into the wave's A tile and come back as this lane's four A fragments, with the
-        // matching pieces of the mean.  No f64 arithmetic here: the f64 VALU shares the pipe the OTHER group's MFMAs are
-        // queued on (measured: four v_add_f64 + four v_cmp_f64 in this place cost 1 900 cycles per slab) -- the mask and the
-        // finiteness test are integer operations, the subtraction waits for this group's own turn (finish).
+        // The raw row values go into the wave's A tile (masked: dead rows and the padding columns are zero) and come back
+        // as this lane's four A fragments R = Q - mu of the next slab.  The finiteness test is an integer test of the
+        // exponent field.
         auto consume = [&]() {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -133,20 +130,13 @@ __global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
             EMX_WAVE_SYNC();
             const int kf = kn - 4 * aseg + ak;                 // first k of this lane's fragments
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                araw[i] = At[am * ART + 4 * i + ak];
-                mraw[i] = muS[kf + 4 * i];
-            }
+            for (int i = 0; i < 4; ++i) afr[i] = At[am * ART + 4 * i + ak] - muS[kf + 4 * i];
             EMX_WAVE_SYNC();
-        };
-        auto finish = [&]() {                                  // R = Q - mu: the A fragments of the slab about to be multiplied
-#pragma unroll
-            for (int i = 0; i < 4; ++i) afr[i] = araw[i] - mraw[i];
         };
         auto publish = [&](int buf) {
             double2* dst = reinterpret_cast<double2*>(Bs + (size_t)buf * SLAB);
 #pragma unroll
-            for (int r = 0; r < NLD; ++r) dst[gtx + r * NTG] = bn[r];
+            for (int r = 0; r < NLD; ++r) dst[tx + r * NT] = bn[r];
         };
 
         // slab order: macro block by macro block, k blocks from the diagonal down
@@ -169,7 +159,6 @@ __global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
         for (;;) {
             const int ncb = min(8, DPB - 8 * nbb), nsl = DPB - 8 * nbb;
             const bool last = (sp == nsl - 1) && nbb + 1 >= nmacro;
-            finish();
             const int jlim = min(ncb - 1, sp);                 // column block j starts at its diagonal block: k block >= j
             const double* bs = Bs + (size_t)buf * SLAB;
 #define EMX_SLAB_STEPS(I0, I1)                                                  \
