@@ -431,7 +431,10 @@ def quality_entry(device, rng="philox"):
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU measurement
-EXCHANGES = ("allgather", "pull", "direct")
+EXCHANGES = ("allgather", "pull", "direct")      # measured by default at N > 1
+# "logprob" (proposal / commit replicated, log-prob evaluations shared out: for targets that dominate the step) is measured
+# on request only: on the closed-form BASELINE targets the replicated part is most of the step
+ALL_EXCHANGES = EXCHANGES + ("logprob",)
 
 
 _NCCL_GROUP = {}
@@ -460,7 +463,10 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
         eng = DeviceEngine(ens, rank, world, torch.device("cuda", local_rank), exchange=exchange)
         grp = None if dist.get_backend() == "nccl" else _torch_nccl_group(dist)
         gather = lambda out, inp: dist.all_gather_into_tensor(out, inp, group=grp)  # noqa: E731
-        if exchange == "pull":
+        if exchange == "logprob":
+            from emcee_amd.parallel import LogProbStepper
+            stepper = LogProbStepper(eng, gather)
+        elif exchange == "pull":
             stepper = PullStepper(eng, lambda out, inp: dist.all_to_all_single(out, inp, group=grp), gather)
         else:
             stepper = ShardedStepper(eng, gather)
@@ -660,7 +666,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the sharded RCCL path even at world size 1 (testing)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="sharded runs: collectives enqueued by libemx itself (default) or torch.distributed")
-    ap.add_argument("--exchange", default="all", choices=["all"] + list(EXCHANGES))
+    ap.add_argument("--exchange", default="all", choices=["all"] + list(ALL_EXCHANGES))
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="testing on a one-GPU box: every rank uses this device (RCCL refuses duplicate devices, so only the "
                          "control flow -- failure handling, watchdogs, the emitted line -- is exercised)")

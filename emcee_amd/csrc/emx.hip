@@ -1807,6 +1807,8 @@ static int do_halfstep(emx_ctx* c, int split, int target) {
          "pull exchange: use emx_pull_prepare / emx_pull_apply");
     NEED(c, c->exchange != EMX_EXCHANGE_DIRECT || c->world == 1 || target == EMX_TARGET_HOST,
          "direct exchange: use emx_direct_halfstep");
+    NEED(c, c->exchange != EMX_EXCHANGE_LOGPROB || c->world == 1 || target == EMX_TARGET_HOST,
+         "log-prob exchange: use emx_logprob_begin / emx_logprob_finish");
     double* sb = nullptr;
     if (c->sendbuf && target != EMX_TARGET_HOST && c->exchange == EMX_EXCHANGE_ALLGATHER) sb = c->sendbuf;
     NEED(c, !sb || hi - lo <= c->sendbuf_rows, "exchange buffers too small for this move: call emx_set_shard after emx_set_moves");
@@ -2342,6 +2344,25 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
                     }
                     continue;
                 }
+                if (c->comm && c->exchange == EMX_EXCHANGE_LOGPROB) {
+                    // proposal and commit on every rank, the log-probs of a share each, 8 bytes per walker gathered in place
+                    int64_t per = 0;
+                    rc = emx_logprob_begin(c, s, &per);
+                    if (!rc && per > 0) {
+                        const int e = g_rccl.AllGather(c->gathered + (size_t)c->rank * per, c->gathered, (size_t)per, RCCL_FLOAT64, c->comm,
+                                                       c->stream);
+                        if (e != 0) {
+                            c->err = std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+                            rc = -6;
+                        }
+                    }
+                    if (!rc) rc = emx_logprob_finish(c, s);
+                    if (rc) {
+                        c->cur.active = false;
+                        return rc;
+                    }
+                    continue;
+                }
                 if (c->comm && c->exchange == EMX_EXCHANGE_PULL) {
                     // partner rows only: pack what the peers will read, all-to-all, fold in, update own walkers
                     int64_t cap = 0;
@@ -2381,7 +2402,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
         }
     }
     c->prep_hint = 1;
-    if (c->comm && c->exchange != EMX_EXCHANGE_ALLGATHER && c->world > 1) {
+    if (c->comm && (c->exchange == EMX_EXCHANGE_PULL || c->exchange == EMX_EXCHANGE_DIRECT) && c->world > 1) {
         // re-synchronise the replicas: every rank's block of (coords, log_prob, accepted) to every rank
         int64_t per = 0;
         int rc = emx_replica_pack(c, &per);
@@ -2492,7 +2513,8 @@ static int pull_ensure(emx_ctx* c) {
 }
 
 int emx_set_exchange(emx_ctx* c, int32_t kind) {
-    NEED(c, kind == EMX_EXCHANGE_ALLGATHER || kind == EMX_EXCHANGE_PULL || kind == EMX_EXCHANGE_DIRECT, "unknown exchange kind %d", kind);
+    NEED(c, kind == EMX_EXCHANGE_ALLGATHER || kind == EMX_EXCHANGE_PULL || kind == EMX_EXCHANGE_DIRECT || kind == EMX_EXCHANGE_LOGPROB,
+         "unknown exchange kind %d", kind);
     NEED(c, c->world == 1 && !c->comm && !c->sendbuf, "emx_set_exchange: call it before emx_set_shard / emx_comm_init");
     c->exchange = kind;
     return 0;
@@ -2508,6 +2530,14 @@ int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
     exchange_free(c);
     c->pull_split = -1;
     if (c->exchange == EMX_EXCHANGE_PULL) return world > 1 ? pull_ensure(c) : 0;
+    if (c->exchange == EMX_EXCHANGE_LOGPROB) {
+        // the one buffer of this exchange: the log-probs of a split's proposals, world shares of ceil(ns / world) doubles,
+        // gathered in place
+        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)(c->N + world) * 8));
+        c->own_shard_bufs = true;
+        c->recv_doubles = c->N + world;
+        return 0;
+    }
     if (c->exchange == EMX_EXCHANGE_DIRECT) {
         NEED(c, world <= EMX_MAX_PEERS, "direct exchange: at most %d ranks (the GPUs of one node)", EMX_MAX_PEERS);
         direct_detach(c);
@@ -2570,6 +2600,63 @@ int emx_set_exchange_buffers(emx_ctx* c, void* send, int64_t send_doubles, void*
 int emx_own_walkers(emx_ctx* c, int64_t* lo, int64_t* hi) {
     *lo = c->N * c->rank / c->world;
     *hi = c->N * (c->rank + 1) / c->world;
+    return 0;
+}
+
+// ---- log-prob exchange: the reference's pool.map model (ensemble.py:486-496) --------------------------------------
+// Every rank proposes for ALL walkers of the split (replicated plan, replicated ensemble: identical proposals), evaluates
+// the target on its share of them, the shares are gathered in place (8 bytes per walker), and every rank takes the
+// decisions and commits ALL walkers -- the replicas stay identical, no coordinate ever crosses xGMI.
+int emx_logprob_begin(emx_ctx* c, int32_t split, int64_t* per_rank) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, c->exchange == EMX_EXCHANGE_LOGPROB && c->gathered, "emx_logprob_begin needs emx_set_exchange(EMX_EXCHANGE_LOGPROB) and emx_set_shard");
+    NEED(c, cur.active && cur.move >= 0 && cur.slot >= 0, "emx_logprob_begin outside a planned step");
+    NEED(c, split >= 0 && split < cur.S, "split out of range");
+    NEED(c, c->target != EMX_TARGET_HOST, "log-prob exchange needs a device target");
+    const emx_move_desc& mv = c->moves[cur.move];
+    const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
+    const int64_t per = ((int64_t)ns + c->world - 1) / c->world;
+    *per_rank = per;
+    if (ns <= 0) return 0;
+    const emx_ctx::PlanSlot* ps = &c->ring[cur.slot];
+    int rc = launch_split(c, mv.kind, EMX_TARGET_HOST, cur.S, split, pos0, ns, 0, ns, &mv, ps, nullptr, c->X, c->lp, nullptr, nullptr,
+                          nullptr);
+    if (rc) return rc;
+    const int lo = (int)std::min<int64_t>((int64_t)c->rank * per, ns), hi = (int)std::min<int64_t>(lo + per, ns);
+    if (hi <= lo) return 0;
+    // log-probs of the proposals [lo, hi): row t of qout -> gathered[t]
+    return launch_split(c, MOVE_EVAL, c->target, 1, 0, 0, ns, lo, hi, &mv, nullptr, c->iota, c->qout, c->gathered, nullptr, nullptr,
+                        nullptr);
+}
+
+int emx_logprob_finish(emx_ctx* c, int32_t split) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, c->exchange == EMX_EXCHANGE_LOGPROB && c->gathered, "emx_logprob_finish needs emx_set_exchange(EMX_EXCHANGE_LOGPROB) and emx_set_shard");
+    NEED(c, cur.active && cur.move >= 0 && cur.slot >= 0 && split >= 0 && split < cur.S, "emx_logprob_finish outside a planned step");
+    const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
+    if (ns <= 0) return 0;
+    const emx_ctx::PlanSlot* ps = &c->ring[cur.slot];
+    WideCommitArgs k{};
+    k.X = c->X;
+    k.lp = c->lp;
+    k.acc = c->acc;
+    k.acc_count = c->acc_count;
+    if (cur.store) {
+        k.chain = c->chain + (size_t)c->stored * c->N * c->D;
+        k.chain_lp = c->chain_lp + (size_t)c->stored * c->N;
+    }
+    k.qout = c->qout;
+    k.fout = c->fout;
+    k.newlp = c->gathered;
+    k.order = ps->order;
+    k.logu = ps->logu;
+    k.D = c->D;
+    k.pos0 = pos0;
+    k.t_lo = 0;
+    k.t_hi = ns;
+    if (launch_wide_commit(k, ns, c->num_cu, c->stream) != hipSuccess) FAIL(c, -2, "log-prob exchange: commit kernel launch failed");
     return 0;
 }
 
@@ -3015,6 +3102,8 @@ int emx_comm_init(emx_ctx* c, int32_t rank, int32_t world, const uint8_t id[128]
     } else if (c->exchange == EMX_EXCHANGE_DIRECT) {
         rc = direct_ensure(c);
         if (rc) return rc;
+    } else if (c->exchange == EMX_EXCHANGE_LOGPROB) {
+        // emx_set_shard allocated the gather buffer
     } else if (!c->sendbuf) {   // world == 1: still exercise the exchange buffers
         const int64_t per = c->N + 2;
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));

@@ -299,7 +299,8 @@ class DeviceEnsemble:
     # ---- pull exchange (walker-block ownership; include/emx.h) ----
     def set_exchange(self, kind):
         """'allgather' (every updated row to every rank) or 'pull' (only the partner rows read)."""
-        k = {"allgather": _lib.EXCHANGE_ALLGATHER, "pull": _lib.EXCHANGE_PULL, "direct": _lib.EXCHANGE_DIRECT}.get(kind, kind)
+        k = {"allgather": _lib.EXCHANGE_ALLGATHER, "pull": _lib.EXCHANGE_PULL, "direct": _lib.EXCHANGE_DIRECT,
+             "logprob": _lib.EXCHANGE_LOGPROB}.get(kind, kind)
         self._ck(self.lib.emx_set_exchange(self.ctx, int(k)))
 
     def exchange_layout(self):
@@ -322,6 +323,16 @@ class DeviceEnsemble:
 
     def pull_apply(self, split):
         self._ck(self.lib.emx_pull_apply(self.ctx, int(split)))
+
+    def logprob_begin(self, split):
+        """log-prob exchange: proposals of the whole split + the log-probs of this rank's share -> doubles per rank of the
+        in-place all-gather that follows (buffer: device_ptr(3))"""
+        n = C.c_int64(0)
+        self._ck(self.lib.emx_logprob_begin(self.ctx, int(split), C.byref(n)))
+        return int(n.value)
+
+    def logprob_finish(self, split):
+        self._ck(self.lib.emx_logprob_finish(self.ctx, int(split)))
 
     # ---- direct exchange (partner rows read in place from the peers' HBM; include/emx.h) ----
     def direct_export(self):

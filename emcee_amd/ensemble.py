@@ -107,8 +107,8 @@ class EnsembleSampler(object):
             if not dist.is_initialized():
                 raise RuntimeError("distributed=True needs an initialised torch.distributed process group "
                                    "(it is only used to bootstrap RCCL and to replicate the inputs)")
-            if exchange not in ("allgather", "pull"):
-                raise ValueError("exchange must be 'allgather' or 'pull'")
+            if exchange not in ("allgather", "pull", "logprob"):
+                raise ValueError("exchange must be 'allgather', 'pull' or 'logprob'")
             self._dist = dist
             self._exchange = exchange
             self._comm_ready = False

@@ -149,6 +149,44 @@ class PullStepper:
         self.sync_replicas()
 
 
+class LogProbStepper:
+    """Drives one engine per rank through steps of the log-prob exchange (the reference's pool.map model,
+    ensemble.py:486-496): proposal, decision and commit replicated, the log-prob evaluations shared out.
+
+    engine API: step_begin(store) -> (move, nsplits); logprob_begin(split) -> doubles per rank; logprob_finish(split);
+    step_end(); attributes gathered (flat float64 buffer, gathered in place), rank, world.
+    all_gather(out, inp): every rank's `inp`, concatenated in rank order (`inp` is block `rank` of `out`).
+    """
+
+    def __init__(self, engine, all_gather):
+        self.engine = engine
+        self.all_gather = all_gather
+
+    def step(self, store=False):
+        e = self.engine
+        move, nsplits = e.step_begin(store)
+        for split in range(nsplits):
+            per = e.logprob_begin(split)                      # 8 bytes per walker-update travel, never a coordinate
+            if per > 0:
+                self.all_gather(e.gathered[:e.world * per], e.gathered[e.rank * per:(e.rank + 1) * per])
+            e.logprob_finish(split)
+        e.step_end()
+        return move
+
+    def run(self, nsteps, thin_by=1, store=False):
+        i = 0
+        total = nsteps * thin_by
+        hint = getattr(self.engine, "set_prep_hint", None)
+        for _ in range(nsteps):
+            for _ in range(thin_by):
+                if hint is not None:
+                    hint(total - i)
+                self.step(store and (i + 1) % thin_by == 0)
+                i += 1
+        if hint is not None:
+            hint(1)
+
+
 class _DevView(object):
     """__cuda_array_interface__ carrier for a library-owned device buffer of float64"""
 
@@ -198,6 +236,12 @@ class DeviceEngine:
             self.sendbuf = _wrap_device_buffer(ens, 2, dev)
             self.gathered = _wrap_device_buffer(ens, 3, dev)
             return
+        if exchange == "logprob":
+            ens.set_exchange("logprob")
+            ens.set_shard(rank, world)
+            self.sendbuf = None
+            self.gathered = _wrap_device_buffer(ens, 3, dev)       # the library's buffer, gathered in place
+            return
         if exchange == "pull":
             ens.set_exchange("pull")
             ens.set_shard(rank, world)
@@ -218,6 +262,12 @@ class DeviceEngine:
 
     def pull_apply(self, split):
         self.ens.pull_apply(split)
+
+    def logprob_begin(self, split):
+        return self.ens.logprob_begin(split)
+
+    def logprob_finish(self, split):
+        self.ens.logprob_finish(split)
 
     def replica_pack(self):
         return self.ens.replica_pack()

@@ -187,6 +187,7 @@ int emx_scatter_gathered(emx_ctx* ctx, int32_t split);
 #define EMX_EXCHANGE_ALLGATHER 0
 #define EMX_EXCHANGE_PULL 1
 #define EMX_EXCHANGE_DIRECT 2      /* see "direct exchange" below */
+#define EMX_EXCHANGE_LOGPROB 3     /* see "log-prob exchange" below */
 int emx_set_exchange(emx_ctx* ctx, int32_t kind);          /* before emx_set_shard / emx_comm_init */
 /* doubles the send / receive buffers must hold for the moves installed (pull exchange) */
 int emx_exchange_layout(emx_ctx* ctx, int64_t* send_doubles, int64_t* recv_doubles);
@@ -219,6 +220,20 @@ int emx_direct_import(emx_ctx* ctx, const uint8_t* handles /* world * 128 bytes,
 int emx_direct_attach(emx_ctx* ctx, void* const* peer_coords /* [world] */, void* const* peer_flags /* [world] or NULL */);
 /* barrier != 0: device-side barrier with the peers first (needs their flag arrays); 0: the caller orders the ranks itself */
 int emx_direct_halfstep(emx_ctx* ctx, int32_t split, int32_t barrier);
+
+/* ---- log-prob exchange: the reference's own parallel model (ensemble.py:486-496: pool.map over the proposals) ------------
+ * Proposal, decision and commit are replicated -- every rank holds the whole ensemble and the same plan, so every rank computes
+ * the same proposals -- and only the log-probability evaluations are shared out: rank r evaluates the proposals
+ * [r * per, (r + 1) * per) of the split, per = ceil(ns / world).  What travels is 8 bytes per walker-update (an in-place
+ * all-gather of `per` doubles per rank on the buffer emx_device_ptr(which = 3) returns), never a coordinate; the replicas stay
+ * identical, so there is nothing to re-synchronise.  The protocol for targets whose evaluation dominates the step (wide dense
+ * Gaussians here); for the cheap closed-form targets of the BASELINE configurations the replicated part is most of the step.
+ *   emx_set_exchange(EMX_EXCHANGE_LOGPROB); emx_set_shard / emx_comm_init; per step:
+ *   emx_step_begin; for every split: emx_logprob_begin(split, &per) -> all-gather(in place, per doubles per rank)
+ *   -> emx_logprob_finish(split); emx_step_end   (emx_run does it when emx_comm_init ran).
+ * Results are bit-identical to the single-rank run. */
+int emx_logprob_begin(emx_ctx* ctx, int32_t split, int64_t* per_rank);
+int emx_logprob_finish(emx_ctx* ctx, int32_t split);
 
 /* RCCL driven by the library itself (ncclAllGather enqueued on the context stream between the
  * half-step kernels, so that emx_run covers sharded runs with no host round trip per step).

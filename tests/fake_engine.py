@@ -239,3 +239,47 @@ class FakeDirectEngine(FakePullEngine):
         for s in (self._shm_x, self._shm_f):
             s.close()
             s.unlink()
+
+
+class FakeLogProbEngine(FakeEngine):
+    """The log-prob exchange (emcee_amd.parallel.LogProbStepper) on the NumPy double: proposal, decision and commit
+    replicated on every rank, the target evaluated on a share of the proposals, 8 bytes per walker gathered in place."""
+
+    def __init__(self, *a, **kw):
+        make_buffer = kw.get("make_buffer", np.zeros)
+        super().__init__(*a, **kw)
+        self.ndim = self.D
+        self.sendbuf = None
+        self.gathered = make_buffer(self.N + self.world)
+        self.evaluated = 0          # proposals this rank evaluated (the point of the protocol: ~1/world of them)
+
+    def _sub(self, split):
+        off = self.plan["off"]
+        sub = {k: v[off[split]: off[split + 1]] for k, v in self.plan.items() if k != "off"}
+        sub["off"] = np.array([0, off[split + 1] - off[split]])
+        return sub
+
+    def logprob_begin(self, split):
+        sub = self._sub(split)
+        ns = int(sub["off"][1])
+        per = -(-ns // self.world)
+        box = {}
+
+        def capture(q):               # the oracle's own proposal arithmetic, on copies; nothing is evaluated here
+            box["q"] = np.array(q, copy=True)
+            return np.zeros(len(q))
+
+        so.propose_planned(self.X.copy(), self.lp.copy(), capture, sub, self.move)
+        lo, hi = min(self.rank * per, ns), min((self.rank + 1) * per, ns)
+        if hi > lo:
+            self._np(self.gathered)[lo:hi] = self.lp_fn(box["q"][lo:hi])
+            self.evaluated += hi - lo
+        self._ns = ns
+        return per
+
+    def logprob_finish(self, split):
+        sub = self._sub(split)
+        new_lp = np.array(self._np(self.gathered)[: self._ns], copy=True)
+        acc = so.propose_planned(self.X, self.lp, lambda q: new_lp, sub, self.move)
+        idx = sub["order"]
+        self.acc[idx] = acc[idx]
