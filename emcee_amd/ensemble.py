@@ -250,9 +250,11 @@ class EnsembleSampler(object):
             if vec is not None and descs[i].kind == _lib.MOVE_GAUSS:
                 ens.set_move_scale(i, vec())
         if self._dist is not None:
-            if not fused:
-                raise RuntimeError("distributed=True needs a DeviceTarget log_prob_fn (the sharded step is the fused one)")
-            self._join_communicator(ens)
+            if fused:
+                self._join_communicator(ens)
+            elif self._exchange != "logprob":
+                raise RuntimeError("distributed=True with a Python log_prob_fn needs exchange='logprob' (every rank proposes and "
+                                   "commits, the calls of log_prob_fn are shared out); the other exchanges shard the fused step")
         if self.rng == "mt19937":
             self._flush_rng()
             ens.set_rng_mode(_lib.RNG_MT19937)
@@ -339,9 +341,9 @@ class EnsembleSampler(object):
 
         yield_step, checkpoint_step, nsaves = _thinning_plan(iterations, thin_by, thin)
 
-        if self._dist is not None and not fused:
-            raise RuntimeError("distributed=True needs a DeviceTarget log_prob_fn and built-in moves "
-                               "(the sharded step is the fused one)")
+        if self._dist is not None and not fused and not (native and self._exchange == "logprob"):
+            raise RuntimeError("distributed=True needs built-in moves, and a DeviceTarget log_prob_fn or exchange='logprob' "
+                               "(a Python log_prob_fn: its calls are shared out over the ranks)")
         self._refuse_partial_chain(store)
         ens = None
         if native:
@@ -567,18 +569,42 @@ class EnsembleSampler(object):
                 raise ValueError("Probability function returned NaN")
             return log_prob, None
 
+        if self._dist is not None and self._exchange == "logprob":
+            log_prob, blob = self._shared_log_prob(np.atleast_2d(p))
+        else:
+            log_prob, blob = self._call_log_prob_fn(p)
+        if np.any(np.isnan(log_prob)):
+            raise ValueError("Probability function returned NaN")
+        return log_prob, blob
+
+    def _call_log_prob_fn(self, p):
         if self.params_are_named:
             p = ndarray_to_list_of_dicts(p, self.parameter_names)
-
         if self.vectorize:
             results = self.log_prob_fn(p)
         else:
             mapper = map if self.pool is None else self.pool.map
             results = list(mapper(self.log_prob_fn, p))
+        return _split_log_prob_and_blobs(results, self.blobs_dtype)
 
-        log_prob, blob = _split_log_prob_and_blobs(results, self.blobs_dtype)
-        if np.any(np.isnan(log_prob)):
-            raise ValueError("Probability function returned NaN")
+    def _shared_log_prob(self, p):
+        """exchange='logprob' with a Python callable: the reference's ``pool.map`` (ensemble.py:486-496) over the ranks of
+        the process group -- every rank holds the same proposals, calls ``log_prob_fn`` on its share of the rows and all
+        ranks gather the results (rank order = row order)."""
+        dist = self._dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        n = len(p)
+        per = -(-n // world)
+        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+        mine = self._call_log_prob_fn(p[lo:hi]) if hi > lo else (np.empty(0), None)
+        parts = [None] * world
+        dist.all_gather_object(parts, (np.asarray(mine[0], dtype=np.float64), mine[1]))
+        log_prob = np.concatenate([np.atleast_1d(a) for a, _ in parts])
+        blobs = [b for a, b in parts if len(np.atleast_1d(a))]
+        if any(b is None for b in blobs):
+            blob = None
+        else:
+            blob = np.concatenate([np.asarray(b) for b in blobs]) if blobs else None
         return log_prob, blob
 
     # ------------------------------------------------------------------ results
