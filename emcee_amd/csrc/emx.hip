@@ -467,7 +467,7 @@ inline int lean_kind(const HalfStepArgs& a, int G, int V, int CH, int move, bool
     const int WPW = 64 / G, PF = prefetch_depth_host(G, V, CH, move, dense);
     const int spw = (dense && PF * WPW < 16) ? 16 : PF * WPW;
     const bool common = !a.ablate && !a.desc && !a.sendbuf && !a.disp && !a.skew_sleep && (EMX_OPT_STAMPS || !a.dbg) && a.target != TGT_NONE &&
-                        a.D == G * V * CH && a.spw == spw && a.t_lo == 0;
+                        (!EMX_LEAN_FOLD_D || a.D == G * V * CH) && a.spw == spw && a.t_lo == 0;      // ndim is folded only with EMX_LEAN_FOLD_D
     if (!common) return 0;
     return (a.t_hi_dev || a.npeer) ? 2 : 1;
 }
@@ -485,6 +485,16 @@ hipError_t launch_valu(const Shape& sh, dim3 grid, dim3 block, hipStream_t st, c
             if (lk == 1) return launch_one<64, 2, 8, MOVE, 0, 1>(grid, block, 0, st, a);
             if (lk == 2) return launch_one<64, 2, 8, MOVE, 0, 2>(grid, block, 0, st, a);
         }
+    }
+    if constexpr (MOVE == MOVE_STRETCH) {          // every element-wise shape: LEAN stretch instantiation (+2 ... 5 %)
+#define EMX_LEAN_CASE(g, v, c)                                                                         \
+    if (sh.G == g && sh.V == v && sh.CH == c && lean_kind(a, g, v, c, MOVE, false) == 1)                \
+        return launch_one<g, v, c, MOVE, 0, 1>(grid, block, 0, st, a);
+        EMX_LEAN_CASE(4, 1, 1) EMX_LEAN_CASE(8, 1, 1) EMX_LEAN_CASE(8, 1, 2) EMX_LEAN_CASE(8, 1, 4) EMX_LEAN_CASE(16, 1, 4)
+        EMX_LEAN_CASE(32, 1, 4) EMX_LEAN_CASE(64, 1, 4) EMX_LEAN_CASE(64, 1, 8) EMX_LEAN_CASE(4, 2, 1) EMX_LEAN_CASE(8, 2, 1)
+        EMX_LEAN_CASE(8, 2, 4) EMX_LEAN_CASE(16, 2, 4) EMX_LEAN_CASE(32, 2, 4) EMX_LEAN_CASE(64, 2, 4) EMX_LEAN_CASE(64, 1, 16)
+        EMX_LEAN_CASE(64, 2, 16)
+#undef EMX_LEAN_CASE
     }
 #define EMX_CASE(g, v, c) \
     if (sh.G == g && sh.V == v && sh.CH == c) return launch_one<g, v, c, MOVE, 0>(grid, block, 0, st, a);
@@ -514,6 +524,17 @@ hipError_t launch_dense(int dpb, int V, dim3 grid, dim3 block, size_t lds, hipSt
                 if (lk == 1) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, 1>(grid, block, lds, st, a);
             }
         }
+    }
+    if constexpr (MOVE == MOVE_STRETCH) {
+        // every dense shape has a LEAN stretch instantiation: the general kernel's scalar-register spills cost a dense half-step
+        // up to 26 % (65 536 x 32: 20.1 -> 15.9 us/step, tools/valu_shape_probe.py)
+#define EMX_LEAN_CASE(b, v)                                                                          \
+    if (dpb == b && V == v && lean_kind(a, dense_g(b, v), v, dense_ch(b, v), MOVE, true) == 1)       \
+        return launch_one<dense_g(b, v), v, dense_ch(b, v), MOVE, b, 1>(grid, block, lds, st, a);
+        EMX_LEAN_CASE(1, 1) EMX_LEAN_CASE(2, 1) EMX_LEAN_CASE(3, 1) EMX_LEAN_CASE(4, 1) EMX_LEAN_CASE(5, 1) EMX_LEAN_CASE(6, 1)
+        EMX_LEAN_CASE(7, 1) EMX_LEAN_CASE(1, 2) EMX_LEAN_CASE(2, 2) EMX_LEAN_CASE(3, 2) EMX_LEAN_CASE(5, 2) EMX_LEAN_CASE(6, 2)
+        EMX_LEAN_CASE(7, 2)
+#undef EMX_LEAN_CASE
     }
 #define EMX_CASE(b, v) \
     if (dpb == b && V == v) return launch_one<dense_g(b, v), v, dense_ch(b, v), MOVE, b>(grid, block, lds, st, a);
