@@ -486,14 +486,19 @@ hipError_t launch_valu(const Shape& sh, dim3 grid, dim3 block, hipStream_t st, c
             if (lk == 2) return launch_one<64, 2, 8, MOVE, 0, 2>(grid, block, 0, st, a);
         }
     }
-    if constexpr (MOVE == MOVE_STRETCH) {          // every element-wise shape: LEAN stretch instantiation (+2 ... 5 %)
+    if constexpr (MOVE != MOVE_EVAL) {   // every element-wise shape has a LEAN instantiation
 #define EMX_LEAN_CASE(g, v, c)                                                                         \
     if (sh.G == g && sh.V == v && sh.CH == c && lean_kind(a, g, v, c, MOVE, false) == 1)                \
         return launch_one<g, v, c, MOVE, 0, 1>(grid, block, 0, st, a);
         EMX_LEAN_CASE(4, 1, 1) EMX_LEAN_CASE(8, 1, 1) EMX_LEAN_CASE(8, 1, 2) EMX_LEAN_CASE(8, 1, 4) EMX_LEAN_CASE(16, 1, 4)
         EMX_LEAN_CASE(32, 1, 4) EMX_LEAN_CASE(64, 1, 4) EMX_LEAN_CASE(64, 1, 8) EMX_LEAN_CASE(4, 2, 1) EMX_LEAN_CASE(8, 2, 1)
-        EMX_LEAN_CASE(8, 2, 4) EMX_LEAN_CASE(16, 2, 4) EMX_LEAN_CASE(32, 2, 4) EMX_LEAN_CASE(64, 2, 4) EMX_LEAN_CASE(64, 1, 16)
-        EMX_LEAN_CASE(64, 2, 16)
+        EMX_LEAN_CASE(8, 2, 4) EMX_LEAN_CASE(16, 2, 4) EMX_LEAN_CASE(32, 2, 4) EMX_LEAN_CASE(64, 2, 4)
+        if constexpr (MOVE == MOVE_STRETCH || MOVE == MOVE_GAUSS) {
+            EMX_LEAN_CASE(64, 1, 16) EMX_LEAN_CASE(64, 2, 16)
+        }
+        if constexpr (MOVE != MOVE_STRETCH) {         // the stretch move's own are above (with the block-ownership variant)
+            EMX_LEAN_CASE(8, 2, 2) EMX_LEAN_CASE(64, 2, 8)
+        }
 #undef EMX_LEAN_CASE
     }
 #define EMX_CASE(g, v, c) \
@@ -525,9 +530,9 @@ hipError_t launch_dense(int dpb, int V, dim3 grid, dim3 block, size_t lds, hipSt
             }
         }
     }
-    if constexpr (MOVE == MOVE_STRETCH) {
-        // every dense shape has a LEAN stretch instantiation: the general kernel's scalar-register spills cost a dense half-step
-        // up to 26 % (65 536 x 32: 20.1 -> 15.9 us/step, tools/valu_shape_probe.py)
+    if constexpr (MOVE != MOVE_EVAL) {
+        // every dense shape has a LEAN instantiation: the general kernel's scalar-register spills cost a dense half-step
+        // 14 ... 31 % (65 536 x 32: 20.3 -> 16.0 us/step; profiles/r02/lean_shapes.txt)
 #define EMX_LEAN_CASE(b, v)                                                                          \
     if (dpb == b && V == v && lean_kind(a, dense_g(b, v), v, dense_ch(b, v), MOVE, true) == 1)       \
         return launch_one<dense_g(b, v), v, dense_ch(b, v), MOVE, b, 1>(grid, block, lds, st, a);
