@@ -366,6 +366,7 @@ struct emx_ctx {
     int64_t cap = 0, stored = 0, proposals = 0;
     // split-phase buffers
     double *qout = nullptr, *fout = nullptr, *newlp = nullptr;
+    double* tp1_full = nullptr;        // dense target, ndim <= 112: the full image the wide-target kernels read (tuning "dense_wide")
     double *evalX = nullptr, *evallp = nullptr;
     // sharding
     int rank = 0, world = 1;
@@ -570,7 +571,7 @@ hipError_t dispatch_halfstep(int move, bool dense, int dpb, const Shape& sh, dim
 
 size_t dense_lds_bytes(int Dp, int waves) {
     const int RT = Dp + 2;
-    return ((size_t)Dp * Dp + Dp + (size_t)waves * (16 * RT + 32)) * sizeof(double);
+    return ((size_t)dense_img_doubles(Dp) + Dp + (size_t)waves * (16 * RT + 32)) * sizeof(double);
 }
 
 int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
@@ -604,7 +605,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         }
         WideLpArgs w{};
         w.order = order ? order : (ps ? ps->order : nullptr);
-        w.img = c->tp1;
+        w.img = c->tp1_full ? c->tp1_full : c->tp1;
         w.status = c->status;
         w.t_hi_dev = t_hi_dev;
         w.D = D;
@@ -934,7 +935,7 @@ int emx_destroy(emx_ctx* c) {
         if (c->bounce_ev[k]) hipEventDestroy(c->bounce_ev[k]);
     }
     void* ptrs[] = {c->X, c->lp, c->acc, c->acc_count, c->iota, c->qout, c->fout, c->newlp, c->evalX,
-                    c->evallp, c->tp0, c->tp1, c->chain, c->chain_lp, c->own_shard_bufs ? c->sendbuf : nullptr,
+                    c->evallp, c->tp0, c->tp1, c->tp1_full, c->chain, c->chain_lp, c->own_shard_bufs ? c->sendbuf : nullptr,
                     c->own_shard_bufs ? c->gathered : nullptr};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1177,16 +1178,18 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
     // fresh buffers; the context's target is replaced only once the new one is complete, so a refused target
     // leaves the previous one fully usable.
     const size_t D = (size_t)c->D;
-    double *ntp0 = nullptr, *ntp1 = nullptr;
+    double *ntp0 = nullptr, *ntp1 = nullptr, *ntpf = nullptr;
     int nDp = c->Dp;
     struct Guard {          // frees the new buffers on every early return
         double*& a;
         double*& b;
+        double*& f;
         ~Guard() {
             if (a) hipFree(a);
             if (b) hipFree(b);
+            if (f) hipFree(f);
         }
-    } guard{ntp0, ntp1};
+    } guard{ntp0, ntp1, ntpf};
     if (kind == EMX_TARGET_DIAG_GAUSS || kind == EMX_TARGET_DENSE_GAUSS) {
         NEED(c, p0 && p1, "target needs (mu, ivar|icov)");
         std::vector<double> img;
@@ -1217,6 +1220,21 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
                         if (k < n && col < n && k >= col) img[((size_t)nb * KK + kk) * 64 + l] = Lm[(size_t)k * n + col];
                     }
             for (int d = 0; d < n; ++d) img[(size_t)Dp * Dp + d] = p0[d];
+            if (Dp <= 112) {
+                // the fused kernel and k_small_run stage only the non-zero 16 x 16 blocks (dense_block, emx_kernels.hpp); the
+                // full image stays next to it for the wide-target kernels (tuning "dense_wide")
+                HIPOK(c, hipMalloc((void**)&ntpf, img.size() * 8));
+                HIPOK(c, hipMemcpy(ntpf, img.data(), img.size() * 8, hipMemcpyHostToDevice));
+                const int B = Dp / 16;
+                std::vector<double> packed((size_t)dense_img_doubles(Dp) + Dp, 0.0);
+                for (int nb = 0; nb < B; ++nb)
+                    for (int kb = nb; kb < B; ++kb)
+                        for (int i = 0; i < 4; ++i)
+                            for (int l = 0; l < 64; ++l)
+                                packed[((size_t)dense_block(B, nb, kb) * 4 + i) * 64 + l] = img[((size_t)nb * KK + 4 * kb + i) * 64 + l];
+                for (int d = 0; d < Dp; ++d) packed[(size_t)dense_img_doubles(Dp) + d] = img[(size_t)Dp * Dp + d];
+                img.swap(packed);
+            }
         }
         HIPOK(c, hipMalloc((void**)&ntp0, D * 8));
         HIPOK(c, hipMemcpy(ntp0, p0, D * 8, hipMemcpyHostToDevice));
@@ -1228,6 +1246,7 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
     HIPOK(c, hipStreamSynchronize(c->stream));      // no kernel still reads the old parameters
     std::swap(c->tp0, ntp0);                        // the guard now frees the OLD buffers
     std::swap(c->tp1, ntp1);
+    std::swap(c->tp1_full, ntpf);
     c->Dp = nDp;
     graph_invalidate(c);
     c->graph_warm = false;
@@ -2062,7 +2081,7 @@ static int small_batch(int64_t N) { return (int)std::max<int64_t>(1, std::min<in
 static size_t small_lds_bytes(int64_t N, int D, int dense_dp = 0, int waves = 0) {
     const size_t B = (size_t)small_batch(N);
     size_t b = (size_t)N * ((size_t)D * 8 + 8 + 4 + 1) + B * (size_t)N * (3 * 8 + 4 * 4) + 64;
-    if (dense_dp > 0) b += 16 + ((size_t)dense_dp * dense_dp + dense_dp + (size_t)waves * (16 * (dense_dp + 2) + 16)) * 8;
+    if (dense_dp > 0) b += 16 + ((size_t)dense_img_doubles(dense_dp) + dense_dp + (size_t)waves * (16 * (dense_dp + 2) + 16)) * 8;
     return b;
 }
 

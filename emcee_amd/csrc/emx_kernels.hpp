@@ -432,8 +432,16 @@ __device__ __forceinline__ double eval_valu_target(const Row<G, V, CH>& q, const
 //   DPB = Dp/16 for the dense-Gaussian (MFMA) target, 0 for element-wise targets.
 // A wave prefetches the rows of PF passes (PF * 64/G walkers) before touching any of them, so a
 // batch costs one memory round trip instead of PF.
-// Dynamic LDS (dense only): Sfrag[Dp*Dp] (MFMA B-fragment order) | mu[Dp] | per wave: tile[16][Dp+2], qf[16], fac[16]
+// Dynamic LDS (dense only): Sfrag[non-zero blocks of L] (MFMA B-fragment order) | mu[Dp] | per wave: tile[16][Dp+2], qf[16], fac[16]
 // ----------------------------------------------------------------------------------------
+// The LDS image of a dense Gaussian target (fused kernel, k_small_run): only the non-zero 16 x 16 blocks of the lower
+// triangular factor L, column block by column block, k blocks from the diagonal down --
+//   block(nb, kb), kb >= nb:  img[((block * 4 + i) * 64) + l] = L[k = 16 kb + 4 i + (l >> 4)][n = 16 nb + (l & 15)]
+// followed by the zero-padded mean.  (B (B + 1) / 2 blocks of 2 KB instead of B^2: 20 instead of 32 KB at ndim 64, 56 instead
+// of 98 KB at ndim 112, which is what decides how many waves of tiles fit next to it.)
+__host__ __device__ constexpr int dense_block(int B, int nb, int kb) { return nb * B - nb * (nb - 1) / 2 + (kb - nb); }
+__host__ __device__ constexpr int dense_img_doubles(int Dp) { return (Dp / 16) * (Dp / 16 + 1) / 2 * 256; }
+
 #define EMX_WAVE_SYNC()                                        \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -687,17 +695,17 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     }
 
     double* Sfrag = smem;
-    double* muS = smem + (size_t)Dp * Dp;
+    double* muS = smem + dense_img_doubles(Dp);
     double* tile = muS + Dp + (size_t)wib * (16 * RT + 32);
     double* qfS = tile + 16 * RT;
     double* facS = qfS + 16;
 
     // Dense target: A.tp1 holds the image the MFMA stage wants in LDS -- the Cholesky factor L of the
     // precision matrix (icov = L L^T) in B-fragment order, zero padded, followed by the padded mean:
-    //   img[(nb*KK + kk)*64 + l] = L[k = 4 kk + (l >> 4)][n = 16 nb + (l & 15)],  img[Dp*Dp + d] = mu[d]
+    //   the non-zero 16 x 16 blocks (dense_block above), then mu
     // (built once by emx_set_target).  Its global loads are issued first and written to LDS only after
     // the first batch's row loads are in flight; one workgroup barrier precedes the first MFMA stage.
-    constexpr int IMG2 = (Dp * Dp + Dp) / 2;                // image size in double2
+    constexpr int IMG2 = (dense_img_doubles(Dp) + Dp) / 2;  // image size in double2
     constexpr int NSTG = 5;                                 // double2 per thread held in registers (first round; 9 = the whole image of a skewed stager in one round was measured 2.7 % slower)
     double2 stg0, stg1, stg2, stg3, stg4, stg5, stg6, stg7, stg8;
     stg0 = stg1 = stg2 = stg3 = stg4 = stg5 = stg6 = stg7 = stg8 = double2{0.0, 0.0};
@@ -987,7 +995,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             d4 accv = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                             for (int kk = 4 * nb; kk < KK; ++kk)
-                                accv = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], Sfrag[(nb * KK + kk) * 64 + lane], accv, 0, 0, 0);
+                                accv = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], Sfrag[(dense_block(DPB, nb, kk >> 2) * 4 + (kk & 3)) * 64 + lane], accv, 0, 0, 0);
                             // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
                             for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
@@ -1230,11 +1238,11 @@ static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A)
     uint8_t* accs = reinterpret_cast<uint8_t*>(acnt + N);
     // dense target: the Cholesky image (as in k_halfstep) and one 16-row tile per wave, 16-byte aligned behind the rest
     double* Sfrag = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(accs + N) + 15) & ~(uintptr_t)15);
-    double* muS = Sfrag + (size_t)Dp * Dp;
+    double* muS = Sfrag + dense_img_doubles(Dp);
     double* tile = muS + Dp + (size_t)wv * (16 * RT + 16);
     double* facS = tile + 16 * RT;
     if constexpr (DENSE)
-        for (int e = tid; e < Dp * Dp + Dp; e += T) Sfrag[e] = A.tp1[e];
+        for (int e = tid; e < dense_img_doubles(Dp) + Dp; e += T) Sfrag[e] = A.tp1[e];
 
     for (int e = tid; e < N * D; e += T) Xs[e] = A.X[e];
     for (int e = tid; e < N; e += T) {
@@ -1377,7 +1385,7 @@ static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A)
                                 d4 accv = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                                 for (int kk = 4 * nb; kk < KK; ++kk)
-                                    accv = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], Sfrag[(nb * KK + kk) * 64 + lane], accv, 0, 0, 0);
+                                    accv = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], Sfrag[(dense_block(DPB, nb, kk >> 2) * 4 + (kk & 3)) * 64 + lane], accv, 0, 0, 0);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
                             }
