@@ -107,8 +107,8 @@ class EnsembleSampler(object):
             if not dist.is_initialized():
                 raise RuntimeError("distributed=True needs an initialised torch.distributed process group "
                                    "(it is only used to bootstrap RCCL and to replicate the inputs)")
-            if exchange not in ("allgather", "pull", "logprob"):
-                raise ValueError("exchange must be 'allgather', 'pull' or 'logprob'")
+            if exchange not in ("allgather", "pull", "direct", "logprob"):
+                raise ValueError("exchange must be 'allgather', 'pull', 'direct' or 'logprob'")
             self._dist = dist
             self._exchange = exchange
             self._comm_ready = False
@@ -208,9 +208,10 @@ class EnsembleSampler(object):
         return box[0]
 
     def _refuse_partial_chain(self, store):
-        if self._dist is not None and self._exchange == "pull" and store:
-            raise RuntimeError("exchange='pull' keeps only each rank's block of walkers current between steps, so a stored "
-                               "chain would be partial: run with store=False, or use exchange='allgather'")
+        if self._dist is not None and self._exchange in ("pull", "direct") and store:
+            raise RuntimeError("exchange='%s' keeps only each rank's block of walkers current between steps, so a stored "
+                               "chain would be partial: run with store=False, or use exchange='allgather' / 'logprob'"
+                               % self._exchange)
 
     def _join_communicator(self, ens):
         """RCCL communicator for this ensemble (once, after the moves are installed: the exchange buffers are sized
@@ -222,6 +223,9 @@ class EnsembleSampler(object):
         uid = self._replicate(DeviceEnsemble.rccl_unique_id() if rank == 0 else None)
         ens.set_exchange(self._exchange)
         ens.comm_init(rank, world, uid)
+        if self._exchange == "direct":           # map the peers' coordinate arrays and barrier flags (IPC handles over the group)
+            from .parallel import import_direct_peers
+            import_direct_peers(ens, self._dist)
         self._comm_ready = True
 
     # ------------------------------------------------------------------ device plumbing

@@ -543,9 +543,26 @@ def test_distributed_front_end_world1():
         ref = make_sampler(spec, g, rng="philox")
         ref_last = ref.run_mcmc(g["p0"], 40, skip_initial_state_check=True, store=False)
         assert np.array_equal(last.coords, ref_last.coords) and np.array_equal(last.log_prob, ref_last.log_prob)
+        s = make_sampler(spec, g, distributed=True, exchange="direct", rng="philox")     # in-place partner reads: block ownership too
+        with pytest.raises(RuntimeError, match="partial"):
+            s.run_mcmc(g["p0"], 3, skip_initial_state_check=True)
+        last = s.run_mcmc(g["p0"], 40, skip_initial_state_check=True, store=False)
+        assert np.array_equal(last.coords, ref_last.coords) and np.array_equal(last.log_prob, ref_last.log_prob)
+        s = make_sampler(spec, g, distributed=True, exchange="logprob")                  # replicas stay whole: stored chains are fine
+        s.run_mcmc(g["p0"], spec["nsteps"], skip_initial_state_check=True)
+        assert np.array_equal(s.get_chain(), g["chain"])
         with pytest.raises(RuntimeError, match="DeviceTarget"):
             bad = emcee_amd.EnsembleSampler(32, 3, lambda x: -0.5 * np.sum(x * x), distributed=True)
             bad.run_mcmc(g["p0"], 2)
+        # a Python callable: its calls are shared out over the ranks (all of them to the one rank here)
+        fn = cases.make_target(spec["desc"])
+        np.random.seed(3)
+        a = emcee_amd.EnsembleSampler(32, 3, fn, vectorize=True, distributed=True, exchange="logprob")
+        a.run_mcmc(g["p0"], 10)
+        np.random.seed(3)
+        b = emcee_amd.EnsembleSampler(32, 3, fn, vectorize=True)
+        b.run_mcmc(g["p0"], 10)
+        assert np.array_equal(a.get_chain(), b.get_chain()) and np.array_equal(a.get_log_prob(), b.get_log_prob())
     finally:
         if created:
             dist.destroy_process_group()
