@@ -723,7 +723,7 @@ def main():
                          "algorithmic_bytes_per_walker_update": B, "walker_updates_per_launch": slots_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "per_launch_event_us": per_launch_us,
                          "note": "avg_launch_us = hipEvent time of the timed region / half-step launches: it includes the "
-                                 "inter-kernel gaps and the batched plan kernel (k_native_plan_batch, 1 launch per 8 steps)"
+                                 "inter-kernel gaps and the batched plan kernel (k_native_plan_batch, 1 launch per 16 steps)"
                                  + (" and, on sharded runs, the exchange" if sharded else "") +
                                  "; per_launch_event_us brackets single half-step launches with hipEvents"},
         }

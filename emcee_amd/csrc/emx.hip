@@ -396,7 +396,7 @@ struct emx_ctx {
     int32_t* direct_counts = nullptr;         // [64]: owned slots per split of the step begun
     bool direct_planned = false;              // k_own_plan has run for the step begun
     int64_t tune_direct_timeout_ms = 5000;
-    // hipGraph replay of the native 8-step block (single move, thin_by 1, one rank)
+    // hipGraph replay of the native NATIVE_BATCH_MAX-step block (single move, thin_by 1, one rank)
     struct GraphSlot {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
@@ -1046,7 +1046,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_throttle = v;
         return 0;
     }
-    if (!strcmp(key, "graph")) {        // 1: replay the native 8-step block as a hipGraph (default 0: plain launches)
+    if (!strcmp(key, "graph")) {        // 1: replay the native NATIVE_BATCH_MAX-step block as a hipGraph (default 0: plain launches)
         c->tune_graph = v;
         return 0;
     }
@@ -2364,7 +2364,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
                                        (long long)c->stored);
                     ctr_synced = true;
                 }
-                HIPOK(c, hipGraphLaunch(g->exec, c->stream));      // 8 steps: plan + 8 x nsplits half-steps
+                HIPOK(c, hipGraphLaunch(g->exec, c->stream));      // one block: plan + NATIVE_BATCH_MAX x nsplits half-steps
                 c->ph_step += NATIVE_BATCH_MAX;
                 c->proposals += NATIVE_BATCH_MAX;
                 if (store) c->stored += NATIVE_BATCH_MAX;

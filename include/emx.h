@@ -120,7 +120,7 @@ int emx_chain_config(emx_ctx* ctx, int64_t capacity_steps); /* Backend.grow (bac
 int emx_chain_reset(emx_ctx* ctx);                            /* Backend.reset (backend.py:19-35) */
 int emx_run(emx_ctx* ctx, int64_t nsteps, int32_t thin_by, int32_t store);
 int emx_iteration(emx_ctx* ctx, int64_t* stored_steps, int64_t* proposals);
-/* With tuning key "graph" = 1, emx_run replays the native 8-step block (plan kernel + 8 x nsplits
+/* With tuning key "graph" = 1, emx_run replays the native 16-step block (plan kernel + 16 x nsplits
  * half-steps, per-replay state in device memory) as ONE hipGraph launch when it can (Philox, one move,
  * thin_by 1, one rank).  Off by default: measured 5 % slower than back-to-back launches on MI355X unless
  * the host is the bottleneck (a busy or slow host thread); results are bit-identical either way.  captured: bit0 no-store graph, bit1 store graph. */
