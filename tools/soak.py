@@ -20,8 +20,8 @@ def dense(D, seed=0):
     return mu, cov, 0.5 * (icov + icov.T)
 
 
-def run(label, N, D, target, mv, nsteps, thin_by, p0, check):
-    s = emcee_amd.EnsembleSampler(N, D, target, moves=mv, rng="philox")
+def run(label, N, D, target, mv, nsteps, thin_by, p0, check, rng="philox"):
+    s = emcee_amd.EnsembleSampler(N, D, target, moves=mv, rng=rng)
     t0 = time.perf_counter()
     st = s.run_mcmc(p0, nsteps, thin_by=thin_by, skip_initial_state_check=True)
     dt = time.perf_counter() - t0
@@ -54,4 +54,10 @@ if __name__ == "__main__":
     rosen = lambda x: -np.sum(100.0 * (x[:, 1:] - x[:, :-1] ** 2) ** 2 + (1 - x[:, :-1]) ** 2, axis=1) / 20.0  # noqa: E731
     res.append(run("c3 262144x32 rosenbrock", 262144, 32, targets.Rosenbrock(20.0), moves.StretchMove(), 20, 250,
                    1 + 0.1 * rs.randn(262144, 32), rosen))
+    res.append(run("c2 65536x64 dense stretch, exact MT19937 mode (plan pipeline)", 65536, 64, targets.DenseGaussian(mu, icov),
+                   moves.StretchMove(), 20, 250, p0, dg, rng="mt19937"))
+    muw, covw, icovw = dense(256, 3)
+    pw = muw + rs.randn(8192, 256) @ np.linalg.cholesky(covw).T
+    dgw = lambda x: -0.5 * np.einsum("ij,jk,ik->i", x - muw, icovw, x - muw)  # noqa: E731
+    res.append(run("wide dense 8192x256 stretch", 8192, 256, targets.DenseGaussian(muw, icovw), moves.StretchMove(), 20, 250, pw, dgw))
     json.dump(res, open("gpurun_out/soak.json", "w"), indent=1)
