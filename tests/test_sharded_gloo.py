@@ -182,6 +182,64 @@ def test_logprob_protocol_over_gloo(name, world):
     assert total_eval == nst * N                                # every proposal evaluated exactly once
 
 
+def _shared_lp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import emcee_amd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"rows": 0}
+
+    def fn(x):                                   # vectorised, with a blob column
+        calls["rows"] += len(x)
+        return np.column_stack([-0.5 * np.sum(x * x, axis=1), x[:, 0] + 1.0])
+
+    def fn1(x):                                  # per walker, no blobs
+        calls["rows"] += 1
+        return -0.5 * float(np.sum(x * x))
+
+    X = np.random.RandomState(4).randn(37, 3)    # 37 rows over 3 ranks: shares of 13, 13, 11
+    s = emcee_amd.EnsembleSampler(37, 3, fn, vectorize=True, distributed=True, exchange="logprob")
+    lp, blobs = s.compute_log_prob(X)
+    rows_vec = calls["rows"]
+    calls["rows"] = 0
+    s1 = emcee_amd.EnsembleSampler(37, 3, fn1, distributed=True, exchange="logprob")
+    lp1, blobs1 = s1.compute_log_prob(X)
+    lp_few, _ = s1.compute_log_prob(X[:2])       # fewer rows than ranks: somebody's share is empty
+    q.put((rank, lp, blobs, rows_vec, lp1, blobs1, calls["rows"], lp_few))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_python_log_prob_calls_are_shared_out_over_gloo():
+    """exchange='logprob' with a Python callable (ensemble.py:_shared_log_prob; the reference's pool.map, ensemble.py:486-496,
+    with the ranks of the process group for workers): every rank gets the full vector and blobs, in row order, having called
+    the function on its share only.  No GPU involved: compute_log_prob is host code."""
+    import torch.multiprocessing as mp
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 34500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shared_lp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X = np.random.RandomState(4).randn(37, 3)
+    want = -0.5 * np.sum(X * X, axis=1)
+    shares = {0: 13, 1: 13, 2: 11}
+    for rank, lp, blobs, rows_vec, lp1, blobs1, rows_one, lp_few in res:
+        assert np.array_equal(lp, want) and np.array_equal(np.ravel(blobs), X[:, 0] + 1.0)
+        assert rows_vec == shares[rank]
+        assert np.array_equal(lp1, want) and blobs1 is None
+        assert rows_one == shares[rank] + (1 if rank < 2 else 0)
+        assert np.array_equal(lp_few, want[:2])
+
+
 def _direct_worker(rank, world, port, name, nst, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
