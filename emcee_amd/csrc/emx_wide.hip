@@ -230,11 +230,13 @@ __global__ __launch_bounds__(256) void k_wide_commit(const WideCommitArgs A) {
         double* xr = A.X + (size_t)i * D;
         double* ch = A.chain ? A.chain + (size_t)i * D : nullptr;
         double* sb = A.sendbuf ? A.sendbuf + (size_t)(t - A.t_lo) * (D + 2) : nullptr;
-        for (int d = lane; d < D; d += 64) {
-            const double v = accept ? q[d] : xr[d];
-            if (accept) xr[d] = v;
-            if (ch) ch[d] = v;
-            if (sb) sb[d] = v;
+        if (accept || ch || sb) {               // a rejected proposal of an unstored, unsharded step touches no row at all
+            for (int d = lane; d < D; d += 64) {
+                const double v = accept ? q[d] : xr[d];
+                if (accept) xr[d] = v;
+                if (ch) ch[d] = v;
+                if (sb) sb[d] = v;
+            }
         }
         if (lane == 0) {
             const double lp_fin = accept ? nlp : lp_old;
