@@ -613,6 +613,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         w.pos0 = pos0;
         w.t_lo = t_lo;
         w.t_hi = t_hi;
+        w.single_role = c->tune_dense_wide == 2;
         if (move == MOVE_EVAL) {
             w.rows = X;
             w.out = lp;
@@ -1063,7 +1064,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "dense_wide")) {      // 1: take the wide-target path (emx_wide.hip) whatever the ndim -- parity tests against the fused kernel
-        c->tune_dense_wide = v ? 1 : 0;
+        c->tune_dense_wide = v == 2 ? 2 : (v ? 1 : 0);      // 2: the wide path with the single-role log-prob kernel only
         graph_invalidate(c);
         return 0;
     }

@@ -38,6 +38,7 @@ struct WideLpArgs {
     uint32_t* status;
     const int32_t* t_hi_dev;     // device-side slot count (block-ownership exchanges), or nullptr
     int32_t D, Dp, pos0, t_lo, t_hi, scatter, check_bad;
+    int32_t single_role;         // 1: never the role-split kernel (tuning "dense_wide" = 2: parity tests of the two kernels)
 };
 struct WideCommitArgs {
     double* X;

@@ -215,6 +215,208 @@ __global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
     }
 }
 
+// ---- the same contraction with the work split by ROLE (8 tiles per workgroup: ensembles of >= 8 tiles per CU) ----------------
+// Waves 0-3 (one per SIMD) only multiply, two row tiles each: per slab 8 A-fragment reads, 32 B-fragment reads (each feeds
+// two MFMAs), 64 MFMAs.  Waves 4-7 (the other wave of each SIMD) only stage: they load the next slab of L and the next
+// 16 x 16 piece of all eight row tiles (a slab ahead, in registers), subtract the mean, test finiteness and write both into
+// the other LDS buffers.  One workgroup barrier per slab hands the buffers over.  In the single-role kernel above every wave
+// carries ~150 staging instructions per slab in front of the same barrier as its 32 MFMAs, and MFMA issue blocks its wave:
+// the matrix pipe idled for a fifth of the kernel whatever the order.
+constexpr int WS_TILES = 8, WS_CONS = 4, WS_LOAD = 4, WS_NT = 64 * (WS_CONS + WS_LOAD), WS_NLT = 64 * WS_LOAD;
+
+__host__ __device__ constexpr size_t wide_ws_lds_bytes(int Dp) {
+    return ((size_t)2 * SLAB + (size_t)2 * WS_TILES * 16 * ART + (size_t)Dp) * sizeof(double) + WS_TILES * 16 * 8;
+}
+
+// one slab against the first NC column blocks for TWO row tiles: every B fragment feeds two MFMAs
+template <int NC>
+__device__ __forceinline__ void slab_mfma2(double4_t (&acc0)[8], double4_t (&acc1)[8], const double (&a0)[4], const double (&a1)[4],
+                                           const double* bs, int lane) {
+    double b[2][NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) b[0][j] = bs[(j * 4) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i + 1 < 4) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) b[(i + 1) & 1][j] = bs[(j * 4 + i + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            acc0[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b[i & 1][j], acc0[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b[i & 1][j], acc1[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];      // slab[2][SLAB] | A tiles [2][8][16][ART] | mu[Dp] | bad[8][16][8]
+    typedef double4_t d4;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, tx = threadIdx.x;
+    const int D = A.D, Dp = A.Dp, DPB = Dp / 16, KK = Dp / 4;
+    const int t_hi = A.t_hi_dev ? *A.t_hi_dev : A.t_hi;
+    const int ntiles = (t_hi - A.t_lo + 15) / 16;
+    const int nmacro = (DPB + 7) / 8;
+    double* Bs = dsm;
+    double* As = dsm + (size_t)2 * SLAB;
+    double* muS = As + (size_t)2 * WS_TILES * 16 * ART;
+    unsigned char* badS = reinterpret_cast<unsigned char*>(muS + Dp);
+    for (int d = tx; d < Dp; d += WS_NT) muS[d] = A.img[(size_t)Dp * Dp + d];      // zero padded beyond D
+    __syncthreads();
+    auto next_of = [&](int& nb_, int& sp_) {                  // slab order: macro block by macro block, k blocks from the diagonal down
+        if (++sp_ == DPB - 8 * nb_) {
+            ++nb_;
+            sp_ = 0;
+        }
+    };
+    int nslabs = 0;
+    for (int m = 0; m < nmacro; ++m) nslabs += DPB - 8 * m;
+
+    for (int base = blockIdx.x * WS_TILES; base < ntiles; base += gridDim.x * WS_TILES) {      // workgroup-uniform
+        if (wib >= WS_CONS) {
+            // ------------------------------------------------ loader waves ------------------------------------------------
+            const int lt = tx - 64 * WS_CONS;                  // 0 .. 255
+            const double2* img2 = reinterpret_cast<const double2*>(A.img);
+            // slab of L: double2 number e = lt + r * 256 of the 32 chunks (column block j, k-step i) x 32
+            int boff[4], bj[4];
+            // row pieces: (tile w, row, 16-byte piece) number e of 8 x 16 x 8
+            const double* rbase[4];
+            bool rlive[4];
+            int aoff[4], apc[4];
+            bool bad[4] = {false, false, false, false};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = lt + r * WS_NLT, chunk = e >> 5, within = e & 31;
+                bj[r] = chunk >> 2;
+                boff[r] = ((chunk >> 2) * KK + (chunk & 3)) * 32 + within;
+                const int w = e >> 7, row = (e >> 3) & 15, pc = e & 7;
+                const int tile = base + w, t = A.t_lo + tile * 16 + row;
+                rlive[r] = tile < ntiles && t < t_hi;
+                rbase[r] = A.rows + (size_t)(rlive[r] ? (A.order ? A.order[A.pos0 + t] : t) : 0) * D;
+                aoff[r] = (w * 16 + row) * ART + 2 * pc;
+                apc[r] = 2 * pc;
+            }
+            double2 bn[4], xn[4];
+            auto issue = [&](int nbb, int sp) {                // raw loads only; first use one slab later
+                const int ncb = min(8, DPB - 8 * nbb), kb = 8 * nbb + sp;
+                const double2* src = img2 + ((size_t)(8 * nbb) * KK + 4 * kb) * 32;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bn[r] = bj[r] < ncb ? src[boff[r]] : double2{0.0, 0.0};
+                const int k0 = 16 * kb;
+                if (k0 + 16 <= D) {                            // uniform: the whole k block lies inside the rows
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double2_a8 v = *reinterpret_cast<const double2_a8*>(rbase[r] + k0 + apc[r]);
+                        xn[r] = double2{v.x, v.y};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        xn[r] = double2{rbase[r][min(k0 + apc[r], D - 1)], rbase[r][min(k0 + apc[r] + 1, D - 1)]};
+                }
+            };
+            auto publish = [&](int kb, int buf) {              // R = Q - mu, masked; the finiteness test on the raw values
+                double2* bdst = reinterpret_cast<double2*>(Bs + (size_t)buf * SLAB);
+                double* adst = As + (size_t)buf * WS_TILES * 16 * ART;
+                const int k0 = 16 * kb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bdst[lt + r * WS_NLT] = bn[r];
+                    const int k = k0 + apc[r];
+                    const double x0 = (rlive[r] && k < D) ? xn[r].x : 0.0, x1 = (rlive[r] && k + 1 < D) ? xn[r].y : 0.0;
+                    bad[r] |= (__double2hiint(x0) & 0x7ff00000) == 0x7ff00000 || (__double2hiint(x1) & 0x7ff00000) == 0x7ff00000;
+                    *reinterpret_cast<double2*>(adst + aoff[r]) = double2{x0 - muS[k], x1 - muS[k + 1]};
+                }
+            };
+            int nbl = 0, spl = 0;
+            issue(0, 0);
+            publish(0, 0);
+            next_of(nbl, spl);
+            if (nbl < nmacro) issue(nbl, spl);
+            __syncthreads();                                   // slab 0 is in buffer 0
+            for (int s = 0; s < nslabs; ++s) {
+                if (s + 1 < nslabs) {
+                    publish(8 * nbl + spl, (s + 1) & 1);       // nobody reads that buffer any more
+                    next_of(nbl, spl);
+                    if (nbl < nmacro) issue(nbl, spl);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) badS[lt + r * WS_NLT] = bad[r] ? 1 : 0;
+            __syncthreads();                                   // the flags are visible to the deciding lanes
+            __syncthreads();                                   // ... and read before the next pass overwrites anything
+        } else {
+            // ----------------------------------------------- consumer waves -----------------------------------------------
+            const int am = lane & 15, ak = lane >> 4;
+            double part0[4] = {0.0, 0.0, 0.0, 0.0}, part1[4] = {0.0, 0.0, 0.0, 0.0};
+            d4 acc0[8], acc1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc0[j] = acc1[j] = d4{0.0, 0.0, 0.0, 0.0};
+            int s = 0;
+            __syncthreads();                                   // slab 0 is in buffer 0
+            // one slab: A fragments of both tiles, the MFMAs against the first NC column blocks, hand the buffers over
+#define EMX_WS_SLAB(NC)                                                                              \
+    do {                                                                                             \
+        const double* bs = Bs + (size_t)(s & 1) * SLAB;                                              \
+        const double* at = As + ((size_t)(s & 1) * WS_TILES + 2 * wib) * 16 * ART;                   \
+        double a0[4], a1[4];                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+            a0[i] = at[am * ART + 4 * i + ak];                                                       \
+            a1[i] = at[16 * ART + am * ART + 4 * i + ak];                                            \
+        }                                                                                            \
+        slab_mfma2<NC>(acc0, acc1, a0, a1, bs, lane);                                                \
+        ++s;                                                                                         \
+        __syncthreads();                                                                             \
+    } while (0)
+            for (int m = 0; m < nmacro; ++m) {
+                const int ncb = min(8, DPB - 8 * m), nsl = DPB - 8 * m;
+                // the slabs across the diagonal blocks: column block j starts at its diagonal block (k block >= j); the column
+                // blocks a short last macro block does not have hold zeros (the loaders write them) and are never folded
+                if (nsl > 0) EMX_WS_SLAB(1);
+                if (nsl > 1) EMX_WS_SLAB(2);
+                if (nsl > 2) EMX_WS_SLAB(3);
+                if (nsl > 3) EMX_WS_SLAB(4);
+                if (nsl > 4) EMX_WS_SLAB(5);
+                if (nsl > 5) EMX_WS_SLAB(6);
+                if (nsl > 6) EMX_WS_SLAB(7);
+                for (int sp = 7; sp < nsl; ++sp) EMX_WS_SLAB(8);
+                // macro block complete: fold the squares, column blocks ascending
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < ncb) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            part0[r] = fma(acc0[j][r], acc0[j][r], part0[r]);
+                            part1[r] = fma(acc1[j][r], acc1[j][r], part1[r]);
+                        }
+                    }
+                    acc0[j] = acc1[j] = d4{0.0, 0.0, 0.0, 0.0};
+                }
+            }
+#undef EMX_WS_SLAB
+            __syncthreads();                                   // the loaders' finiteness flags
+            const int myrow = (lane >> 4) + 4 * (lane & 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double qf = h ? row16_sum4(part1[0], part1[1], part1[2], part1[3], lane)
+                                    : row16_sum4(part0[0], part0[1], part0[2], part0[3], lane);
+                const int w = 2 * wib + h, tile = base + w;
+                const int tt = A.t_lo + tile * 16 + myrow;
+                if ((lane & 15) < 4 && tile < ntiles && tt < t_hi) {
+                    const unsigned long long fl = *reinterpret_cast<const unsigned long long*>(badS + (w * 16 + myrow) * 8);
+                    const bool rowbad = A.check_bad && fl != 0ull;
+                    const double lpn = rowbad ? -__builtin_inf() : -0.5 * qf;    // a non-finite proposal is rejected (ensemble.py:476-479 raised already)
+                    if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);         // ensemble.py:550-551
+                    A.out[A.scatter ? (A.order ? A.order[A.pos0 + tt] : tt) : tt] = lpn;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // decision + commit of one half-step from (qout, fout, newlp): red_blue.py:96-101, move.py:33-34; one wave per slot
 __global__ __launch_bounds__(256) void k_wide_commit(const WideCommitArgs A) {
     const int lane = threadIdx.x & 63;
@@ -281,6 +483,18 @@ hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipS
     const int W = ntiles >= 8 * num_cu ? 8 : ntiles >= 4 * num_cu ? 4 : ntiles >= 2 * num_cu ? 2 : 1;
     const int nblocks = (ntiles + W - 1) / W;
     const dim3 grid((unsigned)std::min(nblocks, 4 * num_cu));
+    if (W == 8 && !a.single_role) {
+        const size_t lds = wide_ws_lds_bytes(a.Dp);
+        static size_t lds_granted[MAX_DEVICES] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
+            const hipError_t e = hipFuncSetAttribute((const void*)k_wide_lp_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_granted[dev] = lds;
+        }
+        hipLaunchKernelGGL(k_wide_lp_ws, grid, dim3(WS_NT), lds, st, a);
+        return hipGetLastError();
+    }
     switch (W) {
         case 8: return launch_lp<8>(a, grid, st);
         case 4: return launch_lp<4>(a, grid, st);

@@ -81,7 +81,8 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  * "small_kernel" (1: ensembles that fit one CU's LDS run whole emx_run calls in one workgroup; default),
  * "mt_pipeline" (MT19937 mode, emx_run: -1 plans from the threaded host pipeline, finisher threads chosen from the core
  * count (default); k > 0: k finisher threads; 0: plans made inline by the calling thread),
- * "dense_wide" (1: dense targets take the propose / log-prob / commit path of wide targets whatever the ndim; parity tests),
+ * "dense_wide" (1: dense targets take the propose / log-prob / commit path of wide targets whatever the ndim; 2: the same with
+ * the single-role log-prob kernel even where the role-split one applies; parity tests),
  * "phase_clock" (instrumented builds) */
 int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value);
 

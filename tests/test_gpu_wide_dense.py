@@ -102,3 +102,27 @@ def test_wide_non_finite_proposal_is_rejected_and_reported():
     x, lp = ens.get_state()
     assert np.all(np.isfinite(x))
     ens.close()
+
+
+@pytest.mark.parametrize("N,D,moves", [(65536 + 40, 64, [_S("stretch")]), (2 * 8 * 256 * 16 + 16, 130, [_S("de", live_dangerously=True)])])
+def test_role_split_log_prob_kernel_equals_the_single_role_one(N, D, moves):
+    """Ensembles of >= 8 row tiles per CU take k_wide_lp_ws (four waves multiply two tiles each, four waves stage); the
+    same contraction order as k_wide_lp, so the chains agree bit for bit -- and, at ndim 64, with the fused kernel too."""
+    spec = _spec(N, D, moves, seed=11)
+    outs = []
+    for wide in ((0, 1, 2) if D <= 112 else (1, 2)):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_tuning("dense_wide", wide)
+        ens.eval_state_log_prob()
+        lp0 = ens.get_state()[1]
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(31, 0)
+        ens.run(4, 1, False)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        outs.append((lp0, x, lp, ens.accepted_mask().copy()))
+        ens.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+    assert outs[0][3].sum() > 0
