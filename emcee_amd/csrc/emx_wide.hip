@@ -185,15 +185,21 @@ __global__ __launch_bounds__(64 * W) void k_wide_lp(const WideLpArgs A) {
             EMX_SLAB_STEPS(0, 4);
             stage();
 #undef EMX_SLAB_STEPS
-            if (sp == nsl - 1) {                               // macro block complete: fold the squares, column blocks ascending
+            if (sp == nsl - 1) {
+                // macro block complete: its squares folded column block by column block (one chain from zero), the chain's
+                // total added to the row sums -- macro block by macro block, so that the macro blocks of a tile can also be
+                // computed by different waves (k_wide_lp_ms) and give the same bits
+                double pm[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < ncb) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) part[r] = fma(acc[j][r], acc[j][r], part[r]);
+                        for (int r = 0; r < 4; ++r) pm[r] = fma(acc[j][r], acc[j][r], pm[r]);
                     }
                     acc[j] = d4{0.0, 0.0, 0.0, 0.0};
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[r] += pm[r];
             }
             __syncthreads();                                   // slab s + 1 is published; nobody reads slab s any more
             if (last) break;
@@ -382,17 +388,23 @@ __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
                 if (nsl > 5) EMX_WS_SLAB(6);
                 if (nsl > 6) EMX_WS_SLAB(7);
                 for (int sp = 7; sp < nsl; ++sp) EMX_WS_SLAB(8);
-                // macro block complete: fold the squares, column blocks ascending
+                // macro block complete: the chain of its squares (from zero), then the chain's total into the row sums
+                double pm0[4] = {0.0, 0.0, 0.0, 0.0}, pm1[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < ncb) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            part0[r] = fma(acc0[j][r], acc0[j][r], part0[r]);
-                            part1[r] = fma(acc1[j][r], acc1[j][r], part1[r]);
+                            pm0[r] = fma(acc0[j][r], acc0[j][r], pm0[r]);
+                            pm1[r] = fma(acc1[j][r], acc1[j][r], pm1[r]);
                         }
                     }
                     acc0[j] = acc1[j] = d4{0.0, 0.0, 0.0, 0.0};
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    part0[r] += pm0[r];
+                    part1[r] += pm1[r];
                 }
             }
 #undef EMX_WS_SLAB
@@ -414,6 +426,157 @@ __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
             }
             __syncthreads();
         }
+    }
+}
+
+// ---- the same contraction for ensembles of FEW row tiles: the macro blocks of one tile on different waves ----------------------
+// A workgroup owns one 16-row tile; wave w computes macro blocks w, w + 4, ... (128 columns of Y each) on its own: A fragments
+// through a wave-private LDS tile as above, B fragments straight from the image in L2 (nothing to share: every wave reads a
+// different part of L), double-buffered a slab ahead in registers, no workgroup barrier inside the loop.  Each macro block's
+// chain of squares goes to LDS; wave 0 adds them in macro order -- the order of the other two kernels, so the bits are the same
+// -- and decides.  With the tiles of a small ensemble on one wave each (k_wide_lp<1>) a 512-dimensional log-prob took 80
+// slabs in sequence per tile; here the longest wave takes 32.
+constexpr int MS_W = 4;
+
+__host__ __device__ constexpr size_t wide_ms_lds_bytes(int Dp) {
+    return ((size_t)Dp + (size_t)MS_W * 16 * ART + (size_t)((Dp / 16 + 7) / 8) * 256) * sizeof(double);
+}
+
+// the B fragments of slab (m, sp) for the first NC column blocks: 4 k-steps x NC loads of 8 bytes per lane
+template <int NC>
+__device__ __forceinline__ void ms_load_b(double (&b)[4][8], const double* img, int KK, int m, int kb, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) b[i][j] = img[((size_t)(8 * m + j) * KK + 4 * kb + i) * 64 + lane];
+}
+
+template <int NC>
+__device__ __forceinline__ void ms_mfma(double4_t (&acc)[8], const double (&afr)[4], const double (&b)[4][8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[i], b[i][j], acc[j], 0, 0, 0);
+}
+
+__global__ __launch_bounds__(64 * MS_W) void k_wide_lp_ms(const WideLpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];      // mu[Dp] | per wave: A tile [16][ART] | per macro block: chain totals [64][4]
+    typedef double4_t d4;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, tx = threadIdx.x;
+    const int am = lane & 15, ak = lane >> 4;
+    const int arow = lane >> 2, aseg = lane & 3;
+    const int D = A.D, Dp = A.Dp, DPB = Dp / 16, KK = Dp / 4;
+    const int t_hi = A.t_hi_dev ? *A.t_hi_dev : A.t_hi;
+    const int ntiles = (t_hi - A.t_lo + 15) / 16;
+    const int nmacro = (DPB + 7) / 8;
+    double* muS = dsm;
+    double* At = muS + Dp + wib * 16 * ART;
+    double* pmS = muS + Dp + MS_W * 16 * ART;
+    for (int d = tx; d < Dp; d += 64 * MS_W) muS[d] = A.img[(size_t)Dp * Dp + d];
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {          // workgroup-uniform
+        const int t = A.t_lo + tile * 16 + arow;
+        const bool rowlive = t < t_hi;
+        const double* rowp = A.rows + (size_t)(rowlive ? (A.order ? A.order[A.pos0 + t] : t) : 0) * D;
+        bool bad = false;
+        for (int m = wib; m < nmacro; m += MS_W) {
+            const int ncb = min(8, DPB - 8 * m), nsl = DPB - 8 * m;
+            d4 acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+            double afr[4], xn[4], bc[4][8], bn[4][8];
+            // the A fragments of k block kb: raw loads (issue), then mask / finiteness / tile / R = Q - mu (consume)
+            auto issue_a = [&](int kb) {
+                const int kn = 16 * kb + 4 * aseg;
+                if (16 * kb + 16 <= D) {
+                    const double* rp = rowlive ? rowp + kn : A.rows;
+                    const double2_a8 lo = *reinterpret_cast<const double2_a8*>(rp);
+                    const double2_a8 hi = *reinterpret_cast<const double2_a8*>(rp + 2);
+                    xn[0] = lo.x;
+                    xn[1] = lo.y;
+                    xn[2] = hi.x;
+                    xn[3] = hi.y;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xn[e] = rowp[min(kn + e, D - 1)];
+                }
+            };
+            auto consume_a = [&](int kb) {
+                const int kn = 16 * kb + 4 * aseg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xn[e] = (rowlive && kn + e < D) ? xn[e] : 0.0;
+                    bad |= (__double2hiint(xn[e]) & 0x7ff00000) == 0x7ff00000;
+                }
+                double2* dst = reinterpret_cast<double2*>(At + arow * ART + 4 * aseg);
+                dst[0] = double2{xn[0], xn[1]};
+                dst[1] = double2{xn[2], xn[3]};
+                EMX_WAVE_SYNC();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) afr[i] = At[am * ART + 4 * i + ak] - muS[16 * kb + 4 * i + ak];
+                EMX_WAVE_SYNC();
+            };
+            // one slab with NC column blocks; the operands of the next one (NCN column blocks) are loaded meanwhile
+#define EMX_MS_SLAB(NC, NCN)                                                   \
+    do {                                                                       \
+        const int kb_ = 8 * m + sp_;                                           \
+        const bool more_ = sp_ + 1 < nsl;                                      \
+        if (more_) {                                                           \
+            ms_load_b<NCN>(bn, A.img, KK, m, kb_ + 1, lane);                   \
+            issue_a(kb_ + 1);                                                  \
+        }                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        ms_mfma<NC>(acc, afr, bc);                                             \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        if (more_) {                                                           \
+            consume_a(kb_ + 1);                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                   \
+                _Pragma("unroll") for (int j_ = 0; j_ < NCN; ++j_) bc[i_][j_] = bn[i_][j_]; \
+        }                                                                      \
+        ++sp_;                                                                 \
+    } while (0)
+            int sp_ = 0;
+            ms_load_b<1>(bc, A.img, KK, m, 8 * m, lane);
+            issue_a(8 * m);
+            consume_a(8 * m);
+            if (nsl > 0) EMX_MS_SLAB(1, 2);
+            if (nsl > 1) EMX_MS_SLAB(2, 3);
+            if (nsl > 2) EMX_MS_SLAB(3, 4);
+            if (nsl > 3) EMX_MS_SLAB(4, 5);
+            if (nsl > 4) EMX_MS_SLAB(5, 6);
+            if (nsl > 5) EMX_MS_SLAB(6, 7);
+            if (nsl > 6) EMX_MS_SLAB(7, 8);
+            while (sp_ < nsl) EMX_MS_SLAB(8, 8);
+#undef EMX_MS_SLAB
+            double pm[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < ncb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pm[r] = fma(acc[j][r], acc[j][r], pm[r]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pmS[((size_t)m * 64 + lane) * 4 + r] = pm[r];
+        }
+        const unsigned long long bm = __ballot(bad);          // lanes 4 r .. 4 r + 3 loaded row r; wave 0 saw every k (macro block 0)
+        __syncthreads();
+        if (wib == 0) {
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int m = 0; m < nmacro; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[r] += pmS[((size_t)m * 64 + lane) * 4 + r];
+            const double qf = row16_sum4(part[0], part[1], part[2], part[3], lane);
+            const int myrow = (lane >> 4) + 4 * (lane & 3);
+            const int tt = A.t_lo + tile * 16 + myrow;
+            const bool rowbad = A.check_bad && ((bm >> (4 * myrow)) & 0xFull);
+            if ((lane & 15) < 4 && tt < t_hi) {
+                const double lpn = rowbad ? -__builtin_inf() : -0.5 * qf;        // a non-finite proposal is rejected (ensemble.py:476-479 raised already)
+                if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);             // ensemble.py:550-551
+                A.out[A.scatter ? (A.order ? A.order[A.pos0 + tt] : tt) : tt] = lpn;
+            }
+        }
+        __syncthreads();                                       // the chain totals are consumed before the next tile overwrites them
     }
 }
 
@@ -483,6 +646,21 @@ hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipS
     const int W = ntiles >= 8 * num_cu ? 8 : ntiles >= 4 * num_cu ? 4 : ntiles >= 2 * num_cu ? 2 : 1;
     const int nblocks = (ntiles + W - 1) / W;
     const dim3 grid((unsigned)std::min(nblocks, 4 * num_cu));
+    const int nmacro = (a.Dp / 16 + 7) / 8;
+    if (!a.single_role && nmacro >= 2 && ntiles < num_cu * (nmacro >= 4 ? 5 : 3)) {
+        // few row tiles per CU, several macro blocks: the macro blocks of a tile on different waves (a wave's longest chain is
+        // DPB slabs of ~2 500 cycles against nslabs ~ DPB (nmacro + 1) / 2 slabs of ~5 300 in the single-role kernel)
+        const size_t lds = wide_ms_lds_bytes(a.Dp);
+        static size_t lds_granted[MAX_DEVICES] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
+            const hipError_t e = hipFuncSetAttribute((const void*)k_wide_lp_ms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_granted[dev] = lds;
+        }
+        hipLaunchKernelGGL(k_wide_lp_ms, dim3((unsigned)std::min(ntiles, 4 * num_cu)), dim3(64 * MS_W), lds, st, a);
+        return hipGetLastError();
+    }
     if (W == 8 && !a.single_role) {
         const size_t lds = wide_ws_lds_bytes(a.Dp);
         static size_t lds_granted[MAX_DEVICES] = {};

@@ -104,10 +104,13 @@ def test_wide_non_finite_proposal_is_rejected_and_reported():
     ens.close()
 
 
-@pytest.mark.parametrize("N,D,moves", [(65536 + 40, 64, [_S("stretch")]), (2 * 8 * 256 * 16 + 16, 130, [_S("de", live_dangerously=True)])])
+@pytest.mark.parametrize("N,D,moves", [(65536 + 40, 64, [_S("stretch")]), (2 * 8 * 256 * 16 + 16, 130, [_S("de", live_dangerously=True)]),
+                                       (600, 300, [_S("stretch", live_dangerously=True)]), (90, 1000, [_S("stretch", live_dangerously=True)]),
+                                       (5000, 520, [_S("de", live_dangerously=True)])])
 def test_role_split_log_prob_kernel_equals_the_single_role_one(N, D, moves):
-    """Ensembles of >= 8 row tiles per CU take k_wide_lp_ws (four waves multiply two tiles each, four waves stage); the
-    same contraction order as k_wide_lp, so the chains agree bit for bit -- and, at ndim 64, with the fused kernel too."""
+    """Ensembles of >= 8 row tiles per CU take k_wide_lp_ws (four waves multiply two tiles each, four waves stage), ensembles
+    of few row tiles and more than 128 columns k_wide_lp_ms (the macro blocks of a tile on different waves); the same
+    contraction order as k_wide_lp, so the chains agree bit for bit -- and, at ndim 64, with the fused kernel too."""
     spec = _spec(N, D, moves, seed=11)
     outs = []
     for wide in ((0, 1, 2) if D <= 112 else (1, 2)):
