@@ -13,6 +13,12 @@
 // lanes per row), pass through a 16 x 16 LDS tile of its own and come back as A fragments.  Every load is issued a whole
 // slab before its first use, and nothing touches a loaded register in between (a select or a compare on a loaded value
 // there cost a vmcnt(0) in the issue phase: 23 % of the kernel, measured).
+//
+// Three forms of that kernel, one fold order (per 128-column macro block a chain of squares from zero, the chains' totals added
+// macro block by macro block), hence the same bits:
+//   k_wide_lp_ms   few row tiles per CU: one tile per workgroup, its macro blocks on different waves, no barrier in the loop
+//   k_wide_lp<W>   in between: W tiles per workgroup share every slab of L through LDS
+//   k_wide_lp_ws   >= 8 tiles per CU: four waves multiply two tiles each, four waves stage for all eight
 #include <algorithm>
 
 #include "emx_launch.hpp"
