@@ -447,13 +447,15 @@ def _torch_nccl_group(dist):
     return _NCCL_GROUP["g"]
 
 
-def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode, single_block=False):
+def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode, single_block=False, direct_timeout_ms=None):
     """One sharded measurement (fresh context): spin-up, W warm-up steps, K-step blocks."""
     import torch
     from emcee_amd.device import DeviceEnsemble
     ens = DeviceEnsemble(wl.N, wl.D, device=local_rank)
     wl.install(ens, "philox")
     ens.set_exchange(exchange)
+    if direct_timeout_ms:
+        ens.set_tuning("direct_timeout_ms", int(direct_timeout_ms))
     comm_used = None
     if comm_mode == "torch":
         if exchange == "direct":
@@ -522,10 +524,119 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
     res = {"wall_s": float(np.median(walls)), "gpu_ms": float(np.median(gpus)), "blocks": nblk, "comm": comm_used,
            "exchange": exchange, "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(),
            "digest": digest, "replicas_agree": len(set(every)) == 1}
+    res.update(_rank_census(ens, dist, comm_mode, local_rank))
     if comm_mode != "torch":
         ens.comm_destroy()
     ens.close()
     return res
+
+
+def _rank_census(ens, dist, comm_mode, local_rank):
+    """How many ranks the communicator that carried the exchange really has (ncclCommCount of libemx's communicator, or the
+    torch process group's size) and how many DISTINCT devices the ranks sit on: n_gpus = N is only claimed when both say N."""
+    import torch
+    try:
+        ranks = ens.comm_count() if comm_mode != "torch" else dist.get_world_size()
+    except Exception as e:  # noqa: BLE001
+        log("comm_count failed:", e)
+        ranks = None
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        ident = "%s/%s" % (getattr(p, "uuid", None), "%x:%x:%x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0),
+                                                                    getattr(p, "pci_device_id", 0)))
+    except Exception:  # noqa: BLE001
+        ident = "device%d" % local_rank
+    every = [None] * dist.get_world_size()
+    dist.all_gather_object(every, ident)
+    return {"rccl_ranks": ranks, "distinct_devices": len(set(every))}
+
+
+class TinyWorkload(Workload):
+    """Preflight: a few thousand walkers, isotropic Gaussian, StretchMove -- one millisecond of work per protocol."""
+
+    def __init__(self, world):
+        from emcee_amd import _lib
+        self.key = "preflight"
+        self.N, self.D = 4096 * world, 16
+        self.target = (_lib.TARGET_ISO, None, None, 0.0)
+        self.p0 = np.random.RandomState(3).randn(self.N, self.D)
+        self.moves = [("stretch", _lib.MoveDesc(0, 2, 1, 0, 2.0, 1e-5, 0.4, 1.7))]
+        self.weights = [1.0]
+        self.label = "preflight: %d x %d isotropic Gaussian" % (self.N, self.D)
+
+
+def preflight_child(args, rank, world, local_rank, dist):
+    """`--child preflight:<exchange,...>`: first contact with the node, seconds per item instead of a 120 s watchdog each.
+    Checks, in order: peer access between the devices, then every exchange protocol asked for on a tiny ensemble (8 steps,
+    ensembles compared across the ranks).  One line per finished item goes out immediately, so a hang is attributed to the item
+    in flight."""
+    import torch
+    out = _claim_stdout()
+
+    def say(item, verdict):
+        out.write("EMX_PREFLIGHT %s %s\n" % (item, json.dumps(verdict)))
+        out.flush()
+
+    res = {}
+    try:
+        ndev = torch.cuda.device_count()
+        peers = [bool(torch.cuda.can_device_access_peer(local_rank, q)) for q in range(min(ndev, world)) if q != local_rank] \
+            if args.all_on_device is None else []
+        res["p2p"] = {"ok": all(peers), "devices_visible": ndev, "peer_access": peers}
+    except Exception as e:  # noqa: BLE001
+        res["p2p"] = {"ok": False, "error": repr(e)}
+    say("p2p", res["p2p"])
+    wl = TinyWorkload(world)
+    for ex in args.child.split(":", 1)[1].split(","):
+        if not ex:
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = measure_sharded(wl, 8, 2, ex, rank, world, local_rank, dist, args.comm, single_block=True, direct_timeout_ms=2000)
+            ok = r["status"] == 0 and r["replicas_agree"]
+            res[ex] = {"ok": bool(ok), "seconds": time.perf_counter() - t0, "device_status": r["status"], "replicas_agree": r["replicas_agree"],
+                       "digest": r["digest"], "rccl_ranks": r.get("rccl_ranks"), "distinct_devices": r.get("distinct_devices")}
+        except Exception as e:  # noqa: BLE001
+            res[ex] = {"ok": False, "seconds": time.perf_counter() - t0, "error": repr(e)[:300]}
+        allok = torch_all_ok(dist, res[ex]["ok"])
+        if not allok and res[ex]["ok"]:
+            res[ex] = {"ok": False, "error": "failed on another rank"}
+        say(ex, res[ex])
+    return res
+
+
+def run_preflight(args, world, dist, port0, exchanges):
+    """-> {item: verdict}.  A child that hangs is killed after --preflight-timeout; what it had finished counts, the item in
+    flight is marked failed and the rest is tried again in a fresh child."""
+    verdicts = {}
+    todo = list(exchanges)
+    attempt = 0
+    while True:
+        r = run_child(args, "preflight", ",".join(todo), port0 + attempt, args.preflight_timeout + (180.0 if attempt == 0 else 0.0),
+                      keep_partial=True)
+        attempt += 1
+        done = r.get("preflight", {}) if isinstance(r, dict) else {}
+        for k, v in done.items():
+            verdicts.setdefault(k, v)
+        left = [e for e in todo if e not in verdicts]
+        # every rank must take the same decision: agree on the shortest list of finished items
+        n_done = len(todo) - len(left)
+        import torch
+        t = torch.tensor([n_done])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        n_done = int(t[0])
+        for e in todo[n_done:]:
+            verdicts.pop(e, None)
+        left = todo[n_done:]
+        if not left or attempt >= 4:
+            for e in left:
+                verdicts[e] = {"ok": False, "error": "not reached"}
+            break
+        verdicts[left[0]] = {"ok": False, "error": r.get("error") or "hung or crashed during the preflight (child killed)"}
+        todo = left[1:]
+        if not todo:
+            break
+    return verdicts
 
 
 def sharded_workload(key, world, args):
@@ -539,9 +650,19 @@ def child_main(args, rank, world, local_rank):
     collective takes this child with it, not the rank's orchestrating parent (which never touches the GPU at N > 1)."""
     import torch
     import torch.distributed as dist
-    key, ex = args.child.split(":")
+    key, ex = args.child.split(":", 1)
     torch.cuda.set_device(local_rank)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % args.child_port, rank=rank, world_size=world)
+    if key == "preflight":
+        out = {"preflight": preflight_child(args, rank, world, local_rank, dist)}
+        _claim_stdout().write("EMX_CHILD_RESULT " + json.dumps(out) + "\n")
+        _claim_stdout().flush()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        return
     wl, _ = sharded_workload(key, world, args)
     out = {"error": None}
     try:
@@ -567,7 +688,19 @@ def child_main(args, rank, world, local_rank):
         pass
 
 
-def run_child(args, key, ex, port, timeout_s):
+def _partial_preflight(text):
+    done = {}
+    for line in (text or "").splitlines():
+        if line.startswith("EMX_PREFLIGHT "):
+            try:
+                _, item, verdict = line.split(" ", 2)
+                done[item] = json.loads(verdict)
+            except Exception:  # noqa: BLE001
+                pass
+    return done
+
+
+def run_child(args, key, ex, port, timeout_s, keep_partial=False):
     """-> the child's result dict, or {"error": ...} (non-zero exit, no result line, or the timeout)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
@@ -578,18 +711,53 @@ def run_child(args, key, ex, port, timeout_s):
         cmd += ["--all-on-device", str(args.all_on_device)]
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, text=True, timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        return {"error": "no result within %.0f s (hung; child killed)" % timeout_s}
+    except subprocess.TimeoutExpired as e:
+        out = {"error": "no result within %.0f s (hung; child killed)" % timeout_s}
+        if keep_partial:
+            txt = e.stdout.decode() if isinstance(e.stdout, bytes) else e.stdout
+            out["preflight"] = _partial_preflight(txt)
+        return out
     for line in (r.stdout or "").splitlines():
         if line.startswith("EMX_CHILD_RESULT "):
             try:
                 return json.loads(line[len("EMX_CHILD_RESULT "):])
             except Exception as e:  # noqa: BLE001
                 return {"error": "unreadable child result: %r" % (e,)}
-    return {"error": "child exited with code %d and no result" % r.returncode}
+    out = {"error": "child exited with code %d and no result" % r.returncode}
+    if keep_partial:
+        out["preflight"] = _partial_preflight(r.stdout)
+    return out
 
 
 _CHILDREN_RUN = []
+
+
+XGMI_INGRESS_GBPS = 7 * 76.8        # MI355X: 7 links x 153.6 GB/s bidirectional = 76.8 GB/s per direction each (MI355X_MICROARCH.md)
+
+# DESIGN.md section 6, "What to expect": microseconds per step of the protocol expected to win, written down BEFORE the first
+# multi-GPU run so that the first curve can be read against a prediction (world size -> us/step)
+PREDICTED_US_PER_STEP = {
+    "c2": {2: 40.0, 4: 42.0, 8: 56.0},
+    "c3": {2: 38.0, 4: 34.0, 8: 33.0},
+    "c5": {2: 44.0, 4: 36.0, 8: 33.0},
+    "w512": {2: 300.0, 4: 170.0, 8: 105.0},
+}
+
+
+def xgmi_bytes_per_update(wl, ex, world, accept_frac=None):
+    """Bytes a GPU receives over xGMI per walker-update of the whole ensemble's step."""
+    G, D = world, wl.D
+    w = np.asarray(wl.weights) / np.sum(wl.weights)
+    npart = float(sum(wi * partner_rows(kind) for wi, (kind, _) in zip(w, wl.moves)))
+    if ex == "allgather":
+        return (G - 1) * 8.0 * (D + 2)
+    if ex == "pull":
+        return npart * (G - 1) / G * 8.0 * (D + 1) * 1.2
+    if ex == "direct":
+        return npart * (G - 1) / G * 8.0 * D
+    if ex in ("logprob", "replay"):
+        return (G - 1) * 8.0
+    return float("nan")
 
 
 def sharded_config(key, world, K, rank, dist, args, port0, skip):
@@ -624,18 +792,35 @@ def sharded_config(key, world, K, rank, dist, args, port0, skip):
             continue
         if ref_digest is None:
             ref_digest = r["digest"]
-        valid = r["status"] == 0 and r["replicas_agree"] and r["digest"] == ref_digest
-        summary[ex] = {"ms_per_step": r["wall_s"] * 1e3 / K, "wu_per_s": wl.N * K / r["wall_s"], "comm": r["comm"],
+        census_ok = args.all_on_device is not None or (r.get("rccl_ranks") == world and r.get("distinct_devices") == world)
+        valid = r["status"] == 0 and r["replicas_agree"] and r["digest"] == ref_digest and census_ok
+        wu = wl.N * K / r["wall_s"]
+        xb = xgmi_bytes_per_update(wl, ex, world, r.get("accept_frac"))
+        B = wl.bytes_per_update(False)
+        summary[ex] = {"ms_per_step": r["wall_s"] * 1e3 / K, "wu_per_s": wu, "comm": r["comm"],
                        "device_status": r["status"], "replicas_agree": r["replicas_agree"],
-                       "same_final_state_as_first": r["digest"] == ref_digest, "blocks_timed": r["blocks"]}
+                       "same_final_state_as_first": r["digest"] == ref_digest, "blocks_timed": r["blocks"],
+                       "rccl_ranks": r.get("rccl_ranks"), "distinct_devices": r.get("distinct_devices"),
+                       "roofline_frac_per_gpu": wu * B / 1e9 / HBM_PEAK_GBPS / world,
+                       # bytes every GPU RECEIVES over xGMI per step, and the rate that is against the 7-link ingress cap
+                       "xgmi_bytes_per_walker_update": xb, "xgmi_bytes_per_step_per_gpu": xb * wl.N / world,
+                       "xgmi_ingress_GBps_per_gpu": xb * wu / world / 1e9,
+                       "xgmi_ingress_frac_of_cap": xb * wu / world / 1e9 / XGMI_INGRESS_GBPS}
+        if not census_ok:
+            summary[ex]["error"] = "rank census failed: %s RCCL ranks on %s distinct devices, expected %d" % (
+                r.get("rccl_ranks"), r.get("distinct_devices"), world)
         if valid and (best is None or r["wall_s"] < best["wall_s"]):
             best = r
     entry = {"workload": wl.label, "nwalkers": wl.N, "ndim": wl.D, "scaling": scaling, "exchange": summary}
+    pred = PREDICTED_US_PER_STEP.get(key, {}).get(world)
+    if pred:
+        entry["predicted_us_per_step"] = {"value": pred, "source": "DESIGN.md section 6 (written before any N>1 run)"}
     if best is not None:
         B = wl.bytes_per_update(False)
         wu = wl.N * K / best["wall_s"]
         entry.update({"reported": best["exchange"], "ms_per_step": best["wall_s"] * 1e3 / K, "wu_per_s": wu,
                       "steps_per_s": K / best["wall_s"], "accept_frac": best["accept_frac"],
+                      "rccl_ranks": best.get("rccl_ranks"), "distinct_devices": best.get("distinct_devices"),
                       "roofline_frac_per_gpu": wu * B / 1e9 / HBM_PEAK_GBPS / world})
     return wl, best, entry
 
@@ -647,8 +832,103 @@ def torch_all_ok(dist, ok):
     return int(flag[0]) == 1
 
 
+
+# ------------------------------------------------------------------------------------------------ self-launch (N > 1)
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def error_line(args, msg, extra=None):
+    line = {"metric": "walker-updates/sec (whole node), 64-dim correlated Gaussian, StretchMove a=2", "value": None,
+            "unit": "walker-updates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": msg}
+    if extra:
+        line.update(extra)
+    return line
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks HERE, one process per GPU, with the
+    environment torch.distributed.run would have given them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), and pass
+    rank 0's single JSON line through.  This process never touches a GPU.  Under torchrun (WORLD_SIZE already set) main() takes
+    the rank path directly, so both ways of starting an N-GPU run execute the same code."""
+    import subprocess
+    out = _claim_stdout()
+    N = args.gpus
+    ndev = None
+    if args.all_on_device is None and not os.environ.get("EMX_BENCH_STUB"):
+        try:
+            from emcee_amd import _lib
+            ndev = _lib.device_count()
+        except Exception as e:  # noqa: BLE001
+            log("device count unavailable:", e)
+        if ndev is not None and ndev < N:
+            out.write(json.dumps(error_line(args, "--gpus %d but only %d HIP device(s) are visible" % (N, ndev),
+                                            {"devices_visible": ndev})) + "\n")
+            out.flush()
+            return 2
+    port = _free_port()
+    env0 = dict(os.environ)
+    env0.update({"WORLD_SIZE": str(N), "LOCAL_WORLD_SIZE": str(N), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                 "EMX_BENCH_SELF_LAUNCHED": "1"})
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL and hipIpc between processes need it
+    procs = []
+    for r in range(N):
+        env = dict(env0)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+        # rank 0's stdout carries the line; the other ranks' goes to stderr (they print nothing there by contract)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None, text=(r == 0),
+                                      start_new_session=True))
+    log("self-launch: %d ranks (pids %s), rendezvous 127.0.0.1:%d" % (N, [p.pid for p in procs], port))
+    deadline = time.time() + args.launch_timeout
+    line0 = None
+    try:
+        try:
+            line0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            line0 = None
+        for p in procs[1:]:
+            try:
+                p.wait(timeout=max(1.0, min(60.0, deadline - time.time())))
+            except subprocess.TimeoutExpired:
+                pass
+    finally:
+        for p in procs:                       # exactly the process groups started above
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, 9)
+                except Exception:  # noqa: BLE001
+                    pass
+    rcs = [p.returncode for p in procs]
+    text = [ln for ln in (line0 or "").splitlines() if ln.strip().startswith("{")]
+    if not text:
+        out.write(json.dumps(error_line(args, "the ranks produced no result line (exit codes %s%s)"
+                                        % (rcs, "; timed out after %.0f s" % args.launch_timeout if line0 is None else ""))) + "\n")
+        out.flush()
+        return 1
+    try:
+        line = json.loads(text[-1])
+        line["launcher"] = "bench.py self-launch: %d rank processes, one per GPU (no torchrun around it)" % N
+        out.write(json.dumps(line) + "\n")
+    except Exception:  # noqa: BLE001
+        out.write(text[-1] + "\n")
+    out.flush()
+    return 0 if all(rc == 0 for rc in rcs) else 1
+
+
 # ------------------------------------------------------------------------------------------------ main
-def main():
+def emit_line(line):
+    out = _claim_stdout()
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
+def main(argv=None):
     _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -672,17 +952,37 @@ def main():
                          "control flow -- failure handling, watchdogs, the emitted line -- is exercised)")
     ap.add_argument("--exchange-timeout", type=float, default=120.0,
                     help="seconds after which a stuck exchange measurement (a child process per rank) is killed")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 started without torchrun: seconds after which the rank processes started here are killed")
+    ap.add_argument("--preflight-timeout", type=float, default=45.0,
+                    help="N > 1: seconds a preflight child (peer access + every exchange on a tiny ensemble) may take")
+    ap.add_argument("--no-preflight", action="store_true")
+    ap.add_argument("--preflight", action="store_true", help="N > 1: run the preflight only and print its verdicts")
     ap.add_argument("--child", default=None, help=argparse.SUPPRESS)          # internal: "<config>:<exchange>"
     ap.add_argument("--child-port", type=int, default=0, help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
+
+    stub = os.environ.get("EMX_BENCH_STUB")       # tests only: a module whose install(bench) replaces the GPU legs
+    if stub:
+        import importlib
+        importlib.import_module(stub).install(sys.modules[__name__])
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.child:
+        # started as plain `python bench.py --gpus N`: this process becomes the launcher of the N ranks
+        return self_launch(args, argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.all_on_device is not None:
         local_rank = args.all_on_device
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        # the line would claim n_gpus = --gpus while measuring WORLD_SIZE ranks: refuse instead of printing a wrong number
+        if rank == 0:
+            emit_line(error_line(args, "--gpus %d but WORLD_SIZE=%d: start one rank per GPU (torch.distributed.run "
+                                       "--nproc-per-node %d) or run bench.py without a launcher" % (args.gpus, world, args.gpus)))
+        return 2
     K, W = args.steps, args.warmup
     if args.child:
         return child_main(args, rank, world, local_rank)
@@ -784,6 +1084,27 @@ def main():
     multi = {}
     line = None
     skip = {}
+    exchanges = EXCHANGES if args.exchange == "all" else (args.exchange,)
+    pre = None
+    if not args.no_preflight or args.preflight:
+        t0 = time.perf_counter()
+        pre = run_preflight(args, world, dist, port_base + 200, exchanges)
+        pre_s = time.perf_counter() - t0
+        for ex in exchanges:
+            v = pre.get(ex, {})
+            if not v.get("ok"):
+                skip[ex] = "preflight: " + str(v.get("error") or "final ensembles differ / device status %s" % v.get("device_status"))[:200]
+        if not pre.get("p2p", {}).get("ok", True):
+            log("preflight: no peer access between the devices -- the direct exchange cannot work")
+            skip.setdefault("direct", "preflight: hipDeviceCanAccessPeer is false for some pair of devices")
+        pre = {"seconds": pre_s, "items": pre, "disabled": dict(skip)}
+        log("rank %d preflight (%.1f s): %s" % (rank, pre_s, {k: v.get("ok") for k, v in pre["items"].items()}))
+        if args.preflight:
+            if rank == 0:
+                emit_line({"preflight": pre, "n_gpus": world})
+            dist.barrier()
+            dist.destroy_process_group()
+            return 0
     for kn, key in enumerate(keys):
         wl, best, entry = sharded_config(key, world, K, rank, dist, args, port_base + 8 * kn, skip)
         multi[{"c2": "c2_weak_65536_per_gpu", "c3": "c3_262144x32_rosen_sharded", "c5": "c5_16384x1024_strong"}[key]
@@ -801,16 +1122,19 @@ def main():
                                     "direct": "partner rows read in place from the peers' HBM (direct exchange)"}.get(
                                         best["exchange"], best["exchange"]), best["comm"])
             line = headline(wl, best["wall_s"], best["gpu_ms"], None, best["accept_frac"], best["status"], how,
-                            {"timed_blocks": best["blocks"]})
+                            {"timed_blocks": best["blocks"], "rccl_ranks": best.get("rccl_ranks"),
+                             "distinct_devices": best.get("distinct_devices")})
             line["scaling"] = entry["scaling"]
             line["cpu_baseline"] = None
             line["multi_gpu"] = multi
     if rank == 0 and line is not None:
         line["multi_gpu"] = multi
+        if pre is not None:
+            line["preflight"] = pre
         emit(line)
     dist.barrier()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -200,6 +200,7 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
 } g_rccl;
 constexpr int RCCL_FLOAT64 = 8;   // ncclFloat64 (rccl.h:467)
 
@@ -226,6 +227,7 @@ int rccl_load(const char* path, std::string& err) {
     g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
     g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
         err = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllGather";
         return -5;
@@ -3175,6 +3177,17 @@ int emx_comm_destroy(emx_ctx* c) {
         g_rccl.CommDestroy(c->comm);
         c->comm = nullptr;
     }
+    return 0;
+}
+
+int emx_comm_count(emx_ctx* c, int32_t* ranks_out) {
+    *ranks_out = 0;
+    if (!c->comm) return 0;
+    NEED(c, g_rccl.CommCount, "librccl lacks ncclCommCount");
+    int n = 0;
+    const int e = g_rccl.CommCount(c->comm, &n);
+    if (e != 0) FAIL(c, -6, "ncclCommCount failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    *ranks_out = n;
     return 0;
 }
 

@@ -399,6 +399,12 @@ class DeviceEnsemble:
     def comm_destroy(self):
         self._ck(self.lib.emx_comm_destroy(self.ctx))
 
+    def comm_count(self):
+        """ranks of the library's RCCL communicator (ncclCommCount); 0 without one"""
+        n = C.c_int32(0)
+        self._ck(self.lib.emx_comm_count(self.ctx, C.byref(n)))
+        return n.value
+
     # ---- measurement ----
     def timer_start(self):
         self._ck(self.lib.emx_timer_start(self.ctx))

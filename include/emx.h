@@ -245,6 +245,9 @@ int emx_comm_load(const char* librccl_path /* or NULL */);
 int emx_comm_get_unique_id(uint8_t id[128]);
 int emx_comm_init(emx_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[128]);
 int emx_comm_destroy(emx_ctx* ctx);
+/* ranks of the communicator emx_comm_init created, as RCCL itself counts them (ncclCommCount) -- what a bench line may claim
+ * as its number of GPUs; 0 when no communicator exists */
+int emx_comm_count(emx_ctx* ctx, int32_t* ranks_out);
 
 /* ---- around the hot loop: autocorrelation time and the initial-state check ------------------------------------------ */
 /* Integrated autocorrelation time of the device-resident chain, per parameter (autocorr.py:49-123 integrated_time applied to
