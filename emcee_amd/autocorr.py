@@ -4,8 +4,8 @@ Estimator (reference ``autocorr.py:49-123``, Sokal's recipe): normalised autocor
 function of every walker's series by FFT, averaged over walkers for each parameter, cumulative
 sum ``tau(M) = 2 sum_{t<=M} rho(t) - 1`` and the smallest window ``M >= c tau(M)``.  Here the FFTs
 of all walkers of one parameter are taken in a single batched real transform instead of one
-Python call per walker; ``emcee_amd/_devfft.py`` runs the same thing on the GPU for chains that
-live in HBM."""
+Python call per walker.  Chains that live in HBM are analysed there by ``emx_autocorr`` (csrc/emx_aux.hip, behind the C
+ABI), which ``Backend.get_autocorr_time`` prefers; this module is its fallback and the estimator for host-side chains."""
 import logging
 
 import numpy as np

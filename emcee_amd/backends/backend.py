@@ -8,6 +8,7 @@ through ``Move.propose``) it is a plain in-memory store with the reference's ``s
 import numpy as np
 
 from .. import autocorr
+from .._lib import EmxError
 from ..state import State
 
 __all__ = ["Backend"]
@@ -156,16 +157,23 @@ class Backend(object):
         only = {k: v for k, v in kwargs.items() if k in ("c", "tol", "quiet")}
         if self._dev is not None and kwargs.get("has_walkers", True) and len(only) == len(kwargs):
             c, tol, quiet = only.get("c", 5), only.get("tol", 50), only.get("quiet", False)
-            tau_est, _, n_t = self._dev.autocorr(discard=discard, thin=thin, c=c)
-            flag = tol * tau_est > n_t
-            if np.any(flag):
-                msg = ("The chain is shorter than {0} times the integrated autocorrelation time for {1} parameter(s). "
-                       "Use this estimate with caution and run a longer chain!\n").format(tol, np.sum(flag))
-                msg += "N/{0} = {1:.0f};\ntau: {2}".format(tol, n_t / tol, tau_est)
-                if not quiet:
-                    raise autocorr.AutocorrError(tau_est, msg)
-                autocorr.logger.warning(msg)
-            return thin * tau_est
+            try:
+                tau_est, _, n_t = self._dev.autocorr(discard=discard, thin=thin, c=c)
+            except EmxError as e:
+                # libhipfft not loadable, no room for the work buffers next to a long chain, an empty selection ...: the host
+                # estimator below computes the same numbers from a copy of the chain (and raises the reference's own errors)
+                autocorr.logger.debug("device autocorrelation unavailable (%s): host estimator", e)
+                tau_est = None
+            if tau_est is not None:
+                flag = tol * tau_est > n_t
+                if np.any(flag):
+                    msg = ("The chain is shorter than {0} times the integrated autocorrelation time for {1} parameter(s). "
+                           "Use this estimate with caution and run a longer chain!\n").format(tol, np.sum(flag))
+                    msg += "N/{0} = {1:.0f};\ntau: {2}".format(tol, n_t / tol, tau_est)
+                    if not quiet:
+                        raise autocorr.AutocorrError(tau_est, msg)
+                    autocorr.logger.warning(msg)
+                return thin * tau_est
         x = self.get_chain(discard=discard, thin=thin)
         return thin * autocorr.integrated_time(x, **kwargs)
 

@@ -398,6 +398,9 @@ struct emx_ctx {
     int32_t* direct_counts = nullptr;         // [64]: owned slots per split of the step begun
     bool direct_planned = false;              // k_own_plan has run for the step begun
     int64_t tune_direct_timeout_ms = 5000;
+    bool eval_check_bad = false;              // MOVE_EVAL over proposals (log-prob exchange): non-finite rows get -inf, as in the fused path
+    bool direct_dead = false;                 // a barrier timed out (seen by emx_status): no half-step until the peers are re-attached
+    bool direct_first_barrier = false;        // the next barrier is the first of an emx_run call: the ranks may enter seconds apart
     // hipGraph replay of the native NATIVE_BATCH_MAX-step block (single move, thin_by 1, one rank)
     struct GraphSlot {
         hipGraph_t graph = nullptr;
@@ -620,7 +623,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
             w.rows = X;
             w.out = lp;
             w.scatter = 1;
-            w.check_bad = 0;
+            w.check_bad = c->eval_check_bad ? 1 : 0;
             if (launch_wide_lp(w, t_hi - t_lo, c->num_cu, c->stream) != hipSuccess) {
                 c->err = "wide dense target: log-prob kernel launch failed";
                 return -2;
@@ -1005,6 +1008,7 @@ int emx_status(emx_ctx* c, uint32_t* bits) {
     uint32_t b = 0;
     for (int k = 0; k < 4; ++k)
         if (__atomic_exchange_n(&c->status_host[k], 0u, __ATOMIC_ACQ_REL)) b |= 1u << k;
+    if (b & ST_EXCHANGE_TIMEOUT) c->direct_dead = true;      // sticky on the host too: emx_direct_halfstep / emx_run refuse from here on
     *bits = b;
     return 0;
 }
@@ -2328,6 +2332,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
          "emx_run on a sharded context needs emx_comm_init (or drive emx_halfstep / the collective from the host layer)");
     NEED(c, c->exchange != EMX_EXCHANGE_DIRECT || c->world == 1 || c->peers_ready,
          "direct exchange: the peers' arrays are not mapped yet (emx_direct_export / emx_direct_import, or emx_direct_attach)");
+    c->direct_first_barrier = true;
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     const int64_t total = nsteps * thin_by;
     bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
@@ -2673,9 +2678,14 @@ int emx_logprob_begin(emx_ctx* c, int32_t split, int64_t* per_rank) {
     if (rc) return rc;
     const int lo = (int)std::min<int64_t>((int64_t)c->rank * per, ns), hi = (int)std::min<int64_t>(lo + per, ns);
     if (hi <= lo) return 0;
-    // log-probs of the proposals [lo, hi): row t of qout -> gathered[t]
-    return launch_split(c, MOVE_EVAL, c->target, 1, 0, 0, ns, lo, hi, &mv, nullptr, c->iota, c->qout, c->gathered, nullptr, nullptr,
-                        nullptr);
+    // log-probs of the proposals [lo, hi): row t of qout -> gathered[t].  A non-finite proposal was reported by the propose pass
+    // above -- on EVERY rank, they all propose everything -- and gets -inf here (rejected), exactly as on the single-rank wide
+    // path: no rank sees a status (ST_NAN_LOGP) the others do not
+    c->eval_check_bad = true;
+    rc = launch_split(c, MOVE_EVAL, c->target, 1, 0, 0, ns, lo, hi, &mv, nullptr, c->iota, c->qout, c->gathered, nullptr, nullptr,
+                      nullptr);
+    c->eval_check_bad = false;
+    return rc;
 }
 
 int emx_logprob_finish(emx_ctx* c, int32_t split) {
@@ -2873,6 +2883,20 @@ static int direct_ensure(emx_ctx* c) {
     return 0;
 }
 
+// (Re-)attaching the peers is collective: every rank starts over at epoch 0 with clean flags, and a barrier that timed out
+// in an earlier attachment is forgotten (until then it stays raised in the status word and refused on the host).  Called
+// where no peer can be writing this rank's flags yet: emx_direct_export, and emx_direct_attach (contexts of one process,
+// attached one after the other before any of them runs).
+static int direct_rearm(emx_ctx* c) {
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    if (c->direct_counts) HIPOK(c, hipMemset(c->direct_counts, 0, 65 * 4));
+    if (c->my_flags) HIPOK(c, hipMemset(c->my_flags, 0, EMX_MAX_PEERS * 8));
+    c->direct_epoch = 0;
+    c->direct_dead = false;
+    __atomic_store_n(&c->status_host[3], 0u, __ATOMIC_RELEASE);
+    return 0;
+}
+
 static int direct_publish_table(emx_ctx* c) {
     PeerTable t{};
     for (int q = 0; q < c->world; ++q) {
@@ -2889,6 +2913,10 @@ int emx_direct_export(emx_ctx* c, uint8_t handles[128]) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, c->exchange == EMX_EXCHANGE_DIRECT, "emx_direct_export needs emx_set_exchange(EMX_EXCHANGE_DIRECT)");
     int rc = direct_ensure(c);
+    if (rc) return rc;
+    // every rank exports before any rank can import (the host layer's all-gather of the handles sits in between), so this is
+    // the one point where no peer can be writing this rank's flags: start the new attachment from epoch 0
+    rc = direct_rearm(c);
     if (rc) return rc;
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle size");
     hipIpcMemHandle_t hx, hf;
@@ -2938,6 +2966,8 @@ int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_fl
         NEED(c, c->peerX[q], "emx_direct_attach: no coordinate array for rank %d", q);
     }
     c->peers_ready = true;
+    rc = direct_rearm(c);
+    if (rc) return rc;
     return direct_publish_table(c);
 }
 
@@ -2949,6 +2979,8 @@ int emx_direct_halfstep(emx_ctx* c, int32_t split, int32_t barrier) {
     NEED(c, split >= 0 && split < cur.S && cur.S <= 64, "split out of range");
     NEED(c, c->target != EMX_TARGET_HOST, "sharded stepping needs a device target");
     NEED(c, c->peers_ready || c->world == 1, "direct exchange: peers not mapped");
+    NEED(c, !c->direct_dead, "direct exchange: an earlier barrier timed out (a peer never arrived): the ranks are no longer ordered -- "
+                             "attach the peers again (emx_direct_import / emx_direct_attach on every rank)");
     const emx_move_desc& mv = c->moves[cur.move];
     const auto& ps = c->ring[cur.slot];
     const int64_t G = c->world, N = c->N;
@@ -2992,7 +3024,10 @@ int emx_direct_halfstep(emx_ctx* c, int32_t split, int32_t barrier) {
         b.dead = c->direct_counts + 64;
         b.status = c->status;
         b.epoch = ++c->direct_epoch;
-        b.timeout_ticks = (unsigned long long)c->tune_direct_timeout_ms * 100000ull;      // wall_clock64: 100 MHz
+        // the first barrier of an emx_run call waits six times longer: the ranks reach emx_run through host code of their own
+        // (Python between two yields, the plan pipeline's start-up) and may be seconds apart; later barriers are kernel to kernel
+        b.timeout_ticks = (unsigned long long)c->tune_direct_timeout_ms * (c->direct_first_barrier ? 6ull : 1ull) * 100000ull;      // wall_clock64: 100 MHz
+        c->direct_first_barrier = false;
         b.rank = c->rank;
         b.npeer = (int32_t)G;
         hipLaunchKernelGGL(k_peer_barrier, dim3(1), dim3(64), 0, c->stream, b);
@@ -3280,7 +3315,9 @@ int emx_host_plan_mt_stream(emx_mt* m, int64_t N, int32_t D, int32_t nmoves, con
         sinks[r].uacc = hp.uacc;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    MtPlanPipeline pipe(m->mt, N, D, nmoves, moves, cdf, nsteps, sinks.data(), nsinks, nworkers);
+    // fill_unused_fields: a stretch plan's p1 / p2 carry the walker itself, as emx_host_plan_mt's do (the header promises the
+    // same plans; emx_run's own pipeline leaves those columns alone because nothing reads or uploads them)
+    MtPlanPipeline pipe(m->mt, N, D, nmoves, moves, cdf, nsteps, sinks.data(), nsinks, nworkers, true);
     int64_t n = 0;
     for (; n < nsteps; ++n) {
         PipeStepInfo info;

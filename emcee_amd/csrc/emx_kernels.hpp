@@ -1796,7 +1796,8 @@ struct PullRowsArgs {
 static __global__ __launch_bounds__(256) void k_pull_scatter(const PullRowsArgs A) {
     const int r = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
-    if (blockIdx.x == 0 && threadIdx.x <= A.G) A.counts_next[threadIdx.x] = 0;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k <= A.G; k += blockDim.x) A.counts_next[k] = 0;      // world sizes up to EMX_MAX_RANKS
     if (r >= A.G * A.cap) return;
     const size_t o = (size_t)r * (A.D + 1);
     if (r / A.cap != A.rank) {
@@ -1888,6 +1889,9 @@ static __global__ __launch_bounds__(64) void k_peer_barrier(const PeerBarrierArg
         __hip_atomic_store(&A.peer_flags[q][A.rank], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long t0 = wall_clock64();
         const bool dead = *A.dead != 0;
+        // a barrier that timed out earlier: the epochs of the ranks no longer line up, nothing after it is ordered.  Say so on
+        // EVERY later barrier (the host refuses further half-steps as well) until the peers are attached again
+        if (dead) raise_status(A.status, ST_EXCHANGE_TIMEOUT);
         while (!dead && __hip_atomic_load(&A.my_flags[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.epoch) {
             if (wall_clock64() - t0 > A.timeout_ticks) {           // a peer never arrived: never hang the GPU
                 raise_status(A.status, ST_EXCHANGE_TIMEOUT);

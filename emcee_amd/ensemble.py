@@ -600,9 +600,26 @@ class EnsembleSampler(object):
         n = len(p)
         per = -(-n // world)
         lo, hi = min(rank * per, n), min((rank + 1) * per, n)
-        mine = self._call_log_prob_fn(p[lo:hi]) if hi > lo else (np.empty(0), None)
+        # an exception in one rank's share must reach EVERY rank (pool.map re-raises in the parent, ensemble.py:496): a rank that
+        # raised before the collective would leave the others waiting in it for ever
+        import hashlib
+        digest = hashlib.sha1(np.ascontiguousarray(p, dtype=np.float64).tobytes()).hexdigest()[:16]
+        try:
+            mine = self._call_log_prob_fn(p[lo:hi]) if hi > lo else (np.empty(0), None)
+            payload = (digest, None, np.asarray(mine[0], dtype=np.float64), mine[1])
+        except BaseException as e:  # noqa: BLE001  (re-raised on all ranks below)
+            payload = (digest, e, None, None)
         parts = [None] * world
-        dist.all_gather_object(parts, (np.asarray(mine[0], dtype=np.float64), mine[1]))
+        dist.all_gather_object(parts, payload)
+        for r, (_, err, _, _) in enumerate(parts):
+            if err is not None:
+                if r == rank:
+                    raise err
+                raise RuntimeError("log_prob_fn failed on rank %d: %r" % (r, err))
+        if len({d for d, _, _, _ in parts}) != 1:
+            raise RuntimeError("exchange='logprob': the ranks hold different coordinates (every rank must pass the same initial "
+                               "state and seed)")
+        parts = [(a, b) for _, _, a, b in parts]
         log_prob = np.concatenate([np.atleast_1d(a) for a, _ in parts])
         blobs = [b for a, b in parts if len(np.atleast_1d(a))]
         if any(b is None for b in blobs):

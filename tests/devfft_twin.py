@@ -1,12 +1,14 @@
-"""Device-side integrated autocorrelation time (SURVEY.md 8f "next" item 2).
+"""TEST-ONLY twin of emx_autocorr (csrc/emx_aux.hip): the same estimator through torch.fft, kept as a cross-check of the
+library's hipFFT path (tests/test_gpu_sampler_api.py).  Not part of the product package.
+
+Device-side integrated autocorrelation time (SURVEY.md 8f "next" item 2).
 
 The chain already lives in HBM (``(nsteps, nwalkers, ndim)``, written by the half-step kernel);
 the reference estimator (``autocorr.py:20-123``: FFT autocorrelation of every walker's series,
 averaged over walkers per dimension, Sokal window) is run there with batched rocFFT through
 ``torch.fft`` -- a plain library op -- on zero-copy views of the library's buffers, chunked over
 walkers so that the padded spectra fit.  Only the (nsteps, ndim) mean ACF crosses PCIe; the
-window search is the reference's host code.  Used by ``Backend.get_autocorr_time`` when the
-chain is device resident; otherwise the host path in ``autocorr.py`` is used.
+window search is the reference's host code.
 """
 import numpy as np
 

@@ -23,7 +23,7 @@ FUSED = ["gauss_iso_vector_40x3", "gauss_diag_random_factor_30x4", "gauss_iso_se
 def read_disp(ens):
     """The (N, D) displacement rows of the step begun, copied from HBM."""
     import torch
-    from emcee_amd._devfft import _DevView
+    from devfft_twin import _DevView
     ptr, nbytes = ens.device_ptr(6)
     assert ptr and nbytes == ens.nwalkers * ens.ndim * 8
     ens.sync()

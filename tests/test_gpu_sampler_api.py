@@ -415,7 +415,7 @@ def test_device_autocorr_equals_host_estimator():
     """tau from emx_autocorr (batched hipFFT on the HBM-resident chain, behind the C ABI) == the host
     estimator (which tests/test_autocorr_cpu.py holds equal to the reference's) == the torch.fft cross-check."""
     from emcee_amd import autocorr
-    from emcee_amd._devfft import integrated_time_device, mean_acf
+    from devfft_twin import integrated_time_device, mean_acf
     np.random.seed(5)
     s = emcee_amd.EnsembleSampler(96, 3, targets.IsoGaussian(), rng="philox")
     s.run_mcmc(np.random.randn(96, 3), 1500)

@@ -26,7 +26,7 @@ NAMES = ["start -> plan loads issued", "plan arrived, row loads issued", "image 
 
 def main(target="dense", N=65536, D=64):
     import torch
-    from emcee_amd._devfft import _DevView
+    from emcee_amd.parallel import _DevView
     ens = DeviceEnsemble(N, D)
     rs = np.random.RandomState(1)
     mu, cov, icov = dense_params(D)
@@ -46,7 +46,7 @@ def main(target="dense", N=65536, D=64):
         ens.run(3, 1, False)
         ens.sync()
         ptr, nbytes = ens.device_ptr(7)
-        t = torch.as_tensor(_DevView(ptr, (nbytes // 8,)), device=torch.device("cuda", 0))
+        t = torch.as_tensor(_DevView(ptr, nbytes // 8), device=torch.device("cuda", 0))
         raw = t.view(torch.int64).cpu().numpy().reshape(-1, 16)
         raw = raw[raw[:, 0] != 0]
         rows.append(raw.copy())
