@@ -47,6 +47,10 @@ SIGNATURES = {
     "emx_set_state": (C.c_int, [_P, _P, _P]),
     "emx_get_state": (C.c_int, [_P, _P, _P]),
     "emx_get_accepted": (C.c_int, [_P, _u8p]),
+    "emx_snapshot_save": (C.c_int, [_P, C.c_int32]),
+    "emx_snapshot_read": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "emx_snapshot_restore": (C.c_int, [_P, C.c_int32]),
+    "emx_snapshot_free": (C.c_int, [_P, C.c_int32]),
     "emx_set_target": (C.c_int, [_P, C.c_int32, _P, _P, C.c_double]),
     "emx_eval_state_log_prob": (C.c_int, [_P]),
     "emx_eval_log_prob": (C.c_int, [_P, _dp, C.c_int64, _dp]),

@@ -295,6 +295,9 @@ struct emx_ctx {
     uint32_t* status_host = nullptr;   // `status` lives in mapped pinned host memory: kernels only touch it on errors
                                        // (system-scope atomicOr), the host reads it without a device copy
     int32_t* iota = nullptr;
+    // device-side snapshots of (coords, log_prob): a state handed out by an earlier call, kept in HBM (emx_snapshot_*)
+    static constexpr int NSNAPSHOT = 8;
+    double* snap[NSNAPSHOT] = {};
     // target
     int target = EMX_TARGET_HOST;
     double *tp0 = nullptr, *tp1 = nullptr;
@@ -945,6 +948,8 @@ int emx_destroy(emx_ctx* c) {
                     c->own_shard_bufs ? c->gathered : nullptr};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    for (double* s : c->snap)
+        if (s) hipFree(s);
     for (auto& s : c->ring) {
         if (s.order) hipFree(s.order);       // the slot's single block
         if (s.host) hipHostFree(s.host);
@@ -997,14 +1002,44 @@ int emx_set_stream(emx_ctx* c, void* s) {
     return 0;
 }
 
+// Waiting for the stream: poll first.  hipStreamSynchronize / hipEventSynchronize park the thread on the completion signal
+// and wake it through the driver -- 10-20 us after the last kernel finished, which is a few per cent of a 20-step call at
+// the headline size (0.5 ms).  A query loop sees the completion within a microsecond; after 2 ms of polling (a long run: the
+// wake-up no longer matters) it falls back to the blocking call so that a waiting host thread does not burn a core.
+static const bool g_spin_sync = !(getenv("EMX_SPIN_SYNC") && atoi(getenv("EMX_SPIN_SYNC")) == 0);
+
+static hipError_t wait_stream(hipStream_t s) {
+    if (g_spin_sync) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; ++it) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) return e;
+            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    return hipStreamSynchronize(s);
+}
+
+static hipError_t wait_event(hipEvent_t ev) {
+    if (g_spin_sync) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; ++it) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e != hipErrorNotReady) return e;
+            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    return hipEventSynchronize(ev);
+}
+
 int emx_sync(emx_ctx* c) {
     HIPOK(c, hipSetDevice(c->device));
-    HIPOK(c, hipStreamSynchronize(c->stream));
+    HIPOK(c, wait_stream(c->stream));
     return 0;
 }
 
 int emx_status(emx_ctx* c, uint32_t* bits) {
-    HIPOK(c, hipStreamSynchronize(c->stream));      // every launch that could still raise a bit has finished
+    HIPOK(c, wait_stream(c->stream));      // every launch that could still raise a bit has finished
     uint32_t b = 0;
     for (int k = 0; k < 4; ++k)
         if (__atomic_exchange_n(&c->status_host[k], 0u, __ATOMIC_ACQ_REL)) b |= 1u << k;
@@ -1169,6 +1204,53 @@ int emx_get_state(emx_ctx* c, double* coords, double* log_prob) {
         if (rc) return rc;
     }
     HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- snapshots: the state a call handed out stays on the device until somebody reads it -----------------------------------
+// (ensemble.py:441-447: run_mcmc(None | previous State) continues from the state the last call returned -- which already IS
+// the device state; a snapshot is the copy-on-write copy taken when the next call is about to change it while the old object
+// is still alive, so that the old object keeps the values it was returned with: 2 x 33.5 MB inside HBM instead of over PCIe)
+int emx_snapshot_save(emx_ctx* c, int32_t slot) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, slot >= 0 && slot < emx_ctx::NSNAPSHOT, "snapshot slot out of range");
+    const size_t nx = (size_t)c->N * c->D, nl = (size_t)c->N;
+    if (!c->snap[slot]) HIPOK(c, hipMalloc((void**)&c->snap[slot], (nx + nl) * 8));
+    HIPOK(c, hipMemcpyAsync(c->snap[slot], c->X, nx * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(c->snap[slot] + nx, c->lp, nl * 8, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int emx_snapshot_read(emx_ctx* c, int32_t slot, double* coords, double* log_prob) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, slot >= 0 && slot < emx_ctx::NSNAPSHOT && c->snap[slot], "no snapshot in slot %d", slot);
+    const size_t nx = (size_t)c->N * c->D;
+    if (log_prob) HIPOK(c, hipMemcpyAsync(log_prob, c->snap[slot] + nx, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (coords) {
+        const int rc = big_copy_to_host(c, coords, c->snap[slot], nx * 8);
+        if (rc) return rc;
+    }
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int emx_snapshot_restore(emx_ctx* c, int32_t slot) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, slot >= 0 && slot < emx_ctx::NSNAPSHOT && c->snap[slot], "no snapshot in slot %d", slot);
+    const size_t nx = (size_t)c->N * c->D;
+    HIPOK(c, hipMemcpyAsync(c->X, c->snap[slot], nx * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPOK(c, hipMemcpyAsync(c->lp, c->snap[slot] + nx, (size_t)c->N * 8, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int emx_snapshot_free(emx_ctx* c, int32_t slot) {
+    NEED(c, slot >= 0 && slot < emx_ctx::NSNAPSHOT, "snapshot slot out of range");
+    if (c->snap[slot]) {
+        HIPOK(c, hipSetDevice(c->device));
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        HIPOK(c, hipFree(c->snap[slot]));
+        c->snap[slot] = nullptr;
+    }
     return 0;
 }
 
@@ -2383,7 +2465,10 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
         {
             const int st = store && ((i + 1) % thin_by == 0);                   // ensemble.py:416
             int mvi, S;
-            c->prep_hint = total - i;
+            // native plans are made NATIVE_BATCH_MAX steps at a time whatever is left of THIS call: they do not depend on the
+            // walkers, what a short call leaves over serves the next one (a 20-step call: 16 + 16 with 12 carried over, not
+            // 16 + 4 -- the launch is the same size either way)
+            c->prep_hint = std::max<int64_t>(total - i, NATIVE_BATCH_MAX);
             if (thin_by == 1 && !c->graph_disabled && c->tune_graph && !c->graph_warm) c->prep_hint = 1;   // graph follows
             int rc = emx_step_begin(c, st, &mvi, &S);
             if (rc) return rc;
@@ -3234,7 +3319,7 @@ int emx_timer_start(emx_ctx* c) {
 
 int emx_timer_stop(emx_ctx* c, float* ms) {
     HIPOK(c, hipEventRecord(c->ev1, c->stream));
-    HIPOK(c, hipEventSynchronize(c->ev1));
+    HIPOK(c, wait_event(c->ev1));
     HIPOK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     return 0;
 }

@@ -18,6 +18,26 @@ namespace emx {
 
 EMX_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
 
+// Both halves of a 32 x 32 -> 64 bit product.  On the device ONE v_mad_u64_u32: the compiler splits the C expression into
+// v_mul_hi_u32 + v_mul_lo_u32, two quarter-rate instructions where one delivers both words -- and the integer multiplies of the
+// Philox rounds are what bounds the plan kernel (k_native_plan_batch: ~1 600 of its ~2 500 cycles per 64 entries) and the
+// Gaussian move's noise.  Same bits either way.
+#ifndef EMX_PHILOX_MAD64
+#define EMX_PHILOX_MAD64 1
+#endif
+EMX_HD void mul_hilo32(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+#if defined(__HIP_DEVICE_COMPILE__) && EMX_PHILOX_MAD64
+    uint64_t r, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(a), "v"(b));
+    hi = (uint32_t)(r >> 32);
+    lo = (uint32_t)r;
+#else
+    const uint64_t r = (uint64_t)a * (uint64_t)b;
+    hi = (uint32_t)(r >> 32);
+    lo = (uint32_t)r;
+#endif
+}
+
 struct Philox4 {
     uint32_t v[4];
 };
@@ -30,8 +50,9 @@ EMX_HD Philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        uint32_t hi0, lo0, hi1, lo1;
+        mul_hilo32(M0, c0, hi0, lo0);
+        mul_hilo32(M1, c2, hi1, lo1);
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;

@@ -38,6 +38,11 @@ class DeviceEnsemble:
         self.ctx = ctx
         self._target_kind = _lib.TARGET_HOST
         self._moves = None
+        # resident states (state.ResidentState): the object a run handed out that still IS the device state, and the snapshot
+        # slots of older ones
+        self._gen = 0
+        self._resident = None            # weakref to the ResidentState mirroring generation _gen
+        self._free_slots = list(range(8))
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -54,7 +59,39 @@ class DeviceEnsemble:
         _lib.check(self.lib, self.ctx, rc)
 
     # ---- state ----
+    def _touch(self):
+        """Called before anything changes (coords, log_prob) on the device: a live, never-read ResidentState of the current
+        generation keeps its values in a device-side snapshot (or on the host when the slots are used up)."""
+        ref, self._resident = self._resident, None
+        self._gen += 1
+        st = ref() if ref is not None else None
+        if st is not None:
+            st._detach_before_change()
+
+    def snapshot_save(self):
+        """-> slot holding a device-side copy of the current (coords, log_prob), or None when all slots are taken"""
+        if not self._free_slots:
+            return None
+        slot = self._free_slots.pop()
+        self._ck(self.lib.emx_snapshot_save(self.ctx, slot))
+        return slot
+
+    def snapshot_read(self, slot):
+        x, lp = np.empty((self.nwalkers, self.ndim)), np.empty(self.nwalkers)
+        self._ck(self.lib.emx_snapshot_read(self.ctx, slot, x.ctypes.data, lp.ctypes.data))
+        return x, lp
+
+    def snapshot_restore(self, slot):
+        self._touch()
+        self._ck(self.lib.emx_snapshot_restore(self.ctx, slot))
+
+    def snapshot_release(self, slot):
+        """the slot may be reused (its buffer stays allocated for the next snapshot)"""
+        if slot is not None and slot not in self._free_slots:
+            self._free_slots.append(slot)
+
     def set_state(self, coords, log_prob=None):
+        self._touch()
         coords = _as_f64(coords, (self.nwalkers, self.ndim))
         lp = None if log_prob is None else _as_f64(log_prob, (self.nwalkers,))
         self._ck(self.lib.emx_set_state(self.ctx, coords.ctypes.data, None if lp is None else lp.ctypes.data))
@@ -106,6 +143,7 @@ class DeviceEnsemble:
         self._target_kind = int(kind)
 
     def eval_state_log_prob(self):
+        self._touch()
         self._ck(self.lib.emx_eval_state_log_prob(self.ctx))
 
     def eval_log_prob(self, coords):
@@ -172,6 +210,7 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_chain_reset(self.ctx))
 
     def run(self, nsteps, thin_by=1, store=True):
+        self._touch()
         self._ck(self.lib.emx_run(self.ctx, int(nsteps), int(thin_by), int(bool(store))))
 
     def iteration(self):
@@ -225,11 +264,13 @@ class DeviceEnsemble:
 
     # ---- split-phase ----
     def step_begin(self, store=False):
+        self._touch()
         mv, S = C.c_int32(), C.c_int32()
         self._ck(self.lib.emx_step_begin(self.ctx, int(bool(store)), C.byref(mv), C.byref(S)))
         return mv.value, S.value
 
     def step_begin_with(self, move_index, store=False):
+        self._touch()
         S = C.c_int32()
         self._ck(self.lib.emx_step_begin_with(self.ctx, int(bool(store)), int(move_index), C.byref(S)))
         return S.value
@@ -362,6 +403,7 @@ class DeviceEnsemble:
         return n.value
 
     def replica_unpack(self):
+        self._touch()
         self._ck(self.lib.emx_replica_unpack(self.ctx))
 
     # ---- library-driven RCCL ----

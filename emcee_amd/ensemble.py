@@ -28,7 +28,7 @@ from .backends import Backend
 from .model import Model
 from .moves import StretchMove
 from .pbar import get_progress_bar
-from .state import DeviceState, State
+from .state import DeviceState, ResidentState, State
 from .targets import DeviceTarget
 from .utils import deprecation_warning
 
@@ -507,17 +507,29 @@ class EnsembleSampler(object):
         store = kw.get("store", True)
         if thin_by <= 0:
             raise ValueError("Invalid thinning argument")
-        state = State(initial_state, copy=True)
-        if self._dist is not None:
-            state = self._replicate(state)
-        if state.blobs is not None:
-            return None
-        if np.shape(state.coords) != (self.nwalkers, self.ndim):
-            raise ValueError(f"incompatible input dimensions {np.shape(state.coords)}")
-        _refuse_extended_precision(state.coords)
-        if (not kw.get("skip_initial_state_check", False)) and (not walkers_independent(state.coords)):
-            raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
-                             "linearly independent for the best performance")
+        # the State a device run returned, handed back unread (or None -> _previous_state): it already is -- or, from its
+        # snapshot, can again become -- the device state without crossing PCIe (reference semantics: ensemble.py:312,441-447)
+        resident = None
+        if isinstance(initial_state, ResidentState) and self._dist is None and self._ens is not None and \
+                initial_state._ens is self._ens and initial_state._c is None and initial_state._lp is None:
+            resident = initial_state
+        if resident is not None:
+            state = resident
+            if (not kw.get("skip_initial_state_check", False)) and (not walkers_independent(resident._peek_coords())):
+                raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
+                                 "linearly independent for the best performance")
+        else:
+            state = State(initial_state, copy=True)
+            if self._dist is not None:
+                state = self._replicate(state)
+            if state.blobs is not None:
+                return None
+            if np.shape(state.coords) != (self.nwalkers, self.ndim):
+                raise ValueError(f"incompatible input dimensions {np.shape(state.coords)}")
+            _refuse_extended_precision(state.coords)
+            if (not kw.get("skip_initial_state_check", False)) and (not walkers_independent(state.coords)):
+                raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
+                                 "linearly independent for the best performance")
         for m in self._moves:
             if self.nwalkers < 2 * self.ndim and hasattr(m, "nsplits") and not getattr(m, "live_dangerously", False):
                 raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice "
@@ -525,7 +537,9 @@ class EnsembleSampler(object):
         self.random_state = state.random_state
         self._refuse_partial_chain(store)
         ens = self._configure_device(descs, True)
-        if state.log_prob is None:
+        if resident is not None and (resident._is_device_state(ens) or resident._restore_on_device(ens)):
+            lp0 = None                # log-probs of a state a run produced: finite by construction (NaN proposals are rejected)
+        elif state.log_prob is None:
             ens.set_state(state.coords)
             ens.eval_state_log_prob()
             ens.raise_on_status()
@@ -535,7 +549,7 @@ class EnsembleSampler(object):
             if np.shape(lp0) != (self.nwalkers,):
                 raise ValueError("incompatible input dimensions")
             ens.set_state(state.coords, lp0)
-        if np.any(np.isnan(lp0)):
+        if lp0 is not None and np.any(np.isnan(lp0)):
             raise ValueError("The initial log_prob was NaN")
         if store:
             if self.backend._dev is not ens:
@@ -546,8 +560,11 @@ class EnsembleSampler(object):
         ens.run(nsteps, thin_by, store and self.backend._dev is ens)
         self._sync_rng_from_device(ens)
         self._raise_on_device_status(ens, store)
-        coords, lp = ens.get_state()
-        out = State(coords, log_prob=lp, random_state=self.random_state)
+        if self._dist is None:
+            out = ResidentState(ens, random_state=self.random_state)      # the arrays cross PCIe when (if) they are read
+        else:
+            coords, lp = ens.get_state()
+            out = State(coords, log_prob=lp, random_state=self.random_state)
         if store:
             self.backend.random_state = out.random_state
         return out

@@ -90,6 +90,14 @@ int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value);
 int emx_set_state(emx_ctx* ctx, const double* coords, const double* log_prob /* or NULL */);
 int emx_get_state(emx_ctx* ctx, double* coords /* or NULL */, double* log_prob /* or NULL */);
 int emx_get_accepted(emx_ctx* ctx, uint8_t* mask /* N */); /* `accepted` of the last propose */
+/* Snapshots (slots 0..7): run_mcmc returns a State and accepts it back (ensemble.py:441-447, 312) -- a State that is the
+ * device state needs no PCIe round trip.  The host layer hands out a lazy State; when a later call is about to change the
+ * ensemble while that object is still alive, emx_snapshot_save keeps its values in HBM (device-to-device copy on the context
+ * stream); emx_snapshot_read materialises them on demand, emx_snapshot_restore makes a snapshot the current state again. */
+int emx_snapshot_save(emx_ctx* ctx, int32_t slot);
+int emx_snapshot_read(emx_ctx* ctx, int32_t slot, double* coords /* or NULL */, double* log_prob /* or NULL */);
+int emx_snapshot_restore(emx_ctx* ctx, int32_t slot);
+int emx_snapshot_free(emx_ctx* ctx, int32_t slot);
 
 /* ---- target: the batched log-prob (ensemble.py:458-553, vectorised) -------------------- */
 /* p0/p1: DIAG (mu, ivar); DENSE (mu, icov[D*D], symmetric positive definite: factored once as

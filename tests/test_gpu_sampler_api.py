@@ -217,6 +217,64 @@ def test_input_state_not_overwritten_and_pickle():
     assert c is x.coords and len(x) == 3 and x[-1] is rs
 
 
+@pytest.mark.parametrize("rng", ["mt19937", "philox"])
+def test_state_handed_back_unread_continues_on_the_device(rng):
+    """run_mcmc returns a State and takes it back (reference ensemble.py:312, 441-447).  Here the returned object is lazy
+    (ResidentState): handed back unread it costs no upload, yet it keeps the values it was returned with whatever runs later,
+    and every way of continuing gives the chain of the plain-array continuation."""
+    from emcee_amd.state import ResidentState
+    mk = lambda: emcee_amd.EnsembleSampler(64, 4, targets.IsoGaussian(), rng=rng)  # noqa: E731
+    p0 = np.random.RandomState(11).randn(64, 4)
+
+    def seeded():
+        s = mk()
+        s._random.seed(5)
+        return s
+
+    # reference continuation: arrays go down and up again between the calls
+    a = seeded()
+    st = a.run_mcmc(p0, 7)
+    mid = (st.coords.copy(), st.log_prob.copy())
+    st2 = a.run_mcmc(State(st.coords.copy(), log_prob=st.log_prob.copy(), random_state=st.random_state), 9)
+    ref_chain, ref_end = a.get_chain(), st2.coords.copy()
+
+    # handed back unread: same chain, and the FIRST returned object still shows the state after 7 steps
+    b = seeded()
+    r1 = b.run_mcmc(p0, 7)
+    assert isinstance(r1, ResidentState) and r1._c is None
+    r2 = b.run_mcmc(r1, 9)
+    assert r1._c is None and r1._slot is not None          # kept by a device-side snapshot, never crossed PCIe
+    assert np.array_equal(b.get_chain(), ref_chain) and np.array_equal(r2.coords, ref_end)
+    assert np.array_equal(r1.coords, mid[0]) and np.array_equal(r1.log_prob, mid[1]) and r1._slot is None
+
+    # initial_state=None -> the previous state; and an OLD unread state restarts from its snapshot (no upload either)
+    c = seeded()
+    q1 = c.run_mcmc(p0, 7)
+    c.run_mcmc(None, 9)
+    assert np.array_equal(c.get_chain(), ref_chain)
+    rs_mid = q1.random_state
+    c.reset()
+    c.random_state = rs_mid
+    if rng == "philox":
+        c._philox_step = 7              # the counter of the native stream is sampler state, not part of random_state
+    q3 = c.run_mcmc(q1, 9)                                  # q1 is two generations old: restored inside HBM
+    assert np.array_equal(c.get_chain(), ref_chain[7:]) and np.array_equal(q3.coords, ref_end)
+
+    # read and edited by the caller: an ordinary State, uploaded like one
+    d = seeded()
+    e1 = d.run_mcmc(p0, 7)
+    e1.coords[:] = mid[0][::-1]
+    e1.log_prob[:] = mid[1][::-1]
+    e2 = d.run_mcmc(e1, 3, store=False)
+    f = mk()
+    f.random_state = e1.random_state
+    g2 = f.run_mcmc(State(mid[0][::-1].copy(), log_prob=mid[1][::-1].copy(), random_state=e1.random_state), 3, store=False)
+    assert np.array_equal(e2.coords, g2.coords)
+    # pickling materialises
+    h = pickle.loads(pickle.dumps(r2))
+    assert type(h) is State and np.array_equal(h.coords, ref_end)
+
+
 def test_infinite_iterations_without_store():
     s, p0 = _mk()
     for i, st in enumerate(s.sample(p0, iterations=None, store=False)):
