@@ -35,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
+HBM_ACHIEVABLE_GBPS = 6300.0   # what a streaming kernel sustains on this part (same guide): the second yardstick of the beyond-MALL configs
+MFMA_F64_PEAK_TFLOPS = 78.6    # dense f64 matrix peak (v_mfma_f64_16x16x4_f64: 256 flop x 4 SIMD x 256 CU x 2.4 GHz / 8 passes)
 MIN_TIMED_MS = 50.0
 MAX_BLOCKS = 400
 
@@ -88,13 +90,27 @@ class Workload(object):
             self.p0 = 1.0 + 0.1 * rs.randn(self.N, self.D)
             self.moves, self.weights = [("stretch", std("stretch", 32))], [1.0]
             self.label = "configs[2]: nwalkers=%d, ndim=32, Rosenbrock/20, StretchMove a=2.0" % self.N
-        elif key == "c5":
+        elif key in ("hbm_dense", "w512", "w128"):
+            # C2's target at other sizes: hbm_dense = 1 048 576 x 64 (537 MB of coordinates: past the 256 MB Infinity Cache);
+            # w512 / w128 = 65 536 walkers on a 512- / 128-dimensional dense Gaussian (the MFMA-bound wide path, emx_wide.hip)
+            self.D = {"hbm_dense": 64, "w512": 512, "w128": 128}[key]
+            mu, cov, icov = dense_gaussian(self.D)
+            self.params = (mu, cov, icov)
+            self.target = (_lib.TARGET_DENSE, mu, icov, 0.0)
+            self.p0 = mu + np.random.default_rng(1).standard_normal((self.N, self.D)) @ np.linalg.cholesky(cov).T
+            self.moves, self.weights = [("stretch", std("stretch", self.D))], [1.0]
+            self.label = "nwalkers=%d, ndim=%d, dense-precision Gaussian, StretchMove a=2.0" % (self.N, self.D)
+        elif key in ("c5", "hbm_wide"):
             self.D = 1024
             ivar = 1.0 / np.random.RandomState(0).rand(self.D)                        # docs/index.rst:41-45
             self.target = (_lib.TARGET_DIAG, np.zeros(self.D), ivar, 0.0)
-            self.p0 = rs.randn(self.N, self.D) / np.sqrt(ivar)
+            if key == "c5":
+                self.p0 = rs.randn(self.N, self.D) / np.sqrt(ivar)
+                self.label = "configs[4]: nwalkers=%d, ndim=1024, diagonal Gaussian, StretchMove a=2.0" % self.N
+            else:       # 262 144 x 1024: 2.1 GB of coordinates, nothing of it cache resident
+                self.p0 = np.random.default_rng(1).standard_normal((self.N, self.D)) / np.sqrt(ivar)
+                self.label = "nwalkers=%d, ndim=1024, diagonal Gaussian, StretchMove a=2.0" % self.N
             self.moves, self.weights = [("stretch", std("stretch", 1024))], [1.0]
-            self.label = "configs[4]: nwalkers=%d, ndim=1024, diagonal Gaussian, StretchMove a=2.0" % self.N
         else:
             raise ValueError(key)
 
@@ -332,6 +348,30 @@ def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=F
     return res
 
 
+def wide_entry(wl, res, K):
+    """Dense Gaussian beyond ndim 112 (emx_wide.hip): propose -> k_wide_lp -> commit.  The MFMA log-prob kernel dominates and is
+    bound by the f64 matrix pipe, not by HBM: D^2 + 3 D flop per walker-update in the Cholesky form, against
+    24 D + 17 bytes."""
+    D, N = wl.D, wl.N
+    flops = float(D) * D + 3.0 * D
+    ms = res["wall_s"] * 1e3 / K
+    wu = N * K / res["wall_s"]
+    out = {"workload": wl.label, "nwalkers": N, "ndim": D, "ms_per_step": ms, "wu_per_s": wu, "steps_per_s": K / res["wall_s"],
+           "blocks_timed": res["blocks"], "accept_frac": res["accept_frac"], "device_status": res["status"]}
+    rl = {"bound": "mfma_f64", "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "algorithmic_flops_per_walker_update": flops,
+          "walker_updates_per_launch": N / 2.0, "kernel": "emx::k_wide_lp* (Y = R L by v_mfma_f64_16x16x4_f64, L streamed through LDS)",
+          "frac_wall_clock": wu * flops / 1e12 / MFMA_F64_PEAK_TFLOPS,
+          "hbm_frac_wall_clock": wu * wl.bytes_per_update(False) / 1e9 / HBM_PEAK_GBPS}
+    if res["per_launch_us"]:
+        rl["avg_launch_us"] = res["per_launch_us"]
+        rl["achieved"] = (N / 2.0) * flops / (res["per_launch_us"] * 1e-6) / 1e12
+        rl["frac"] = rl["achieved"] / MFMA_F64_PEAK_TFLOPS
+        rl["note"] = "avg_launch_us = hipEvents around single k_wide_lp launches (median of 128); frac_wall_clock prices the WHOLE step " \
+                     "(propose + log-prob + commit passes) against the matrix peak"
+    out["roofline"] = rl
+    return out
+
+
 def config_entry(wl, res, K, store):
     B = wl.bytes_per_update(store)
     lps = wl.launches_per_step()
@@ -347,7 +387,19 @@ def config_entry(wl, res, K, store):
                         "frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS,
                         "avg_launch_us": ev_ms * 1e3 / lps, "per_launch_event_us": res["per_launch_us"],
                         "launches_per_step": lps}}
+    state_mb = wl.N * wl.D * 8 / 1e6
+    if state_mb > 256.0:
+        out["roofline"].update({"state_MB": state_mb, "beyond_infinity_cache": True,
+                                "frac_of_achievable_6300": wl.N * B / (ev_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS,
+                                "traffic": hbm_traffic(wl.key), "traffic_source": "profiles/pmc_traffic.json (static; rocprofv3 PMC passes)"})
     return out
+
+
+def hbm_traffic(key):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key + "_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def exact_mode_entry(wl, K, W, device):
@@ -934,7 +986,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--config", default="all", choices=["all", "c2", "c3", "c4", "c5"],
+    ap.add_argument("--config", default="all", choices=["all", "c2", "c3", "c4", "c5", "hbm_dense", "hbm_wide", "w512", "w128"],
                     help="which BASELINE configuration(s) to measure beside the C2 headline (N>1: c2, c3, c5)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="N>1: auto = C2 weak (65536 walkers per GPU), C3 / C5 strong (BASELINE's fixed totals)")
@@ -1042,16 +1094,24 @@ def main(argv=None):
         line = headline(wl, res["wall_s"], res["gpu_ms"], res["per_launch_us"], res["accept_frac"], res["status"], "", extra)
         if not args.no_extras:
             cfgs = {}
-            plan = [("c3", 262144, False), ("c4", 65536, False), ("c5", 16384, False), ("c2", 65536, True)]
+            plan = [("c3", 262144, False), ("c4", 65536, False), ("c5", 16384, False), ("c2", 65536, True),
+                    # beyond the BASELINE list: two ensembles no cache can hold (the HBM roofline taken literally) and the
+                    # MFMA-bound wide dense targets
+                    ("hbm_dense", 1048576, False), ("hbm_wide", 262144, False), ("w512", 65536, False), ("w128", 65536, False)]
             for key, n, st in plan:
                 if args.config not in ("all", key):
                     continue
-                name = {"c3": "c3_262144x32_rosen", "c4": "c4_de_snooker", "c5": "c5_16384x1024_diag", "c2": "c2_store"}[key]
+                name = {"c3": "c3_262144x32_rosen", "c4": "c4_de_snooker", "c5": "c5_16384x1024_diag", "c2": "c2_store",
+                        "hbm_dense": "hbm_1048576x64_dense", "hbm_wide": "hbm_262144x1024_diag", "w512": "wide_65536x512_dense",
+                        "w128": "wide_65536x128_dense"}[key]
                 try:
                     w2 = wl if key == "c2" else Workload(key, n)
                     Ks = K if not st else min(K, 200)          # stored chain: 33.5 MB per step
-                    r2 = measure_single(w2, Ks, min(W, Ks), device=local_rank, rng="philox", store=st, single_block=args.single_block)
-                    cfgs[name] = config_entry(w2, r2, Ks, st)
+                    if key in ("hbm_dense", "hbm_wide", "w512"):
+                        Ks = max(4, min(K, 20))                # 0.2 - 1.5 ms per step: a few steps fill the timed 50 ms
+                    r2 = measure_single(w2, Ks, min(W, Ks), device=local_rank, rng="philox", store=st, single_block=args.single_block,
+                                        spin_s=0.05 if key.startswith(("hbm", "w")) else 0.15)
+                    cfgs[name] = wide_entry(w2, r2, Ks) if key in ("w512", "w128") else config_entry(w2, r2, Ks, st)
                 except Exception as e:  # noqa: BLE001
                     cfgs[name] = {"error": repr(e)}
                     log("config %s failed: %r" % (name, e))
@@ -1078,7 +1138,7 @@ def main(argv=None):
     dist.init_process_group("gloo")
     port_base = int(os.environ["MASTER_PORT"]) + 17
 
-    keys = ["c2", "c3", "c5"] if args.config == "all" else [args.config if args.config != "c4" else "c2"]
+    keys = ["c2", "c3", "c5"] if args.config == "all" else [args.config if args.config in ("c2", "c3", "c5") else "c2"]
     if "c2" not in keys:
         keys = ["c2"] + keys                 # the headline is always C2
     multi = {}

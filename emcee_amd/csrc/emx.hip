@@ -637,8 +637,14 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
             c->err = "wide dense target: half-step without a plan";
             return -1;
         }
+        // per-launch profile events (emx_profile_enable) bracket the MFMA log-prob kernel here -- the dominant kernel of this
+        // path -- not the propose pass
+        const int prof_max = c->prof_max;
+        const bool prof = prof_max > 0 && c->prof_n < prof_max;
+        c->prof_max = 0;
         int rc = launch_split(c, move, EMX_TARGET_HOST, S, split, pos0, ns, t_lo, t_hi, mv, ps, order, X, lp, nullptr, nullptr,
                               nullptr, nullptr, t_hi_dev);
+        c->prof_max = prof_max;
         if (rc) return rc;
         w.rows = c->qout;
         w.order = nullptr;
@@ -663,8 +669,13 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         k.pos0 = pos0;
         k.t_lo = t_lo;
         k.t_hi = t_hi;
-        if (launch_wide_lp(w, t_hi - t_lo, c->num_cu, c->stream) != hipSuccess ||
-            launch_wide_commit(k, t_hi - t_lo, c->num_cu, c->stream) != hipSuccess) {
+        if (prof && hipEventRecord(c->prof[2 * c->prof_n], c->stream) != hipSuccess) return -2;
+        const hipError_t e_lp = launch_wide_lp(w, t_hi - t_lo, c->num_cu, c->stream);
+        if (prof) {
+            if (hipEventRecord(c->prof[2 * c->prof_n + 1], c->stream) != hipSuccess) return -2;
+            c->prof_n++;
+        }
+        if (e_lp != hipSuccess || launch_wide_commit(k, t_hi - t_lo, c->num_cu, c->stream) != hipSuccess) {
             c->err = "wide dense target: kernel launch failed";
             return -2;
         }
