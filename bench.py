@@ -483,10 +483,12 @@ def quality_entry(device, rng="philox"):
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU measurement
-EXCHANGES = ("allgather", "pull", "direct")      # measured by default at N > 1
+EXCHANGES = ("allgather", "pull", "direct", "replay")      # measured by default at N > 1
 # "logprob" (proposal / commit replicated, log-prob evaluations shared out: for targets that dominate the step) is measured
 # on request only: on the closed-form BASELINE targets the replicated part is most of the step
 ALL_EXCHANGES = EXCHANGES + ("logprob",)
+# the compute-heavy configuration (65 536 x 512 dense, strong scaling): the two protocols that share out the evaluation
+HEAVY_EXCHANGES = ("replay", "logprob")
 
 
 _NCCL_GROUP = {}
@@ -520,6 +522,9 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
         if exchange == "logprob":
             from emcee_amd.parallel import LogProbStepper
             stepper = LogProbStepper(eng, gather)
+        elif exchange == "replay":
+            from emcee_amd.parallel import ReplayStepper
+            stepper = ReplayStepper(eng, gather)
         elif exchange == "pull":
             stepper = PullStepper(eng, lambda out, inp: dist.all_to_all_single(out, inp, group=grp), gather)
         else:
@@ -692,8 +697,8 @@ def run_preflight(args, world, dist, port0, exchanges):
 
 
 def sharded_workload(key, world, args):
-    scaling = {"c2": "weak", "c3": "strong", "c5": "strong"}[key] if args.scaling == "auto" else args.scaling
-    base = {"c2": 65536, "c3": 262144, "c5": 16384}[key]
+    scaling = {"c2": "weak", "c3": "strong", "c5": "strong", "w512": "strong"}[key] if args.scaling == "auto" else args.scaling
+    base = {"c2": 65536, "c3": 262144, "c5": 16384, "w512": 65536}[key]
     return Workload(key, base * world if scaling == "weak" else base), scaling
 
 
@@ -818,7 +823,7 @@ def sharded_config(key, world, K, rank, dist, args, port0, skip):
     configuration (not tried again)."""
     wl, scaling = sharded_workload(key, world, args)
     results, errors = {}, {}
-    exchanges = EXCHANGES if args.exchange == "all" else (args.exchange,)
+    exchanges = (HEAVY_EXCHANGES if key == "w512" else EXCHANGES) if args.exchange == "all" else (args.exchange,)
     for n, ex in enumerate(exchanges):
         if ex in skip:
             errors[ex] = "skipped: failed on an earlier configuration (%s)" % skip[ex]
@@ -870,6 +875,8 @@ def sharded_config(key, world, K, rank, dist, args, port0, skip):
     if best is not None:
         B = wl.bytes_per_update(False)
         wu = wl.N * K / best["wall_s"]
+        if key == "w512":      # MFMA-bound: D^2 + 3 D flop per walker-update against the f64 matrix peak
+            entry["mfma_frac_per_gpu"] = wu * (float(wl.D) ** 2 + 3.0 * wl.D) / 1e12 / MFMA_F64_PEAK_TFLOPS / world
         entry.update({"reported": best["exchange"], "ms_per_step": best["wall_s"] * 1e3 / K, "wu_per_s": wu,
                       "steps_per_s": K / best["wall_s"], "accept_frac": best["accept_frac"],
                       "rccl_ranks": best.get("rccl_ranks"), "distinct_devices": best.get("distinct_devices"),
@@ -1116,14 +1123,15 @@ def main(argv=None):
                     cfgs[name] = {"error": repr(e)}
                     log("config %s failed: %r" % (name, e))
             line["configs"] = cfgs
-            try:
-                line["exact_mode"] = exact_mode_entry(wl, K, W, local_rank)
-            except Exception as e:  # noqa: BLE001
-                line["exact_mode"] = {"error": repr(e)}
-            try:
-                line["quality"] = quality_entry(local_rank)
-            except Exception as e:  # noqa: BLE001
-                line["quality"] = {"error": repr(e)}
+            if args.config == "all":          # (a single --config: that configuration only, e.g. under rocprofv3)
+                try:
+                    line["exact_mode"] = exact_mode_entry(wl, K, W, local_rank)
+                except Exception as e:  # noqa: BLE001
+                    line["exact_mode"] = {"error": repr(e)}
+                try:
+                    line["quality"] = quality_entry(local_rank)
+                except Exception as e:  # noqa: BLE001
+                    line["quality"] = {"error": repr(e)}
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(wl)
         emit(line)
         return
@@ -1138,13 +1146,13 @@ def main(argv=None):
     dist.init_process_group("gloo")
     port_base = int(os.environ["MASTER_PORT"]) + 17
 
-    keys = ["c2", "c3", "c5"] if args.config == "all" else [args.config if args.config in ("c2", "c3", "c5") else "c2"]
+    keys = ["c2", "c3", "c5", "w512"] if args.config == "all" else [args.config if args.config in ("c2", "c3", "c5", "w512") else "c2"]
     if "c2" not in keys:
         keys = ["c2"] + keys                 # the headline is always C2
     multi = {}
     line = None
     skip = {}
-    exchanges = EXCHANGES if args.exchange == "all" else (args.exchange,)
+    exchanges = (EXCHANGES + ("logprob",) if "w512" in keys else EXCHANGES) if args.exchange == "all" else (args.exchange,)
     pre = None
     if not args.no_preflight or args.preflight:
         t0 = time.perf_counter()
@@ -1167,7 +1175,8 @@ def main(argv=None):
             return 0
     for kn, key in enumerate(keys):
         wl, best, entry = sharded_config(key, world, K, rank, dist, args, port_base + 8 * kn, skip)
-        multi[{"c2": "c2_weak_65536_per_gpu", "c3": "c3_262144x32_rosen_sharded", "c5": "c5_16384x1024_strong"}[key]
+        multi[{"c2": "c2_weak_65536_per_gpu", "c3": "c3_262144x32_rosen_sharded", "c5": "c5_16384x1024_strong",
+               "w512": "wide_65536x512_dense_strong"}[key]
               if args.scaling == "auto" else "%s_%s" % (key, entry["scaling"])] = entry
         if key == "c2":
             if best is None:
@@ -1179,7 +1188,8 @@ def main(argv=None):
                 return
             how = ", %s via %s" % ({"pull": "all-to-all of the partner rows (pull exchange)",
                                     "allgather": "all-gather of the updated rows",
-                                    "direct": "partner rows read in place from the peers' HBM (direct exchange)"}.get(
+                                    "direct": "partner rows read in place from the peers' HBM (direct exchange)",
+                                    "replay": "all-gather of the decisions, accepted updates recomputed on every replica (replay exchange)"}.get(
                                         best["exchange"], best["exchange"]), best["comm"])
             line = headline(wl, best["wall_s"], best["gpu_ms"], None, best["accept_frac"], best["status"], how,
                             {"timed_blocks": best["blocks"], "rccl_ranks": best.get("rccl_ranks"),

@@ -11,7 +11,7 @@ TARGET_HOST, TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_ROSENBROCK, TARGET_BO
 MOVE_STRETCH, MOVE_DE, MOVE_SNOOKER, MOVE_GAUSS = range(4)
 GAUSS_VECTOR, GAUSS_RANDOM, GAUSS_SEQUENTIAL = range(3)
 RNG_INPUTS, RNG_MT19937, RNG_PHILOX = range(3)
-EXCHANGE_ALLGATHER, EXCHANGE_PULL, EXCHANGE_DIRECT, EXCHANGE_LOGPROB = range(4)
+EXCHANGE_ALLGATHER, EXCHANGE_PULL, EXCHANGE_DIRECT, EXCHANGE_LOGPROB, EXCHANGE_REPLAY = range(5)
 
 
 class MoveDesc(C.Structure):
@@ -92,6 +92,8 @@ SIGNATURES = {
     "emx_pull_apply": (C.c_int, [_P, C.c_int32]),
     "emx_logprob_begin": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64)]),
     "emx_logprob_finish": (C.c_int, [_P, C.c_int32]),
+    "emx_replay_begin": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64)]),
+    "emx_replay_finish": (C.c_int, [_P, C.c_int32]),
     "emx_replica_pack": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "emx_replica_unpack": (C.c_int, [_P]),
     "emx_direct_export": (C.c_int, [_P, _u8p]),

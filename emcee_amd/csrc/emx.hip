@@ -350,6 +350,8 @@ struct emx_ctx {
     int ring_pos = 0;
     struct Prepared {   // native plans already evaluated on the device, in step order
         int move, S, slot;
+        bool lean;          // only the columns the fused half-step reads were written
+        int gcol;           // Gaussian sequential mode: the coordinate this step moves
         uint64_t step;
         NativeArgs nat;
         double cursor_before;   // Gaussian sequential mode: the move's cursor before this step was planned
@@ -363,6 +365,8 @@ struct emx_ctx {
         int move = 0, S = 2, slot = 0;
         bool store = false;
         bool native = false;
+        bool lean = false;     // native plan without the columns nothing on the fused path reads (emx_plan_get completes it)
+        int gcol = 0;
         std::vector<int32_t> off;
         NativeArgs nat{};
     } cur;
@@ -401,6 +405,11 @@ struct emx_ctx {
     int32_t* direct_counts = nullptr;         // [64]: owned slots per split of the step begun
     bool direct_planned = false;              // k_own_plan has run for the step begun
     int64_t tune_direct_timeout_ms = 5000;
+    // replay exchange: decisions travel, accepted updates are recomputed on every replica
+    int32_t* replay_counts = nullptr;         // [2]: accepted foreign slots of the current / next half-step (k_replay_compact re-arms)
+    int replay_parity = 0;
+    int replay_split = -1;                    // emx_replay_begin ran for this split
+    double* launch_declp = nullptr;           // set around a launch_split call: the launch writes its decisions here
     bool eval_check_bad = false;              // MOVE_EVAL over proposals (log-prob exchange): non-finite rows get -inf, as in the fused path
     bool direct_dead = false;                 // a barrier timed out (seen by emx_status): no half-step until the peers are re-attached
     bool direct_first_barrier = false;        // the next barrier is the first of an emx_run call: the ranks may enter seconds apart
@@ -423,6 +432,7 @@ struct emx_ctx {
     bool graph_warm = false;         // one ordinary step has run (function attributes set, kernels loaded)
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
+    int64_t tune_full_plan = 0;      // 1: native plans always carry every column
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -436,6 +446,7 @@ static void pipe_stop(emx_ctx* c);
 static void direct_detach(emx_ctx* c);
 static int direct_ensure(emx_ctx* c);
 static void exchange_free(emx_ctx* c);
+static int replay_ensure(emx_ctx* c);
 
 // forget native plans evaluated ahead of time; the Gaussian sequential cursors they advanced go back
 static void drop_prepared(emx_ctx* c) {
@@ -478,7 +489,7 @@ inline int lean_kind(const HalfStepArgs& a, int G, int V, int CH, int move, bool
     const bool common = !a.ablate && !a.desc && !a.sendbuf && !a.disp && !a.skew_sleep && (EMX_OPT_STAMPS || !a.dbg) && a.target != TGT_NONE &&
                         (!EMX_LEAN_FOLD_D || a.D == G * V * CH) && a.spw == spw && a.t_lo == 0;      // ndim is folded only with EMX_LEAN_FOLD_D
     if (!common) return 0;
-    return (a.t_hi_dev || a.npeer) ? 2 : 1;
+    return (a.t_hi_dev || a.npeer || a.declp) ? 2 : 1;
 }
 
 template <int MOVE>
@@ -488,6 +499,9 @@ hipError_t launch_valu(const Shape& sh, dim3 grid, dim3 block, hipStream_t st, c
             const int lk = lean_kind(a, 8, 2, 2, MOVE, false);
             if (lk == 1) return launch_one<8, 2, 2, MOVE, 0, 1>(grid, block, 0, st, a);
             if (lk == 2) return launch_one<8, 2, 2, MOVE, 0, 2>(grid, block, 0, st, a);
+        }
+        if (sh.G == 8 && sh.V == 2 && sh.CH == 4) {       // ndim 64 (the replay of C2's accepted updates on the other replicas)
+            if (lean_kind(a, 8, 2, 4, MOVE, false) == 2) return launch_one<8, 2, 4, MOVE, 0, 2>(grid, block, 0, st, a);
         }
         if (sh.G == 64 && sh.V == 2 && sh.CH == 8) {
             const int lk = lean_kind(a, 64, 2, 8, MOVE, false);
@@ -642,8 +656,11 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         const int prof_max = c->prof_max;
         const bool prof = prof_max > 0 && c->prof_n < prof_max;
         c->prof_max = 0;
+        double* const declp = c->launch_declp;      // the commit kernel below writes the decisions, not the propose pass
+        c->launch_declp = nullptr;
         int rc = launch_split(c, move, EMX_TARGET_HOST, S, split, pos0, ns, t_lo, t_hi, mv, ps, order, X, lp, nullptr, nullptr,
                               nullptr, nullptr, t_hi_dev);
+        c->launch_declp = declp;
         c->prof_max = prof_max;
         if (rc) return rc;
         w.rows = c->qout;
@@ -665,6 +682,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         k.order = order ? order : ps->order;
         k.logu = ps->logu;
         k.t_hi_dev = t_hi_dev;
+        k.declp = c->launch_declp;
         k.D = D;
         k.pos0 = pos0;
         k.t_lo = t_lo;
@@ -681,7 +699,11 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         }
         return 0;
     }
-    const Shape sh = pick_shape(D, dense ? c->Dp : D);
+    // a replay launch (TGT_REPLAY: element-wise kernel, no target) uses the row layout of the rank that took the decisions --
+    // the dense layout when the context's target is the fused dense Gaussian -- so that the snooker move's group reductions
+    // associate identically and the recomputed proposal has the owner's bits
+    const bool dense_layout = dense || (target == TGT_REPLAY && c->target == EMX_TARGET_DENSE_GAUSS && !dense_is_wide(c));
+    const Shape sh = pick_shape(D, dense_layout ? c->Dp : D);
     const int WPW = 64 / sh.G;
     const int nown = t_hi - t_lo;
     const int PF = prefetch_depth_host(sh.G, sh.V, sh.CH, move, dense);
@@ -755,6 +777,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.chain_all = c->chain;
     a.chain_lp_all = c->chain_lp;
     a.t_hi_dev = t_hi_dev;
+    a.declp = c->launch_declp;
     if (move == MOVE_GAUSS && mv) {
         const bool in_registers = c->cur.active && c->cur.native && !c->tune_gauss_materialize;
         a.disp = in_registers ? nullptr : c->disp;
@@ -973,7 +996,7 @@ int emx_destroy(emx_ctx* c) {
     }
     {
         auto& p = c->cplan;
-        void* q[] = {p.order, p.p0, p.p1, p.p2, p.s0, p.uacc, p.logu, p.fac, c->pull_counts};
+        void* q[] = {p.order, p.p0, p.p1, p.p2, p.s0, p.uacc, p.logu, p.fac, c->pull_counts, c->replay_counts};
         for (void* x : q)
             if (x) hipFree(x);
     }
@@ -1118,6 +1141,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "dense_wide")) {      // 1: take the wide-target path (emx_wide.hip) whatever the ndim -- parity tests against the fused kernel
         c->tune_dense_wide = v == 2 ? 2 : (v ? 1 : 0);      // 2: the wide path with the single-role log-prob kernel only
         graph_invalidate(c);
+        return 0;
+    }
+    if (!strcmp(key, "full_plan")) {     // 1: native plans with every column (default 0: what the fused kernel reads)
+        c->tune_full_plan = v ? 1 : 0;
+        drop_prepared(c);
         return 0;
     }
     if (!strcmp(key, "blocks_per_cu")) {
@@ -1800,6 +1828,8 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
             B.N = (int32_t)c->N;
             B.D = c->D;
             B.nb = nb;
+            // single replica, fused device target: nobody but the half-step kernel reads these plans
+            B.lean = (c->target != EMX_TARGET_HOST && c->world == 1 && !c->sendbuf && !c->comm && !c->tune_full_plan) ? 1 : 0;
             for (int b = 0; b < nb; ++b) {
                 const uint64_t step = c->ph_step + (uint64_t)b;
                 const int mi = forced_move >= 0 ? forced_move : philox_move_choice(c->ph_seed, step, c->cdf.data(), nm);
@@ -1816,9 +1846,11 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
                 pr.nat.step = step;
                 pr.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, step);
                 pr.cursor_before = m.gammas;
+                pr.lean = B.lean != 0;
                 if (m.kind == EMX_MOVE_GAUSS) {
                     B.gmode[b] = m.reserved;
                     B.gcol[b] = (int32_t)((int64_t)m.gammas % c->D);
+                    pr.gcol = B.gcol[b];
                     if (m.reserved == EMX_GAUSS_SEQUENTIAL) c->moves[mi].gammas = (double)(((int64_t)m.gammas + 1) % c->D);
                 }
                 c->prepared.push_back(pr);
@@ -1845,6 +1877,8 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         cur.move = pr.move;
         cur.S = pr.S;
         cur.native = true;
+        cur.lean = pr.lean;
+        cur.gcol = pr.gcol;
         cur.nat = pr.nat;
         cur.slot = pr.slot;
         cur.off.assign(cur.S + 1, 0);
@@ -1900,6 +1934,38 @@ int emx_plan_get(emx_ctx* c, int32_t* off, int32_t* order, int32_t* p0, int32_t*
         // the plan was evaluated on the device by k_native_plan at emx_step_begin
         NEED(c, cur.slot >= 0, "no plan available");
         auto& ps = c->ring[cur.slot];
+        if (cur.lean) {
+            // a lean plan (only the columns the fused kernel reads): the same kernel evaluates this step once more, every
+            // column this time -- the plan is a pure function of (seed, step, walker)
+            NEED(c, cur.move >= 0, "no plan available");
+            const emx_move_desc& m = c->moves[cur.move];
+            NativeBatchArgs B{};
+            B.N = (int32_t)c->N;
+            B.D = c->D;
+            B.nb = 1;
+            B.lean = 0;
+            B.nat[0] = cur.nat;
+            B.order[0] = ps.order;
+            B.p0[0] = ps.p0;
+            B.p1[0] = ps.p1;
+            B.p2[0] = ps.p2;
+            B.s0[0] = ps.s0;
+            B.uacc[0] = ps.uacc;
+            B.logu[0] = ps.logu;
+            B.fac[0] = ps.fac;
+            B.a[0] = m.a;
+            B.sigma[0] = m.sigma;
+            B.g0[0] = m.g0;
+            B.move[0] = m.kind;
+            B.S[0] = m.nsplits;
+            if (m.kind == EMX_MOVE_GAUSS) {
+                B.gmode[0] = m.reserved;
+                B.gcol[0] = cur.gcol;
+            }
+            hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), 1u), dim3(256), 0, c->stream, B);
+            HIPOK(c, hipGetLastError());
+            cur.lean = false;
+        }
         HIPOK(c, hipMemcpyAsync(order, ps.order, N * 4, hipMemcpyDeviceToHost, c->stream));
         HIPOK(c, hipMemcpyAsync(p0, ps.p0, N * 4, hipMemcpyDeviceToHost, c->stream));
         HIPOK(c, hipMemcpyAsync(p1, ps.p1, N * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1954,6 +2020,8 @@ static int do_halfstep(emx_ctx* c, int split, int target) {
          "direct exchange: use emx_direct_halfstep");
     NEED(c, c->exchange != EMX_EXCHANGE_LOGPROB || c->world == 1 || target == EMX_TARGET_HOST,
          "log-prob exchange: use emx_logprob_begin / emx_logprob_finish");
+    NEED(c, c->exchange != EMX_EXCHANGE_REPLAY || c->world == 1 || target == EMX_TARGET_HOST,
+         "replay exchange: use emx_replay_begin / emx_replay_finish");
     double* sb = nullptr;
     if (c->sendbuf && target != EMX_TARGET_HOST && c->exchange == EMX_EXCHANGE_ALLGATHER) sb = c->sendbuf;
     NEED(c, !sb || hi - lo <= c->sendbuf_rows, "exchange buffers too small for this move: call emx_set_shard after emx_set_moves");
@@ -2512,6 +2580,24 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
                     }
                     continue;
                 }
+                if (c->comm && c->exchange == EMX_EXCHANGE_REPLAY) {
+                    // own slots fused; 8 bytes of decision per walker-update gathered; the others' accepted updates replayed
+                    int64_t rows = 0;
+                    rc = emx_replay_begin(c, s, &rows);
+                    if (!rc && rows > 0 && c->world > 1) {
+                        const int e = g_rccl.AllGather(c->sendbuf, c->gathered, (size_t)rows, RCCL_FLOAT64, c->comm, c->stream);
+                        if (e != 0) {
+                            c->err = std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+                            rc = -6;
+                        }
+                    }
+                    if (!rc) rc = emx_replay_finish(c, s);
+                    if (rc) {
+                        c->cur.active = false;
+                        return rc;
+                    }
+                    continue;
+                }
                 if (c->comm && c->exchange == EMX_EXCHANGE_PULL) {
                     // partner rows only: pack what the peers will read, all-to-all, fold in, update own walkers
                     int64_t cap = 0;
@@ -2662,7 +2748,8 @@ static int pull_ensure(emx_ctx* c) {
 }
 
 int emx_set_exchange(emx_ctx* c, int32_t kind) {
-    NEED(c, kind == EMX_EXCHANGE_ALLGATHER || kind == EMX_EXCHANGE_PULL || kind == EMX_EXCHANGE_DIRECT || kind == EMX_EXCHANGE_LOGPROB,
+    NEED(c, kind == EMX_EXCHANGE_ALLGATHER || kind == EMX_EXCHANGE_PULL || kind == EMX_EXCHANGE_DIRECT || kind == EMX_EXCHANGE_LOGPROB ||
+                kind == EMX_EXCHANGE_REPLAY,
          "unknown exchange kind %d", kind);
     NEED(c, c->world == 1 && !c->comm && !c->sendbuf, "emx_set_exchange: call it before emx_set_shard / emx_comm_init");
     c->exchange = kind;
@@ -2692,6 +2779,7 @@ int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
         direct_detach(c);
         return direct_ensure(c);
     }
+    if (c->exchange == EMX_EXCHANGE_REPLAY) return replay_ensure(c);
     if (world > 1) {
         const int64_t per = shard_rows_per_rank(c->N, world, min_nsplits_of(c));
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));
@@ -2723,6 +2811,10 @@ int emx_set_shard_buffers(emx_ctx* c, void* sendbuf, void* gathered, int64_t row
 int emx_exchange_layout(emx_ctx* c, int64_t* send_doubles, int64_t* recv_doubles) {
     if (c->exchange == EMX_EXCHANGE_PULL) {
         pull_layout(c, *send_doubles, *recv_doubles);
+    } else if (c->exchange == EMX_EXCHANGE_REPLAY) {
+        const int64_t per = shard_rows_per_rank(c->N, c->world, min_nsplits_of(c));      // one double per walker-update
+        *send_doubles = per;
+        *recv_doubles = per * c->world;
     } else {
         const int64_t per = shard_rows_per_rank(c->N, c->world, min_nsplits_of(c));
         *send_doubles = per * (c->D + 2);
@@ -2811,6 +2903,131 @@ int emx_logprob_finish(emx_ctx* c, int32_t split) {
     k.t_lo = 0;
     k.t_hi = ns;
     if (launch_wide_commit(k, ns, c->num_cu, c->stream) != hipSuccess) FAIL(c, -2, "log-prob exchange: commit kernel launch failed");
+    return 0;
+}
+
+// ---- replay exchange (emx_kernels.hpp "Replay exchange"): decisions travel, accepted updates are recomputed ---------------
+static int replay_ensure(emx_ctx* c) {
+    const int64_t N = c->N;
+    if (c->cplan_rows < N) {          // compact plan of the accepted foreign slots of one half-step (at most a whole split)
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        auto& p = c->cplan;
+        void* old[] = {p.order, p.p0, p.p1, p.p2, p.s0, p.uacc, p.logu, p.fac};
+        for (void* q : old)
+            if (q) hipFree(q);
+        HIPOK(c, hipMalloc((void**)&p.order, N * 4));
+        HIPOK(c, hipMalloc((void**)&p.p0, N * 4));
+        HIPOK(c, hipMalloc((void**)&p.p1, N * 4));
+        HIPOK(c, hipMalloc((void**)&p.p2, N * 4));
+        HIPOK(c, hipMalloc((void**)&p.s0, N * 8));
+        HIPOK(c, hipMalloc((void**)&p.uacc, N * 8));
+        HIPOK(c, hipMalloc((void**)&p.logu, N * 8));
+        HIPOK(c, hipMalloc((void**)&p.fac, N * 8));
+        HIPOK(c, hipMemset(p.fac, 0, N * 8));
+        c->cplan_rows = N;
+    }
+    if (!c->replay_counts) {
+        HIPOK(c, hipMalloc((void**)&c->replay_counts, 2 * 4));
+        HIPOK(c, hipMemset(c->replay_counts, 0, 2 * 4));
+        c->replay_parity = 0;
+    }
+    const int64_t per = c->world > 1 ? shard_rows_per_rank(N, c->world, min_nsplits_of(c)) : N + 2;
+    if (c->send_doubles < per || c->recv_doubles < per * c->world) {
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        exchange_free(c);
+        HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * 8));
+        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * c->world * 8));
+        c->own_shard_bufs = true;
+        c->sendbuf_rows = per;
+        c->gathered_rows = per * c->world;
+        c->send_doubles = per;
+        c->recv_doubles = per * c->world;
+    }
+    return 0;
+}
+
+int emx_replay_begin(emx_ctx* c, int32_t split, int64_t* rows_per_rank) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, c->exchange == EMX_EXCHANGE_REPLAY, "emx_replay_begin needs emx_set_exchange(EMX_EXCHANGE_REPLAY)");
+    NEED(c, cur.active && cur.move >= 0 && cur.slot >= 0, "emx_replay_begin outside a planned step");
+    NEED(c, split >= 0 && split < cur.S, "split out of range");
+    NEED(c, c->target != EMX_TARGET_HOST, "sharded stepping needs a device target");
+    int rc = replay_ensure(c);
+    if (rc) return rc;
+    const emx_move_desc& mv = c->moves[cur.move];
+    const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
+    const int64_t rows = ((int64_t)ns + c->world - 1) / c->world;
+    NEED(c, rows <= c->sendbuf_rows, "replay exchange: buffers too small for this move (call emx_set_shard after emx_set_moves)");
+    if (rows_per_rank) *rows_per_rank = rows;
+    c->replay_split = split;
+    int64_t lo, hi;
+    shard_range(ns, c->rank, c->world, lo, hi);
+    if (hi <= lo) return 0;
+    // own slots, fused: the plan is entered at this rank's first slot, so the launch sees slots [0, hi - lo) -- the form the
+    // production (LEAN) instantiations take -- and decision e of the launch is slot lo + e
+    c->launch_declp = c->sendbuf;
+    rc = launch_split(c, mv.kind, c->target, cur.S, split, pos0 + (int)lo, (int)(hi - lo), 0, (int)(hi - lo), &mv, &c->ring[cur.slot], nullptr,
+                      c->X, c->lp, nullptr, nullptr, nullptr);
+    c->launch_declp = nullptr;
+    return rc;
+}
+
+int emx_replay_finish(emx_ctx* c, int32_t split) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, c->exchange == EMX_EXCHANGE_REPLAY && cur.active && c->replay_split == split, "emx_replay_finish: emx_replay_begin(%d) has not run", split);
+    c->replay_split = -1;
+    const emx_move_desc& mv = c->moves[cur.move];
+    const auto& ps = c->ring[cur.slot];
+    const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
+    int64_t lo, hi;
+    shard_range(ns, c->rank, c->world, lo, hi);
+    const int64_t foreign = ns - (hi - lo);
+    if (foreign > 0) {
+        ReplayCompactArgs a{};
+        a.order = ps.order + pos0;
+        a.p0 = ps.p0 + pos0;
+        a.p1 = ps.p1 + pos0;
+        a.p2 = ps.p2 + pos0;
+        a.s0 = ps.s0 + pos0;
+        a.gathered = c->gathered;
+        a.corder = c->cplan.order;
+        a.cp0 = c->cplan.p0;
+        a.cp1 = c->cplan.p1;
+        a.cp2 = c->cplan.p2;
+        a.cs0 = c->cplan.s0;
+        a.clogu = c->cplan.logu;
+        a.count = c->replay_counts + c->replay_parity;
+        a.count_next = c->replay_counts + (c->replay_parity ^ 1);
+        a.acc = c->acc;
+        a.ns = ns;
+        a.G = c->world;
+        a.rank = c->rank;
+        a.rows = (int32_t)(((int64_t)ns + c->world - 1) / c->world);
+        hipLaunchKernelGGL(k_replay_compact, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, c->stream, a);
+        HIPOK(c, hipGetLastError());
+        const int32_t* count_now = a.count;
+        c->replay_parity ^= 1;
+        // grid for the worst case (every foreign proposal accepted); the count is read on the device, idle waves leave at once
+        const int rc = launch_split(c, mv.kind, TGT_REPLAY, cur.S, split, 0, (int)foreign, 0, (int)foreign, &mv, &c->cplan, nullptr, c->X,
+                                    c->lp, nullptr, nullptr, nullptr, nullptr, count_now);
+        if (rc) return rc;
+    }
+    if (cur.store && split == cur.S - 1) {
+        StoreStepArgs s{};
+        s.X = c->X;
+        s.lp = c->lp;
+        s.acc = c->acc;
+        s.acc_count = c->acc_count;
+        s.chain = c->chain + (size_t)c->stored * c->N * c->D;
+        s.chain_lp = c->chain_lp + (size_t)c->stored * c->N;
+        s.nx = (long long)c->N * c->D;
+        s.N = (int32_t)c->N;
+        const long long nb = std::min<long long>((s.nx + 255) / 256, (long long)c->num_cu * 16);
+        hipLaunchKernelGGL(k_store_step, dim3((unsigned)std::max<long long>(1, nb)), dim3(256), 0, c->stream, s);
+        HIPOK(c, hipGetLastError());
+    }
     return 0;
 }
 
@@ -3281,8 +3498,8 @@ int emx_comm_init(emx_ctx* c, int32_t rank, int32_t world, const uint8_t id[128]
     } else if (c->exchange == EMX_EXCHANGE_DIRECT) {
         rc = direct_ensure(c);
         if (rc) return rc;
-    } else if (c->exchange == EMX_EXCHANGE_LOGPROB) {
-        // emx_set_shard allocated the gather buffer
+    } else if (c->exchange == EMX_EXCHANGE_LOGPROB || c->exchange == EMX_EXCHANGE_REPLAY) {
+        // emx_set_shard allocated the gather buffer(s)
     } else if (!c->sendbuf) {   // world == 1: still exercise the exchange buffers
         const int64_t per = c->N + 2;
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * (c->D + 2) * 8));

@@ -54,7 +54,8 @@ namespace emx {
 
 enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_GAUSS = 3, MOVE_EVAL = 4 };
 enum : int { GAUSS_VECTOR = 0, GAUSS_RANDOM = 1, GAUSS_SEQUENTIAL = 2 };
-enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5 };
+enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5,
+             TGT_REPLAY = 6 };     // replay exchange: no target, no decision -- the slot is a peer's ACCEPTED update, its new log-prob comes with the plan
 enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u, ST_EXCHANGE_TIMEOUT = 8u };
 constexpr int EMX_MAX_PEERS = 8;       // direct exchange: GPUs of one node
 
@@ -138,6 +139,9 @@ struct HalfStepArgs {
     // one replica (everything else).  peer_lo is ascending; own entry of peerX == X.
     const struct PeerTable* peers;     // device memory (not kernel arguments: 24 scalar registers the single-GPU path never needs)
     int32_t npeer;
+    // replay exchange: the decision of every slot of this launch, 8 bytes each -- the new log-prob of an accepted proposal,
+    // NaN for a rejected one (an accepted log-prob is never NaN: NaN > log u is false) -- slot t at declp[t - t_lo]
+    double* declp;
     int32_t skew_sleep;            // EMX_OPT_SKEW experiments: extra delay of the staging waves, in s_sleep(8) units (0 in production)
 };
 
@@ -667,6 +671,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     const int32_t* const thidev_ = LEAN == 1 ? nullptr : A.t_hi_dev;        // LEAN 2: the block-ownership exchanges (pull, direct)
     const double* const disp_ = LEAN ? nullptr : A.disp;
     const int skewsl_ = LEAN ? 0 : A.skew_sleep;
+    double* const declp_ = LEAN == 1 ? nullptr : A.declp;                  // LEAN 2: + the replay exchange's own pass
     const int target_ = (LEAN && DPB > 0) ? (int)TGT_DENSE : A.target;
     static_assert(G >= 4 && G <= 64 && (64 % G) == 0, "G lanes per walker");
     constexpr bool DENSE = DPB > 0;
@@ -895,6 +900,15 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                             store_row<G, V, CH>(q, A.qout + (size_t)t * D, D, gl);
                             if (gl == 0) A.fout[t] = factor;
                         }
+                    } else if (LEAN != 1 && !DENSE && target_ == TGT_REPLAY) {      // (a replay launch reads its slot count on the device: never LEAN 1)
+                        // a peer's accepted update, recomputed from the replica: the same rows, the same draws, the same
+                        // instructions as on the rank that took the decision, hence the same bits (move.py:33-34)
+                        if constexpr (MOVE != MOVE_EVAL) {
+                            if (live) {
+                                store_row<G, V, CH>(q, A.X + (size_t)i * D, D, gl);
+                                if (gl == 0) A.lp[i] = loguv[k];         // the plan's logu column carries the new log-prob
+                            }
+                        }
                     } else if constexpr (!DENSE) {
                         const double lp_new = eval_valu_target<G, V, CH>(q, mu, iv, A.tp0, A.tp1, target_, A.tscale, D, gl, lane);
                         if (live && gl == 0 && (lp_new != lp_new)) raise_status(A.status, ST_NAN_LOGP);   // ensemble.py:550-551
@@ -914,6 +928,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                     chain_lp_[i] = accept ? lp_new : lp_old;
                                     if (accept) A.acc_count[i] += 1u;
                                 }
+                                if (declp_) declp_[t0 + srow - tlo_] = accept ? lp_new : __builtin_nan("");
                             }
                             if (live && chain_) store_row<G, V, CH>(accept ? q : xi[k], chain_ + (size_t)i * D, D, gl);
                             if (live && sendbuf_) {
@@ -1035,6 +1050,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                 chain_lp_[my_i] = lp_fin;
                                 if (acc) A.acc_count[my_i] += 1u;
                             }
+                            if (declp_) declp_[t0 + tb + myrow - tlo_] = acc ? lpn : __builtin_nan("");
                         }
                     }
                     EMX_STAMP(8);      // decisions made, flag / log-prob stores issued
@@ -1593,6 +1609,7 @@ struct NativeBatchArgs {
     int32_t move[NATIVE_BATCH_MAX], S[NATIVE_BATCH_MAX];
     int32_t gmode[NATIVE_BATCH_MAX], gcol[NATIVE_BATCH_MAX];   // Gaussian move: mode, the sequential mode's column
     int32_t N, D, nb;
+    int32_t lean;           // 1: only the columns the fused half-step kernel of the step's move reads are written (below)
     const StepDesc* desc;   // graph replay: per-step NativeArgs from device memory instead of nat[]
 };
 
@@ -1619,12 +1636,18 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
         native_slot<MOVE_DE>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
     else
         native_slot<MOVE_SNOOKER>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
+    // This kernel is bound by what it WRITES (48 bytes per entry at ~3 TB/s: 16.8 us per 16 steps at 65 536 walkers, 75 us at
+    // 262 144), not by its arithmetic.  The fused half-step reads order, p0 (+ p1 for DE, + p1, p2 for the snooker move), s0
+    // (not the snooker move), logu and fac -- never uacc, whose logarithm it is handed.  A lean plan leaves the other columns
+    // unwritten: 32 instead of 48 bytes per entry for the stretch move.  Whoever wants them (emx_plan_get: the parity tests; the
+    // split-phase and sharded paths) gets a full plan.
+    const bool full = !B.lean;
     B.order[b][pos] = i;
     B.p0[b][pos] = a0;
-    B.p1[b][pos] = a1;
-    B.p2[b][pos] = a2;
-    B.s0[b][pos] = z;
-    B.uacc[b][pos] = u;
+    if (full || mv == MOVE_DE || mv == MOVE_SNOOKER) B.p1[b][pos] = a1;
+    if (full || mv == MOVE_SNOOKER) B.p2[b][pos] = a2;
+    if (full || mv != MOVE_SNOOKER) B.s0[b][pos] = z;
+    if (full) B.uacc[b][pos] = u;
     B.logu[b][pos] = log(u);
     B.fac[b][pos] = (mv == MOVE_STRETCH) ? ((double)B.D - 1.0) * log(z) : 0.0;
 }
@@ -1868,6 +1891,85 @@ static __global__ __launch_bounds__(256) void k_own_plan(const OwnPlanArgs A) {
             A.cfac[e] = A.fac[t];
         }
         todo &= ~m;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// Replay exchange (full replicas, slot-range ownership): what a half-step sends is its DECISIONS -- 8 bytes per walker-update,
+// never a coordinate.  Rank r proposes / evaluates / accepts the slots [ns r / G, ns (r+1) / G) of the split (k_halfstep, fused)
+// and writes for each the new log-prob, or NaN when the proposal was rejected; one all-gather replicates those decisions; then
+// every rank REPLAYS the accepted updates of the others on its own replica: the proposal of slot t is a function of the rows
+// of the replica (identical on every rank before the half-step), of the replicated plan and of nothing else, so recomputing it
+// gives the bits the owner committed.  Extra HBM traffic per rank: the accepted fraction of the other ranks' slots
+// (24 D + 8 bytes each) -- the price of never touching xGMI with a row.
+//   k_replay_compact -> the compact plan of the accepted slots of the other ranks (its logu column = their new log-probs),
+//                       the accepted flags of ALL foreign slots, and the count on the device
+//   k_halfstep<..., target = TGT_REPLAY> over the compact plan
+// ----------------------------------------------------------------------------------------
+struct ReplayCompactArgs {
+    const int32_t *order, *p0, *p1, *p2;      // this split's plan (already offset to the split)
+    const double* s0;
+    const double* gathered;                   // [G][rows]: block q = rank q's decisions, its slot lo_q first
+    int32_t *corder, *cp0, *cp1, *cp2;        // compact plan of the accepted foreign slots
+    double *cs0, *clogu;
+    int32_t* count;                           // this half-step's counter (zero on entry)
+    int32_t* count_next;                      // the other counter: zeroed here for the next half-step
+    uint8_t* acc;
+    int32_t ns, G, rank, rows;
+};
+
+static __global__ __launch_bounds__(256) void k_replay_compact(const ReplayCompactArgs A) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *A.count_next = 0;
+    bool hit = false;
+    double v = 0.0;
+    int i = 0;
+    if (t < A.ns) {
+        const int q = block_owner(t, A.ns, A.G);                       // the rank whose slot range holds t (shard_range)
+        if (q != A.rank) {
+            const int lo = (int)((long long)A.ns * q / A.G);
+            v = A.gathered[(size_t)q * A.rows + (t - lo)];
+            hit = !(v != v);
+            i = A.order[t];
+            A.acc[i] = hit ? 1 : 0;
+        }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (!m) return;
+    int base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(A.count, __popcll(m));
+    base = __shfl(base, leader);
+    if (hit) {
+        const int e = base + __popcll(m & ((1ull << lane) - 1ull));
+        A.corder[e] = i;
+        A.cp0[e] = A.p0[t];
+        A.cp1[e] = A.p1[t];
+        A.cp2[e] = A.p2[t];
+        A.cs0[e] = A.s0[t];
+        A.clogu[e] = v;
+    }
+}
+
+// stored step of the replay exchange: the chain row is the replica after the step (backend.py:225-231)
+struct StoreStepArgs {
+    const double* X;
+    const double* lp;
+    const uint8_t* acc;
+    uint32_t* acc_count;
+    double* chain;
+    double* chain_lp;
+    long long nx;      // N * D
+    int32_t N;
+};
+
+static __global__ __launch_bounds__(256) void k_store_step(const StoreStepArgs A) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < A.nx; e += stride) A.chain[e] = A.X[e];
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < A.N; w += (long long)gridDim.x * blockDim.x) {
+        A.chain_lp[w] = A.lp[w];
+        A.acc_count[w] += A.acc[w];
     }
 }
 

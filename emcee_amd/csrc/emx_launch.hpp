@@ -54,6 +54,7 @@ struct WideCommitArgs {
     const int32_t* order;
     const double* logu;
     const int32_t* t_hi_dev;
+    double* declp;               // replay exchange: decision of slot t at declp[t - t_lo] (new log-prob, NaN when rejected), or nullptr
     int32_t D, pos0, t_lo, t_hi;
 };
 hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipStream_t st);

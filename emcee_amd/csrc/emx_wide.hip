@@ -621,6 +621,7 @@ __global__ __launch_bounds__(256) void k_wide_commit(const WideCommitArgs A) {
                 sb[D] = lp_fin;
                 sb[D + 1] = accept ? 1.0 : 0.0;
             }
+            if (A.declp) A.declp[t - A.t_lo] = accept ? nlp : __builtin_nan("");
         }
     }
 }

@@ -339,9 +339,10 @@ class DeviceEnsemble:
 
     # ---- pull exchange (walker-block ownership; include/emx.h) ----
     def set_exchange(self, kind):
-        """'allgather' (every updated row to every rank) or 'pull' (only the partner rows read)."""
+        """'allgather' (every updated row to every rank), 'pull' (only the partner rows read), 'direct' (partner rows read in
+        place over xGMI), 'logprob' (evaluations shared out) or 'replay' (decisions travel, accepted updates recomputed)."""
         k = {"allgather": _lib.EXCHANGE_ALLGATHER, "pull": _lib.EXCHANGE_PULL, "direct": _lib.EXCHANGE_DIRECT,
-             "logprob": _lib.EXCHANGE_LOGPROB}.get(kind, kind)
+             "logprob": _lib.EXCHANGE_LOGPROB, "replay": _lib.EXCHANGE_REPLAY}.get(kind, kind)
         self._ck(self.lib.emx_set_exchange(self.ctx, int(k)))
 
     def exchange_layout(self):
@@ -374,6 +375,16 @@ class DeviceEnsemble:
 
     def logprob_finish(self, split):
         self._ck(self.lib.emx_logprob_finish(self.ctx, int(split)))
+
+    def replay_begin(self, split):
+        """own slots of `split` (fused), decisions into the send buffer -> doubles per rank for the all-gather"""
+        n = C.c_int64()
+        self._ck(self.lib.emx_replay_begin(self.ctx, int(split), C.byref(n)))
+        return n.value
+
+    def replay_finish(self, split):
+        """after the all-gather of the decisions: the other ranks' accepted updates, recomputed on this replica"""
+        self._ck(self.lib.emx_replay_finish(self.ctx, int(split)))
 
     # ---- direct exchange (partner rows read in place from the peers' HBM; include/emx.h) ----
     def direct_export(self):

@@ -107,7 +107,7 @@ class EnsembleSampler(object):
             if not dist.is_initialized():
                 raise RuntimeError("distributed=True needs an initialised torch.distributed process group "
                                    "(it is only used to bootstrap RCCL and to replicate the inputs)")
-            if exchange not in ("allgather", "pull", "direct", "logprob"):
+            if exchange not in ("allgather", "pull", "direct", "logprob", "replay"):
                 raise ValueError("exchange must be 'allgather', 'pull', 'direct' or 'logprob'")
             self._dist = dist
             self._exchange = exchange

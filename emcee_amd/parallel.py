@@ -26,7 +26,7 @@ double) so the protocols themselves are covered by world_size-2 gloo tests witho
 """
 import numpy as np
 
-__all__ = ["shard_range", "rows_per_rank", "ShardedStepper", "PullStepper", "DeviceEngine", "LocalGroup",
+__all__ = ["shard_range", "rows_per_rank", "ShardedStepper", "PullStepper", "ReplayStepper", "DeviceEngine", "LocalGroup",
            "block_range", "block_owner", "pull_capacity", "attach_direct_peers", "import_direct_peers"]
 
 
@@ -187,6 +187,44 @@ class LogProbStepper:
             hint(1)
 
 
+class ReplayStepper:
+    """Drives one engine per rank through steps of the replay exchange (include/emx.h "replay exchange"): every rank updates its
+    share of each split and publishes its DECISIONS (the new log-prob of an accepted proposal, NaN otherwise: 8 bytes per
+    walker-update); after the all-gather every rank recomputes the accepted updates of the others on its own replica.
+
+    engine API: step_begin(store) -> (move, nsplits); replay_begin(split) -> doubles per rank; replay_finish(split); step_end();
+    attributes sendbuf / gathered (flat float64 buffers), world.
+    all_gather(out, inp): every rank's `inp`, concatenated in rank order."""
+
+    def __init__(self, engine, all_gather):
+        self.engine = engine
+        self.all_gather = all_gather
+
+    def step(self, store=False):
+        e = self.engine
+        move, nsplits = e.step_begin(store)
+        for split in range(nsplits):
+            rows = e.replay_begin(split)
+            if rows > 0 and e.world > 1:
+                self.all_gather(e.gathered[:e.world * rows], e.sendbuf[:rows])
+            e.replay_finish(split)
+        e.step_end()
+        return move
+
+    def run(self, nsteps, thin_by=1, store=False):
+        i = 0
+        total = nsteps * thin_by
+        hint = getattr(self.engine, "set_prep_hint", None)
+        for _ in range(nsteps):
+            for _ in range(thin_by):
+                if hint is not None:
+                    hint(total - i)
+                self.step(store and (i + 1) % thin_by == 0)
+                i += 1
+        if hint is not None:
+            hint(1)
+
+
 class _DevView(object):
     """__cuda_array_interface__ carrier for a library-owned device buffer of float64"""
 
@@ -242,6 +280,12 @@ class DeviceEngine:
             self.sendbuf = None
             self.gathered = _wrap_device_buffer(ens, 3, dev)       # the library's buffer, gathered in place
             return
+        if exchange == "replay":
+            ens.set_exchange("replay")
+            ens.set_shard(rank, world)
+            self.sendbuf = _wrap_device_buffer(ens, 2, dev)        # decisions of the own slots
+            self.gathered = _wrap_device_buffer(ens, 3, dev)       # ... of every rank
+            return
         if exchange == "pull":
             ens.set_exchange("pull")
             ens.set_shard(rank, world)
@@ -268,6 +312,12 @@ class DeviceEngine:
 
     def logprob_finish(self, split):
         self.ens.logprob_finish(split)
+
+    def replay_begin(self, split):
+        return self.ens.replay_begin(split)
+
+    def replay_finish(self, split):
+        self.ens.replay_finish(split)
 
     def replica_pack(self):
         return self.ens.replica_pack()

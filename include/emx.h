@@ -197,6 +197,7 @@ int emx_scatter_gathered(emx_ctx* ctx, int32_t split);
 #define EMX_EXCHANGE_PULL 1
 #define EMX_EXCHANGE_DIRECT 2      /* see "direct exchange" below */
 #define EMX_EXCHANGE_LOGPROB 3     /* see "log-prob exchange" below */
+#define EMX_EXCHANGE_REPLAY 4      /* see "replay exchange" below */
 int emx_set_exchange(emx_ctx* ctx, int32_t kind);          /* before emx_set_shard / emx_comm_init */
 /* doubles the send / receive buffers must hold for the moves installed (pull exchange) */
 int emx_exchange_layout(emx_ctx* ctx, int64_t* send_doubles, int64_t* recv_doubles);
@@ -243,6 +244,23 @@ int emx_direct_halfstep(emx_ctx* ctx, int32_t split, int32_t barrier);
  * Results are bit-identical to the single-rank run. */
 int emx_logprob_begin(emx_ctx* ctx, int32_t split, int64_t* per_rank);
 int emx_logprob_finish(emx_ctx* ctx, int32_t split);
+
+/* ---- replay exchange: the DECISIONS travel (8 bytes per walker-update), every replica recomputes the accepted updates ------
+ * Full replicas, slot-range ownership as in the all-gather exchange -- but where that one ships every updated row to every rank
+ * ((G-1) * 8 (D+2) bytes per walker-update over xGMI), this one ships what the owner decided: the new log-prob of an accepted
+ * proposal, NaN for a rejected one.  A proposal (stretch.py:33, de.py:53-62, de_snooker.py:41-46, gaussian.py:87) is a function
+ * of rows every replica holds identically before the half-step and of the replicated plan, so after the all-gather of the
+ * decisions every rank replays the accepted updates of the others on its own replica and obtains the owner's bits; the
+ * log-probability is evaluated once, by the owner.  Extra HBM work per rank: the accepted fraction of the other ranks' slots
+ * (24 D + 8 bytes each, no target evaluation) -- which is what makes it the protocol for BOTH regimes: cheap targets (nothing
+ * crosses xGMI but 8 (G-1) bytes per update) and expensive ones (the evaluation is shared out like the log-prob exchange's, and
+ * unlike there proposal and commit are shared out too).  Replicas stay identical: stored chains are complete on every rank.
+ *   emx_set_exchange(EMX_EXCHANGE_REPLAY); emx_set_shard / emx_comm_init; per step:
+ *   emx_step_begin; for every split: emx_replay_begin(split, &rows) -> all-gather of `rows` doubles per rank, send buffer
+ *   emx_device_ptr(which = 2) into emx_device_ptr(which = 3) -> emx_replay_finish(split); emx_step_end
+ *   (emx_run does it when emx_comm_init ran).  Results are bit-identical to the single-rank run. */
+int emx_replay_begin(emx_ctx* ctx, int32_t split, int64_t* rows_per_rank);
+int emx_replay_finish(emx_ctx* ctx, int32_t split);
 
 /* RCCL driven by the library itself (ncclAllGather enqueued on the context stream between the
  * half-step kernels, so that emx_run covers sharded runs with no host round trip per step).

@@ -283,3 +283,71 @@ class FakeLogProbEngine(FakeEngine):
         acc = so.propose_planned(self.X, self.lp, lambda q: new_lp, sub, self.move)
         idx = sub["order"]
         self.acc[idx] = acc[idx]
+
+
+class FakeReplayEngine(FakeEngine):
+    """The replay exchange (emcee_amd.parallel.ReplayStepper) on the NumPy double: a rank updates its share of the split and
+    publishes its decisions -- the new log-prob of an accepted proposal, NaN otherwise: 8 bytes per walker-update -- and after
+    the all-gather recomputes the accepted updates of the others on its own replica (same rows, same plan, same formulas)."""
+
+    def __init__(self, *a, **kw):
+        make_buffer = kw.get("make_buffer", np.zeros)
+        super().__init__(*a, **kw)
+        self.ndim = self.D
+        per = rows_per_rank(self.N, self.world, min([2] + [m.nsplits for m in self.moves]))
+        self.sendbuf = make_buffer(per)
+        self.gathered = make_buffer(per * self.world)
+        self.evaluated = 0            # target evaluations on this rank: ~1/world of them, and never for a replayed update
+        self.doubles_sent = 0
+
+    def _sub(self, split, lo, hi):
+        off = self.plan["off"]
+        sub = {k: v[off[split] + lo: off[split] + hi] for k, v in self.plan.items() if k != "off"}
+        sub["off"] = np.array([0, hi - lo])
+        return sub
+
+    def replay_begin(self, split):
+        off = self.plan["off"]
+        ns = int(off[split + 1] - off[split])
+        rows = -(-ns // self.world)
+        lo, hi = shard_range(ns, self.rank, self.world)
+        if hi > lo:
+            sub = self._sub(split, lo, hi)
+            box = {}
+
+            def lp_counted(q):
+                box["lp"] = np.asarray(self.lp_fn(q), dtype=np.float64)
+                self.evaluated += len(q)
+                return box["lp"]
+
+            idx = sub["order"]
+            acc = so.propose_planned(self.X, self.lp, lp_counted, sub, self.move)
+            self.acc[idx] = acc[idx]
+            self._np(self.sendbuf)[: hi - lo] = np.where(acc[idx], box["lp"], np.nan)
+        self._ns = ns
+        self.doubles_sent += rows
+        return rows
+
+    def replay_finish(self, split):
+        ns, rows = self._ns, -(-self._ns // self.world)
+        ga = self._np(self.gathered)
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            lo, hi = shard_range(ns, r, self.world)
+            if hi <= lo:
+                continue
+            dec = np.array(ga[r * rows: r * rows + hi - lo], copy=True)
+            ok = ~np.isnan(dec)
+            sub = self._sub(split, lo, hi)
+            idx = sub["order"]
+            self.acc[idx] = ok
+            if not ok.any():
+                continue
+            hit = {k: (v[ok] if k != "off" else np.array([0, int(ok.sum())])) for k, v in sub.items()}
+            # the proposal arithmetic again, on this replica; the decision is the owner's (forced), the log-prob the owner's value
+            forced = dict(hit)
+            forced["uacc"] = np.zeros(int(ok.sum()))                 # ln 0 = -inf: every replayed proposal is "accepted"
+            new_lp = dec[ok]
+            with np.errstate(divide="ignore"):
+                so.propose_planned(self.X, self.lp, lambda q: new_lp, forced, self.move)

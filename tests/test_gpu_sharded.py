@@ -274,6 +274,75 @@ def test_direct_exchange_device_side_barrier(name, world, rng):
 
 @pytest.mark.parametrize("name,world,rng", [
     ("c1_stretch_32x5_iso", 2, "mt"), ("stretch_50x3_iso", 3, "mt"), ("stretch_128x64_dense", 2, "mt"),
+    ("stretch_128x64_dense", 5, "philox"), ("mix_de_snooker_128x8_dense", 3, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt"),
+    ("stretch_128x8_rosen", 8, "philox"), ("stretch_nsplits3_45x2", 2, "mt"), ("stretch_50x3_iso", 7, "philox"),
+    ("stretch_box_32x1", 3, "mt"), ("mix_stretch_gauss_32x3", 2, "mt"), ("gauss_diag_random_factor_30x4", 3, "philox"),
+    ("stretch_48x130_dense", 3, "philox"), ("mix_de_snooker_40x113_dense", 2, "mt"), ("snooker_38x3_diag", 4, "mt"),
+])
+def test_replay_exchange_equals_single_rank(name, world, rng):
+    """Replay exchange: every logical rank updates its share of each split (the fused kernel), publishes its decisions (new
+    log-prob or NaN, 8 bytes per walker-update -- the all-gather is done here with device copies between the contexts'
+    buffers) and recomputes the accepted updates of the others on its own replica.  Every replica's chain, log-probs and
+    accept counts equal the single-rank run BIT FOR BIT -- the snooker move included: the replay runs in the row layout of
+    the kernel that took the decision, so its group reductions associate identically."""
+    import torch
+    from emcee_amd.parallel import ReplayStepper
+    g = load_golden(name)
+    spec = cases.build(name)
+    nst = min(8, spec["nsteps"])
+
+    def setup(ens):
+        if rng == "mt":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(rng_from_fixture(g).get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(777, 0)
+        ens.set_tuning("small_kernel", 0)
+        ens.chain_config(nst)
+
+    ref = make_ens(spec, g["p0"])
+    setup(ref)
+    ref.run(nst, 1, True)
+    ref_chain, ref_lp, ref_acc = ref.chain_read(0, 0, nst), ref.chain_read(1, 0, nst), ref.accepted_counts()
+    engines = []
+    for r in range(world):
+        ens = make_ens(spec, g["p0"])
+        setup(ens)
+        engines.append(DeviceEngine(ens, r, world, torch.device("cuda", 0), exchange="replay"))
+    for _ in range(nst):
+        res = [e.step_begin(True) for e in engines]
+        assert all(x == res[0] for x in res)
+        for split in range(res[0][1]):
+            rows = [e.replay_begin(split) for e in engines]
+            assert len(set(rows)) == 1
+            n = rows[0]
+            for e in engines:
+                e.ens.sync()
+            for dst in engines:                       # the all-gather of the decisions
+                for r, src in enumerate(engines):
+                    dst.gathered[r * n:(r + 1) * n] = src.sendbuf[:n]
+            torch.cuda.synchronize()
+            for e in engines:
+                e.replay_finish(split)
+        for e in engines:
+            e.step_end()
+    for e in engines:
+        ens = e.ens
+        assert ens.status() == 0
+        assert np.array_equal(ens.chain_read(0, 0, nst), ref_chain)
+        assert np.array_equal(ens.chain_read(1, 0, nst), ref_lp)
+        assert np.array_equal(ens.accepted_counts(), ref_acc)
+        x, lp = ens.get_state()
+        assert np.array_equal(x, ref_chain[-1]) and np.array_equal(lp, ref_lp[-1])
+        assert np.array_equal(ens.accepted_mask(), ref.accepted_mask())
+        ens.close()
+    ref.close()
+    assert ReplayStepper is not None
+
+
+@pytest.mark.parametrize("name,world,rng", [
+    ("c1_stretch_32x5_iso", 2, "mt"), ("stretch_50x3_iso", 3, "mt"), ("stretch_128x64_dense", 2, "mt"),
     ("stretch_128x64_dense", 5, "philox"), ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
     ("stretch_nsplits3_45x2", 2, "mt"), ("stretch_50x3_iso", 7, "philox"), ("stretch_box_32x1", 3, "mt"),
     ("mix_stretch_gauss_32x3", 2, "mt"), ("gauss_diag_random_factor_30x4", 3, "philox"),

@@ -182,6 +182,68 @@ def test_logprob_protocol_over_gloo(name, world):
     assert total_eval == nst * N                                # every proposal evaluated exactly once
 
 
+def _replay_worker(rank, world, port, name, nst, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    from emcee_amd.parallel import ReplayStepper
+    from fake_engine import FakeReplayEngine
+    from helpers import load_golden, rng_from_fixture
+    from oracle import cases
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden(name)
+    spec = cases.build(name)
+    eng = FakeReplayEngine(g["p0"], cases.make_target(spec["desc"]), spec["moves"], spec["weights"],
+                           rng_from_fixture(g).get_state(), rank, world,
+                           make_buffer=lambda n: torch.zeros(n, dtype=torch.float64))
+    st = ReplayStepper(eng, lambda out, inp: dist.all_gather_into_tensor(out, inp.clone()))
+    st.run(nst, 1, True)
+    q.put((rank, np.stack(eng.chain), np.stack(eng.chain_lp), eng.acc_count.copy(), eng.evaluated, eng.doubles_sent))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("stretch_50x3_iso", 2), ("mix_de_snooker_128x8_dense", 3),
+                                        ("stretch_nsplits3_45x2", 2), ("stretch_128x64_dense", 3)])
+def test_replay_protocol_over_gloo(name, world):
+    """Replay exchange over a real all-gather between processes: what travels is one double per walker-update (the decision),
+    every rank's replica of the chain equals the single-rank oracle chain, every proposal is evaluated exactly once across
+    the ranks and a replayed update never evaluates the target."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    from helpers import load_golden
+    g = load_golden(name)
+    nst = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 34500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_replay_worker, args=(r, world, port, name, nst, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exact = "snooker" not in name
+    N, D = g["p0"].shape
+    acc_total = (np.diff(g["chain"][: nst], axis=0, prepend=g["p0"][None]) != 0).any(axis=2).sum(axis=0)
+    total_eval = 0
+    for rank, chain, lp, acc, evaluated, sent in res:
+        if exact:
+            assert np.array_equal(chain, g["chain"][:nst]), "rank %d diverged" % rank
+        else:
+            np.testing.assert_allclose(chain, g["chain"][:nst], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(lp, g["log_prob"][:nst], rtol=1e-12)
+        assert np.array_equal(acc, acc_total)
+        total_eval += evaluated
+        assert sent <= nst * (N // world + 6)                   # 8 bytes per own walker-update, never a row
+    assert total_eval == nst * N
+
+
 def _shared_lp_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
