@@ -7,7 +7,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libemx.so")
 
-TARGET_HOST, TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_ROSENBROCK, TARGET_BOX = range(6)
+TARGET_HOST, TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_ROSENBROCK, TARGET_BOX, TARGET_CALLBACK = range(7)
 MOVE_STRETCH, MOVE_DE, MOVE_SNOOKER, MOVE_GAUSS = range(4)
 GAUSS_VECTOR, GAUSS_RANDOM, GAUSS_SEQUENTIAL = range(3)
 RNG_INPUTS, RNG_MT19937, RNG_PHILOX = range(3)
@@ -24,6 +24,9 @@ class EmxError(RuntimeError):
 
 
 _lib = None
+
+# emx_device_log_prob_fn (include/emx.h): (user, coords_dev, n, ndim, log_prob_dev, hip_stream) -> int
+DEVICE_LOG_PROB_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p)
 
 _P = C.c_void_p
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -52,6 +55,7 @@ SIGNATURES = {
     "emx_snapshot_restore": (C.c_int, [_P, C.c_int32]),
     "emx_snapshot_free": (C.c_int, [_P, C.c_int32]),
     "emx_set_target": (C.c_int, [_P, C.c_int32, _P, _P, C.c_double]),
+    "emx_set_target_callback": (C.c_int, [_P, DEVICE_LOG_PROB_FN, _P]),
     "emx_eval_state_log_prob": (C.c_int, [_P]),
     "emx_eval_log_prob": (C.c_int, [_P, _dp, C.c_int64, _dp]),
     "emx_set_moves": (C.c_int, [_P, C.c_int32, C.POINTER(MoveDesc), _dp]),

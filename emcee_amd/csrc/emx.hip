@@ -299,6 +299,8 @@ struct emx_ctx {
     static constexpr int NSNAPSHOT = 8;
     double* snap[NSNAPSHOT] = {};
     // target
+    emx_device_log_prob_fn cb_fn = nullptr;   // EMX_TARGET_DEVICE_CALLBACK: the caller's batched log-prob, run on device buffers
+    void* cb_user = nullptr;
     int target = EMX_TARGET_HOST;
     double *tp0 = nullptr, *tp1 = nullptr;
     double tscale = 1.0;
@@ -350,6 +352,7 @@ struct emx_ctx {
     int ring_pos = 0;
     struct Prepared {   // native plans already evaluated on the device, in step order
         int move, S, slot;
+        hipEvent_t wait_ev; // first step of a batch evaluated on the side stream: the main stream waits for this before using it
         bool lean;          // only the columns the fused half-step reads were written
         int gcol;           // Gaussian sequential mode: the coordinate this step moves
         uint64_t step;
@@ -432,6 +435,10 @@ struct emx_ctx {
     bool graph_warm = false;         // one ordinary step has run (function attributes set, kernels loaded)
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
+    hipStream_t plan_stream = nullptr;        // native plans one batch ahead, next to the half-steps (tuning "plan_stream")
+    hipEvent_t plan_ev[3] = {nullptr, nullptr, nullptr};     // [0], [1]: batch evaluated (alternating); [2]: main-stream mark
+    int plan_ev_pos = 0;
+    int64_t tune_plan_stream = getenv("EMX_PLAN_STREAM") ? atoi(getenv("EMX_PLAN_STREAM")) : 0;
     int64_t tune_full_plan = 0;      // 1: native plans always carry every column
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
     // timing
@@ -442,6 +449,7 @@ struct emx_ctx {
 };
 
 static void graph_invalidate(emx_ctx* c);
+static void apply_env_tuning(emx_ctx* c);
 static void pipe_stop(emx_ctx* c);
 static void direct_detach(emx_ctx* c);
 static int direct_ensure(emx_ctx* c);
@@ -599,7 +607,7 @@ size_t dense_lds_bytes(int Dp, int waves) {
 int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
     const int WPW = 64 / G;
     const int nr = (move == MOVE_STRETCH || move == MOVE_GAUSS) ? 2 : move == MOVE_DE ? 3 : move == MOVE_SNOOKER ? 4 : 1;
-    int pf = 48 / (nr * CH * V);
+    int pf = (move == MOVE_SNOOKER ? 64 : 48) / (nr * CH * V);      // prefetch_depth in emx_kernels.hpp
     pf = pf < 1 ? 1 : (pf > 8 ? 8 : pf);
     int p2 = 1;
     while (p2 * 2 <= pf) p2 *= 2;
@@ -618,13 +626,39 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     if (t_hi <= t_lo) return 0;
     const bool dense = target == EMX_TARGET_DENSE_GAUSS;
     const int D = c->D;
-    if (dense && dense_is_wide(c)) {
-        // precision matrix too wide for LDS: propose -> k_wide_lp (MFMA, L streamed through LDS) -> k_wide_commit, all on the
-        // stream (emx_wide.hip); the reference's compute_log_prob between get_proposal and the accept loop (red_blue.py:90-101)
+    const bool callback = target == EMX_TARGET_DEVICE_CALLBACK;
+    if ((dense && dense_is_wide(c)) || callback) {
+        // Three passes on the stream -- the reference's compute_log_prob between get_proposal and the accept loop
+        // (red_blue.py:90-101): propose -> log-prob of the proposal block -> decision + commit.  The log-prob pass is
+        //   * k_wide_lp (MFMA, L streamed through LDS; emx_wide.hip) for a precision matrix too wide for LDS, or
+        //   * the caller's device callback (emx_set_target_callback): ensemble.py:486-487's "one call on (Ns, ndim)", the block
+        //     and the result staying in HBM.
         if (step_desc) {
-            c->err = "wide dense target: not replayable from a step graph";
+            c->err = "three-pass targets are not replayable from a step graph";
             return -1;
         }
+        if (callback) {
+            if (!c->cb_fn) {
+                c->err = "device callback target without a callback (emx_set_target_callback)";
+                return -1;
+            }
+            if (t_hi_dev) {
+                c->err = "device callback target: the block-ownership exchanges (pull, direct) size the block on the device; use the "
+                         "all-gather, log-prob or replay exchange";
+                return -1;
+            }
+        }
+        // the caller's function enqueues its work on the context stream; rows [t_lo, t_hi) of `rows` -> out[t_lo .. t_hi)
+        auto call_back = [&](const double* rows, double* out) -> int {
+            const int rcb = c->cb_fn(c->cb_user, rows + (size_t)t_lo * D, (int64_t)(t_hi - t_lo), D, out + t_lo, (void*)c->stream);
+            if (rcb != 0) {
+                char b[160];
+                snprintf(b, sizeof(b), "the device log-prob callback failed (returned %d)", rcb);
+                c->err = b;
+                return -7;
+            }
+            return 0;
+        };
         WideLpArgs w{};
         w.order = order ? order : (ps ? ps->order : nullptr);
         w.img = c->tp1_full ? c->tp1_full : c->tp1;
@@ -636,6 +670,13 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         w.t_lo = t_lo;
         w.t_hi = t_hi;
         w.single_role = c->tune_dense_wide == 2;
+        if (move == MOVE_EVAL && callback) {
+            if (order && order != c->iota) {
+                c->err = "device callback target: batched evaluation in plan order is not supported";
+                return -1;
+            }
+            return call_back(X, lp);
+        }
         if (move == MOVE_EVAL) {
             w.rows = X;
             w.out = lp;
@@ -687,8 +728,15 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         k.pos0 = pos0;
         k.t_lo = t_lo;
         k.t_hi = t_hi;
+        k.status = c->status;
         if (prof && hipEventRecord(c->prof[2 * c->prof_n], c->stream) != hipSuccess) return -2;
-        const hipError_t e_lp = launch_wide_lp(w, t_hi - t_lo, c->num_cu, c->stream);
+        hipError_t e_lp = hipSuccess;
+        if (callback) {
+            rc = call_back(c->qout, c->newlp);
+            if (rc) return rc;
+        } else {
+            e_lp = launch_wide_lp(w, t_hi - t_lo, c->num_cu, c->stream);
+        }
         if (prof) {
             if (hipEventRecord(c->prof[2 * c->prof_n + 1], c->stream) != hipSuccess) return -2;
             c->prof_n++;
@@ -961,8 +1009,25 @@ int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
     d.gammas = 1.7;
     c->moves.assign(1, d);
     c->cdf.assign(1, 1.0);
+    apply_env_tuning(c);
     *out = c;
     return 0;
+}
+
+// EMX_TUNE="key=value,key=value": tuning keys applied to every context at creation (A/B measurements through unmodified callers)
+static void apply_env_tuning(emx_ctx* c) {
+    const char* e = getenv("EMX_TUNE");
+    if (!e || !*e) return;
+    std::string s(e);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t end = s.find(',', pos);
+        if (end == std::string::npos) end = s.size();
+        const std::string kv = s.substr(pos, end - pos);
+        const size_t eq = kv.find('=');
+        if (eq != std::string::npos) emx_set_tuning(c, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1));
+        pos = end + 1;
+    }
 }
 
 int emx_destroy(emx_ctx* c) {
@@ -984,6 +1049,12 @@ int emx_destroy(emx_ctx* c) {
         if (p) hipFree(p);
     for (double* s : c->snap)
         if (s) hipFree(s);
+    if (c->plan_stream) {
+        hipStreamSynchronize(c->plan_stream);
+        hipStreamDestroy(c->plan_stream);
+        for (auto e : c->plan_ev)
+            if (e) hipEventDestroy(e);
+    }
     for (auto& s : c->ring) {
         if (s.order) hipFree(s.order);       // the slot's single block
         if (s.host) hipHostFree(s.host);
@@ -1143,6 +1214,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         graph_invalidate(c);
         return 0;
     }
+    if (!strcmp(key, "plan_stream")) {   // 1: native plans one batch ahead on a second stream
+        drop_prepared(c);
+        c->tune_plan_stream = v ? 1 : 0;
+        return 0;
+    }
     if (!strcmp(key, "full_plan")) {     // 1: native plans with every column (default 0: what the fused kernel reads)
         c->tune_full_plan = v ? 1 : 0;
         drop_prepared(c);
@@ -1243,6 +1319,23 @@ int emx_get_state(emx_ctx* c, double* coords, double* log_prob) {
         if (rc) return rc;
     }
     HIPOK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// The caller's own batched log-prob on device buffers (include/emx.h): ensemble.py:486-487's vectorised call without the PCIe
+// hop.  The fused closed-form targets are replaced by three passes on the stream (launch_split).
+int emx_set_target_callback(emx_ctx* c, emx_device_log_prob_fn fn, void* user) {
+    HIPOK(c, hipSetDevice(c->device));
+    NEED(c, fn != nullptr, "emx_set_target_callback: no function");
+    pipe_stop(c);
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    c->cb_fn = fn;
+    c->cb_user = user;
+    c->Dp = 0;
+    graph_invalidate(c);
+    c->graph_warm = false;
+    c->target = EMX_TARGET_DEVICE_CALLBACK;
+    c->tscale = 1.0;
     return 0;
 }
 
@@ -1764,6 +1857,61 @@ int emx_step_begin_with(emx_ctx* c, int32_t store, int32_t move_index, int32_t* 
     return step_begin_impl(c, store, move_index, nullptr, S_out);
 }
 
+// Native (Philox) plans of `nb` consecutive steps from `first_step`, evaluated full width by ONE launch on stream `st`, appended
+// to c->prepared in step order.
+static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int forced_move, hipStream_t st) {
+    const int nm = (int)c->moves.size();
+    NativeBatchArgs B{};
+    B.N = (int32_t)c->N;
+    B.D = c->D;
+    B.nb = nb;
+    // single replica, fused device target: nobody but the half-step kernel reads these plans
+    B.lean = (c->target != EMX_TARGET_HOST && c->world == 1 && !c->sendbuf && !c->comm && !c->tune_full_plan) ? 1 : 0;
+    for (int b = 0; b < nb; ++b) {
+        const uint64_t step = first_step + (uint64_t)b;
+        const int mi = forced_move >= 0 ? forced_move : philox_move_choice(c->ph_seed, step, c->cdf.data(), nm);
+        const emx_move_desc& m = c->moves[mi];
+        emx_ctx::PlanSlot* ps;
+        int rc = acquire_slot(c, &ps, false);
+        if (rc) return rc;
+        emx_ctx::Prepared pr{};
+        pr.move = mi;
+        pr.S = m.nsplits;
+        pr.slot = c->ring_pos;
+        pr.step = step;
+        pr.nat.seed = c->ph_seed;
+        pr.nat.step = step;
+        pr.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, step);
+        pr.cursor_before = m.gammas;
+        pr.lean = B.lean != 0;
+        pr.wait_ev = nullptr;
+        if (m.kind == EMX_MOVE_GAUSS) {
+            B.gmode[b] = m.reserved;
+            B.gcol[b] = (int32_t)((int64_t)m.gammas % c->D);
+            pr.gcol = B.gcol[b];
+            if (m.reserved == EMX_GAUSS_SEQUENTIAL) c->moves[mi].gammas = (double)(((int64_t)m.gammas + 1) % c->D);
+        }
+        c->prepared.push_back(pr);
+        B.nat[b] = pr.nat;
+        B.order[b] = ps->order;
+        B.p0[b] = ps->p0;
+        B.p1[b] = ps->p1;
+        B.p2[b] = ps->p2;
+        B.s0[b] = ps->s0;
+        B.uacc[b] = ps->uacc;
+        B.logu[b] = ps->logu;
+        B.fac[b] = ps->fac;
+        B.a[b] = m.a;
+        B.sigma[b] = m.sigma;
+        B.g0[b] = m.g0;
+        B.move[b] = m.kind;
+        B.S[b] = m.nsplits;
+    }
+    hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), (unsigned)nb), dim3(256), 0, st, B);
+    HIPOK(c, hipGetLastError());
+    return 0;
+}
+
 static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32_t* move_out, int32_t* S_out) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, !c->cur.active, "emx_step_begin: previous step not ended");
@@ -1824,56 +1972,33 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
             // evaluate the plans of the next nb steps (both splits each) in one full-width launch
             int64_t nbw = forced_move >= 0 ? 1 : c->prep_hint;
             const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(nbw, NATIVE_BATCH_MAX));
-            NativeBatchArgs B{};
-            B.N = (int32_t)c->N;
-            B.D = c->D;
-            B.nb = nb;
-            // single replica, fused device target: nobody but the half-step kernel reads these plans
-            B.lean = (c->target != EMX_TARGET_HOST && c->world == 1 && !c->sendbuf && !c->comm && !c->tune_full_plan) ? 1 : 0;
-            for (int b = 0; b < nb; ++b) {
-                const uint64_t step = c->ph_step + (uint64_t)b;
-                const int mi = forced_move >= 0 ? forced_move : philox_move_choice(c->ph_seed, step, c->cdf.data(), nm);
-                const emx_move_desc& m = c->moves[mi];
-                emx_ctx::PlanSlot* ps;
-                int rc = acquire_slot(c, &ps, false);
-                if (rc) return rc;
-                emx_ctx::Prepared pr{};
-                pr.move = mi;
-                pr.S = m.nsplits;
-                pr.slot = c->ring_pos;
-                pr.step = step;
-                pr.nat.seed = c->ph_seed;
-                pr.nat.step = step;
-                pr.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, step);
-                pr.cursor_before = m.gammas;
-                pr.lean = B.lean != 0;
-                if (m.kind == EMX_MOVE_GAUSS) {
-                    B.gmode[b] = m.reserved;
-                    B.gcol[b] = (int32_t)((int64_t)m.gammas % c->D);
-                    pr.gcol = B.gcol[b];
-                    if (m.reserved == EMX_GAUSS_SEQUENTIAL) c->moves[mi].gammas = (double)(((int64_t)m.gammas + 1) % c->D);
-                }
-                c->prepared.push_back(pr);
-                B.nat[b] = pr.nat;
-                B.order[b] = ps->order;
-                B.p0[b] = ps->p0;
-                B.p1[b] = ps->p1;
-                B.p2[b] = ps->p2;
-                B.s0[b] = ps->s0;
-                B.uacc[b] = ps->uacc;
-                B.logu[b] = ps->logu;
-                B.fac[b] = ps->fac;
-                B.a[b] = m.a;
-                B.sigma[b] = m.sigma;
-                B.g0[b] = m.g0;
-                B.move[b] = m.kind;
-                B.S[b] = m.nsplits;
-            }
-            hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), (unsigned)nb), dim3(256), 0, c->stream, B);
-            HIPOK(c, hipGetLastError());
+            const int rc = native_prepare_batch(c, c->ph_step, nb, forced_move, c->stream);
+            if (rc) return rc;
         }
         const emx_ctx::Prepared pr = c->prepared.front();
         c->prepared.pop_front();
+        if (pr.wait_ev) HIPOK(c, hipStreamWaitEvent(c->stream, pr.wait_ev, 0));      // first step of a batch made on the side stream
+        if (c->tune_plan_stream && forced_move < 0 && (int)c->prepared.size() < NATIVE_BATCH_MAX && c->world == 1 && !c->comm) {
+            // Stay one batch ahead, off the critical path: the plans do not depend on the walkers, so the NEXT batch is evaluated
+            // on a second stream while this batch's half-steps run (which raise their waves' issue priority: the plan kernel is
+            // bound by its instruction count and fills the issue slots the latency-bound half-step leaves empty).  It goes into
+            // the ring half whose steps were all enqueued before this point: the side stream waits for the main stream to get here.
+            if (!c->plan_stream) {
+                int lo = 0, hi = 0;
+                HIPOK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo: the least urgent
+                HIPOK(c, hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, lo));
+                for (auto& e : c->plan_ev) HIPOK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            const uint64_t next = c->prepared.empty() ? pr.step + 1 : c->prepared.back().step + 1;
+            HIPOK(c, hipEventRecord(c->plan_ev[2], c->stream));
+            HIPOK(c, hipStreamWaitEvent(c->plan_stream, c->plan_ev[2], 0));
+            const size_t at = c->prepared.size();
+            const int rc = native_prepare_batch(c, next, NATIVE_BATCH_MAX, -1, c->plan_stream);
+            if (rc) return rc;
+            hipEvent_t done = c->plan_ev[c->plan_ev_pos ^= 1];
+            HIPOK(c, hipEventRecord(done, c->plan_stream));
+            c->prepared[at].wait_ev = done;
+        }
         cur.move = pr.move;
         cur.S = pr.S;
         cur.native = true;

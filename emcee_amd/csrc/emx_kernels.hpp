@@ -46,6 +46,9 @@
 #ifndef EMX_OPT_SKEW
 #define EMX_OPT_SKEW 1        // dense target, 8-wave workgroups: the upper four waves stage the whole LDS image before they issue
 #endif                        // their row loads, so the two waves of a SIMD run out of phase (loads first for the lower four)
+#ifndef EMX_OPT_SETPRIO
+#define EMX_OPT_SETPRIO 2     // wave issue priority of the half-step kernel (0: leave the default)
+#endif
 #ifndef EMX_OPT_STAMPS
 #define EMX_OPT_STAMPS 0      // phase timestamps (tools/phase_clock.py builds its own copy with -DEMX_OPT_STAMPS=1: they cost 1 %)
 #endif
@@ -504,7 +507,10 @@ constexpr int rows_per_pass() {
 template <int G, int V, int CH, int MOVE, int DPB>
 constexpr int prefetch_depth() {
     constexpr int WPW = 64 / G;
-    int pf = 48 / (rows_per_pass<MOVE>() * CH * V);        // <= 48 doubles of rows in flight per lane
+    // <= 48 doubles of rows in flight per lane -- 64 for the snooker move, whose four rows per walker would otherwise split a
+    // 16-row MFMA tile at ndim 64 into two DEPENDENT memory round trips (its quarter-ensemble launches run one wave per SIMD:
+    // registers are not what they are short of)
+    int pf = (MOVE == MOVE_SNOOKER ? 64 : 48) / (rows_per_pass<MOVE>() * CH * V);
     pf = pf < 1 ? 1 : (pf > 8 ? 8 : pf);
     int p2 = 1;
     while (p2 * 2 <= pf) p2 *= 2;
@@ -686,6 +692,11 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     static_assert(!DENSE || G * V * CH >= Dp, "row layout must cover the padded dimension");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (ablate_ & 64) return;     // timing experiments: launch + dispatch floor
+#if EMX_OPT_SETPRIO
+    // the half-step is on the step's critical path and latency-bound (it issues in ~20 % of its cycles); whatever else shares the
+    // SIMD -- the next batch's plan kernel on the side stream -- takes the issue slots that are left
+    __builtin_amdgcn_s_setprio(EMX_OPT_SETPRIO);
+#endif
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int sub = lane / G;

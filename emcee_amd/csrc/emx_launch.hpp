@@ -54,6 +54,7 @@ struct WideCommitArgs {
     const int32_t* order;
     const double* logu;
     const int32_t* t_hi_dev;
+    uint32_t* status;            // sticky status flags: a NaN log-prob (ensemble.py:550-551) is reported and the proposal rejected
     double* declp;               // replay exchange: decision of slot t at declp[t - t_lo] (new log-prob, NaN when rejected), or nullptr
     int32_t D, pos0, t_lo, t_hi;
 };

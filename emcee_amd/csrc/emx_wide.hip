@@ -595,6 +595,7 @@ __global__ __launch_bounds__(256) void k_wide_commit(const WideCommitArgs A) {
         const int pos = A.pos0 + t;
         const int i = A.order[pos];
         const double nlp = A.newlp[t], lp_old = A.lp[i];
+        if (A.status && lane == 0 && nlp != nlp) raise_status(A.status, ST_NAN_LOGP);      // ensemble.py:550-551 (a caller's callback may return one)
         const double lnpdiff = A.fout[t] + nlp - lp_old;                     // red_blue.py:99
         const bool accept = lnpdiff > A.logu[pos];                          // red_blue.py:100
         const double* q = A.qout + (size_t)t * D;

@@ -56,6 +56,9 @@ class DeviceEnsemble:
             pass
 
     def _ck(self, rc):
+        exc, self._cb_exc = getattr(self, "_cb_exc", None), None
+        if exc is not None:               # raised inside a device log-prob callback: the caller's own exception, not our code
+            raise exc
         _lib.check(self.lib, self.ctx, rc)
 
     # ---- state ----
@@ -141,6 +144,38 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_set_target(self.ctx, int(kind), None if a0 is None else a0.ctypes.data,
                                          None if a1 is None else a1.ctypes.data, float(scale)))
         self._target_kind = int(kind)
+
+    def set_target_callback(self, fn):
+        """``fn(q) -> log_prob`` on device memory (include/emx.h, emx_set_target_callback): ``q`` is a float64 CUDA tensor
+        ``(n, ndim)`` viewing the library's proposal block, the result a length-n float64 CUDA tensor (anything
+        ``torch.as_tensor`` takes from the device).  Called once per half-step on the host thread that drives the run; its
+        work is enqueued on the context's stream, nothing is synchronised and nothing crosses PCIe."""
+        import torch
+        from .parallel import _DevView
+        streams = {}
+
+        def tramp(user, q_ptr, n, ndim, lp_ptr, stream):
+            try:
+                s = streams.get(stream)
+                if s is None:
+                    s = streams[stream] = torch.cuda.ExternalStream(stream or 0) if stream else torch.cuda.default_stream()
+                dev = torch.device("cuda", torch.cuda.current_device())
+                with torch.cuda.stream(s):
+                    q = torch.as_tensor(_DevView(q_ptr, n * ndim), device=dev).view(n, ndim)
+                    out = torch.as_tensor(_DevView(lp_ptr, n), device=dev)
+                    res = fn(q)
+                    res = torch.as_tensor(res, dtype=torch.float64, device=dev).reshape(-1)
+                    if res.numel() != n:
+                        raise ValueError("the device log_prob_fn returned %d values for %d walkers" % (res.numel(), n))
+                    out.copy_(res)
+                return 0
+            except BaseException as e:  # noqa: BLE001  (handed to the caller by _ck)
+                self._cb_exc = e
+                return -1
+
+        self._cb_keep = _lib.DEVICE_LOG_PROB_FN(tramp)          # the library holds the pointer: keep the object alive
+        self._ck(self.lib.emx_set_target_callback(self.ctx, self._cb_keep, None))
+        self._target_kind = _lib.TARGET_CALLBACK
 
     def eval_state_log_prob(self):
         self._touch()

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["DeviceTarget", "IsoGaussian", "DiagGaussian", "DenseGaussian", "Rosenbrock", "UniformBox"]
+__all__ = ["DeviceTarget", "IsoGaussian", "DiagGaussian", "DenseGaussian", "Rosenbrock", "UniformBox", "DeviceCallable"]
 
 
 class DeviceTarget(object):
@@ -104,3 +104,30 @@ class Rosenbrock(DeviceTarget):
 class UniformBox(DeviceTarget):
     """0 inside [0, 1]^ndim, -inf outside   (reference test_proposal.py:25-28)."""
     kind = _lib.TARGET_BOX
+
+
+class DeviceCallable(DeviceTarget):
+    """A user's vectorised ``log_prob_fn`` that runs on the GPU: ``fn(q)`` receives the ``(n, ndim)`` block of a split's
+    proposals as a float64 CUDA tensor -- a zero-copy view of the library's buffer, rows in the order the reference passes them
+    (``ensemble.py:486-487``, called at ``red_blue.py:93``) -- and returns their ``n`` log-probabilities as a CUDA tensor.
+    Nothing crosses PCIe and nothing synchronises per split: the proposal kernel, ``fn``'s kernels and the accept / commit kernel
+    are enqueued on one stream, and ``run_mcmc`` stays one native call.  ``-inf`` is legal; NaN raises the reference's error.
+    Blobs are not supported on this path (use an ordinary callable).
+
+        mu_t, icov_t = torch.as_tensor(mu).cuda(), torch.as_tensor(icov).cuda()
+        def log_prob(q):                       # q: torch.float64 (n, ndim) on the GPU
+            d = q - mu_t
+            return -0.5 * ((d @ icov_t) * d).sum(1)
+        sampler = EnsembleSampler(nwalkers, ndim, DeviceCallable(log_prob))
+    """
+    kind = _lib.TARGET_CALLBACK
+
+    def __init__(self, fn):
+        if not callable(fn):
+            raise TypeError("DeviceCallable needs a callable")
+        self.fn = fn
+
+    def bind(self, ens):
+        if getattr(ens, "_cb_owner", None) is not self:
+            ens.set_target_callback(self.fn)
+            ens._cb_owner = self

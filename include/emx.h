@@ -29,7 +29,8 @@ enum emx_target_kind {
     EMX_TARGET_DIAG_GAUSS = 2, /* -0.5 sum ivar (x-mu)^2  docs/index.rst:41-45                 */
     EMX_TARGET_DENSE_GAUSS = 3,/* -0.5 (x-mu)^T icov (x-mu)  docs/tutorials/quickstart.ipynb:76 */
     EMX_TARGET_ROSENBROCK = 4, /* -sum[100 (x_{i+1}-x_i^2)^2 + (1-x_i)^2] / scale (BASELINE C3) */
-    EMX_TARGET_BOX = 5         /* 0 inside [0,1]^D else -inf   test_proposal.py:25-28           */
+    EMX_TARGET_BOX = 5,        /* 0 inside [0,1]^D else -inf   test_proposal.py:25-28           */
+    EMX_TARGET_DEVICE_CALLBACK = 6 /* the caller's batched log-prob on device buffers (emx_set_target_callback) */
 };
 
 enum emx_move_kind {
@@ -98,6 +99,17 @@ int emx_snapshot_save(emx_ctx* ctx, int32_t slot);
 int emx_snapshot_read(emx_ctx* ctx, int32_t slot, double* coords /* or NULL */, double* log_prob /* or NULL */);
 int emx_snapshot_restore(emx_ctx* ctx, int32_t slot);
 int emx_snapshot_free(emx_ctx* ctx, int32_t slot);
+
+/* The caller's own batched log-prob, on device memory: the reference's vectorize=True contract -- ONE call of log_prob_fn on the
+ * (Ns, ndim) block of a split's proposals (ensemble.py:486-487, called at red_blue.py:93) -- without the block or the result
+ * leaving HBM.  The function is called on the host thread that drives the step; it must ENQUEUE work on `hip_stream` (a kernel
+ * launch, a library call) that reads the n rows of coords_dev (row-major, ndim doubles each, in the order the reference passes
+ * them: ascending walker index within the split) and writes n log-probabilities to log_prob_dev, and return 0 (non-zero aborts
+ * the step with an error).  It must not synchronise.  -inf is a legal value, NaN raises the reference's error.  Replaces the
+ * closed-form target: emx_run, emx_halfstep, emx_eval_log_prob and the all-gather / log-prob / replay exchanges work over it. */
+typedef int (*emx_device_log_prob_fn)(void* user, const double* coords_dev, int64_t n, int32_t ndim, double* log_prob_dev,
+                                      void* hip_stream);
+int emx_set_target_callback(emx_ctx* ctx, emx_device_log_prob_fn fn, void* user);
 
 /* ---- target: the batched log-prob (ensemble.py:458-553, vectorised) -------------------- */
 /* p0/p1: DIAG (mu, ivar); DENSE (mu, icov[D*D], symmetric positive definite: factored once as

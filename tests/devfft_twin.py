@@ -55,7 +55,7 @@ def mean_acf(ens, nstored, discard=0, thin=1, max_bytes=8 << 30):
 
 def integrated_time_device(ens, nstored, discard=0, thin=1, c=5, tol=50, quiet=False):
     """Same return value / errors as ``autocorr.integrated_time`` for the device-resident chain."""
-    from . import autocorr
+    from emcee_amd import autocorr
     f = mean_acf(ens, nstored, discard=discard, thin=thin)
     n_t, n_d = f.shape
     tau_est = np.empty(n_d)

@@ -1,0 +1,135 @@
+"""A user's log_prob_fn that runs ON the GPU (targets.DeviceCallable / emx_set_target_callback): the reference's vectorize=True
+contract -- one call on the (Ns, ndim) block of a split's proposals, ensemble.py:486-487 -- without a PCIe hop or a host
+synchronisation per split.  Pinned to the reference: torch re-statements of the fixture targets reproduce the golden chains."""
+import time
+
+import numpy as np
+import pytest
+
+import emcee_amd
+from emcee_amd import targets
+from oracle import cases
+
+from helpers import load_golden
+from test_gpu_sampler_api import make_sampler
+
+pytestmark = pytest.mark.gpu
+
+
+def torch_target(desc):
+    import torch
+    dev = torch.device("cuda", 0)
+    k = desc["kind"]
+    if k == "iso":
+        return lambda q: -0.5 * (q * q).sum(1)
+    if k == "dense":
+        mu, icov = torch.as_tensor(desc["mu"], device=dev), torch.as_tensor(desc["icov"], device=dev)
+
+        def dense(q):
+            d = q - mu
+            return -0.5 * ((d @ icov) * d).sum(1)
+        return dense
+    if k == "rosenbrock":
+        return lambda q: -(100.0 * (q[:, 1:] - q[:, :-1] ** 2) ** 2 + (1.0 - q[:, :-1]) ** 2).sum(1) / 20.0
+    if k == "box":
+        return lambda q: torch.where(((q > 1) | (q < 0)).any(1), -float("inf"), 0.0).to(torch.float64)
+    raise ValueError(k)
+
+
+@pytest.mark.parametrize("name", ["c1_stretch_32x5_iso", "stretch_50x3_iso", "stretch_128x64_dense", "stretch_256x16_dense",
+                                  "stretch_128x8_rosen", "stretch_box_32x1", "mix_stretch_de_64x5", "stretch_nsplits3_45x2",
+                                  "mix_de_snooker_128x8_dense", "stretch_thin3_32x2"])
+def test_device_callable_reproduces_the_reference_chain(name):
+    g = load_golden(name)
+    spec = cases.build(name)
+    fn = torch_target(spec["desc"])
+    calls = {"n": 0, "rows": 0, "cuda": True}
+
+    def counted(q):
+        calls["n"] += 1
+        calls["rows"] += q.shape[0]
+        calls["cuda"] &= bool(q.is_cuda) and q.dtype.is_floating_point and q.shape[1] == spec["D"]
+        return fn(q)
+
+    s = make_sampler(spec, g, log_prob=targets.DeviceCallable(counted))
+    s.run_mcmc(g["p0"], spec["nsteps"], thin_by=spec["thin_by"], skip_initial_state_check=True)
+    assert calls["cuda"]
+    # the same accept decisions: identical accept counts, a row differs from the reference only through rounding of its own
+    # log-prob (which never enters the coordinates): coordinates bit-identical for stretch / DE
+    assert np.array_equal(s.backend.accepted, g["accepted_count"])
+    if "snooker" in name:
+        np.testing.assert_allclose(s.get_chain(), g["chain"], rtol=1e-9, atol=1e-10)
+    else:
+        assert np.array_equal(s.get_chain(), g["chain"])
+    np.testing.assert_allclose(s.get_log_prob(), g["log_prob"], rtol=1e-11, atol=1e-13)
+    st = s.random_state
+    assert np.array_equal(st[1], g["rng_key1"]) and st[2] == int(g["rng_pos1"])
+    # one call per split (+ one for the initial state), every proposal exactly once
+    nprop = spec["nsteps"] * spec["thin_by"]
+    assert calls["rows"] == spec["N"] * (nprop + 1)
+
+
+def test_device_callable_errors_and_generator_path():
+    import torch
+    p0 = np.random.RandomState(2).randn(64, 3)
+
+    def boom(q):
+        raise KeyError("user bug")
+
+    s = emcee_amd.EnsembleSampler(64, 3, targets.DeviceCallable(boom))
+    with pytest.raises(KeyError):                      # the caller's own exception, not an EmxError
+        s.run_mcmc(p0, 3)
+
+    nanny = emcee_amd.EnsembleSampler(64, 3, targets.DeviceCallable(lambda q: torch.full((q.shape[0],), float("nan"), device=q.device,
+                                                                                           dtype=torch.float64)))
+    with pytest.raises(ValueError):                    # ensemble.py:550-551
+        nanny.run_mcmc(p0, 3)
+
+    short = emcee_amd.EnsembleSampler(64, 3, targets.DeviceCallable(lambda q: q[:5, 0]))
+    with pytest.raises(ValueError):
+        short.run_mcmc(p0, 3)
+
+    # the sample() generator and compute_log_prob go through the same callback
+    iso = targets.DeviceCallable(lambda q: -0.5 * (q * q).sum(1))
+    a = emcee_amd.EnsembleSampler(64, 3, iso)
+    a._random.seed(9)
+    for _ in a.sample(p0, iterations=5):
+        pass
+    b = emcee_amd.EnsembleSampler(64, 3, targets.IsoGaussian())
+    b._random.seed(9)
+    b.run_mcmc(p0, 5)
+    assert np.array_equal(a.get_chain(), b.get_chain())
+    lp, blobs = a.compute_log_prob(p0)
+    np.testing.assert_allclose(lp, -0.5 * (p0 ** 2).sum(1), rtol=1e-13)
+    assert blobs is None
+
+
+def test_device_callable_at_the_headline_size_is_a_device_path():
+    """C2's shape through a torch log_prob_fn: the callable stays within a small factor of the fused target because nothing
+    crosses PCIe (the split-phase path moves 2 x 16.8 MB per step and synchronises twice)."""
+    import torch
+    from bench import dense_gaussian
+    N, D = 65536, 64
+    mu, cov, icov = dense_gaussian(D)
+    p0 = mu + np.random.RandomState(1).randn(N, D) @ np.linalg.cholesky(cov).T
+    dev = torch.device("cuda", 0)
+    mu_t, icov_t = torch.as_tensor(mu, device=dev), torch.as_tensor(icov, device=dev)
+
+    def lp(q):
+        d = q - mu_t
+        return -0.5 * ((d @ icov_t) * d).sum(1)
+
+    out = {}
+    for label, target in (("fused", targets.DenseGaussian(mu, icov)), ("callable", targets.DeviceCallable(lp))):
+        s = emcee_amd.EnsembleSampler(N, D, target, rng="philox")
+        s._random.seed(3)
+        st = s.run_mcmc(p0, 20, store=False, skip_initial_state_check=True)
+        t0 = time.perf_counter()
+        st = s.run_mcmc(st, 200, store=False, skip_initial_state_check=True)
+        st.coords                                    # wait for the device
+        out[label] = ((time.perf_counter() - t0) / 200, st)
+    # same seed, same plan, same decisions up to the rounding of the log-prob: the ensembles agree almost everywhere
+    same = np.mean(np.all(out["fused"][1].coords == out["callable"][1].coords, axis=1))
+    assert same > 0.99, same
+    print("us/step: fused %.1f, device callable %.1f" % (out["fused"][0] * 1e6, out["callable"][0] * 1e6))
+    assert out["callable"][0] < 6 * out["fused"][0]
