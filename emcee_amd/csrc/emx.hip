@@ -352,7 +352,6 @@ struct emx_ctx {
     int ring_pos = 0;
     struct Prepared {   // native plans already evaluated on the device, in step order
         int move, S, slot;
-        hipEvent_t wait_ev; // first step of a batch evaluated on the side stream: the main stream waits for this before using it
         bool lean;          // only the columns the fused half-step reads were written
         int gcol;           // Gaussian sequential mode: the coordinate this step moves
         uint64_t step;
@@ -435,10 +434,6 @@ struct emx_ctx {
     bool graph_warm = false;         // one ordinary step has run (function attributes set, kernels loaded)
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
-    hipStream_t plan_stream = nullptr;        // native plans one batch ahead, next to the half-steps (tuning "plan_stream")
-    hipEvent_t plan_ev[3] = {nullptr, nullptr, nullptr};     // [0], [1]: batch evaluated (alternating); [2]: main-stream mark
-    int plan_ev_pos = 0;
-    int64_t tune_plan_stream = getenv("EMX_PLAN_STREAM") ? atoi(getenv("EMX_PLAN_STREAM")) : 0;
     int64_t tune_full_plan = 0;      // 1: native plans always carry every column
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
     // timing
@@ -607,7 +602,7 @@ size_t dense_lds_bytes(int Dp, int waves) {
 int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
     const int WPW = 64 / G;
     const int nr = (move == MOVE_STRETCH || move == MOVE_GAUSS) ? 2 : move == MOVE_DE ? 3 : move == MOVE_SNOOKER ? 4 : 1;
-    int pf = (move == MOVE_SNOOKER ? 64 : 48) / (nr * CH * V);      // prefetch_depth in emx_kernels.hpp
+    int pf = (move == MOVE_SNOOKER ? EMX_SNOOKER_BUDGET : 48) / (nr * CH * V);      // prefetch_depth in emx_kernels.hpp
     pf = pf < 1 ? 1 : (pf > 8 ? 8 : pf);
     int p2 = 1;
     while (p2 * 2 <= pf) p2 *= 2;
@@ -820,7 +815,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.spw = (int32_t)spw;
     a.target = target;
     a.Dp = dense ? c->Dp : 16;
-    a.ablate = (int32_t)c->tune_ablate;
+    a.ablate = (int32_t)(c->tune_ablate & 0xff);          // (bits 8.. are the plan kernel's)
     a.desc = step_desc;
     a.chain_all = c->chain;
     a.chain_lp_all = c->chain_lp;
@@ -1049,12 +1044,7 @@ int emx_destroy(emx_ctx* c) {
         if (p) hipFree(p);
     for (double* s : c->snap)
         if (s) hipFree(s);
-    if (c->plan_stream) {
-        hipStreamSynchronize(c->plan_stream);
-        hipStreamDestroy(c->plan_stream);
-        for (auto e : c->plan_ev)
-            if (e) hipEventDestroy(e);
-    }
+
     for (auto& s : c->ring) {
         if (s.order) hipFree(s.order);       // the slot's single block
         if (s.host) hipHostFree(s.host);
@@ -1212,11 +1202,6 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "dense_wide")) {      // 1: take the wide-target path (emx_wide.hip) whatever the ndim -- parity tests against the fused kernel
         c->tune_dense_wide = v == 2 ? 2 : (v ? 1 : 0);      // 2: the wide path with the single-role log-prob kernel only
         graph_invalidate(c);
-        return 0;
-    }
-    if (!strcmp(key, "plan_stream")) {   // 1: native plans one batch ahead on a second stream
-        drop_prepared(c);
-        c->tune_plan_stream = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "full_plan")) {     // 1: native plans with every column (default 0: what the fused kernel reads)
@@ -1858,7 +1843,9 @@ int emx_step_begin_with(emx_ctx* c, int32_t store, int32_t move_index, int32_t* 
 }
 
 // Native (Philox) plans of `nb` consecutive steps from `first_step`, evaluated full width by ONE launch on stream `st`, appended
-// to c->prepared in step order.
+// to c->prepared in step order.  (Measured and dropped, rounds 2 and 3: the NEXT batch on a second, low-priority stream next to
+// this batch's half-steps, with and without raised wave priority for the half-step kernel -- the co-resident plan waves slow
+// every half-step launch by 0.8 us: C2 23.69 -> 24.40 us/step, C3 38.65 -> 39.5; profiles/r03/ab_side_stream.txt.)
 static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int forced_move, hipStream_t st) {
     const int nm = (int)c->moves.size();
     NativeBatchArgs B{};
@@ -1867,6 +1854,7 @@ static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int for
     B.nb = nb;
     // single replica, fused device target: nobody but the half-step kernel reads these plans
     B.lean = (c->target != EMX_TARGET_HOST && c->world == 1 && !c->sendbuf && !c->comm && !c->tune_full_plan) ? 1 : 0;
+    B.ablate = (int32_t)(c->tune_ablate >> 8);
     for (int b = 0; b < nb; ++b) {
         const uint64_t step = first_step + (uint64_t)b;
         const int mi = forced_move >= 0 ? forced_move : philox_move_choice(c->ph_seed, step, c->cdf.data(), nm);
@@ -1884,7 +1872,6 @@ static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int for
         pr.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, step);
         pr.cursor_before = m.gammas;
         pr.lean = B.lean != 0;
-        pr.wait_ev = nullptr;
         if (m.kind == EMX_MOVE_GAUSS) {
             B.gmode[b] = m.reserved;
             B.gcol[b] = (int32_t)((int64_t)m.gammas % c->D);
@@ -1977,28 +1964,6 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         }
         const emx_ctx::Prepared pr = c->prepared.front();
         c->prepared.pop_front();
-        if (pr.wait_ev) HIPOK(c, hipStreamWaitEvent(c->stream, pr.wait_ev, 0));      // first step of a batch made on the side stream
-        if (c->tune_plan_stream && forced_move < 0 && (int)c->prepared.size() < NATIVE_BATCH_MAX && c->world == 1 && !c->comm) {
-            // Stay one batch ahead, off the critical path: the plans do not depend on the walkers, so the NEXT batch is evaluated
-            // on a second stream while this batch's half-steps run (which raise their waves' issue priority: the plan kernel is
-            // bound by its instruction count and fills the issue slots the latency-bound half-step leaves empty).  It goes into
-            // the ring half whose steps were all enqueued before this point: the side stream waits for the main stream to get here.
-            if (!c->plan_stream) {
-                int lo = 0, hi = 0;
-                HIPOK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));          // lo: the least urgent
-                HIPOK(c, hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, lo));
-                for (auto& e : c->plan_ev) HIPOK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
-            const uint64_t next = c->prepared.empty() ? pr.step + 1 : c->prepared.back().step + 1;
-            HIPOK(c, hipEventRecord(c->plan_ev[2], c->stream));
-            HIPOK(c, hipStreamWaitEvent(c->plan_stream, c->plan_ev[2], 0));
-            const size_t at = c->prepared.size();
-            const int rc = native_prepare_batch(c, next, NATIVE_BATCH_MAX, -1, c->plan_stream);
-            if (rc) return rc;
-            hipEvent_t done = c->plan_ev[c->plan_ev_pos ^= 1];
-            HIPOK(c, hipEventRecord(done, c->plan_stream));
-            c->prepared[at].wait_ev = done;
-        }
         cur.move = pr.move;
         cur.S = pr.S;
         cur.native = true;

@@ -46,8 +46,8 @@
 #ifndef EMX_OPT_SKEW
 #define EMX_OPT_SKEW 1        // dense target, 8-wave workgroups: the upper four waves stage the whole LDS image before they issue
 #endif                        // their row loads, so the two waves of a SIMD run out of phase (loads first for the lower four)
-#ifndef EMX_OPT_SETPRIO
-#define EMX_OPT_SETPRIO 2     // wave issue priority of the half-step kernel (0: leave the default)
+#ifndef EMX_SNOOKER_BUDGET
+#define EMX_SNOOKER_BUDGET 64  // doubles of rows in flight per lane for the snooker move (48: the other moves' budget)
 #endif
 #ifndef EMX_OPT_STAMPS
 #define EMX_OPT_STAMPS 0      // phase timestamps (tools/phase_clock.py builds its own copy with -DEMX_OPT_STAMPS=1: they cost 1 %)
@@ -58,7 +58,7 @@ namespace emx {
 enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_GAUSS = 3, MOVE_EVAL = 4 };
 enum : int { GAUSS_VECTOR = 0, GAUSS_RANDOM = 1, GAUSS_SEQUENTIAL = 2 };
 enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5,
-             TGT_REPLAY = 6 };     // replay exchange: no target, no decision -- the slot is a peer's ACCEPTED update, its new log-prob comes with the plan
+             TGT_REPLAY = 7 };      // (6 is EMX_TARGET_DEVICE_CALLBACK, a host-side three-pass target: never a kernel's)     // replay exchange: no target, no decision -- the slot is a peer's ACCEPTED update, its new log-prob comes with the plan
 enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u, ST_EXCHANGE_TIMEOUT = 8u };
 constexpr int EMX_MAX_PEERS = 8;       // direct exchange: GPUs of one node
 
@@ -510,7 +510,7 @@ constexpr int prefetch_depth() {
     // <= 48 doubles of rows in flight per lane -- 64 for the snooker move, whose four rows per walker would otherwise split a
     // 16-row MFMA tile at ndim 64 into two DEPENDENT memory round trips (its quarter-ensemble launches run one wave per SIMD:
     // registers are not what they are short of)
-    int pf = (MOVE == MOVE_SNOOKER ? 64 : 48) / (rows_per_pass<MOVE>() * CH * V);
+    int pf = (MOVE == MOVE_SNOOKER ? EMX_SNOOKER_BUDGET : 48) / (rows_per_pass<MOVE>() * CH * V);
     pf = pf < 1 ? 1 : (pf > 8 ? 8 : pf);
     int p2 = 1;
     while (p2 * 2 <= pf) p2 *= 2;
@@ -632,11 +632,13 @@ __device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row
             }
         const double norm = sqrt(group_sum<G>(n2));
         double d1 = 0.0, d2 = 0.0;
+        Row<G, V, CH> uu;                                    // u = delta / norm, computed once (de_snooker.py:42)
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const double u = (xi.x[c][v] - xa.x[c][v]) / norm;
+                uu.x[c][v] = u;
                 d1 = fma(u, xb.x[c][v], d1);
                 d2 = fma(u, xc.x[c][v], d2);
             }
@@ -648,7 +650,7 @@ __device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                const double u = (xi.x[c][v] - xa.x[c][v]) / norm;
+                const double u = uu.x[c][v];
                 const double ug = u * gammas;                   // u * gammas
                 const double prod = ug * dd;                    // * (dot(u,z1) - dot(u,z2))
                 const int d = (c * G + gl) * V + v;
@@ -692,11 +694,6 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     static_assert(!DENSE || G * V * CH >= Dp, "row layout must cover the padded dimension");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (ablate_ & 64) return;     // timing experiments: launch + dispatch floor
-#if EMX_OPT_SETPRIO
-    // the half-step is on the step's critical path and latency-bound (it issues in ~20 % of its cycles); whatever else shares the
-    // SIMD -- the next batch's plan kernel on the side stream -- takes the issue slots that are left
-    __builtin_amdgcn_s_setprio(EMX_OPT_SETPRIO);
-#endif
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int sub = lane / G;
@@ -1621,13 +1618,14 @@ struct NativeBatchArgs {
     int32_t gmode[NATIVE_BATCH_MAX], gcol[NATIVE_BATCH_MAX];   // Gaussian move: mode, the sequential mode's column
     int32_t N, D, nb;
     int32_t lean;           // 1: only the columns the fused half-step kernel of the step's move reads are written (below)
+    int32_t ablate;         // timing experiments only (tuning "ablate" bits 8..): 1 no logs, 2 no stores, 4 return at once; 0 in production
     const StepDesc* desc;   // graph replay: per-step NativeArgs from device memory instead of nat[]
 };
 
 static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs B) {
     const int b = blockIdx.y;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= B.N) return;
+    if (pos >= B.N || (B.ablate & 4)) return;
     const int N = B.N, S = B.S[b];
     int split = 0, t = pos;
     for (int s = 0; s < S; ++s) {
@@ -1653,6 +1651,18 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
     // unwritten: 32 instead of 48 bytes per entry for the stretch move.  Whoever wants them (emx_plan_get: the parity tests; the
     // split-phase and sharded paths) gets a full plan.
     const bool full = !B.lean;
+    if (B.ablate & 2) {                                  // timing experiments: keep the arithmetic alive, write one word
+        if (i + a0 + a1 + a2 == -12345 && z + u == 1.2345e-300) B.order[b][pos] = i;
+        return;
+    }
+    if (B.ablate & 1) {
+        B.order[b][pos] = i;
+        B.p0[b][pos] = a0;
+        B.s0[b][pos] = z;
+        B.logu[b][pos] = u;
+        B.fac[b][pos] = z;
+        return;
+    }
     B.order[b][pos] = i;
     B.p0[b][pos] = a0;
     if (full || mv == MOVE_DE || mv == MOVE_SNOOKER) B.p1[b][pos] = a1;
