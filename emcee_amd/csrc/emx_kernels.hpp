@@ -47,7 +47,7 @@
 #define EMX_OPT_SKEW 1        // dense target, 8-wave workgroups: the upper four waves stage the whole LDS image before they issue
 #endif                        // their row loads, so the two waves of a SIMD run out of phase (loads first for the lower four)
 #ifndef EMX_SNOOKER_BUDGET
-#define EMX_SNOOKER_BUDGET 64  // doubles of rows in flight per lane for the snooker move (48: the other moves' budget)
+#define EMX_SNOOKER_BUDGET 48  // doubles of rows in flight per lane for the snooker move (64 measured slower, see prefetch_depth)
 #endif
 #ifndef EMX_OPT_STAMPS
 #define EMX_OPT_STAMPS 0      // phase timestamps (tools/phase_clock.py builds its own copy with -DEMX_OPT_STAMPS=1: they cost 1 %)
@@ -507,9 +507,9 @@ constexpr int rows_per_pass() {
 template <int G, int V, int CH, int MOVE, int DPB>
 constexpr int prefetch_depth() {
     constexpr int WPW = 64 / G;
-    // <= 48 doubles of rows in flight per lane -- 64 for the snooker move, whose four rows per walker would otherwise split a
-    // 16-row MFMA tile at ndim 64 into two DEPENDENT memory round trips (its quarter-ensemble launches run one wave per SIMD:
-    // registers are not what they are short of)
+    // <= 48 doubles of rows in flight per lane.  (Round 3: 64 for the snooker move -- whose four rows per walker split a 16-row
+    // MFMA tile at ndim 64 into two dependent memory round trips -- was measured: one round trip, but 254 VGPRs and a spill,
+    // C4 33.55 -> 34.15 us/step; profiles/r03/ab_snooker_budget.txt.  EMX_SNOOKER_BUDGET stays for the record.)
     int pf = (MOVE == MOVE_SNOOKER ? EMX_SNOOKER_BUDGET : 48) / (rows_per_pass<MOVE>() * CH * V);
     pf = pf < 1 ? 1 : (pf > 8 ? 8 : pf);
     int p2 = 1;

@@ -145,7 +145,7 @@ class DeviceEnsemble:
                                          None if a1 is None else a1.ctypes.data, float(scale)))
         self._target_kind = int(kind)
 
-    def set_target_callback(self, fn):
+    def set_target_callback(self, fn, graph=False):
         """``fn(q) -> log_prob`` on device memory (include/emx.h, emx_set_target_callback): ``q`` is a float64 CUDA tensor
         ``(n, ndim)`` viewing the library's proposal block, the result a length-n float64 CUDA tensor (anything
         ``torch.as_tensor`` takes from the device).  Called once per half-step on the host thread that drives the run; its
@@ -153,6 +153,16 @@ class DeviceEnsemble:
         import torch
         from .parallel import _DevView
         streams = {}
+        graphs = self._cb_graphs = {}   # graph=True: (block address, rows, result address) -> [eager calls so far, graph or False]
+
+        def eager(q_ptr, n, ndim, lp_ptr, dev):
+            q = torch.as_tensor(_DevView(q_ptr, n * ndim), device=dev).view(n, ndim)
+            out = torch.as_tensor(_DevView(lp_ptr, n), device=dev)
+            res = fn(q)
+            res = torch.as_tensor(res, dtype=torch.float64, device=dev).reshape(-1)
+            if res.numel() != n:
+                raise ValueError("the device log_prob_fn returned %d values for %d walkers" % (res.numel(), n))
+            out.copy_(res)
 
         def tramp(user, q_ptr, n, ndim, lp_ptr, stream):
             try:
@@ -161,13 +171,27 @@ class DeviceEnsemble:
                     s = streams[stream] = torch.cuda.ExternalStream(stream or 0) if stream else torch.cuda.default_stream()
                 dev = torch.device("cuda", torch.cuda.current_device())
                 with torch.cuda.stream(s):
-                    q = torch.as_tensor(_DevView(q_ptr, n * ndim), device=dev).view(n, ndim)
-                    out = torch.as_tensor(_DevView(lp_ptr, n), device=dev)
-                    res = fn(q)
-                    res = torch.as_tensor(res, dtype=torch.float64, device=dev).reshape(-1)
-                    if res.numel() != n:
-                        raise ValueError("the device log_prob_fn returned %d values for %d walkers" % (res.numel(), n))
-                    out.copy_(res)
+                    if not graph:
+                        eager(q_ptr, n, ndim, lp_ptr, dev)
+                        return 0
+                    # The library hands every split the same buffers, so the kernels fn launches for a given (block, rows) are
+                    # the same every time: after two eager calls they are captured once and replayed -- one graph launch per
+                    # split instead of one Python dispatch per torch operation.
+                    key = (q_ptr, n, lp_ptr)
+                    ent = graphs.setdefault(key, [0, None])
+                    if ent[1]:
+                        ent[1].replay()
+                        return 0
+                    eager(q_ptr, n, ndim, lp_ptr, dev)
+                    ent[0] += 1
+                    if ent[1] is None and ent[0] == 2:
+                        try:
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g):
+                                eager(q_ptr, n, ndim, lp_ptr, dev)
+                            ent[1] = g
+                        except Exception:  # noqa: BLE001  (capture unsupported for what fn does: stay eager)
+                            ent[1] = False
                 return 0
             except BaseException as e:  # noqa: BLE001  (handed to the caller by _ck)
                 self._cb_exc = e
@@ -175,6 +199,14 @@ class DeviceEnsemble:
 
         self._cb_keep = _lib.DEVICE_LOG_PROB_FN(tramp)          # the library holds the pointer: keep the object alive
         self._ck(self.lib.emx_set_target_callback(self.ctx, self._cb_keep, None))
+        self._target_kind = _lib.TARGET_CALLBACK
+
+    def set_target_callback_c(self, fn_ptr, user_ptr=None):
+        """A native ``emx_device_log_prob_fn`` (include/emx.h) -- e.g. a function of the user's own shared library that launches
+        a HIP kernel -- as the target: ``fn_ptr`` a ctypes function pointer or address, ``user_ptr`` its opaque argument."""
+        fn = fn_ptr if isinstance(fn_ptr, _lib.DEVICE_LOG_PROB_FN) else C.cast(fn_ptr, _lib.DEVICE_LOG_PROB_FN)
+        self._cb_keep = fn
+        self._ck(self.lib.emx_set_target_callback(self.ctx, fn, C.c_void_p(user_ptr) if not isinstance(user_ptr, C.c_void_p) else user_ptr))
         self._target_kind = _lib.TARGET_CALLBACK
 
     def eval_state_log_prob(self):

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["DeviceTarget", "IsoGaussian", "DiagGaussian", "DenseGaussian", "Rosenbrock", "UniformBox", "DeviceCallable"]
+__all__ = ["DeviceTarget", "IsoGaussian", "DiagGaussian", "DenseGaussian", "Rosenbrock", "UniformBox", "DeviceCallable", "DeviceKernel"]
 
 
 class DeviceTarget(object):
@@ -122,12 +122,30 @@ class DeviceCallable(DeviceTarget):
     """
     kind = _lib.TARGET_CALLBACK
 
-    def __init__(self, fn):
+    def __init__(self, fn, graph=False):
+        """``graph=True``: after two eager calls per split shape the kernels ``fn`` launches are captured in a HIP graph and
+        replayed (``fn`` must then be a pure function of its argument: same operations, same shapes every call)."""
         if not callable(fn):
             raise TypeError("DeviceCallable needs a callable")
         self.fn = fn
+        self.graph = bool(graph)
 
     def bind(self, ens):
         if getattr(ens, "_cb_owner", None) is not self:
-            ens.set_target_callback(self.fn)
+            ens.set_target_callback(self.fn, graph=self.graph)
+            ens._cb_owner = self
+
+
+class DeviceKernel(DeviceTarget):
+    """A native log-probability: a C function with the signature ``emx_device_log_prob_fn`` of ``include/emx.h`` (typically one
+    that launches the user's own HIP kernel on the stream it is handed) and its opaque ``user`` pointer.  The whole step stays
+    three kernel launches per split -- proposal, the user's kernel, accept / commit -- with no Python in between."""
+    kind = _lib.TARGET_CALLBACK
+
+    def __init__(self, fn_ptr, user_ptr=None):
+        self.fn_ptr, self.user_ptr = fn_ptr, user_ptr
+
+    def bind(self, ens):
+        if getattr(ens, "_cb_owner", None) is not self:
+            ens.set_target_callback_c(self.fn_ptr, self.user_ptr)
             ens._cb_owner = self

@@ -69,6 +69,20 @@ def test_device_callable_reproduces_the_reference_chain(name):
     assert calls["rows"] == spec["N"] * (nprop + 1)
 
 
+@pytest.mark.parametrize("name", ["stretch_256x16_dense", "mix_stretch_de_64x5"])
+def test_device_callable_with_graph_capture(name):
+    """graph=True: the kernels the callable launches are captured after two eager calls per split shape and replayed"""
+    g = load_golden(name)
+    spec = cases.build(name)
+    s = make_sampler(spec, g, log_prob=targets.DeviceCallable(torch_target(spec["desc"]), graph=True))
+    s.run_mcmc(g["p0"], spec["nsteps"], skip_initial_state_check=True)
+    assert np.array_equal(s.backend.accepted, g["accepted_count"])
+    assert np.array_equal(s.get_chain(), g["chain"])
+    np.testing.assert_allclose(s.get_log_prob(), g["log_prob"], rtol=1e-11, atol=1e-13)
+    captured = [e[1] for e in s._ens._cb_graphs.values()]
+    assert captured and all(c is not None for c in captured)          # captured (a graph) or refused once (False), never pending
+
+
 def test_device_callable_errors_and_generator_path():
     import torch
     p0 = np.random.RandomState(2).randn(64, 3)
@@ -133,3 +147,72 @@ def test_device_callable_at_the_headline_size_is_a_device_path():
     assert same > 0.99, same
     print("us/step: fused %.1f, device callable %.1f" % (out["fused"][0] * 1e6, out["callable"][0] * 1e6))
     assert out["callable"][0] < 6 * out["fused"][0]
+
+
+def _build_user_lib(tmp_path):
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c", "user_logprob.hip")
+    so = str(tmp_path / "libuser_logprob.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", src, "-o", so], check=True, timeout=600,
+                   capture_output=True)
+    from emcee_amd import _lib
+    _lib.load()                                  # one HIP runtime per process: the library's (torch's) first
+    user = C.CDLL(so)
+    user.user_setup.restype = C.c_void_p
+    user.user_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    user.user_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    user.user_teardown.argtypes = [C.c_void_p]
+    return user
+
+
+def test_a_users_hip_kernel_through_the_c_abi(tmp_path):
+    """The drop-in boundary for a likelihood that lives on the GPU: a user's shared library exports an emx_device_log_prob_fn
+    that launches its own HIP kernel; libemx calls it between the proposal and the accept kernel of every split.  The reference
+    fixture is reproduced, and at the headline size the step is three launches per split."""
+    import ctypes as C
+    user = _build_user_lib(tmp_path)
+    name = "stretch_128x64_dense"
+    g = load_golden(name)
+    spec = cases.build(name)
+    mu = np.ascontiguousarray(spec["desc"]["mu"])
+    icov = np.ascontiguousarray(spec["desc"]["icov"])
+    h = user.user_setup(mu.ctypes.data, icov.ctypes.data, 64)
+    assert h
+    s = make_sampler(spec, g, log_prob=targets.DeviceKernel(user.user_log_prob, h))
+    s.run_mcmc(g["p0"], spec["nsteps"], skip_initial_state_check=True)
+    assert np.array_equal(s.backend.accepted, g["accepted_count"])
+    assert np.array_equal(s.get_chain(), g["chain"])
+    np.testing.assert_allclose(s.get_log_prob(), g["log_prob"], rtol=1e-11)
+    calls, rows = C.c_longlong(), C.c_longlong()
+    user.user_stats(h, C.byref(calls), C.byref(rows))
+    assert rows.value == spec["N"] * (spec["nsteps"] + 1) and calls.value == 2 * spec["nsteps"] + 1
+    user.user_teardown(h)
+
+    # headline size: fused target against the user's kernel
+    from bench import dense_gaussian
+    N, D = 65536, 64
+    mu, cov, icov = dense_gaussian(D)
+    p0 = mu + np.random.RandomState(1).randn(N, D) @ np.linalg.cholesky(cov).T
+    h = user.user_setup(np.ascontiguousarray(mu).ctypes.data, np.ascontiguousarray(icov).ctypes.data, D)
+    out = {}
+    for label, target in (("fused", targets.DenseGaussian(mu, icov)), ("user kernel", targets.DeviceKernel(user.user_log_prob, h))):
+        smp = emcee_amd.EnsembleSampler(N, D, target, rng="philox")
+        smp._random.seed(3)
+        st = smp.run_mcmc(p0, 10, store=False, skip_initial_state_check=True)
+        t_end = time.perf_counter() + 0.3
+        while time.perf_counter() < t_end:                       # clocks up
+            st = smp.run_mcmc(st, 200, store=False, skip_initial_state_check=True)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            st = smp.run_mcmc(st, 400, store=False, skip_initial_state_check=True)
+            smp._ens.sync()
+            best = min(best, (time.perf_counter() - t0) / 400)
+        out[label] = best
+    user.user_teardown(h)
+    print("us/step: fused %.1f, user HIP kernel through emx_set_target_callback %.1f" % (out["fused"] * 1e6, out["user kernel"] * 1e6))
+    assert out["user kernel"] < 2.5 * out["fused"]

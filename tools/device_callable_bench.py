@@ -46,4 +46,5 @@ def measure(label, target, nst, **kw):
 
 measure("fused DenseGaussian target", targets.DenseGaussian(mu, icov), 400)
 measure("DeviceCallable(torch fn), eager", targets.DeviceCallable(lp_torch), 400)
+measure("DeviceCallable(torch fn), HIP graph", targets.DeviceCallable(lp_torch, graph=True), 400)
 measure("host callable, vectorize=True (split-phase)", lp_numpy, 20, vectorize=True)
