@@ -489,7 +489,7 @@ int prefetch_depth_host(int G, int V, int CH, int move, bool dense);
 inline int lean_kind(const HalfStepArgs& a, int G, int V, int CH, int move, bool dense) {
     const int WPW = 64 / G, PF = prefetch_depth_host(G, V, CH, move, dense);
     const int spw = (dense && PF * WPW < 16) ? 16 : PF * WPW;
-    const bool common = !a.ablate && !a.desc && !a.sendbuf && !a.disp && !a.skew_sleep && (EMX_OPT_STAMPS || !a.dbg) && a.target != TGT_NONE &&
+    const bool common = !a.ablate && !a.desc && !a.sendbuf && !a.disp && !a.skew_sleep && (EMX_OPT_STAMPS || !a.dbg) && (a.target != TGT_NONE || !dense) &&      // (propose-only passes run element-wise instantiations)
                         (!EMX_LEAN_FOLD_D || a.D == G * V * CH) && a.spw == spw && a.t_lo == 0;      // ndim is folded only with EMX_LEAN_FOLD_D
     if (!common) return 0;
     return (a.t_hi_dev || a.npeer || a.declp) ? 2 : 1;
@@ -552,6 +552,9 @@ hipError_t launch_dense(int dpb, int V, dim3 grid, dim3 block, size_t lds, hipSt
             if constexpr (MOVE == MOVE_STRETCH) {
                 if (lk) return launch_hot_stretch_dense64(lk, grid, block, lds, st, a);       // emx_hot.hip (its own scheduler strategy)
             } else {
+#if EMX_HOT_DE_SNOOKER
+                if (lk == 1 && (MOVE == MOVE_DE || MOVE == MOVE_SNOOKER)) return launch_hot_de_snooker_dense64(MOVE, grid, block, lds, st, a);
+#endif
                 if (lk == 1) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, 1>(grid, block, lds, st, a);
             }
         }

@@ -28,6 +28,13 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
 // while the same flag costs the element-wise kernels up to 6 % (C3), so it is not a global build flag.
 hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a);
 
+#ifndef EMX_HOT_DE_SNOOKER
+#define EMX_HOT_DE_SNOOKER 0
+#endif
+#if EMX_HOT_DE_SNOOKER
+hipError_t launch_hot_de_snooker_dense64(int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a);
+#endif
+
 // Wide dense Gaussian targets (padded ndim > 112, emx_wide.hip): log-probs of a block of rows, and the decision + commit
 // of a half-step whose proposals sit in qout / fout.
 struct WideLpArgs {

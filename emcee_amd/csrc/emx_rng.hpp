@@ -18,24 +18,13 @@ namespace emx {
 
 EMX_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
 
-// Both halves of a 32 x 32 -> 64 bit product.  On the device ONE v_mad_u64_u32: the compiler splits the C expression into
-// v_mul_hi_u32 + v_mul_lo_u32, two quarter-rate instructions where one delivers both words -- and the integer multiplies of the
-// Philox rounds are what bounds the plan kernel (k_native_plan_batch: ~1 600 of its ~2 500 cycles per 64 entries) and the
-// Gaussian move's noise.  Same bits either way.
-#ifndef EMX_PHILOX_MAD64
-#define EMX_PHILOX_MAD64 1
-#endif
+// Both halves of a 32 x 32 -> 64 bit product.  (Round 3 measured ONE v_mad_u64_u32 in place of the v_mul_hi_u32 + v_mul_lo_u32
+// pair the compiler emits for this: no difference -- C2 23.68 against 23.68, C3 38.61 against 38.67 us/step,
+// profiles/r03/ab_mad64_spinsync.txt -- the wide multiply costs what the two it replaces cost.  Plain C it stays.)
 EMX_HD void mul_hilo32(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
-#if defined(__HIP_DEVICE_COMPILE__) && EMX_PHILOX_MAD64
-    uint64_t r, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(a), "v"(b));
-    hi = (uint32_t)(r >> 32);
-    lo = (uint32_t)r;
-#else
     const uint64_t r = (uint64_t)a * (uint64_t)b;
     hi = (uint32_t)(r >> 32);
     lo = (uint32_t)r;
-#endif
 }
 
 struct Philox4 {

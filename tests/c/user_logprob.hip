@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_user_dense(const double* __restrict__ q
     __syncthreads();
     double y = 0.0;
     if (live && lane < D)
-        for (int j = 0; j < D; ++j) y = fma(icov[lane * D + j], r[w][j], y);
+        for (int j = 0; j < D; ++j) y = fma(icov[j * D + lane], r[w][j], y);       // (icov is symmetric: row j, coalesced over the lanes)
     double part = rd * y;
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     if (live && lane == 0) out[row] = -0.5 * part;
