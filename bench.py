@@ -483,12 +483,12 @@ def quality_entry(device, rng="philox"):
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU measurement
-EXCHANGES = ("allgather", "pull", "direct", "replay")      # measured by default at N > 1
+EXCHANGES = ("allgather", "pull", "direct", "replay", "replay_push")      # measured by default at N > 1
 # "logprob" (proposal / commit replicated, log-prob evaluations shared out: for targets that dominate the step) is measured
 # on request only: on the closed-form BASELINE targets the replicated part is most of the step
 ALL_EXCHANGES = EXCHANGES + ("logprob",)
-# the compute-heavy configuration (65 536 x 512 dense, strong scaling): the two protocols that share out the evaluation
-HEAVY_EXCHANGES = ("replay", "logprob")
+# the compute-heavy configuration (65 536 x 512 dense per GPU, weak scaling): the protocols that share out the evaluation
+HEAVY_EXCHANGES = ("replay", "replay_push", "logprob")
 
 
 _NCCL_GROUP = {}
@@ -507,6 +507,11 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
     from emcee_amd.device import DeviceEnsemble
     ens = DeviceEnsemble(wl.N, wl.D, device=local_rank)
     wl.install(ens, "philox")
+    push = exchange == "replay_push"          # the replay exchange with the decisions stored into the peers' buffers (no collective)
+    if push:
+        if comm_mode == "torch":
+            raise RuntimeError("the device-side replay exchange is driven by libemx itself (--comm rccl)")
+        exchange = "replay"
     ens.set_exchange(exchange)
     if direct_timeout_ms:
         ens.set_tuning("direct_timeout_ms", int(direct_timeout_ms))
@@ -535,7 +540,7 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
         uid = [DeviceEnsemble.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ens.comm_init(rank, world, uid[0])      # ncclCommInitRank; emx_run now exchanges per half-step
-        if exchange == "direct":                # map the peers' coordinate arrays and barrier flags (IPC handles over gloo)
+        if exchange == "direct" or push:        # map the peers' coordinate arrays / receive buffers and barrier flags (IPC handles over gloo)
             from emcee_amd.parallel import import_direct_peers
             import_direct_peers(ens, dist)
         run = lambda k: ens.run(k, 1, False)  # noqa: E731
@@ -579,7 +584,7 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
         if single_block or (total >= MIN_TIMED_MS and nblk >= 3) or nblk >= 60:     # same decision on every rank: t is reduced
             break
     res = {"wall_s": float(np.median(walls)), "gpu_ms": float(np.median(gpus)), "blocks": nblk, "comm": comm_used,
-           "exchange": exchange, "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(),
+           "exchange": "replay_push" if push else exchange, "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(),
            "digest": digest, "replicas_agree": len(set(every)) == 1}
     res.update(_rank_census(ens, dist, comm_mode, local_rank))
     if comm_mode != "torch":
@@ -697,7 +702,7 @@ def run_preflight(args, world, dist, port0, exchanges):
 
 
 def sharded_workload(key, world, args):
-    scaling = {"c2": "weak", "c3": "strong", "c5": "strong", "w512": "strong"}[key] if args.scaling == "auto" else args.scaling
+    scaling = {"c2": "weak", "c3": "strong", "c5": "strong", "w512": "weak"}[key] if args.scaling == "auto" else args.scaling
     base = {"c2": 65536, "c3": 262144, "c5": 16384, "w512": 65536}[key]
     return Workload(key, base * world if scaling == "weak" else base), scaling
 
@@ -728,7 +733,7 @@ def child_main(args, rank, world, local_rank):
         first = repr(e)
         log("rank %d: exchange '%s' on %s failed: %s" % (rank, ex, key, first))
         out = {"error": first}
-    if args.comm == "rccl" and ex != "direct":
+    if args.comm == "rccl" and ex not in ("direct", "replay_push"):
         # library-driven RCCL unavailable on some rank: the same protocol over torch.distributed's communicator
         if not torch_all_ok(dist, out.get("error") is None):
             try:
@@ -793,11 +798,11 @@ XGMI_INGRESS_GBPS = 7 * 76.8        # MI355X: 7 links x 153.6 GB/s bidirectional
 
 # DESIGN.md section 6, "What to expect": microseconds per step of the protocol expected to win, written down BEFORE the first
 # multi-GPU run so that the first curve can be read against a prediction (world size -> us/step)
-PREDICTED_US_PER_STEP = {
-    "c2": {2: 40.0, 4: 42.0, 8: 56.0},
-    "c3": {2: 38.0, 4: 34.0, 8: 33.0},
-    "c5": {2: 44.0, 4: 36.0, 8: 33.0},
-    "w512": {2: 300.0, 4: 170.0, 8: 105.0},
+PREDICTED_US_PER_STEP = {      # the device-side replay exchange (replay_push); the model and its inputs are in DESIGN.md section 6
+    "c2": {2: 50.0, 4: 61.0, 8: 80.0},          # weak, 65 536 walkers per GPU: 0.95x / 1.55x / 2.4x one GPU's 23.7 us
+    "c3": {2: 55.0, 4: 53.0, 8: 53.0},          # strong, 38.6 us on one GPU: every G > 1 is expected to be SLOWER (0.7x)
+    "c5": {2: 64.0, 4: 51.0, 8: 46.0},          # strong, 53.6 us on one GPU: 0.84x / 1.05x / 1.16x
+    "w512": {2: 550.0, 4: 582.0, 8: 640.0},     # weak, 508 us on one GPU: 1.85x / 3.5x / 6.3x -- the workload that reaches 6x
 }
 
 
@@ -812,7 +817,7 @@ def xgmi_bytes_per_update(wl, ex, world, accept_frac=None):
         return npart * (G - 1) / G * 8.0 * (D + 1) * 1.2
     if ex == "direct":
         return npart * (G - 1) / G * 8.0 * D
-    if ex in ("logprob", "replay"):
+    if ex in ("logprob", "replay", "replay_push"):
         return (G - 1) * 8.0
     return float("nan")
 
@@ -1176,7 +1181,7 @@ def main(argv=None):
     for kn, key in enumerate(keys):
         wl, best, entry = sharded_config(key, world, K, rank, dist, args, port_base + 8 * kn, skip)
         multi[{"c2": "c2_weak_65536_per_gpu", "c3": "c3_262144x32_rosen_sharded", "c5": "c5_16384x1024_strong",
-               "w512": "wide_65536x512_dense_strong"}[key]
+               "w512": "wide_65536x512_dense_weak"}[key]
               if args.scaling == "auto" else "%s_%s" % (key, entry["scaling"])] = entry
         if key == "c2":
             if best is None:
@@ -1189,7 +1194,9 @@ def main(argv=None):
             how = ", %s via %s" % ({"pull": "all-to-all of the partner rows (pull exchange)",
                                     "allgather": "all-gather of the updated rows",
                                     "direct": "partner rows read in place from the peers' HBM (direct exchange)",
-                                    "replay": "all-gather of the decisions, accepted updates recomputed on every replica (replay exchange)"}.get(
+                                    "replay": "all-gather of the decisions, accepted updates recomputed on every replica (replay exchange)",
+                                    "replay_push": "decisions stored into the peers' buffers, accepted updates recomputed on every replica "
+                                                   "(device-side replay exchange)"}.get(
                                         best["exchange"], best["exchange"]), best["comm"])
             line = headline(wl, best["wall_s"], best["gpu_ms"], None, best["accept_frac"], best["status"], how,
                             {"timed_blocks": best["blocks"], "rccl_ranks": best.get("rccl_ranks"),

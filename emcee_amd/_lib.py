@@ -98,6 +98,7 @@ SIGNATURES = {
     "emx_logprob_finish": (C.c_int, [_P, C.c_int32]),
     "emx_replay_begin": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int64)]),
     "emx_replay_finish": (C.c_int, [_P, C.c_int32]),
+    "emx_replay_exchange": (C.c_int, [_P, C.c_int32]),
     "emx_replica_pack": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "emx_replica_unpack": (C.c_int, [_P]),
     "emx_direct_export": (C.c_int, [_P, _u8p]),

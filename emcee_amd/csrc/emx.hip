@@ -411,6 +411,9 @@ struct emx_ctx {
     int32_t* replay_counts = nullptr;         // [2]: accepted foreign slots of the current / next half-step (k_replay_compact re-arms)
     int replay_parity = 0;
     int replay_split = -1;                    // emx_replay_begin ran for this split
+    int64_t replay_recv_off = 0;              // doubles into `gathered`: the receive buffer of the half-step being finished
+    int64_t replay_buf = 0;                   // doubles per receive buffer (there are two: the device-side exchange alternates)
+    int replay_push_parity = 0;
     double* launch_declp = nullptr;           // set around a launch_split call: the launch writes its decisions here
     bool eval_check_bad = false;              // MOVE_EVAL over proposals (log-prob exchange): non-finite rows get -inf, as in the fused path
     bool direct_dead = false;                 // a barrier timed out (seen by emx_status): no half-step until the peers are re-attached
@@ -450,6 +453,7 @@ static void direct_detach(emx_ctx* c);
 static int direct_ensure(emx_ctx* c);
 static void exchange_free(emx_ctx* c);
 static int replay_ensure(emx_ctx* c);
+static int flags_ensure(emx_ctx* c);
 
 // forget native plans evaluated ahead of time; the Gaussian sequential cursors they advanced go back
 static void drop_prepared(emx_ctx* c) {
@@ -552,9 +556,6 @@ hipError_t launch_dense(int dpb, int V, dim3 grid, dim3 block, size_t lds, hipSt
             if constexpr (MOVE == MOVE_STRETCH) {
                 if (lk) return launch_hot_stretch_dense64(lk, grid, block, lds, st, a);       // emx_hot.hip (its own scheduler strategy)
             } else {
-#if EMX_HOT_DE_SNOOKER
-                if (lk == 1 && (MOVE == MOVE_DE || MOVE == MOVE_SNOOKER)) return launch_hot_de_snooker_dense64(MOVE, grid, block, lds, st, a);
-#endif
                 if (lk == 1) return launch_one<dense_g(4, 2), 2, dense_ch(4, 2), MOVE, 4, 1>(grid, block, lds, st, a);
             }
         }
@@ -2677,7 +2678,9 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
                     // own slots fused; 8 bytes of decision per walker-update gathered; the others' accepted updates replayed
                     int64_t rows = 0;
                     rc = emx_replay_begin(c, s, &rows);
-                    if (!rc && rows > 0 && c->world > 1) {
+                    if (!rc && c->peers_ready && c->world > 1) {
+                        rc = emx_replay_exchange(c, s);          // stores into the peers' buffers + the device-side barrier
+                    } else if (!rc && rows > 0 && c->world > 1) {
                         const int e = g_rccl.AllGather(c->sendbuf, c->gathered, (size_t)rows, RCCL_FLOAT64, c->comm, c->stream);
                         if (e != 0) {
                             c->err = std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
@@ -3025,17 +3028,71 @@ static int replay_ensure(emx_ctx* c) {
         c->replay_parity = 0;
     }
     const int64_t per = c->world > 1 ? shard_rows_per_rank(N, c->world, min_nsplits_of(c)) : N + 2;
-    if (c->send_doubles < per || c->recv_doubles < per * c->world) {
+    if (c->send_doubles < per || c->recv_doubles < 2 * per * c->world) {
+        NEED(c, !c->peers_ready, "replay exchange: the installed moves need larger buffers than the ones the peers have mapped: install "
+                                 "the moves before emx_set_shard / emx_comm_init, or attach the peers again");
         HIPOK(c, hipStreamSynchronize(c->stream));
         exchange_free(c);
         HIPOK(c, hipMalloc((void**)&c->sendbuf, (size_t)per * 8));
-        HIPOK(c, hipMalloc((void**)&c->gathered, (size_t)per * c->world * 8));
+        // two receive buffers (the device-side exchange alternates between them); peers may write them over xGMI while this
+        // device reads: fine-grained (never stale in the local L2) where the runtime offers it
+        void* g = nullptr;
+        if (hipExtMallocWithFlags(&g, (size_t)2 * per * c->world * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPOK(c, hipMalloc(&g, (size_t)2 * per * c->world * 8));
+        }
+        c->gathered = (double*)g;
         c->own_shard_bufs = true;
         c->sendbuf_rows = per;
         c->gathered_rows = per * c->world;
         c->send_doubles = per;
-        c->recv_doubles = per * c->world;
+        c->recv_doubles = 2 * per * c->world;
+        c->replay_buf = per * c->world;
+        c->replay_recv_off = 0;
+        c->replay_push_parity = 0;
     }
+    return flags_ensure(c);
+}
+
+// Device-side exchange of the decisions (needs the peers' receive buffers and flags: emx_direct_export / _import / _attach):
+// push to every peer, then the barrier.  emx_replay_finish then reads this half-step's buffer.
+int emx_replay_exchange(emx_ctx* c, int32_t split) {
+    HIPOK(c, hipSetDevice(c->device));
+    auto& cur = c->cur;
+    NEED(c, c->exchange == EMX_EXCHANGE_REPLAY && cur.active && c->replay_split == split, "emx_replay_exchange: emx_replay_begin(%d) has not run", split);
+    NEED(c, c->peers_ready || c->world == 1, "replay exchange: the peers' receive buffers are not mapped (emx_direct_export / emx_direct_import, "
+                                             "or emx_direct_attach); without them use an all-gather of the send buffer");
+    NEED(c, !c->direct_dead, "replay exchange: an earlier barrier timed out (a peer never arrived): attach the peers again");
+    NEED(c, c->world <= EMX_MAX_PEERS, "device-side exchange: at most %d ranks (the GPUs of one node)", EMX_MAX_PEERS);
+    const int ns = cur.off[split + 1] - cur.off[split];
+    const int64_t rows = ((int64_t)ns + c->world - 1) / c->world;
+    const int64_t G = c->world;
+    c->replay_recv_off = (int64_t)c->replay_push_parity * c->replay_buf;
+    c->replay_push_parity ^= 1;
+    if (G == 1 || rows <= 0) return 0;
+    PushArgs a{};
+    a.src = c->sendbuf;
+    for (int q = 0; q < G; ++q) a.peer[q] = c->peerX[q];
+    a.off = c->replay_recv_off + (int64_t)c->rank * rows;
+    a.rows = (int32_t)rows;
+    a.npeer = (int32_t)G;
+    hipLaunchKernelGGL(k_push_decisions, dim3((unsigned)((rows + 255) / 256), (unsigned)G), dim3(256), 0, c->stream, a);
+    HIPOK(c, hipGetLastError());
+    PeerBarrierArgs b{};
+    for (int q = 0; q < G; ++q) {
+        NEED(c, c->peer_flags[q], "replay exchange: no barrier flags for rank %d", q);
+        b.peer_flags[q] = c->peer_flags[q];
+    }
+    b.my_flags = c->my_flags;
+    b.dead = c->direct_counts + 64;
+    b.status = c->status;
+    b.epoch = ++c->direct_epoch;
+    b.timeout_ticks = (unsigned long long)c->tune_direct_timeout_ms * (c->direct_first_barrier ? 6ull : 1ull) * 100000ull;
+    c->direct_first_barrier = false;
+    b.rank = c->rank;
+    b.npeer = (int32_t)G;
+    hipLaunchKernelGGL(k_peer_barrier, dim3(1), dim3(64), 0, c->stream, b);
+    HIPOK(c, hipGetLastError());
     return 0;
 }
 
@@ -3054,6 +3111,7 @@ int emx_replay_begin(emx_ctx* c, int32_t split, int64_t* rows_per_rank) {
     NEED(c, rows <= c->sendbuf_rows, "replay exchange: buffers too small for this move (call emx_set_shard after emx_set_moves)");
     if (rows_per_rank) *rows_per_rank = rows;
     c->replay_split = split;
+    c->replay_recv_off = 0;          // an all-gather fills the first receive buffer; emx_replay_exchange picks its own
     int64_t lo, hi;
     shard_range(ns, c->rank, c->world, lo, hi);
     if (hi <= lo) return 0;
@@ -3084,7 +3142,7 @@ int emx_replay_finish(emx_ctx* c, int32_t split) {
         a.p1 = ps.p1 + pos0;
         a.p2 = ps.p2 + pos0;
         a.s0 = ps.s0 + pos0;
-        a.gathered = c->gathered;
+        a.gathered = c->gathered + c->replay_recv_off;
         a.corder = c->cplan.order;
         a.cp0 = c->cplan.p0;
         a.cp1 = c->cplan.p1;
@@ -3241,6 +3299,27 @@ static void direct_detach(emx_ctx* c) {
     c->peers_ready = false;
 }
 
+// what the device-side barrier needs (direct exchange, device-side replay exchange)
+static int flags_ensure(emx_ctx* c) {
+    if (!c->direct_counts) {
+        HIPOK(c, hipMalloc((void**)&c->direct_counts, 65 * 4));       // [64]: "a barrier timed out" (later barriers do not wait again)
+        HIPOK(c, hipMemset(c->direct_counts, 0, 65 * 4));
+    }
+    if (!c->my_flags) {
+        // the barrier flags are written by the peers while this device polls them: fine-grained (uncached) device memory
+        // where the runtime offers it, ordinary device memory otherwise (the polls are system-scope atomics either way)
+        void* f = nullptr;
+        if (hipExtMallocWithFlags(&f, EMX_MAX_PEERS * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPOK(c, hipMalloc(&f, EMX_MAX_PEERS * 8));
+        }
+        c->my_flags = (unsigned long long*)f;
+        HIPOK(c, hipMemset(c->my_flags, 0, EMX_MAX_PEERS * 8));
+        c->direct_epoch = 0;
+    }
+    return 0;
+}
+
 static int direct_ensure(emx_ctx* c) {
     const int64_t G = c->world, N = c->N, bmax = (N + G - 1) / G;
     if (c->cplan_rows < N) {          // the compact plans of all splits of a step, split s at offset off[s]
@@ -3259,21 +3338,9 @@ static int direct_ensure(emx_ctx* c) {
         HIPOK(c, hipMalloc((void**)&p.fac, N * 8));
         c->cplan_rows = N;
     }
-    if (!c->direct_counts) {
-        HIPOK(c, hipMalloc((void**)&c->direct_counts, 65 * 4));       // [64]: "a barrier timed out" (later barriers do not wait again)
-        HIPOK(c, hipMemset(c->direct_counts, 0, 65 * 4));
-    }
-    if (!c->my_flags) {
-        // the barrier flags are written by the peers while this device polls them: fine-grained (uncached) device memory
-        // where the runtime offers it, ordinary device memory otherwise (the polls are system-scope atomics either way)
-        void* f = nullptr;
-        if (hipExtMallocWithFlags(&f, EMX_MAX_PEERS * 8, hipDeviceMallocFinegrained) != hipSuccess) {
-            (void)hipGetLastError();
-            HIPOK(c, hipMalloc(&f, EMX_MAX_PEERS * 8));
-        }
-        c->my_flags = (unsigned long long*)f;
-        HIPOK(c, hipMemset(c->my_flags, 0, EMX_MAX_PEERS * 8));
-        c->direct_epoch = 0;
+    {
+        const int rcf = flags_ensure(c);
+        if (rcf) return rcf;
     }
     // buffers of the replica re-synchronisation (one all-gather of the blocks when emx_run returns)
     const int64_t send = bmax * (c->D + 3), recv = G * bmax * (c->D + 3);
@@ -3315,10 +3382,16 @@ static int direct_publish_table(emx_ctx* c) {
     return 0;
 }
 
+// the array a peer maps: the coordinates (direct exchange: partner rows are read from it) or the receive buffers of the
+// decisions (replay exchange: the peers store into it)
+static inline bool maps_peers(const emx_ctx* c) { return c->exchange == EMX_EXCHANGE_DIRECT || c->exchange == EMX_EXCHANGE_REPLAY; }
+static inline int peers_ensure(emx_ctx* c) { return c->exchange == EMX_EXCHANGE_REPLAY ? replay_ensure(c) : direct_ensure(c); }
+static inline double* peer_mapped_array(emx_ctx* c) { return c->exchange == EMX_EXCHANGE_REPLAY ? c->gathered : c->X; }
+
 int emx_direct_export(emx_ctx* c, uint8_t handles[128]) {
     HIPOK(c, hipSetDevice(c->device));
-    NEED(c, c->exchange == EMX_EXCHANGE_DIRECT, "emx_direct_export needs emx_set_exchange(EMX_EXCHANGE_DIRECT)");
-    int rc = direct_ensure(c);
+    NEED(c, maps_peers(c), "emx_direct_export needs emx_set_exchange(EMX_EXCHANGE_DIRECT or EMX_EXCHANGE_REPLAY)");
+    int rc = peers_ensure(c);
     if (rc) return rc;
     // every rank exports before any rank can import (the host layer's all-gather of the handles sits in between), so this is
     // the one point where no peer can be writing this rank's flags: start the new attachment from epoch 0
@@ -3326,7 +3399,7 @@ int emx_direct_export(emx_ctx* c, uint8_t handles[128]) {
     if (rc) return rc;
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle size");
     hipIpcMemHandle_t hx, hf;
-    HIPOK(c, hipIpcGetMemHandle(&hx, c->X));
+    HIPOK(c, hipIpcGetMemHandle(&hx, peer_mapped_array(c)));
     HIPOK(c, hipIpcGetMemHandle(&hf, c->my_flags));
     memset(handles, 0, 128);
     memcpy(handles, &hx, sizeof(hx));
@@ -3336,13 +3409,14 @@ int emx_direct_export(emx_ctx* c, uint8_t handles[128]) {
 
 int emx_direct_import(emx_ctx* c, const uint8_t* handles) {
     HIPOK(c, hipSetDevice(c->device));
-    NEED(c, c->exchange == EMX_EXCHANGE_DIRECT && c->world >= 1, "emx_direct_import needs the direct exchange and emx_set_shard");
-    int rc = direct_ensure(c);
+    NEED(c, maps_peers(c) && c->world >= 1, "emx_direct_import needs the direct or the replay exchange and emx_set_shard");
+    NEED(c, c->world <= EMX_MAX_PEERS, "peer mapping: at most %d ranks (the GPUs of one node)", EMX_MAX_PEERS);
+    int rc = peers_ensure(c);
     if (rc) return rc;
     direct_detach(c);
     for (int q = 0; q < c->world; ++q) {
         if (q == c->rank) {
-            c->peerX[q] = c->X;
+            c->peerX[q] = peer_mapped_array(c);
             c->peer_flags[q] = c->my_flags;
             continue;
         }
@@ -3358,23 +3432,24 @@ int emx_direct_import(emx_ctx* c, const uint8_t* handles) {
         c->peer_ipc_f[q] = true;
     }
     c->peers_ready = true;
-    return direct_publish_table(c);
+    return c->exchange == EMX_EXCHANGE_DIRECT ? direct_publish_table(c) : 0;
 }
 
 int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_flags) {
-    NEED(c, c->exchange == EMX_EXCHANGE_DIRECT && c->world >= 1, "emx_direct_attach needs the direct exchange and emx_set_shard");
-    int rc = direct_ensure(c);
+    NEED(c, maps_peers(c) && c->world >= 1, "emx_direct_attach needs the direct or the replay exchange and emx_set_shard");
+    NEED(c, c->world <= EMX_MAX_PEERS, "peer mapping: at most %d ranks (the GPUs of one node)", EMX_MAX_PEERS);
+    int rc = peers_ensure(c);
     if (rc) return rc;
     direct_detach(c);
     for (int q = 0; q < c->world; ++q) {
-        c->peerX[q] = q == c->rank ? c->X : (double*)peer_coords[q];
+        c->peerX[q] = q == c->rank ? peer_mapped_array(c) : (double*)peer_coords[q];
         c->peer_flags[q] = q == c->rank ? c->my_flags : (unsigned long long*)(peer_flags ? peer_flags[q] : nullptr);
         NEED(c, c->peerX[q], "emx_direct_attach: no coordinate array for rank %d", q);
     }
     c->peers_ready = true;
     rc = direct_rearm(c);
     if (rc) return rc;
-    return direct_publish_table(c);
+    return c->exchange == EMX_EXCHANGE_DIRECT ? direct_publish_table(c) : 0;
 }
 
 int emx_direct_halfstep(emx_ctx* c, int32_t split, int32_t barrier) {

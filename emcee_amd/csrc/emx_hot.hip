@@ -9,12 +9,4 @@ hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t ld
     return launch_one<8, 2, 4, MOVE_STRETCH, 4, 1>(grid, block, lds, st, a);
 }
 
-#if EMX_HOT_DE_SNOOKER
-// experiment (tools/ab_variants.sh hotds "-DEMX_HOT_DE_SNOOKER=1"): C4's two kernels under the ILP scheduler as well
-hipError_t launch_hot_de_snooker_dense64(int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
-    if (move == MOVE_DE) return launch_one<8, 2, 4, MOVE_DE, 4, 1>(grid, block, lds, st, a);
-    return launch_one<8, 2, 4, MOVE_SNOOKER, 4, 1>(grid, block, lds, st, a);
-}
-#endif
-
 }  // namespace emx

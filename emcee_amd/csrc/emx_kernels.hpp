@@ -1973,6 +1973,24 @@ static __global__ __launch_bounds__(256) void k_replay_compact(const ReplayCompa
     }
 }
 
+// Replay exchange without a collective library: every rank stores its decisions straight into every peer's receive buffer
+// (mapped like the direct exchange's arrays: hipIpc between processes) -- 8 bytes per own walker-update to each peer -- and the
+// one-wave barrier kernel (k_peer_barrier: system-scope release, a flag into every peer's array, spin, acquire) tells everybody
+// that everybody's decisions have landed.  Two receive buffers alternate by half-step: a peer can only be writing half-step
+// h + 2's decisions once this rank has pushed h + 1's, i.e. after it finished reading h's.
+struct PushArgs {
+    const double* src;                     // this rank's decisions of the half-step: rows doubles
+    double* peer[EMX_MAX_PEERS];           // [q]: rank q's receive buffers as mapped here (own entry: the local one)
+    long long off;                         // this half-step's buffer (0 or the buffer size) + rank * rows
+    int32_t rows, npeer;
+};
+
+static __global__ __launch_bounds__(256) void k_push_decisions(const PushArgs A) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;
+    if (e < A.rows && q < A.npeer) A.peer[q][A.off + e] = A.src[e];
+}
+
 // stored step of the replay exchange: the chain row is the replica after the step (backend.py:225-231)
 struct StoreStepArgs {
     const double* X;

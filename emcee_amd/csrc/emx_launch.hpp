@@ -25,15 +25,9 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
 // The headline shape -- stretch move, dense Gaussian target, ndim 64 (k_halfstep<8,2,4,STRETCH,4,LEAN>) -- lives in a
 // translation unit of its own (emx_hot.hip) built with -amdgpu-sched-strategy=max-ilp: this kernel runs two waves per SIMD
 // in lock step, i.e. it lives on instruction-level parallelism inside a wave, and the ILP scheduler is worth +2.2 % there,
-// while the same flag costs the element-wise kernels up to 6 % (C3), so it is not a global build flag.
+// while the same flag costs the element-wise kernels up to 6 % (C3), so it is not a global build flag (nor one for C4's DE /
+// snooker kernels of the same shape: 33.2 -> 33.9 us/step under it, round 3, profiles/r03/ab_hot_de_snooker.txt).
 hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a);
-
-#ifndef EMX_HOT_DE_SNOOKER
-#define EMX_HOT_DE_SNOOKER 0
-#endif
-#if EMX_HOT_DE_SNOOKER
-hipError_t launch_hot_de_snooker_dense64(int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a);
-#endif
 
 // Wide dense Gaussian targets (padded ndim > 112, emx_wide.hip): log-probs of a block of rows, and the decision + commit
 // of a half-step whose proposals sit in qout / fout.

@@ -449,6 +449,10 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_replay_begin(self.ctx, int(split), C.byref(n)))
         return n.value
 
+    def replay_exchange(self, split):
+        """device-side exchange of the decisions (peers mapped): stores into every peer's receive buffer + the barrier kernel"""
+        self._ck(self.lib.emx_replay_exchange(self.ctx, int(split)))
+
     def replay_finish(self, split):
         """after the all-gather of the decisions: the other ranks' accepted updates, recomputed on this replica"""
         self._ck(self.lib.emx_replay_finish(self.ctx, int(split)))

@@ -239,11 +239,12 @@ def _wrap_device_buffer(ens, which, dev):
     return torch.as_tensor(_DevView(ptr, nbytes // 8), device=dev)
 
 
-def attach_direct_peers(ensembles):
+def attach_direct_peers(ensembles, which=0):
     """Logical ranks of ONE process (tests, several contexts on one GPU): hand every context the others' coordinate
-    arrays and barrier flags as plain device pointers.  Between processes the same is done with IPC handles:
+    arrays (``which=0``: direct exchange) or receive buffers (``which=3``: device-side replay exchange) and barrier flags as
+    plain device pointers.  Between processes the same is done with IPC handles:
     ``handles = all_gather(ens.direct_export()); ens.direct_import(handles)``."""
-    xs = [e.device_ptr(0)[0] for e in ensembles]
+    xs = [e.device_ptr(which)[0] for e in ensembles]
     fs = [e.device_ptr(8)[0] for e in ensembles]
     for e in ensembles:
         e.direct_attach(xs, fs)

@@ -273,6 +273,13 @@ int emx_logprob_finish(emx_ctx* ctx, int32_t split);
  *   (emx_run does it when emx_comm_init ran).  Results are bit-identical to the single-rank run. */
 int emx_replay_begin(emx_ctx* ctx, int32_t split, int64_t* rows_per_rank);
 int emx_replay_finish(emx_ctx* ctx, int32_t split);
+/* The same exchange without a collective library (one node): after emx_direct_export / emx_direct_import (or emx_direct_attach)
+ * -- which under this exchange map every rank's RECEIVE buffers (emx_device_ptr which = 3: two of them, used alternately) and
+ * barrier flags -- emx_replay_exchange(split) replaces the all-gather: a kernel stores the decisions into every peer's buffer
+ * over xGMI (8 bytes per own walker-update and peer) and the one-wave device-side barrier of the direct exchange tells every
+ * rank that all of them have landed.  No host round trip, no collective launch latency; emx_run uses it when the peers are
+ * mapped.  Between emx_replay_begin and emx_replay_finish. */
+int emx_replay_exchange(emx_ctx* ctx, int32_t split);
 
 /* RCCL driven by the library itself (ncclAllGather enqueued on the context stream between the
  * half-step kernels, so that emx_run covers sharded runs with no host round trip per step).

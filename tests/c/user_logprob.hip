@@ -25,7 +25,13 @@ __global__ __launch_bounds__(256) void k_user_dense(const double* __restrict__ q
     __syncthreads();
     double y = 0.0;
     if (live && lane < D)
-        for (int j = 0; j < D; ++j) y = fma(icov[j * D + lane], r[w][j], y);       // (icov is symmetric: row j, coalesced over the lanes)
+        for (int j0 = 0; j0 < D; j0 += 8) {       // eight loads in flight (icov is symmetric: row j, coalesced over the lanes)
+            double a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = j0 + k < D ? icov[(j0 + k) * D + lane] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y = fma(a[k], j0 + k < D ? r[w][j0 + k] : 0.0, y);
+        }
     double part = rd * y;
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     if (live && lane == 0) out[row] = -0.5 * part;

@@ -13,7 +13,7 @@ def install(bench):
     fail = set(filter(None, os.environ.get("EMX_BENCH_STUB_FAIL", "").split(",")))          # exchanges whose preflight fails
     hang = set(filter(None, os.environ.get("EMX_BENCH_STUB_HANG", "").split(",")))          # ... or never answers
     short = os.environ.get("EMX_BENCH_STUB_RANKS")                                          # census lie: RCCL saw fewer ranks
-    speed = {"allgather": 4.0, "pull": 2.0, "direct": 1.0, "replay": 0.8, "logprob": 3.0}
+    speed = {"allgather": 4.0, "pull": 2.0, "direct": 1.0, "replay": 0.8, "replay_push": 0.7, "logprob": 3.0}
 
     def run_child(args, key, ex, port, timeout_s, keep_partial=False):
         if outdir:

@@ -47,9 +47,9 @@ def test_self_launch_runs_n_ranks_and_prints_one_line(tmp_path):
     seqs = {tuple((d["key"], d["ex"]) for d in v) for v in seen.values()}
     assert len(seqs) == 1
     multi = line["multi_gpu"]
-    assert set(multi) == {"c2_weak_65536_per_gpu", "c3_262144x32_rosen_sharded", "c5_16384x1024_strong", "wide_65536x512_dense_strong"}
-    assert set(multi["wide_65536x512_dense_strong"]["exchange"]) == {"replay", "logprob"}       # the protocols that share out the evaluation
-    assert set(c2_ex := multi["c2_weak_65536_per_gpu"]["exchange"]) == {"allgather", "pull", "direct", "replay"} and c2_ex
+    assert set(multi) == {"c2_weak_65536_per_gpu", "c3_262144x32_rosen_sharded", "c5_16384x1024_strong", "wide_65536x512_dense_weak"}
+    assert set(multi["wide_65536x512_dense_weak"]["exchange"]) == {"replay", "replay_push", "logprob"}       # the protocols that share out the evaluation
+    assert set(c2_ex := multi["c2_weak_65536_per_gpu"]["exchange"]) == {"allgather", "pull", "direct", "replay", "replay_push"} and c2_ex
     c2 = multi["c2_weak_65536_per_gpu"]
     assert c2["nwalkers"] == 4 * 65536 and c2["scaling"] == "weak" and line["scaling"] == "weak"
     assert c2["reported"] == min(c2["exchange"], key=lambda e: c2["exchange"][e]["ms_per_step"])

@@ -22,3 +22,16 @@ def test_two_processes_map_each_other_and_reproduce_the_single_rank_chain():
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
     assert out.count("OK") >= 2 and "MISMATCH" not in out, out[-4000:]
+
+
+def test_two_processes_store_their_decisions_into_each_other_and_replay():
+    """device-side replay exchange between processes (tests/workers/replay_ipc_worker.py): emx_direct_export / _import of the
+    receive buffers, remote stores, the barrier, the replay -- every rank's full replica equals the single-rank chain"""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29673", os.path.join(ROOT, "tests", "workers", "replay_ipc_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert out.count("OK") >= 2 and "MISMATCH" not in out, out[-4000:]

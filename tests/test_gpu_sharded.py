@@ -341,6 +341,62 @@ def test_replay_exchange_equals_single_rank(name, world, rng):
     assert ReplayStepper is not None
 
 
+@pytest.mark.parametrize("name,world,rng", [("stretch_128x64_dense", 2, "philox"), ("mix_de_snooker_128x8_dense", 3, "mt"),
+                                            ("stretch_50x3_iso", 4, "philox"), ("stretch_48x130_dense", 2, "mt")])
+def test_replay_exchange_device_side(name, world, rng):
+    """The replay exchange with no collective at all: every context stores its decisions into the other contexts' receive
+    buffers (between GPUs: over xGMI into the peers' HBM) and the ranks meet at the one-wave barrier kernel -- no host
+    synchronisation inside a step; each context runs on its own stream.  Bit-identical to the single-rank run."""
+    from emcee_amd.parallel import attach_direct_peers
+    g = load_golden(name)
+    spec = cases.build(name)
+    nst = min(8, spec["nsteps"])
+
+    def setup(ens):
+        if rng == "mt":
+            ens.set_rng_mode(_lib.RNG_MT19937)
+            ens.set_mt19937(rng_from_fixture(g).get_state())
+        else:
+            ens.set_rng_mode(_lib.RNG_PHILOX)
+            ens.set_philox(777, 0)
+        ens.set_tuning("small_kernel", 0)
+        ens.chain_config(nst)
+
+    ref = make_ens(spec, g["p0"])
+    setup(ref)
+    ref.run(nst, 1, True)
+    ref_chain, ref_lp, ref_acc = ref.chain_read(0, 0, nst), ref.chain_read(1, 0, nst), ref.accepted_counts()
+    ref.close()
+    ensembles = []
+    for r in range(world):
+        ens = make_ens(spec, g["p0"])
+        setup(ens)
+        ens.set_exchange("replay")
+        ens.set_shard(r, world)
+        ens.set_tuning("direct_timeout_ms", 3000)
+        ensembles.append(ens)
+    attach_direct_peers(ensembles, which=3)              # receive buffers + barrier flags of every context
+    for _ in range(nst):
+        res = [e.step_begin(True) for e in ensembles]
+        assert all(x == res[0] for x in res)
+        for split in range(res[0][1]):
+            for e in ensembles:
+                e.replay_begin(split)
+                e.replay_exchange(split)                 # push + barrier kernels: they meet on the device
+                e.replay_finish(split)
+        for e in ensembles:
+            e.step_end()
+    for ens in ensembles:
+        ens.sync()
+    for ens in ensembles:
+        assert ens.status() == 0
+        assert np.array_equal(ens.chain_read(0, 0, nst), ref_chain)
+        assert np.array_equal(ens.chain_read(1, 0, nst), ref_lp)
+        assert np.array_equal(ens.accepted_counts(), ref_acc)
+    for ens in ensembles:
+        ens.close()
+
+
 @pytest.mark.parametrize("name,world,rng", [
     ("c1_stretch_32x5_iso", 2, "mt"), ("stretch_50x3_iso", 3, "mt"), ("stretch_128x64_dense", 2, "mt"),
     ("stretch_128x64_dense", 5, "philox"), ("mix_de_snooker_128x8_dense", 3, "philox"), ("stretch_128x8_rosen", 8, "philox"),
