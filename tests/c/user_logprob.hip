@@ -13,28 +13,34 @@ struct user_gauss {
     long long rows;
 };
 
+// One wavefront takes ROWS consecutive rows; lane d keeps COLUMN d of icov in registers (read once per wave, not once per
+// row: a first version that re-read the matrix for every row was bound by L1 bandwidth at 61 us per launch), the residual of
+// the current row is broadcast through LDS.
+constexpr int ROWS = 16;
+
 __global__ __launch_bounds__(256) void k_user_dense(const double* __restrict__ q, long long n, int D, const double* __restrict__ mu,
                                                     const double* __restrict__ icov, double* __restrict__ out) {
     __shared__ double r[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long row = (long long)blockIdx.x * 4 + w;
-    const bool live = row < n;
-    double rd = 0.0;
-    if (live && lane < D) rd = q[row * D + lane] - mu[lane];
-    r[w][lane] = rd;
-    __syncthreads();
-    double y = 0.0;
-    if (live && lane < D)
-        for (int j0 = 0; j0 < D; j0 += 8) {       // eight loads in flight (icov is symmetric: row j, coalesced over the lanes)
-            double a[8];
+    double col[64];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a[k] = j0 + k < D ? icov[(j0 + k) * D + lane] : 0.0;
+    for (int j = 0; j < 64; ++j) col[j] = (j < D && lane < D) ? icov[j * D + lane] : 0.0;       // icov is symmetric
+    const double m = lane < D ? mu[lane] : 0.0;
+    const long long row0 = ((long long)blockIdx.x * 4 + w) * ROWS;
+    for (int k = 0; k < ROWS; ++k) {
+        const long long row = row0 + k;
+        if (row >= n) break;                                  // wave-uniform
+        const double rd = lane < D ? q[row * D + lane] - m : 0.0;
+        r[w][lane] = rd;
+        __builtin_amdgcn_wave_barrier();
+        double y = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) y = fma(a[k], j0 + k < D ? r[w][j0 + k] : 0.0, y);
-        }
-    double part = rd * y;
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-    if (live && lane == 0) out[row] = -0.5 * part;
+        for (int j = 0; j < 64; ++j) y = fma(col[j], r[w][j], y);
+        double part = rd * y;
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if (lane == 0) out[row] = -0.5 * part;
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 extern "C" {
@@ -71,7 +77,7 @@ int user_log_prob(void* user, const double* coords_dev, int64_t n, int32_t ndim,
     u->calls += 1;
     u->rows += n;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_user_dense, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, coords_dev, (long long)n, (int)ndim,
+    hipLaunchKernelGGL(k_user_dense, dim3((unsigned)((n + 4 * ROWS - 1) / (4 * ROWS))), dim3(256), 0, (hipStream_t)hip_stream, coords_dev, (long long)n, (int)ndim,
                        u->mu, u->icov, log_prob_dev);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
