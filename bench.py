@@ -336,7 +336,13 @@ def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=F
     wall = float(np.median(walls))
     gpu_ms = float(np.median(gpus))
     res = {"wall_s": wall, "gpu_ms": gpu_ms, "blocks": len(walls), "wall_min_s": float(np.min(walls)),
-           "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(), "per_launch_us": None}
+           "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(), "per_launch_us": None,
+           "walls_s": [float(w) for w in walls]}
+    if rng == "mt19937":
+        try:
+            res["pipeline"] = ens.pipeline_stats()
+        except Exception as e:  # noqa: BLE001
+            log("pipeline stats unavailable:", e)
     if want_kernel:
         # per-launch hipEvent durations of the half-step kernel (separate pass: event records perturb)
         ens.profile_enable(128)
@@ -435,9 +441,13 @@ def exact_mode_entry(wl, K, W, device):
             "best_block_ms_per_step": res["wall_min_s"] * 1e3 / Kx,
             "host_plan_ms": host_ms, "kernel_us": res["per_launch_us"], "accept_frac": res["accept_frac"],
             "roofline_frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS,
+            "block_spread": float(np.max(res["walls_s"]) / np.min(res["walls_s"])),
+            "pipeline_stage_us_per_step": res.get("pipeline"),
             "note": "host_plan_ms = one step's plan made inline by ONE host thread (emx_host_plan_mt, no GPU) -- round 1's path; emx_run "
                     "now takes its plans from the host pipeline (csrc/emx_mtpipe.cpp: MT19937 generator thread, tokenizer thread, "
-                    "3 finisher threads confined to one L3 domain, uploads on a side stream), so ms_per_step is the pipeline's rate"}
+                    "four finisher threads confined to one L3 domain, uploads on a side stream), so ms_per_step is the pipeline's rate; "
+                    "pipeline_stage_us_per_step says which stage bounds it on THIS host (the stages run concurrently: the largest of "
+                    "generator / tokenizer / finishers-summed over the thread count is the pipeline's floor)"}
 
 
 def quality_entry(device, rng="philox"):

@@ -3696,6 +3696,17 @@ int emx_comm_destroy(emx_ctx* c) {
     return 0;
 }
 
+// exact mode: where the plan pipeline's time goes (all zeros when no pipeline is alive)
+int emx_pipeline_stats(emx_ctx* c, double out[6], int64_t* steps_produced, int32_t* finisher_threads) {
+    for (int k = 0; k < 6; ++k) out[k] = 0.0;
+    if (steps_produced) *steps_produced = 0;
+    if (finisher_threads) *finisher_threads = 0;
+    if (!c->pipe) return 0;
+    c->pipe->stage_times(out, steps_produced);
+    if (finisher_threads) *finisher_threads = c->pipe->workers();
+    return 0;
+}
+
 int emx_comm_count(emx_ctx* c, int32_t* ranks_out) {
     *ranks_out = 0;
     if (!c->comm) return 0;

@@ -626,7 +626,8 @@ struct MtPlanPipeline::Impl {
     bool joined = false;
     uint64_t t_start = 0, tok_wait_sink_ns = 0, tok_done_ns = 0;
     bool vec_scan = false, stats = false, fill_unused = false;
-    uint64_t tok_shuffle_ns = 0;
+    uint64_t tok_shuffle_ns = 0, tok_busy_ns = 0;
+    std::atomic<int64_t> tok_steps{0};             // steps tokenised so far
     std::vector<uint64_t> fin_wait_ns, fin_busy_ns;
 
     void tokenizer_main();
@@ -724,6 +725,23 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
 }
 
 int MtPlanPipeline::workers() const { return impl_->K; }
+
+// Where the pipeline's time goes, per step PRODUCED so far (plain counters of the stage threads, read while they run: a
+// snapshot for reporting, not a synchronisation).
+void MtPlanPipeline::stage_times(double out[6], int64_t* steps) const {
+    const Impl& m = *impl_;
+    const int64_t n = std::max<int64_t>(1, m.tok_steps.load(std::memory_order_relaxed));
+    const double elapsed = (double)(now_ns() - m.t_start);
+    uint64_t fin = 0;
+    for (uint64_t b : m.fin_busy_ns) fin += b;
+    out[0] = elapsed * 1e-3 / n;                                   // wall clock per produced step (it runs ahead: an upper bound)
+    out[1] = (elapsed - (double)m.ws.gen_wait_ns) * 1e-3 / n;      // generator: twist + temper
+    out[2] = (double)m.tok_busy_ns * 1e-3 / n;                     // tokenizer: rejection tests, raw words handed on
+    out[3] = (double)fin * 1e-3 / n;                               // finishers, summed over the K threads
+    out[4] = (double)m.ws.rd_wait_ns * 1e-3 / n;                   // tokenizer waited for the generator
+    out[5] = (double)m.tok_wait_sink_ns * 1e-3 / n;                // tokenizer waited for a free staging buffer (the consumer)
+    if (steps) *steps = m.tok_steps.load(std::memory_order_relaxed);
+}
 
 void MtPlanPipeline::Impl::join_all() {
     if (joined) return;
@@ -857,7 +875,12 @@ void MtPlanPipeline::Impl::tokenizer_main() {
             tok_wait_sink_ns += now_ns() - t0;
         }
         if (stop.load(std::memory_order_relaxed)) return;
-        tokenize(rd, n, has_gauss, gauss);
+        {
+            const uint64_t t0 = now_ns();
+            const uint64_t w0 = ws.rd_wait_ns;
+            tokenize(rd, n, has_gauss, gauss);
+            tok_busy_ns += (now_ns() - t0) - (ws.rd_wait_ns - w0);         // without the time it waited for words
+        }
         if (rd.dead) return;
         // generator state after this step (NumPy get_state() semantics: a block consumed to its end reports pos = 624)
         {
@@ -871,6 +894,7 @@ void MtPlanPipeline::Impl::tokenizer_main() {
             sn.set_state(key, (int)(a - blk * BLK), has_gauss, gauss);
         }
         raw_ready[n % NR].v.store(n, std::memory_order_release);
+        tok_steps.store(n + 1, std::memory_order_relaxed);
     }
     tok_done_ns = now_ns() - t_start;
 }

@@ -77,6 +77,9 @@ class MtPlanPipeline {
     // Stop all threads; `out` receives the generator state after `steps_consumed` steps (NumPy get_state() semantics).
     void finish(int64_t steps_consumed, MT19937Legacy& out);
     int workers() const;
+    // microseconds per produced step: [0] wall, [1] generator busy, [2] tokenizer busy, [3] finishers busy (summed), [4] tokenizer
+    // waiting for words, [5] tokenizer waiting for a free staging buffer
+    void stage_times(double out[6], int64_t* steps) const;
 
    private:
     struct Impl;

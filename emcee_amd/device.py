@@ -523,6 +523,16 @@ class DeviceEnsemble:
     def comm_destroy(self):
         self._ck(self.lib.emx_comm_destroy(self.ctx))
 
+    def pipeline_stats(self):
+        """exact mode: us per produced step of the plan pipeline's stages (include/emx.h emx_pipeline_stats), or None"""
+        out = np.zeros(6)
+        n, k = C.c_int64(0), C.c_int32(0)
+        self._ck(self.lib.emx_pipeline_stats(self.ctx, out, C.byref(n), C.byref(k)))
+        if n.value <= 0:
+            return None
+        return {"steps_produced": n.value, "finisher_threads": k.value, "wall_us": out[0], "generator_us": out[1], "tokenizer_us": out[2],
+                "finishers_us_summed": out[3], "tokenizer_waited_for_words_us": out[4], "tokenizer_waited_for_consumer_us": out[5]}
+
     def comm_count(self):
         """ranks of the library's RCCL communicator (ncclCommCount); 0 without one"""
         n = C.c_int32(0)

@@ -319,6 +319,11 @@ int emx_timer_stop(emx_ctx* ctx, float* ms);       /* record + synchronize + ela
 int emx_profile_enable(emx_ctx* ctx, int32_t max_launches);
 int emx_profile_read(emx_ctx* ctx, float* ms_out, int32_t* n_inout);
 
+/* exact (MT19937) mode: microseconds per produced step of the host plan pipeline's stages while it is alive -- out[0] wall
+ * clock, [1] generator (twist + temper), [2] tokenizer (the serial walk of the stream: rejection tests), [3] finishers (summed
+ * over the threads), [4] tokenizer waiting for words, [5] tokenizer waiting for a free staging buffer (i.e. for the consumer) */
+int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int32_t* finisher_threads);
+
 /* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------------------- */
 typedef struct emx_mt emx_mt;
 emx_mt* emx_mt_create(const uint32_t key[624], int32_t pos, int32_t has_gauss, double cached);
