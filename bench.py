@@ -907,6 +907,50 @@ def torch_all_ok(dist, ok):
 
 
 
+# ------------------------------------------------------------------------------------------------ --pmc
+def refresh_pmc_traffic(args):
+    """`--pmc`: HBM traffic of the headline kernel measured NOW instead of read from profiles/pmc_traffic.json -- this command is
+    re-run under rocprofv3 with FETCH_SIZE and with WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md, HBM section: the two
+    counters are not collected together; FETCH_SIZE is doubled on gfx950), medians per launch of the stretch / dense half-step.
+    -> (bytes per launch, source text) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        return None, "rocprofv3 not on PATH"
+    med = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="emx_pmc_")
+        cmd = [prof, "--pmc", ctr, "-d", d, "-o", "p", "-f", "csv", "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "10",
+               "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+        env = dict(os.environ)
+        env.setdefault("TMPDIR", "/tmp")
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, env=env, cwd=ROOT)
+            agg = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_halfstep<8, 2, 4, 0, 4, 1>" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        agg[r.get("Grid_Size", "")].append(float(r["Counter_Value"]))
+            vals = max(agg.values(), key=len) if agg else []
+            if len(vals) < 8:
+                return None, "rocprofv3 --pmc %s produced no samples of the half-step kernel" % ctr
+            med[ctr] = statistics.median(vals)
+        except Exception as e:  # noqa: BLE001
+            return None, "rocprofv3 --pmc %s failed: %r" % (ctr, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    nbytes = (2.0 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0
+    return nbytes, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of this command, medians per launch: "
+                    "%.1f KB / %.1f KB; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE doubled per the gfx950 correction)"
+                    % (med["FETCH_SIZE"], med["WRITE_SIZE"]))
+
+
 # ------------------------------------------------------------------------------------------------ self-launch (N > 1)
 def _free_port():
     import socket
@@ -1016,6 +1060,9 @@ def main(argv=None):
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no configs / exact_mode / quality)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="N=1: re-measure roofline.traffic (HBM bytes per launch) with two rocprofv3 --pmc passes of this command "
+                         "instead of reading profiles/pmc_traffic.json")
     ap.add_argument("--single-block", action="store_true", help="time one K-step block instead of the median of >= 50 ms of blocks")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded RCCL path even at world size 1 (testing)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
@@ -1073,6 +1120,16 @@ def main(argv=None):
         except Exception:  # noqa: BLE001
             traffic = None
 
+    traffic_source = ("profiles/pmc_traffic.json (static: rocprofv3 PMC passes of an earlier run of this command, FETCH_SIZE x2 gfx950 "
+                      "correction + WRITE_SIZE; not re-measured here; `bench.py --pmc` re-measures)")
+    if args.pmc and not sharded:
+        fresh, why = refresh_pmc_traffic(args)
+        if fresh is not None:
+            traffic, traffic_source = fresh, why
+        else:
+            log("--pmc:", why)
+            traffic_source += " [--pmc failed: %s]" % why
+
     def headline(wl, wall_s, gpu_ms, per_launch_us, accept, status, how, extra):
         B = wl.bytes_per_update(args.store)
         lps = wl.launches_per_step()
@@ -1091,8 +1148,7 @@ def main(argv=None):
             "steps_per_s": K / wall_s, "accept_frac": accept, "device_status": status,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 PMC passes of an earlier run of this command, "
-                                           "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; not re-measured here)",
+                         "traffic_source": traffic_source,
                          "kernel": "emx::k_halfstep<8,2,4,STRETCH,DPB=4,LEAN> (G=8 lanes/walker, V=2, CH=4; f64 MFMA dense target)",
                          "algorithmic_bytes_per_walker_update": B, "walker_updates_per_launch": slots_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "per_launch_event_us": per_launch_us,
