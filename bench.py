@@ -445,7 +445,7 @@ def exact_mode_entry(wl, K, W, device):
             "pipeline_stage_us_per_step": res.get("pipeline"),
             "note": "host_plan_ms = one step's plan made inline by ONE host thread (emx_host_plan_mt, no GPU) -- round 1's path; emx_run "
                     "now takes its plans from the host pipeline (csrc/emx_mtpipe.cpp: MT19937 generator thread, tokenizer thread, "
-                    "four finisher threads confined to one L3 domain, uploads on a side stream), so ms_per_step is the pipeline's rate; "
+                    "finisher threads -- six where the L3 domain has room -- confined to that domain, uploads on a side stream), so ms_per_step is the pipeline's rate; "
                     "pipeline_stage_us_per_step says which stage bounds it on THIS host (the stages run concurrently: the largest of "
                     "generator / tokenizer / finishers-summed over the thread count is the pipeline's floor)"}
 

@@ -659,9 +659,18 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     m.sinks.assign(sinks, sinks + nsinks);
     m.nsinks = nsinks;
     int K = nworkers;
+    const CpuSet cs = pipeline_cpus();
     if (K <= 0) {
+        // CPUs the threads may actually run on: the L3 domain they are confined to, else what the machine reports.  Six finishers
+        // where there is room (round 3, MI355X host, 16 CPUs in the domain: 0.078-0.082 -> 0.063 ms/step at 65 536 walkers, eight
+        // no better: 0.061-0.063; the finishers' writes into cache-cold pinned memory were the slowest stage at four, 84 us per
+        // thread and step against 69 for the generator) -- generator + tokenizer + finishers + the caller must fit.
+#if defined(__linux__)
+        const unsigned hw = cs.valid ? (unsigned)CPU_COUNT(&cs.set) : std::thread::hardware_concurrency();
+#else
         const unsigned hw = std::thread::hardware_concurrency();
-        K = hw >= 16 ? 4 : hw >= 8 ? 3 : hw >= 4 ? 2 : 1;       // four finishers keep up with the tokenizer (tools/mt_pipe_bench.py)
+#endif
+        K = hw >= 14 ? 6 : hw >= 10 ? 4 : hw >= 6 ? 3 : hw >= 4 ? 2 : 1;
     }
     K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(K, nsinks), nsteps));
     m.K = K;
@@ -709,7 +718,6 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     m.fin_wait_ns.assign(K, 0);
     m.fin_busy_ns.assign(K, 0);
     m.t_start = now_ns();
-    const CpuSet cs = pipeline_cpus();
     // One physical core per thread is the fastest placement on an idle host (0.080 vs 0.100 ms/step at 65 536 walkers) and the
     // slowest when another tenant of the machine occupies one of the chosen cores (0.19 seen): opt-in (EMX_PIPE_CORE_PINNING=1);
     // by default the threads may move inside the L3 domain.
