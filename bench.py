@@ -64,10 +64,13 @@ def algorithmic_bytes(ndim, kind, store):
 class Workload(object):
     """One BASELINE.json configuration: synthetic inputs + how to install it on a DeviceEnsemble."""
 
-    def __init__(self, key, nwalkers):
+    def __init__(self, key, nwalkers, make_p0=True):
+        """make_p0=False: the description only (sizes, moves, byte formulas) -- the N > 1 orchestrators never touch the ensemble,
+        and a weak-scaled start state is gigabytes of host normals per process"""
         from emcee_amd import _lib
         self.key = key
         self.N = int(nwalkers)
+        self._make_p0 = make_p0
         std = lambda kind, D, S=2: _lib.MoveDesc({"stretch": 0, "de": 1, "snooker": 2}[kind], 4 if kind == "snooker" else S, 1, 0,  # noqa: E731
                                                  2.0, 1e-5, 2.38 / np.sqrt(2 * D), 1.7)
         rs = np.random.RandomState(1)
@@ -76,7 +79,7 @@ class Workload(object):
             mu, cov, icov = dense_gaussian(self.D)
             self.params = (mu, cov, icov)
             self.target = (_lib.TARGET_DENSE, mu, icov, 0.0)
-            self.p0 = mu + rs.randn(self.N, self.D) @ np.linalg.cholesky(cov).T      # equilibrium start
+            self.p0 = mu + rs.randn(self.N, self.D) @ np.linalg.cholesky(cov).T if make_p0 else None     # equilibrium start
             if key == "c2":
                 self.moves, self.weights = [("stretch", std("stretch", 64))], [1.0]
                 self.label = "configs[1]: nwalkers=%d, ndim=64, dense-precision Gaussian, StretchMove a=2.0, nsplits=2" % self.N
@@ -87,7 +90,7 @@ class Workload(object):
         elif key == "c3":
             self.D = 32
             self.target = (_lib.TARGET_ROSENBROCK, None, None, 20.0)
-            self.p0 = 1.0 + 0.1 * rs.randn(self.N, self.D)
+            self.p0 = 1.0 + 0.1 * rs.randn(self.N, self.D) if make_p0 else None
             self.moves, self.weights = [("stretch", std("stretch", 32))], [1.0]
             self.label = "configs[2]: nwalkers=%d, ndim=32, Rosenbrock/20, StretchMove a=2.0" % self.N
         elif key in ("hbm_dense", "w512", "w128"):
@@ -97,14 +100,17 @@ class Workload(object):
             mu, cov, icov = dense_gaussian(self.D)
             self.params = (mu, cov, icov)
             self.target = (_lib.TARGET_DENSE, mu, icov, 0.0)
-            self.p0 = mu + np.random.default_rng(1).standard_normal((self.N, self.D)) @ np.linalg.cholesky(cov).T
+            self.p0 = mu + np.random.default_rng(1).standard_normal((self.N, self.D)) @ np.linalg.cholesky(cov).T if make_p0 else None
             self.moves, self.weights = [("stretch", std("stretch", self.D))], [1.0]
             self.label = "nwalkers=%d, ndim=%d, dense-precision Gaussian, StretchMove a=2.0" % (self.N, self.D)
         elif key in ("c5", "hbm_wide"):
             self.D = 1024
             ivar = 1.0 / np.random.RandomState(0).rand(self.D)                        # docs/index.rst:41-45
             self.target = (_lib.TARGET_DIAG, np.zeros(self.D), ivar, 0.0)
-            if key == "c5":
+            if not make_p0:
+                self.p0 = None
+                self.label = ("configs[4]: " if key == "c5" else "") + "nwalkers=%d, ndim=1024, diagonal Gaussian, StretchMove a=2.0" % self.N
+            elif key == "c5":
                 self.p0 = rs.randn(self.N, self.D) / np.sqrt(ivar)
                 self.label = "configs[4]: nwalkers=%d, ndim=1024, diagonal Gaussian, StretchMove a=2.0" % self.N
             else:       # 262 144 x 1024: 2.1 GB of coordinates, nothing of it cache resident
@@ -711,10 +717,10 @@ def run_preflight(args, world, dist, port0, exchanges):
     return verdicts
 
 
-def sharded_workload(key, world, args):
+def sharded_workload(key, world, args, make_p0=True):
     scaling = {"c2": "weak", "c3": "strong", "c5": "strong", "w512": "weak"}[key] if args.scaling == "auto" else args.scaling
     base = {"c2": 65536, "c3": 262144, "c5": 16384, "w512": 65536}[key]
-    return Workload(key, base * world if scaling == "weak" else base), scaling
+    return Workload(key, base * world if scaling == "weak" else base, make_p0=make_p0), scaling
 
 
 def child_main(args, rank, world, local_rank):
@@ -836,7 +842,7 @@ def sharded_config(key, world, K, rank, dist, args, port0, skip):
     """Every exchange protocol on one workload, each in its own child process per rank; the fastest whose final ensemble
     agrees on all ranks (and with the first protocol's) is reported.  `skip`: protocols that already failed on an earlier
     configuration (not tried again)."""
-    wl, scaling = sharded_workload(key, world, args)
+    wl, scaling = sharded_workload(key, world, args, make_p0=False)       # the orchestrator only needs the description
     results, errors = {}, {}
     exchanges = (HEAVY_EXCHANGES if key == "w512" else EXCHANGES) if args.exchange == "all" else (args.exchange,)
     for n, ex in enumerate(exchanges):
@@ -846,7 +852,8 @@ def sharded_config(key, world, K, rank, dist, args, port0, skip):
         # the very first child also pays for cold caches (kernel modules, code objects, a slower first torch import)
         first = not _CHILDREN_RUN
         _CHILDREN_RUN.append((key, ex))
-        r = run_child(args, key, ex, port0 + n, args.exchange_timeout + (180.0 if first else 0.0))
+        # (the weak-scaled 512-dimensional ensemble is 2 GB of start state per rank to generate and upload: give it time)
+        r = run_child(args, key, ex, port0 + n, args.exchange_timeout + (180.0 if first else 0.0) + (180.0 if key == "w512" else 0.0))
         ok = r.get("error") is None and "wall_s" in r
         if not torch_all_ok(dist, ok):             # the parents' own gloo group: CPU only
             errors[ex] = r.get("error") or "failed on another rank"

@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
     SYM(emx_rng_set_philox) SYM(emx_set_state) SYM(emx_eval_state_log_prob) SYM(emx_chain_config)
     SYM(emx_run) SYM(emx_chain_read) SYM(emx_accepted_counts) SYM(emx_get_state) SYM(emx_status)
     SYM(emx_autocorr) SYM(emx_walkers_independent)
+    SYM(emx_snapshot_save) SYM(emx_snapshot_read) SYM(emx_snapshot_restore) SYM(emx_snapshot_free) SYM(emx_comm_count) SYM(emx_pipeline_stats)
     printf("version: %s\n", p_emx_version());
 
     /* host-only: MT19937 seeded with init_genrand(5489)-style key is not needed; use a fixed key */
@@ -114,6 +115,23 @@ int main(int argc, char** argv) {
     for (int i = 0; i < N; ++i) x0[i * D + 3] = 2.0 * x0[i * D + 1];          /* a linearly dependent coordinate */
     if (p_emx_walkers_independent(0, x0, N, D, &indep, &cond) != 0 || indep != 0) { fprintf(stderr, "dependent walkers accepted\n"); return 13; }
     printf("initial-state check ok\n");
+    /* a State handed out earlier stays on the device: snapshot, move on, read it back, make it current again (ensemble.py:441-447) */
+    static double xs[N * D], ls[N], xr[N * D], lr[N];
+    rc = p_emx_snapshot_save(ctx, 3);
+    rc |= p_emx_run(ctx, 20, 1, 0);
+    rc |= p_emx_snapshot_read(ctx, 3, xs, ls);
+    if (rc || memcmp(xs, xf, sizeof(xf)) != 0 || memcmp(ls, lp, sizeof(lp)) != 0) { fprintf(stderr, "snapshot differs from the state it was taken of\n"); return 14; }
+    rc |= p_emx_get_state(ctx, xr, lr);
+    if (rc || memcmp(xr, xf, sizeof(xf)) == 0) { fprintf(stderr, "the ensemble did not move on\n"); return 14; }
+    rc |= p_emx_snapshot_restore(ctx, 3);
+    rc |= p_emx_get_state(ctx, xr, lr);
+    rc |= p_emx_snapshot_free(ctx, 3);
+    if (rc || memcmp(xr, xf, sizeof(xf)) != 0 || memcmp(lr, lp, sizeof(lp)) != 0) { fprintf(stderr, "snapshot restore failed\n"); return 14; }
+    int32_t ranks = -1, fin = -1;
+    int64_t produced = -1;
+    double stage[6];
+    if (p_emx_comm_count(ctx, &ranks) != 0 || ranks != 0 || p_emx_pipeline_stats(ctx, stage, &produced, &fin) != 0 || produced != 0) return 15;
+    printf("snapshots ok\n");
     p_emx_destroy(ctx);
     return 0;
 }

@@ -225,3 +225,66 @@ def test_a_users_hip_kernel_through_the_c_abi(tmp_path):
     # three launches per split instead of one: the library's propose + commit passes are ~19 us of every split (1.6x the fused
     # step before the user's kernel does anything); this test kernel adds 22 us per launch (profiles/r03/callback_user_kernel_stats.csv)
     assert out["user kernel"] < 5 * out["fused"]
+
+
+@pytest.mark.parametrize("exchange", ["replay", "allgather", "logprob"])
+def test_device_callable_under_the_sharded_exchanges(exchange):
+    """The caller's device log-prob with the ensemble sharded over logical ranks: every rank evaluates only its share of each
+    split through the callback (the replay and all-gather exchanges) or the shares of the log-prob exchange; every replica's
+    chain equals the single-rank chain of the same callable."""
+    import torch
+    from emcee_amd import _lib
+    from emcee_amd.parallel import DeviceEngine
+    name, world, nst = "stretch_256x16_dense", 3, 6
+    g = load_golden(name)
+    spec = cases.build(name)
+    fn = torch_target(spec["desc"])
+    rows = {"n": 0}
+
+    def make(counted):
+        from test_gpu_parity import make_ens
+        ens = make_ens(spec, g["p0"])
+        ens.set_target_callback((lambda q: (rows.__setitem__("n", rows["n"] + q.shape[0]), fn(q))[1]) if counted else fn)
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(99, 0)
+        ens.set_tuning("small_kernel", 0)
+        ens.eval_state_log_prob()
+        ens.chain_config(nst)
+        return ens
+
+    ref = make(False)
+    ref.run(nst, 1, True)
+    ref_chain, ref_lp = ref.chain_read(0, 0, nst), ref.chain_read(1, 0, nst)
+    ref.close()
+    engines = [DeviceEngine(make(True), r, world, torch.device("cuda", 0), exchange=exchange) for r in range(world)]
+    rows["n"] = 0
+    for _ in range(nst):
+        res = [e.step_begin(True) for e in engines]
+        for split in range(res[0][1]):
+            if exchange == "replay":
+                n = [e.replay_begin(split) for e in engines][0]
+            elif exchange == "logprob":
+                n = [e.logprob_begin(split) for e in engines][0]
+            else:
+                for e in engines:
+                    e.halfstep(split)
+                n = engines[0].sendbuf.shape[0]
+            for e in engines:
+                e.ens.sync()
+            for dst in engines:
+                for r, src in enumerate(engines):
+                    if exchange == "logprob":
+                        if src is not dst:
+                            dst.gathered[r * n:(r + 1) * n] = src.gathered[r * n:(r + 1) * n]
+                    else:
+                        dst.gathered[r * n:(r + 1) * n] = src.sendbuf[:n]
+            torch.cuda.synchronize()
+            for e in engines:
+                (e.replay_finish if exchange == "replay" else e.logprob_finish if exchange == "logprob" else e.scatter_gathered)(split)
+        for e in engines:
+            e.step_end()
+    for e in engines:
+        assert e.ens.status() == 0
+        assert np.array_equal(e.ens.chain_read(0, 0, nst), ref_chain) and np.array_equal(e.ens.chain_read(1, 0, nst), ref_lp)
+        e.ens.close()
+    assert rows["n"] == nst * spec["N"]                 # every proposal went through the callable exactly once across the ranks
