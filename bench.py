@@ -525,14 +525,12 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
     wl.install(ens, "philox")
     push = exchange == "replay_push"          # the replay exchange with the decisions stored into the peers' buffers (no collective)
     if push:
-        if comm_mode == "torch":
-            raise RuntimeError("the device-side replay exchange is driven by libemx itself (--comm rccl)")
         exchange = "replay"
     ens.set_exchange(exchange)
     if direct_timeout_ms:
         ens.set_tuning("direct_timeout_ms", int(direct_timeout_ms))
     comm_used = None
-    if comm_mode == "torch":
+    if comm_mode == "torch" and not push:
         if exchange == "direct":
             raise RuntimeError("the direct exchange is driven by libemx itself (--comm rccl)")
         from emcee_amd.parallel import DeviceEngine, PullStepper, ShardedStepper
@@ -552,11 +550,19 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
             stepper = ShardedStepper(eng, gather)
         run = lambda k: stepper.run(k, 1, False)  # noqa: E731
         comm_used = "torch.distributed(nccl)"
+    elif push:
+        # no collective library anywhere on this path: the ranks map each other's receive buffers and barrier flags (hipIpc
+        # handles over the gloo bootstrap group) and emx_run exchanges the decisions with plain stores + the device-side barrier
+        from emcee_amd.parallel import import_direct_peers
+        ens.set_shard(rank, world)
+        import_direct_peers(ens, dist)
+        run = lambda k: ens.run(k, 1, False)  # noqa: E731
+        comm_used = "hipIpc stores + device-side barrier (no collective library)"
     else:
         uid = [DeviceEnsemble.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ens.comm_init(rank, world, uid[0])      # ncclCommInitRank; emx_run now exchanges per half-step
-        if exchange == "direct" or push:        # map the peers' coordinate arrays / receive buffers and barrier flags (IPC handles over gloo)
+        if exchange == "direct":                # map the peers' coordinate arrays and barrier flags (IPC handles over gloo)
             from emcee_amd.parallel import import_direct_peers
             import_direct_peers(ens, dist)
         run = lambda k: ens.run(k, 1, False)  # noqa: E731
@@ -568,6 +574,7 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
         dist.barrier()
         torch.cuda.synchronize()
 
+    dist.barrier()                # the ranks enter the first step together (the device-side barriers are bounded, not patient)
     for _ in range(6):            # a FIXED count: every rank must issue the same collectives
         run(5)
         ens.sync()
@@ -602,9 +609,11 @@ def measure_sharded(wl, K, W, exchange, rank, world, local_rank, dist, comm_mode
     res = {"wall_s": float(np.median(walls)), "gpu_ms": float(np.median(gpus)), "blocks": nblk, "comm": comm_used,
            "exchange": "replay_push" if push else exchange, "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(),
            "digest": digest, "replicas_agree": len(set(every)) == 1}
-    res.update(_rank_census(ens, dist, comm_mode, local_rank))
-    if comm_mode != "torch":
+    res.update(_rank_census(ens, dist, "peers" if push else comm_mode, local_rank))
+    if comm_mode != "torch" and not push:
         ens.comm_destroy()
+    if push:
+        dist.barrier()                          # nobody unmaps while a peer may still store into its buffers
     ens.close()
     return res
 
@@ -614,7 +623,10 @@ def _rank_census(ens, dist, comm_mode, local_rank):
     torch process group's size) and how many DISTINCT devices the ranks sit on: n_gpus = N is only claimed when both say N."""
     import torch
     try:
-        ranks = ens.comm_count() if comm_mode != "torch" else dist.get_world_size()
+        if comm_mode == "peers":               # device-side replay exchange: the ranks whose buffers this rank mapped (itself included)
+            ranks = dist.get_world_size()
+        else:
+            ranks = ens.comm_count() if comm_mode != "torch" else dist.get_world_size()
     except Exception as e:  # noqa: BLE001
         log("comm_count failed:", e)
         ranks = None

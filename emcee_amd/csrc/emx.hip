@@ -2583,7 +2583,9 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
     NEED(c, thin_by >= 1, "Invalid thinning argument");
     NEED(c, c->rng_mode != EMX_RNG_INPUTS, "emx_run needs an RNG mode that generates plans");
     NEED(c, c->target != EMX_TARGET_HOST, "emx_run needs a device target");
-    NEED(c, (c->world == 1 && !c->sendbuf) || c->comm,
+    // the device-side replay exchange needs no collective library at all: mapped peers are enough
+    const bool push_replay = c->exchange == EMX_EXCHANGE_REPLAY && c->peers_ready;
+    NEED(c, (c->world == 1 && !c->sendbuf) || c->comm || push_replay || (c->world == 1 && c->exchange == EMX_EXCHANGE_REPLAY),
          "emx_run on a sharded context needs emx_comm_init (or drive emx_halfstep / the collective from the host layer)");
     NEED(c, c->exchange != EMX_EXCHANGE_DIRECT || c->world == 1 || c->peers_ready,
          "direct exchange: the peers' arrays are not mapped yet (emx_direct_export / emx_direct_import, or emx_direct_attach)");
@@ -2674,7 +2676,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
                     }
                     continue;
                 }
-                if (c->comm && c->exchange == EMX_EXCHANGE_REPLAY) {
+                if ((c->comm || push_replay) && c->exchange == EMX_EXCHANGE_REPLAY) {
                     // own slots fused; 8 bytes of decision per walker-update gathered; the others' accepted updates replayed
                     int64_t rows = 0;
                     rc = emx_replay_begin(c, s, &rows);
