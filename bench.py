@@ -1177,6 +1177,9 @@ def main(argv=None):
                                  "; per_launch_event_us brackets single half-step launches with hipEvents"},
         }
         line.update(extra)
+        if args.all_on_device is not None:
+            line["test_mode"] = ("--all-on-device %d: every rank shares ONE GPU -- a control-flow / protocol test of the N > 1 path, NOT a "
+                                 "multi-GPU measurement" % args.all_on_device)
         return line
 
     def emit(line):
