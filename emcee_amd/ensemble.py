@@ -107,8 +107,8 @@ class EnsembleSampler(object):
             if not dist.is_initialized():
                 raise RuntimeError("distributed=True needs an initialised torch.distributed process group "
                                    "(it is only used to bootstrap RCCL and to replicate the inputs)")
-            if exchange not in ("allgather", "pull", "direct", "logprob", "replay"):
-                raise ValueError("exchange must be 'allgather', 'pull', 'direct' or 'logprob'")
+            if exchange not in ("allgather", "pull", "direct", "logprob", "replay", "replay_push"):
+                raise ValueError("exchange must be 'allgather', 'pull', 'direct', 'logprob', 'replay' or 'replay_push'")
             self._dist = dist
             self._exchange = exchange
             self._comm_ready = False
@@ -220,6 +220,16 @@ class EnsembleSampler(object):
             return
         from .device import DeviceEnsemble
         rank, world = self._dist.get_rank(), self._dist.get_world_size()
+        if self._exchange == "replay_push":
+            # the replay exchange with the decisions stored straight into the peers' buffers: no collective library involved,
+            # the ranks only map each other's receive buffers and barrier flags (IPC handles over the process group)
+            from .parallel import import_direct_peers
+            ens.set_exchange("replay")
+            ens.set_shard(rank, world)
+            import_direct_peers(ens, self._dist)
+            self._dist.barrier()
+            self._comm_ready = True
+            return
         uid = self._replicate(DeviceEnsemble.rccl_unique_id() if rank == 0 else None)
         ens.set_exchange(self._exchange)
         ens.comm_init(rank, world, uid)
