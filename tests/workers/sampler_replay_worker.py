@@ -45,7 +45,18 @@ def main():
             return s.get_chain(), s.get_log_prob(), s.acceptance_fraction, np.asarray(st.coords)
         ref = run()
         got = run(distributed=True, exchange="replay_push")
-        same = all(np.array_equal(a, b) for a, b in zip(ref, got))
+        if label == "dense":
+            same = all(np.array_equal(a, b) for a, b in zip(ref, got))
+        else:
+            # a torch callable's rounding may depend on the size of the block it is handed (the library behind `@` picks its
+            # tiling by shape), and a rank hands it its SHARE of a split: the log-probs agree to rounding, the decisions -- hence
+            # the coordinates -- exactly
+            same = np.array_equal(ref[0], got[0]) and np.array_equal(ref[2], got[2]) and np.array_equal(ref[3], got[3]) and \
+                np.allclose(ref[1], got[1], rtol=1e-12, atol=1e-13)
+        if not same:
+            print("SAMPLER_REPLAY rank %d %s: chain equal %s (max |d| %.3g), log-prob max |d| %.3g, acceptance equal %s" % (
+                rank, label, np.array_equal(ref[0], got[0]), float(np.max(np.abs(ref[0] - got[0]))), float(np.max(np.abs(ref[1] - got[1]))),
+                np.array_equal(ref[2], got[2])), flush=True)
         print("SAMPLER_REPLAY rank %d %s %s" % (rank, label, "OK" if same else "MISMATCH"), flush=True)
         ok = ok and same
         dist.barrier()
