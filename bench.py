@@ -95,7 +95,8 @@ class Workload(object):
             self.label = "configs[2]: nwalkers=%d, ndim=32, Rosenbrock/20, StretchMove a=2.0" % self.N
         elif key in ("hbm_dense", "w512", "w128"):
             # C2's target at other sizes: hbm_dense = 1 048 576 x 64 (537 MB of coordinates: past the 256 MB Infinity Cache);
-            # w512 / w128 = 65 536 walkers on a 512- / 128-dimensional dense Gaussian (the MFMA-bound wide path, emx_wide.hip)
+            # w512 = 65 536 walkers on a 512-dimensional dense Gaussian (the MFMA-bound wide path, emx_wide.hip); w128 = on a
+            # 128-dimensional one: the widest target the FUSED half-step kernel takes (round 3; the wide path before)
             self.D = {"hbm_dense": 64, "w512": 512, "w128": 128}[key]
             mu, cov, icov = dense_gaussian(self.D)
             self.params = (mu, cov, icov)
@@ -1203,7 +1204,7 @@ def main(argv=None):
                     continue
                 name = {"c3": "c3_262144x32_rosen", "c4": "c4_de_snooker", "c5": "c5_16384x1024_diag", "c2": "c2_store",
                         "hbm_dense": "hbm_1048576x64_dense", "hbm_wide": "hbm_262144x1024_diag", "w512": "wide_65536x512_dense",
-                        "w128": "wide_65536x128_dense"}[key]
+                        "w128": "dense_65536x128_fused"}[key]
                 try:
                     w2 = wl if key == "c2" else Workload(key, n)
                     Ks = K if not st else min(K, 200)          # stored chain: 33.5 MB per step
@@ -1211,7 +1212,11 @@ def main(argv=None):
                         Ks = max(4, min(K, 20))                # 0.2 - 1.5 ms per step: a few steps fill the timed 50 ms
                     r2 = measure_single(w2, Ks, min(W, Ks), device=local_rank, rng="philox", store=st, single_block=args.single_block,
                                         spin_s=0.05 if key.startswith(("hbm", "w")) else 0.15)
-                    cfgs[name] = wide_entry(w2, r2, Ks) if key in ("w512", "w128") else config_entry(w2, r2, Ks, st)
+                    cfgs[name] = wide_entry(w2, r2, Ks) if key == "w512" else config_entry(w2, r2, Ks, st)
+                    if key == "w128":     # fused: HBM roofline as for C2; the contraction is 5.4 flop per byte here (C2: 2.7)
+                        fl = float(w2.D) ** 2 + 3.0 * w2.D
+                        cfgs[name]["roofline"]["mfma_f64_frac_wall_clock"] = cfgs[name]["wu_per_s"] * fl / 1e12 / MFMA_F64_PEAK_TFLOPS
+                        cfgs[name]["roofline"]["kernel"] = "emx::k_halfstep<16,2,4,STRETCH,DPB=8,LEAN> (144 f64 MFMAs per 16-row tile)"
                 except Exception as e:  # noqa: BLE001
                     cfgs[name] = {"error": repr(e)}
                     log("config %s failed: %r" % (name, e))

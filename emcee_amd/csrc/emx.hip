@@ -567,14 +567,14 @@ hipError_t launch_dense(int dpb, int V, dim3 grid, dim3 block, size_t lds, hipSt
     if (dpb == b && V == v && lean_kind(a, dense_g(b, v), v, dense_ch(b, v), MOVE, true) == 1)       \
         return launch_one<dense_g(b, v), v, dense_ch(b, v), MOVE, b, 1>(grid, block, lds, st, a);
         EMX_LEAN_CASE(1, 1) EMX_LEAN_CASE(2, 1) EMX_LEAN_CASE(3, 1) EMX_LEAN_CASE(4, 1) EMX_LEAN_CASE(5, 1) EMX_LEAN_CASE(6, 1)
-        EMX_LEAN_CASE(7, 1) EMX_LEAN_CASE(1, 2) EMX_LEAN_CASE(2, 2) EMX_LEAN_CASE(3, 2) EMX_LEAN_CASE(5, 2) EMX_LEAN_CASE(6, 2)
-        EMX_LEAN_CASE(7, 2)
+        EMX_LEAN_CASE(7, 1) EMX_LEAN_CASE(8, 1) EMX_LEAN_CASE(1, 2) EMX_LEAN_CASE(2, 2) EMX_LEAN_CASE(3, 2) EMX_LEAN_CASE(5, 2)
+        EMX_LEAN_CASE(6, 2) EMX_LEAN_CASE(7, 2) EMX_LEAN_CASE(8, 2)
 #undef EMX_LEAN_CASE
     }
 #define EMX_CASE(b, v) \
     if (dpb == b && V == v) return launch_one<dense_g(b, v), v, dense_ch(b, v), MOVE, b>(grid, block, lds, st, a);
-    EMX_CASE(1, 1) EMX_CASE(2, 1) EMX_CASE(3, 1) EMX_CASE(4, 1) EMX_CASE(5, 1) EMX_CASE(6, 1) EMX_CASE(7, 1)
-    EMX_CASE(1, 2) EMX_CASE(2, 2) EMX_CASE(3, 2) EMX_CASE(4, 2) EMX_CASE(5, 2) EMX_CASE(6, 2) EMX_CASE(7, 2)
+    EMX_CASE(1, 1) EMX_CASE(2, 1) EMX_CASE(3, 1) EMX_CASE(4, 1) EMX_CASE(5, 1) EMX_CASE(6, 1) EMX_CASE(7, 1) EMX_CASE(8, 1)
+    EMX_CASE(1, 2) EMX_CASE(2, 2) EMX_CASE(3, 2) EMX_CASE(4, 2) EMX_CASE(5, 2) EMX_CASE(6, 2) EMX_CASE(7, 2) EMX_CASE(8, 2)
 #undef EMX_CASE
     return hipErrorInvalidValue;
 }
@@ -615,7 +615,10 @@ int prefetch_depth_host(int G, int V, int CH, int move, bool dense) {
 }
 
 // dense Gaussian targets whose Cholesky image does not fit LDS next to the MFMA tiles (or tuning "dense_wide" = 1, for tests)
-inline bool dense_is_wide(const emx_ctx* c) { return c->Dp > 112 || c->tune_dense_wide; }
+// The fused kernel holds the packed triangular image of L plus one 16-row tile per wave in LDS: up to padded ndim 128
+// (36 blocks = 72 KB + 4 waves x 16.6 KB; round 3 -- 112 with 8- and 4-wave groups before)
+constexpr int DENSE_FUSED_MAX_DP = 128;
+inline bool dense_is_wide(const emx_ctx* c) { return c->Dp > DENSE_FUSED_MAX_DP || c->tune_dense_wide; }
 
 // launch one fused (or propose-only) half-step over the slots [t_lo, t_hi) of `split`
 int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, int ns, int t_lo, int t_hi,
@@ -773,7 +776,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         while (waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
         lds = dense_lds_bytes(c->Dp, waves_per_block);
         if (lds > 160 * 1024) {
-            c->err = "dense Gaussian target: ndim too large for the LDS-resident precision matrix (max 112)";
+            c->err = "dense Gaussian target: ndim too large for the LDS-resident precision matrix (max 128)";
             return -1;
         }
     }
@@ -1430,7 +1433,7 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
                         if (k < n && col < n && k >= col) img[((size_t)nb * KK + kk) * 64 + l] = Lm[(size_t)k * n + col];
                     }
             for (int d = 0; d < n; ++d) img[(size_t)Dp * Dp + d] = p0[d];
-            if (Dp <= 112) {
+            if (Dp <= DENSE_FUSED_MAX_DP) {
                 // the fused kernel and k_small_run stage only the non-zero 16 x 16 blocks (dense_block, emx_kernels.hpp); the
                 // full image stays next to it for the wide-target kernels (tuning "dense_wide")
                 HIPOK(c, hipMalloc((void**)&ntpf, img.size() * 8));

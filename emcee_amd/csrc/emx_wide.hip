@@ -1,4 +1,4 @@
-// Dense Gaussian targets too wide for the LDS-resident precision matrix (padded ndim > 112): the half-step is
+// Dense Gaussian targets too wide for the LDS-resident precision matrix (padded ndim > 128): the half-step is
 //   k_halfstep (propose only: q, factor -> qout / fout)  ->  k_wide_lp  ->  k_wide_commit
 // all on the device, on the context's stream.  The reference evaluates the same thing as one vectorised log_prob_fn
 // call on the proposal block (ensemble.py:486-501, compute_log_prob) between get_proposal and the accept loop

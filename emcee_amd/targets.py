@@ -75,7 +75,7 @@ class DenseGaussian(DeviceTarget):
     """log p = -0.5 (x - mean)^T icov (x - mean)   (reference docs/tutorials/quickstart.ipynb:76).
 
     Evaluated with v_mfma_f64_16x16x4_f64 against the Cholesky factor of ``icov``: LDS-resident and fused into the
-    half-step kernel up to ndim 112, streamed through LDS by a log-prob kernel of its own up to ndim 2048."""
+    half-step kernel up to ndim 128, streamed through LDS by a log-prob kernel of its own up to ndim 2048."""
     kind = _lib.TARGET_DENSE
 
     def __init__(self, mean, icov):

@@ -10,7 +10,7 @@ from emcee_amd.device import DeviceEnsemble    # noqa: E402
 from bench import dense_gaussian               # noqa: E402
 
 N = 65536
-for D in (64, 80, 96, 100, 112):
+for D in (96, 112, 113, 120, 128):
     for wide in (0, 1):
         ens = DeviceEnsemble(N, D)
         mu, cov, icov = dense_gaussian(D)
