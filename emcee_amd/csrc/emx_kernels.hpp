@@ -348,6 +348,34 @@ __device__ __forceinline__ void store_row(const Row<G, V, CH>& r, double* __rest
     }
 }
 
+// Chain rows are written once and read, if ever, by a later get_chain: streaming ("nt") stores, so that 33.5 MB of them per
+// stored step do not push the ensemble itself out of the Infinity Cache.
+#ifndef EMX_OPT_NT_CHAIN
+#define EMX_OPT_NT_CHAIN 1
+#endif
+template <int G, int V, int CH>
+__device__ __forceinline__ void store_row_stream(const Row<G, V, CH>& r, double* __restrict__ base, int D, int gl) {
+#if EMX_OPT_NT_CHAIN
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int d = (c * G + gl) * V;
+        if constexpr (V == 2) {
+            if (d + 1 < D) {
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                d2v t;
+                t.x = r.x[c][0];
+                t.y = r.x[c][1];
+                __builtin_nontemporal_store(t, reinterpret_cast<d2v*>(base + d));
+            }
+        } else {
+            if (d < D) __builtin_nontemporal_store(r.x[c][0], base + d);
+        }
+    }
+#else
+    store_row<G, V, CH>(r, base, D, gl);
+#endif
+}
+
 // ----------------------------------------------------------------------------------------
 // element-wise targets evaluated from the register-resident proposal
 // ----------------------------------------------------------------------------------------
@@ -938,7 +966,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                 }
                                 if (declp_) declp_[t0 + srow - tlo_] = accept ? lp_new : __builtin_nan("");
                             }
-                            if (live && chain_) store_row<G, V, CH>(accept ? q : xi[k], chain_ + (size_t)i * D, D, gl);
+                            if (live && chain_) store_row_stream<G, V, CH>(accept ? q : xi[k], chain_ + (size_t)i * D, D, gl);
                             if (live && sendbuf_) {
                                 double* sb = sendbuf_ + (size_t)(t0 + srow - tlo_) * (D + 2);
                                 store_row<G, V, CH>(accept ? q : xi[k], sb, D, gl);
@@ -967,7 +995,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                         // stored step / sharded run: the current row goes out now (fire and forget); an accepted
                         // proposal overwrites it after the decision -- no reload of rejected rows in the commit
                         if constexpr (MOVE != MOVE_EVAL) {
-                            if (live && chain_) store_row<G, V, CH>(xi[k], chain_ + (size_t)i * D, D, gl);
+                            if (live && chain_) store_row_stream<G, V, CH>(xi[k], chain_ + (size_t)i * D, D, gl);
                             if (live && sendbuf_)
                                 store_row<G, V, CH>(xi[k], sendbuf_ + (size_t)(t0 + srow - tlo_) * (D + 2), D, gl);
                         }
@@ -1103,7 +1131,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                     }
                             }
                             store_row<G, V, CH>(rr, A.X + (size_t)wi2 * D, D, gl);
-                            if (chain_) store_row<G, V, CH>(rr, chain_ + (size_t)wi2 * D, D, gl);
+                            if (chain_) store_row_stream<G, V, CH>(rr, chain_ + (size_t)wi2 * D, D, gl);
                             if (sendbuf_) store_row<G, V, CH>(rr, sendbuf_ + (size_t)(t0 + sidx - tlo_) * (D + 2), D, gl);
                         }
                     }
@@ -1537,7 +1565,7 @@ static __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
     if (accept)
         for (int d = lane; d < A.D; d += 64) xr[d] = q[d];
     if (A.chain)
-        for (int d = lane; d < A.D; d += 64) A.chain[(size_t)i * A.D + d] = accept ? q[d] : xr[d];
+        for (int d = lane; d < A.D; d += 64) __builtin_nontemporal_store(accept ? q[d] : xr[d], &A.chain[(size_t)i * A.D + d]);
     if (lane == 0) {
         if (accept) A.lp[i] = nlp;
         A.acc[i] = accept ? 1 : 0;
@@ -2005,7 +2033,7 @@ struct StoreStepArgs {
 
 static __global__ __launch_bounds__(256) void k_store_step(const StoreStepArgs A) {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < A.nx; e += stride) A.chain[e] = A.X[e];
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < A.nx; e += stride) __builtin_nontemporal_store(A.X[e], &A.chain[e]);
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < A.N; w += (long long)gridDim.x * blockDim.x) {
         A.chain_lp[w] = A.lp[w];
         A.acc_count[w] += A.acc[w];

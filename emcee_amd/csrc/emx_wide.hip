@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_wide_commit(const WideCommitArgs A) {
             for (int d = lane; d < D; d += 64) {
                 const double v = accept ? q[d] : xr[d];
                 if (accept) xr[d] = v;
-                if (ch) ch[d] = v;
+                if (ch) __builtin_nontemporal_store(v, &ch[d]);          // chain rows stream past the Infinity Cache (store_row_stream)
                 if (sb) sb[d] = v;
             }
         }
