@@ -1677,7 +1677,9 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
     // 262 144), not by its arithmetic.  The fused half-step reads order, p0 (+ p1 for DE, + p1, p2 for the snooker move), s0
     // (not the snooker move), logu and fac -- never uacc, whose logarithm it is handed.  A lean plan leaves the other columns
     // unwritten: 32 instead of 48 bytes per entry for the stretch move.  Whoever wants them (emx_plan_get: the parity tests; the
-    // split-phase and sharded paths) gets a full plan.
+    // split-phase and sharded paths) gets a full plan.  (Streaming stores for these columns -- written once, read once -- were
+    // measured: the half-step then fetches its plan entries from HBM instead of the Infinity Cache, C2 23.61 -> 24.19 us/step,
+    // C3 stored 57.5 -> 61.5; profiles/r03/ab_nt_plan_stores.txt.)
     const bool full = !B.lean;
     if (B.ablate & 2) {                                  // timing experiments: keep the arithmetic alive, write one word
         if (i + a0 + a1 + a2 == -12345 && z + u == 1.2345e-300) B.order[b][pos] = i;
