@@ -75,8 +75,8 @@ int emx_set_stream(emx_ctx* ctx, void* hip_stream);
 int emx_sync(emx_ctx* ctx);
 /* sticky device status: bit0 NaN log-prob (ensemble.py:550-551), bit1 non-finite coordinate
  * (ensemble.py:476-479), bit2 pull-exchange record capacity exceeded (a >8 sigma event: the run is
- * invalid, never silently wrong), bit3 direct exchange: a peer did not reach the device-side barrier in time.
- * Reading clears it. */
+ * invalid, never silently wrong), bit3 direct / replay exchange: a peer did not reach the device-side barrier in time
+ * (raised again by every later barrier of that attachment).  Reading clears it. */
 int emx_status(emx_ctx* ctx, uint32_t* bits);
 /* keys: "spw", "blocks_per_cu", "waves_per_block", "prep_hint", "graph", "throttle", "gauss_materialize",
  * "small_kernel" (1: ensembles that fit one CU's LDS run whole emx_run calls in one workgroup; default),
@@ -84,7 +84,12 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  * count (default); k > 0: k finisher threads; 0: plans made inline by the calling thread),
  * "dense_wide" (1: dense targets take the propose / log-prob / commit path of wide targets whatever the ndim; 2: the same with
  * the single-role log-prob kernel even where the role-split one applies; parity tests),
- * "phase_clock" (instrumented builds) */
+ * "full_plan" (1: native plans carry every column; default 0: only the ones the fused kernel of the step's move reads),
+ * "direct_timeout_ms" (device-side barriers of the direct and replay exchanges; the first barrier of an emx_run waits 6x longer),
+ * "ablate" (timing experiments: bits 0-7 half-step phases, bits 8.. plan kernel), "phase_clock" (instrumented builds).
+ * The environment variable EMX_TUNE="key=value,key=value" applies keys to every context at creation (A/B measurements through
+ * unmodified callers).  After a barrier timeout (status bit 3) the context refuses further sharded half-steps until the peers are
+ * attached again (emx_direct_export / _import or _attach on every rank). */
 int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value);
 
 /* ---- state: State(coords, log_prob) (state.py:10-45) ---------------------------------- */
