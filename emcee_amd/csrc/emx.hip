@@ -415,6 +415,9 @@ struct emx_ctx {
     int64_t replay_buf = 0;                   // doubles per receive buffer (there are two: the device-side exchange alternates)
     int replay_push_parity = 0;
     double* launch_declp = nullptr;           // set around a launch_split call: the launch writes its decisions here
+    bool launch_push = false;                 // ... and (device-side exchange) into every peer's receive buffer at replay_recv_off
+    bool replay_pushed = false;               // the own pass of this half-step did push (a fused launch): no push kernel needed
+    int64_t launch_push_off = 0;
     bool eval_check_bad = false;              // MOVE_EVAL over proposals (log-prob exchange): non-finite rows get -inf, as in the fused path
     bool direct_dead = false;                 // a barrier timed out (seen by emx_status): no half-step until the peers are re-attached
     bool direct_first_barrier = false;        // the next barrier is the first of an emx_run call: the ranks may enter seconds apart
@@ -828,6 +831,12 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
     a.chain_lp_all = c->chain_lp;
     a.t_hi_dev = t_hi_dev;
     a.declp = c->launch_declp;
+    if (c->launch_declp && c->launch_push && c->peer_table) {      // fused own pass of the device-side replay exchange
+        a.push_peers = c->peer_table;
+        a.npush = c->world;
+        a.push_off = c->launch_push_off;
+        c->replay_pushed = true;
+    }
     if (move == MOVE_GAUSS && mv) {
         const bool in_registers = c->cur.active && c->cur.native && !c->tune_gauss_materialize;
         a.disp = in_registers ? nullptr : c->disp;
@@ -3072,17 +3081,19 @@ int emx_replay_exchange(emx_ctx* c, int32_t split) {
     const int ns = cur.off[split + 1] - cur.off[split];
     const int64_t rows = ((int64_t)ns + c->world - 1) / c->world;
     const int64_t G = c->world;
-    c->replay_recv_off = (int64_t)c->replay_push_parity * c->replay_buf;
-    c->replay_push_parity ^= 1;
     if (G == 1 || rows <= 0) return 0;
-    PushArgs a{};
-    a.src = c->sendbuf;
-    for (int q = 0; q < G; ++q) a.peer[q] = c->peerX[q];
-    a.off = c->replay_recv_off + (int64_t)c->rank * rows;
-    a.rows = (int32_t)rows;
-    a.npeer = (int32_t)G;
-    hipLaunchKernelGGL(k_push_decisions, dim3((unsigned)((rows + 255) / 256), (unsigned)G), dim3(256), 0, c->stream, a);
-    HIPOK(c, hipGetLastError());
+    if (!c->replay_pushed) {
+        // the own pass was not a fused launch that stores into the peers itself (three-pass targets; an empty share): push now.
+        // (emx_replay_begin chose this half-step's receive buffer.)
+        PushArgs a{};
+        a.src = c->sendbuf;
+        for (int q = 0; q < G; ++q) a.peer[q] = c->peerX[q];
+        a.off = c->replay_recv_off + (int64_t)c->rank * rows;
+        a.rows = (int32_t)rows;
+        a.npeer = (int32_t)G;
+        hipLaunchKernelGGL(k_push_decisions, dim3((unsigned)((rows + 255) / 256), (unsigned)G), dim3(256), 0, c->stream, a);
+        HIPOK(c, hipGetLastError());
+    }
     PeerBarrierArgs b{};
     for (int q = 0; q < G; ++q) {
         NEED(c, c->peer_flags[q], "replay exchange: no barrier flags for rank %d", q);
@@ -3116,16 +3127,25 @@ int emx_replay_begin(emx_ctx* c, int32_t split, int64_t* rows_per_rank) {
     NEED(c, rows <= c->sendbuf_rows, "replay exchange: buffers too small for this move (call emx_set_shard after emx_set_moves)");
     if (rows_per_rank) *rows_per_rank = rows;
     c->replay_split = split;
-    c->replay_recv_off = 0;          // an all-gather fills the first receive buffer; emx_replay_exchange picks its own
+    c->replay_recv_off = 0;          // an all-gather fills the first receive buffer; the device-side exchange alternates two
+    c->replay_pushed = false;
+    const bool device_side = c->peers_ready && c->world > 1;
+    if (device_side) {
+        c->replay_recv_off = (int64_t)c->replay_push_parity * c->replay_buf;
+        c->replay_push_parity ^= 1;
+    }
     int64_t lo, hi;
     shard_range(ns, c->rank, c->world, lo, hi);
     if (hi <= lo) return 0;
+    c->launch_push = device_side;
+    c->launch_push_off = c->replay_recv_off + (int64_t)c->rank * rows;
     // own slots, fused: the plan is entered at this rank's first slot, so the launch sees slots [0, hi - lo) -- the form the
     // production (LEAN) instantiations take -- and decision e of the launch is slot lo + e
     c->launch_declp = c->sendbuf;
     rc = launch_split(c, mv.kind, c->target, cur.S, split, pos0 + (int)lo, (int)(hi - lo), 0, (int)(hi - lo), &mv, &c->ring[cur.slot], nullptr,
                       c->X, c->lp, nullptr, nullptr, nullptr);
     c->launch_declp = nullptr;
+    c->launch_push = false;
     return rc;
 }
 
@@ -3437,7 +3457,7 @@ int emx_direct_import(emx_ctx* c, const uint8_t* handles) {
         c->peer_ipc_f[q] = true;
     }
     c->peers_ready = true;
-    return c->exchange == EMX_EXCHANGE_DIRECT ? direct_publish_table(c) : 0;
+    return direct_publish_table(c);          // direct: the peers' coordinate arrays; replay: their receive buffers
 }
 
 int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_flags) {
@@ -3454,7 +3474,7 @@ int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_fl
     c->peers_ready = true;
     rc = direct_rearm(c);
     if (rc) return rc;
-    return c->exchange == EMX_EXCHANGE_DIRECT ? direct_publish_table(c) : 0;
+    return direct_publish_table(c);
 }
 
 int emx_direct_halfstep(emx_ctx* c, int32_t split, int32_t barrier) {

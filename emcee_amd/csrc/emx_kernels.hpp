@@ -145,6 +145,12 @@ struct HalfStepArgs {
     // replay exchange: the decision of every slot of this launch, 8 bytes each -- the new log-prob of an accepted proposal,
     // NaN for a rejected one (an accepted log-prob is never NaN: NaN > log u is false) -- slot t at declp[t - t_lo]
     double* declp;
+    // ... and, with the peers' receive buffers mapped (device-side replay exchange), stored straight into every one of them
+    // as well: element push_off + (t - t_lo) of push_peers->X[q], q < npush (remote stores over xGMI, fire and forget; the
+    // barrier kernel that follows publishes them)
+    const struct PeerTable* push_peers;
+    long long push_off;
+    int32_t npush;
     int32_t skew_sleep;            // EMX_OPT_SKEW experiments: extra delay of the staging waves, in s_sleep(8) units (0 in production)
 };
 
@@ -708,6 +714,15 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     const double* const disp_ = LEAN ? nullptr : A.disp;
     const int skewsl_ = LEAN ? 0 : A.skew_sleep;
     double* const declp_ = LEAN == 1 ? nullptr : A.declp;                  // LEAN 2: + the replay exchange's own pass
+    auto put_decision = [&](int idx, double v) {
+        declp_[idx] = v;
+        if (A.npush) {
+            const PeerTable* __restrict__ T = A.push_peers;
+#pragma unroll
+            for (int q = 0; q < EMX_MAX_PEERS; ++q)
+                if (q < A.npush) const_cast<double*>(T->X[q])[A.push_off + idx] = v;
+        }
+    };
     const int target_ = (LEAN && DPB > 0) ? (int)TGT_DENSE : A.target;
     static_assert(G >= 4 && G <= 64 && (64 % G) == 0, "G lanes per walker");
     constexpr bool DENSE = DPB > 0;
@@ -964,7 +979,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                     chain_lp_[i] = accept ? lp_new : lp_old;
                                     if (accept) A.acc_count[i] += 1u;
                                 }
-                                if (declp_) declp_[t0 + srow - tlo_] = accept ? lp_new : __builtin_nan("");
+                                if (declp_) put_decision(t0 + srow - tlo_, accept ? lp_new : __builtin_nan(""));
                             }
                             if (live && chain_) store_row_stream<G, V, CH>(accept ? q : xi[k], chain_ + (size_t)i * D, D, gl);
                             if (live && sendbuf_) {
@@ -1086,7 +1101,7 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
                                 chain_lp_[my_i] = lp_fin;
                                 if (acc) A.acc_count[my_i] += 1u;
                             }
-                            if (declp_) declp_[t0 + tb + myrow - tlo_] = acc ? lpn : __builtin_nan("");
+                            if (declp_) put_decision(t0 + tb + myrow - tlo_, acc ? lpn : __builtin_nan(""));
                         }
                     }
                     EMX_STAMP(8);      // decisions made, flag / log-prob stores issued
