@@ -586,16 +586,21 @@ __global__ __launch_bounds__(64 * MS_W) void k_wide_lp_ms(const WideLpArgs A) {
     }
 }
 
-// decision + commit of one half-step from (qout, fout, newlp): red_blue.py:96-101, move.py:33-34; one wave per slot
+// decision + commit of one half-step from (qout, fout, newlp): red_blue.py:96-101, move.py:33-34.  GL lanes per slot: a whole
+// wave for the wide rows this file is about, 8-32 for the narrow rows of a device-callback target (emx_set_target_callback;
+// at ndim 64 a wave per slot was 32 768 waves of four dependent loads each: 8.8 us per launch, round 3).
+template <int GL>
 __global__ __launch_bounds__(256) void k_wide_commit(const WideCommitArgs A) {
-    const int lane = threadIdx.x & 63;
+    constexpr int SPW = 64 / GL;                       // slots per wave
+    const int lane = threadIdx.x & 63, gl = lane % GL, sub = lane / GL;
     const int t_hi = A.t_hi_dev ? *A.t_hi_dev : A.t_hi;
     const int D = A.D;
-    for (int t = A.t_lo + blockIdx.x * 4 + (threadIdx.x >> 6); t < t_hi; t += gridDim.x * 4) {
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+    for (int t = A.t_lo + wave * SPW + sub; t < t_hi; t += nwave * SPW) {
         const int pos = A.pos0 + t;
         const int i = A.order[pos];
         const double nlp = A.newlp[t], lp_old = A.lp[i];
-        if (A.status && lane == 0 && nlp != nlp) raise_status(A.status, ST_NAN_LOGP);      // ensemble.py:550-551 (a caller's callback may return one)
+        if (A.status && gl == 0 && nlp != nlp) raise_status(A.status, ST_NAN_LOGP);      // ensemble.py:550-551 (a caller's callback may return one)
         const double lnpdiff = A.fout[t] + nlp - lp_old;                     // red_blue.py:99
         const bool accept = lnpdiff > A.logu[pos];                          // red_blue.py:100
         const double* q = A.qout + (size_t)t * D;
@@ -603,14 +608,14 @@ __global__ __launch_bounds__(256) void k_wide_commit(const WideCommitArgs A) {
         double* ch = A.chain ? A.chain + (size_t)i * D : nullptr;
         double* sb = A.sendbuf ? A.sendbuf + (size_t)(t - A.t_lo) * (D + 2) : nullptr;
         if (accept || ch || sb) {               // a rejected proposal of an unstored, unsharded step touches no row at all
-            for (int d = lane; d < D; d += 64) {
+            for (int d = gl; d < D; d += GL) {
                 const double v = accept ? q[d] : xr[d];
                 if (accept) xr[d] = v;
                 if (ch) __builtin_nontemporal_store(v, &ch[d]);          // chain rows stream past the Infinity Cache (store_row_stream)
                 if (sb) sb[d] = v;
             }
         }
-        if (lane == 0) {
+        if (gl == 0) {
             const double lp_fin = accept ? nlp : lp_old;
             if (accept) A.lp[i] = nlp;
             A.acc[i] = accept ? 1 : 0;
@@ -691,8 +696,13 @@ hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipS
 
 hipError_t launch_wide_commit(const WideCommitArgs& a, int nrows_bound, int num_cu, hipStream_t st) {
     if (nrows_bound <= 0) return hipSuccess;
-    const int nblocks = (nrows_bound + 3) / 4;
-    hipLaunchKernelGGL(k_wide_commit, dim3((unsigned)std::min(nblocks, 64 * num_cu)), dim3(256), 0, st, a);
+    const int gl = a.D <= 64 ? 8 : a.D <= 128 ? 16 : a.D <= 256 ? 32 : 64;           // lanes per slot
+    const int per_block = 4 * (64 / gl);
+    const int nblocks = std::min((nrows_bound + per_block - 1) / per_block, 64 * num_cu);
+    if (gl == 8) hipLaunchKernelGGL(k_wide_commit<8>, dim3((unsigned)nblocks), dim3(256), 0, st, a);
+    else if (gl == 16) hipLaunchKernelGGL(k_wide_commit<16>, dim3((unsigned)nblocks), dim3(256), 0, st, a);
+    else if (gl == 32) hipLaunchKernelGGL(k_wide_commit<32>, dim3((unsigned)nblocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_wide_commit<64>, dim3((unsigned)nblocks), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
