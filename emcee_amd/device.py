@@ -46,6 +46,14 @@ class DeviceEnsemble:
 
     def close(self):
         if getattr(self, "ctx", None):
+            ref = getattr(self, "_resident", None)
+            st = ref() if ref is not None else None
+            if st is not None:                       # a State handed out earlier still lives on this context: bring it home first
+                try:
+                    st._materialise(live=True)
+                except Exception:  # noqa: BLE001
+                    pass
+                self._resident = None
             self.lib.emx_destroy(self.ctx)
             self.ctx = None
 
