@@ -43,6 +43,8 @@ class DeviceEnsemble:
         self._gen = 0
         self._resident = None            # weakref to the ResidentState mirroring generation _gen
         self._free_slots = list(range(8))
+        import weakref
+        self._snap_states = weakref.WeakSet()   # ResidentStates whose values sit in a snapshot slot
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -54,6 +56,11 @@ class DeviceEnsemble:
                 except Exception:  # noqa: BLE001
                     pass
                 self._resident = None
+            for st in list(getattr(self, "_snap_states", ())):      # ... and the ones kept in snapshot slots
+                try:
+                    st._materialise()
+                except Exception:  # noqa: BLE001
+                    pass
             self.lib.emx_destroy(self.ctx)
             self.ctx = None
 

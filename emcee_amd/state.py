@@ -160,6 +160,7 @@ class ResidentState(State):
             self._materialise(live=True)         # no slot left: over PCIe after all
         else:
             self._slot = slot
+            self._ens._snap_states.add(self)
 
     def _materialise(self, live=None):
         if self._c is not None and self._lp is not None:
