@@ -275,6 +275,13 @@ def test_state_handed_back_unread_continues_on_the_device(rng):
     # pickling materialises
     h = pickle.loads(pickle.dumps(r2))
     assert type(h) is State and np.array_equal(h.coords, ref_end)
+    # a context that goes away brings home what still lives on it: the current state and the ones in snapshot slots
+    k = seeded()
+    s1 = k.run_mcmc(p0, 7)
+    s2 = k.run_mcmc(s1, 9)
+    assert s1._slot is not None and s2._c is None
+    k._ens.close()
+    assert np.array_equal(s1.coords, mid[0]) and np.array_equal(s2.coords, ref_end)
 
 
 def test_infinite_iterations_without_store():
