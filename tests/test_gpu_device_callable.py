@@ -69,6 +69,38 @@ def test_device_callable_reproduces_the_reference_chain(name):
     assert calls["rows"] == spec["N"] * (nprop + 1)
 
 
+def test_device_callable_sees_the_blocks_the_reference_hands_its_log_prob_fn():
+    """ensemble.py:486-487 called at red_blue.py:93: the block is q for the walkers of the split in ASCENDING WALKER INDEX
+    (s = coords[inds == split]).  Pinned with the reference's own split labels (tests/golden: `labels`, recorded from the live
+    reference): the rows of every block that were accepted must be the chain rows of exactly those walkers, at those positions."""
+    name = "stretch_50x3_iso"
+    g = load_golden(name)
+    spec = cases.build(name)
+    blocks = []
+
+    def fn(q):
+        blocks.append(q.detach().cpu().numpy().copy())
+        return -0.5 * (q * q).sum(1)
+
+    s = make_sampler(spec, g, log_prob=targets.DeviceCallable(fn))
+    s.run_mcmc(g["p0"], spec["nsteps"], skip_initial_state_check=True)
+    assert np.array_equal(s.get_chain(), g["chain"])
+    assert np.array_equal(blocks[0], g["p0"])                       # the initial state, in walker order
+    prev = g["p0"]
+    k = 1
+    for t in range(spec["nsteps"]):
+        for split in range(2):
+            members = np.nonzero(g["labels"][t] == split)[0]          # ascending walker index
+            q = blocks[k]
+            k += 1
+            assert q.shape == (len(members), spec["D"])
+            moved = np.any(g["chain"][t][members] != prev[members], axis=1)
+            assert moved.any()
+            assert np.array_equal(q[moved], g["chain"][t][members][moved])
+        prev = g["chain"][t]
+    assert k == len(blocks)
+
+
 @pytest.mark.parametrize("name", ["stretch_256x16_dense", "mix_stretch_de_64x5"])
 def test_device_callable_with_graph_capture(name):
     """graph=True: the kernels the callable launches are captured after two eager calls per split shape and replayed"""
