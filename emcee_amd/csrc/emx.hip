@@ -440,6 +440,7 @@ struct emx_ctx {
     bool graph_warm = false;         // one ordinary step has run (function attributes set, kernels loaded)
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
+    int64_t tune_replay_two_pass = 0;         // 1: the replay exchange always compacts, then replays (tests of that form)
     int64_t tune_full_plan = 0;      // 1: native plans always carry every column
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
     // timing
@@ -598,6 +599,21 @@ hipError_t dispatch_halfstep(int move, bool dense, int dpb, const Shape& sh, dim
         case MOVE_EVAL:
             return dense ? launch_dense<MOVE_EVAL>(dpb, sh.V, grid, block, lds, st, a) : launch_valu<MOVE_EVAL>(sh, grid, block, st, a);
     }
+    return hipErrorInvalidValue;
+}
+
+// the stretch move's one-launch replay (k_replay_stretch), by row layout
+hipError_t launch_replay_stretch(const Shape& sh, dim3 grid, hipStream_t st, const ReplayFusedArgs& a) {
+#define EMX_CASE(g, v, c)                                                                              \
+    if (sh.G == g && sh.V == v && sh.CH == c) {                                                        \
+        hipLaunchKernelGGL((k_replay_stretch<g, v, c>), grid, dim3(256), 0, st, a);                    \
+        return hipGetLastError();                                                                      \
+    }
+    EMX_CASE(4, 1, 1) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4) EMX_CASE(16, 1, 4) EMX_CASE(32, 1, 4)
+    EMX_CASE(64, 1, 4) EMX_CASE(64, 1, 8) EMX_CASE(64, 1, 16)
+    EMX_CASE(4, 2, 1) EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(16, 2, 4) EMX_CASE(32, 2, 4)
+    EMX_CASE(64, 2, 4) EMX_CASE(64, 2, 8) EMX_CASE(64, 2, 16)
+#undef EMX_CASE
     return hipErrorInvalidValue;
 }
 
@@ -1218,6 +1234,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "dense_wide")) {      // 1: take the wide-target path (emx_wide.hip) whatever the ndim -- parity tests against the fused kernel
         c->tune_dense_wide = v == 2 ? 2 : (v ? 1 : 0);      // 2: the wide path with the single-role log-prob kernel only
         graph_invalidate(c);
+        return 0;
+    }
+    if (!strcmp(key, "replay_two_pass")) {
+        c->tune_replay_two_pass = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "full_plan")) {     // 1: native plans with every column (default 0: what the fused kernel reads)
@@ -3160,7 +3180,33 @@ int emx_replay_finish(emx_ctx* c, int32_t split) {
     int64_t lo, hi;
     shard_range(ns, c->rank, c->world, lo, hi);
     const int64_t foreign = ns - (hi - lo);
-    if (foreign > 0) {
+    bool done = false;
+    if (foreign > 0 && mv.kind == EMX_MOVE_STRETCH && !c->tune_replay_two_pass) {
+        // the stretch move: flags + replay in one launch over the full plan (k_replay_stretch)
+        ReplayFusedArgs f{};
+        f.X = c->X;
+        f.lp = c->lp;
+        f.acc = c->acc;
+        f.order = ps.order + pos0;
+        f.p0 = ps.p0 + pos0;
+        f.s0 = ps.s0 + pos0;
+        f.gathered = c->gathered + c->replay_recv_off;
+        f.ns = ns;
+        f.G = c->world;
+        f.rank = c->rank;
+        f.rows = (int32_t)(((int64_t)ns + c->world - 1) / c->world);
+        f.D = c->D;
+        const bool dense_layout = c->target == EMX_TARGET_DENSE_GAUSS && !dense_is_wide(c);      // the layout that took the decisions
+        const Shape sh = pick_shape(c->D, dense_layout ? c->Dp : c->D);
+        const int64_t nchunks = ((int64_t)ns + 63) / 64;
+        const hipError_t e = launch_replay_stretch(sh, dim3((unsigned)((nchunks + 3) / 4)), c->stream, f);
+        if (e == hipSuccess)
+            done = true;
+        else if (e != hipErrorInvalidValue)
+            FAIL(c, -2, "replay launch failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
+    if (foreign > 0 && !done) {
         ReplayCompactArgs a{};
         a.order = ps.order + pos0;
         a.p0 = ps.p0 + pos0;

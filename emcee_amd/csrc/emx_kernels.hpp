@@ -2018,6 +2018,67 @@ static __global__ __launch_bounds__(256) void k_replay_compact(const ReplayCompa
     }
 }
 
+// The stretch move's replay in ONE launch (the configurations that are measured at N > 1 all use it): a wave scans 64 slots of the
+// split -- one decision per lane --, sets the accepted flags of the foreign ones and replays the accepted among them 64 / G at a
+// time, picking its plan entries straight from the full plan (no compact plan, no device-side count, one launch less on every
+// half-step's dependency chain).  Same load_row / make_proposal / store_row as the kernel that took the decisions: same bits.
+struct ReplayFusedArgs {
+    double* X;
+    double* lp;
+    uint8_t* acc;
+    const int32_t *order, *p0;                // this split's plan (already offset to the split)
+    const double* s0;
+    const double* gathered;                   // this half-step's receive buffer: [G][rows]
+    int32_t ns, G, rank, rows, D;
+};
+
+template <int G, int V, int CH>
+static __global__ __launch_bounds__(256) void k_replay_stretch(const ReplayFusedArgs A) {
+    constexpr int WPW = 64 / G;
+    const int lane = threadIdx.x & 63, sub = lane / G, gl = lane % G;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+    const int D = A.D;
+    for (int chunk = wave; chunk * 64 < A.ns; chunk += nwaves) {       // wave-uniform
+        const int t = chunk * 64 + lane;
+        bool hit = false;
+        double v = 0.0;
+        if (t < A.ns) {
+            const int q = block_owner(t, A.ns, A.G);
+            if (q != A.rank) {
+                const int lo = (int)((long long)A.ns * q / A.G);
+                v = A.gathered[(size_t)q * A.rows + (t - lo)];
+                hit = !(v != v);
+                A.acc[A.order[t]] = hit ? 1 : 0;
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        const int cnt = __popcll(m);
+        const int myrank = hit ? __popcll(m & ((1ull << lane) - 1ull)) : -1;
+        for (int base = 0; base < cnt; base += WPW) {                  // wave-uniform
+            int src = -1;
+#pragma unroll
+            for (int s = 0; s < WPW; ++s) {
+                const unsigned long long b = __ballot(myrank == base + s);
+                if (sub == s) src = b ? __ffsll((long long)b) - 1 : -1;
+            }
+            const bool live = src >= 0;
+            const int ts = __shfl(t, live ? src : 0, 64);
+            const double vs = __shfl(v, live ? src : 0, 64);
+            const int i = A.order[ts], j = A.p0[ts];
+            const double z = A.s0[ts];
+            Row<G, V, CH> xi, xa, qrow;
+            load_row<G, V, CH>(xi, A.X + (size_t)i * D, D, gl);
+            load_row<G, V, CH>(xa, A.X + (size_t)j * D, D, gl);
+            double factor = 0.0;
+            make_proposal<G, V, CH, MOVE_STRETCH>(xi, xa, xa, xa, z, 0.0, D, gl, qrow, factor);
+            if (live) {
+                store_row<G, V, CH>(qrow, A.X + (size_t)i * D, D, gl);
+                if (gl == 0) A.lp[i] = vs;
+            }
+        }
+    }
+}
+
 // Replay exchange without a collective library: every rank stores its decisions straight into every peer's receive buffer
 // (mapped like the direct exchange's arrays: hipIpc between processes) -- 8 bytes per own walker-update to each peer -- and the
 // one-wave barrier kernel (k_peer_barrier: system-scope release, a flag into every peer's array, spin, acquire) tells everybody

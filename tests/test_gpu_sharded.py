@@ -358,6 +358,15 @@ def test_replay_exchange_equals_single_rank(name, world, rng):
     assert ReplayStepper is not None
 
 
+@pytest.mark.parametrize("name,world,rng", [("stretch_128x64_dense", 3, "philox"), ("stretch_50x3_iso", 4, "mt"),
+                                            ("stretch_48x130_dense", 2, "mt"), ("stretch_128x8_rosen", 5, "philox")])
+def test_replay_exchange_two_pass_form_of_the_stretch_move(name, world, rng, monkeypatch):
+    """The stretch move replays in one launch (k_replay_stretch); its two-pass form -- compact plan, then k_halfstep with
+    TGT_REPLAY, what the other moves use -- must give the same bits (tuning key replay_two_pass, through EMX_TUNE)."""
+    monkeypatch.setenv("EMX_TUNE", "replay_two_pass=1")
+    test_replay_exchange_equals_single_rank(name, world, rng)
+
+
 @pytest.mark.parametrize("name,world,rng", [("stretch_128x64_dense", 2, "philox"), ("mix_de_snooker_128x8_dense", 2, "mt"),
                                             ("stretch_50x3_iso", 2, "philox"), ("stretch_48x130_dense", 2, "mt")])
 def test_replay_exchange_device_side(name, world, rng):
