@@ -325,6 +325,7 @@ def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=F
     ens.sync()
     walls, gpus = [], []
     total = 0.0
+    pinfo0 = ens.persist_info()
     while True:
         if store:
             ens.chain_reset()
@@ -344,7 +345,11 @@ def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=F
     gpu_ms = float(np.median(gpus))
     res = {"wall_s": wall, "gpu_ms": gpu_ms, "blocks": len(walls), "wall_min_s": float(np.min(walls)),
            "accept_frac": float(ens.accepted_mask().mean()), "status": ens.status(), "per_launch_us": None,
-           "walls_s": [float(w) for w in walls]}
+           "walls_s": [float(w) for w in walls], "halfsteps_per_launch": 1.0}
+    pinfo1 = ens.persist_info()
+    persistent = pinfo1["launches"] > pinfo0["launches"]
+    if persistent:      # k_persist: several half-steps per launch (16 steps when a call is aligned with the plan batches)
+        res["halfsteps_per_launch"] = (pinfo1["halfsteps"] - pinfo0["halfsteps"]) / float(pinfo1["launches"] - pinfo0["launches"])
     if rng == "mt19937":
         try:
             res["pipeline"] = ens.pipeline_stats()
@@ -352,11 +357,19 @@ def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=F
             log("pipeline stats unavailable:", e)
     if want_kernel:
         # per-launch hipEvent durations of the half-step kernel (separate pass: event records perturb)
+        if persistent and rng == "philox":
+            seed, step = ens.get_philox()
+            ens.set_philox(seed, step)          # forget the plans evaluated ahead: the launches below are whole 16-step batches
+        pinfo2 = ens.persist_info()
         ens.profile_enable(128)
         ens.run(48, 1, False)
         pl = ens.profile_read(128)
         if len(pl):
             res["per_launch_us"] = float(np.median(pl) * 1e3)
+            pinfo3 = ens.persist_info()
+            if pinfo3["launches"] > pinfo2["launches"]:
+                res["per_launch_halfsteps"] = (pinfo3["halfsteps"] - pinfo2["halfsteps"]) / float(pinfo3["launches"] - pinfo2["launches"])
+    res["persist_total"] = ens.persist_info()
     ens.close()
     return res
 
@@ -398,8 +411,11 @@ def config_entry(wl, res, K, store):
                         "achieved": wl.N * B / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": wl.N * B / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                         "frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS,
-                        "avg_launch_us": ev_ms * 1e3 / lps, "per_launch_event_us": res["per_launch_us"],
-                        "launches_per_step": lps}}
+                        "avg_launch_us": ev_ms * 1e3 / lps * res.get("halfsteps_per_launch", 1.0), "per_launch_event_us": res["per_launch_us"],
+                        "launches_per_step": lps / res.get("halfsteps_per_launch", 1.0)}}
+    if res.get("halfsteps_per_launch", 1.0) > 1.0:
+        out["roofline"]["kernel"] = "emx::k_persist<8,2,4,DPB=4>: %.1f half-steps per launch" % res["halfsteps_per_launch"]
+        out["roofline"]["per_launch_event_halfsteps"] = res.get("per_launch_halfsteps")
     state_mb = wl.N * wl.D * 8 / 1e6
     if state_mb > 256.0:
         out["roofline"].update({"state_MB": state_mb, "beyond_infinity_cache": True,
@@ -932,7 +948,7 @@ def refresh_pmc_traffic(args):
     """`--pmc`: HBM traffic of the headline kernel measured NOW instead of read from profiles/pmc_traffic.json -- this command is
     re-run under rocprofv3 with FETCH_SIZE and with WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md, HBM section: the two
     counters are not collected together; FETCH_SIZE is doubled on gfx950), medians per launch of the stretch / dense half-step.
-    -> (bytes per launch, source text) or (None, reason)."""
+    -> (bytes per launch -- per half-step when the kernel is the persistent one --, source text, per_halfstep) or (None, reason, False)."""
     import collections
     import csv
     import glob
@@ -942,8 +958,9 @@ def refresh_pmc_traffic(args):
     import tempfile
     prof = shutil.which("rocprofv3")
     if not prof:
-        return None, "rocprofv3 not on PATH"
+        return None, "rocprofv3 not on PATH", False
     med = {}
+    per_halfstep = False
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="emx_pmc_")
         cmd = [prof, "--pmc", ctr, "-d", d, "-o", "p", "-f", "csv", "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "10",
@@ -951,24 +968,41 @@ def refresh_pmc_traffic(args):
         env = dict(os.environ)
         env.setdefault("TMPDIR", "/tmp")
         try:
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, env=env, cwd=ROOT)
+            cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env, cwd=ROOT)
+            child = None
+            for ln in cp.stdout.decode(errors="replace").splitlines():
+                if ln.startswith("{") and '"metric"' in ln:
+                    child = json.loads(ln)
+            ptot = (child or {}).get("persist") or {}
             agg = collections.defaultdict(list)
+            persist_sum = 0.0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "k_halfstep<8, 2, 4, 0, 4, 1>" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                    if r["Counter_Name"] != ctr:
+                        continue
+                    if "k_halfstep<8, 2, 4, 0, 4, 1>" in r["Kernel_Name"]:
                         agg[r.get("Grid_Size", "")].append(float(r["Counter_Value"]))
+                    elif "k_persist<" in r["Kernel_Name"]:
+                        persist_sum += float(r["Counter_Value"])
+            if ptot.get("halfsteps", 0) > 0 and persist_sum > 0.0:
+                # the persistent kernel: launches run different numbers of half-steps, so the sum over every launch of the
+                # process / the half-steps they ran (the child's own count), per HALF-STEP
+                med[ctr] = persist_sum / float(ptot["halfsteps"])
+                per_halfstep = True
+                continue
             vals = max(agg.values(), key=len) if agg else []
             if len(vals) < 8:
-                return None, "rocprofv3 --pmc %s produced no samples of the half-step kernel" % ctr
+                return None, "rocprofv3 --pmc %s produced no samples of the half-step kernel" % ctr, False
             med[ctr] = statistics.median(vals)
         except Exception as e:  # noqa: BLE001
-            return None, "rocprofv3 --pmc %s failed: %r" % (ctr, e)
+            return None, "rocprofv3 --pmc %s failed: %r" % (ctr, e), False
         finally:
             shutil.rmtree(d, ignore_errors=True)
     nbytes = (2.0 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0
-    return nbytes, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of this command, medians per launch: "
+    return nbytes, ("measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of this command, %s: "
                     "%.1f KB / %.1f KB; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH_SIZE doubled per the gfx950 correction)"
-                    % (med["FETCH_SIZE"], med["WRITE_SIZE"]))
+                    % ("sum over the k_persist launches / the half-steps they ran, i.e. per HALF-STEP" if per_halfstep else "medians per launch",
+                       med["FETCH_SIZE"], med["WRITE_SIZE"])), per_halfstep
 
 
 # ------------------------------------------------------------------------------------------------ self-launch (N > 1)
@@ -1132,27 +1166,37 @@ def main(argv=None):
     if not sharded:
         import torch
         torch.cuda.set_device(local_rank)
-    traffic = None
+    # HBM traffic of the headline kernel: per launch of k_halfstep, per HALF-STEP of k_persist (whose launches differ in length)
+    traffic_static = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("c2_stretch_dense_bytes_per_launch")
+            traffic_static = json.load(open(tpath))
         except Exception:  # noqa: BLE001
-            traffic = None
-
+            traffic_static = {}
+    traffic_fresh = None          # (bytes, per_halfstep)
     traffic_source = ("profiles/pmc_traffic.json (static: rocprofv3 PMC passes of an earlier run of this command, FETCH_SIZE x2 gfx950 "
                       "correction + WRITE_SIZE; not re-measured here; `bench.py --pmc` re-measures)")
     if args.pmc and not sharded:
-        fresh, why = refresh_pmc_traffic(args)
+        fresh, why, per_hs = refresh_pmc_traffic(args)
         if fresh is not None:
-            traffic, traffic_source = fresh, why
+            traffic_fresh, traffic_source = (fresh, per_hs), why
         else:
             log("--pmc:", why)
             traffic_source += " [--pmc failed: %s]" % why
 
-    def headline(wl, wall_s, gpu_ms, per_launch_us, accept, status, how, extra):
+    def traffic_per_launch(hpl):
+        if traffic_fresh is not None:
+            nbytes, per_hs = traffic_fresh
+            return nbytes * hpl if per_hs else (nbytes if hpl == 1.0 else None)
+        if hpl > 1.0:
+            per_hs = traffic_static.get("c2_persist_bytes_per_halfstep")
+            return per_hs * hpl if per_hs else None
+        return traffic_static.get("c2_stretch_dense_bytes_per_launch")
+
+    def headline(wl, wall_s, gpu_ms, per_launch_us, accept, status, how, extra, hpl=1.0, event_hpl=None, persist_total=None):
         B = wl.bytes_per_update(args.store)
-        lps = wl.launches_per_step()
+        lps = wl.launches_per_step() / hpl                            # hpl: half-steps per launch (k_persist; 1 otherwise)
         slots_per_launch = (wl.N // world) / lps                      # per GPU
         avg_launch_s = gpu_ms * 1e-3 / (K * lps)                       # timed-region events / launches
         achieved = slots_per_launch * B / avg_launch_s / 1e9
@@ -1167,17 +1211,24 @@ def main(argv=None):
                       if not args.single_block else "one K-step block",
             "steps_per_s": K / wall_s, "accept_frac": accept, "device_status": status,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_per_launch(hpl),
                          "traffic_source": traffic_source,
-                         "kernel": "emx::k_halfstep<8,2,4,STRETCH,DPB=4,LEAN> (G=8 lanes/walker, V=2, CH=4; f64 MFMA dense target)",
+                         "kernel": ("emx::k_persist<8,2,4,DPB=4> (persistent: %.1f half-steps per launch, a device-wide barrier between them; "
+                                    "G=8 lanes/walker, V=2, CH=4; f64 MFMA dense target)" % hpl) if hpl > 1.0 else
+                                   "emx::k_halfstep<8,2,4,STRETCH,DPB=4,LEAN> (G=8 lanes/walker, V=2, CH=4; f64 MFMA dense target)",
+                         "halfsteps_per_launch": hpl, "avg_halfstep_us": avg_launch_s * 1e6 / hpl,
+                         "per_launch_event_halfsteps": event_hpl,
                          "algorithmic_bytes_per_walker_update": B, "walker_updates_per_launch": slots_per_launch,
                          "avg_launch_us": avg_launch_s * 1e6, "per_launch_event_us": per_launch_us,
-                         "note": "avg_launch_us = hipEvent time of the timed region / half-step launches: it includes the "
+                         "note": "avg_launch_us = hipEvent time of the timed region / launches of the kernel: it includes the "
                                  "inter-kernel gaps and the batched plan kernel (k_native_plan_batch, 1 launch per 16 steps)"
                                  + (" and, on sharded runs, the exchange" if sharded else "") +
-                                 "; per_launch_event_us brackets single half-step launches with hipEvents"},
+                                 "; per_launch_event_us brackets single launches (of per_launch_event_halfsteps half-steps when "
+                                 "persistent) with hipEvents"},
         }
         line.update(extra)
+        if persist_total:
+            line["persist"] = persist_total
         if args.all_on_device is not None:
             line["test_mode"] = ("--all-on-device %d: every rank shares ONE GPU -- a control-flow / protocol test of the N > 1 path, NOT a "
                                  "multi-GPU measurement" % args.all_on_device)
@@ -1192,7 +1243,9 @@ def main(argv=None):
         wl = Workload("c2", 65536)
         res = measure_single(wl, K, W, device=local_rank, rng=args.rng, store=args.store, single_block=args.single_block)
         extra = {"timed_blocks": res["blocks"], "best_block_ms_per_step": res["wall_min_s"] * 1e3 / K}
-        line = headline(wl, res["wall_s"], res["gpu_ms"], res["per_launch_us"], res["accept_frac"], res["status"], "", extra)
+        line = headline(wl, res["wall_s"], res["gpu_ms"], res["per_launch_us"], res["accept_frac"], res["status"], "", extra,
+                        hpl=res.get("halfsteps_per_launch", 1.0), event_hpl=res.get("per_launch_halfsteps"),
+                        persist_total=res.get("persist_total"))
         if not args.no_extras:
             cfgs = {}
             plan = [("c3", 262144, False), ("c4", 65536, False), ("c5", 16384, False), ("c2", 65536, True),

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -440,6 +441,22 @@ struct emx_ctx {
     bool graph_warm = false;         // one ordinary step has run (function attributes set, kernels loaded)
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
+    // persistent half-steps (tuning "persist", default on): k_persist runs a batch of native steps in one launch
+    int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_groups = 192;
+    bool state_pinned = false;       // somebody holds the state arrays' addresses (emx_device_ptr, IPC export): they stay where they are
+    int64_t persist_launches = 0, persist_halfsteps = 0;
+    struct PersistCapture {
+        HalfStepArgs a;
+        dim3 grid, block;
+        size_t lds;
+        int move, dpb, lean;
+        bool dense, got;
+    };
+    PersistCapture* persist_cap = nullptr;      // launch_split fills this instead of launching
+    unsigned* persist_bar = nullptr;
+    unsigned* persist_ver = nullptr;  // (N) stamps, uncached
+    unsigned persist_epoch = 0;
+    bool state_uncached = false;     // X, lp, acc, acc_count are in uncached device memory (state_migrate)
     int64_t tune_replay_two_pass = 0;         // 1: the replay exchange always compacts, then replays (tests of that form)
     int64_t tune_full_plan = 0;      // 1: native plans always carry every column
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
@@ -792,6 +809,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         // 65 536 walkers): two co-resident 4-wave groups per CU, two tiles per wave, overlap better than one 8-wave group
         // (24.0 vs 26.5 us/step, tools/wpb_sweep.py)
         waves_per_block = c->tune_wpb > 0 ? (int)c->tune_wpb : (ntiles >= 2048 && move != MOVE_GAUSS ? 8 : 4);
+        if (c->persist_cap) waves_per_block = 8;            // k_persist: 8-wave workgroups whatever the ensemble size
         while (waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
         lds = dense_lds_bytes(c->Dp, waves_per_block);
         if (lds > 160 * 1024) {
@@ -877,6 +895,19 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         e0 = c->prof[2 * c->prof_n];
         e1 = c->prof[2 * c->prof_n + 1];
         if (hipEventRecord(e0, c->stream) != hipSuccess) return -2;
+    }
+    if (c->persist_cap) {        // run_persist collects the launches of a batch of steps
+        auto& pc = *c->persist_cap;
+        pc.a = a;
+        pc.grid = dim3((unsigned)nblocks);
+        pc.block = dim3(64 * waves_per_block);
+        pc.lds = lds;
+        pc.move = move;
+        pc.dpb = c->Dp / 16;
+        pc.dense = dense;
+        pc.lean = lean_kind(a, sh.G, sh.V, sh.CH, move, dense);
+        pc.got = nbatch == nblocks * waves_per_block && (nown % spw) == 0 && sh.G == 8 && sh.V == 2 && sh.CH == 4;     // every wave exactly one full tile
+        return 0;
     }
     hipError_t e = dispatch_halfstep(move, dense, c->Dp / 16, sh, dim3((unsigned)nblocks), dim3(64 * waves_per_block), lds,
                                      c->stream, a);
@@ -1104,6 +1135,8 @@ int emx_destroy(emx_ctx* c) {
     if (c->dbg) hipFree(c->dbg);
     if (c->noise_host) hipHostFree(c->noise_host);
     if (c->noise_ev) hipEventDestroy(c->noise_ev);
+    if (c->persist_bar) hipFree(c->persist_bar);
+    if (c->persist_ver) hipFree(c->persist_ver);
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_ctr) hipFree(c->d_ctr);
     if (c->h_ctr) hipHostFree(c->h_ctr);
@@ -1234,6 +1267,18 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "dense_wide")) {      // 1: take the wide-target path (emx_wide.hip) whatever the ndim -- parity tests against the fused kernel
         c->tune_dense_wide = v == 2 ? 2 : (v ? 1 : 0);      // 2: the wide path with the single-role log-prob kernel only
         graph_invalidate(c);
+        return 0;
+    }
+    if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
+        c->tune_persist = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_timeout_ms")) {      // bound of a device-wide barrier wait inside k_persist
+        c->tune_persist_timeout_ms = v > 0 ? v : 2000;
+        return 0;
+    }
+    if (!strcmp(key, "persist_min_groups")) {      // fewest workgroups (128 walker-updates each) a persistent half-step is used for
+        c->tune_persist_min_groups = v > 0 ? v : 1;
         return 0;
     }
     if (!strcmp(key, "replay_two_pass")) {
@@ -2593,6 +2638,171 @@ static int rccl_all_to_all(emx_ctx* c, size_t count) {
 
 static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store);
 
+// ---- persistent half-steps ------------------------------------------------------------------------------------------
+// The headline shape -- one stretch move, the fused dense Gaussian target at padded ndim 64, Philox plans, a single replica, an
+// ensemble whose half-step is exactly one 16-walker tile per wave of a co-resident grid of 8-wave workgroups (nwalkers a
+// multiple of 256, at most 256 x the CU count) -- runs up to 16 steps per launch in k_persist (emx_kernels.hpp).  The walker
+// state then lives in uncached device memory: state_migrate moves it there (and back when the configuration stops qualifying:
+// the launch-per-half-step kernels are 1 ... 4 % slower on uncached rows, profiles/r03/state_memory.txt).
+static bool persist_wanted(const emx_ctx* c) {
+    if (!c->tune_persist) return false;
+    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.size() != 1) return false;
+    if (c->moves[0].kind != EMX_MOVE_STRETCH || c->moves[0].nsplits != 2) return false;
+    if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp != 64 || dense_is_wide(c)) return false;
+    if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
+    const int64_t half = c->N / 2;
+    if ((c->N & 1) || (half % 128) != 0 || half / 128 > c->num_cu || half / 128 < c->tune_persist_min_groups) return false;
+    const Shape sh = pick_shape(c->D, c->Dp);
+    return sh.G == 8 && sh.V == 2 && sh.CH == 4;
+}
+
+// X, lp, acc, acc_count into uncached device memory or back (contents preserved; addresses change)
+static int state_migrate(emx_ctx* c, bool uncached) {
+    if (c->state_uncached == uncached) return 0;
+    NEED(c, !c->state_pinned, "the walker state's addresses are held by the caller (emx_device_ptr / IPC export)");
+    const size_t N = (size_t)c->N, D = (size_t)c->D;
+    const size_t bytes[4] = {N * D * 8, N * 8, N, N * 4};
+    void* old[4] = {c->X, c->lp, c->acc, c->acc_count};
+    void* neu[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < 4; ++k) {
+        const hipError_t e = uncached ? hipExtMallocWithFlags(&neu[k], bytes[k], hipDeviceMallocUncached) : hipMalloc(&neu[k], bytes[k]);
+        if (e != hipSuccess) {
+            for (int j = 0; j < k; ++j) hipFree(neu[j]);
+            FAIL(c, -2, "state_migrate: allocation failed: %s", hipGetErrorString(e));
+        }
+    }
+    for (int k = 0; k < 4; ++k) HIPOK(c, hipMemcpyAsync(neu[k], old[k], bytes[k], hipMemcpyDeviceToDevice, c->stream));
+    HIPOK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 4; ++k) hipFree(old[k]);
+    c->X = (double*)neu[0];
+    c->lp = (double*)neu[1];
+    c->acc = (uint8_t*)neu[2];
+    c->acc_count = (uint32_t*)neu[3];
+    c->state_uncached = uncached;
+    graph_invalidate(c);
+    return 0;
+}
+
+// the caller is about to learn the state arrays' addresses: ordinary memory, and they stay put from here on
+static int state_pin(emx_ctx* c) {
+    if (c->state_uncached) {
+        const int rc = state_migrate(c, false);
+        if (rc) return rc;
+    }
+    c->state_pinned = true;
+    return 0;
+}
+
+// Two persistent grids that each hold part of the device would wait for each other until their barriers time out: launches of
+// one process on one device are chained (each waits for the one before; a few cycles when it is the same stream).
+static std::mutex g_persist_mu;
+static hipEvent_t g_persist_ev[MAX_DEVICES] = {};
+static const emx_ctx* g_persist_last[MAX_DEVICES] = {};
+
+static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, int32_t store, int64_t* done) {
+    *done = 0;
+    if (!c->persist_bar) {
+        HIPOK(c, hipMalloc((void**)&c->persist_bar, 10 * 32 * sizeof(unsigned)));
+        HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 10 * 32 * sizeof(unsigned), c->stream));
+        c->persist_epoch = 0;
+    }
+    if (!c->persist_ver) {
+        HIPOK(c, hipExtMallocWithFlags((void**)&c->persist_ver, (size_t)c->N * 4, hipDeviceMallocUncached));
+        HIPOK(c, hipMemsetAsync(c->persist_ver, 0, (size_t)c->N * 4, c->stream));
+    }
+    PersistArgs P{};
+    emx_ctx::PersistCapture cap{};
+    dim3 grid, block;
+    size_t lds = 0;
+    int n = 0;
+    int64_t steps = 0;
+    while (i0 + steps < total && n + 2 <= PERSIST_MAX_ITERS) {
+        if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
+        c->prep_hint = NATIVE_BATCH_MAX;
+        const int st = store && ((i0 + steps + 1) % thin_by == 0);          // ensemble.py:416
+        int mvi, S;
+        int rc = emx_step_begin(c, st, &mvi, &S);
+        if (rc) return rc;
+        for (int s = 0; s < S; ++s) {
+            cap.got = false;
+            c->persist_cap = &cap;
+            rc = do_halfstep(c, s, c->target);
+            c->persist_cap = nullptr;
+            if (!rc && (!cap.got || !cap.dense || cap.dpb != 4 || cap.move != MOVE_STRETCH || (int64_t)cap.grid.x > c->num_cu ||
+                        cap.block.x != 512)) {
+                c->err = "persistent half-steps: launch shape not eligible";
+                rc = -1;
+            }
+            if (rc) {
+                c->cur.active = false;
+                return rc;
+            }
+            if (n == 0) {
+                P.base = cap.a;
+                grid = cap.grid;
+                block = cap.block;
+                lds = cap.lds;
+            }
+            PersistIter& I = P.it[n++];
+            I.order = cap.a.order;
+            I.p0 = cap.a.p0;
+            I.s0 = cap.a.s0;
+            I.logu = cap.a.logu;
+            I.fac = cap.a.fac;
+            I.chain = cap.a.chain;
+            I.chain_lp = cap.a.chain_lp;
+            I.pos0 = cap.a.pos0;
+            I.split = cap.a.split;
+        }
+        rc = emx_step_end(c);
+        if (rc) return rc;
+        ++steps;
+    }
+    P.niter = n;
+    P.bar = c->persist_bar;
+    P.ver = c->persist_ver;
+    P.epoch0 = c->persist_epoch;
+    P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
+    c->persist_epoch += (unsigned)(n - 1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max;
+    if (prof) {
+        e0 = c->prof[2 * c->prof_n];
+        e1 = c->prof[2 * c->prof_n + 1];
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_persist_mu);
+        const int dev = c->device;
+        if (dev >= 0 && dev < MAX_DEVICES) {
+            if (!g_persist_ev[dev]) HIPOK(c, hipEventCreateWithFlags(&g_persist_ev[dev], hipEventDisableTiming));
+            if (g_persist_last[dev] && g_persist_last[dev] != c) HIPOK(c, hipStreamWaitEvent(c->stream, g_persist_ev[dev], 0));
+        }
+        if (prof) HIPOK(c, hipEventRecord(e0, c->stream));
+        const hipError_t e = launch_hot_persist_dense64(grid, block, lds, c->stream, P);
+        if (e != hipSuccess) FAIL(c, -2, "persistent half-step launch failed: %s", hipGetErrorString(e));
+        if (prof) {
+            HIPOK(c, hipEventRecord(e1, c->stream));
+            c->prof_n++;
+        }
+        if (dev >= 0 && dev < MAX_DEVICES) {
+            HIPOK(c, hipEventRecord(g_persist_ev[dev], c->stream));
+            g_persist_last[dev] = c;
+        }
+    }
+    c->persist_launches++;
+    c->persist_halfsteps += n;
+    *done = steps;
+    return 0;
+}
+
+int emx_persist_info(emx_ctx* c, int64_t out[4]) {
+    out[0] = persist_wanted(c) ? 1 : 0;
+    out[1] = c->state_uncached ? 1 : 0;
+    out[2] = c->persist_launches;
+    out[3] = c->persist_halfsteps;
+    return 0;
+}
+
 int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, thin_by >= 1, "Invalid thinning argument");
@@ -2624,6 +2834,17 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
     c->direct_first_barrier = true;
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     const int64_t total = nsteps * thin_by;
+    // persistent half-steps: the state moves to uncached memory when a run long enough to pay for the move qualifies, and back
+    // when the configuration no longer does
+    bool persist_on = persist_wanted(c) && !small_eligible(c);
+    if (persist_on && !c->state_uncached && total >= NATIVE_BATCH_MAX && !c->state_pinned) {
+        const int rc = state_migrate(c, true);
+        if (rc) return rc;
+    } else if (!persist_on && c->state_uncached && !c->state_pinned) {
+        const int rc = state_migrate(c, false);
+        if (rc) return rc;
+    }
+    persist_on = persist_on && c->state_uncached;
     bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
     int64_t next_mark = c->tune_throttle > 0 ? c->tune_throttle : total + 1;
     int marks = 0;
@@ -2650,6 +2871,14 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
             const int rc = run_small(c, i, chunk, thin_by, store);
             if (rc) return rc;
             i += chunk;
+            ctr_synced = false;
+            continue;
+        }
+        if (persist_on) {
+            int64_t done = 0;
+            const int rc = run_persist(c, i, total, thin_by, store, &done);
+            if (rc) return rc;
+            i += done;
             ctr_synced = false;
             continue;
         }
@@ -3462,7 +3691,9 @@ static inline double* peer_mapped_array(emx_ctx* c) { return c->exchange == EMX_
 int emx_direct_export(emx_ctx* c, uint8_t handles[128]) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, maps_peers(c), "emx_direct_export needs emx_set_exchange(EMX_EXCHANGE_DIRECT or EMX_EXCHANGE_REPLAY)");
-    int rc = peers_ensure(c);
+    int rc = state_pin(c);          // the peers map these addresses
+    if (rc) return rc;
+    rc = peers_ensure(c);
     if (rc) return rc;
     // every rank exports before any rank can import (the host layer's all-gather of the handles sits in between), so this is
     // the one point where no peer can be writing this rank's flags: start the new attachment from epoch 0
@@ -3509,7 +3740,9 @@ int emx_direct_import(emx_ctx* c, const uint8_t* handles) {
 int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_flags) {
     NEED(c, maps_peers(c) && c->world >= 1, "emx_direct_attach needs the direct or the replay exchange and emx_set_shard");
     NEED(c, c->world <= EMX_MAX_PEERS, "peer mapping: at most %d ranks (the GPUs of one node)", EMX_MAX_PEERS);
-    int rc = peers_ensure(c);
+    int rc = state_pin(c);
+    if (rc) return rc;
+    rc = peers_ensure(c);
     if (rc) return rc;
     direct_detach(c);
     for (int q = 0; q < c->world; ++q) {
@@ -3638,6 +3871,10 @@ int emx_replica_unpack(emx_ctx* c) {
 }
 
 int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
+    if (which == 0 || which == 1) {
+        const int rc = state_pin(c);
+        if (rc) return rc;
+    }
     switch (which) {
         case 0: *ptr = c->X; *nbytes = c->N * c->D * 8; return 0;
         case 1: *ptr = c->lp; *nbytes = c->N * 8; return 0;

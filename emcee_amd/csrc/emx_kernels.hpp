@@ -1162,6 +1162,306 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 }
 
 // ----------------------------------------------------------------------------------------
+// Persistent form of the fused dense stretch half-step: up to PERSIST_MAX_ITERS consecutive half-steps (= 16 steps of two
+// splits) in ONE launch, a device-wide barrier where the kernel boundaries were.  A wave owns the same 16 plan slots of every
+// split (the grid is exactly one 16-walker tile per wave, all workgroups co-resident); the LDS image of the target is staged
+// once.  Two things make it pay:
+//   * the walker state (X, lp, acc) lives in UNCACHED device memory (EMX_STATE_MEM=3): a commit is in memory once its store
+//     has been acknowledged and a partner-row load after the barrier reads memory, so no L2 write-back / invalidate is owed
+//     per half-step (that was 3.2 of the 5.0 us a fenced barrier took, profiles/r02/gridbarrier2_ubench.txt); the barrier
+//     itself is per-XCD arrival counters and one "go" word only the last arriver writes (1.8 us);
+//   * what the NEXT half-step reads is loaded while this one computes: its plan entries, and its own rows and log-probs, in
+//     flight during the MFMA phase when the memory system is idle.  When it is the second split of the same step its walkers
+//     are this half-step's untouched complement (red_blue.py:62-67) and those loads are final; when it is the first split of
+//     a new step some of them are being moved right now, so every accepted update also writes the half-step's stamp to ver[]
+//     and after the barrier the walkers whose stamp is this half-step's (8 % at C2's acceptance) are loaded again.
+//     Only the partner rows (the walkers just updated) always wait for the barrier.
+// Same load_row / make_proposal / MFMA chain / reductions / decision as k_halfstep<G, V, CH, STRETCH, DPB, 1>, in the same
+// order: the same bits (tests/test_gpu_persist.py).  Every spin is bounded by the wall clock: a barrier that is never met
+// raises the exchange-timeout status bit and the kernel runs to its end unsynchronised (reported; never a hang).
+// ----------------------------------------------------------------------------------------
+// Loads and stores of the walker state inside the persistent kernel are AGENT-scope accesses (sc1).  An ordinary load may be
+// served by a line the vector L1 or this XCD's L2 still holds from before another workgroup's commit -- uncached memory or not
+// (measured: with plain loads every run of 37 steps differs from the reference path in a few hundred rows; buffer_inv sc1
+// after the barrier repairs that at 13 us a time, sc1 on the loads costs nothing; profiles/r03/persist_coherence.txt).  An
+// ordinary store is acknowledged once this XCD's L2 has taken it; an agent-scope store when the device can see it, which is
+// what the s_waitcnt before the barrier arrival has to mean (with plain stores about one run in a hundred still differed).
+typedef unsigned int emx_u4 __attribute__((ext_vector_type(4)));
+constexpr int EMX_CPOL_SC1 = 16;
+template <int G, int V, int CH>
+__device__ __forceinline__ void load_row_agent(Row<G, V, CH>& r, __amdgpu_buffer_rsrc_t rsrc, int row, int D, int gl) {
+    static_assert(V == 2, "two coordinates per lane and chunk");
+    const int base = row * D;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int d = (c * G + gl) * V;
+        if (d + 1 < D) {
+            const emx_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + d) * 8, 0, EMX_CPOL_SC1);
+            double2 t;
+            __builtin_memcpy(&t, &w, 16);
+            r.x[c][0] = t.x;
+            r.x[c][1] = t.y;
+        } else {
+            r.x[c][0] = 0.0;
+            r.x[c][1] = 0.0;
+        }
+    }
+}
+template <int G, int V, int CH>
+__device__ __forceinline__ void store_row_agent(const Row<G, V, CH>& r, __amdgpu_buffer_rsrc_t rsrc, int row, int D, int gl) {
+    static_assert(V == 2, "two coordinates per lane and chunk");
+    const int base = row * D;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int d = (c * G + gl) * V;
+        if (d + 1 < D) {
+            const double2 t = {r.x[c][0], r.x[c][1]};
+            emx_u4 w;
+            __builtin_memcpy(&w, &t, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (base + d) * 8, 0, EMX_CPOL_SC1);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double load_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned load_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int PERSIST_MAX_ITERS = 32;
+struct PersistIter {
+    const int32_t *order, *p0;
+    const double *s0, *logu, *fac;
+    double *chain, *chain_lp;      // this step's row of the stored chain (backend.py:229), or nullptr
+    int32_t pos0, split;
+};
+struct PersistArgs {
+    HalfStepArgs base;
+    PersistIter it[PERSIST_MAX_ITERS];
+    unsigned* bar;                 // [8][32] per-XCD arrival counters | [32] global counter | [32] go word
+    unsigned* ver;                 // (N) stamp of the half-step that last moved the walker (uncached, like the state)
+    unsigned epoch0;               // barriers already passed on these counters
+    unsigned long long timeout_ticks;
+    int32_t niter;
+};
+
+__device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits have been acknowledged (uncached memory)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int xcd = blockIdx.x & 7;
+        const unsigned per = (gridDim.x + 7 - xcd) / 8;
+        unsigned* xctr = P.bar + xcd * 32;
+        unsigned* gctr = P.bar + 8 * 32;
+        unsigned* go = P.bar + 9 * 32;
+        const unsigned old = __hip_atomic_fetch_add(xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == k * per - 1) {
+            const unsigned o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (o2 == k * 8 - 1) __hip_atomic_store(go, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - k) < 0) {      // (the counters wrap)
+            if (wall_clock64() - t0 > P.timeout_ticks) {
+                raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int G, int V, int CH, int DPB>
+static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
+    constexpr int MOVE = MOVE_STRETCH;
+    constexpr int WPW = 64 / G;
+    constexpr int PPT = 16 / WPW;
+    constexpr int PF = prefetch_depth<G, V, CH, MOVE, DPB>();
+    static_assert(PF == PPT && EMX_OPT_RTILE && EMX_OPT_RED4, "the persistent kernel is the one-tile-per-batch form");
+    constexpr int Dp = DPB * 16, KK = Dp / 4, RT = Dp + 2;
+    static_assert(G * V * CH >= Dp, "row layout must cover the padded dimension");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const HalfStepArgs& A = P.base;
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int sub = lane / G;
+    const int gl = lane % G;
+    const int D = A.D;
+    double* Sfrag = smem;
+    double* muS = smem + dense_img_doubles(Dp);
+    double* tile = muS + Dp + (size_t)wib * (16 * RT + 32);
+    double* qfS = tile + 16 * RT;
+    double* facS = qfS + 16;
+    {   // the image of the target (emx_set_target): once per launch
+        constexpr int IMG2 = (dense_img_doubles(Dp) + Dp) / 2;
+        const double2* img = reinterpret_cast<const double2*>(A.tp1);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int e = threadIdx.x; e < IMG2; e += blockDim.x) dst[e] = img[e];
+    }
+    Row<G, V, CH> mu;
+    load_row<G, V, CH>(mu, A.tp0, D, gl);
+    __syncthreads();
+    const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
+    const int t0 = wave * 16;                                   // this wave's slots of every split
+    const __amdgpu_buffer_rsrc_t Xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.X, 0, A.N * D * 8, 0x00020000);
+    const int myrow = (lane >> 4) + 4 * (lane & 3);             // decision lanes: (lane & 15) < 4 decide tile row myrow
+    const bool mine = (lane & 15) < 4;
+
+    int wi[PF], ja[PF], my_i;
+    double s0v[PF], facv[PF], my_logu, my_lpo;
+    Row<G, V, CH> xi[PF];
+    {
+        const PersistIter& I = P.it[0];
+        const int pbase = I.pos0 + t0;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int pos = pbase + k * WPW + sub;
+            wi[k] = I.order[pos];
+            ja[k] = I.p0[pos];
+            s0v[k] = I.s0[pos];
+            facv[k] = I.fac[pos];
+        }
+        my_i = I.order[pbase + myrow];
+        my_logu = I.logu[pbase + myrow];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH>(xi[k], Xr, wi[k], D, gl);
+        my_lpo = load_agent(A.lp + my_i);
+    }
+    for (int n = 0; n < P.niter; ++n) {
+        const PersistIter& I = P.it[n];
+        // -------- partner rows: the walkers the previous half-step updated --------
+        Row<G, V, CH> xa[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH>(xa[k], Xr, ja[k], D, gl);
+        // -------- plan entries of the next half-step (written by the plan kernel before this launch) --------
+        const bool more = n + 1 < P.niter;
+        const PersistIter& J = P.it[more ? n + 1 : n];
+        const bool pre = more && J.split != 0;                   // its own walkers are this half-step's complement
+        const unsigned stamp = P.epoch0 + (unsigned)n + 1u;      // of this half-step (never 0 before the counters wrap)
+        int wi_n[PF], ja_n[PF], my_i_n;
+        double s0_n[PF], fac_n[PF], my_logu_n;
+        {
+            const int pbase = J.pos0 + t0;
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int pos = pbase + k * WPW + sub;
+                wi_n[k] = J.order[pos];
+                ja_n[k] = J.p0[pos];
+                s0_n[k] = J.s0[pos];
+                fac_n[k] = J.fac[pos];
+            }
+            my_i_n = J.order[pbase + myrow];
+            my_logu_n = J.logu[pbase + myrow];
+        }
+        // -------- proposals -> the wave's LDS tile (R = Q - mu), kept in registers for the commit --------
+        Row<G, V, CH> qk[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int srow = k * WPW + sub;
+            double factor = facv[k];
+            Row<G, V, CH> q;
+            make_proposal<G, V, CH, MOVE>(xi[k], xa[k], xa[k], xa[k], s0v[k], A.gammas, D, gl, q, factor, ja[k]);
+            bool bl = false;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
+            const bool badq = group_any<G>(bl, sub);
+            if (badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
+            const int trow = srow & 15;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int d = (c * G + gl) * V + v;
+                    if (d < Dp) tile[trow * RT + d] = !badq ? q.x[c][v] - mu.x[c][v] : 0.0;
+                }
+            qk[k] = q;
+            if (gl == 0) facS[trow] = badq ? -__builtin_inf() : factor;
+            // stored step: the current row goes out now (fire and forget); an accepted proposal overwrites it after the decision
+            if (I.chain) store_row_stream<G, V, CH>(xi[k], I.chain + (size_t)wi[k] * D, D, gl);
+        }
+        // -------- own rows of the next half-step: in flight during the MFMA phase (speculative unless `pre`) --------
+        double my_lpo_n = 0.0;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH>(xi[k], Xr, wi_n[k], D, gl);
+            my_lpo_n = load_agent(A.lp + my_i_n);
+        }
+        EMX_WAVE_SYNC();
+        // -------- Y = R L by v_mfma_f64_16x16x4_f64, qf[w] = sum_n Y[w][n]^2 (as k_halfstep) --------
+        double my_qf;
+        {
+            const int am = lane & 15, ak = lane >> 4;
+            typedef double d4 __attribute__((ext_vector_type(4)));
+            double afr[KK];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) afr[kk] = tile[am * RT + 4 * kk + ak];
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int nb = 0; nb < DPB; ++nb) {
+                d4 accv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 4 * nb; kk < KK; ++kk)
+                    accv = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], Sfrag[(dense_block(DPB, nb, kk >> 2) * 4 + (kk & 3)) * 64 + lane], accv, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
+            }
+            my_qf = row16_sum4(part[0], part[1], part[2], part[3], lane);
+        }
+        // -------- decisions (red_blue.py:99-100) and commit (move.py:33-34) --------
+        bool acc = false;
+        if (mine) {
+            const double lpn = -0.5 * my_qf;
+            if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);
+            const double lnpdiff = facS[myrow] + lpn - my_lpo;
+            acc = lnpdiff > my_logu;
+            A.acc[my_i] = acc ? 1 : 0;
+            if (acc) {
+                store_agent(A.lp + my_i, lpn);
+                store_agent(P.ver + my_i, stamp);
+            }
+            if (I.chain_lp) {
+                I.chain_lp[my_i] = acc ? lpn : my_lpo;
+                if (acc) store_agent(A.acc_count + my_i, load_agent(A.acc_count + my_i) + 1u);
+            }
+        }
+        const unsigned long long am64 = __ballot(acc);           // bit (row & 3) * 16 + (row >> 2) <-> tile row
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) {
+            const int row = pp * WPW + sub;
+            const bool ac = (am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull;
+            if (ac) {
+                store_row_agent<G, V, CH>(qk[pp], Xr, wi[pp], D, gl);
+                if (I.chain) store_row_stream<G, V, CH>(qk[pp], I.chain + (size_t)wi[pp] * D, D, gl);
+            }
+        }
+        EMX_WAVE_SYNC();
+        if (!more) break;
+        persist_barrier(P, P.epoch0 + (unsigned)n + 1u);
+        // -------- roll over --------
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            wi[k] = wi_n[k];
+            ja[k] = ja_n[k];
+            s0v[k] = s0_n[k];
+            facv[k] = fac_n[k];
+        }
+        my_i = my_i_n;
+        my_logu = my_logu_n;
+        my_lpo = my_lpo_n;
+        if (!pre) {      // first split of a new step: the walkers that moved in the half-step before are loaded again
+            unsigned vk[PF];
+#pragma unroll
+            for (int k = 0; k < PF; ++k) vk[k] = load_agent(P.ver + wi[k]);
+            const unsigned vm = load_agent(P.ver + my_i);
+#pragma unroll
+            for (int k = 0; k < PF; ++k)
+                if (vk[k] == stamp) load_row_agent<G, V, CH>(xi[k], Xr, wi[k], D, gl);
+            if (vm == stamp) my_lpo = load_agent(A.lp + my_i);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // Small ensembles: the whole run in ONE workgroup.
 // When the ensemble (coordinates, log-probs, one step's plan) fits the 160 KB LDS of a CU, a step is two
 // launches of pure latency (~3.6 us each).  Here one workgroup keeps the ensemble in LDS and iterates

@@ -548,6 +548,12 @@ class DeviceEnsemble:
         return {"steps_produced": n.value, "finisher_threads": k.value, "wall_us": out[0], "generator_us": out[1], "tokenizer_us": out[2],
                 "finishers_us_summed": out[3], "tokenizer_waited_for_words_us": out[4], "tokenizer_waited_for_consumer_us": out[5]}
 
+    def persist_info(self):
+        """persistent half-steps (include/emx.h emx_persist_info): does the configuration qualify, where the state lives, launches, half-steps"""
+        out = (C.c_int64 * 4)()
+        self._ck(self.lib.emx_persist_info(self.ctx, out))
+        return {"qualifies": bool(out[0]), "state_uncached": bool(out[1]), "launches": int(out[2]), "halfsteps": int(out[3])}
+
     def comm_count(self):
         """ranks of the library's RCCL communicator (ncclCommCount); 0 without one"""
         n = C.c_int32(0)

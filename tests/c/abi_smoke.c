@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     SYM(emx_rng_set_philox) SYM(emx_set_state) SYM(emx_eval_state_log_prob) SYM(emx_chain_config)
     SYM(emx_run) SYM(emx_chain_read) SYM(emx_accepted_counts) SYM(emx_get_state) SYM(emx_status)
     SYM(emx_autocorr) SYM(emx_walkers_independent)
-    SYM(emx_snapshot_save) SYM(emx_snapshot_read) SYM(emx_snapshot_restore) SYM(emx_snapshot_free) SYM(emx_comm_count) SYM(emx_pipeline_stats)
+    SYM(emx_snapshot_save) SYM(emx_snapshot_read) SYM(emx_snapshot_restore) SYM(emx_snapshot_free) SYM(emx_comm_count) SYM(emx_pipeline_stats) SYM(emx_persist_info)
     printf("version: %s\n", p_emx_version());
 
     /* host-only: MT19937 seeded with init_genrand(5489)-style key is not needed; use a fixed key */
@@ -131,6 +131,8 @@ int main(int argc, char** argv) {
     int64_t produced = -1;
     double stage[6];
     if (p_emx_comm_count(ctx, &ranks) != 0 || ranks != 0 || p_emx_pipeline_stats(ctx, stage, &produced, &fin) != 0 || produced != 0) return 15;
+    int64_t pinfo[4] = {-1, -1, -1, -1};
+    if (p_emx_persist_info(ctx, pinfo) != 0 || pinfo[0] != 0 || pinfo[2] != 0) return 16;      /* a tiny ensemble never qualifies */
     printf("snapshots ok\n");
     p_emx_destroy(ctx);
     return 0;

@@ -1,0 +1,210 @@
+"""The persistent half-step kernel (k_persist, include/emx.h emx_persist_info): 16 steps per launch, a device-wide barrier where
+the kernel boundaries were.  It must be the path emx_run takes for the headline shape, and give the bits of the launch-per-
+half-step kernels -- which tests/test_gpu_full_size.py and tests/test_gpu_parity.py hold equal to the oracle -- and of the oracle
+itself (red_blue.py:55-106 with stretch.py:27-34) at the BASELINE size."""
+import numpy as np
+import pytest
+
+from emcee_amd import _lib
+from oracle import cases
+from oracle import sampler_oracle as so
+
+from emx_testlib import move_desc, philox_plan
+from test_gpu_full_size import FULL, full_spec
+from test_gpu_parity import assert_lp_close, make_ens
+
+pytestmark = pytest.mark.gpu
+
+S = so.MoveSpec
+SEED = 0x5EED5
+
+
+def dense_spec(N, D, seed=3):
+    return full_spec(N, D, "dense", [S("stretch")], seed=seed)
+
+
+def native_ens(spec, persist, step=0):
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_PHILOX)
+    ens.set_philox(SEED, step)
+    ens.set_tuning("persist", persist)
+    ens.set_tuning("persist_min_groups", 1)        # (by default only ensembles that fill the device: 192 workgroups and more)
+    return ens
+
+
+def run_both(spec, nsteps, thin_by=1, store=False, calls=1):
+    out = []
+    for persist in (1, 0):
+        ens = native_ens(spec, persist)
+        if store:
+            ens.chain_config(nsteps * calls)
+        for _ in range(calls):
+            ens.run(nsteps, thin_by, store)
+        assert ens.status() == 0
+        info = ens.persist_info()
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=info)
+        if store:
+            rec["chain"] = ens.chain_read(0, 0, nsteps * calls)
+            rec["chain_lp"] = ens.chain_read(1, 0, nsteps * calls)
+            rec["counts"] = ens.accepted_counts()
+        ens.close()
+        out.append(rec)
+    return out
+
+
+@pytest.mark.parametrize("N,D", [(65536, 64), (4096, 64), (2048, 64), (16384, 50), (8192, 62)])
+def test_persistent_kernel_gives_the_bits_of_the_launch_per_halfstep_path(N, D):
+    """37 steps (16 + 16 + 5: full and partial launches), no chain: coordinates, log-probs and the last accept marks bit-equal;
+    the persistent run really was persistent (launch and half-step counters), the control really was not."""
+    spec = dense_spec(N, D)
+    p, c = run_both(spec, 37)
+    assert p["info"]["qualifies"] and p["info"]["state_uncached"] and p["info"]["halfsteps"] == 74 and p["info"]["launches"] == 3
+    assert c["info"]["launches"] == 0 and not c["info"]["state_uncached"]
+    assert np.array_equal(p["x"], c["x"])
+    assert np.array_equal(p["lp"], c["lp"])
+    assert np.array_equal(p["acc"], c["acc"])
+
+
+@pytest.mark.parametrize("thin_by", [1, 3])
+def test_persistent_kernel_stores_the_chain(thin_by):
+    """the chain row, its log-probs and the per-walker accept counters of stored steps (backend.py:229), two calls, thinning"""
+    spec = dense_spec(8192, 64, seed=4)
+    p, c = run_both(spec, 19, thin_by=thin_by, store=True, calls=2)
+    assert p["info"]["halfsteps"] == 2 * 2 * 19 * thin_by and c["info"]["launches"] == 0
+    for key in ("x", "lp", "chain", "chain_lp", "counts"):
+        assert np.array_equal(p[key], c[key]), key
+    assert p["counts"].sum() > 0
+
+
+def test_persistent_kernel_equals_the_oracle_at_the_headline_size():
+    """BASELINE config 2 through emx_run (one launch of 3 steps): the oracle's arithmetic applied with the host twin of the
+    Philox plans gives the same chain, bit for bit, and the same accept counters."""
+    spec = FULL["c2_65536x64_dense_stretch"]()
+    fn = cases.make_target(spec["desc"])
+    N, D = spec["N"], spec["D"]
+    nst = 3
+    ens = native_ens(spec, 1)
+    ens.chain_config(nst)
+    x, lp = ens.get_state()
+    ens.run(nst, 1, True)
+    assert ens.status() == 0
+    info = ens.persist_info()
+    assert info["launches"] == 1 and info["halfsteps"] == 2 * nst
+    chain = ens.chain_read(0, 0, nst)
+    chain_lp = ens.chain_read(1, 0, nst)
+    counts = np.zeros(N, dtype=np.int64)
+    mv = spec["moves"][0]
+    for step in range(nst):
+        plan = philox_plan(SEED, step, N, move_desc(mv, D))
+        counts += so.propose_planned(x, lp, fn, plan, mv)
+        assert np.array_equal(chain[step], x), step
+        assert_lp_close(chain_lp[step], lp, 1e-11)
+    assert np.array_equal(ens.accepted_counts(), counts)
+    ens.close()
+
+
+def test_state_moves_to_uncached_memory_and_back():
+    """the step API, snapshots and evaluations work on the migrated state; a configuration that stops qualifying (another move
+    set) brings it back; emx_device_ptr pins it in ordinary memory for good"""
+    spec = dense_spec(4096, 64, seed=5)
+    ens = native_ens(spec, 1)
+    ref = native_ens(spec, 0)
+    for e in (ens, ref):
+        e.run(20, 1, False)
+    assert ens.persist_info()["state_uncached"] and not ref.persist_info()["state_uncached"]
+    slot = ens.snapshot_save()
+    for e in (ens, ref):                       # the step API on either kind of memory
+        for _ in range(2):
+            k, nsplit = e.step_begin(store=False)
+            for s in range(nsplit):
+                e.halfstep(s)
+            e.step_end()
+    a, b = ens.get_state(), ref.get_state()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    ens.snapshot_restore(slot)
+    ens.set_philox(SEED, 20)
+    ref2 = native_ens(spec, 0)
+    ref2.run(20, 1, False)
+    # another move set: no longer the persistent shape
+    de = [move_desc(S("de"), 64)]
+    for e in (ens, ref2):
+        e.set_moves(de, np.array([1.0]))
+        e.run(5, 1, False)
+    info = ens.persist_info()
+    assert not info["qualifies"] and not info["state_uncached"]
+    a, b = ens.get_state(), ref2.get_state()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # back to the stretch move; then the caller takes the coordinates' address
+    st = [move_desc(S("stretch"), 64)]
+    for e in (ens, ref2):
+        e.set_moves(st, np.array([1.0]))
+        e.run(16, 1, False)
+    assert ens.persist_info()["state_uncached"]
+    ptr, nbytes = ens.device_ptr(0)
+    assert ptr and nbytes == 4096 * 64 * 8 and not ens.persist_info()["state_uncached"]
+    launches = ens.persist_info()["launches"]
+    for e in (ens, ref2):
+        e.run(16, 1, False)
+    assert ens.persist_info()["launches"] == launches
+    a, b = ens.get_state(), ref2.get_state()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for e in (ens, ref, ref2):
+        assert e.status() == 0
+        e.close()
+
+
+def test_what_does_not_qualify():
+    for N, D, why in ((1000, 64, "not a multiple of 256"), (4096, 32, "another row layout"), (4096, 63, "odd ndim"), (131072, 64, "more tiles than waves")):
+        ens = native_ens(dense_spec(N, D), 1)
+        assert not ens.persist_info()["qualifies"], why
+        ens.run(16, 1, False)
+        assert ens.persist_info()["launches"] == 0 and ens.status() == 0
+        ens.close()
+    ens = native_ens(dense_spec(4096, 64), 1)
+    ens.set_rng_mode(_lib.RNG_MT19937)
+    assert not ens.persist_info()["qualifies"]
+    ens.close()
+
+
+def test_two_ensembles_of_one_process_take_turns():
+    """two persistent grids that each held half of the device would wait for each other: the launches of a process are chained"""
+    specs = [dense_spec(65536, 64, seed=6), dense_spec(32768, 64, seed=7)]
+    ens = [native_ens(s, 1) for s in specs]
+    for _ in range(6):
+        for e in ens:
+            e.run(16, 1, False)          # asynchronous: both streams hold work
+    got = []
+    for e in ens:
+        assert e.status() == 0
+        assert e.persist_info()["launches"] == 6
+        got.append(e.get_state())
+        e.close()
+    for s, g in zip(specs, got):
+        ref = native_ens(s, 0)
+        ref.run(96, 1, False)
+        x, lp = ref.get_state()
+        assert np.array_equal(g[0], x) and np.array_equal(g[1], lp)
+        ref.close()
+
+
+def test_sampler_runs_persistently(monkeypatch):
+    """EnsembleSampler.run_mcmc with the device target and rng="philox" takes the persistent path by itself; EMX_TUNE turns it off"""
+    import emcee_amd
+    from emcee_amd import targets
+    rs = np.random.RandomState(8)
+    A = rs.randn(64, 64)
+    icov = A @ A.T / 64 + np.eye(64)
+    mu = rs.randn(64)
+    p0 = rs.randn(2048, 64)
+    chains = []
+    for tune in ("persist_min_groups=1", "persist=0"):
+        monkeypatch.setenv("EMX_TUNE", tune)
+        np.random.seed(9)
+        s = emcee_amd.EnsembleSampler(2048, 64, targets.DenseGaussian(mu, icov), rng="philox")
+        s.run_mcmc(p0, 40)
+        info = s.backend._dev.persist_info()
+        assert (info["launches"] > 0) == (tune != "persist=0")
+        chains.append((s.get_chain().copy(), s.get_log_prob().copy(), s.acceptance_fraction.copy()))
+    for a, b in zip(*chains):
+        assert np.array_equal(a, b)
