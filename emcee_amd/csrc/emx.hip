@@ -443,7 +443,6 @@ struct emx_ctx {
     // tuning
     // persistent half-steps (tuning "persist", default on): k_persist runs a batch of native steps in one launch
     int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_groups = 192;
-    bool state_pinned = false;       // somebody holds the state arrays' addresses (emx_device_ptr, IPC export): they stay where they are
     int64_t persist_launches = 0, persist_halfsteps = 0;
     struct PersistCapture {
         HalfStepArgs a;
@@ -454,9 +453,8 @@ struct emx_ctx {
     };
     PersistCapture* persist_cap = nullptr;      // launch_split fills this instead of launching
     unsigned* persist_bar = nullptr;
-    unsigned* persist_ver = nullptr;  // (N) stamps, uncached
+    unsigned* persist_ver = nullptr;  // (N) stamp of the half-step that last moved the walker
     unsigned persist_epoch = 0;
-    bool state_uncached = false;     // X, lp, acc, acc_count are in uncached device memory (state_migrate)
     int64_t tune_replay_two_pass = 0;         // 1: the replay exchange always compacts, then replays (tests of that form)
     int64_t tune_full_plan = 0;      // 1: native plans always carry every column
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
@@ -2641,9 +2639,10 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store);
 // ---- persistent half-steps ------------------------------------------------------------------------------------------
 // The headline shape -- one stretch move, the fused dense Gaussian target at padded ndim 64, Philox plans, a single replica, an
 // ensemble whose half-step is exactly one 16-walker tile per wave of a co-resident grid of 8-wave workgroups (nwalkers a
-// multiple of 256, at most 256 x the CU count) -- runs up to 16 steps per launch in k_persist (emx_kernels.hpp).  The walker
-// state then lives in uncached device memory: state_migrate moves it there (and back when the configuration stops qualifying:
-// the launch-per-half-step kernels are 1 ... 4 % slower on uncached rows, profiles/r03/state_memory.txt).
+// multiple of 256, at most 256 x the CU count) -- runs up to 16 steps per launch in k_persist (emx_kernels.hpp).
+// (Measured and dropped: the next batch's plan kernel on a stream of its own next to the running persistent launch -- no
+// difference, 20.6 us/step either way: what the plan kernel's waves gain in overlap the lock-stepped half-steps lose to them;
+// profiles/r03/persist_side_plan.txt.)
 static bool persist_wanted(const emx_ctx* c) {
     if (!c->tune_persist) return false;
     if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.size() != 1) return false;
@@ -2654,43 +2653,6 @@ static bool persist_wanted(const emx_ctx* c) {
     if ((c->N & 1) || (half % 128) != 0 || half / 128 > c->num_cu || half / 128 < c->tune_persist_min_groups) return false;
     const Shape sh = pick_shape(c->D, c->Dp);
     return sh.G == 8 && sh.V == 2 && sh.CH == 4;
-}
-
-// X, lp, acc, acc_count into uncached device memory or back (contents preserved; addresses change)
-static int state_migrate(emx_ctx* c, bool uncached) {
-    if (c->state_uncached == uncached) return 0;
-    NEED(c, !c->state_pinned, "the walker state's addresses are held by the caller (emx_device_ptr / IPC export)");
-    const size_t N = (size_t)c->N, D = (size_t)c->D;
-    const size_t bytes[4] = {N * D * 8, N * 8, N, N * 4};
-    void* old[4] = {c->X, c->lp, c->acc, c->acc_count};
-    void* neu[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int k = 0; k < 4; ++k) {
-        const hipError_t e = uncached ? hipExtMallocWithFlags(&neu[k], bytes[k], hipDeviceMallocUncached) : hipMalloc(&neu[k], bytes[k]);
-        if (e != hipSuccess) {
-            for (int j = 0; j < k; ++j) hipFree(neu[j]);
-            FAIL(c, -2, "state_migrate: allocation failed: %s", hipGetErrorString(e));
-        }
-    }
-    for (int k = 0; k < 4; ++k) HIPOK(c, hipMemcpyAsync(neu[k], old[k], bytes[k], hipMemcpyDeviceToDevice, c->stream));
-    HIPOK(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 4; ++k) hipFree(old[k]);
-    c->X = (double*)neu[0];
-    c->lp = (double*)neu[1];
-    c->acc = (uint8_t*)neu[2];
-    c->acc_count = (uint32_t*)neu[3];
-    c->state_uncached = uncached;
-    graph_invalidate(c);
-    return 0;
-}
-
-// the caller is about to learn the state arrays' addresses: ordinary memory, and they stay put from here on
-static int state_pin(emx_ctx* c) {
-    if (c->state_uncached) {
-        const int rc = state_migrate(c, false);
-        if (rc) return rc;
-    }
-    c->state_pinned = true;
-    return 0;
 }
 
 // Two persistent grids that each hold part of the device would wait for each other until their barriers time out: launches of
@@ -2707,7 +2669,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         c->persist_epoch = 0;
     }
     if (!c->persist_ver) {
-        HIPOK(c, hipExtMallocWithFlags((void**)&c->persist_ver, (size_t)c->N * 4, hipDeviceMallocUncached));
+        HIPOK(c, hipMalloc((void**)&c->persist_ver, (size_t)c->N * 4));
         HIPOK(c, hipMemsetAsync(c->persist_ver, 0, (size_t)c->N * 4, c->stream));
     }
     PersistArgs P{};
@@ -2797,9 +2759,9 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
 
 int emx_persist_info(emx_ctx* c, int64_t out[4]) {
     out[0] = persist_wanted(c) ? 1 : 0;
-    out[1] = c->state_uncached ? 1 : 0;
-    out[2] = c->persist_launches;
-    out[3] = c->persist_halfsteps;
+    out[1] = c->persist_launches;
+    out[2] = c->persist_halfsteps;
+    out[3] = 0;
     return 0;
 }
 
@@ -2834,17 +2796,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
     c->direct_first_barrier = true;
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     const int64_t total = nsteps * thin_by;
-    // persistent half-steps: the state moves to uncached memory when a run long enough to pay for the move qualifies, and back
-    // when the configuration no longer does
-    bool persist_on = persist_wanted(c) && !small_eligible(c);
-    if (persist_on && !c->state_uncached && total >= NATIVE_BATCH_MAX && !c->state_pinned) {
-        const int rc = state_migrate(c, true);
-        if (rc) return rc;
-    } else if (!persist_on && c->state_uncached && !c->state_pinned) {
-        const int rc = state_migrate(c, false);
-        if (rc) return rc;
-    }
-    persist_on = persist_on && c->state_uncached;
+    const bool persist_on = persist_wanted(c) && !small_eligible(c);
     bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
     int64_t next_mark = c->tune_throttle > 0 ? c->tune_throttle : total + 1;
     int marks = 0;
@@ -3691,9 +3643,7 @@ static inline double* peer_mapped_array(emx_ctx* c) { return c->exchange == EMX_
 int emx_direct_export(emx_ctx* c, uint8_t handles[128]) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, maps_peers(c), "emx_direct_export needs emx_set_exchange(EMX_EXCHANGE_DIRECT or EMX_EXCHANGE_REPLAY)");
-    int rc = state_pin(c);          // the peers map these addresses
-    if (rc) return rc;
-    rc = peers_ensure(c);
+    int rc = peers_ensure(c);
     if (rc) return rc;
     // every rank exports before any rank can import (the host layer's all-gather of the handles sits in between), so this is
     // the one point where no peer can be writing this rank's flags: start the new attachment from epoch 0
@@ -3740,9 +3690,7 @@ int emx_direct_import(emx_ctx* c, const uint8_t* handles) {
 int emx_direct_attach(emx_ctx* c, void* const* peer_coords, void* const* peer_flags) {
     NEED(c, maps_peers(c) && c->world >= 1, "emx_direct_attach needs the direct or the replay exchange and emx_set_shard");
     NEED(c, c->world <= EMX_MAX_PEERS, "peer mapping: at most %d ranks (the GPUs of one node)", EMX_MAX_PEERS);
-    int rc = state_pin(c);
-    if (rc) return rc;
-    rc = peers_ensure(c);
+    int rc = peers_ensure(c);
     if (rc) return rc;
     direct_detach(c);
     for (int q = 0; q < c->world; ++q) {
@@ -3871,10 +3819,6 @@ int emx_replica_unpack(emx_ctx* c) {
 }
 
 int emx_device_ptr(emx_ctx* c, int32_t which, void** ptr, int64_t* nbytes) {
-    if (which == 0 || which == 1) {
-        const int rc = state_pin(c);
-        if (rc) return rc;
-    }
     switch (which) {
         case 0: *ptr = c->X; *nbytes = c->N * c->D * 8; return 0;
         case 1: *ptr = c->lp; *nbytes = c->N * 8; return 0;

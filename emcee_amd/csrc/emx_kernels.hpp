@@ -1166,10 +1166,11 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 // splits) in ONE launch, a device-wide barrier where the kernel boundaries were.  A wave owns the same 16 plan slots of every
 // split (the grid is exactly one 16-walker tile per wave, all workgroups co-resident); the LDS image of the target is staged
 // once.  Two things make it pay:
-//   * the walker state (X, lp, acc) lives in UNCACHED device memory (EMX_STATE_MEM=3): a commit is in memory once its store
-//     has been acknowledged and a partner-row load after the barrier reads memory, so no L2 write-back / invalidate is owed
-//     per half-step (that was 3.2 of the 5.0 us a fenced barrier took, profiles/r02/gridbarrier2_ubench.txt); the barrier
-//     itself is per-XCD arrival counters and one "go" word only the last arriver writes (1.8 us);
+//   * no cache maintenance at the barrier.  A fenced device-wide barrier costs 5.0 us, 3.2 of them the L2 write-back and
+//     invalidate (profiles/r02/gridbarrier2_ubench.txt).  Here every access to the walker state (X, lp, acc_count, the stamps)
+//     is an agent-scope access instead -- sc1 loads that are served by memory, sc1 stores that are acknowledged when the
+//     device can see them -- so the barrier is s_waitcnt + per-XCD arrival counters + one "go" word only the last arriver
+//     writes (1.8 us);
 //   * what the NEXT half-step reads is loaded while this one computes: its plan entries, and its own rows and log-probs, in
 //     flight during the MFMA phase when the memory system is idle.  When it is the second split of the same step its walkers
 //     are this half-step's untouched complement (red_blue.py:62-67) and those loads are final; when it is the first split of
@@ -1181,11 +1182,12 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 // raises the exchange-timeout status bit and the kernel runs to its end unsynchronised (reported; never a hang).
 // ----------------------------------------------------------------------------------------
 // Loads and stores of the walker state inside the persistent kernel are AGENT-scope accesses (sc1).  An ordinary load may be
-// served by a line the vector L1 or this XCD's L2 still holds from before another workgroup's commit -- uncached memory or not
-// (measured: with plain loads every run of 37 steps differs from the reference path in a few hundred rows; buffer_inv sc1
-// after the barrier repairs that at 13 us a time, sc1 on the loads costs nothing; profiles/r03/persist_coherence.txt).  An
-// ordinary store is acknowledged once this XCD's L2 has taken it; an agent-scope store when the device can see it, which is
-// what the s_waitcnt before the barrier arrival has to mean (with plain stores about one run in a hundred still differed).
+// served by a line the vector L1 or this XCD's L2 still holds from before another workgroup's commit -- even when the
+// allocation is hipDeviceMallocUncached (measured there: with plain loads every run of 37 steps differs from the reference
+// path in a few hundred rows; buffer_inv sc1 after the barrier repairs that at 13 us a time, sc1 on the loads costs nothing).
+// An ordinary store is acknowledged once this XCD's L2 has taken it; an agent-scope store when the device can see it, which
+// is what the s_waitcnt before the barrier arrival has to mean (with plain stores about one run in a hundred still differed).
+// With both, ordinary device memory is as good as uncached memory (profiles/r03/persist_coherence.txt).
 typedef unsigned int emx_u4 __attribute__((ext_vector_type(4)));
 constexpr int EMX_CPOL_SC1 = 16;
 template <int G, int V, int CH>
@@ -1238,14 +1240,14 @@ struct PersistArgs {
     HalfStepArgs base;
     PersistIter it[PERSIST_MAX_ITERS];
     unsigned* bar;                 // [8][32] per-XCD arrival counters | [32] global counter | [32] go word
-    unsigned* ver;                 // (N) stamp of the half-step that last moved the walker (uncached, like the state)
+    unsigned* ver;                 // (N) stamp of the half-step that last moved the walker
     unsigned epoch0;               // barriers already passed on these counters
     unsigned long long timeout_ticks;
     int32_t niter;
 };
 
 __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits have been acknowledged (uncached memory)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits (agent-scope stores) are visible to the device
     __syncthreads();
     if (threadIdx.x == 0) {
         const int xcd = blockIdx.x & 7;
@@ -1414,7 +1416,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);
             const double lnpdiff = facS[myrow] + lpn - my_lpo;
             acc = lnpdiff > my_logu;
-            A.acc[my_i] = acc ? 1 : 0;
+            store_agent(A.acc + my_i, (uint8_t)(acc ? 1 : 0));       // (a walker's mark is written by another XCD every step: write-through)
             if (acc) {
                 store_agent(A.lp + my_i, lpn);
                 store_agent(P.ver + my_i, stamp);

@@ -549,10 +549,10 @@ class DeviceEnsemble:
                 "finishers_us_summed": out[3], "tokenizer_waited_for_words_us": out[4], "tokenizer_waited_for_consumer_us": out[5]}
 
     def persist_info(self):
-        """persistent half-steps (include/emx.h emx_persist_info): does the configuration qualify, where the state lives, launches, half-steps"""
+        """persistent half-steps (include/emx.h emx_persist_info): does the configuration qualify, launches, half-steps they ran"""
         out = (C.c_int64 * 4)()
         self._ck(self.lib.emx_persist_info(self.ctx, out))
-        return {"qualifies": bool(out[0]), "state_uncached": bool(out[1]), "launches": int(out[2]), "halfsteps": int(out[3])}
+        return {"qualifies": bool(out[0]), "launches": int(out[1]), "halfsteps": int(out[2])}
 
     def comm_count(self):
         """ranks of the library's RCCL communicator (ncclCommCount); 0 without one"""

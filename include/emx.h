@@ -330,15 +330,15 @@ int emx_profile_read(emx_ctx* ctx, float* ms_out, int32_t* n_inout);
 int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int32_t* finisher_threads);
 
 /* Persistent half-steps.  emx_run takes the headline shape -- one stretch move (red_blue.py:55-106 with stretch.py:27-34), the
- * fused dense Gaussian target at padded ndim 64, Philox plans, one replica, nwalkers a multiple of 256 up to 256 x the CU count
- * -- 16 steps per kernel launch: a device-wide barrier stands where the kernel boundaries were, the next half-step's plan
- * entries (and, inside a step, its own rows) are loaded while this one computes.  Same draws, same arithmetic, same bits as the
- * launch-per-half-step path.  The walker state then lives in uncached device memory; emx_run moves it there and back by itself
- * (never once emx_device_ptr(0 / 1) or an IPC export has handed its addresses out).  Tuning "persist" = 0 turns it off;
- * "persist_timeout_ms" bounds a barrier wait (default 2000: a grid that cannot become co-resident -- another process holding
- * the device's CUs -- raises status bit 3 instead of hanging).  With emx_profile_enable the events bracket whole launches.
- *   out[0] 1 when the current configuration qualifies, [1] 1 when the state is in uncached memory,
- *   out[2] persistent launches so far, [3] half-steps they ran */
+ * fused dense Gaussian target at padded ndim 64, Philox plans, one replica, nwalkers a multiple of 256 that fills the device
+ * (192 ... 256 workgroups of 128 walker-updates per half-step on MI355X: 49 152 ... 65 536 walkers; tuning
+ * "persist_min_groups" lowers the bound) -- 16 steps per kernel launch: a device-wide barrier stands where the kernel
+ * boundaries were, and the next half-step's plan entries and own rows are loaded while this one computes.  Same draws, same
+ * arithmetic, same bits as the launch-per-half-step path.  Tuning "persist" = 0 turns it off; "persist_timeout_ms" bounds a
+ * barrier wait (default 2000: a grid that cannot become co-resident -- another process holding the device's CUs -- raises
+ * status bit 3 instead of hanging).  With emx_profile_enable the events bracket whole launches.
+ *   out[0] 1 when the current configuration qualifies, out[1] persistent launches so far, out[2] half-steps they ran,
+ *   out[3] reserved (0) */
 int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
 
 /* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------------------- */

@@ -132,7 +132,7 @@ int main(int argc, char** argv) {
     double stage[6];
     if (p_emx_comm_count(ctx, &ranks) != 0 || ranks != 0 || p_emx_pipeline_stats(ctx, stage, &produced, &fin) != 0 || produced != 0) return 15;
     int64_t pinfo[4] = {-1, -1, -1, -1};
-    if (p_emx_persist_info(ctx, pinfo) != 0 || pinfo[0] != 0 || pinfo[2] != 0) return 16;      /* a tiny ensemble never qualifies */
+    if (p_emx_persist_info(ctx, pinfo) != 0 || pinfo[0] != 0 || pinfo[1] != 0 || pinfo[2] != 0) return 16;      /* a tiny ensemble never qualifies */
     printf("snapshots ok\n");
     p_emx_destroy(ctx);
     return 0;

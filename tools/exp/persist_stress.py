@@ -34,9 +34,9 @@ for t in range(T):
             e.chain_reset()
         e.run(nsteps, thin, store)
         x, lp = e.get_state()
-        got.append((x, lp, e.status(), e.chain_read(0, 0, nsteps) if store else None))
-    (x1, l1, s1, c1), (x0, l0, s0, c0) = got
-    rows = int((x1 != x0).any(1).sum())
+        got.append((x, lp, e.status(), e.chain_read(0, 0, nsteps) if store else None, e.accepted_mask(), e.accepted_counts()))
+    (x1, l1, s1, c1, a1, n1), (x0, l0, s0, c0, a0, n0) = got
+    rows = int((x1 != x0).any(1).sum()) + int((a1 != a0).sum()) + int((n1 != n0).sum())
     first = -1
     if store and not np.array_equal(c1, c0):
         first = int(np.argmax((c1 != c0).any((1, 2))))
