@@ -1176,7 +1176,9 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 //     are this half-step's untouched complement (red_blue.py:62-67) and those loads are final; when it is the first split of
 //     a new step some of them are being moved right now, so every accepted update also writes the half-step's stamp to ver[]
 //     and after the barrier the walkers whose stamp is this half-step's (8 % at C2's acceptance) are loaded again.
-//     Only the partner rows (the walkers just updated) always wait for the barrier.
+//     Only the partner rows (the walkers just updated) always wait for the barrier.  (Measured and dropped: loading them
+//     speculatively too and re-loading the sixth that moved -- 94 % of the waves then need the second round trip after the
+//     stamps: 20.4 -> 23.0 us/step; profiles/r03/persist_spec_partners.txt.)
 // Same load_row / make_proposal / MFMA chain / reductions / decision as k_halfstep<G, V, CH, STRETCH, DPB, 1>, in the same
 // order: the same bits (tests/test_gpu_persist.py).  Every spin is bounded by the wall clock: a barrier that is never met
 // raises the exchange-timeout status bit and the kernel runs to its end unsynchronised (reported; never a hang).
