@@ -442,7 +442,8 @@ struct emx_ctx {
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
     // persistent half-steps (tuning "persist", default on): k_persist runs a batch of native steps in one launch
-    int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_groups = 192;
+    int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_walkers = 512;
+    int persist_wpb = 8;
     int64_t persist_launches = 0, persist_halfsteps = 0;
     struct PersistCapture {
         HalfStepArgs a;
@@ -807,7 +808,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         // 65 536 walkers): two co-resident 4-wave groups per CU, two tiles per wave, overlap better than one 8-wave group
         // (24.0 vs 26.5 us/step, tools/wpb_sweep.py)
         waves_per_block = c->tune_wpb > 0 ? (int)c->tune_wpb : (ntiles >= 2048 && move != MOVE_GAUSS ? 8 : 4);
-        if (c->persist_cap) waves_per_block = 8;            // k_persist: 8-wave workgroups whatever the ensemble size
+        if (c->persist_cap) waves_per_block = c->persist_wpb;            // k_persist: about one workgroup per CU (persist_shape)
         while (waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
         lds = dense_lds_bytes(c->Dp, waves_per_block);
         if (lds > 160 * 1024) {
@@ -1275,8 +1276,8 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_persist_timeout_ms = v > 0 ? v : 2000;
         return 0;
     }
-    if (!strcmp(key, "persist_min_groups")) {      // fewest workgroups (128 walker-updates each) a persistent half-step is used for
-        c->tune_persist_min_groups = v > 0 ? v : 1;
+    if (!strcmp(key, "persist_min_walkers")) {      // smallest ensemble the persistent kernel is used for
+        c->tune_persist_min_walkers = v > 0 ? v : 2;
         return 0;
     }
     if (!strcmp(key, "replay_two_pass")) {
@@ -2643,14 +2644,26 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store);
 // (Measured and dropped: the next batch's plan kernel on a stream of its own next to the running persistent launch -- no
 // difference, 20.6 us/step either way: what the plan kernel's waves gain in overlap the lock-stepped half-steps lose to them;
 // profiles/r03/persist_side_plan.txt.)
+// -> waves per workgroup of the persistent grid (0: the ensemble does not fit one): every wave exactly one 16-walker tile of a
+// half-step, about one workgroup per CU, all of them co-resident
+static int persist_shape(const emx_ctx* c) {
+    const int64_t half = c->N / 2;
+    if ((c->N & 1) || (half % 16) != 0) return 0;
+    const int64_t tiles = half / 16;
+    const int64_t cu = std::max(1, c->num_cu);
+    int wpb = tiles >= 6 * cu ? 8 : tiles >= 3 * cu ? 4 : tiles >= 3 * cu / 2 ? 2 : 1;
+    while (wpb > 1 && (tiles % wpb) != 0) wpb >>= 1;
+    if (tiles / wpb > cu * (wpb == 8 ? 1 : 2)) return 0;       // (103 KB of LDS per 8-wave group: one per CU)
+    return wpb;
+}
+
 static bool persist_wanted(const emx_ctx* c) {
     if (!c->tune_persist) return false;
     if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.size() != 1) return false;
     if (c->moves[0].kind != EMX_MOVE_STRETCH || c->moves[0].nsplits != 2) return false;
     if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp != 64 || dense_is_wide(c)) return false;
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
-    const int64_t half = c->N / 2;
-    if ((c->N & 1) || (half % 128) != 0 || half / 128 > c->num_cu || half / 128 < c->tune_persist_min_groups) return false;
+    if (c->N < c->tune_persist_min_walkers || persist_shape(c) == 0) return false;
     const Shape sh = pick_shape(c->D, c->Dp);
     return sh.G == 8 && sh.V == 2 && sh.CH == 4;
 }
@@ -2672,6 +2685,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         HIPOK(c, hipMalloc((void**)&c->persist_ver, (size_t)c->N * 4));
         HIPOK(c, hipMemsetAsync(c->persist_ver, 0, (size_t)c->N * 4, c->stream));
     }
+    c->persist_wpb = persist_shape(c);
     PersistArgs P{};
     emx_ctx::PersistCapture cap{};
     dim3 grid, block;
@@ -2690,8 +2704,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             c->persist_cap = &cap;
             rc = do_halfstep(c, s, c->target);
             c->persist_cap = nullptr;
-            if (!rc && (!cap.got || !cap.dense || cap.dpb != 4 || cap.move != MOVE_STRETCH || (int64_t)cap.grid.x > c->num_cu ||
-                        cap.block.x != 512)) {
+            if (!rc && (!cap.got || !cap.dense || cap.dpb != 4 || cap.move != MOVE_STRETCH || (int)cap.block.x != 64 * c->persist_wpb)) {
                 c->err = "persistent half-steps: launch shape not eligible";
                 rc = -1;
             }

@@ -1329,6 +1329,16 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH>(xi[k], Xr, wi[k], D, gl);
         my_lpo = load_agent(A.lp + my_i);
     }
+    // stored steps: the rows (and log-probs) of a half-step leave one half-step later
+    Row<G, V, CH> crow[PF];
+    int cwi[PF], cmy_i = 0;
+    double clp = 0.0;
+    double *cchain = nullptr, *cchain_lp = nullptr;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        crow[k] = xi[k];
+        cwi[k] = 0;
+    }
     for (int n = 0; n < P.niter; ++n) {
         const PersistIter& I = P.it[n];
         // -------- partner rows: the walkers the previous half-step updated --------
@@ -1380,8 +1390,18 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
                 }
             qk[k] = q;
             if (gl == 0) facS[trow] = badq ? -__builtin_inf() : factor;
-            // stored step: the current row goes out now (fire and forget); an accepted proposal overwrites it after the decision
-            if (I.chain) store_row_stream<G, V, CH>(xi[k], I.chain + (size_t)wi[k] * D, D, gl);
+        }
+        // -------- stored steps: the rows of the half-step BEFORE go out now, next to the MFMA phase -- issued before its barrier
+        //          their 17 MB would sit between the commits and the arrival (every store is acknowledged in order) --------
+        if (cchain) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) store_row_stream<G, V, CH>(crow[k], cchain + (size_t)cwi[k] * D, D, gl);
+            if (mine) cchain_lp[cmy_i] = clp;
+            cchain = nullptr;
+        }
+        if (I.chain) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) crow[k] = xi[k];          // an accepted proposal replaces it after the decision
         }
         // -------- own rows of the next half-step: in flight during the MFMA phase (speculative unless `pre`) --------
         double my_lpo_n = 0.0;
@@ -1424,7 +1444,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
                 store_agent(P.ver + my_i, stamp);
             }
             if (I.chain_lp) {
-                I.chain_lp[my_i] = acc ? lpn : my_lpo;
+                clp = acc ? lpn : my_lpo;
                 if (acc) store_agent(A.acc_count + my_i, load_agent(A.acc_count + my_i) + 1u);
             }
         }
@@ -1435,8 +1455,15 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             const bool ac = (am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull;
             if (ac) {
                 store_row_agent<G, V, CH>(qk[pp], Xr, wi[pp], D, gl);
-                if (I.chain) store_row_stream<G, V, CH>(qk[pp], I.chain + (size_t)wi[pp] * D, D, gl);
+                if (I.chain) crow[pp] = qk[pp];
             }
+        }
+        if (I.chain) {
+            cchain = I.chain;
+            cchain_lp = I.chain_lp;
+            cmy_i = my_i;
+#pragma unroll
+            for (int k = 0; k < PF; ++k) cwi[k] = wi[k];
         }
         EMX_WAVE_SYNC();
         if (!more) break;
@@ -1462,6 +1489,11 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
                 if (vk[k] == stamp) load_row_agent<G, V, CH>(xi[k], Xr, wi[k], D, gl);
             if (vm == stamp) my_lpo = load_agent(A.lp + my_i);
         }
+    }
+    if (cchain) {      // the last half-step's rows
+#pragma unroll
+        for (int k = 0; k < PF; ++k) store_row_stream<G, V, CH>(crow[k], cchain + (size_t)cwi[k] * D, D, gl);
+        if (mine) cchain_lp[cmy_i] = clp;
     }
 }
 

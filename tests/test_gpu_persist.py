@@ -28,7 +28,6 @@ def native_ens(spec, persist, step=0):
     ens.set_rng_mode(_lib.RNG_PHILOX)
     ens.set_philox(SEED, step)
     ens.set_tuning("persist", persist)
-    ens.set_tuning("persist_min_groups", 1)        # (by default only ensembles that fill the device: 192 workgroups and more)
     return ens
 
 
@@ -53,10 +52,11 @@ def run_both(spec, nsteps, thin_by=1, store=False, calls=1):
     return out
 
 
-@pytest.mark.parametrize("N,D", [(65536, 64), (4096, 64), (2048, 64), (16384, 50), (8192, 62)])
+@pytest.mark.parametrize("N,D", [(65536, 64), (49152, 64), (32768, 64), (4096, 64), (1024, 64), (512, 64), (16384, 50), (8192, 62), (2080, 64)])
 def test_persistent_kernel_gives_the_bits_of_the_launch_per_halfstep_path(N, D):
     """37 steps (16 + 16 + 5: full and partial launches), no chain: coordinates, log-probs and the last accept marks bit-equal;
-    the persistent run really was persistent (launch and half-step counters), the control really was not."""
+    the persistent run really was persistent (launch and half-step counters), the control really was not.  The sizes cover
+    every workgroup shape of the persistent grid (8, 4, 2 and 1 waves: about one workgroup per CU)."""
     spec = dense_spec(N, D)
     p, c = run_both(spec, 37)
     assert p["info"]["qualifies"] and p["info"]["halfsteps"] == 74 and p["info"]["launches"] == 3
@@ -144,7 +144,8 @@ def test_persistent_launches_and_the_step_api_interleave():
 
 
 def test_what_does_not_qualify():
-    for N, D, why in ((1000, 64, "not a multiple of 256"), (4096, 32, "another row layout"), (4096, 63, "odd ndim"), (131072, 64, "more tiles than waves")):
+    for N, D, why in ((1000, 64, "half an ensemble of whole 16-walker tiles"), (4096, 32, "another row layout"), (4096, 63, "odd ndim"),
+                      (131072, 64, "more tiles than waves"), (480, 64, "below persist_min_walkers")):
         ens = native_ens(dense_spec(N, D), 1)
         assert not ens.persist_info()["qualifies"], why
         ens.run(16, 1, False)
@@ -187,8 +188,9 @@ def test_sampler_runs_persistently(monkeypatch):
     mu = rs.randn(64)
     p0 = rs.randn(2048, 64)
     chains = []
-    for tune in ("persist_min_groups=1", "persist=0"):
-        monkeypatch.setenv("EMX_TUNE", tune)
+    for tune in (None, "persist=0"):
+        if tune:
+            monkeypatch.setenv("EMX_TUNE", tune)
         np.random.seed(9)
         s = emcee_amd.EnsembleSampler(2048, 64, targets.DenseGaussian(mu, icov), rng="philox")
         s.run_mcmc(p0, 40)

@@ -27,7 +27,6 @@ for N in sizes:
             ens = DeviceEnsemble(wl.N, wl.D, device=0)
             wl.install(ens, "philox")
             ens.set_tuning("persist", persist)
-            ens.set_tuning("persist_min_groups", 1)
             if store:
                 ens.chain_config(160)
             t_end = time.perf_counter() + 0.15

@@ -19,7 +19,6 @@ for persist in (1, 0):
     e = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(e, "philox")
     e.set_tuning("persist", persist)
-    e.set_tuning("persist_min_groups", 1)
     if store:
         e.chain_config(nsteps)
     ens.append(e)
