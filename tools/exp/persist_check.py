@@ -9,6 +9,8 @@ sys.path.insert(0, ".")
 import bench  # noqa: E402
 from emcee_amd.device import DeviceEnsemble  # noqa: E402
 
+import os
+KEY = os.environ.get("PERSIST_CFG", "c2")          # bench.Workload key: c2 (dense 64) or c3 (Rosenbrock 32)
 sizes = [int(a) for a in sys.argv[1:]] or [65536, 32768, 16384, 4096, 2048]
 
 
@@ -23,10 +25,10 @@ for N in sizes:
     for store in (False, True):
         row = []
         for persist in (0, 1):
-            wl = bench.Workload("c2", N)
+            wl = bench.Workload(KEY, N)
             ens = DeviceEnsemble(wl.N, wl.D, device=0)
             wl.install(ens, "philox")
-            ens.set_tuning("persist", persist)
+            ens.set_tuning("persist", 3 * persist)
             if store:
                 ens.chain_config(160)
             t_end = time.perf_counter() + 0.15
@@ -45,5 +47,5 @@ for N in sizes:
             row.append((np.median(ts) * 1e6, np.median(ts2) * 1e6, ens.status(), ens.persist_info()["launches"]))
             ens.close()
         (a20, a160, s0, l0), (b20, b160, s1, l1) = row
-        print("N=%6d store=%d   K=20: %.2f -> %.2f us/step (%+.1f %%)   K=160: %.2f -> %.2f (%+.1f %%)   status %d/%d  launches %d/%d" % (
+        print(KEY + " N=%6d store=%d   K=20: %.2f -> %.2f us/step (%+.1f %%)   K=160: %.2f -> %.2f (%+.1f %%)   status %d/%d  launches %d/%d" % (
             N, store, a20, b20, (b20 / a20 - 1) * 100, a160, b160, (b160 / a160 - 1) * 100, s0, s1, l0, l1), flush=True)

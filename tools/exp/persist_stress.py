@@ -13,12 +13,13 @@ nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 37
 store = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
 thin = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-wl = bench.Workload("c2", N)
+import os
+wl = bench.Workload(os.environ.get("PERSIST_CFG", "c2"), N)
 ens = []
 for persist in (1, 0):
     e = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(e, "philox")
-    e.set_tuning("persist", persist)
+    e.set_tuning("persist", 3 * persist)
     if store:
         e.chain_config(nsteps)
     ens.append(e)
