@@ -2638,9 +2638,10 @@ static int rccl_all_to_all(emx_ctx* c, size_t count) {
 static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store);
 
 // ---- persistent half-steps ------------------------------------------------------------------------------------------
-// The headline shape -- one stretch move, the fused dense Gaussian target at padded ndim 64, Philox plans, a single replica, an
-// ensemble whose half-step is exactly one 16-walker tile per wave of a co-resident grid of 8-wave workgroups (nwalkers a
-// multiple of 256, at most 256 x the CU count) -- runs up to 16 steps per launch in k_persist (emx_kernels.hpp).
+// The headline shape -- stretch-move or DE-move steps of two splits, the fused dense Gaussian target at padded ndim 64, Philox
+// plans, a single replica, an ensemble whose half-step is exactly one 16-walker tile per wave of a co-resident grid of about one
+// workgroup per CU (persist_shape) -- runs up to 16 steps per launch in k_persist (emx_kernels.hpp); in a mixture of moves a
+// launch takes the consecutive steps of one such move and the other moves' steps go through the per-half-step launches.
 // (Measured and dropped: the next batch's plan kernel on a stream of its own next to the running persistent launch -- no
 // difference, 20.6 us/step either way: what the plan kernel's waves gain in overlap the lock-stepped half-steps lose to them;
 // profiles/r03/persist_side_plan.txt.)
@@ -2657,10 +2658,17 @@ static int persist_shape(const emx_ctx* c) {
     return wpb;
 }
 
+// the moves k_persist has an instantiation for (the other moves of a mixture run their steps through the per-half-step launches)
+static bool persist_move_ok(const emx_move_desc& m) {
+    return (m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2;
+}
+
 static bool persist_wanted(const emx_ctx* c) {
     if (!c->tune_persist) return false;
-    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.size() != 1) return false;
-    if (c->moves[0].kind != EMX_MOVE_STRETCH || c->moves[0].nsplits != 2) return false;
+    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
+    bool any = false;
+    for (const auto& m : c->moves) any = any || persist_move_ok(m);
+    if (!any) return false;
     if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp != 64 || dense_is_wide(c)) return false;
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
     if (c->N < c->tune_persist_min_walkers || persist_shape(c) == 0) return false;
@@ -2692,19 +2700,23 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     size_t lds = 0;
     int n = 0;
     int64_t steps = 0;
+    int launch_move = -1;                // EMX_MOVE_STRETCH or EMX_MOVE_DE: the move of every step of this launch
     while (i0 + steps < total && n + 2 <= PERSIST_MAX_ITERS) {
         if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
+        if (steps > 0 && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
         c->prep_hint = NATIVE_BATCH_MAX;
         const int st = store && ((i0 + steps + 1) % thin_by == 0);          // ensemble.py:416
         int mvi, S;
         int rc = emx_step_begin(c, st, &mvi, &S);
         if (rc) return rc;
+        if (launch_move < 0) launch_move = c->moves[mvi].kind;
         for (int s = 0; s < S; ++s) {
             cap.got = false;
             c->persist_cap = &cap;
             rc = do_halfstep(c, s, c->target);
             c->persist_cap = nullptr;
-            if (!rc && (!cap.got || !cap.dense || cap.dpb != 4 || cap.move != MOVE_STRETCH || (int)cap.block.x != 64 * c->persist_wpb)) {
+            if (!rc && (!cap.got || !cap.dense || cap.dpb != 4 || cap.move != (launch_move == EMX_MOVE_DE ? MOVE_DE : MOVE_STRETCH) ||
+                        (int)cap.block.x != 64 * c->persist_wpb)) {
                 c->err = "persistent half-steps: launch shape not eligible";
                 rc = -1;
             }
@@ -2721,6 +2733,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             PersistIter& I = P.it[n++];
             I.order = cap.a.order;
             I.p0 = cap.a.p0;
+            I.p1 = cap.a.p1;
             I.s0 = cap.a.s0;
             I.logu = cap.a.logu;
             I.fac = cap.a.fac;
@@ -2753,7 +2766,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             if (g_persist_last[dev] && g_persist_last[dev] != c) HIPOK(c, hipStreamWaitEvent(c->stream, g_persist_ev[dev], 0));
         }
         if (prof) HIPOK(c, hipEventRecord(e0, c->stream));
-        const hipError_t e = launch_hot_persist_dense64(grid, block, lds, c->stream, P);
+        const hipError_t e = launch_hot_persist_dense64(launch_move == EMX_MOVE_DE ? MOVE_DE : MOVE_STRETCH, grid, block, lds, c->stream, P);
         if (e != hipSuccess) FAIL(c, -2, "persistent half-step launch failed: %s", hipGetErrorString(e));
         if (prof) {
             HIPOK(c, hipEventRecord(e1, c->stream));
@@ -2840,12 +2853,20 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
             continue;
         }
         if (persist_on) {
-            int64_t done = 0;
-            const int rc = run_persist(c, i, total, thin_by, store, &done);
-            if (rc) return rc;
-            i += done;
-            ctr_synced = false;
-            continue;
+            // the next step's move decides (a mixture: runs of steps of one move the persistent kernel knows, the others one by one)
+            if (!c->prepared.empty() && c->prepared.front().step != c->ph_step) drop_prepared(c);
+            if (c->prepared.empty()) {
+                const int rcp = native_prepare_batch(c, c->ph_step, NATIVE_BATCH_MAX, -1, c->stream);
+                if (rcp) return rcp;
+            }
+            if (persist_move_ok(c->moves[c->prepared.front().move])) {
+                int64_t done = 0;
+                const int rc = run_persist(c, i, total, thin_by, store, &done);
+                if (rc) return rc;
+                i += done;
+                ctr_synced = false;
+                continue;
+            }
         }
         if (thin_by == 1 && total - i >= NATIVE_BATCH_MAX) {
             emx_ctx::GraphSlot* g = graph_ready(c, store);

@@ -9,8 +9,9 @@ hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t ld
     return launch_one<8, 2, 4, MOVE_STRETCH, 4, 1>(grid, block, lds, st, a);
 }
 
-hipError_t launch_hot_persist_dense64(dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-    auto kern = k_persist<8, 2, 4, 4>;
+template <int MOVE>
+static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+    auto kern = k_persist<8, 2, 4, 4, MOVE>;
     static size_t lds_granted[MAX_DEVICES] = {};
     int dev = 0;
     if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
@@ -20,6 +21,11 @@ hipError_t launch_hot_persist_dense64(dim3 grid, dim3 block, size_t lds, hipStre
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, P);
     return hipGetLastError();
+}
+
+hipError_t launch_hot_persist_dense64(int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+    if (move == MOVE_DE) return launch_persist<MOVE_DE>(grid, block, lds, st, P);
+    return launch_persist<MOVE_STRETCH>(grid, block, lds, st, P);
 }
 
 }  // namespace emx

@@ -1162,8 +1162,8 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 }
 
 // ----------------------------------------------------------------------------------------
-// Persistent form of the fused dense stretch half-step: up to PERSIST_MAX_ITERS consecutive half-steps (= 16 steps of two
-// splits) in ONE launch, a device-wide barrier where the kernel boundaries were.  A wave owns the same 16 plan slots of every
+// Persistent form of the fused dense stretch (and DE: MOVE template parameter) half-step: up to PERSIST_MAX_ITERS consecutive
+// half-steps (= 16 steps of two splits) in ONE launch, a device-wide barrier where the kernel boundaries were.  A wave owns the same 16 plan slots of every
 // split (the grid is exactly one 16-walker tile per wave, all workgroups co-resident); the LDS image of the target is staged
 // once.  Two things make it pay:
 //   * no cache maintenance at the barrier.  A fenced device-wide barrier costs 5.0 us, 3.2 of them the L2 write-back and
@@ -1233,7 +1233,7 @@ __device__ __forceinline__ unsigned load_agent(const unsigned* p) { return __hip
 
 constexpr int PERSIST_MAX_ITERS = 32;
 struct PersistIter {
-    const int32_t *order, *p0;
+    const int32_t *order, *p0, *p1;       // (p1: the DE move's second partner)
     const double *s0, *logu, *fac;
     double *chain, *chain_lp;      // this step's row of the stored chain (backend.py:229), or nullptr
     int32_t pos0, split;
@@ -1273,9 +1273,11 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
     __syncthreads();
 }
 
-template <int G, int V, int CH, int DPB>
+template <int G, int V, int CH, int DPB, int MOVE = MOVE_STRETCH>
 static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
-    constexpr int MOVE = MOVE_STRETCH;
+    static_assert(MOVE == MOVE_STRETCH || MOVE == MOVE_DE, "moves with one or two partner rows");
+    constexpr bool DE = MOVE == MOVE_DE;               // de.py:40-64: two partners, q = s + gamma (c[pair 1] - c[pair 0])
+    constexpr bool DEFER = !DE;                        // chain rows one half-step later (the DE form has no registers to spare)
     constexpr int WPW = 64 / G;
     constexpr int PPT = 16 / WPW;
     constexpr int PF = prefetch_depth<G, V, CH, MOVE, DPB>();
@@ -1309,7 +1311,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     const int myrow = (lane >> 4) + 4 * (lane & 3);             // decision lanes: (lane & 15) < 4 decide tile row myrow
     const bool mine = (lane & 15) < 4;
 
-    int wi[PF], ja[PF], my_i;
+    int wi[PF], ja[PF], jb[DE ? PF : 1], my_i;
     double s0v[PF], facv[PF], my_logu, my_lpo;
     Row<G, V, CH> xi[PF];
     {
@@ -1320,6 +1322,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             const int pos = pbase + k * WPW + sub;
             wi[k] = I.order[pos];
             ja[k] = I.p0[pos];
+            if constexpr (DE) jb[k] = I.p1[pos];
             s0v[k] = I.s0[pos];
             facv[k] = I.fac[pos];
         }
@@ -1330,27 +1333,30 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         my_lpo = load_agent(A.lp + my_i);
     }
     // stored steps: the rows (and log-probs) of a half-step leave one half-step later
-    Row<G, V, CH> crow[PF];
+    Row<G, V, CH> crow[DEFER ? PF : 1];
     int cwi[PF], cmy_i = 0;
     double clp = 0.0;
     double *cchain = nullptr, *cchain_lp = nullptr;
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
-        crow[k] = xi[k];
+        if (DEFER || k == 0) crow[DEFER ? k : 0] = xi[k];
         cwi[k] = 0;
     }
     for (int n = 0; n < P.niter; ++n) {
         const PersistIter& I = P.it[n];
         // -------- partner rows: the walkers the previous half-step updated --------
-        Row<G, V, CH> xa[PF];
+        Row<G, V, CH> xa[PF], xb[DE ? PF : 1];
 #pragma unroll
-        for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH>(xa[k], Xr, ja[k], D, gl);
+        for (int k = 0; k < PF; ++k) {
+            load_row_agent<G, V, CH>(xa[k], Xr, ja[k], D, gl);
+            if constexpr (DE) load_row_agent<G, V, CH>(xb[k], Xr, jb[k], D, gl);
+        }
         // -------- plan entries of the next half-step (written by the plan kernel before this launch) --------
         const bool more = n + 1 < P.niter;
         const PersistIter& J = P.it[more ? n + 1 : n];
         const bool pre = more && J.split != 0;                   // its own walkers are this half-step's complement
         const unsigned stamp = P.epoch0 + (unsigned)n + 1u;      // of this half-step (never 0 before the counters wrap)
-        int wi_n[PF], ja_n[PF], my_i_n;
+        int wi_n[PF], ja_n[PF], jb_n[DE ? PF : 1], my_i_n;
         double s0_n[PF], fac_n[PF], my_logu_n;
         {
             const int pbase = J.pos0 + t0;
@@ -1359,6 +1365,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
                 const int pos = pbase + k * WPW + sub;
                 wi_n[k] = J.order[pos];
                 ja_n[k] = J.p0[pos];
+                if constexpr (DE) jb_n[k] = J.p1[pos];
                 s0_n[k] = J.s0[pos];
                 fac_n[k] = J.fac[pos];
             }
@@ -1372,7 +1379,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             const int srow = k * WPW + sub;
             double factor = facv[k];
             Row<G, V, CH> q;
-            make_proposal<G, V, CH, MOVE>(xi[k], xa[k], xa[k], xa[k], s0v[k], A.gammas, D, gl, q, factor, ja[k]);
+            make_proposal<G, V, CH, MOVE>(xi[k], xa[k], xb[DE ? k : 0], xa[k], s0v[k], A.gammas, D, gl, q, factor, ja[k]);
             bool bl = false;
 #pragma unroll
             for (int c = 0; c < CH; ++c)
@@ -1393,7 +1400,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         }
         // -------- stored steps: the rows of the half-step BEFORE go out now, next to the MFMA phase -- issued before its barrier
         //          their 17 MB would sit between the commits and the arrival (every store is acknowledged in order) --------
-        if (cchain) {
+        if (DEFER && cchain) {
 #pragma unroll
             for (int k = 0; k < PF; ++k) store_row_stream<G, V, CH>(crow[k], cchain + (size_t)cwi[k] * D, D, gl);
             if (mine) cchain_lp[cmy_i] = clp;
@@ -1401,7 +1408,12 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         }
         if (I.chain) {
 #pragma unroll
-            for (int k = 0; k < PF; ++k) crow[k] = xi[k];          // an accepted proposal replaces it after the decision
+            for (int k = 0; k < PF; ++k) {
+                if constexpr (DEFER)
+                    crow[k] = xi[k];          // an accepted proposal replaces it after the decision
+                else
+                    store_row_stream<G, V, CH>(xi[k], I.chain + (size_t)wi[k] * D, D, gl);      // fire and forget; overwritten on accept
+            }
         }
         // -------- own rows of the next half-step: in flight during the MFMA phase (speculative unless `pre`) --------
         double my_lpo_n = 0.0;
@@ -1444,7 +1456,10 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
                 store_agent(P.ver + my_i, stamp);
             }
             if (I.chain_lp) {
-                clp = acc ? lpn : my_lpo;
+                if constexpr (DEFER)
+                    clp = acc ? lpn : my_lpo;
+                else
+                    I.chain_lp[my_i] = acc ? lpn : my_lpo;
                 if (acc) store_agent(A.acc_count + my_i, load_agent(A.acc_count + my_i) + 1u);
             }
         }
@@ -1455,10 +1470,15 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             const bool ac = (am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull;
             if (ac) {
                 store_row_agent<G, V, CH>(qk[pp], Xr, wi[pp], D, gl);
-                if (I.chain) crow[pp] = qk[pp];
+                if (I.chain) {
+                    if constexpr (DEFER)
+                        crow[pp] = qk[pp];
+                    else
+                        store_row_stream<G, V, CH>(qk[pp], I.chain + (size_t)wi[pp] * D, D, gl);
+                }
             }
         }
-        if (I.chain) {
+        if (DEFER && I.chain) {
             cchain = I.chain;
             cchain_lp = I.chain_lp;
             cmy_i = my_i;
@@ -1473,6 +1493,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         for (int k = 0; k < PF; ++k) {
             wi[k] = wi_n[k];
             ja[k] = ja_n[k];
+            if constexpr (DE) jb[k] = jb_n[k];
             s0v[k] = s0_n[k];
             facv[k] = fac_n[k];
         }
@@ -1490,7 +1511,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             if (vm == stamp) my_lpo = load_agent(A.lp + my_i);
         }
     }
-    if (cchain) {      // the last half-step's rows
+    if (DEFER && cchain) {      // the last half-step's rows
 #pragma unroll
         for (int k = 0; k < PF; ++k) store_row_stream<G, V, CH>(crow[k], cchain + (size_t)cwi[k] * D, D, gl);
         if (mine) cchain_lp[cmy_i] = clp;

@@ -77,6 +77,32 @@ def test_persistent_kernel_stores_the_chain(thin_by):
     assert p["counts"].sum() > 0
 
 
+@pytest.mark.parametrize("N,store", [(65536, False), (8192, True), (1024, False)])
+def test_de_move_runs_persistently_too(N, store):
+    """DEMove (de.py:40-64: two partner rows, gamma from the plan): the k_persist<..., MOVE_DE> instantiation, same bits"""
+    spec = full_spec(N, 64, "dense", [S("de")], seed=8)
+    p, c = run_both(spec, 37, store=store)
+    assert p["info"]["qualifies"] and p["info"]["halfsteps"] == 74 and c["info"]["launches"] == 0
+    for key in ("x", "lp", "acc") + (("chain", "chain_lp", "counts") if store else ()):
+        assert np.array_equal(p[key], c[key]), key
+
+
+def test_mixture_takes_the_persistent_kernel_for_the_runs_it_can():
+    """BASELINE config 4 (DEMove 0.8 + DESnookerMove 0.2): consecutive DE steps share a persistent launch, snooker steps go
+    through the per-half-step kernels; the chain is the one the per-half-step path alone produces"""
+    spec = FULL["c4_65536x64_dense_de_snooker"]()
+    nst = 40
+    p, c = run_both(spec, nst, store=True)
+    lib = _lib.load()
+    from emx_testlib import cdf_of
+    cdf = cdf_of(spec["weights"], len(spec["moves"]))
+    n_de = sum(1 for step in range(nst) if spec["moves"][lib.emx_host_move_choice_philox(SEED, step, cdf, len(cdf))].kind == "de")
+    assert 0 < n_de < nst
+    assert p["info"]["halfsteps"] == 2 * n_de and 1 <= p["info"]["launches"] <= n_de and c["info"]["launches"] == 0
+    for key in ("x", "lp", "acc", "chain", "chain_lp", "counts"):
+        assert np.array_equal(p[key], c[key]), key
+
+
 def test_persistent_kernel_equals_the_oracle_at_the_headline_size():
     """BASELINE config 2 through emx_run (one launch of 3 steps): the oracle's arithmetic applied with the host twin of the
     Philox plans gives the same chain, bit for bit, and the same accept counters."""
@@ -125,9 +151,9 @@ def test_persistent_launches_and_the_step_api_interleave():
     ens.set_philox(SEED, 20)
     ref2 = native_ens(spec, 0)
     ref2.run(20, 1, False)
-    de = [move_desc(S("de"), 64)]              # another move set: no longer the persistent shape
+    sn = [move_desc(S("snooker"), 64)]         # a move the persistent kernel has no instantiation for
     for e in (ens, ref2):
-        e.set_moves(de, np.array([1.0]))
+        e.set_moves(sn, np.array([1.0]))
         e.run(5, 1, False)
     assert not ens.persist_info()["qualifies"]
     launches = ens.persist_info()["launches"]
