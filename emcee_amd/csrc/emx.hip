@@ -905,7 +905,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         pc.dpb = c->Dp / 16;
         pc.dense = dense;
         pc.lean = lean_kind(a, sh.G, sh.V, sh.CH, move, dense);
-        pc.got = nbatch == nblocks * waves_per_block && (nown % spw) == 0 && sh.G == 8 && sh.V == 2 && sh.CH == 4;     // every wave exactly one full tile
+        pc.got = nbatch == nblocks * waves_per_block && (nown % spw) == 0;     // every wave exactly one full tile
         return 0;
     }
     hipError_t e = dispatch_halfstep(move, dense, c->Dp / 16, sh, dim3((unsigned)nblocks), dim3(64 * waves_per_block), lds,
@@ -2669,11 +2669,13 @@ static bool persist_wanted(const emx_ctx* c) {
     bool any = false;
     for (const auto& m : c->moves) any = any || persist_move_ok(m);
     if (!any) return false;
-    if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp != 64 || dense_is_wide(c)) return false;
+    if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || dense_is_wide(c)) return false;
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
     if (c->N < c->tune_persist_min_walkers || persist_shape(c) == 0) return false;
+    // even ndim up to 64 (two coordinates per lane, rows of 8 lanes): the row layouts k_persist is instantiated for
     const Shape sh = pick_shape(c->D, c->Dp);
-    return sh.G == 8 && sh.V == 2 && sh.CH == 4;
+    const int dpb = c->Dp / 16;
+    return sh.G == 8 && sh.V == 2 && sh.CH == (dpb == 1 ? 1 : dpb == 2 ? 2 : 4);
 }
 
 // Two persistent grids that each hold part of the device would wait for each other until their barriers time out: launches of
@@ -2715,7 +2717,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             c->persist_cap = &cap;
             rc = do_halfstep(c, s, c->target);
             c->persist_cap = nullptr;
-            if (!rc && (!cap.got || !cap.dense || cap.dpb != 4 || cap.move != (launch_move == EMX_MOVE_DE ? MOVE_DE : MOVE_STRETCH) ||
+            if (!rc && (!cap.got || !cap.dense || cap.dpb != c->Dp / 16 || cap.move != (launch_move == EMX_MOVE_DE ? MOVE_DE : MOVE_STRETCH) ||
                         (int)cap.block.x != 64 * c->persist_wpb)) {
                 c->err = "persistent half-steps: launch shape not eligible";
                 rc = -1;
@@ -2766,7 +2768,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             if (g_persist_last[dev] && g_persist_last[dev] != c) HIPOK(c, hipStreamWaitEvent(c->stream, g_persist_ev[dev], 0));
         }
         if (prof) HIPOK(c, hipEventRecord(e0, c->stream));
-        const hipError_t e = launch_hot_persist_dense64(launch_move == EMX_MOVE_DE ? MOVE_DE : MOVE_STRETCH, grid, block, lds, c->stream, P);
+        const hipError_t e = launch_hot_persist_dense(c->Dp / 16, launch_move == EMX_MOVE_DE ? MOVE_DE : MOVE_STRETCH, grid, block, lds, c->stream, P);
         if (e != hipSuccess) FAIL(c, -2, "persistent half-step launch failed: %s", hipGetErrorString(e));
         if (prof) {
             HIPOK(c, hipEventRecord(e1, c->stream));
@@ -2822,7 +2824,8 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
     c->direct_first_barrier = true;
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     const int64_t total = nsteps * thin_by;
-    const bool persist_on = persist_wanted(c) && !small_eligible(c);
+    // (padded ndim 16 with a stored chain is the one measured shape the persistent kernel loses on: +5 %, profiles/r03/persist_dims.txt)
+    const bool persist_on = persist_wanted(c) && !small_eligible(c) && !(store && c->Dp == 16);
     bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
     int64_t next_mark = c->tune_throttle > 0 ? c->tune_throttle : total + 1;
     int marks = 0;

@@ -9,9 +9,9 @@ hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t ld
     return launch_one<8, 2, 4, MOVE_STRETCH, 4, 1>(grid, block, lds, st, a);
 }
 
-template <int MOVE>
+template <int G, int V, int CH, int DPB, int MOVE>
 static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-    auto kern = k_persist<8, 2, 4, 4, MOVE>;
+    auto kern = k_persist<G, V, CH, DPB, MOVE>;
     static size_t lds_granted[MAX_DEVICES] = {};
     int dev = 0;
     if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
@@ -23,9 +23,14 @@ static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_hot_persist_dense64(int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-    if (move == MOVE_DE) return launch_persist<MOVE_DE>(grid, block, lds, st, P);
-    return launch_persist<MOVE_STRETCH>(grid, block, lds, st, P);
+// padded ndim 16 * dpb, even ndim (two coordinates per lane): rows of 8 lanes, dpb = 1 ... 4
+hipError_t launch_hot_persist_dense(int dpb, int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+#define EMX_CASE(b, ch)                                                                                       \
+    if (dpb == b) return move == MOVE_DE ? launch_persist<8, 2, ch, b, MOVE_DE>(grid, block, lds, st, P)        \
+                                         : launch_persist<8, 2, ch, b, MOVE_STRETCH>(grid, block, lds, st, P);
+    EMX_CASE(1, 1) EMX_CASE(2, 2) EMX_CASE(3, 4) EMX_CASE(4, 4)
+#undef EMX_CASE
+    return hipErrorInvalidValue;
 }
 
 }  // namespace emx

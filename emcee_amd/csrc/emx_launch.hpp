@@ -28,9 +28,10 @@ hipError_t launch_one(dim3 grid, dim3 block, size_t lds, hipStream_t st, const H
 // while the same flag costs the element-wise kernels up to 6 % (C3), so it is not a global build flag (nor one for C4's DE /
 // snooker kernels of the same shape: 33.2 -> 33.9 us/step under it, round 3, profiles/r03/ab_hot_de_snooker.txt).
 hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a);
-// ... and its persistent form (k_persist of the same shape, stretch or DE move): `P.niter` half-steps in one launch.  The grid must be co-resident
+// ... and its persistent form (k_persist; padded ndim 16 ... 64 with two coordinates per lane, stretch or DE move): `P.niter`
+// half-steps in one launch.  The grid must be co-resident
 // (one workgroup per CU at most).
-hipError_t launch_hot_persist_dense64(int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
+hipError_t launch_hot_persist_dense(int dpb, int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
 
 // Wide dense Gaussian targets (padded ndim > 112, emx_wide.hip): log-probs of a block of rows, and the decision + commit
 // of a half-step whose proposals sit in qout / fout.

@@ -331,7 +331,7 @@ int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int
 
 /* Persistent half-steps.  emx_run takes the headline shape -- stretch-move steps (red_blue.py:55-106 with stretch.py:27-34) and
  * DE-move steps (de.py:40-64) of two splits, the
- * fused dense Gaussian target at padded ndim 64, Philox plans, one replica, nwalkers a multiple of 32 from 512 (tuning
+ * fused dense Gaussian target at an even ndim up to 64, Philox plans, one replica, nwalkers a multiple of 32 from 512 (tuning
  * "persist_min_walkers") to 256 x the CU count, i.e. one 16-walker tile per wave of a co-resident grid of about one workgroup
  * per CU -- up to 16 steps per kernel launch (in a mixture: the consecutive steps of one such move; the steps of other moves
  * take the per-half-step launches): a device-wide barrier stands where the kernel

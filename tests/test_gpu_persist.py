@@ -52,11 +52,13 @@ def run_both(spec, nsteps, thin_by=1, store=False, calls=1):
     return out
 
 
-@pytest.mark.parametrize("N,D", [(65536, 64), (49152, 64), (32768, 64), (4096, 64), (1024, 64), (512, 64), (16384, 50), (8192, 62), (2080, 64)])
+@pytest.mark.parametrize("N,D", [(65536, 64), (49152, 64), (32768, 64), (4096, 64), (1024, 64), (512, 64), (16384, 50), (8192, 62), (2080, 64),
+                                 (65536, 32), (8192, 16), (4096, 10), (16384, 24), (8192, 48), (2048, 40)])
 def test_persistent_kernel_gives_the_bits_of_the_launch_per_halfstep_path(N, D):
     """37 steps (16 + 16 + 5: full and partial launches), no chain: coordinates, log-probs and the last accept marks bit-equal;
     the persistent run really was persistent (launch and half-step counters), the control really was not.  The sizes cover
-    every workgroup shape of the persistent grid (8, 4, 2 and 1 waves: about one workgroup per CU)."""
+    every workgroup shape of the persistent grid (8, 4, 2 and 1 waves: about one workgroup per CU) and every row layout
+    k_persist is instantiated for (even ndim up to 64: padded to 16, 32, 48, 64)."""
     spec = dense_spec(N, D)
     p, c = run_both(spec, 37)
     assert p["info"]["qualifies"] and p["info"]["halfsteps"] == 74 and p["info"]["launches"] == 3
@@ -170,7 +172,7 @@ def test_persistent_launches_and_the_step_api_interleave():
 
 
 def test_what_does_not_qualify():
-    for N, D, why in ((1000, 64, "half an ensemble of whole 16-walker tiles"), (4096, 32, "another row layout"), (4096, 63, "odd ndim"),
+    for N, D, why in ((1000, 64, "half an ensemble of whole 16-walker tiles"), (4096, 66, "ndim above 64"), (4096, 63, "odd ndim"),
                       (131072, 64, "more tiles than waves"), (480, 64, "below persist_min_walkers")):
         ens = native_ens(dense_spec(N, D), 1)
         assert not ens.persist_info()["qualifies"], why

@@ -26,6 +26,14 @@ for N in sizes:
         row = []
         for persist in (0, 1):
             wl = bench.Workload(KEY, N)
+            if os.environ.get("PERSIST_D"):        # the dense target at another even ndim <= 64
+                from emcee_amd import _lib
+                Dn = int(os.environ["PERSIST_D"])
+                mu, cov, icov = bench.dense_gaussian(Dn)
+                wl.D = Dn
+                wl.target = (_lib.TARGET_DENSE, mu, icov, 0.0)
+                wl.p0 = mu + np.random.RandomState(1).randn(N, Dn) @ np.linalg.cholesky(cov).T
+                wl.moves = [("stretch", _lib.MoveDesc(0, 2, 1, 0, 2.0, 1e-5, 2.38 / np.sqrt(2 * Dn), 1.7))]
             ens = DeviceEnsemble(wl.N, wl.D, device=0)
             wl.install(ens, "philox")
             ens.set_tuning("persist", 3 * persist)
@@ -47,5 +55,5 @@ for N in sizes:
             row.append((np.median(ts) * 1e6, np.median(ts2) * 1e6, ens.status(), ens.persist_info()["launches"]))
             ens.close()
         (a20, a160, s0, l0), (b20, b160, s1, l1) = row
-        print(KEY + " N=%6d store=%d   K=20: %.2f -> %.2f us/step (%+.1f %%)   K=160: %.2f -> %.2f (%+.1f %%)   status %d/%d  launches %d/%d" % (
+        print(KEY + os.environ.get("PERSIST_D", "") + " N=%6d store=%d   K=20: %.2f -> %.2f us/step (%+.1f %%)   K=160: %.2f -> %.2f (%+.1f %%)   status %d/%d  launches %d/%d" % (
             N, store, a20, b20, (b20 / a20 - 1) * 100, a160, b160, (b160 / a160 - 1) * 100, s0, s1, l0, l1), flush=True)
