@@ -411,11 +411,20 @@ def config_entry(wl, res, K, store):
                         "achieved": wl.N * B / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": wl.N * B / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                         "frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS,
-                        "avg_launch_us": ev_ms * 1e3 / lps * res.get("halfsteps_per_launch", 1.0), "per_launch_event_us": res["per_launch_us"],
-                        "launches_per_step": lps / res.get("halfsteps_per_launch", 1.0)}}
-    if res.get("halfsteps_per_launch", 1.0) > 1.0:
-        out["roofline"]["kernel"] = "emx::k_persist<8,2,4,DPB=4>: %.1f half-steps per launch" % res["halfsteps_per_launch"]
-        out["roofline"]["per_launch_event_halfsteps"] = res.get("per_launch_halfsteps")
+                        "avg_launch_us": ev_ms * 1e3 / lps, "per_launch_event_us": res["per_launch_us"],
+                        "launches_per_step": lps}}
+    hpl = res.get("halfsteps_per_launch", 1.0)
+    if hpl > 1.0 and len(wl.moves) == 1:
+        # every step through the persistent kernel: a launch is hpl half-steps
+        out["roofline"].update({"kernel": "emx::k_persist<8,2,4,DPB=4>: %.1f half-steps per launch" % hpl,
+                                "avg_launch_us": ev_ms * 1e3 / lps * hpl, "launches_per_step": lps / hpl, "avg_halfstep_us": ev_ms * 1e3 / lps,
+                                "per_launch_event_halfsteps": res.get("per_launch_halfsteps")})
+    elif hpl > 1.0:
+        # a mixture: the runs of consecutive DE steps share persistent launches (k_persist<..., MOVE_DE>), the snooker steps take the
+        # per-half-step kernels; avg_launch_us stays the timed region / half-steps
+        out["roofline"]["kernel"] = ("DE steps: emx::k_persist<8,2,4,DPB=4,MOVE_DE>, %.1f half-steps per launch (a run of consecutive DE steps); "
+                                     "snooker steps: emx::k_halfstep<8,2,4,SNOOKER,4,LEAN>" % hpl)
+        out["roofline"]["avg_launch_us_is"] = "hipEvent time of the timed region / half-steps (persistent launches counted by their half-steps)"
     state_mb = wl.N * wl.D * 8 / 1e6
     if state_mb > 256.0:
         out["roofline"].update({"state_MB": state_mb, "beyond_infinity_cache": True,

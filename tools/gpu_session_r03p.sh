@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round 3 closing session after the persistent kernel: the suite, the driver's bench command (+ --pmc), rocprofv3 summaries of the same command
 set -u
-mkdir -p gpurun_out/r03t
-O=gpurun_out/r03t
+mkdir -p gpurun_out/r03z
+O=gpurun_out/r03z
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; tail -2 $O/bench_n1.err; head -c 400 $O/bench_n1.json; echo
