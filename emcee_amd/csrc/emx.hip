@@ -456,6 +456,7 @@ struct emx_ctx {
     unsigned* persist_bar = nullptr;
     unsigned* persist_ver = nullptr;  // (N) stamp of the half-step that last moved the walker
     unsigned persist_epoch = 0;
+    unsigned persist_grid = 0;        // workgroups of the launches the barrier counters have counted so far
     int64_t tune_replay_two_pass = 0;         // 1: the replay exchange always compacts, then replays (tests of that form)
     int64_t tune_full_plan = 0;      // 1: native plans always carry every column
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
@@ -2638,19 +2639,20 @@ static int rccl_all_to_all(emx_ctx* c, size_t count) {
 static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store);
 
 // ---- persistent half-steps ------------------------------------------------------------------------------------------
-// The headline shape -- stretch-move or DE-move steps of two splits, the fused dense Gaussian target at padded ndim 64, Philox
-// plans, a single replica, an ensemble whose half-step is exactly one 16-walker tile per wave of a co-resident grid of about one
-// workgroup per CU (persist_shape) -- runs up to 16 steps per launch in k_persist (emx_kernels.hpp); in a mixture of moves a
-// launch takes the consecutive steps of one such move and the other moves' steps go through the per-half-step launches.
+// The headline shape -- stretch / DE steps of two splits and snooker steps of four, the fused dense Gaussian target at an even
+// ndim up to 64, Philox plans, a single replica, an ensemble whose half-step is exactly one 16-walker tile per wave of a
+// co-resident grid of about one workgroup per CU (persist_shape) -- runs up to 32 half-steps per launch in k_persist
+// (emx_kernels.hpp); in a mixture of moves a launch takes the consecutive steps of one move.
 // (Measured and dropped: the next batch's plan kernel on a stream of its own next to the running persistent launch -- no
 // difference, 20.6 us/step either way: what the plan kernel's waves gain in overlap the lock-stepped half-steps lose to them;
 // profiles/r03/persist_side_plan.txt.)
-// -> waves per workgroup of the persistent grid (0: the ensemble does not fit one): every wave exactly one 16-walker tile of a
-// half-step, about one workgroup per CU, all of them co-resident
-static int persist_shape(const emx_ctx* c) {
-    const int64_t half = c->N / 2;
-    if ((c->N & 1) || (half % 16) != 0) return 0;
-    const int64_t tiles = half / 16;
+// -> waves per workgroup of the persistent grid for a move of `nsplits` splits (0: the ensemble does not fit one): every wave
+// exactly one 16-walker tile of a half-step, about one workgroup per CU, all of them co-resident
+static int persist_shape(const emx_ctx* c, int nsplits) {
+    if (nsplits < 2 || (c->N % nsplits) != 0) return 0;
+    const int64_t own = c->N / nsplits;
+    if ((own % 16) != 0) return 0;
+    const int64_t tiles = own / 16;
     const int64_t cu = std::max(1, c->num_cu);
     int wpb = tiles >= 6 * cu ? 8 : tiles >= 3 * cu ? 4 : tiles >= 3 * cu / 2 ? 2 : 1;
     while (wpb > 1 && (tiles % wpb) != 0) wpb >>= 1;
@@ -2659,19 +2661,20 @@ static int persist_shape(const emx_ctx* c) {
 }
 
 // the moves k_persist has an instantiation for (the other moves of a mixture run their steps through the per-half-step launches)
-static bool persist_move_ok(const emx_move_desc& m) {
-    return (m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2;
+static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
+    const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
+    return known && persist_shape(c, m.nsplits) != 0;
 }
 
 static bool persist_wanted(const emx_ctx* c) {
     if (!c->tune_persist) return false;
     if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
-    bool any = false;
-    for (const auto& m : c->moves) any = any || persist_move_ok(m);
-    if (!any) return false;
     if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || dense_is_wide(c)) return false;
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
-    if (c->N < c->tune_persist_min_walkers || persist_shape(c) == 0) return false;
+    if (c->N < c->tune_persist_min_walkers) return false;
+    bool any = false;
+    for (const auto& m : c->moves) any = any || persist_move_ok(c, m);
+    if (!any) return false;
     // even ndim up to 64 (two coordinates per lane, rows of 8 lanes): the row layouts k_persist is instantiated for
     const Shape sh = pick_shape(c->D, c->Dp);
     const int dpb = c->Dp / 16;
@@ -2695,15 +2698,15 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         HIPOK(c, hipMalloc((void**)&c->persist_ver, (size_t)c->N * 4));
         HIPOK(c, hipMemsetAsync(c->persist_ver, 0, (size_t)c->N * 4, c->stream));
     }
-    c->persist_wpb = persist_shape(c);
     PersistArgs P{};
     emx_ctx::PersistCapture cap{};
     dim3 grid, block;
     size_t lds = 0;
     int n = 0;
     int64_t steps = 0;
-    int launch_move = -1;                // EMX_MOVE_STRETCH or EMX_MOVE_DE: the move of every step of this launch
-    while (i0 + steps < total && n + 2 <= PERSIST_MAX_ITERS) {
+    int launch_move = -1;                // EMX_MOVE_STRETCH, _DE or _SNOOKER: the move of every step of this launch
+    int launch_S = 2;
+    while (i0 + steps < total && n + launch_S <= PERSIST_MAX_ITERS) {
         if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
         if (steps > 0 && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
         c->prep_hint = NATIVE_BATCH_MAX;
@@ -2711,13 +2714,17 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         int mvi, S;
         int rc = emx_step_begin(c, st, &mvi, &S);
         if (rc) return rc;
-        if (launch_move < 0) launch_move = c->moves[mvi].kind;
+        if (launch_move < 0) {
+            launch_move = c->moves[mvi].kind;
+            launch_S = S;
+            c->persist_wpb = persist_shape(c, S);
+        }
         for (int s = 0; s < S; ++s) {
             cap.got = false;
             c->persist_cap = &cap;
             rc = do_halfstep(c, s, c->target);
             c->persist_cap = nullptr;
-            if (!rc && (!cap.got || !cap.dense || cap.dpb != c->Dp / 16 || cap.move != (launch_move == EMX_MOVE_DE ? MOVE_DE : MOVE_STRETCH) ||
+            if (!rc && (!cap.got || !cap.dense || cap.dpb != c->Dp / 16 || cap.move != launch_move ||
                         (int)cap.block.x != 64 * c->persist_wpb)) {
                 c->err = "persistent half-steps: launch shape not eligible";
                 rc = -1;
@@ -2736,6 +2743,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             I.order = cap.a.order;
             I.p0 = cap.a.p0;
             I.p1 = cap.a.p1;
+            I.p2 = cap.a.p2;
             I.s0 = cap.a.s0;
             I.logu = cap.a.logu;
             I.fac = cap.a.fac;
@@ -2747,6 +2755,13 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         rc = emx_step_end(c);
         if (rc) return rc;
         ++steps;
+    }
+    if (grid.x != c->persist_grid) {
+        // the arrival counters count workgroups: another grid size (another move of a mixture, another ensemble shape) starts them
+        // afresh -- on the stream, i.e. after every earlier launch has left the barrier
+        HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 10 * 32 * sizeof(unsigned), c->stream));
+        c->persist_epoch = 0;
+        c->persist_grid = grid.x;
     }
     P.niter = n;
     P.bar = c->persist_bar;
@@ -2768,7 +2783,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             if (g_persist_last[dev] && g_persist_last[dev] != c) HIPOK(c, hipStreamWaitEvent(c->stream, g_persist_ev[dev], 0));
         }
         if (prof) HIPOK(c, hipEventRecord(e0, c->stream));
-        const hipError_t e = launch_hot_persist_dense(c->Dp / 16, launch_move == EMX_MOVE_DE ? MOVE_DE : MOVE_STRETCH, grid, block, lds, c->stream, P);
+        const hipError_t e = launch_hot_persist_dense(c->Dp / 16, launch_move, grid, block, lds, c->stream, P);
         if (e != hipSuccess) FAIL(c, -2, "persistent half-step launch failed: %s", hipGetErrorString(e));
         if (prof) {
             HIPOK(c, hipEventRecord(e1, c->stream));
@@ -2862,7 +2877,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
                 const int rcp = native_prepare_batch(c, c->ph_step, NATIVE_BATCH_MAX, -1, c->stream);
                 if (rcp) return rcp;
             }
-            if (persist_move_ok(c->moves[c->prepared.front().move])) {
+            if (persist_move_ok(c, c->moves[c->prepared.front().move])) {
                 int64_t done = 0;
                 const int rc = run_persist(c, i, total, thin_by, store, &done);
                 if (rc) return rc;

@@ -25,9 +25,11 @@ static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t 
 
 // padded ndim 16 * dpb, even ndim (two coordinates per lane): rows of 8 lanes, dpb = 1 ... 4
 hipError_t launch_hot_persist_dense(int dpb, int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-#define EMX_CASE(b, ch)                                                                                       \
-    if (dpb == b) return move == MOVE_DE ? launch_persist<8, 2, ch, b, MOVE_DE>(grid, block, lds, st, P)        \
-                                         : launch_persist<8, 2, ch, b, MOVE_STRETCH>(grid, block, lds, st, P);
+#define EMX_CASE(b, ch)                                                                                            \
+    if (dpb == b)                                                                                                  \
+        return move == MOVE_DE        ? launch_persist<8, 2, ch, b, MOVE_DE>(grid, block, lds, st, P)              \
+               : move == MOVE_SNOOKER ? launch_persist<8, 2, ch, b, MOVE_SNOOKER>(grid, block, lds, st, P)         \
+                                      : launch_persist<8, 2, ch, b, MOVE_STRETCH>(grid, block, lds, st, P);
     EMX_CASE(1, 1) EMX_CASE(2, 2) EMX_CASE(3, 4) EMX_CASE(4, 4)
 #undef EMX_CASE
     return hipErrorInvalidValue;

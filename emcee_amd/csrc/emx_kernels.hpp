@@ -1162,8 +1162,8 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 }
 
 // ----------------------------------------------------------------------------------------
-// Persistent form of the fused dense stretch (and DE: MOVE template parameter) half-step: up to PERSIST_MAX_ITERS consecutive
-// half-steps (= 16 steps of two splits) in ONE launch, a device-wide barrier where the kernel boundaries were.  A wave owns the same 16 plan slots of every
+// Persistent form of the fused dense half-step (stretch, DE or snooker: MOVE template parameter): up to PERSIST_MAX_ITERS
+// consecutive half-steps (= 16 steps of two splits, 8 of four) in ONE launch, a device-wide barrier where the kernel boundaries were.  A wave owns the same 16 plan slots of every
 // split (the grid is exactly one 16-walker tile per wave, all workgroups co-resident); the LDS image of the target is staged
 // once.  Two things make it pay:
 //   * no cache maintenance at the barrier.  A fenced device-wide barrier costs 5.0 us, 3.2 of them the L2 write-back and
@@ -1233,7 +1233,7 @@ __device__ __forceinline__ unsigned load_agent(const unsigned* p) { return __hip
 
 constexpr int PERSIST_MAX_ITERS = 32;
 struct PersistIter {
-    const int32_t *order, *p0, *p1;       // (p1: the DE move's second partner)
+    const int32_t *order, *p0, *p1, *p2;  // (p1: the DE move's second partner; p1, p2: the snooker move's z1, z2)
     const double *s0, *logu, *fac;
     double *chain, *chain_lp;      // this step's row of the stored chain (backend.py:229), or nullptr
     int32_t pos0, split;
@@ -1275,13 +1275,14 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
 
 template <int G, int V, int CH, int DPB, int MOVE = MOVE_STRETCH>
 static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
-    static_assert(MOVE == MOVE_STRETCH || MOVE == MOVE_DE, "moves with one or two partner rows");
-    constexpr bool DE = MOVE == MOVE_DE;               // de.py:40-64: two partners, q = s + gamma (c[pair 1] - c[pair 0])
-    constexpr bool DEFER = !DE;                        // chain rows one half-step later (the DE form has no registers to spare)
+    static_assert(MOVE == MOVE_STRETCH || MOVE == MOVE_DE || MOVE == MOVE_SNOOKER, "the red / blue moves");
+    constexpr bool DE = MOVE == MOVE_DE || MOVE == MOVE_SNOOKER;   // de.py:40-64: two partners, q = s + gamma (c[pair 1] - c[pair 0])
+    constexpr bool SN = MOVE == MOVE_SNOOKER;          // de_snooker.py:31-46: three partners z, z1, z2 (one from each other set)
+    constexpr bool DEFER = !DE;                        // chain rows one half-step later (the other forms have no registers to spare)
     constexpr int WPW = 64 / G;
     constexpr int PPT = 16 / WPW;
-    constexpr int PF = prefetch_depth<G, V, CH, MOVE, DPB>();
-    static_assert(PF == PPT && EMX_OPT_RTILE && EMX_OPT_RED4, "the persistent kernel is the one-tile-per-batch form");
+    constexpr int PF = PPT;        // every pass of the tile in one batch (k_halfstep's snooker form splits it: two dependent round trips)
+    static_assert(EMX_OPT_RTILE && EMX_OPT_RED4, "the persistent kernel is the one-tile-per-batch form");
     constexpr int Dp = DPB * 16, KK = Dp / 4, RT = Dp + 2;
     static_assert(G * V * CH >= Dp, "row layout must cover the padded dimension");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1311,7 +1312,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     const int myrow = (lane >> 4) + 4 * (lane & 3);             // decision lanes: (lane & 15) < 4 decide tile row myrow
     const bool mine = (lane & 15) < 4;
 
-    int wi[PF], ja[PF], jb[DE ? PF : 1], my_i;
+    int wi[PF], ja[PF], jb[DE ? PF : 1], jc[SN ? PF : 1], my_i;
     double s0v[PF], facv[PF], my_logu, my_lpo;
     Row<G, V, CH> xi[PF];
     {
@@ -1323,7 +1324,8 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             wi[k] = I.order[pos];
             ja[k] = I.p0[pos];
             if constexpr (DE) jb[k] = I.p1[pos];
-            s0v[k] = I.s0[pos];
+            if constexpr (SN) jc[k] = I.p2[pos];
+            s0v[k] = SN ? 0.0 : I.s0[pos];
             facv[k] = I.fac[pos];
         }
         my_i = I.order[pbase + myrow];
@@ -1345,18 +1347,19 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     for (int n = 0; n < P.niter; ++n) {
         const PersistIter& I = P.it[n];
         // -------- partner rows: the walkers the previous half-step updated --------
-        Row<G, V, CH> xa[PF], xb[DE ? PF : 1];
+        Row<G, V, CH> xa[PF], xb[DE ? PF : 1], xc[SN ? PF : 1];
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             load_row_agent<G, V, CH>(xa[k], Xr, ja[k], D, gl);
             if constexpr (DE) load_row_agent<G, V, CH>(xb[k], Xr, jb[k], D, gl);
+            if constexpr (SN) load_row_agent<G, V, CH>(xc[k], Xr, jc[k], D, gl);
         }
         // -------- plan entries of the next half-step (written by the plan kernel before this launch) --------
         const bool more = n + 1 < P.niter;
         const PersistIter& J = P.it[more ? n + 1 : n];
         const bool pre = more && J.split != 0;                   // its own walkers are this half-step's complement
         const unsigned stamp = P.epoch0 + (unsigned)n + 1u;      // of this half-step (never 0 before the counters wrap)
-        int wi_n[PF], ja_n[PF], jb_n[DE ? PF : 1], my_i_n;
+        int wi_n[PF], ja_n[PF], jb_n[DE ? PF : 1], jc_n[SN ? PF : 1], my_i_n;
         double s0_n[PF], fac_n[PF], my_logu_n;
         {
             const int pbase = J.pos0 + t0;
@@ -1366,7 +1369,8 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
                 wi_n[k] = J.order[pos];
                 ja_n[k] = J.p0[pos];
                 if constexpr (DE) jb_n[k] = J.p1[pos];
-                s0_n[k] = J.s0[pos];
+                if constexpr (SN) jc_n[k] = J.p2[pos];
+                s0_n[k] = SN ? 0.0 : J.s0[pos];
                 fac_n[k] = J.fac[pos];
             }
             my_i_n = J.order[pbase + myrow];
@@ -1379,7 +1383,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             const int srow = k * WPW + sub;
             double factor = facv[k];
             Row<G, V, CH> q;
-            make_proposal<G, V, CH, MOVE>(xi[k], xa[k], xb[DE ? k : 0], xa[k], s0v[k], A.gammas, D, gl, q, factor, ja[k]);
+            make_proposal<G, V, CH, MOVE>(xi[k], xa[k], xb[DE ? k : 0], xc[SN ? k : 0], s0v[k], A.gammas, D, gl, q, factor, ja[k]);
             bool bl = false;
 #pragma unroll
             for (int c = 0; c < CH; ++c)
@@ -1494,6 +1498,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             wi[k] = wi_n[k];
             ja[k] = ja_n[k];
             if constexpr (DE) jb[k] = jb_n[k];
+            if constexpr (SN) jc[k] = jc_n[k];
             s0v[k] = s0_n[k];
             facv[k] = fac_n[k];
         }

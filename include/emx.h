@@ -330,11 +330,11 @@ int emx_profile_read(emx_ctx* ctx, float* ms_out, int32_t* n_inout);
 int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int32_t* finisher_threads);
 
 /* Persistent half-steps.  emx_run takes the headline shape -- stretch-move steps (red_blue.py:55-106 with stretch.py:27-34) and
- * DE-move steps (de.py:40-64) of two splits, the
+ * DE-move steps (de.py:40-64) of two splits, snooker steps (de_snooker.py:31-46) of four, the
  * fused dense Gaussian target at an even ndim up to 64, Philox plans, one replica, nwalkers a multiple of 32 from 512 (tuning
  * "persist_min_walkers") to 256 x the CU count, i.e. one 16-walker tile per wave of a co-resident grid of about one workgroup
- * per CU -- up to 16 steps per kernel launch (in a mixture: the consecutive steps of one such move; the steps of other moves
- * take the per-half-step launches): a device-wide barrier stands where the kernel
+ * per CU -- up to 32 half-steps per kernel launch (in a mixture: the consecutive steps of one move; steps with another number of
+ * splits take the per-half-step launches): a device-wide barrier stands where the kernel
  * boundaries were, and the next half-step's plan entries and own rows are loaded while this one computes.  Same draws, same
  * arithmetic, same bits as the launch-per-half-step path.  Tuning "persist" = 0 turns it off; "persist_timeout_ms" bounds a
  * barrier wait (default 2000: a grid that cannot become co-resident -- another process holding the device's CUs -- raises

@@ -28,6 +28,7 @@ def native_ens(spec, persist, step=0):
     ens.set_rng_mode(_lib.RNG_PHILOX)
     ens.set_philox(SEED, step)
     ens.set_tuning("persist", persist)
+    ens.set_tuning("persist_timeout_ms", 100)        # (a test that deadlocks should fail in a moment, not after seconds per barrier)
     return ens
 
 
@@ -89,9 +90,21 @@ def test_de_move_runs_persistently_too(N, store):
         assert np.array_equal(p[key], c[key]), key
 
 
+@pytest.mark.parametrize("N,D,store", [(65536, 64, False), (8192, 64, True), (2048, 32, False), (4096, 48, True)])
+def test_snooker_move_runs_persistently_too(N, D, store):
+    """DESnookerMove (de_snooker.py:31-46: four splits, three partner rows, norms and dots by group reductions): the
+    k_persist<..., MOVE_SNOOKER> instantiation loads the whole 16-row tile's rows in ONE round trip where k_halfstep takes two
+    -- the same arithmetic per walker, the same bits"""
+    spec = full_spec(N, D, "dense", [S("snooker")], seed=9)
+    p, c = run_both(spec, 21, store=store)
+    assert p["info"]["qualifies"] and p["info"]["halfsteps"] == 4 * 21 and p["info"]["launches"] == 3 and c["info"]["launches"] == 0
+    for key in ("x", "lp", "acc") + (("chain", "chain_lp", "counts") if store else ()):
+        assert np.array_equal(p[key], c[key]), key
+
+
 def test_mixture_takes_the_persistent_kernel_for_the_runs_it_can():
-    """BASELINE config 4 (DEMove 0.8 + DESnookerMove 0.2): consecutive DE steps share a persistent launch, snooker steps go
-    through the per-half-step kernels; the chain is the one the per-half-step path alone produces"""
+    """BASELINE config 4 (DEMove 0.8 + DESnookerMove 0.2): the consecutive steps of one move share a persistent launch (two
+    half-steps per DE step, four per snooker step); the chain is the one the per-half-step path alone produces"""
     spec = FULL["c4_65536x64_dense_de_snooker"]()
     nst = 40
     p, c = run_both(spec, nst, store=True)
@@ -100,7 +113,17 @@ def test_mixture_takes_the_persistent_kernel_for_the_runs_it_can():
     cdf = cdf_of(spec["weights"], len(spec["moves"]))
     n_de = sum(1 for step in range(nst) if spec["moves"][lib.emx_host_move_choice_philox(SEED, step, cdf, len(cdf))].kind == "de")
     assert 0 < n_de < nst
-    assert p["info"]["halfsteps"] == 2 * n_de and 1 <= p["info"]["launches"] <= n_de and c["info"]["launches"] == 0
+    assert p["info"]["halfsteps"] == 2 * n_de + 4 * (nst - n_de) and 2 <= p["info"]["launches"] <= nst and c["info"]["launches"] == 0
+    for key in ("x", "lp", "acc", "chain", "chain_lp", "counts"):
+        assert np.array_equal(p[key], c[key]), key
+
+
+def test_mixture_whose_moves_take_grids_of_different_sizes():
+    """8 192 walkers: a DE half-step is 256 one-wave workgroups, a snooker half-step 128 -- the barrier's arrival counters start
+    afresh when the grid changes (a barrier that waited for the other grid's count would time out: status bit 3)"""
+    spec = full_spec(8192, 64, "dense", [S("de"), S("snooker")], weights=[0.6, 0.4], seed=10)
+    p, c = run_both(spec, 40, store=True)
+    assert p["info"]["launches"] >= 2 and c["info"]["launches"] == 0
     for key in ("x", "lp", "acc", "chain", "chain_lp", "counts"):
         assert np.array_equal(p[key], c[key]), key
 
@@ -153,7 +176,7 @@ def test_persistent_launches_and_the_step_api_interleave():
     ens.set_philox(SEED, 20)
     ref2 = native_ens(spec, 0)
     ref2.run(20, 1, False)
-    sn = [move_desc(S("snooker"), 64)]         # a move the persistent kernel has no instantiation for
+    sn = [move_desc(S("stretch", nsplits=3), 64)]         # three splits: a step the persistent kernel has no instantiation for
     for e in (ens, ref2):
         e.set_moves(sn, np.array([1.0]))
         e.run(5, 1, False)

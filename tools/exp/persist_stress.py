@@ -20,6 +20,7 @@ for persist in (1, 0):
     e = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(e, "philox")
     e.set_tuning("persist", 3 * persist)
+    e.set_tuning("persist_timeout_ms", 50)
     if store:
         e.chain_config(nsteps)
     ens.append(e)
