@@ -420,10 +420,10 @@ def config_entry(wl, res, K, store):
                                 "avg_launch_us": ev_ms * 1e3 / lps * hpl, "launches_per_step": lps / hpl, "avg_halfstep_us": ev_ms * 1e3 / lps,
                                 "per_launch_event_halfsteps": res.get("per_launch_halfsteps")})
     elif hpl > 1.0:
-        # a mixture: the runs of consecutive DE steps share persistent launches (k_persist<..., MOVE_DE>), the snooker steps take the
-        # per-half-step kernels; avg_launch_us stays the timed region / half-steps
-        out["roofline"]["kernel"] = ("DE steps: emx::k_persist<8,2,4,DPB=4,MOVE_DE>, %.1f half-steps per launch (a run of consecutive DE steps); "
-                                     "snooker steps: emx::k_halfstep<8,2,4,SNOOKER,4,LEAN>" % hpl)
+        # a mixture: the consecutive steps of one move share a persistent launch (k_persist<..., MOVE_DE / MOVE_SNOOKER>: two half-steps
+        # per DE step, four per snooker step); avg_launch_us stays the timed region / half-steps
+        out["roofline"]["kernel"] = ("emx::k_persist<8,2,4,DPB=4,MOVE_DE> and <...,MOVE_SNOOKER>: %.1f half-steps per launch (a run of consecutive "
+                                     "steps of one move)" % hpl)
         out["roofline"]["avg_launch_us_is"] = "hipEvent time of the timed region / half-steps (persistent launches counted by their half-steps)"
     state_mb = wl.N * wl.D * 8 / 1e6
     if state_mb > 256.0:
