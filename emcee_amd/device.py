@@ -137,6 +137,10 @@ class DeviceEnsemble:
         if bits & _STATUS_EXCHANGE_OVERFLOW:
             raise EmxError("pull exchange: record capacity exceeded; the sharded run is invalid")
         if bits & _STATUS_EXCHANGE_TIMEOUT:
+            if self.persist_info()["launches"] > 0:
+                raise EmxError("persistent kernel: its device-wide barrier was not met in time (the grid could not become co-resident: "
+                               "is another process using this GPU?); the run is invalid -- EMX_TUNE=persist=0 selects the per-half-step "
+                               "launches, persist_timeout_ms raises the bound")
             raise EmxError("direct exchange: a peer did not reach the device-side barrier in time; the sharded run is invalid")
         if bits & _STATUS_BAD_COORD:
             raise ValueError("At least one parameter value was infinite or NaN")
