@@ -853,7 +853,8 @@ XGMI_INGRESS_GBPS = 7 * 76.8        # MI355X: 7 links x 153.6 GB/s bidirectional
 # DESIGN.md section 6, "What to expect": microseconds per step of the protocol expected to win, written down BEFORE the first
 # multi-GPU run so that the first curve can be read against a prediction (world size -> us/step)
 PREDICTED_US_PER_STEP = {      # the device-side replay exchange (replay_push); the model and its inputs are in DESIGN.md section 6
-XX
+    "c2": {2: 42.0, 4: 50.0, 8: 62.0},          # weak, 65 536 walkers per GPU: 1.1x / 1.9x / 3.1x one GPU's per-half-step 23.7 us
+                                                # (1.0x / 1.7x / 2.7x the persistent kernel's 20.8 us, which the sharded paths do not use)
     "c3": {2: 44.0, 4: 41.0, 8: 40.0},          # strong, 38.6 us on one GPU: no G > 1 is expected to be faster (0.9-0.97x)
     "c5": {2: 57.0, 4: 44.0, 8: 39.0},          # strong, 53.6 us on one GPU: 0.94x / 1.2x / 1.4x
     "w512": {2: 536.0, 4: 558.0, 8: 600.0},     # weak, 504 us on one GPU: 1.9x / 3.6x / 6.7x -- the workload that reaches 6x
