@@ -2657,6 +2657,7 @@ static int persist_shape(const emx_ctx* c, int nsplits) {
     int wpb = tiles >= 6 * cu ? 8 : tiles >= 3 * cu ? 4 : tiles >= 3 * cu / 2 ? 2 : 1;
     while (wpb > 1 && (tiles % wpb) != 0) wpb >>= 1;
     if (tiles / wpb > cu * (wpb == 8 ? 1 : 2)) return 0;       // (103 KB of LDS per 8-wave group: one per CU)
+    if (tiles / wpb < 8) return 0;                              // (the barrier counts arrivals per XCD: every one of the eight needs a workgroup)
     return wpb;
 }
 
