@@ -442,6 +442,7 @@ struct emx_ctx {
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
     // persistent half-steps (tuning "persist", default on): k_persist runs a batch of native steps in one launch
+    int64_t tune_persist_test_skew = 0;      // tests only: added to the barrier count the next launches wait for
     int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_walkers = 512;
     int persist_wpb = 8;
     int64_t persist_launches = 0, persist_halfsteps = 0;
@@ -1204,6 +1205,7 @@ int emx_status(emx_ctx* c, uint32_t* bits) {
     for (int k = 0; k < 4; ++k)
         if (__atomic_exchange_n(&c->status_host[k], 0u, __ATOMIC_ACQ_REL)) b |= 1u << k;
     if (b & ST_EXCHANGE_TIMEOUT) c->direct_dead = true;      // sticky on the host too: emx_direct_halfstep / emx_run refuse from here on
+    if (b & ST_EXCHANGE_TIMEOUT) c->persist_grid = 0;        // the persistent kernel's barrier words (counters, the dead mark) restart with its next launch
     *bits = b;
     return 0;
 }
@@ -1271,6 +1273,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
         c->tune_persist = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_test_skew")) {       // tests only: the persistent kernel's barriers wait for a count that never comes
+        c->tune_persist_test_skew = v;
         return 0;
     }
     if (!strcmp(key, "persist_timeout_ms")) {      // bound of a device-wide barrier wait inside k_persist
@@ -2690,6 +2696,12 @@ static const emx_ctx* g_persist_last[MAX_DEVICES] = {};
 
 static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, int32_t store, int64_t* done) {
     *done = 0;
+    if (__atomic_load_n(&c->status_host[3], __ATOMIC_ACQUIRE)) {
+        // a barrier of an earlier persistent launch was never met (status bit 3, not read yet): no further launch on top of it
+        c->persist_grid = 0;          // (the counters restart once the status has been taken)
+        FAIL(c, -8, "persistent kernel: a device-wide barrier timed out (the grid could not become co-resident); read emx_status, "
+                    "or turn the persistent path off with tuning \"persist\" = 0");
+    }
     if (!c->persist_bar) {
         HIPOK(c, hipMalloc((void**)&c->persist_bar, 10 * 32 * sizeof(unsigned)));
         HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 10 * 32 * sizeof(unsigned), c->stream));
@@ -2767,7 +2779,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     P.niter = n;
     P.bar = c->persist_bar;
     P.ver = c->persist_ver;
-    P.epoch0 = c->persist_epoch;
+    P.epoch0 = c->persist_epoch + (unsigned)c->tune_persist_test_skew;      // (tests: a barrier that is never met)
     P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
     c->persist_epoch += (unsigned)(n - 1);
     hipEvent_t e0 = nullptr, e1 = nullptr;

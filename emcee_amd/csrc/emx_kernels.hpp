@@ -1256,16 +1256,21 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
         const unsigned per = (gridDim.x + 7 - xcd) / 8;
         unsigned* xctr = P.bar + xcd * 32;
         unsigned* gctr = P.bar + 8 * 32;
-        unsigned* go = P.bar + 9 * 32;
+        unsigned* go = P.bar + 9 * 32;                            // [go | dead]: one 8-byte word, polled with one load
         const unsigned old = __hip_atomic_fetch_add(xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == k * per - 1) {
             const unsigned o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (o2 == k * 8 - 1) __hip_atomic_store(go, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const unsigned long long t0 = wall_clock64();
-        while ((int)(__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - k) < 0) {      // (the counters wrap)
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(reinterpret_cast<unsigned long long*>(go), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)((unsigned)v - k) >= 0 || (v >> 32) != 0ull) break;          // (the counters wrap) | a barrier of this run has timed out
             if (wall_clock64() - t0 > P.timeout_ticks) {
+                // never met: report, and let every later barrier of the run through at once (the results are void anyway;
+                // the host refuses further persistent launches until the status has been read)
                 raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
+                __hip_atomic_store(go + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }

@@ -229,6 +229,38 @@ def test_two_ensembles_of_one_process_take_turns():
         ref.close()
 
 
+def test_a_barrier_that_is_never_met_is_an_error_not_a_hang():
+    """the device-wide barrier is bounded by the wall clock: the first one that is not met raises status bit 3 and opens every
+    later barrier of the run at once (one timeout per run, not one per barrier); the host refuses further persistent launches
+    until the status has been read; after that the context works again"""
+    import time
+    from emcee_amd._lib import EmxError
+    spec = dense_spec(4096, 64, seed=11)
+    ens = native_ens(spec, 1)
+    ens.set_tuning("persist_timeout_ms", 20)
+    ens.set_tuning("persist_test_skew", 1000)
+    t0 = time.perf_counter()
+    ens.run(16, 1, False)
+    ens.sync()
+    assert time.perf_counter() - t0 < 1.0               # one 20 ms timeout, not 31
+    with pytest.raises(EmxError, match="barrier timed out"):
+        ens.run(16, 1, False)
+    with pytest.raises(EmxError, match="persistent kernel"):
+        ens.raise_on_status()
+    assert ens.status() == 0
+    ens.set_tuning("persist_test_skew", 0)
+    ref = native_ens(spec, 0)
+    for e in (ens, ref):
+        e.set_state(spec["p0"])
+        e.eval_state_log_prob()
+        e.set_philox(SEED, 0)
+        e.run(20, 1, False)
+    a, b = ens.get_state(), ref.get_state()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and ens.status() == 0
+    ens.close()
+    ref.close()
+
+
 def test_sampler_runs_persistently(monkeypatch):
     """EnsembleSampler.run_mcmc with the device target and rng="philox" takes the persistent path by itself; EMX_TUNE turns it off"""
     import emcee_amd
