@@ -116,6 +116,7 @@ SIGNATURES = {
     "emx_comm_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "emx_pipeline_stats": (C.c_int, [_P, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "emx_persist_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "emx_host_persist_shape": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "emx_timer_start": (C.c_int, [_P]),
     "emx_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "emx_profile_enable": (C.c_int, [_P, C.c_int32]),

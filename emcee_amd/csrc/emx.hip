@@ -2654,18 +2654,19 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store);
 // profiles/r03/persist_side_plan.txt.)
 // -> waves per workgroup of the persistent grid for a move of `nsplits` splits (0: the ensemble does not fit one): every wave
 // exactly one 16-walker tile of a half-step, about one workgroup per CU, all of them co-resident
-static int persist_shape(const emx_ctx* c, int nsplits) {
-    if (nsplits < 2 || (c->N % nsplits) != 0) return 0;
-    const int64_t own = c->N / nsplits;
+static int persist_shape_of(int64_t N, int nsplits, int64_t cu) {
+    if (nsplits < 2 || N < 2 || (N % nsplits) != 0) return 0;
+    const int64_t own = N / nsplits;
     if ((own % 16) != 0) return 0;
     const int64_t tiles = own / 16;
-    const int64_t cu = std::max(1, c->num_cu);
+    cu = std::max<int64_t>(1, cu);
     int wpb = tiles >= 6 * cu ? 8 : tiles >= 3 * cu ? 4 : tiles >= 3 * cu / 2 ? 2 : 1;
     while (wpb > 1 && (tiles % wpb) != 0) wpb >>= 1;
     if (tiles / wpb > cu * (wpb == 8 ? 1 : 2)) return 0;       // (103 KB of LDS per 8-wave group: one per CU)
     if (tiles / wpb < 8) return 0;                              // (the barrier counts arrivals per XCD: every one of the eight needs a workgroup)
     return wpb;
 }
+static int persist_shape(const emx_ctx* c, int nsplits) { return persist_shape_of(c->N, nsplits, c->num_cu); }
 
 // the moves k_persist has an instantiation for (the other moves of a mixture run their steps through the per-half-step launches)
 static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
@@ -2810,6 +2811,13 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     c->persist_launches++;
     c->persist_halfsteps += n;
     *done = steps;
+    return 0;
+}
+
+int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, int32_t* waves_per_group, int32_t* groups) {
+    const int wpb = persist_shape_of(nwalkers, nsplits, num_cu);
+    *waves_per_group = wpb;
+    *groups = wpb ? (int32_t)(nwalkers / nsplits / 16 / wpb) : 0;
     return 0;
 }
 

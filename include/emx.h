@@ -342,6 +342,9 @@ int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int
  *   out[0] 1 when the current configuration qualifies, out[1] persistent launches so far, out[2] half-steps they ran,
  *   out[3] reserved (0) */
 int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
+/* host only: the grid the persistent kernel takes for `nwalkers` walkers updated in `nsplits` half-steps on a device of `num_cu`
+ * CUs -- waves per workgroup (8 / 4 / 2 / 1; 0: no persistent grid, the per-half-step launches run) and workgroups */
+int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, int32_t* waves_per_group, int32_t* groups);
 
 /* ---- host-only helpers (no GPU needed; used by the CPU test-suite) ---------------------- */
 typedef struct emx_mt emx_mt;

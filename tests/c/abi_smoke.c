@@ -23,8 +23,10 @@ int main(int argc, char** argv) {
     SYM(emx_rng_set_philox) SYM(emx_set_state) SYM(emx_eval_state_log_prob) SYM(emx_chain_config)
     SYM(emx_run) SYM(emx_chain_read) SYM(emx_accepted_counts) SYM(emx_get_state) SYM(emx_status)
     SYM(emx_autocorr) SYM(emx_walkers_independent)
-    SYM(emx_snapshot_save) SYM(emx_snapshot_read) SYM(emx_snapshot_restore) SYM(emx_snapshot_free) SYM(emx_comm_count) SYM(emx_pipeline_stats) SYM(emx_persist_info)
+    SYM(emx_snapshot_save) SYM(emx_snapshot_read) SYM(emx_snapshot_restore) SYM(emx_snapshot_free) SYM(emx_comm_count) SYM(emx_pipeline_stats) SYM(emx_persist_info) SYM(emx_host_persist_shape)
     printf("version: %s\n", p_emx_version());
+    int32_t pw = -1, pg = -1;
+    if (p_emx_host_persist_shape(65536, 2, 256, &pw, &pg) != 0 || pw != 8 || pg != 256) return 17;      /* host only */
 
     /* host-only: MT19937 seeded with init_genrand(5489)-style key is not needed; use a fixed key */
     uint32_t key[624];

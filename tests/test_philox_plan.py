@@ -92,3 +92,36 @@ def test_snooker_picks_one_from_each_complement_set():
     # the role of z is spread over the three sets (uniform permutation)
     frac = np.mean(trio[:, 0] == np.where(own == 0, 1, 0))
     assert 0.2 < frac < 0.47
+
+
+def test_persistent_grid_shape_rule():
+    """the grid k_persist takes (include/emx.h emx_host_persist_shape): one 16-walker tile per wave, about one workgroup per CU,
+    at least eight workgroups (one arrival counter per XCD), never more than fit co-resident; 0 = the per-half-step launches"""
+    import ctypes as C
+    lib = _lib.load()
+
+    def shape(N, S=2, cu=256):
+        w, g = C.c_int32(-1), C.c_int32(-1)
+        assert lib.emx_host_persist_shape(N, S, cu, C.byref(w), C.byref(g)) == 0
+        return w.value, g.value
+
+    assert shape(65536) == (8, 256)                 # BASELINE config 2: 2 048 tiles, 8-wave groups, one per CU
+    assert shape(49152) == (8, 192)
+    assert shape(32768) == (4, 256)
+    assert shape(16384) == (2, 256)
+    assert shape(8192) == (1, 256)
+    assert shape(512) == (1, 16)
+    assert shape(65536, 4) == (4, 256)              # the snooker move's quarter ensembles
+    assert shape(8192, 4) == (1, 128)
+    assert shape(131072) == (0, 0)                  # more tiles than waves of a co-resident grid
+    assert shape(1000) == (0, 0)                    # half an ensemble that is not whole tiles
+    assert shape(65537) == (0, 0)
+    assert shape(128) == (0, 0)                     # fewer than eight workgroups
+    assert shape(4096, 3) == (0, 0)
+    assert shape(4080, 3) == (1, 85)
+    for N in range(32, 70000, 992):                 # every wave exactly one tile, whatever the size
+        for S in (2, 4):
+            w, g = shape(N, S)
+            if w:
+                assert w in (1, 2, 4, 8) and w * g * 16 * S == N and 8 <= g <= 512 and (w < 8 or g <= 256)
+    assert shape(65536, 2, 304) == (8, 256) and shape(77824, 2, 304) == (8, 304)      # a device with more CUs
