@@ -2689,6 +2689,82 @@ static bool persist_wanted(const emx_ctx* c) {
     return sh.G == 8 && sh.V == 2 && sh.CH == (dpb == 1 ? 1 : dpb == 2 ? 2 : 4);
 }
 
+// The Gaussian Metropolis move alone (moves/gaussian.py + mh.py), fused dense target at an even ndim up to 64, Philox plans, one
+// replica, the noise generated in registers: k_persist_gauss keeps every walker in registers for up to 16 steps per launch.
+static bool persist_gauss_wanted(const emx_ctx* c) {
+    if (!c->tune_persist || c->tune_gauss_materialize) return false;
+    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.size() != 1) return false;
+    if (c->moves[0].kind != EMX_MOVE_GAUSS) return false;
+    if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || dense_is_wide(c)) return false;
+    if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
+    if (c->N < c->tune_persist_min_walkers || (c->N % 16) != 0) return false;
+    const Shape sh = pick_shape(c->D, c->Dp);
+    const int dpb = c->Dp / 16;
+    return sh.G == 8 && sh.V == 2 && sh.CH == (dpb == 1 ? 1 : dpb == 2 ? 2 : 4);
+}
+
+static int run_persist_gauss(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, int32_t store, int64_t* done) {
+    *done = 0;
+    const int64_t tiles = c->N / 16;
+    int wpb = 8;
+    while (wpb > 1 && (tiles % wpb) != 0) wpb >>= 1;
+    c->persist_wpb = wpb;
+    PersistGaussArgs P{};
+    emx_ctx::PersistCapture cap{};
+    int64_t steps = 0;
+    while (i0 + steps < total && steps < PERSIST_GAUSS_MAX_STEPS) {
+        if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch
+        c->prep_hint = NATIVE_BATCH_MAX;
+        const int st = store && ((i0 + steps + 1) % thin_by == 0);          // ensemble.py:416
+        int mvi, S;
+        int rc = emx_step_begin(c, st, &mvi, &S);
+        if (rc) return rc;
+        cap.got = false;
+        c->persist_cap = &cap;
+        rc = do_halfstep(c, 0, c->target);
+        c->persist_cap = nullptr;
+        if (!rc && (S != 1 || !cap.dense || cap.move != MOVE_GAUSS || cap.a.disp || cap.dpb != c->Dp / 16)) {
+            c->err = "persistent Gaussian steps: launch shape not eligible";
+            rc = -1;
+        }
+        if (rc) {
+            c->cur.active = false;
+            return rc;
+        }
+        if (steps == 0) P.base = cap.a;
+        PersistGaussStep& G = P.st[steps];
+        G.p0 = cap.a.p0;
+        G.logu = cap.a.logu;
+        G.chain = cap.a.chain;
+        G.chain_lp = cap.a.chain_lp;
+        G.gstep = cap.a.gstep;
+        G.gfac = cap.a.gfac;
+        rc = emx_step_end(c);
+        if (rc) return rc;
+        ++steps;
+    }
+    P.nsteps = (int32_t)steps;
+    const dim3 grid((unsigned)(tiles / wpb)), block(64u * (unsigned)wpb);
+    const size_t lds = dense_lds_bytes(c->Dp, wpb);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max;
+    if (prof) {
+        e0 = c->prof[2 * c->prof_n];
+        e1 = c->prof[2 * c->prof_n + 1];
+        HIPOK(c, hipEventRecord(e0, c->stream));
+    }
+    const hipError_t e = launch_hot_persist_gauss(c->Dp / 16, grid, block, lds, c->stream, P);
+    if (e != hipSuccess) FAIL(c, -2, "persistent Gaussian launch failed: %s", hipGetErrorString(e));
+    if (prof) {
+        HIPOK(c, hipEventRecord(e1, c->stream));
+        c->prof_n++;
+    }
+    c->persist_launches++;
+    c->persist_halfsteps += steps;
+    *done = steps;
+    return 0;
+}
+
 // Two persistent grids that each hold part of the device would wait for each other until their barriers time out: launches of
 // one process on one device are chained (each waits for the one before; a few cycles when it is the same stream).
 static std::mutex g_persist_mu;
@@ -2822,7 +2898,7 @@ int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, in
 }
 
 int emx_persist_info(emx_ctx* c, int64_t out[4]) {
-    out[0] = persist_wanted(c) ? 1 : 0;
+    out[0] = (persist_wanted(c) || persist_gauss_wanted(c)) ? 1 : 0;
     out[1] = c->persist_launches;
     out[2] = c->persist_halfsteps;
     out[3] = 0;
@@ -2862,6 +2938,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
     const int64_t total = nsteps * thin_by;
     // (padded ndim 16 with a stored chain is the one measured shape the persistent kernel loses on: +5 %, profiles/r03/persist_dims.txt)
     const bool persist_on = persist_wanted(c) && !small_eligible(c) && !(store && c->Dp == 16);
+    const bool persist_gauss_on = persist_gauss_wanted(c) && !small_eligible(c);
     bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
     int64_t next_mark = c->tune_throttle > 0 ? c->tune_throttle : total + 1;
     int marks = 0;
@@ -2888,6 +2965,14 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
             const int rc = run_small(c, i, chunk, thin_by, store);
             if (rc) return rc;
             i += chunk;
+            ctr_synced = false;
+            continue;
+        }
+        if (persist_gauss_on) {
+            int64_t done = 0;
+            const int rc = run_persist_gauss(c, i, total, thin_by, store, &done);
+            if (rc) return rc;
+            i += done;
             ctr_synced = false;
             continue;
         }

@@ -35,4 +35,24 @@ hipError_t launch_hot_persist_dense(int dpb, int move, dim3 grid, dim3 block, si
     return hipErrorInvalidValue;
 }
 
+// the Gaussian Metropolis move's persistent form (k_persist_gauss): no barrier, any grid
+hipError_t launch_hot_persist_gauss(int dpb, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistGaussArgs& P) {
+#define EMX_CASE(b, ch)                                                                                              \
+    if (dpb == b) {                                                                                                  \
+        auto kern = k_persist_gauss<8, 2, ch, b>;                                                                    \
+        static size_t lds_granted[MAX_DEVICES] = {};                                                                 \
+        int dev = 0;                                                                                                 \
+        if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) { \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                           \
+            lds_granted[dev] = lds;                                                                                  \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, P);                                                           \
+        return hipGetLastError();                                                                                    \
+    }
+    EMX_CASE(1, 1) EMX_CASE(2, 2) EMX_CASE(3, 4) EMX_CASE(4, 4)
+#undef EMX_CASE
+    return hipErrorInvalidValue;
+}
+
 }  // namespace emx

@@ -1543,6 +1543,152 @@ struct GaussGen {          // what gauss_disp_row needs to generate a walker's d
     double gfac, gsigma;
     const double* gscale;
 };
+// ----------------------------------------------------------------------------------------
+// The Gaussian Metropolis move (moves/gaussian.py + moves/mh.py) on the fused dense target, persistent and WITHOUT any
+// synchronisation: the update of a walker reads nobody else's row (mh.py:57-77), so a wave keeps its 16 walkers' rows and
+// log-probs in registers for every step of the launch -- per step it generates the displacement rows (gauss_disp_row), writes
+// the proposal tile, runs the MFMA chain, decides, and replaces the accepted rows in registers.  Global memory sees the plan's
+// accept uniforms (and the coordinate that moves), the chain rows of stored steps, and the final state once.  Same functions,
+// same order as k_halfstep<G, V, CH, MOVE_GAUSS, DPB, 1>: the same bits (tests/test_gpu_persist.py).
+// ----------------------------------------------------------------------------------------
+constexpr int PERSIST_GAUSS_MAX_STEPS = 16;
+struct PersistGaussStep {
+    const int32_t* p0;             // the coordinate that moves, per walker (-1: all of them; gaussian.py:92-101)
+    const double* logu;            // log of the accept uniform, per walker
+    double *chain, *chain_lp;      // this step's row of the stored chain, or nullptr
+    unsigned long long gstep;      // Philox step of the noise
+    double gfac;                   // this step's step-size factor (gaussian.py:81-84)
+};
+struct PersistGaussArgs {
+    HalfStepArgs base;
+    PersistGaussStep st[PERSIST_GAUSS_MAX_STEPS];
+    int32_t nsteps;
+};
+
+template <int G, int V, int CH, int DPB>
+static __global__ __launch_bounds__(512) void k_persist_gauss(const PersistGaussArgs P) {
+    constexpr int MOVE = MOVE_GAUSS;
+    constexpr int WPW = 64 / G;
+    constexpr int PPT = 16 / WPW;
+    constexpr int Dp = DPB * 16, KK = Dp / 4, RT = Dp + 2;
+    static_assert(EMX_OPT_RTILE && EMX_OPT_RED4 && G * V * CH >= Dp, "the one-tile-per-batch form");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const HalfStepArgs& A = P.base;
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int sub = lane / G;
+    const int gl = lane % G;
+    const int D = A.D;
+    double* Sfrag = smem;
+    double* muS = smem + dense_img_doubles(Dp);
+    double* tile = muS + Dp + (size_t)wib * (16 * RT + 32);
+    double* facS = tile + 16 * RT + 16;
+    {
+        constexpr int IMG2 = (dense_img_doubles(Dp) + Dp) / 2;
+        const double2* img = reinterpret_cast<const double2*>(A.tp1);
+        double2* dst = reinterpret_cast<double2*>(smem);
+        for (int e = threadIdx.x; e < IMG2; e += blockDim.x) dst[e] = img[e];
+    }
+    Row<G, V, CH> mu;
+    load_row<G, V, CH>(mu, A.tp0, D, gl);
+    __syncthreads();
+    const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
+    const int w0 = wave * 16;                                   // this wave's walkers (the Gaussian move's plan order is the identity)
+    const int myrow = (lane >> 4) + 4 * (lane & 3);
+    const bool mine = (lane & 15) < 4;
+    const int my_i = w0 + myrow;
+    Row<G, V, CH> xi[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) load_row<G, V, CH>(xi[k], A.X + (size_t)(w0 + k * WPW + sub) * D, D, gl);
+    double my_lp = A.lp[my_i];
+    bool my_acc = false;
+    for (int s = 0; s < P.nsteps; ++s) {
+        const PersistGaussStep& S = P.st[s];
+        GaussGen gg;
+        gg.gseed = A.gseed;
+        gg.gstep = S.gstep;
+        gg.gfac = S.gfac;
+        gg.gsigma = A.gsigma;
+        gg.gscale = A.gscale;
+        const double my_logu = S.logu[my_i];
+        Row<G, V, CH> qk[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = w0 + k * WPW + sub;
+            const int col = S.p0[i];
+            Row<G, V, CH> xa, q;
+            gauss_disp_row<G, V, CH>(xa, gg, i, col, D, gl);
+            double factor = 0.0;                                 // the plan's fac column of a Gaussian step (symmetric proposal)
+            make_proposal<G, V, CH, MOVE>(xi[k], xa, xa, xa, 0.0, A.gammas, D, gl, q, factor, col);
+            bool bl = false;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int v = 0; v < V; ++v) bl |= !(fabs(q.x[c][v]) <= 1.79769313486231570815e308);
+            const bool badq = group_any<G>(bl, sub);
+            if (badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
+            const int trow = (k * WPW + sub) & 15;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int d = (c * G + gl) * V + v;
+                    if (d < Dp) tile[trow * RT + d] = !badq ? q.x[c][v] - mu.x[c][v] : 0.0;
+                }
+            qk[k] = q;
+            if (gl == 0) facS[trow] = badq ? -__builtin_inf() : factor;
+        }
+        EMX_WAVE_SYNC();
+        double my_qf;
+        {
+            const int am = lane & 15, ak = lane >> 4;
+            typedef double d4 __attribute__((ext_vector_type(4)));
+            double afr[KK];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) afr[kk] = tile[am * RT + 4 * kk + ak];
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int nb = 0; nb < DPB; ++nb) {
+                d4 accv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 4 * nb; kk < KK; ++kk)
+                    accv = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[kk], Sfrag[(dense_block(DPB, nb, kk >> 2) * 4 + (kk & 3)) * 64 + lane], accv, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
+            }
+            my_qf = row16_sum4(part[0], part[1], part[2], part[3], lane);
+        }
+        bool acc = false;
+        if (mine) {
+            const double lpn = -0.5 * my_qf;
+            if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);
+            const double lnpdiff = facS[myrow] + lpn - my_lp;      // mh.py:63-66
+            acc = lnpdiff > my_logu;
+            if (acc) my_lp = lpn;
+            my_acc = acc;
+            if (S.chain_lp) {
+                S.chain_lp[my_i] = my_lp;
+                if (acc) A.acc_count[my_i] += 1u;
+            }
+        }
+        const unsigned long long am64 = __ballot(acc);
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) {
+            const int row = pp * WPW + sub;
+            const bool ac = (am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull;
+            if (ac) xi[pp] = qk[pp];                               // move.py:33, in registers
+            if (S.chain) store_row_stream<G, V, CH>(xi[pp], S.chain + (size_t)(w0 + row) * D, D, gl);
+        }
+        EMX_WAVE_SYNC();
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) store_row<G, V, CH>(xi[k], A.X + (size_t)(w0 + k * WPW + sub) * D, D, gl);
+    if (mine) {
+        A.lp[my_i] = my_lp;
+        A.acc[my_i] = my_acc ? 1 : 0;
+    }
+}
+
 constexpr int SMALL_ANY_MOVE = 7;      // MOVESEL: the kernel carries all three split-ensemble moves and picks per step
 
 // move of a native-mode step: one Philox draw against the cdf (the host's philox_move_choice)

@@ -118,6 +118,40 @@ def test_mixture_takes_the_persistent_kernel_for_the_runs_it_can():
         assert np.array_equal(p[key], c[key]), key
 
 
+@pytest.mark.parametrize("N,D,mode,factor,store", [(65536, 64, "vector", None, False), (8192, 64, "random", 1.3, True), (4096, 48, "sequential", 2.0, True),
+                                                   (2048, 32, "vector", None, False), (1024, 16, "vector", 1.1, True), (32768, 64, "vector", None, True)])
+def test_gaussian_move_keeps_its_walkers_in_registers(N, D, mode, factor, store):
+    """GaussianMove / MHMove (gaussian.py:76-101, mh.py:57-77) on the fused dense target: k_persist_gauss runs up to 16 steps per
+    launch with every walker in registers and no synchronisation at all -- the chain of the per-step launches, bit for bit, in
+    the three proposal modes, with and without the step-size factor"""
+    rs = np.random.RandomState(D + N)
+    mv = S("gaussian", cov=(0.5 + rs.rand(D)) / D, mode=mode, factor=factor)
+    mu, cov_, icov = cases._dense_params(D, 5)
+    spec = dict(N=N, D=D, moves=[mv], weights=None, desc=dict(kind="dense", mu=mu, cov=cov_, icov=icov))
+    p0 = mu + 0.1 * rs.randn(N, D)
+    out = []
+    for persist in (1, 0):
+        ens = make_ens(spec, p0)
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(SEED, 0)
+        ens.set_tuning("persist", persist)
+        if store:
+            ens.chain_config(37)
+        ens.run(37, 1, store)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=ens.persist_info())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, 37), chain_lp=ens.chain_read(1, 0, 37), counts=ens.accepted_counts())
+        ens.close()
+        out.append(rec)
+    p, c = out
+    assert p["info"]["qualifies"] and p["info"]["launches"] == 3 and p["info"]["halfsteps"] == 37 and c["info"]["launches"] == 0
+    for key in ("x", "lp", "acc") + (("chain", "chain_lp", "counts") if store else ()):
+        assert np.array_equal(p[key], c[key]), key
+    assert 0.0 < p["acc"].mean() < 1.0
+
+
 def test_mixture_whose_moves_take_grids_of_different_sizes():
     """8 192 walkers: a DE half-step is 256 one-wave workgroups, a snooker half-step 128 -- the barrier's arrival counters start
     afresh when the grid changes (a barrier that waited for the other grid's count would time out: status bit 3)"""
