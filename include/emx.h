@@ -339,6 +339,9 @@ int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int
  * arithmetic, same bits as the launch-per-half-step path.  Tuning "persist" = 0 turns it off; "persist_timeout_ms" bounds a
  * barrier wait (default 2000: a grid that cannot become co-resident -- another process holding the device's CUs -- raises
  * status bit 3 instead of hanging).  With emx_profile_enable the events bracket whole launches.
+ * A context whose only move is the Gaussian Metropolis move (gaussian.py:76-101 / mh.py:57-77; same target, RNG and replica
+ * conditions, nwalkers a multiple of 16) runs up to 16 steps per launch with every walker in registers and no barrier at all
+ * (k_persist_gauss).
  *   out[0] 1 when the current configuration qualifies, out[1] persistent launches so far, out[2] half-steps they ran,
  *   out[3] reserved (0) */
 int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
