@@ -442,6 +442,7 @@ struct emx_ctx {
     int64_t tune_graph = 0;          // opt-in: on MI355X the replay is ~5 % slower than back-to-back launches unless the host is the bottleneck
     // tuning
     // persistent half-steps (tuning "persist", default on): k_persist runs a batch of native steps in one launch
+    int64_t tune_persist_gauss_wpb = 0;       // waves per workgroup of k_persist_gauss (0: four)
     int64_t tune_persist_test_skew = 0;      // tests only: added to the barrier count the next launches wait for
     int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_walkers = 512;
     int persist_wpb = 8;
@@ -1273,6 +1274,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
         c->tune_persist = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_gauss_wpb")) {       // waves per workgroup of the persistent Gaussian kernel: 1, 2, 4 or 8 (0: automatic)
+        c->tune_persist_gauss_wpb = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
         return 0;
     }
     if (!strcmp(key, "persist_test_skew")) {       // tests only: the persistent kernel's barriers wait for a count that never comes
@@ -2706,7 +2711,8 @@ static bool persist_gauss_wanted(const emx_ctx* c) {
 static int run_persist_gauss(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, int32_t store, int64_t* done) {
     *done = 0;
     const int64_t tiles = c->N / 16;
-    int wpb = 8;
+    // (four-wave groups, two per CU, drift out of phase: 12.9 against 13.0 us/step with eight-wave groups, 13.9 with two-wave ones)
+    int wpb = c->tune_persist_gauss_wpb > 0 ? (int)c->tune_persist_gauss_wpb : 4;
     while (wpb > 1 && (tiles % wpb) != 0) wpb >>= 1;
     c->persist_wpb = wpb;
     PersistGaussArgs P{};
