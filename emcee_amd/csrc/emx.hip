@@ -1405,6 +1405,7 @@ int emx_set_target_callback(emx_ctx* c, emx_device_log_prob_fn fn, void* user) {
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, fn != nullptr, "emx_set_target_callback: no function");
     pipe_stop(c);
+    drop_prepared(c);          // plans made ahead were shaped (lean or full) for the previous target
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->cb_fn = fn;
     c->cb_user = user;
@@ -1542,6 +1543,7 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
         HIPOK(c, hipMemcpy(ntp1, src1, n1 * 8, hipMemcpyHostToDevice));
     }
     HIPOK(c, hipStreamSynchronize(c->stream));      // no kernel still reads the old parameters
+    drop_prepared(c);                               // plans made ahead were shaped (lean or full) for the previous target
     std::swap(c->tp0, ntp0);                        // the guard now frees the OLD buffers
     std::swap(c->tp1, ntp1);
     std::swap(c->tp1_full, ntpf);
@@ -2081,6 +2083,45 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
     return 0;
 }
 
+// A lean native plan carries only the columns the fused half-step kernel of the step's move reads (k_native_plan_batch): whoever
+// else reads the plan of the open step -- emx_plan_get, the split-phase accept (uacc), the pull and direct exchanges' compact
+// plans -- first has the same kernel evaluate the step once more with every column (the plan is a pure function of
+// (seed, step, walker), so the columns already consumed do not change).
+static int complete_lean_plan(emx_ctx* c) {
+    auto& cur = c->cur;
+    if (!cur.active || !cur.native || !cur.lean) return 0;
+    NEED(c, cur.move >= 0 && cur.slot >= 0, "no plan available");
+    auto& ps = c->ring[cur.slot];
+    const emx_move_desc& m = c->moves[cur.move];
+    NativeBatchArgs B{};
+    B.N = (int32_t)c->N;
+    B.D = c->D;
+    B.nb = 1;
+    B.lean = 0;
+    B.nat[0] = cur.nat;
+    B.order[0] = ps.order;
+    B.p0[0] = ps.p0;
+    B.p1[0] = ps.p1;
+    B.p2[0] = ps.p2;
+    B.s0[0] = ps.s0;
+    B.uacc[0] = ps.uacc;
+    B.logu[0] = ps.logu;
+    B.fac[0] = ps.fac;
+    B.a[0] = m.a;
+    B.sigma[0] = m.sigma;
+    B.g0[0] = m.g0;
+    B.move[0] = m.kind;
+    B.S[0] = m.nsplits;
+    if (m.kind == EMX_MOVE_GAUSS) {
+        B.gmode[0] = m.reserved;
+        B.gcol[0] = cur.gcol;
+    }
+    hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), 1u), dim3(256), 0, c->stream, B);
+    HIPOK(c, hipGetLastError());
+    cur.lean = false;
+    return 0;
+}
+
 int emx_plan_set(emx_ctx* c, int32_t move_index, const int32_t* off, const int32_t* order, const int32_t* p0,
                  const int32_t* p1, const int32_t* p2, const double* s0, const double* uacc) {
     NEED(c, c->cur.active, "emx_plan_set outside a step");
@@ -2116,37 +2157,9 @@ int emx_plan_get(emx_ctx* c, int32_t* off, int32_t* order, int32_t* p0, int32_t*
         // the plan was evaluated on the device by k_native_plan at emx_step_begin
         NEED(c, cur.slot >= 0, "no plan available");
         auto& ps = c->ring[cur.slot];
-        if (cur.lean) {
-            // a lean plan (only the columns the fused kernel reads): the same kernel evaluates this step once more, every
-            // column this time -- the plan is a pure function of (seed, step, walker)
-            NEED(c, cur.move >= 0, "no plan available");
-            const emx_move_desc& m = c->moves[cur.move];
-            NativeBatchArgs B{};
-            B.N = (int32_t)c->N;
-            B.D = c->D;
-            B.nb = 1;
-            B.lean = 0;
-            B.nat[0] = cur.nat;
-            B.order[0] = ps.order;
-            B.p0[0] = ps.p0;
-            B.p1[0] = ps.p1;
-            B.p2[0] = ps.p2;
-            B.s0[0] = ps.s0;
-            B.uacc[0] = ps.uacc;
-            B.logu[0] = ps.logu;
-            B.fac[0] = ps.fac;
-            B.a[0] = m.a;
-            B.sigma[0] = m.sigma;
-            B.g0[0] = m.g0;
-            B.move[0] = m.kind;
-            B.S[0] = m.nsplits;
-            if (m.kind == EMX_MOVE_GAUSS) {
-                B.gmode[0] = m.reserved;
-                B.gcol[0] = cur.gcol;
-            }
-            hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), 1u), dim3(256), 0, c->stream, B);
-            HIPOK(c, hipGetLastError());
-            cur.lean = false;
+        {
+            const int rcl = complete_lean_plan(c);
+            if (rcl) return rcl;
         }
         HIPOK(c, hipMemcpyAsync(order, ps.order, N * 4, hipMemcpyDeviceToHost, c->stream));
         HIPOK(c, hipMemcpyAsync(p0, ps.p0, N * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2258,6 +2271,10 @@ int emx_accept(emx_ctx* c, int32_t split, const double* new_lp) {
     NEED(c, split >= 0 && split < cur.S, "emx_accept: split %d out of range (the step has %d)", split, cur.S);
     const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
     if (ns <= 0) return 0;
+    {
+        const int rcl = complete_lean_plan(c);          // k_accept reads uacc, which a lean plan does not carry
+        if (rcl) return rcl;
+    }
     HIPOK(c, hipMemcpyAsync(c->newlp, new_lp, (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
     AcceptArgs a{};
     a.X = c->X;
@@ -3227,6 +3244,7 @@ int emx_set_exchange(emx_ctx* c, int32_t kind) {
                 kind == EMX_EXCHANGE_REPLAY,
          "unknown exchange kind %d", kind);
     NEED(c, c->world == 1 && !c->comm && !c->sendbuf, "emx_set_exchange: call it before emx_set_shard / emx_comm_init");
+    drop_prepared(c);          // plans made ahead were shaped (lean or full) for the previous configuration
     c->exchange = kind;
     return 0;
 }
@@ -3236,6 +3254,7 @@ int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
     NEED(c, world >= 1 && rank >= 0 && rank < world, "bad (rank, world)");
     NEED(c, world <= c->N, "more ranks than walkers");
     HIPOK(c, hipStreamSynchronize(c->stream));
+    drop_prepared(c);          // plans made ahead were shaped (lean or full) for the previous sharding
     c->rank = rank;
     c->world = world;
     exchange_free(c);
@@ -3607,6 +3626,8 @@ int emx_pull_prepare(emx_ctx* c, int32_t split, int64_t* records_per_peer) {
     NEED(c, c->target != EMX_TARGET_HOST, "sharded stepping needs a device target");
     int rc = pull_ensure(c);
     if (rc) return rc;
+    rc = complete_lean_plan(c);         // the compact plan copies every column (a plan made before the context was sharded may be lean)
+    if (rc) return rc;
     const emx_move_desc& mv = c->moves[cur.move];
     const auto& ps = c->ring[cur.slot];
     const int pos0 = cur.off[split], ns = cur.off[split + 1] - cur.off[split];
@@ -3878,6 +3899,10 @@ int emx_direct_halfstep(emx_ctx* c, int32_t split, int32_t barrier) {
     NEED(c, c->peers_ready || c->world == 1, "direct exchange: peers not mapped");
     NEED(c, !c->direct_dead, "direct exchange: an earlier barrier timed out (a peer never arrived): the ranks are no longer ordered -- "
                              "attach the peers again (emx_direct_import / emx_direct_attach on every rank)");
+    {
+        const int rcl = complete_lean_plan(c);         // k_own_plan copies every column
+        if (rcl) return rcl;
+    }
     const emx_move_desc& mv = c->moves[cur.move];
     const auto& ps = c->ring[cur.slot];
     const int64_t G = c->world, N = c->N;

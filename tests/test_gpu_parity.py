@@ -196,6 +196,47 @@ def test_host_target_split_phase_equals_fused(name):
     ens.close()
 
 
+@pytest.mark.parametrize("name", ["c1_stretch_32x5_iso", "stretch_128x64_dense", "de_64x4_iso", "mix_de_snooker_128x8_dense"])
+@pytest.mark.parametrize("flow", ["device_target_split_phase", "run_then_host_target"])
+def test_philox_split_phase_completes_lean_plans(name, flow):
+    """Lean native plans (made for the fused kernel: no uacc column) must be completed before a non-fused consumer reads them
+    (round-3 advisor finding).  Flow 1: a device target is set, Philox plans, emx_propose / emx_accept.  Flow 2: emx_run leaves
+    plans prepared ahead, then the target becomes the host: the next steps' accept decisions must not come from stale columns.
+    Either way every step must equal the oracle applied to the plan the host twin computes for (seed, step)."""
+    spec = cases.build(name)
+    fn = cases.make_target(spec["desc"])
+    ens = make_ens(spec, spec["p0"])
+    ens.set_rng_mode(_lib.RNG_PHILOX)
+    seed = 0xFACADE + spec["seed"]
+    ens.set_philox(seed, 0)
+    cdf = cdf_of(spec["weights"], len(spec["moves"]))
+    step0 = 0
+    if flow == "run_then_host_target":
+        ens.run(3, 1, False)             # prepares NATIVE_BATCH_MAX lean plans, takes three
+        ens.set_target(_lib.TARGET_HOST, None, None)
+        step0 = 3
+    for step in range(step0, step0 + 4):
+        x0, lp0 = ens.get_state()
+        k, S = ens.step_begin(store=False)
+        assert k == ens.lib.emx_host_move_choice_philox(seed, step, cdf, len(cdf))
+        mv = spec["moves"][k]
+        plan = philox_plan(seed, step, spec["N"], move_desc(mv, spec["D"]))
+        for s in range(S):
+            q = ens.propose(s)
+            ens.accept(s, fn(q))
+        ens.step_end()
+        assert ens.status() == 0
+        x1, lp1 = ens.get_state()
+        xo, lpo = x0.copy(), lp0.copy()
+        acc_or = so.propose_planned(xo, lpo, fn, plan, mv)
+        assert np.array_equal(ens.accepted_mask(), acc_or), "accept mask differs at step %d" % step
+        if mv.kind == "snooker":
+            np.testing.assert_allclose(x1, xo, rtol=SNOOKER_RTOL, atol=SNOOKER_ATOL)
+        else:
+            assert np.array_equal(x1, xo), "coordinates differ at step %d" % step
+    ens.close()
+
+
 @pytest.mark.parametrize("kind,D", [("iso", 1), ("iso", 5), ("iso", 64), ("iso", 129), ("diag", 7), ("diag", 1024),
                                     ("diag", 2048), ("rosenbrock", 2), ("rosenbrock", 32), ("rosenbrock", 33),
                                     ("rosenbrock", 300), ("dense", 3), ("dense", 16), ("dense", 17), ("dense", 64),

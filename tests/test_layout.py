@@ -35,7 +35,37 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "/root/reference" in txt.replace(
                         "/root/reference/src/emcee", ""):
                     bad.append(os.path.join(dirpath, f))
+                # ... nor the reference itself: neither the materialised copy (oracle/_ref, tools/make_ref.sh) nor any `emcee` import
+                if "_ref" in txt and re.search(r"oracle[/.]_ref|ref_shim", txt):
+                    bad.append(os.path.join(dirpath, f))
+                if f.endswith(".py") and re.search(r"^\s*(from|import)\s+emcee\b(?!_amd)", txt, flags=re.M):
+                    bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_reference_copy_is_never_tracked():
+    """oracle/_ref (tools/make_ref.sh: the reference's package, for bench.py's cpu_baseline leg on the GPU box) must stay out of
+    history: git-ignored, and not listed in .gpurunignore (it has to travel)."""
+    ign = open(os.path.join(ROOT, ".gitignore")).read().split()
+    assert "oracle/_ref/" in ign
+    gi = os.path.join(ROOT, ".gpurunignore")
+    if os.path.exists(gi):
+        assert "oracle/_ref" not in open(gi).read()
+    import subprocess
+    r = subprocess.run(["git", "ls-files", "oracle/_ref"], cwd=ROOT, capture_output=True, text=True)
+    if r.returncode == 0:
+        assert r.stdout.strip() == "", "oracle/_ref is tracked: %s" % r.stdout
+
+
+def test_ref_shim_finds_a_materialised_reference(tmp_path, monkeypatch):
+    from oracle import ref_shim
+    monkeypatch.setattr(ref_shim, "REF_SRC", str(tmp_path / "nowhere"))
+    monkeypatch.setattr(ref_shim, "LOCAL_SRC", str(tmp_path / "nowhere2"))
+    assert not ref_shim.available()
+    (tmp_path / "loc" / "emcee").mkdir(parents=True)
+    (tmp_path / "loc" / "emcee" / "ensemble.py").write_text("")
+    monkeypatch.setattr(ref_shim, "LOCAL_SRC", str(tmp_path / "loc"))
+    assert ref_shim.available() and ref_shim.source() == str(tmp_path / "loc")
 
 
 def test_no_cpu_fallback_without_a_gpu():
