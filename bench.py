@@ -61,6 +61,39 @@ def algorithmic_bytes(ndim, kind, store):
     return (16 + 8 * partner_rows(kind)) * ndim + 17 + ((8 * ndim + 8) if store else 0)
 
 
+def moved_bytes(ndim, kind, store, accept_frac):
+    """Bytes that must actually MOVE per walker-update: SURVEY.md 8d's formula counts the 8*D write of x_k' for every proposal, but a
+    rejected proposal writes nothing back (`Move.update` commits accepted rows only, move.py:12-45; the kernels do the same) -- so
+    the coordinate write is weighted by the measured acceptance fraction: (8 + 8*partners)*D + 8*D*acc + 17 (+ chain row)."""
+    return (8 + 8 * partner_rows(kind)) * ndim + 8 * ndim * accept_frac + 17 + ((8 * ndim + 8) if store else 0)
+
+
+def roofline_audit(rl, wl, store, accept_frac, updates_per_s, traffic_bytes_per_launch=None, launch_s=None):
+    """Make a roofline entry auditable (round-3 verdict): next to `achieved` (SURVEY 8d's nominal bytes) the acceptance-aware
+    rate and, when PMC traffic is known, the rate of the bytes HBM really served.  An entry whose nominal rate exceeds what
+    the memory system can deliver says which bytes never moved."""
+    w = np.asarray(wl.weights) / np.sum(wl.weights)
+    Bm = float(sum(wi * moved_bytes(wl.D, kind, store, accept_frac) for wi, (kind, _) in zip(w, wl.moves)))
+    rl["moved_bytes_per_walker_update"] = Bm
+    rl["achieved_moved"] = updates_per_s * Bm / 1e9
+    rl["frac_moved"] = rl["achieved_moved"] / HBM_PEAK_GBPS
+    rl["moved_is"] = "16*D + 8*D*accept_frac + 17 for the stretch move (%.3f accepted): rejected proposals write no row back" % accept_frac
+    if traffic_bytes_per_launch and launch_s:
+        rl["traffic_rate"] = traffic_bytes_per_launch / launch_s / 1e9
+        rl["frac_traffic"] = rl["traffic_rate"] / HBM_PEAK_GBPS
+    else:
+        rl["frac_traffic"] = None
+    nominal = rl.get("achieved")
+    if nominal is not None and nominal > HBM_ACHIEVABLE_GBPS:
+        B = wl.bytes_per_update(store)
+        rl["above_achievable_because"] = (
+            "nominal rate %.0f GB/s > the %.0f GB/s the memory system delivers: SURVEY 8d's %.0f B/update count %.0f B of coordinate "
+            "writes per update that never happen at acceptance %.3f (moved: %.0f B/update -> %.0f GB/s)%s"
+            % (nominal, HBM_ACHIEVABLE_GBPS, B, 8 * wl.D * (1 - accept_frac), accept_frac, Bm, rl["achieved_moved"],
+               "" if wl.N * wl.D * 8 / 1e6 > 256.0 else "; the state also fits the 256 MB Infinity Cache, so part of the rest is not HBM traffic either"))
+    return rl
+
+
 class Workload(object):
     """One BASELINE.json configuration: synthetic inputs + how to install it on a DeviceEnsemble."""
 
@@ -439,10 +472,15 @@ def config_entry(wl, res, K, store):
                                      "steps of one move)" % hpl)
         out["roofline"]["avg_launch_us_is"] = "hipEvent time of the timed region / half-steps (persistent launches counted by their half-steps)"
     state_mb = wl.N * wl.D * 8 / 1e6
+    traffic = None
     if state_mb > 256.0:
+        traffic = hbm_traffic(wl.key)
         out["roofline"].update({"state_MB": state_mb, "beyond_infinity_cache": True,
                                 "frac_of_achievable_6300": wl.N * B / (ev_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS,
-                                "traffic": hbm_traffic(wl.key), "traffic_source": "profiles/pmc_traffic.json (static; rocprofv3 PMC passes)"})
+                                "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (static; rocprofv3 PMC passes)"})
+    roofline_audit(out["roofline"], wl, store, res["accept_frac"], wl.N / (ev_ms * 1e-3), traffic, ev_ms * 1e-3 / lps)
+    if state_mb > 256.0:
+        out["roofline"]["frac_moved_of_achievable_6300"] = out["roofline"]["achieved_moved"] / HBM_ACHIEVABLE_GBPS
     return out
 
 
@@ -1249,6 +1287,7 @@ def main(argv=None):
                                  "; per_launch_event_us brackets single launches (of per_launch_event_halfsteps half-steps when "
                                  "persistent) with hipEvents"},
         }
+        roofline_audit(line["roofline"], wl, args.store, accept, slots_per_launch / avg_launch_s, line["roofline"]["traffic"], avg_launch_s)
         line.update(extra)
         if persist_total:
             line["persist"] = persist_total

@@ -459,6 +459,18 @@ struct emx_ctx {
     unsigned* persist_ver = nullptr;  // (N) stamp of the half-step that last moved the walker
     unsigned persist_epoch = 0;
     unsigned persist_grid = 0;        // workgroups of the launches the barrier counters have counted so far
+    // what a persistent launch did, kept until the stream is known to have run it: a launch whose grid could not become co-resident
+    // leaves without a store (persist_handshake), and persist_recover takes its steps again on the per-half-step path
+    struct PersistLog {
+        unsigned seq;
+        uint64_t ph_step;
+        int64_t i0, steps, stored0, proposals0;
+        int32_t thin_by, store;
+    };
+    std::deque<PersistLog> plog;
+    unsigned persist_seq = 0;
+    int64_t persist_recovered = 0;    // launches redone by persist_recover (emx_persist_info)
+    int8_t persist_fits[4] = {-1, -1, -1, -1};      // [move kind]: the grid of that move's launches fits the device (occupancy query), -1: not asked yet
     int64_t tune_replay_two_pass = 0;         // 1: the replay exchange always compacts, then replays (tests of that form)
     int64_t tune_full_plan = 0;      // 1: native plans always carry every column
     int64_t tune_spw = 0, tune_bpc = 2, tune_wpb = 0, tune_ablate = 0, tune_dense_wide = 0;
@@ -477,6 +489,7 @@ static int direct_ensure(emx_ctx* c);
 static void exchange_free(emx_ctx* c);
 static int replay_ensure(emx_ctx* c);
 static int flags_ensure(emx_ctx* c);
+static int persist_settle(emx_ctx* c);
 
 // forget native plans evaluated ahead of time; the Gaussian sequential cursors they advanced go back
 static void drop_prepared(emx_ctx* c) {
@@ -1093,6 +1106,7 @@ static void apply_env_tuning(emx_ctx* c) {
 int emx_destroy(emx_ctx* c) {
     if (!c) return 0;
     pipe_stop(c);                 // its threads write into the pinned staging buffers freed below
+    c->plog.clear();
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm), c->comm = nullptr;
@@ -1197,11 +1211,15 @@ static hipError_t wait_event(hipEvent_t ev) {
 int emx_sync(emx_ctx* c) {
     HIPOK(c, hipSetDevice(c->device));
     HIPOK(c, wait_stream(c->stream));
-    return 0;
+    return persist_settle(c);
 }
 
 int emx_status(emx_ctx* c, uint32_t* bits) {
     HIPOK(c, wait_stream(c->stream));      // every launch that could still raise a bit has finished
+    {
+        const int rcs = persist_settle(c);     // a persistent launch that gave up untouched is redone here: no bit, no void state
+        if (rcs) return rcs;
+    }
     uint32_t b = 0;
     for (int k = 0; k < 4; ++k)
         if (__atomic_exchange_n(&c->status_host[k], 0u, __ATOMIC_ACQ_REL)) b |= 1u << k;
@@ -1378,6 +1396,7 @@ static int big_copy_to_device(emx_ctx* c, void* dst, const void* src, size_t byt
 }
 
 int emx_set_state(emx_ctx* c, const double* coords, const double* log_prob) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     {
         const int rc = big_copy_to_device(c, c->X, coords, (size_t)c->N * c->D * 8);
@@ -1389,6 +1408,7 @@ int emx_set_state(emx_ctx* c, const double* coords, const double* log_prob) {
 }
 
 int emx_get_state(emx_ctx* c, double* coords, double* log_prob) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     if (log_prob) HIPOK(c, hipMemcpyAsync(log_prob, c->lp, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
     if (coords) {
@@ -1402,6 +1422,7 @@ int emx_get_state(emx_ctx* c, double* coords, double* log_prob) {
 // The caller's own batched log-prob on device buffers (include/emx.h): ensemble.py:486-487's vectorised call without the PCIe
 // hop.  The fused closed-form targets are replaced by three passes on the stream (launch_split).
 int emx_set_target_callback(emx_ctx* c, emx_device_log_prob_fn fn, void* user) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, fn != nullptr, "emx_set_target_callback: no function");
     pipe_stop(c);
@@ -1422,6 +1443,7 @@ int emx_set_target_callback(emx_ctx* c, emx_device_log_prob_fn fn, void* user) {
 // the device state; a snapshot is the copy-on-write copy taken when the next call is about to change it while the old object
 // is still alive, so that the old object keeps the values it was returned with: 2 x 33.5 MB inside HBM instead of over PCIe)
 int emx_snapshot_save(emx_ctx* c, int32_t slot) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, slot >= 0 && slot < emx_ctx::NSNAPSHOT, "snapshot slot out of range");
     const size_t nx = (size_t)c->N * c->D, nl = (size_t)c->N;
@@ -1432,6 +1454,7 @@ int emx_snapshot_save(emx_ctx* c, int32_t slot) {
 }
 
 int emx_snapshot_read(emx_ctx* c, int32_t slot, double* coords, double* log_prob) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, slot >= 0 && slot < emx_ctx::NSNAPSHOT && c->snap[slot], "no snapshot in slot %d", slot);
     const size_t nx = (size_t)c->N * c->D;
@@ -1445,6 +1468,7 @@ int emx_snapshot_read(emx_ctx* c, int32_t slot, double* coords, double* log_prob
 }
 
 int emx_snapshot_restore(emx_ctx* c, int32_t slot) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, slot >= 0 && slot < emx_ctx::NSNAPSHOT && c->snap[slot], "no snapshot in slot %d", slot);
     const size_t nx = (size_t)c->N * c->D;
@@ -1465,12 +1489,14 @@ int emx_snapshot_free(emx_ctx* c, int32_t slot) {
 }
 
 int emx_get_accepted(emx_ctx* c, uint8_t* mask) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipMemcpyAsync(mask, c->acc, (size_t)c->N, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
 int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1, double scale) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, kind >= EMX_TARGET_HOST && kind <= EMX_TARGET_BOX, "unknown target kind %d", kind);
     // Everything that can fail (argument checks, the Cholesky factorisation, allocations, uploads) happens on
@@ -1548,6 +1574,7 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
     std::swap(c->tp1, ntp1);
     std::swap(c->tp1_full, ntpf);
     c->Dp = nDp;
+    for (auto& f : c->persist_fits) f = -1;
     graph_invalidate(c);
     c->graph_warm = false;
     c->target = kind;
@@ -1564,6 +1591,7 @@ static int eval_rows(emx_ctx* c, double* X, double* lp, int64_t n) {
 }
 
 int emx_eval_state_log_prob(emx_ctx* c) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     return eval_rows(c, c->X, c->lp, c->N);
 }
@@ -1581,6 +1609,7 @@ int emx_eval_log_prob(emx_ctx* c, const double* coords, int64_t n, double* out) 
 }
 
 int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const double* cdf) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     NEED(c, nmoves >= 1, "need at least one move");
     pipe_stop(c);
     for (int i = 0; i < nmoves; ++i) {
@@ -1601,6 +1630,7 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
     }
     c->moves.assign(moves, moves + nmoves);
     c->cdf.assign(cdf, cdf + nmoves);
+    for (auto& f : c->persist_fits) f = -1;
     for (double* p : c->mscale)
         if (p) {
             hipStreamSynchronize(c->stream);
@@ -1616,6 +1646,7 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
 }
 
 int emx_set_rng_mode(emx_ctx* c, int32_t mode) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     NEED(c, mode >= 0 && mode <= 2, "unknown rng mode");
     pipe_stop(c);
     c->rng_mode = mode;
@@ -1660,6 +1691,7 @@ int emx_rng_get_mt19937(emx_ctx* c, uint32_t key[624], int32_t* pos, int32_t* hg
 }
 
 int emx_rng_set_philox(emx_ctx* c, uint64_t seed, uint64_t step) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     c->ph_seed = seed;
     c->ph_step = step;
     drop_prepared(c);
@@ -1668,12 +1700,14 @@ int emx_rng_set_philox(emx_ctx* c, uint64_t seed, uint64_t step) {
 }
 
 int emx_rng_get_philox(emx_ctx* c, uint64_t* seed, uint64_t* step) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     *seed = c->ph_seed;
     *step = c->ph_step;
     return 0;
 }
 
 int emx_chain_config(emx_ctx* c, int64_t cap) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, cap >= c->stored, "capacity below the number of stored steps");
     if (cap == c->cap) return 0;
@@ -1703,6 +1737,7 @@ int emx_chain_config(emx_ctx* c, int64_t cap) {
 }
 
 int emx_chain_reset(emx_ctx* c) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     c->stored = 0;
     c->proposals = 0;
@@ -1717,12 +1752,14 @@ int emx_graph_state(emx_ctx* c, int32_t* disabled, int32_t* captured) {
 }
 
 int emx_iteration(emx_ctx* c, int64_t* stored, int64_t* proposals) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     *stored = c->stored;
     *proposals = c->proposals;
     return 0;
 }
 
 int emx_chain_read(emx_ctx* c, int32_t what, int64_t start, int64_t stop, int64_t stride, double* out) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, stride >= 1 && start >= 0 && stop <= c->stored, "chain slice out of range");
     const size_t row = what == 0 ? (size_t)c->N * c->D * 8 : (size_t)c->N * 8;
@@ -1747,6 +1784,7 @@ int emx_chain_read(emx_ctx* c, int32_t what, int64_t start, int64_t stop, int64_
 }
 
 int emx_accepted_counts(emx_ctx* c, double* out) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     std::vector<uint32_t> h((size_t)c->N);
     HIPOK(c, hipMemcpyAsync(h.data(), c->acc_count, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(c, hipStreamSynchronize(c->stream));
@@ -2691,9 +2729,25 @@ static int persist_shape_of(int64_t N, int nsplits, int64_t cu) {
 static int persist_shape(const emx_ctx* c, int nsplits) { return persist_shape_of(c->N, nsplits, c->num_cu); }
 
 // the moves k_persist has an instantiation for (the other moves of a mixture run their steps through the per-half-step launches)
+// Checked, not assumed: the runtime's occupancy figure for this instantiation, block size and LDS need x the CU count must cover
+// the grid, or the launch could never become co-resident even on an idle device (asked once per context and move).
+static bool persist_grid_fits(const emx_ctx* cc, const emx_move_desc& m, int wpb) {
+    emx_ctx* c = const_cast<emx_ctx*>(cc);
+    if (m.kind < 0 || m.kind > 3) return false;
+    if (c->persist_fits[m.kind] < 0) {
+        const int64_t groups = c->N / m.nsplits / 16 / wpb;
+        int per_cu = 0;
+        const hipError_t e = hot_persist_occupancy(c->Dp / 16, m.kind, 64 * wpb, dense_lds_bytes(c->Dp, wpb), &per_cu);
+        c->persist_fits[m.kind] = (e != hipSuccess || (int64_t)per_cu * c->num_cu >= groups) ? 1 : 0;     // (no answer: as before)
+    }
+    return c->persist_fits[m.kind] != 0;
+}
+
 static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
     const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
-    return known && persist_shape(c, m.nsplits) != 0;
+    if (!known) return false;
+    const int wpb = persist_shape(c, m.nsplits);
+    return wpb != 0 && persist_grid_fits(c, m, wpb);
 }
 
 static bool persist_wanted(const emx_ctx* c) {
@@ -2797,10 +2851,24 @@ static const emx_ctx* g_persist_last[MAX_DEVICES] = {};
 static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, int32_t store, int64_t* done) {
     *done = 0;
     if (__atomic_load_n(&c->status_host[3], __ATOMIC_ACQUIRE)) {
-        // a barrier of an earlier persistent launch was never met (status bit 3, not read yet): no further launch on top of it
-        c->persist_grid = 0;          // (the counters restart once the status has been taken)
-        FAIL(c, -8, "persistent kernel: a device-wide barrier timed out (the grid could not become co-resident); read emx_status, "
-                    "or turn the persistent path off with tuning \"persist\" = 0");
+        // a barrier of an earlier persistent launch was never met (status bit 3, not read yet): a launch that gave up at its
+        // handshake left the ensemble untouched and is redone on the per-half-step path; anything else is void
+        const int rcs = persist_settle(c);
+        if (rcs) return rcs;
+        if (__atomic_load_n(&c->status_host[3], __ATOMIC_ACQUIRE)) {
+            c->persist_grid = 0;          // (the counters restart once the status has been taken)
+            FAIL(c, -8, "persistent kernel: a device-wide barrier timed out in the middle of a launch; read emx_status, "
+                        "or turn the persistent path off with tuning \"persist\" = 0");
+        }
+        return 0;                         // (*done == 0: the caller's loop comes back, now on the per-half-step path)
+    }
+    if (c->plog.size() >= 4096) {         // bound the log: everything the stream has run without a timeout is settled
+        if (hipStreamQuery(c->stream) == hipSuccess && !__atomic_load_n(&c->status_host[3], __ATOMIC_ACQUIRE)) {
+            c->plog.clear();
+        } else if (c->plog.size() >= 65536) {
+            const int rcs = persist_settle(c);
+            if (rcs) return rcs;
+        }
     }
     if (!c->persist_bar) {
         HIPOK(c, hipMalloc((void**)&c->persist_bar, 10 * 32 * sizeof(unsigned)));
@@ -2817,6 +2885,13 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     size_t lds = 0;
     int n = 0;
     int64_t steps = 0;
+    emx_ctx::PersistLog lg{};
+    lg.ph_step = c->ph_step;
+    lg.i0 = i0;
+    lg.stored0 = c->stored;
+    lg.proposals0 = c->proposals;
+    lg.thin_by = thin_by;
+    lg.store = store;
     int launch_move = -1;                // EMX_MOVE_STRETCH, _DE or _SNOOKER: the move of every step of this launch
     int launch_S = 2;
     while (i0 + steps < total && n + launch_S <= PERSIST_MAX_ITERS) {
@@ -2881,7 +2956,11 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     P.ver = c->persist_ver;
     P.epoch0 = c->persist_epoch + (unsigned)c->tune_persist_test_skew;      // (tests: a barrier that is never met)
     P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
-    c->persist_epoch += (unsigned)(n - 1);
+    c->persist_epoch += (unsigned)n;          // the handshake and the n - 1 barriers between the half-steps
+    P.seq = ++c->persist_seq;
+    lg.seq = P.seq;
+    lg.steps = steps;
+    c->plog.push_back(lg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max;
     if (prof) {
@@ -2913,6 +2992,68 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     return 0;
 }
 
+// Everything a persistent launch was asked to do is known to be done -- or is done again here.  A launch whose grid could not
+// become co-resident within the time limit (another process holds the CUs with a persistent grid of its own: the one case the
+// occupancy check cannot see) left at its handshake WITHOUT a store, and so did every persistent launch queued behind it (the
+// dead mark): the ensemble is exactly what the last completed launch left, and the logged steps of the others are taken
+// again by the launch-per-half-step kernels -- same plans (a pure function of the step number), same bits.  The persistent
+// path is then switched off for this context (tuning "persist" = 1 turns it back on).  A time-out in the MIDDLE of a launch
+// (a resident workgroup that stopped for seconds: nothing we know produces it) stays what it was: status bit 3, void state.
+static int persist_settle(emx_ctx* c) {
+    if (c->plog.empty()) return 0;
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, wait_stream(c->stream));
+    if (!__atomic_load_n(&c->status_host[3], __ATOMIC_ACQUIRE) || !c->persist_bar) {
+        c->plog.clear();
+        return 0;
+    }
+    unsigned w[4] = {0, 0, 0, 0};
+    HIPOK(c, hipMemcpy(w, c->persist_bar + 9 * 32, sizeof(w), hipMemcpyDeviceToHost));
+    if (w[1] != 1u) {           // not (only) a clean handshake time-out: a direct-exchange barrier, or the middle of a launch
+        c->plog.clear();
+        return 0;
+    }
+    const unsigned done_seq = w[3];
+    std::deque<emx_ctx::PersistLog> redo;
+    for (const auto& e : c->plog)
+        if ((int)(e.seq - done_seq) > 0) redo.push_back(e);
+    c->plog.clear();
+    // the barrier words restart, the status bit is taken back: nothing is void
+    HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 10 * 32 * sizeof(unsigned), c->stream));
+    c->persist_epoch = 0;
+    c->persist_grid = 0;
+    __atomic_store_n(&c->status_host[3], 0u, __ATOMIC_RELEASE);
+    if (redo.empty()) return 0;
+    NEED(c, !c->cur.active, "persistent launches to redo, but a step is open");
+    const int64_t stored_end = c->stored, proposals_end = c->proposals;
+    const uint64_t ph_end = c->ph_step;
+    for (const auto& m : c->moves) NEED(c, m.kind != EMX_MOVE_GAUSS, "persistent launches to redo in a mixture with a Gaussian move");
+    drop_prepared(c);                         // (the ring slots of plans made ahead are about to be reused)
+    c->tune_persist = 0;                      // and it stays off: whatever held the CUs may still be there ("persist" = 1 turns it back on)
+    c->ph_step = redo.front().ph_step;
+    c->stored = redo.front().stored0;
+    c->proposals = redo.front().proposals0;
+    int rc = 0;
+    for (const auto& e : redo) {
+        NEED(c, c->ph_step == e.ph_step && c->stored == e.stored0, "persistent launches to redo are not consecutive");
+        for (int64_t k = 0; k < e.steps && !rc; ++k) {
+            const int st = e.store && ((e.i0 + k + 1) % e.thin_by == 0);          // ensemble.py:416
+            int mvi, S;
+            c->prep_hint = NATIVE_BATCH_MAX;
+            rc = emx_step_begin(c, st, &mvi, &S);
+            for (int sp = 0; sp < S && !rc; ++sp) rc = do_halfstep(c, sp, c->target);
+            if (rc) c->cur.active = false;
+            if (!rc) rc = emx_step_end(c);
+        }
+        if (rc) break;
+        c->persist_recovered++;
+    }
+    if (rc) return rc;
+    NEED(c, c->ph_step == ph_end && c->stored == stored_end && c->proposals == proposals_end, "redone steps do not add up");
+    HIPOK(c, wait_stream(c->stream));
+    return 0;
+}
+
 int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, int32_t* waves_per_group, int32_t* groups) {
     const int wpb = persist_shape_of(nwalkers, nsplits, num_cu);
     *waves_per_group = wpb;
@@ -2924,7 +3065,7 @@ int emx_persist_info(emx_ctx* c, int64_t out[4]) {
     out[0] = (persist_wanted(c) || persist_gauss_wanted(c)) ? 1 : 0;
     out[1] = c->persist_launches;
     out[2] = c->persist_halfsteps;
-    out[3] = 0;
+    out[3] = c->persist_recovered;       // launches that gave up untouched and were redone on the per-half-step path (persist_settle)
     return 0;
 }
 
@@ -2999,7 +3140,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
             ctr_synced = false;
             continue;
         }
-        if (persist_on) {
+        if (persist_on && c->tune_persist) {
             // the next step's move decides (a mixture: runs of steps of one move the persistent kernel knows, the others one by one)
             if (!c->prepared.empty() && c->prepared.front().step != c->ph_step) drop_prepared(c);
             if (c->prepared.empty()) {
@@ -3012,7 +3153,8 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
                 if (rc) return rc;
                 i += done;
                 ctr_synced = false;
-                continue;
+                if (done > 0) continue;
+                // (nothing done: launches that gave up were just redone and the persistent path is off for this context -- fall through)
             }
         }
         if (thin_by == 1 && total - i >= NATIVE_BATCH_MAX) {
@@ -3250,6 +3392,7 @@ int emx_set_exchange(emx_ctx* c, int32_t kind) {
 }
 
 int emx_set_shard(emx_ctx* c, int32_t rank, int32_t world) {
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, world >= 1 && rank >= 0 && rank < world, "bad (rank, world)");
     NEED(c, world <= c->N, "more ranks than walkers");

@@ -35,6 +35,28 @@ hipError_t launch_hot_persist_dense(int dpb, int move, dim3 grid, dim3 block, si
     return hipErrorInvalidValue;
 }
 
+// how many workgroups of that instantiation the runtime says a CU holds at once (block size, dynamic LDS): the co-residency check
+template <int G, int V, int CH, int DPB, int MOVE>
+static hipError_t persist_occupancy(int threads, size_t lds, int* per_cu) {
+    auto kern = k_persist<G, V, CH, DPB, MOVE>;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, threads, lds);
+}
+
+hipError_t hot_persist_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu) {
+#define EMX_CASE(b, ch)                                                                                     \
+    if (dpb == b)                                                                                           \
+        return move == MOVE_DE        ? persist_occupancy<8, 2, ch, b, MOVE_DE>(threads, lds, per_cu)       \
+               : move == MOVE_SNOOKER ? persist_occupancy<8, 2, ch, b, MOVE_SNOOKER>(threads, lds, per_cu)  \
+                                      : persist_occupancy<8, 2, ch, b, MOVE_STRETCH>(threads, lds, per_cu);
+    EMX_CASE(1, 1) EMX_CASE(2, 2) EMX_CASE(3, 4) EMX_CASE(4, 4)
+#undef EMX_CASE
+    return hipErrorInvalidValue;
+}
+
 // the Gaussian Metropolis move's persistent form (k_persist_gauss): no barrier, any grid
 hipError_t launch_hot_persist_gauss(int dpb, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistGaussArgs& P) {
 #define EMX_CASE(b, ch)                                                                                              \

@@ -1246,6 +1246,7 @@ struct PersistArgs {
     unsigned epoch0;               // barriers already passed on these counters
     unsigned long long timeout_ticks;
     int32_t niter;
+    unsigned seq;                  // number of this launch (left in the barrier block's fourth `go` word once its grid is known co-resident)
 };
 
 __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k) {
@@ -1270,12 +1271,62 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
                 // never met: report, and let every later barrier of the run through at once (the results are void anyway;
                 // the host refuses further persistent launches until the status has been read)
                 raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
-                __hip_atomic_store(go + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(go + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // 2: in the middle of a launch
                 break;
             }
         }
     }
     __syncthreads();
+}
+
+// The first barrier of a launch, BEFORE anything is written: every workgroup of the grid reports in.  Once it has been passed the
+// whole grid is resident (nothing leaves a CU before it exits), so the barriers between the half-steps can only be late, never
+// unmet.  When it is NOT passed in time -- another process holds the CUs with a persistent grid of its own -- the launch gives
+// up with the ensemble untouched: the dead mark (1: clean) sends home the workgroups that start later and every launch queued
+// behind this one, and the host redoes those launches' steps on the per-half-step path (persist_recover, emx.hip).
+// -> false: leave without a store.
+__device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        const unsigned k = P.epoch0 + 1u;
+        const int xcd = blockIdx.x & 7;
+        const unsigned per = (gridDim.x + 7 - xcd) / 8;
+        unsigned* xctr = P.bar + xcd * 32;
+        unsigned* gctr = P.bar + 8 * 32;
+        unsigned* go = P.bar + 9 * 32;
+        int ok = 1;
+        const unsigned long long v0 = __hip_atomic_load(reinterpret_cast<unsigned long long*>(go), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v0 >> 32) != 0ull) {
+            ok = 0;                                                 // an earlier launch gave up: not even counted
+        } else {
+            const unsigned old = __hip_atomic_fetch_add(xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == k * per - 1) {
+                const unsigned o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o2 == k * 8 - 1) {
+                    __hip_atomic_store(go + 3, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // this launch will run to its end
+                    __hip_atomic_store(go, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(reinterpret_cast<unsigned long long*>(go), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 32) != 0ull) {
+                    ok = 0;
+                    break;
+                }
+                if ((int)((unsigned)v - k) >= 0) break;
+                if (wall_clock64() - t0 > P.timeout_ticks) {
+                    raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
+                    __hip_atomic_store(go + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // 1: nothing was written
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
 }
 
 template <int G, int V, int CH, int DPB, int MOVE = MOVE_STRETCH>
@@ -1310,7 +1361,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     }
     Row<G, V, CH> mu;
     load_row<G, V, CH>(mu, A.tp0, D, gl);
-    __syncthreads();
+    if (!persist_handshake(P)) return;                          // (also the workgroup barrier behind the image load)
     const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
     const int t0 = wave * 16;                                   // this wave's slots of every split
     const __amdgpu_buffer_rsrc_t Xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.X, 0, A.N * D * 8, 0x00020000);
@@ -1496,7 +1547,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         }
         EMX_WAVE_SYNC();
         if (!more) break;
-        persist_barrier(P, P.epoch0 + (unsigned)n + 1u);
+        persist_barrier(P, P.epoch0 + (unsigned)n + 2u);           // (+ 1: the handshake was this launch's first barrier)
         // -------- roll over --------
 #pragma unroll
         for (int k = 0; k < PF; ++k) {

@@ -337,7 +337,7 @@ struct WordStream {
     alignas(64) std::atomic<uint64_t> produced{0};     // blocks produced
     alignas(64) std::atomic<uint64_t> keep{0};         // lowest block the reader may still touch
     std::atomic<bool> stop{false};
-    uint64_t gen_wait_ns = 0, gen_blocks = 0, rd_wait_ns = 0;
+    std::atomic<uint64_t> gen_wait_ns{0}, gen_blocks{0}, rd_wait_ns{0};     // read by stage_times() while the threads run
 };
 
 void generator_main(WordStream* ws, const uint32_t* start_key) {
@@ -624,11 +624,13 @@ struct MtPlanPipeline::Impl {
     std::thread gen, tok;
     std::vector<std::thread> fin;
     bool joined = false;
-    uint64_t t_start = 0, tok_wait_sink_ns = 0, tok_done_ns = 0;
+    uint64_t t_start = 0, tok_done_ns = 0;
+    std::atomic<uint64_t> tok_wait_sink_ns{0}, tok_busy_ns{0};                 // read by stage_times() while the threads run
     bool vec_scan = false, stats = false, fill_unused = false;
-    uint64_t tok_shuffle_ns = 0, tok_busy_ns = 0;
+    uint64_t tok_shuffle_ns = 0;
     std::atomic<int64_t> tok_steps{0};             // steps tokenised so far
-    std::vector<uint64_t> fin_wait_ns, fin_busy_ns;
+    std::vector<uint64_t> fin_wait_ns;
+    std::vector<std::atomic<uint64_t>> fin_busy_ns;
 
     void tokenizer_main();
     void finisher_main(int id);
@@ -716,7 +718,8 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     m.stats = getenv("EMX_PIPE_STATS") != nullptr;
     m.fill_unused = fill_unused_fields;
     m.fin_wait_ns.assign(K, 0);
-    m.fin_busy_ns.assign(K, 0);
+    m.fin_busy_ns = std::vector<std::atomic<uint64_t>>(K);
+    for (auto& b : m.fin_busy_ns) b.store(0, std::memory_order_relaxed);
     m.t_start = now_ns();
     // One physical core per thread is the fastest placement on an idle host (0.080 vs 0.100 ms/step at 65 536 walkers) and the
     // slowest when another tenant of the machine occupies one of the chosen cores (0.19 seen): opt-in (EMX_PIPE_CORE_PINNING=1);
@@ -741,7 +744,7 @@ void MtPlanPipeline::stage_times(double out[6], int64_t* steps) const {
     const int64_t n = std::max<int64_t>(1, m.tok_steps.load(std::memory_order_relaxed));
     const double elapsed = (double)(now_ns() - m.t_start);
     uint64_t fin = 0;
-    for (uint64_t b : m.fin_busy_ns) fin += b;
+    for (const auto& b : m.fin_busy_ns) fin += b.load(std::memory_order_relaxed);
     out[0] = elapsed * 1e-3 / n;                                   // wall clock per produced step (it runs ahead: an upper bound)
     out[1] = (elapsed - (double)m.ws.gen_wait_ns) * 1e-3 / n;      // generator: twist + temper
     out[2] = (double)m.tok_busy_ns * 1e-3 / n;                     // tokenizer: rejection tests, raw words handed on
@@ -885,9 +888,9 @@ void MtPlanPipeline::Impl::tokenizer_main() {
         if (stop.load(std::memory_order_relaxed)) return;
         {
             const uint64_t t0 = now_ns();
-            const uint64_t w0 = ws.rd_wait_ns;
+            const uint64_t w0 = ws.rd_wait_ns.load(std::memory_order_relaxed);
             tokenize(rd, n, has_gauss, gauss);
-            tok_busy_ns += (now_ns() - t0) - (ws.rd_wait_ns - w0);         // without the time it waited for words
+            tok_busy_ns.fetch_add((now_ns() - t0) - (ws.rd_wait_ns.load(std::memory_order_relaxed) - w0), std::memory_order_relaxed);         // without the time it waited for words
         }
         if (rd.dead) return;
         // generator state after this step (NumPy get_state() semantics: a block consumed to its end reports pos = 624)

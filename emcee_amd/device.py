@@ -41,6 +41,7 @@ class DeviceEnsemble:
         # resident states (state.ResidentState): the object a run handed out that still IS the device state, and the snapshot
         # slots of older ones
         self._gen = 0
+        self._world = 1
         self._resident = None            # weakref to the ResidentState mirroring generation _gen
         self._free_slots = list(range(8))
         import weakref
@@ -80,11 +81,17 @@ class DeviceEnsemble:
     def _touch(self):
         """Called before anything changes (coords, log_prob) on the device: a live, never-read ResidentState of the current
         generation keeps its values in a device-side snapshot (or on the host when the slots are used up)."""
-        ref, self._resident = self._resident, None
-        self._gen += 1
+        ref = self._resident
         st = ref() if ref is not None else None
         if st is not None:
-            st._detach_before_change()
+            # detach FIRST: while the generation still matches, the state can take a device snapshot -- and if that fails (no
+            # memory for one, a pending callback exception) it still can be read live over PCIe, because nothing has changed yet
+            try:
+                st._detach_before_change()
+            except Exception:  # noqa: BLE001
+                st._materialise(live=True)
+        self._resident = None
+        self._gen += 1
 
     def snapshot_save(self):
         """-> slot holding a device-side copy of the current (coords, log_prob), or None when all slots are taken"""
@@ -137,10 +144,12 @@ class DeviceEnsemble:
         if bits & _STATUS_EXCHANGE_OVERFLOW:
             raise EmxError("pull exchange: record capacity exceeded; the sharded run is invalid")
         if bits & _STATUS_EXCHANGE_TIMEOUT:
-            if self.persist_info()["launches"] > 0:
-                raise EmxError("persistent kernel: its device-wide barrier was not met in time (the grid could not become co-resident: "
-                               "is another process using this GPU?); the run is invalid -- EMX_TUNE=persist=0 selects the per-half-step "
-                               "launches, persist_timeout_ms raises the bound")
+            # attributed by the CURRENT configuration (one replica that qualifies for the persistent kernel), not by whether a
+            # persistent launch ever ran in this context's lifetime -- a later sharded run's barrier is the direct exchange's
+            if self._world == 1 and self.persist_info()["qualifies"]:
+                raise EmxError("persistent kernel: a device-wide barrier in the middle of a launch was not met in time (a launch that "
+                               "cannot become co-resident is redone on the per-half-step path instead); the run is invalid -- "
+                               "EMX_TUNE=persist=0 selects the per-half-step launches, persist_timeout_ms raises the bound")
             raise EmxError("direct exchange: a peer did not reach the device-side barrier in time; the sharded run is invalid")
         if bits & _STATUS_BAD_COORD:
             raise ValueError("At least one parameter value was infinite or NaN")
@@ -406,6 +415,7 @@ class DeviceEnsemble:
     # ---- sharding ----
     def set_shard(self, rank, world):
         self._ck(self.lib.emx_set_shard(self.ctx, int(rank), int(world)))
+        self._world = int(world)
 
     def set_shard_buffers(self, sendbuf_ptr, gathered_ptr, rows):
         self._ck(self.lib.emx_set_shard_buffers(self.ctx, sendbuf_ptr, gathered_ptr, int(rows)))
@@ -556,7 +566,7 @@ class DeviceEnsemble:
         """persistent half-steps (include/emx.h emx_persist_info): does the configuration qualify, launches, half-steps they ran"""
         out = (C.c_int64 * 4)()
         self._ck(self.lib.emx_persist_info(self.ctx, out))
-        return {"qualifies": bool(out[0]), "launches": int(out[1]), "halfsteps": int(out[2])}
+        return {"qualifies": bool(out[0]), "launches": int(out[1]), "halfsteps": int(out[2]), "recovered": int(out[3])}
 
     def comm_count(self):
         """ranks of the library's RCCL communicator (ncclCommCount); 0 without one"""

@@ -525,9 +525,10 @@ class EnsembleSampler(object):
             resident = initial_state
         if resident is not None:
             state = resident
-            if (not kw.get("skip_initial_state_check", False)) and (not walkers_independent(resident._peek_coords())):
-                raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
-                                 "linearly independent for the best performance")
+            # No conditioning check here: this state is the output of a run whose own initial state passed it (or whose caller
+            # waived it), and checking would download the whole ensemble (33 MB at 65 536 x 64) on a path whose point is that
+            # nothing crosses PCIe.  (The reference re-checks a continuation, ensemble.py:316-323; an affine-invariant move
+            # cannot make an independent ensemble dependent except by numerical collapse, which the next explicit state would show.)
         else:
             state = State(initial_state, copy=True)
             if self._dist is not None:
@@ -631,18 +632,23 @@ class EnsembleSampler(object):
         # raised before the collective would leave the others waiting in it for ever
         import hashlib
         digest = hashlib.sha1(np.ascontiguousarray(p, dtype=np.float64).tobytes()).hexdigest()[:16]
+        local_exc = None
         try:
             mine = self._call_log_prob_fn(p[lo:hi]) if hi > lo else (np.empty(0), None)
             payload = (digest, None, np.asarray(mine[0], dtype=np.float64), mine[1])
-        except BaseException as e:  # noqa: BLE001  (re-raised on all ranks below)
-            payload = (digest, e, None, None)
+        except Exception as e:  # noqa: BLE001  (re-raised on all ranks below; KeyboardInterrupt / SystemExit take their usual way)
+            # only text travels: an exception object may not pickle (locals, device tensors, custom __init__ signatures), and a
+            # rank that fails to pickle before the collective leaves the others waiting in it -- the hang this exists to prevent
+            import traceback
+            local_exc = e
+            payload = (digest, (type(e).__name__, repr(e), traceback.format_exc()), None, None)
         parts = [None] * world
         dist.all_gather_object(parts, payload)
         for r, (_, err, _, _) in enumerate(parts):
             if err is not None:
-                if r == rank:
-                    raise err
-                raise RuntimeError("log_prob_fn failed on rank %d: %r" % (r, err))
+                if r == rank and local_exc is not None:
+                    raise local_exc
+                raise RuntimeError("log_prob_fn failed on rank %d: %s: %s\n%s" % (r, err[0], err[1], err[2]))
         if len({d for d, _, _, _ in parts}) != 1:
             raise RuntimeError("exchange='logprob': the ranks hold different coordinates (every rank must pass the same initial "
                                "state and seed)")
