@@ -4,12 +4,13 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip", "emx_hot.hip", "emx_wide.hip")]     # translation units, built in parallel
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip", "emx_hot.hip", "emx_wide.hip", "emx_mtdev.hip")]     # translation units, built in parallel
 SRC = SRCS[0]
 LIB = os.path.join(HERE, "libemx.so")
-HOST_SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx_mtpipe.cpp",)]       # plain host C++ (threads, SIMD clones): no device pass
+HOST_SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx_mtpipe.cpp", "emx_mtjump.cpp")]       # plain host C++ (threads, SIMD clones): no device pass
 DEPS = SRCS + HOST_SRCS + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_rng.hpp", "mt19937_legacy.hpp",
-                                                                  "emx_mtpipe.hpp", "emx_internal.hpp", "emx_launch.hpp")] + [
+                                                                  "emx_mtpipe.hpp", "emx_internal.hpp", "emx_launch.hpp", "emx_mtdev.hpp", "emx_mtdev_kernels.hpp",
+                                                                  "emx_mtjump.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "emx.h")]
 HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread"]
 # -ffp-contract=off: the proposal arithmetic must round like NumPy's separate multiply/subtract.

@@ -20,6 +20,8 @@
 #include "emx_internal.hpp"
 #include "emx_kernels.hpp"
 #include "emx_launch.hpp"
+#include "emx_mtdev.hpp"
+#include "emx_mtjump.hpp"
 #include "emx_mtpipe.hpp"
 #include "emx_rng.hpp"
 #include "mt19937_legacy.hpp"
@@ -32,6 +34,8 @@ std::string g_err;
 
 constexpr int PLAN_RING = 2 * NATIVE_BATCH_MAX;     // two native batches (the upper half serves the quarantined graph replay)
 constexpr int PIPE_SINKS = PLAN_RING < 16 ? PLAN_RING : 16;      // exact-mode plan pipeline: pinned staging buffers in flight
+constexpr int MTDEV_SLOTS = MTDEV_NBUF * MTDEV_BATCH;            // exact-mode device producer: its plan slots follow the ring's, allocated on first use
+static_assert(MTDEV_BATCH == NATIVE_BATCH_MAX, "a produced batch is one persistent launch");
 constexpr int EMX_MAX_RANKS = 1024;      // pull / all-gather exchanges: counter storage
 
 // ------------------------------------------------------------------------------------------
@@ -342,7 +346,7 @@ struct emx_ctx {
         hipEvent_t consumed = nullptr;
         hipEvent_t uploaded = nullptr;     // pipeline uploads: copy + logs done on the upload stream
         bool busy = false, host_written = false;
-    } ring[PLAN_RING];
+    } ring[PLAN_RING + MTDEV_SLOTS];
     // exact-mode plan pipeline (emx_mtpipe.hpp): alive only inside emx_run
     MtPlanPipeline* pipe = nullptr;
     int64_t pipe_taken = 0;              // steps whose plan emx_step_begin has taken
@@ -350,6 +354,14 @@ struct emx_ctx {
     std::deque<int64_t> pipe_uploads;    // steps whose upload is enqueued and not yet known to be complete
     hipStream_t up_stream = nullptr;     // plan uploads overlap the previous step's kernels
     int64_t tune_mt_pipeline = -1;       // -1: on, finisher threads chosen from the core count; 0: off; k > 0: k finishers
+    // exact-mode plans made on the device (emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica
+    MtDevProducer* mtdev = nullptr;
+    int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
+    int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead)
+    int64_t mtdev_steps_total = 0, mtdev_starts = 0;
+    bool mtdev_defer_release = false;
+    int64_t mtdev_release_pending = -1;
+    MtDevStats mtdev_stats_last;
     int ring_pos = 0;
     struct Prepared {   // native plans already evaluated on the device, in step order
         int move, S, slot;
@@ -369,6 +381,7 @@ struct emx_ctx {
         bool store = false;
         bool native = false;
         bool lean = false;     // native plan without the columns nothing on the fused path reads (emx_plan_get completes it)
+        bool devplan = false;  // exact-mode plan written by the device producer: there is no host copy of it
         int gcol = 0;
         std::vector<int32_t> off;
         NativeArgs nat{};
@@ -1040,7 +1053,7 @@ int emx_create(int32_t device, int64_t nwalkers, int32_t ndim, emx_ctx** out) {
     ALLOC(c->newlp, N * 8);
     ALLOC(c->evalX, N * D * 8);
     ALLOC(c->evallp, N * 8);
-    for (int r = 0; r < PLAN_RING; ++r) {
+    for (int r = 0; r < PLAN_RING; ++r) {          // (the device producer's slots behind them: mtdev_start)
         auto& s = c->ring[r];
         // one block per slot, laid out like the pinned staging buffer ([order|p0|p1|p2] int32, [s0|uacc] f64) so that a
         // host-made plan goes up in ONE copy; the device-computed logs follow
@@ -1288,6 +1301,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "dense_wide")) {      // 1: take the wide-target path (emx_wide.hip) whatever the ndim -- parity tests against the fused kernel
         c->tune_dense_wide = v == 2 ? 2 : (v ? 1 : 0);      // 2: the wide path with the single-role log-prob kernel only
         graph_invalidate(c);
+        return 0;
+    }
+    if (!strcmp(key, "mt_device")) {         // 0: exact-mode plans never from the device producer (emx_mtdev.hpp)
+        if (!v) pipe_stop(c);
+        c->tune_mt_device = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
@@ -1916,7 +1934,9 @@ static int pipe_start(emx_ctx* c) {
 }
 
 // stop the threads; the context's generator continues from the end of the last step taken
+static void mtdev_stop(emx_ctx* c);
 static void pipe_stop(emx_ctx* c) {
+    mtdev_stop(c);
     if (!c->pipe) return;
     c->pipe->finish(c->pipe_taken, c->mt);
     delete c->pipe;
@@ -1929,6 +1949,84 @@ static void pipe_stop(emx_ctx* c) {
 // one step per call) until something needs the generator state itself or changes what a plan is: emx_rng_get/set_mt19937,
 // emx_set_moves, emx_set_rng_mode, a forced move, the one-workgroup path, emx_destroy.  Those retire it (pipe_stop): the
 // context's generator is set to the state after the last step TAKEN, what was produced ahead is dropped.
+// ---- exact-mode plans made on the device (emx_mtdev.hpp) ----------------------------------------------------------------
+// Same life cycle as the host pipeline's: started by the first step that can use it, runs ahead of the steps taken (plans do not
+// depend on the walkers), retired -- the context's generator set to the state after the last step TAKEN -- by whatever retires
+// the pipeline (pipe_stop calls mtdev_stop).
+static bool mtdev_eligible(const emx_ctx* c) {
+    return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_device != 0 && c->N >= 8192 && c->world == 1 && !c->comm && !c->sendbuf &&
+           !c->peers_ready && !small_eligible(c) && MtDevProducer::supports(c->N, (int32_t)c->moves.size(), c->moves.data());
+}
+
+static int mtdev_start(emx_ctx* c) {
+    const size_t N = (size_t)c->N;
+    MtDevPlanCols cols[MTDEV_SLOTS];
+    for (int r = 0; r < MTDEV_SLOTS; ++r) {
+        auto& s = c->ring[PLAN_RING + r];
+        if (!s.order) {
+            char* blk = nullptr;
+            HIPOK(c, hipMalloc((void**)&blk, N * 48));
+            s.order = (int32_t*)blk;
+            s.p0 = s.order + N;
+            s.s0 = (double*)(blk + N * 8);
+            s.uacc = s.s0 + N;
+            s.p1 = (int32_t*)(blk + N * 24);
+            s.p2 = s.p1 + N;
+            s.logu = (double*)(blk + N * 32);
+            s.fac = s.logu + N;
+        }
+        s.busy = false;
+        s.host_written = false;
+        cols[r] = MtDevPlanCols{s.order, s.p0, s.s0, s.uacc, s.logu, s.fac};
+    }
+    HIPOK(c, hipStreamSynchronize(c->stream));          // no earlier kernel still reads one of the slots
+    c->mtdev = new MtDevProducer(c->device, c->mt, c->N, c->D, c->moves[0], cols, c->status);
+    if (!c->mtdev->ok()) {
+        c->err = c->mtdev->error();
+        delete c->mtdev;
+        c->mtdev = nullptr;
+        return -2;
+    }
+    c->mtdev_taken = 0;
+    c->mtdev_starts++;
+    return 0;
+}
+
+static void mtdev_stop(emx_ctx* c) {
+    if (!c->mtdev) return;
+    hipStreamSynchronize(c->stream);                    // the consumer's last reads of the plan slots
+    MT19937Legacy after = c->mt;
+    const int rc = c->mtdev->finish(c->mtdev_taken, after);
+    if (rc == 0)
+        c->mt = after;
+    else
+        c->err = c->mtdev->error();                     // (a stream under-run also raised status bit 2: the run is void, loudly)
+    c->mtdev_stats_last = c->mtdev->stats();
+    c->mtdev_steps_total += c->mtdev_taken;
+    delete c->mtdev;
+    c->mtdev = nullptr;
+    c->mtdev_taken = 0;
+}
+
+// emx_step_begin's part: the next plan is (or will be, in stream order) in its slot
+static int mtdev_take(emx_ctx* c) {
+    auto& cur = c->cur;
+    const int64_t n = c->mtdev_taken;
+    if (n % MTDEV_BATCH == 0) {
+        const int rc = c->mtdev->ensure_batch(n / MTDEV_BATCH, c->stream);
+        if (rc) FAIL(c, rc, "%s", c->mtdev->error().c_str());
+    }
+    const emx_move_desc& mv = c->moves[0];
+    cur.move = 0;
+    cur.S = mv.nsplits;
+    cur.slot = PLAN_RING + (int)(n % MTDEV_SLOTS);
+    cur.devplan = true;
+    cur.off.assign(cur.S + 1, 0);
+    for (int s = 0; s < cur.S; ++s) cur.off[s + 1] = cur.off[s] + (int32_t)((c->N - s + cur.S - 1) / cur.S);   // label counts survive the shuffle
+    c->mtdev_taken = n + 1;
+    return 0;
+}
+
 static bool pipe_eligible(const emx_ctx* c) {
     return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_pipeline != 0 && !small_eligible(c) &&
            MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
@@ -2038,9 +2136,20 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
     auto& cur = c->cur;
     cur.store = store != 0;
     cur.native = false;
+    cur.devplan = false;
     const int nm = (int)c->moves.size();
-    if (c->pipe && (forced_move >= 0 || !pipe_eligible(c))) pipe_stop(c);      // a forced move skips the choice draw: inline
-    if (c->rng_mode == EMX_RNG_MT19937 && forced_move < 0 && (c->pipe || (c->N >= 8192 && pipe_eligible(c)))) {
+    const bool devp = forced_move < 0 && mtdev_eligible(c);
+    if (c->mtdev && !devp) mtdev_stop(c);
+    if (c->pipe && (devp || forced_move >= 0 || !pipe_eligible(c))) pipe_stop(c);      // a forced move skips the choice draw: inline
+    if (devp) {
+        // exact mode, one stretch move: the plan of this step was (or is being) made on the device, from the same stream
+        if (!c->mtdev) {
+            int rc0 = mtdev_start(c);
+            if (rc0) return rc0;
+        }
+        int rc = mtdev_take(c);
+        if (rc) return rc;
+    } else if (c->rng_mode == EMX_RNG_MT19937 && forced_move < 0 && (c->pipe || (c->N >= 8192 && pipe_eligible(c)))) {
         // exact mode: the plan of this step comes from the pipeline threads (same draws, same order as the inline producer)
         if (!c->pipe) {
             int rc0 = pipe_start(c);
@@ -2210,6 +2319,17 @@ int emx_plan_get(emx_ctx* c, int32_t* off, int32_t* order, int32_t* p0, int32_t*
     }
     NEED(c, cur.slot >= 0, "no plan available");
     auto& ps = c->ring[cur.slot];
+    if (cur.devplan) {
+        // made on the device (emx_mtdev.hpp): no host copy exists; a stretch plan's second and third partner are the walker itself
+        HIPOK(c, hipMemcpyAsync(order, ps.order, N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipMemcpyAsync(p0, ps.p0, N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipMemcpyAsync(s0, ps.s0, N * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipMemcpyAsync(uacc, ps.uacc, N * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(c, hipStreamSynchronize(c->stream));
+        memcpy(p1, order, N * 4);
+        memcpy(p2, order, N * 4);
+        return 0;
+    }
     const HostPlan hp(ps.host, N);
     memcpy(order, hp.order, N * 4);
     memcpy(p0, hp.p0, N * 4);
@@ -2364,6 +2484,15 @@ int emx_step_end(emx_ctx* c) {
         if (s.host_written) {
             HIPOK(c, hipEventRecord(s.consumed, c->stream));
             s.busy = true;
+        }
+    }
+    if (cur.devplan && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) {
+        // the last step of a produced batch: its plan slots may be rewritten once the kernels enqueued so far have run
+        if (c->mtdev_defer_release) {
+            c->mtdev_release_pending = c->mtdev_taken / MTDEV_BATCH - 1;        // (run_persist: the launch is not enqueued yet)
+        } else {
+            const int rc = c->mtdev->release_batch(c->mtdev_taken / MTDEV_BATCH - 1, c->stream);
+            if (rc) FAIL(c, rc, "%s", c->mtdev->error().c_str());
         }
     }
     c->direct_planned = false;
@@ -2752,7 +2881,9 @@ static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
 
 static bool persist_wanted(const emx_ctx* c) {
     if (!c->tune_persist) return false;
-    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
+    // Philox plans, or the reference's own stream with its plans made on the device (emx_mtdev.hpp): either way a batch of 16 steps'
+    // plans is in HBM before the launch that takes them
+    if (!(c->rng_mode == EMX_RNG_PHILOX || mtdev_eligible(c)) || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
     if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || dense_is_wide(c)) return false;
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
     if (c->N < c->tune_persist_min_walkers) return false;
@@ -2885,6 +3016,13 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     size_t lds = 0;
     int n = 0;
     int64_t steps = 0;
+    const bool devp = c->rng_mode == EMX_RNG_MT19937;       // plans from the device producer (persist_wanted saw to it)
+    c->mtdev_defer_release = devp;                          // a batch's slots are released behind the LAUNCH that reads them, not behind the capture
+    c->mtdev_release_pending = -1;
+    struct Undefer {
+        emx_ctx* c;
+        ~Undefer() { c->mtdev_defer_release = false; }
+    } undefer{c};
     emx_ctx::PersistLog lg{};
     lg.ph_step = c->ph_step;
     lg.i0 = i0;
@@ -2895,8 +3033,12 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     int launch_move = -1;                // EMX_MOVE_STRETCH, _DE or _SNOOKER: the move of every step of this launch
     int launch_S = 2;
     while (i0 + steps < total && n + launch_S <= PERSIST_MAX_ITERS) {
-        if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
-        if (steps > 0 && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
+        if (devp) {
+            if (steps > 0 && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) break;      // one produced batch per launch
+        } else {
+            if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
+            if (steps > 0 && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
+        }
         c->prep_hint = NATIVE_BATCH_MAX;
         const int st = store && ((i0 + steps + 1) % thin_by == 0);          // ensemble.py:416
         int mvi, S;
@@ -2960,7 +3102,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     P.seq = ++c->persist_seq;
     lg.seq = P.seq;
     lg.steps = steps;
-    c->plog.push_back(lg);
+    if (!devp) c->plog.push_back(lg);         // (redoing a launch needs its plans again: a pure function of the step for Philox only)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max;
     if (prof) {
@@ -2985,6 +3127,12 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             HIPOK(c, hipEventRecord(g_persist_ev[dev], c->stream));
             g_persist_last[dev] = c;
         }
+    }
+    c->mtdev_defer_release = false;
+    if (c->mtdev_release_pending >= 0 && c->mtdev) {
+        const int rcr = c->mtdev->release_batch(c->mtdev_release_pending, c->stream);
+        c->mtdev_release_pending = -1;
+        if (rcr) FAIL(c, rcr, "%s", c->mtdev->error().c_str());
     }
     c->persist_launches++;
     c->persist_halfsteps += n;
@@ -3054,6 +3202,52 @@ static int persist_settle(emx_ctx* c) {
     return 0;
 }
 
+int emx_mtdev_info(emx_ctx* c, int64_t out[8]) {
+    const MtDevStats& st = c->mtdev ? c->mtdev->stats() : c->mtdev_stats_last;
+    out[0] = mtdev_eligible(c) ? 1 : 0;
+    out[1] = c->mtdev ? 1 : 0;
+    out[2] = c->mtdev_steps_total + c->mtdev_taken;
+    out[3] = st.rounds;
+    out[4] = st.segments;
+    out[5] = st.batches;
+    out[6] = st.windows;
+    out[7] = (int64_t)(st.poly_ms * 1e3);
+    return 0;
+}
+
+int emx_mtdev_debug(emx_ctx* c, int32_t what, int64_t arg, void* out, int64_t n) {
+    NEED(c, c->mtdev != nullptr, "emx_mtdev_debug: no device producer is alive");
+    int rc = -1;
+    if (what == 0) {
+        rc = c->mtdev->debug_stream((uint64_t)arg, n, (uint32_t*)out);
+    } else if (what == 1) {
+        NEED(c, n >= c->N, "emx_mtdev_debug: output too small");
+        rc = c->mtdev->debug_targets(arg, (uint32_t*)out);
+    } else if (what == 2) {
+        const int S = c->moves[0].nsplits;
+        NEED(c, n >= 3 * S + 1, "emx_mtdev_debug: output too small");
+        rc = c->mtdev->debug_positions(arg, (uint64_t*)out, (uint64_t*)out + 3 * S);
+    } else {
+        FAIL(c, -1, "emx_mtdev_debug: unknown item %d", what);
+    }
+    if (rc) FAIL(c, rc, "%s", c->mtdev->error().c_str());
+    return 0;
+}
+
+int emx_host_mt_jump(const uint32_t key[624], uint64_t stride_words, int32_t k, uint32_t out_key[624]) {
+    if (k < 1 || stride_words < 1) return -1;
+    const uint32_t* g = nullptr;
+    if (!mt_jump_polys(stride_words, k, &g)) return -1;
+    std::vector<uint32_t> win((size_t)MT_WINDOW + MT_N), cur(key, key + MT_N), nxt(MT_N);
+    for (size_t have = 0; have < win.size(); have += MT_N) {
+        mt_twist_block(cur.data(), nxt.data());
+        cur.swap(nxt);
+        memcpy(win.data() + have, cur.data(), std::min<size_t>(MT_N, win.size() - have) * 4);
+    }
+    mt_apply_jump(g + (size_t)(k - 1) * MT_POLY_WORDS, win.data(), out_key);
+    return 0;
+}
+
 int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, int32_t* waves_per_group, int32_t* groups) {
     const int wpb = persist_shape_of(nwalkers, nsplits, num_cu);
     *waves_per_group = wpb;
@@ -3076,14 +3270,16 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     const int64_t total = nsteps * thin_by;
     // exact mode, general path: the plans of the whole call come from the host pipeline (generator / tokenizer /
     // finisher threads) instead of being made inline, one step at a time, by this thread
-    const bool piped = pipe_eligible(c) && c->target != EMX_TARGET_HOST && (c->pipe || total >= 2);
+    const bool devp = mtdev_eligible(c);
+    if (c->mtdev && !devp) mtdev_stop(c);
+    const bool piped = !devp && pipe_eligible(c) && c->target != EMX_TARGET_HOST && (c->pipe || total >= 2);
     if (c->pipe && !piped) pipe_stop(c);
     if (piped && !c->pipe) {
         const int rc = pipe_start(c);
         if (rc) return rc;
     }
     const int rc = run_impl(c, nsteps, thin_by, store);
-    if (rc && c->pipe) pipe_stop(c);          // after an error the generator stands after the last plan taken
+    if (rc && (c->pipe || c->mtdev)) pipe_stop(c);          // after an error the generator stands after the last plan taken
     return rc;
 }
 
@@ -3140,7 +3336,17 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
             ctr_synced = false;
             continue;
         }
-        if (persist_on && c->tune_persist) {
+        if (persist_on && c->tune_persist && c->rng_mode == EMX_RNG_MT19937) {
+            // exact mode, plans from the device producer: one move, a launch per produced batch
+            if (persist_move_ok(c, c->moves[0])) {
+                int64_t done = 0;
+                const int rc = run_persist(c, i, total, thin_by, store, &done);
+                if (rc) return rc;
+                i += done;
+                ctr_synced = false;
+                if (done > 0) continue;
+            }
+        } else if (persist_on && c->tune_persist) {
             // the next step's move decides (a mixture: runs of steps of one move the persistent kernel knows, the others one by one)
             if (!c->prepared.empty() && c->prepared.front().step != c->ph_step) drop_prepared(c);
             if (c->prepared.empty()) {

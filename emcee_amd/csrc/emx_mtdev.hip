@@ -1,0 +1,427 @@
+// Device-side exact-plan producer: the host driver of the kernels in emx_mtdev_kernels.hpp (design: emx_mtdev.hpp).
+#include "emx_mtdev.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+#include "emx_mtdev_kernels.hpp"
+#include "emx_mtjump.hpp"
+
+namespace emx {
+using namespace mtdev;
+
+namespace {
+inline uint32_t untemper32(uint32_t y) {
+    y ^= y >> 18;
+    y ^= (y << 15) & 0xefc60000u;
+    uint32_t t = y;
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    t = y ^ ((t << 7) & 0x9d2c5680u);
+    y = t;
+    y ^= y >> 11;
+    y ^= y >> 22;
+    return y;
+}
+}  // namespace
+
+struct MtDevProducer::Impl {
+    int device = 0;
+    int64_t N = 0;
+    int32_t D = 0, S = 2;
+    emx_move_desc mv{};
+    MT19937Legacy start;
+    std::vector<MtDevPlanCols> slots;
+    uint32_t* status = nullptr;
+    // streams: generation | tokenizer | finisher
+    hipStream_t s_gen = nullptr, s_tok = nullptr, s_fin = nullptr;
+    // the stream ring
+    uint32_t* stream = nullptr;
+    uint64_t capw = 0;                 // words, a power of two
+    uint32_t *base_key = nullptr, *xwin = nullptr, *partial = nullptr, *polys = nullptr;
+    uint64_t gen_words = 0;            // words [0, gen_words) are generated (enqueued on s_gen)
+    int64_t rounds = 0;
+    hipEvent_t ev_gen = nullptr;       // after the latest round
+    // tokenizer state
+    unsigned long long* d_pos = nullptr;
+    unsigned* d_err = nullptr;
+    unsigned long long* d_nwin = nullptr;
+    uint32_t *J[2] = {nullptr, nullptr}, *rint[2] = {nullptr, nullptr};        // per batch parity
+    unsigned long long *tokpos[2] = {nullptr, nullptr}, *step_end[MTDEV_NBUF] = {};
+    unsigned long long* h_end = nullptr;       // pinned [NBUF][BATCH]: step end positions of the batch in that buffer
+    uint32_t* scratch = nullptr;
+    uint32_t* blk_words = nullptr;             // [NBUF][BATCH][624]: the (tempered) block every step of the batch ends in: finish() needs no ring
+    // per batch bookkeeping
+    struct Batch {
+        hipEvent_t tok = nullptr, fin = nullptr, pos = nullptr, released = nullptr;
+        bool has_released = false;
+    } bt[MTDEV_NBUF];
+    int64_t enq = 0;                   // batches enqueued so far
+    int64_t known = -1;                // last batch whose end position the host has read
+    uint64_t known_pos = 0;            // ... that position (batch -1: the start position)
+    uint64_t wmax = 0, wmin = 0;       // words per step: bounds
+    uint64_t slack = 0;                // the tokenizer asks for whole windows: words it may look at beyond what it consumes
+};
+
+bool MtDevProducer::supports(int64_t N, int32_t nmoves, const emx_move_desc* moves) {
+    if (nmoves != 1 || moves[0].kind != EMX_MOVE_STRETCH) return false;
+    if (moves[0].nsplits < 2 || moves[0].nsplits > 64) return false;
+    return N >= 2 * moves[0].nsplits && N < ((int64_t)1 << 30);
+}
+
+#define MTD_HIP(expr)                                                                                                 \
+    do {                                                                                                              \
+        hipError_t e_ = (expr);                                                                                       \
+        if (e_ != hipSuccess) {                                                                                       \
+            char b_[384];                                                                                             \
+            snprintf(b_, sizeof(b_), "mtdev: %s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            err_ = b_;                                                                                                \
+            return -2;                                                                                                \
+        }                                                                                                             \
+    } while (0)
+
+MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, int32_t D, const emx_move_desc& mv,
+                             const MtDevPlanCols* slots, uint32_t* status_dev) {
+    im_ = new Impl();
+    Impl& m = *im_;
+    m.device = device;
+    m.N = N;
+    m.D = D;
+    m.S = mv.nsplits;
+    m.mv = mv;
+    m.start = start;
+    m.slots.assign(slots, slots + MTDEV_NBUF * MTDEV_BATCH);
+    m.status = status_dev;
+    auto init = [&]() -> int {
+        MTD_HIP(hipSetDevice(device));
+        // words per step: ensemble.py:406 (2) + shuffle + per split 2 ns + randint + 2 ns
+        uint64_t fixed = 2, rmax = 0, rmin = 0;
+        for (int s = 0; s < m.S; ++s) {
+            const uint64_t ns = (uint64_t)((N - s + m.S - 1) / m.S), nc = (uint64_t)N - ns;
+            fixed += 4 * ns;
+            if (nc <= 1) continue;
+            if ((nc & (nc - 1)) == 0) {
+                rmax += ns;
+                rmin += ns;
+            } else {
+                rmax += 2 * ns + 4096;          // accept probability > 1/2: twice the mean is > 40 sigma out at these sizes
+                rmin += ns;
+            }
+        }
+        const uint64_t sh_max = mv.randomize_split ? 2 * (uint64_t)N + 4096 : 0, sh_min = mv.randomize_split ? (uint64_t)N - 1 : 0;
+        m.wmax = fixed + rmax + sh_max;
+        m.wmin = fixed + rmin + sh_min;
+        m.slack = (uint64_t)TOK_T * TOK_WPT + MT_N;
+        // ring: the batches in flight (the host runs at most NBUF + 1 batches ahead of the tokenizer's known position), a round
+        // ahead, and the slack -- rounded up to a power of two
+        uint64_t need = (uint64_t)(MTDEV_NBUF + 2) * MTDEV_BATCH * m.wmax + 6 * SEG_WORDS + 2 * m.slack;
+        uint64_t cap = (uint64_t)1 << 22;
+        while (cap < need) cap <<= 1;
+        m.capw = cap;
+        MTD_HIP(hipStreamCreateWithFlags(&m.s_gen, hipStreamNonBlocking));
+        MTD_HIP(hipStreamCreateWithFlags(&m.s_tok, hipStreamNonBlocking));
+        MTD_HIP(hipStreamCreateWithFlags(&m.s_fin, hipStreamNonBlocking));
+        MTD_HIP(hipMalloc((void**)&m.stream, cap * 4));
+        MTD_HIP(hipMalloc((void**)&m.base_key, MT_N * 4));
+        MTD_HIP(hipMalloc((void**)&m.xwin, (size_t)WIN_BLOCKS * MT_N * 4));
+        MTD_HIP(hipMalloc((void**)&m.partial, (size_t)(PMAX - 1) * JUMP_SPLIT * MT_N * 4));
+        MTD_HIP(hipMalloc((void**)&m.polys, (size_t)(PMAX - 1) * MT_N * 4));
+        MTD_HIP(hipMalloc((void**)&m.d_pos, 8));
+        MTD_HIP(hipMalloc((void**)&m.d_err, 4));
+        MTD_HIP(hipMalloc((void**)&m.d_nwin, 8));
+        for (int k = 0; k < 2; ++k) {
+            MTD_HIP(hipMalloc((void**)&m.J[k], (size_t)MTDEV_BATCH * N * 4));
+            MTD_HIP(hipMalloc((void**)&m.rint[k], (size_t)MTDEV_BATCH * N * 4));
+            MTD_HIP(hipMalloc((void**)&m.tokpos[k], (size_t)MTDEV_BATCH * m.S * 3 * 8));
+        }
+        for (int k = 0; k < MTDEV_NBUF; ++k) {
+            MTD_HIP(hipMalloc((void**)&m.step_end[k], (size_t)MTDEV_BATCH * 8));
+            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].tok, hipEventDisableTiming));
+            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].fin, hipEventDisableTiming));
+            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].pos, hipEventDisableTiming));
+            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].released, hipEventDisableTiming));
+        }
+        MTD_HIP(hipEventCreateWithFlags(&m.ev_gen, hipEventDisableTiming));
+        MTD_HIP(hipHostMalloc((void**)&m.h_end, (size_t)MTDEV_NBUF * MTDEV_BATCH * 8, hipHostMallocDefault));
+        MTD_HIP(hipMalloc((void**)&m.scratch, (size_t)MTDEV_BATCH * 5 * N * 4));
+        MTD_HIP(hipMalloc((void**)&m.blk_words, (size_t)MTDEV_NBUF * MTDEV_BATCH * MT_N * 4));
+        // the jump polynomials t^(k SEG_WORDS) mod phi, k = 1 .. PMAX - 1 (once per process; ~70 ms)
+        const auto t0 = std::chrono::steady_clock::now();
+        const uint32_t* g = nullptr;
+        if (!mt_jump_polys(SEG_WORDS, PMAX - 1, &g)) {
+            err_ = "mtdev: the MT19937 jump polynomials could not be computed";
+            return -1;
+        }
+        st_.poly_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        MTD_HIP(hipMemcpy(m.polys, g, (size_t)(PMAX - 1) * MT_N * 4, hipMemcpyHostToDevice));
+        MTD_HIP(hipMemcpy(m.base_key, start.key, MT_N * 4, hipMemcpyHostToDevice));
+        const unsigned long long p0 = (unsigned long long)start.pos;
+        MTD_HIP(hipMemcpy(m.d_pos, &p0, 8, hipMemcpyHostToDevice));
+        MTD_HIP(hipMemset(m.d_err, 0, 4));
+        MTD_HIP(hipMemset(m.d_nwin, 0, 8));
+        m.known = -1;
+        m.known_pos = p0;
+        m.gen_words = 0;
+        return 0;
+    };
+    if (init() != 0 && err_.empty()) err_ = "mtdev: initialisation failed";
+}
+
+MtDevProducer::~MtDevProducer() {
+    if (!im_) return;
+    Impl& m = *im_;
+    hipSetDevice(m.device);
+    for (hipStream_t s : {m.s_gen, m.s_tok, m.s_fin})
+        if (s) {
+            hipStreamSynchronize(s);
+            hipStreamDestroy(s);
+        }
+    void* bufs[] = {m.stream, m.base_key, m.xwin, m.partial, m.polys, m.d_pos, m.d_err, m.d_nwin, m.J[0], m.J[1], m.rint[0], m.rint[1],
+                    m.tokpos[0], m.tokpos[1], m.scratch, m.blk_words};
+    for (void* p : bufs)
+        if (p) hipFree(p);
+    for (int k = 0; k < MTDEV_NBUF; ++k) {
+        if (m.step_end[k]) hipFree(m.step_end[k]);
+        for (hipEvent_t e : {m.bt[k].tok, m.bt[k].fin, m.bt[k].pos, m.bt[k].released})
+            if (e) hipEventDestroy(e);
+    }
+    if (m.ev_gen) hipEventDestroy(m.ev_gen);
+    if (m.h_end) hipHostFree(m.h_end);
+    delete im_;
+}
+
+int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) {
+    Impl& m = *im_;
+    if (!err_.empty()) return -1;
+    MTD_HIP(hipSetDevice(m.device));
+    lookahead = std::max(0, std::min(lookahead, MTDEV_NBUF - 2));
+    while (m.enq <= b + lookahead) {
+        const int64_t nbq = m.enq;
+        const int buf = (int)(nbq % MTDEV_NBUF), par = (int)(nbq & 1);
+        // a batch further ahead than the consumer has released slots for is not started (the asked-for batch always can be:
+        // the caller released batch b - NBUF before asking for b)
+        if (nbq >= MTDEV_NBUF && !m.bt[buf].has_released) {
+            if (nbq <= b) {
+                err_ = "mtdev: batch asked for before the batch four earlier was released";
+                return -1;
+            }
+            break;
+        }
+        // exact end positions of finished batches tighten the bounds; the host stays at most NBUF batches ahead of what it knows
+        // (the pinned slot of batch nbq - NBUF is about to be rewritten, and the bounds below must stay inside the ring)
+        while (m.known + 1 < nbq) {
+            hipEvent_t pe = m.bt[(m.known + 1) % MTDEV_NBUF].pos;
+            if (m.known + 1 <= nbq - MTDEV_NBUF) {
+                MTD_HIP(hipEventSynchronize(pe));
+            } else if (hipEventQuery(pe) != hipSuccess) {
+                break;
+            }
+            ++m.known;
+            m.known_pos = m.h_end[(size_t)(m.known % MTDEV_NBUF) * MTDEV_BATCH + MTDEV_BATCH - 1];
+        }
+        // upper bound of where batch nbq ends (+ the window slack): that much of the stream must exist before its tokenizer starts
+        const uint64_t hi_end = m.known_pos + (uint64_t)(nbq - m.known) * MTDEV_BATCH * m.wmax + m.slack;
+        while (m.gen_words < hi_end) {
+            // ---- one round: window -> jumps -> P segments ----
+            const uint64_t want = hi_end - m.gen_words;
+            int P = (int)std::min<uint64_t>(PMAX, (want + SEG_WORDS - 1) / SEG_WORDS + 1);
+            P = std::max(P, 2);
+            // The ring positions this round overwrites: everything below gen_words + round - capw.  (a) Batches already enqueued
+            // may still be reading there (their tokenizer, their finisher): the round waits for the finisher of every one of them
+            // that could start that low.  (b) Words not yet consumed -- everything from the end of the last enqueued batch on --
+            // must not be there at all: checked against the LOWER bound of that end, with the exact position fetched if the bound
+            // is not good enough.
+            const uint64_t round_words = (m.rounds == 0 ? MT_N : 0) + (uint64_t)P * SEG_WORDS;
+            if (m.gen_words + round_words > m.capw) {
+                const uint64_t dead_below = m.gen_words + round_words - m.capw;
+                for (;;) {
+                    const uint64_t lo_next = m.known_pos + (uint64_t)(nbq - 1 - m.known) * MTDEV_BATCH * m.wmin;     // end of batch nbq - 1
+                    if (lo_next >= dead_below + MT_N) break;
+                    if (m.known + 1 >= nbq) {
+                        err_ = "mtdev: the stream ring is too small for this configuration";
+                        return -1;
+                    }
+                    MTD_HIP(hipEventSynchronize(m.bt[(m.known + 1) % MTDEV_NBUF].pos));
+                    ++m.known;
+                    m.known_pos = m.h_end[(size_t)(m.known % MTDEV_NBUF) * MTDEV_BATCH + MTDEV_BATCH - 1];
+                }
+                for (int64_t q = std::max<int64_t>(0, m.enq - MTDEV_NBUF); q < m.enq; ++q) {
+                    const bool maybe_live = q <= m.known + 1 || m.known_pos + (uint64_t)(q - 1 - m.known) * MTDEV_BATCH * m.wmin < dead_below + MT_N;
+                    if (maybe_live) MTD_HIP(hipStreamWaitEvent(m.s_gen, m.bt[q % MTDEV_NBUF].fin, 0));
+                }
+            }
+            const bool first = m.rounds == 0;
+            const uint64_t first_word = first ? MT_N : m.gen_words;       // (the base block of round 0 is words [0, 624))
+            hipLaunchKernelGGL(k_mt_window, dim3(1), dim3(256), 0, m.s_gen, m.base_key, m.xwin, m.stream, (unsigned long long)(m.capw - 1),
+                               0ull, first ? 1 : 0);
+            hipLaunchKernelGGL(k_mt_jump, dim3(JUMP_SPLIT, P - 1), dim3(640), 0, m.s_gen, m.polys, m.xwin, m.partial);
+            GenArgs ga{};
+            ga.xwin = m.xwin;
+            ga.partial = m.partial;
+            ga.stream = m.stream;
+            ga.smask = m.capw - 1;
+            ga.first_word = first_word;
+            ga.next_base = m.base_key;
+            ga.last_seg = P - 1;
+            ga.blocks_per_seg = SEG_BLOCKS;
+            hipLaunchKernelGGL(k_mt_gen, dim3(P), dim3(256), 0, m.s_gen, ga);
+            MTD_HIP(hipGetLastError());
+            MTD_HIP(hipEventRecord(m.ev_gen, m.s_gen));
+            m.gen_words = first_word + (uint64_t)P * SEG_WORDS;
+            ++m.rounds;
+            st_.rounds++;
+            st_.segments += P;
+        }
+        // ---- tokenizer of batch nbq: after the stream it needs, and after the finisher that last read its J / rint / tokpos ----
+        MTD_HIP(hipStreamWaitEvent(m.s_tok, m.ev_gen, 0));
+        if (nbq >= 2) MTD_HIP(hipStreamWaitEvent(m.s_tok, m.bt[(nbq - 2) % MTDEV_NBUF].fin, 0));
+        TokArgs ta{};
+        ta.stream = m.stream;
+        ta.smask = m.capw - 1;
+        ta.pos = m.d_pos;
+        ta.avail_end = m.gen_words;
+        ta.status = m.status;
+        ta.err = m.d_err;
+        ta.J = m.J[par];
+        ta.rint = m.rint[par];
+        ta.tokpos = m.tokpos[par];
+        ta.step_end = m.step_end[buf];
+        ta.nwindows = m.d_nwin;
+        ta.N = (int32_t)m.N;
+        ta.S = m.S;
+        ta.nb = MTDEV_BATCH;
+        ta.randomize = m.mv.randomize_split ? 1 : 0;
+        hipLaunchKernelGGL(k_mt_tok, dim3(1), dim3(TOK_T), 0, m.s_tok, ta);
+        MTD_HIP(hipGetLastError());
+        MTD_HIP(hipEventRecord(m.bt[buf].tok, m.s_tok));
+        MTD_HIP(hipMemcpyAsync(m.h_end + (size_t)buf * MTDEV_BATCH, m.step_end[buf], (size_t)MTDEV_BATCH * 8, hipMemcpyDeviceToHost, m.s_tok));
+        MTD_HIP(hipEventRecord(m.bt[buf].pos, m.s_tok));
+        // ---- finisher: after the tokenizer, and after the consumer's last read of the plan slots it rewrites ----
+        MTD_HIP(hipStreamWaitEvent(m.s_fin, m.bt[buf].tok, 0));
+        if (m.bt[buf].has_released) MTD_HIP(hipStreamWaitEvent(m.s_fin, m.bt[buf].released, 0));
+        m.bt[buf].has_released = false;
+        FinArgs fa{};
+        fa.stream = m.stream;
+        fa.smask = m.capw - 1;
+        fa.J = m.J[par];
+        fa.rint = m.rint[par];
+        fa.tokpos = m.tokpos[par];
+        fa.err = m.d_err;
+        fa.scratch = m.scratch;
+        for (int k = 0; k < MTDEV_BATCH; ++k) {
+            const MtDevPlanCols& pc = m.slots[(size_t)buf * MTDEV_BATCH + k];
+            fa.order[k] = pc.order;
+            fa.p0[k] = pc.p0;
+            fa.s0[k] = pc.s0;
+            fa.uacc[k] = pc.uacc;
+            fa.logu[k] = pc.logu;
+            fa.fac[k] = pc.fac;
+        }
+        fa.step_end = m.step_end[buf];
+        fa.blk_words = m.blk_words + (size_t)buf * MTDEV_BATCH * MT_N;
+        fa.a = m.mv.a;
+        fa.N = (int32_t)m.N;
+        fa.D = m.D;
+        fa.S = m.S;
+        fa.randomize = m.mv.randomize_split ? 1 : 0;
+        hipLaunchKernelGGL(k_mt_fin, dim3(MTDEV_BATCH), dim3(FIN_T), 0, m.s_fin, fa);
+        MTD_HIP(hipGetLastError());
+        MTD_HIP(hipEventRecord(m.bt[buf].fin, m.s_fin));
+        ++m.enq;
+        st_.batches++;
+    }
+    if (m.enq <= b) {
+        err_ = "mtdev: batch not produced";
+        return -1;
+    }
+    MTD_HIP(hipStreamWaitEvent(consumer, m.bt[b % MTDEV_NBUF].fin, 0));
+    return 0;
+}
+
+int MtDevProducer::release_batch(int64_t b, hipStream_t consumer) {
+    Impl& m = *im_;
+    MTD_HIP(hipSetDevice(m.device));
+    const int buf = (int)(b % MTDEV_NBUF);
+    MTD_HIP(hipEventRecord(m.bt[buf].released, consumer));
+    m.bt[buf].has_released = true;
+    return 0;
+}
+
+int MtDevProducer::finish(int64_t steps_taken, MT19937Legacy& out) {
+    Impl& m = *im_;
+    MTD_HIP(hipSetDevice(m.device));
+    MTD_HIP(hipStreamSynchronize(m.s_gen));
+    MTD_HIP(hipStreamSynchronize(m.s_tok));
+    MTD_HIP(hipStreamSynchronize(m.s_fin));
+    {
+        unsigned long long nw = 0;
+        if (hipMemcpy(&nw, m.d_nwin, 8, hipMemcpyDeviceToHost) == hipSuccess) st_.windows = (int64_t)nw;
+    }
+    out = m.start;
+    if (steps_taken <= 0) return 0;
+    unsigned e = 0;
+    MTD_HIP(hipMemcpy(&e, m.d_err, 4, hipMemcpyDeviceToHost));
+    if (e) {
+        err_ = "mtdev: the generated stream ran out under the tokenizer (status bit 2): the run is void";
+        return -9;
+    }
+    const int64_t bq = (steps_taken - 1) / MTDEV_BATCH;
+    if (bq >= m.enq || bq < m.enq - MTDEV_NBUF) {
+        err_ = "mtdev: the batch of the last step taken is no longer (or not yet) in the buffers";
+        return -1;
+    }
+    const uint64_t a = m.h_end[(size_t)(bq % MTDEV_NBUF) * MTDEV_BATCH + (size_t)((steps_taken - 1) % MTDEV_BATCH)];
+    // NumPy get_state(): the key of the block the position stands in; a block consumed to its end reports pos = 624
+    const uint64_t blk = a > 0 ? (a - 1) / MT_N : 0;
+    uint32_t words[MT_N], key[MT_N];
+    MTD_HIP(hipMemcpy(words, m.blk_words + ((size_t)(bq % MTDEV_NBUF) * MTDEV_BATCH + (size_t)((steps_taken - 1) % MTDEV_BATCH)) * MT_N, MT_N * 4,
+                      hipMemcpyDeviceToHost));
+    for (int i = 0; i < MT_N; ++i) key[i] = untemper32(words[i]);          // tempering is a bijection: the state words behind the outputs
+    out.set_state(key, (int)(a - blk * MT_N), m.start.has_gauss, m.start.gauss);
+    return 0;
+}
+
+int MtDevProducer::debug_stream(uint64_t first_word, int64_t n, uint32_t* out) {
+    Impl& m = *im_;
+    MTD_HIP(hipSetDevice(m.device));
+    MTD_HIP(hipDeviceSynchronize());
+    for (int64_t k = 0; k < n;) {
+        const uint64_t off = (first_word + (uint64_t)k) & (m.capw - 1);
+        const int64_t take = (int64_t)std::min<uint64_t>((uint64_t)(n - k), m.capw - off);
+        MTD_HIP(hipMemcpy(out + k, m.stream + off, (size_t)take * 4, hipMemcpyDeviceToHost));
+        k += take;
+    }
+    return 0;
+}
+
+int MtDevProducer::debug_targets(int64_t step, uint32_t* out) {
+    Impl& m = *im_;
+    MTD_HIP(hipSetDevice(m.device));
+    MTD_HIP(hipDeviceSynchronize());
+    const int64_t bq = step / MTDEV_BATCH;
+    if (bq >= m.enq || bq < m.enq - 2) {
+        err_ = "mtdev: that step's targets are not in the buffers";
+        return -1;
+    }
+    MTD_HIP(hipMemcpy(out, m.J[bq & 1] + (size_t)(step % MTDEV_BATCH) * m.N, (size_t)m.N * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int MtDevProducer::debug_positions(int64_t step, uint64_t* tokpos, uint64_t* end) {
+    Impl& m = *im_;
+    MTD_HIP(hipSetDevice(m.device));
+    MTD_HIP(hipDeviceSynchronize());
+    const int64_t bq = step / MTDEV_BATCH;
+    if (bq >= m.enq || bq < m.enq - 2) {
+        err_ = "mtdev: that step's positions are not in the buffers";
+        return -1;
+    }
+    MTD_HIP(hipMemcpy(tokpos, m.tokpos[bq & 1] + (size_t)(step % MTDEV_BATCH) * m.S * 3, (size_t)m.S * 3 * 8, hipMemcpyDeviceToHost));
+    MTD_HIP(hipMemcpy(end, m.step_end[bq % MTDEV_NBUF] + (step % MTDEV_BATCH), 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // namespace emx

@@ -568,6 +568,24 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_persist_info(self.ctx, out))
         return {"qualifies": bool(out[0]), "launches": int(out[1]), "halfsteps": int(out[2]), "recovered": int(out[3])}
 
+    def mtdev_info(self):
+        """exact-mode plans made on the device (include/emx.h emx_mtdev_info)"""
+        out = (C.c_int64 * 8)()
+        self._ck(self.lib.emx_mtdev_info(self.ctx, out))
+        return {"qualifies": bool(out[0]), "alive": bool(out[1]), "steps": int(out[2]), "rounds": int(out[3]), "segments": int(out[4]),
+                "batches": int(out[5]), "windows": int(out[6]), "poly_us": int(out[7])}
+
+    def mtdev_debug(self, what, arg, n=0):
+        """tests: stream words / Fisher-Yates targets / positions of the live device producer (include/emx.h emx_mtdev_debug)"""
+        if what == 0:
+            out = np.empty(int(n), dtype=np.uint32)
+        elif what == 1:
+            out = np.empty(self.nwalkers, dtype=np.uint32)
+        else:
+            out = np.empty(int(n), dtype=np.uint64)
+        self._ck(self.lib.emx_mtdev_debug(self.ctx, int(what), int(arg), out.ctypes.data, out.size))
+        return out
+
     def comm_count(self):
         """ranks of the library's RCCL communicator (ncclCommCount); 0 without one"""
         n = C.c_int32(0)
