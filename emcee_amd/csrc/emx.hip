@@ -358,6 +358,7 @@ struct emx_ctx {
     MtDevProducer* mtdev = nullptr;
     int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead)
+    int64_t tune_mt_lookahead = 2;       // batches the device producer is asked to run ahead of the consumer (0 .. 2)
     int64_t mtdev_steps_total = 0, mtdev_starts = 0;
     bool mtdev_defer_release = false;
     int64_t mtdev_release_pending = -1;
@@ -1308,6 +1309,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_mt_device = v ? 1 : 0;
         return 0;
     }
+    if (!strcmp(key, "mt_device_lookahead")) {       // batches produced ahead of the one asked for (tests: 0 keeps batch 0's raw pieces readable)
+        c->tune_mt_lookahead = v < 0 ? 0 : (v > 2 ? 2 : v);
+        return 0;
+    }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
         c->tune_persist = v ? 1 : 0;
         return 0;
@@ -2013,7 +2018,7 @@ static int mtdev_take(emx_ctx* c) {
     auto& cur = c->cur;
     const int64_t n = c->mtdev_taken;
     if (n % MTDEV_BATCH == 0) {
-        const int rc = c->mtdev->ensure_batch(n / MTDEV_BATCH, c->stream);
+        const int rc = c->mtdev->ensure_batch(n / MTDEV_BATCH, c->stream, (int)c->tune_mt_lookahead);
         if (rc) FAIL(c, rc, "%s", c->mtdev->error().c_str());
     }
     const emx_move_desc& mv = c->moves[0];

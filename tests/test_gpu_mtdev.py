@@ -88,6 +88,7 @@ def test_stream_positions_and_targets_equal_the_serial_walk(N, S, randomize, see
     rs.random_sample(seed * 100 + 7)                      # an arbitrary position inside a block
     state = rs.get_state()
     ens = make(N, 4, md, state)
+    ens.set_tuning("mt_device_lookahead", 0)              # batch 0's raw pieces (targets, positions) stay in their buffers
     assert ens.mtdev_info()["qualifies"]
     k, S_ = ens.step_begin(store=False)                   # starts the producer: the first batches are enqueued
     assert (k, S_) == (0, S) and ens.mtdev_info()["alive"]

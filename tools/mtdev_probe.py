@@ -1,11 +1,12 @@
 """Exact mode at C2 with the plans made on the device vs by the host pipeline: us/step, where the producer's time goes.
-  usage: python tools/mtdev_probe.py [nwalkers] [ndim] [steps]"""
+  usage: python tools/mtdev_probe.py [nwalkers] [ndim] [steps] [modes, e.g. 1,0,1]"""
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from emcee_amd import _lib  # noqa: E402
 from emcee_amd.device import DeviceEnsemble  # noqa: E402
@@ -15,7 +16,8 @@ D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 key = "c2" if D == 64 else "c3"
 wl = bench.Workload(key, N)
-for dev in (1, 0, 1):
+MODES = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 0, 1]
+for dev in MODES:
     e = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(e, "mt19937")
     e.set_tuning("mt_device", dev)
