@@ -357,8 +357,10 @@ struct emx_ctx {
     // exact-mode plans made on the device (emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica
     MtDevProducer* mtdev = nullptr;
     int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
-    int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead)
+    int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
+    int64_t tune_mt_device_min = 131072; // (measured: the host pipeline is faster below ~10^5 walkers, profiles/r04/mtdev_sizes.txt)
     int64_t tune_mt_lookahead = 2;       // batches the device producer is asked to run ahead of the consumer (0 .. 2)
+    int64_t tune_mt_tok_wshift = 12, tune_mt_tok_tail = 2048;      // the device tokenizer's window rule (emx_mtdev_kernels.hpp)
     int64_t mtdev_steps_total = 0, mtdev_starts = 0;
     bool mtdev_defer_release = false;
     int64_t mtdev_release_pending = -1;
@@ -1305,8 +1307,18 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "mt_device")) {         // 0: exact-mode plans never from the device producer (emx_mtdev.hpp)
-        if (!v) pipe_stop(c);
-        c->tune_mt_device = v ? 1 : 0;
+        pipe_stop(c);
+        c->tune_mt_device = v < 0 ? 0 : (v > 2 ? 2 : v);
+        return 0;
+    }
+    if (!strcmp(key, "mt_device_min_walkers")) {
+        pipe_stop(c);
+        c->tune_mt_device_min = v < 8192 ? 8192 : v;
+        return 0;
+    }
+    if (!strcmp(key, "mt_tok_wshift") || !strcmp(key, "mt_tok_tail")) {       // the device tokenizer's window rule (takes effect when a producer starts)
+        pipe_stop(c);
+        (key[7] == 'w' ? c->tune_mt_tok_wshift : c->tune_mt_tok_tail) = v;
         return 0;
     }
     if (!strcmp(key, "mt_device_lookahead")) {       // batches produced ahead of the one asked for (tests: 0 keeps batch 0's raw pieces readable)
@@ -1959,7 +1971,7 @@ static void pipe_stop(emx_ctx* c) {
 // depend on the walkers), retired -- the context's generator set to the state after the last step TAKEN -- by whatever retires
 // the pipeline (pipe_stop calls mtdev_stop).
 static bool mtdev_eligible(const emx_ctx* c) {
-    return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_device != 0 && c->N >= 8192 && c->world == 1 && !c->comm && !c->sendbuf &&
+    return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_device != 0 && c->N >= (c->tune_mt_device == 2 ? 8192 : c->tune_mt_device_min) && c->world == 1 && !c->comm && !c->sendbuf &&
            !c->peers_ready && !small_eligible(c) && MtDevProducer::supports(c->N, (int32_t)c->moves.size(), c->moves.data());
 }
 
@@ -1992,6 +2004,7 @@ static int mtdev_start(emx_ctx* c) {
         c->mtdev = nullptr;
         return -2;
     }
+    c->mtdev->set_window_rule((int)c->tune_mt_tok_wshift, (int)c->tune_mt_tok_tail);
     c->mtdev_taken = 0;
     c->mtdev_starts++;
     return 0;
@@ -2886,9 +2899,10 @@ static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
 
 static bool persist_wanted(const emx_ctx* c) {
     if (!c->tune_persist) return false;
-    // Philox plans, or the reference's own stream with its plans made on the device (emx_mtdev.hpp): either way a batch of 16 steps'
-    // plans is in HBM before the launch that takes them
-    if (!(c->rng_mode == EMX_RNG_PHILOX || mtdev_eligible(c)) || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
+    // Philox plans only.  (The reference's own stream with its plans made on the device -- emx_mtdev.hpp -- has them in HBM in time
+    // too, but its tokenizer is one 1024-thread, 107 KB workgroup that runs all the time: a persistent grid that holds every CU
+    // leaves it none, and the two took turns -- k_persist 314 -> 1 150 us a launch, profiles/r04/mtdev_timeline.txt.)
+    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
     if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || dense_is_wide(c)) return false;
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
     if (c->N < c->tune_persist_min_walkers) return false;
@@ -3217,6 +3231,17 @@ int emx_mtdev_info(emx_ctx* c, int64_t out[8]) {
     out[5] = st.batches;
     out[6] = st.windows;
     out[7] = (int64_t)(st.poly_ms * 1e3);
+    return 0;
+}
+
+int emx_mtdev_tok_stats(emx_ctx* c, int64_t out[8]) {
+    if (c->mtdev) c->mtdev->refresh_stats();
+    const MtDevStats& st = c->mtdev ? c->mtdev->stats() : c->mtdev_stats_last;
+    out[0] = st.windows;
+    out[1] = st.tok_rounds;
+    out[2] = st.tail_groups;
+    out[3] = st.tail_rounds;
+    for (int k = 0; k < 4; ++k) out[4 + k] = st.tok_ticks[k];
     return 0;
 }
 

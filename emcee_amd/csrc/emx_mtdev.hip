@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstring>
 
-#include "emx_mtdev_kernels.hpp"
+#include "emx_mtdev_kernels.hpp"       // (-DEMX_TOK_PROFILE: walk / scan ticks of the tokenizer's first wave on stderr)
 #include "emx_mtjump.hpp"
 
 namespace emx {
@@ -50,6 +50,11 @@ struct MtDevProducer::Impl {
     unsigned* d_err = nullptr;
     unsigned long long* d_nwin = nullptr;
     uint32_t *J[2] = {nullptr, nullptr}, *rint[2] = {nullptr, nullptr};        // per batch parity
+    WalkRec* recs[2] = {nullptr, nullptr};     // [BATCH][maxrec] walk records of the tokenizer (per batch parity)
+    uint32_t* nrec[2] = {nullptr, nullptr};    // [BATCH]
+    int32_t maxrec = 0, nchunk = 0;
+    int32_t wshift = 12, tail = 2048;          // the tokenizer's window rule (emx_mtdev_kernels.hpp)
+    uint32_t *fin_partial = nullptr, *fin_hist = nullptr;
     unsigned long long *tokpos[2] = {nullptr, nullptr}, *step_end[MTDEV_NBUF] = {};
     unsigned long long* h_end = nullptr;       // pinned [NBUF][BATCH]: step end positions of the batch in that buffer
     uint32_t* scratch = nullptr;
@@ -68,8 +73,8 @@ struct MtDevProducer::Impl {
 
 bool MtDevProducer::supports(int64_t N, int32_t nmoves, const emx_move_desc* moves) {
     if (nmoves != 1 || moves[0].kind != EMX_MOVE_STRETCH) return false;
-    if (moves[0].nsplits < 2 || moves[0].nsplits > 64) return false;
-    return N >= 2 * moves[0].nsplits && N < ((int64_t)1 << 30);
+    if (moves[0].nsplits < 2 || moves[0].nsplits > FIN_MAX_S) return false;
+    return N >= 2 * moves[0].nsplits && N <= ((int64_t)1 << 24);
 }
 
 #define MTD_HIP(expr)                                                                                                 \
@@ -98,7 +103,7 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
     auto init = [&]() -> int {
         MTD_HIP(hipSetDevice(device));
         // words per step: ensemble.py:406 (2) + shuffle + per split 2 ns + randint + 2 ns
-        uint64_t fixed = 2, rmax = 0, rmin = 0;
+        uint64_t fixed = 2, rmax = 0, rmin = 0, nrecmax = 0;
         for (int s = 0; s < m.S; ++s) {
             const uint64_t ns = (uint64_t)((N - s + m.S - 1) / m.S), nc = (uint64_t)N - ns;
             fixed += 4 * ns;
@@ -109,21 +114,31 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
             } else {
                 rmax += 2 * ns + 4096;          // accept probability > 1/2: twice the mean is > 40 sigma out at these sizes
                 rmin += ns;
+                nrecmax += (2 * ns + 4096) / TOK_W_MAX + 2;
             }
         }
         const uint64_t sh_max = mv.randomize_split ? 2 * (uint64_t)N + 4096 : 0, sh_min = mv.randomize_split ? (uint64_t)N - 1 : 0;
         m.wmax = fixed + rmax + sh_max;
         m.wmin = fixed + rmin + sh_min;
-        m.slack = (uint64_t)TOK_T * TOK_WPT + MT_N;
+        nrecmax += sh_max / TOK_W_MAX + 256;          // (the narrow windows of the low mask bands: a handful per band)
+        m.maxrec = (int32_t)nrecmax;
+        m.nchunk = (int32_t)((N + FIN_CHUNK - 1) / FIN_CHUNK);
+        m.slack = 2 * (uint64_t)TOK_W_MAX + MT_N;        // the tokenizer decides whole windows (and looks one window further ahead)
         // ring: the batches in flight (the host runs at most NBUF + 1 batches ahead of the tokenizer's known position), a round
         // ahead, and the slack -- rounded up to a power of two
         uint64_t need = (uint64_t)(MTDEV_NBUF + 2) * MTDEV_BATCH * m.wmax + 6 * SEG_WORDS + 2 * m.slack;
         uint64_t cap = (uint64_t)1 << 22;
         while (cap < need) cap <<= 1;
         m.capw = cap;
-        MTD_HIP(hipStreamCreateWithFlags(&m.s_gen, hipStreamNonBlocking));
-        MTD_HIP(hipStreamCreateWithFlags(&m.s_tok, hipStreamNonBlocking));
-        MTD_HIP(hipStreamCreateWithFlags(&m.s_fin, hipStreamNonBlocking));
+        // Streams share the runtime's few hardware queues, and kernels of two streams on one queue run in submission order: with
+        // default priorities the tokenizer and the finisher landed on ONE queue and took turns (profiles/r04/mtdev_timeline.txt).
+        // Queues are pooled per priority: the tokenizer -- the serial stage -- gets the high-priority pool to itself, the
+        // generator and the finisher the low one; the consumer's streams keep the default pool.
+        int prio_lo = 0, prio_hi = 0;
+        MTD_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        MTD_HIP(hipStreamCreateWithPriority(&m.s_gen, hipStreamNonBlocking, prio_lo));
+        MTD_HIP(hipStreamCreateWithPriority(&m.s_tok, hipStreamNonBlocking, prio_hi));
+        MTD_HIP(hipStreamCreateWithPriority(&m.s_fin, hipStreamNonBlocking, prio_lo));
         MTD_HIP(hipMalloc((void**)&m.stream, cap * 4));
         MTD_HIP(hipMalloc((void**)&m.base_key, MT_N * 4));
         MTD_HIP(hipMalloc((void**)&m.xwin, (size_t)WIN_BLOCKS * MT_N * 4));
@@ -131,12 +146,17 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         MTD_HIP(hipMalloc((void**)&m.polys, (size_t)(PMAX - 1) * MT_N * 4));
         MTD_HIP(hipMalloc((void**)&m.d_pos, 8));
         MTD_HIP(hipMalloc((void**)&m.d_err, 4));
-        MTD_HIP(hipMalloc((void**)&m.d_nwin, 8));
+        MTD_HIP(hipMalloc((void**)&m.d_nwin, 96));
         for (int k = 0; k < 2; ++k) {
             MTD_HIP(hipMalloc((void**)&m.J[k], (size_t)MTDEV_BATCH * N * 4));
             MTD_HIP(hipMalloc((void**)&m.rint[k], (size_t)MTDEV_BATCH * N * 4));
             MTD_HIP(hipMalloc((void**)&m.tokpos[k], (size_t)MTDEV_BATCH * m.S * 3 * 8));
+            MTD_HIP(hipMalloc((void**)&m.recs[k], (size_t)MTDEV_BATCH * m.maxrec * sizeof(WalkRec)));
+            MTD_HIP(hipMalloc((void**)&m.nrec[k], (size_t)MTDEV_BATCH * 4));
+            MTD_HIP(hipMemset(m.nrec[k], 0, (size_t)MTDEV_BATCH * 4));
         }
+        MTD_HIP(hipMalloc((void**)&m.fin_partial, (size_t)MTDEV_BATCH * m.nchunk * 4));
+        MTD_HIP(hipMalloc((void**)&m.fin_hist, (size_t)MTDEV_BATCH * m.nchunk * m.S * 4));
         for (int k = 0; k < MTDEV_NBUF; ++k) {
             MTD_HIP(hipMalloc((void**)&m.step_end[k], (size_t)MTDEV_BATCH * 8));
             MTD_HIP(hipEventCreateWithFlags(&m.bt[k].tok, hipEventDisableTiming));
@@ -161,7 +181,7 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         const unsigned long long p0 = (unsigned long long)start.pos;
         MTD_HIP(hipMemcpy(m.d_pos, &p0, 8, hipMemcpyHostToDevice));
         MTD_HIP(hipMemset(m.d_err, 0, 4));
-        MTD_HIP(hipMemset(m.d_nwin, 0, 8));
+        MTD_HIP(hipMemset(m.d_nwin, 0, 96));
         m.known = -1;
         m.known_pos = p0;
         m.gen_words = 0;
@@ -180,7 +200,7 @@ MtDevProducer::~MtDevProducer() {
             hipStreamDestroy(s);
         }
     void* bufs[] = {m.stream, m.base_key, m.xwin, m.partial, m.polys, m.d_pos, m.d_err, m.d_nwin, m.J[0], m.J[1], m.rint[0], m.rint[1],
-                    m.tokpos[0], m.tokpos[1], m.scratch, m.blk_words};
+                    m.tokpos[0], m.tokpos[1], m.scratch, m.blk_words, m.recs[0], m.recs[1], m.nrec[0], m.nrec[1], m.fin_partial, m.fin_hist};
     for (void* p : bufs)
         if (p) hipFree(p);
     for (int k = 0; k < MTDEV_NBUF; ++k) {
@@ -191,6 +211,27 @@ MtDevProducer::~MtDevProducer() {
     if (m.ev_gen) hipEventDestroy(m.ev_gen);
     if (m.h_end) hipHostFree(m.h_end);
     delete im_;
+}
+
+void MtDevProducer::refresh_stats() {
+    Impl& m = *im_;
+    if (hipSetDevice(m.device) != hipSuccess || hipStreamSynchronize(m.s_tok) != hipSuccess) return;
+    unsigned long long nw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpy(nw, m.d_nwin, 96, hipMemcpyDeviceToHost) == hipSuccess) {
+        for (int k = 0; k < 4; ++k) st_.tok_ticks[k] = (int64_t)nw[4 + k];
+#ifdef EMX_TOK_PROFILE
+        fprintf(stderr, "mtdev tok profile: wave-0 walks %llu, %llu ticks; scans %llu ticks\n", nw[8], nw[9], nw[10]);
+#endif
+        st_.windows = (int64_t)nw[0];
+        st_.tok_rounds = (int64_t)nw[1];
+        st_.tail_groups = (int64_t)nw[2];
+        st_.tail_rounds = (int64_t)nw[3];
+    }
+}
+
+void MtDevProducer::set_window_rule(int wshift, int tail) {
+    if (wshift >= 8 && wshift <= 20) im_->wshift = wshift;
+    if (tail >= 0) im_->tail = tail;
 }
 
 int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) {
@@ -257,7 +298,7 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
             const uint64_t first_word = first ? MT_N : m.gen_words;       // (the base block of round 0 is words [0, 624))
             hipLaunchKernelGGL(k_mt_window, dim3(1), dim3(256), 0, m.s_gen, m.base_key, m.xwin, m.stream, (unsigned long long)(m.capw - 1),
                                0ull, first ? 1 : 0);
-            hipLaunchKernelGGL(k_mt_jump, dim3(JUMP_SPLIT, P - 1), dim3(640), 0, m.s_gen, m.polys, m.xwin, m.partial);
+            hipLaunchKernelGGL(k_mt_jump, dim3(JUMP_SPLIT, P - 1), dim3(256), 0, m.s_gen, m.polys, m.xwin, m.partial);
             GenArgs ga{};
             ga.xwin = m.xwin;
             ga.partial = m.partial;
@@ -285,11 +326,15 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
         ta.avail_end = m.gen_words;
         ta.status = m.status;
         ta.err = m.d_err;
-        ta.J = m.J[par];
-        ta.rint = m.rint[par];
+        ta.recs = m.recs[par];
+        ta.nrec = m.nrec[par];
+        ta.maxrec = m.maxrec;
         ta.tokpos = m.tokpos[par];
         ta.step_end = m.step_end[buf];
-        ta.nwindows = m.d_nwin;
+        ta.stats = m.d_nwin;
+        ta.J = m.J[par];
+        ta.wshift = m.wshift;
+        ta.tail = m.tail;
         ta.N = (int32_t)m.N;
         ta.S = m.S;
         ta.nb = MTDEV_BATCH;
@@ -306,11 +351,15 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
         FinArgs fa{};
         fa.stream = m.stream;
         fa.smask = m.capw - 1;
+        fa.recs = m.recs[par];
+        fa.nrec = m.nrec[par];
         fa.J = m.J[par];
         fa.rint = m.rint[par];
         fa.tokpos = m.tokpos[par];
         fa.err = m.d_err;
         fa.scratch = m.scratch;
+        fa.partial = m.fin_partial;
+        fa.hist = m.fin_hist;
         for (int k = 0; k < MTDEV_BATCH; ++k) {
             const MtDevPlanCols& pc = m.slots[(size_t)buf * MTDEV_BATCH + k];
             fa.order[k] = pc.order;
@@ -327,7 +376,22 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
         fa.D = m.D;
         fa.S = m.S;
         fa.randomize = m.mv.randomize_split ? 1 : 0;
-        hipLaunchKernelGGL(k_mt_fin, dim3(MTDEV_BATCH), dim3(FIN_T), 0, m.s_fin, fa);
+        fa.maxrec = m.maxrec;
+        fa.nchunk = m.nchunk;
+        {
+            const dim3 gc((unsigned)m.nchunk, MTDEV_BATCH), blk(FIN_T);
+            hipLaunchKernelGGL(k_fin_init, gc, blk, 0, m.s_fin, fa);
+            hipLaunchKernelGGL(k_fin_walk, dim3((unsigned)m.maxrec * 4u, MTDEV_BATCH), blk, 0, m.s_fin, fa);
+            if (fa.randomize) {
+                hipLaunchKernelGGL(k_fin_hits, gc, blk, 0, m.s_fin, fa);
+                hipLaunchKernelGGL(k_fin_sum, gc, blk, 0, m.s_fin, fa);
+                hipLaunchKernelGGL(k_fin_scan, gc, blk, 0, m.s_fin, fa);
+                hipLaunchKernelGGL(k_fin_bucket, gc, blk, 0, m.s_fin, fa);
+            }
+            hipLaunchKernelGGL(k_fin_label, gc, blk, 0, m.s_fin, fa);
+            hipLaunchKernelGGL(k_fin_order, gc, blk, 0, m.s_fin, fa);
+            hipLaunchKernelGGL(k_fin_plan, dim3((unsigned)((m.N + FIN_T - 1) / FIN_T), MTDEV_BATCH), blk, 0, m.s_fin, fa);
+        }
         MTD_HIP(hipGetLastError());
         MTD_HIP(hipEventRecord(m.bt[buf].fin, m.s_fin));
         ++m.enq;
@@ -356,10 +420,7 @@ int MtDevProducer::finish(int64_t steps_taken, MT19937Legacy& out) {
     MTD_HIP(hipStreamSynchronize(m.s_gen));
     MTD_HIP(hipStreamSynchronize(m.s_tok));
     MTD_HIP(hipStreamSynchronize(m.s_fin));
-    {
-        unsigned long long nw = 0;
-        if (hipMemcpy(&nw, m.d_nwin, 8, hipMemcpyDeviceToHost) == hipSuccess) st_.windows = (int64_t)nw;
-    }
+    refresh_stats();
     out = m.start;
     if (steps_taken <= 0) return 0;
     unsigned e = 0;

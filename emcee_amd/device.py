@@ -575,6 +575,13 @@ class DeviceEnsemble:
         return {"qualifies": bool(out[0]), "alive": bool(out[1]), "steps": int(out[2]), "rounds": int(out[3]), "segments": int(out[4]),
                 "batches": int(out[5]), "windows": int(out[6]), "poly_us": int(out[7])}
 
+    def mtdev_tok_stats(self):
+        """what the device tokenizer has done so far (include/emx.h emx_mtdev_tok_stats)"""
+        out = (C.c_int64 * 8)()
+        self._ck(self.lib.emx_mtdev_tok_stats(self.ctx, out))
+        return {"windows": int(out[0]), "rounds": int(out[1]), "tail_groups": int(out[2]), "tail_rounds": int(out[3]),
+                "wait_us": out[4] / 100.0, "chunk_us": out[5] / 100.0, "tail_us": out[6] / 100.0, "kernel_us": out[7] / 100.0}
+
     def mtdev_debug(self, what, arg, n=0):
         """tests: stream words / Fisher-Yates targets / positions of the live device producer (include/emx.h emx_mtdev_debug)"""
         if what == 0:

@@ -329,19 +329,25 @@ int emx_profile_read(emx_ctx* ctx, float* ms_out, int32_t* n_inout);
  * over the threads), [4] tokenizer waiting for words, [5] tokenizer waiting for a free staging buffer (i.e. for the consumer) */
 int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int32_t* finisher_threads);
 
-/* Exact (MT19937) mode with the plans made ON THE DEVICE (csrc/emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica --
- * the configuration in which "same seed => same chain as the reference" (ensemble.py:166-167,406, moves/red_blue.py:76-80,100,
- * moves/stretch.py:30-32) used to be bounded by host threads.  MT19937 segments by jump-ahead, the rejection tests of
- * random.shuffle / randint and the Fisher-Yates swaps all run in kernels; no host thread touches a draw (tuning key "mt_device" = 0
- * restores the host pipeline).
+/* Exact (MT19937) mode with the plans made ON THE DEVICE (csrc/emx_mtdev.hpp): one StretchMove, one replica, ensembles of
+ * 131 072 walkers or more -- where the serial host stages of "same seed => same chain as the reference" (ensemble.py:166-167,406,
+ * moves/red_blue.py:76-80,100, moves/stretch.py:30-32) cost more than the kernels do.  MT19937 segments by jump-ahead, the rejection
+ * tests of random.shuffle / randint and the Fisher-Yates swaps all run in kernels; no host thread touches a draw.  Tuning key
+ * "mt_device": 0 = always the host pipeline, 1 (default) = from "mt_device_min_walkers" (131 072) on, 2 = from 8 192 walkers on
+ * (measured, MI355X, 64-dim dense Gaussian: 65 536 walkers 94 us/step against the host pipeline's 69; 262 144 x 32: 192 against 316;
+ * 1 048 576: 602 against 1 347 -- profiles/r04/mtdev_sizes.txt).
  *   out[0] 1 when the current configuration takes this producer, [1] 1 while one is alive, [2] steps taken from producers so far,
- *   [3] generation rounds, [4] stream segments (of 1024 MT blocks), [5] batches of 16 steps produced, [6] tokenizer windows,
+ *   [3] generation rounds, [4] stream segments (of 128 MT blocks), [5] batches of 16 steps produced, [6] tokenizer windows,
  *   [7] microseconds spent computing the jump polynomials (once per process)  -- [3..7] of the live or the last producer */
 int emx_mtdev_info(emx_ctx* ctx, int64_t out[8]);
 /* tests: raw pieces of the live producer after a synchronise.  what = 0: `n` tempered stream words from absolute position `arg`
  * (uint32 out); 1: the accepted Fisher-Yates targets J[i], i < nwalkers, of producer step `arg` (uint32 out, entry 0 unused);
  * 2: that step's positions -- nsplits * 3 (z words, randint words, accept words) then the position after the step (uint64 out) */
 int emx_mtdev_debug(emx_ctx* ctx, int32_t what, int64_t arg, void* out, int64_t n);
+/* the device tokenizer's work so far: out = windows decided | fixed-point rounds | 64-word groups of the one-wave tail | its ballot
+ * rounds | then 10 ns ticks: waiting for stream windows | deciding the wide windows | the tail | the whole tokenizer kernels
+ * (red_blue.py:80's masked rejection is the only serial part of a step: this is what it cost) */
+int emx_mtdev_tok_stats(emx_ctx* ctx, int64_t out[8]);
 /* host only: the MT19937 state key `k * stride_words` words after the block FOLLOWING `key` (k >= 1), by the jump polynomial
  * t^(k stride) mod phi applied to the 33-block window after `key` -- the host statement of what k_mt_jump computes */
 int emx_host_mt_jump(const uint32_t key[624], uint64_t stride_words, int32_t k, uint32_t out_key[624]);

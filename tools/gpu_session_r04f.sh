@@ -1,0 +1,14 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r04f
+O=$PWD/gpurun_out/r04f
+R=$PWD
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_mtdev.py -q -x -p no:cacheprovider > $O/mtdev_tests.log 2>&1; echo "mtdev tests rc=$?" | tee -a $O/summary.txt
+tail -n 3 $O/mtdev_tests.log
+for tune in "mt_tok_wshift=12,mt_tok_tail=2048" "mt_tok_wshift=11,mt_tok_tail=2048" "mt_tok_wshift=10,mt_tok_tail=2048" "mt_tok_wshift=9,mt_tok_tail=2048" "mt_tok_wshift=11,mt_tok_tail=4096" "mt_tok_wshift=10,mt_tok_tail=4096" "mt_tok_wshift=11,mt_tok_tail=8192" "mt_tok_wshift=11,mt_tok_tail=4096,persist=0"; do
+  echo "== $tune" | tee -a $O/sweep.log
+  EMX_TUNE="$tune" timeout 300 python tools/mtdev_probe.py 65536 64 400 1 2>&1 | grep "mt_device" | cut -c1-600 | tee -a $O/sweep.log
+done
+cd /tmp
+EMX_TUNE="mt_tok_wshift=11,mt_tok_tail=4096" timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_mtdev -o mtdev -- python $R/tools/mtdev_probe.py 65536 64 200 1 > $O/prof_mtdev.log 2>&1; echo "prof rc=$?" | tee -a $O/summary.txt

@@ -31,6 +31,7 @@ for dev in MODES:
         e.run(K, 1, False)
         e.sync()
         best = min(best, time.perf_counter() - t0)
-    print("mt_device=%d  N=%d D=%d: first 40 steps %.2f ms, then %.2f us/step (best of 5 x %d); status %d; mtdev %r; persist %r; pipeline %r"
-          % (dev, N, D, first * 1e3, best * 1e6 / K, K, e.status(), e.mtdev_info(), e.persist_info(), e.pipeline_stats()), flush=True)
+    print("mt_device=%d  N=%d D=%d: first 40 steps %.2f ms, then %.2f us/step (best of 5 x %d); status %d; mtdev %r; tok %r; persist %r; pipeline %r"
+          % (dev, N, D, first * 1e3, best * 1e6 / K, K, e.status(), e.mtdev_info(), e.mtdev_tok_stats() if dev else None, e.persist_info(),
+             e.pipeline_stats()), flush=True)
     e.close()
