@@ -2904,7 +2904,7 @@ static bool persist_wanted(const emx_ctx* c) {
     // leaves it none, and the two took turns -- k_persist 314 -> 1 150 us a launch, profiles/r04/mtdev_timeline.txt.)
     if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
     if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || dense_is_wide(c)) return false;
-    if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
+    if (c->tune_ablate || (c->dbg && !EMX_OPT_STAMPS) || c->tune_spw || c->tune_wpb || c->tune_graph) return false;     // (an instrumented build stamps k_persist too)
     if (c->N < c->tune_persist_min_walkers) return false;
     bool any = false;
     for (const auto& m : c->moves) any = any || persist_move_ok(c, m);

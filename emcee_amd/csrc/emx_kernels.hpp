@@ -1364,6 +1364,23 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     if (!persist_handshake(P)) return;                          // (also the workgroup barrier behind the image load)
     const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
     const int t0 = wave * 16;                                   // this wave's slots of every split
+    // instrumented build only (tools/persist_phase_clock.py, -DEMX_OPT_STAMPS=1): where the first wave of every workgroup spends a
+    // half-step -- ticks summed over the launch's half-steps: partner rows arrive | proposals + tile | MFMA + reductions |
+    // decisions + commit issued | stores acknowledged | barrier
+    unsigned long long pst[6] = {0, 0, 0, 0, 0, 0}, pt = 0;
+    const bool prof = EMX_OPT_STAMPS && A.dbg && wib == 0;
+    if (prof) {
+        pt = __builtin_readcyclecounter();
+        if (lane == 0) A.dbg[(size_t)blockIdx.x * 16 + 11] = wall_clock64();
+    }
+#define EMX_PSTAMP(k_)                                                   \
+    do {                                                                 \
+        if (prof) {                                                      \
+            const unsigned long long t_ = __builtin_readcyclecounter(); \
+            pst[k_] += t_ - pt;                                          \
+            pt = t_;                                                     \
+        }                                                                \
+    } while (0)
     const __amdgpu_buffer_rsrc_t Xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.X, 0, A.N * D * 8, 0x00020000);
     const int myrow = (lane >> 4) + 4 * (lane & 3);             // decision lanes: (lane & 15) < 4 decide tile row myrow
     const bool mine = (lane & 15) < 4;
@@ -1433,6 +1450,8 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             my_logu_n = J.logu[pbase + myrow];
         }
         // -------- proposals -> the wave's LDS tile (R = Q - mu), kept in registers for the commit --------
+        if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        EMX_PSTAMP(0);       // partner rows (and the next half-step's plan entries) have arrived
         Row<G, V, CH> qk[PF];
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
@@ -1483,6 +1502,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             my_lpo_n = load_agent(A.lp + my_i_n);
         }
         EMX_WAVE_SYNC();
+        EMX_PSTAMP(1);       // proposals made, tile written, chain rows and next own rows issued
         // -------- Y = R L by v_mfma_f64_16x16x4_f64, qf[w] = sum_n Y[w][n]^2 (as k_halfstep) --------
         double my_qf;
         {
@@ -1503,6 +1523,8 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             }
             my_qf = row16_sum4(part[0], part[1], part[2], part[3], lane);
         }
+        if (prof) { asm volatile("s_nop 0" ::: "memory"); }
+        EMX_PSTAMP(2);       // MFMA chain + reductions
         // -------- decisions (red_blue.py:99-100) and commit (move.py:33-34) --------
         bool acc = false;
         if (mine) {
@@ -1546,8 +1568,14 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             for (int k = 0; k < PF; ++k) cwi[k] = wi[k];
         }
         EMX_WAVE_SYNC();
+        EMX_PSTAMP(3);       // decisions made, commit stores issued
+        if (prof) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            EMX_PSTAMP(4);   // stores acknowledged (and the speculative own rows of the next half-step in)
+        }
         if (!more) break;
         persist_barrier(P, P.epoch0 + (unsigned)n + 2u);           // (+ 1: the handshake was this launch's first barrier)
+        EMX_PSTAMP(5);       // device-wide barrier
         // -------- roll over --------
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
@@ -1577,6 +1605,14 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         for (int k = 0; k < PF; ++k) store_row_stream<G, V, CH>(crow[k], cchain + (size_t)cwi[k] * D, D, gl);
         if (mine) cchain_lp[cmy_i] = clp;
     }
+    if (prof && lane == 0) {
+        unsigned long long* o = A.dbg + (size_t)blockIdx.x * 16;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = pst[k];
+        o[6] = (unsigned long long)P.niter;
+        o[12] = wall_clock64();
+    }
+#undef EMX_PSTAMP
 }
 
 // ----------------------------------------------------------------------------------------
