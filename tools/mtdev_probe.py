@@ -20,7 +20,7 @@ MODES = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 0
 for dev in MODES:
     e = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(e, "mt19937")
-    e.set_tuning("mt_device", dev)
+    e.set_tuning("mt_device", 2 if dev else 0)          # 2: the device producer at any size
     t0 = time.perf_counter()
     e.run(40, 1, False)
     e.sync()
