@@ -357,6 +357,7 @@ struct emx_ctx {
     // exact-mode plans made on the device (emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica
     MtDevProducer* mtdev = nullptr;
     int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
+    int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
     int64_t tune_mt_device_min = 131072; // (measured: the host pipeline is faster below ~10^5 walkers, profiles/r04/mtdev_sizes.txt)
     int64_t tune_mt_lookahead = 2;       // batches the device producer is asked to run ahead of the consumer (0 .. 2)
@@ -940,8 +941,20 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         pc.got = nbatch == nblocks * waves_per_block && (nown % spw) == 0;     // every wave exactly one full tile
         return 0;
     }
-    hipError_t e = dispatch_halfstep(move, dense, c->Dp / 16, sh, dim3((unsigned)nblocks), dim3(64 * waves_per_block), lds,
-                                     c->stream, a);
+    hipError_t e;
+    // padded ndim 80 ... 128, even ndim, single replica: the slab form (emx_slab.hip) -- eight waves a CU instead of four
+    // (measured, 65 536 walkers, stretch: padded 128 66.6 -> 50.8 us/step, 112 61.6 -> 44.3; at 96 and 80 the per-tile kernel already
+    // has eight waves a CU and the two are level -- profiles/r04/slab_ab.txt; tuning "slab" = 2 takes it from padded 80 on)
+    const bool slab = dense && c->tune_slab && c->Dp >= (c->tune_slab == 2 ? 80 : 112) && sh.G == 16 && sh.V == 2 && sh.CH == 4 &&
+                      (move == MOVE_STRETCH || move == MOVE_DE) && lean_kind(a, 16, 2, 4, move, true) == 1;
+    if (slab) {
+        const int wpb = 8;
+        const int64_t ntile = (nown + 15) / 16;
+        const int64_t nb = std::min<int64_t>((ntile + wpb - 1) / wpb, (int64_t)c->num_cu * c->tune_bpc);
+        e = launch_slab_dense(c->Dp / 16, move, dim3((unsigned)nb), dim3(64 * wpb), slab_lds_bytes(c->Dp, wpb), c->stream, a);
+    } else {
+        e = dispatch_halfstep(move, dense, c->Dp / 16, sh, dim3((unsigned)nblocks), dim3(64 * waves_per_block), lds, c->stream, a);
+    }
     if (e != hipSuccess) {
         char b[256];
         snprintf(b, sizeof(b), "half-step launch failed (G=%d V=%d CH=%d move=%d dense=%d ndim=%d): %s", sh.G, sh.V, sh.CH,
@@ -1323,6 +1336,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "mt_device_lookahead")) {       // batches produced ahead of the one asked for (tests: 0 keeps batch 0's raw pieces readable)
         c->tune_mt_lookahead = v < 0 ? 0 : (v > 2 ? 2 : v);
+        return 0;
+    }
+    if (!strcmp(key, "slab")) {              // 0: the per-tile kernel at every padded ndim (parity tests, A/B); 1: slab form from padded 112; 2: from padded 80
+        c->tune_slab = v < 0 ? 0 : (v > 2 ? 2 : v);
         return 0;
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)

@@ -129,3 +129,43 @@ def test_role_split_log_prob_kernel_equals_the_single_role_one(N, D, moves):
         for a, b in zip(outs[0], other):
             assert np.array_equal(a, b)
     assert outs[0][3].sum() > 0
+
+
+@pytest.mark.parametrize("N,D,moves,weights", [
+    (4096, 128, [_S("stretch")], None),
+    (4100, 112, [_S("stretch")], None),                    # a ragged last tile
+    (2000, 96, [_S("stretch", nsplits=3)], None),
+    (1536, 66, [_S("stretch")], None),                     # padded 80
+    (3000, 128, [_S("de")], None),
+    (2048, 100, [_S("stretch"), _S("de")], [0.5, 0.5]),
+    (65536, 128, [_S("stretch")], None),                   # the shape of the bench's dense_65536x128_fused entry
+])
+@pytest.mark.parametrize("store", [True, False])
+def test_slab_kernel_equals_per_tile_kernel_bit_for_bit(N, D, moves, weights, store):
+    """padded ndim 80 ... 128, even ndim: k_halfstep_slab (csrc/emx_slab.hip: the tile's proposals in registers, a 32-column LDS
+    slab, eight waves a CU) against k_halfstep<16, 2, 4, MOVE, DPB, 1> (tuning key slab = 0): same arithmetic in the same order,
+    so coordinates, log-probs, accept masks, chain rows and accept counters must agree bit for bit"""
+    spec = _spec(N, D, moves, weights)
+    outs = []
+    for slab in (2, 0):                                    # 2: the slab form from padded ndim 80 on (by default it starts at 112)
+        ens = make_ens(spec, spec["p0"])
+        ens.set_tuning("slab", slab)
+        ens.set_tuning("small_kernel", 0)
+        ens.set_tuning("graph", 0)
+        ens.eval_state_log_prob()
+        ens.set_rng_mode(_lib.RNG_PHILOX)
+        ens.set_philox(424242, 0)
+        nst = 9 if N <= 8192 else 5
+        ens.chain_config(nst)
+        ens.run(nst, 1, store)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask().copy())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, nst), clp=ens.chain_read(1, 0, nst), cnt=ens.accepted_counts())
+        outs.append(rec)
+        ens.close()
+    a, b = outs
+    assert a["acc"].any() and not a["acc"].all()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
