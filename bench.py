@@ -897,6 +897,32 @@ def run_child(args, key, ex, port, timeout_s, keep_partial=False):
 
 
 _CHILDREN_RUN = []
+_DEADLINE = [None]          # N > 1: perf_counter value by which the orchestrator wants to be done (--time-budget)
+
+
+def agreed_remaining(dist):
+    """seconds left of the time budget, the same number on every rank (the minimum over their clocks); None without a budget"""
+    if _DEADLINE[0] is None:
+        return None
+    import torch
+    t = torch.tensor([_DEADLINE[0] - time.perf_counter()], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t[0])
+
+
+def worst_case_seconds(args, keys, exchanges):
+    """what the watchdogs alone would allow: every preflight attempt and every (configuration, exchange) child running into its
+    timeout -- the number the time budget exists to cut down"""
+    pre = 0.0 if args.no_preflight else (args.preflight_timeout + 180.0) + 3 * args.preflight_timeout
+    total = 0.0
+    first = True
+    for key in keys:
+        for ex in ((HEAVY_EXCHANGES if key == "w512" else EXCHANGES) if args.exchange == "all" else (args.exchange,)):
+            total += args.exchange_timeout + (180.0 if first else 0.0) + (180.0 if key == "w512" else 0.0)
+            first = False
+    return {"preflight_s": pre, "measurements_s": total, "unbounded_s": pre + total, "time_budget_s": args.time_budget,
+            "note": "unbounded = every watchdog firing (a protocol that failed once is not tried again, so at most one timeout per "
+                    "protocol in practice); the orchestrator stops starting children once the budget is spent and says what it skipped"}
 
 
 XGMI_INGRESS_GBPS = 7 * 76.8        # MI355X: 7 links x 153.6 GB/s bidirectional = 76.8 GB/s per direction each (MI355X_MICROARCH.md)
@@ -941,9 +967,16 @@ def sharded_config(key, world, K, rank, dist, args, port0, skip):
             continue
         # the very first child also pays for cold caches (kernel modules, code objects, a slower first torch import)
         first = not _CHILDREN_RUN
-        _CHILDREN_RUN.append((key, ex))
         # (the weak-scaled 512-dimensional ensemble is 2 GB of start state per rank to generate and upload: give it time)
-        r = run_child(args, key, ex, port0 + n, args.exchange_timeout + (180.0 if first else 0.0) + (180.0 if key == "w512" else 0.0))
+        timeout_s = args.exchange_timeout + (180.0 if first else 0.0) + (180.0 if key == "w512" else 0.0)
+        rem = agreed_remaining(dist)
+        if rem is not None:
+            if rem < 30.0:
+                errors[ex] = "skipped: the run's time budget (--time-budget %.0f s) is spent" % args.time_budget
+                continue
+            timeout_s = min(timeout_s, rem - 10.0)
+        _CHILDREN_RUN.append((key, ex))
+        r = run_child(args, key, ex, port0 + n, timeout_s)
         ok = r.get("error") is None and "wall_s" in r
         if not torch_all_ok(dist, ok):             # the parents' own gloo group: CPU only
             errors[ex] = r.get("error") or "failed on another rank"
@@ -1192,6 +1225,9 @@ def main(argv=None):
                     help="--gpus N > 1 started without torchrun: seconds after which the rank processes started here are killed")
     ap.add_argument("--preflight-timeout", type=float, default=45.0,
                     help="N > 1: seconds a preflight child (peer access + every exchange on a tiny ensemble) may take")
+    ap.add_argument("--time-budget", type=float, default=840.0,
+                    help="N > 1: wall-clock seconds the whole run may take; what does not fit (the later configurations' slower "
+                         "protocols) is skipped and named in the line -- the watchdogs alone would allow far more")
     ap.add_argument("--no-preflight", action="store_true")
     ap.add_argument("--preflight", action="store_true", help="N > 1: run the preflight only and print its verdicts")
     ap.add_argument("--child", default=None, help=argparse.SUPPRESS)          # internal: "<config>:<exchange>"
@@ -1366,6 +1402,10 @@ def main(argv=None):
     line = None
     skip = {}
     exchanges = (EXCHANGES + ("logprob",) if "w512" in keys else EXCHANGES) if args.exchange == "all" else (args.exchange,)
+    t_start = time.perf_counter()
+    _DEADLINE[0] = t_start + args.time_budget if args.time_budget > 0 else None
+    budget = worst_case_seconds(args, keys, exchanges)
+    log("rank %d: time budget %.0f s (the watchdogs alone would allow %.0f s)" % (rank, args.time_budget, budget["unbounded_s"]))
     pre = None
     if not args.no_preflight or args.preflight:
         t0 = time.perf_counter()
@@ -1378,7 +1418,7 @@ def main(argv=None):
         if not pre.get("p2p", {}).get("ok", True):
             log("preflight: no peer access between the devices -- the direct exchange cannot work")
             skip.setdefault("direct", "preflight: hipDeviceCanAccessPeer is false for some pair of devices")
-        pre = {"seconds": pre_s, "items": pre, "disabled": dict(skip)}
+        pre = {"seconds": pre_s, "items": pre, "disabled": dict(skip), "time_budget": budget}
         log("rank %d preflight (%.1f s): %s" % (rank, pre_s, {k: v.get("ok") for k, v in pre["items"].items()}))
         if args.preflight:
             if rank == 0:
@@ -1414,6 +1454,8 @@ def main(argv=None):
             line["multi_gpu"] = multi
     if rank == 0 and line is not None:
         line["multi_gpu"] = multi
+        budget["used_s"] = time.perf_counter() - t_start
+        line["time_budget"] = budget
         if pre is not None:
             line["preflight"] = pre
         emit(line)

@@ -542,14 +542,18 @@ namespace {
 // the occasional features a LEAN instantiation compiles out
 int prefetch_depth_host(int G, int V, int CH, int move, bool dense);
 
-// -> 0: the full kernel; 1: LEAN; 2: LEAN for the block-ownership exchanges (device-side slot count and / or peer table live)
+// -> 0: the full kernel; 1: LEAN; 2 / 3 / 4: LEAN for the block-ownership exchanges -- 2: peer table (+ device-side slot count),
+// 3: device-side slot count alone, 4: slot count + decision output.  (One instantiation for all three spilled 39 scalar registers at
+// the headline shape; split: 13 / 0 / 6.  Shapes without a 3 take 2, which is a superset of it.)
 inline int lean_kind(const HalfStepArgs& a, int G, int V, int CH, int move, bool dense) {
     const int WPW = 64 / G, PF = prefetch_depth_host(G, V, CH, move, dense);
     const int spw = (dense && PF * WPW < 16) ? 16 : PF * WPW;
     const bool common = !a.ablate && !a.desc && !a.sendbuf && !a.disp && !a.skew_sleep && (EMX_OPT_STAMPS || !a.dbg) && (a.target != TGT_NONE || !dense) &&      // (propose-only passes run element-wise instantiations)
                         (!EMX_LEAN_FOLD_D || a.D == G * V * CH) && a.spw == spw && a.t_lo == 0;      // ndim is folded only with EMX_LEAN_FOLD_D
     if (!common) return 0;
-    return (a.t_hi_dev || a.npeer || a.declp) ? 2 : 1;
+    if (a.npeer) return a.declp ? 0 : 2;         // direct exchange: the peer table
+    if (a.declp) return 4;                       // replay exchange, own pass: decision output (+ push)
+    return a.t_hi_dev ? 3 : 1;                   // pull exchange / replay launches: the device-side slot count alone
 }
 
 template <int MOVE>
@@ -558,15 +562,18 @@ hipError_t launch_valu(const Shape& sh, dim3 grid, dim3 block, hipStream_t st, c
         if (sh.G == 8 && sh.V == 2 && sh.CH == 2) {
             const int lk = lean_kind(a, 8, 2, 2, MOVE, false);
             if (lk == 1) return launch_one<8, 2, 2, MOVE, 0, 1>(grid, block, 0, st, a);
-            if (lk == 2) return launch_one<8, 2, 2, MOVE, 0, 2>(grid, block, 0, st, a);
+            if (lk == 2 || lk == 3) return launch_one<8, 2, 2, MOVE, 0, 2>(grid, block, 0, st, a);
+            if (lk == 4) return launch_one<8, 2, 2, MOVE, 0, 4>(grid, block, 0, st, a);
         }
         if (sh.G == 8 && sh.V == 2 && sh.CH == 4) {       // ndim 64 (the replay of C2's accepted updates on the other replicas)
-            if (lean_kind(a, 8, 2, 4, MOVE, false) == 2) return launch_one<8, 2, 4, MOVE, 0, 2>(grid, block, 0, st, a);
+            const int lk = lean_kind(a, 8, 2, 4, MOVE, false);
+            if (lk == 2 || lk == 3) return launch_one<8, 2, 4, MOVE, 0, 2>(grid, block, 0, st, a);
         }
         if (sh.G == 64 && sh.V == 2 && sh.CH == 8) {
             const int lk = lean_kind(a, 64, 2, 8, MOVE, false);
             if (lk == 1) return launch_one<64, 2, 8, MOVE, 0, 1>(grid, block, 0, st, a);
-            if (lk == 2) return launch_one<64, 2, 8, MOVE, 0, 2>(grid, block, 0, st, a);
+            if (lk == 2 || lk == 3) return launch_one<64, 2, 8, MOVE, 0, 2>(grid, block, 0, st, a);
+            if (lk == 4) return launch_one<64, 2, 8, MOVE, 0, 4>(grid, block, 0, st, a);
         }
     }
     if constexpr (MOVE != MOVE_EVAL) {   // every element-wise shape has a LEAN instantiation

@@ -6,6 +6,8 @@ namespace emx {
 
 hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a) {
     if (lean == 2) return launch_one<8, 2, 4, MOVE_STRETCH, 4, 2>(grid, block, lds, st, a);
+    if (lean == 3) return launch_one<8, 2, 4, MOVE_STRETCH, 4, 3>(grid, block, lds, st, a);
+    if (lean == 4) return launch_one<8, 2, 4, MOVE_STRETCH, 4, 4>(grid, block, lds, st, a);
     return launch_one<8, 2, 4, MOVE_STRETCH, 4, 1>(grid, block, lds, st, a);
 }
 

@@ -162,7 +162,7 @@ struct PeerTable {
 // coordinate array holding the current row of walker j (block ownership: rank q owns [lo[q], lo[q + 1]))
 template <int LEAN>
 __device__ __forceinline__ const double* partner_base(const HalfStepArgs& A, int j) {
-    if (LEAN == 1 || A.npeer == 0) return A.X;      // launch-uniform
+    if (LEAN == 1 || LEAN == 3 || LEAN == 4 || A.npeer == 0) return A.X;      // launch-uniform
     const PeerTable* __restrict__ T = A.peers;      // uniform address: scalar loads
     const double* b = T->X[0];
 #pragma unroll
@@ -703,6 +703,8 @@ __device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row
 // occasional features is in play (sharded send buffers, device-side slot counts, graph replay descriptors, materialised
 // Gaussian displacements, peers, timing experiments): those kernel arguments then fold to constants instead of sitting in
 // scalar registers for the whole kernel -- the full kernel spills 66 SGPRs, and 25 fewer spills were worth 1.3 % at C2.
+// LEAN = 3 / 4 (round 4: the headline shape only) split LEAN = 2 by exchange -- 3: the device-side slot count alone (pull), 4: slot
+// count + decision output (replay), 2: everything (direct: the peer table) -- because LEAN = 2 still spilled 39 scalar registers.
 // LEAN = 2 keeps what the block-ownership exchanges need (the device-side slot count of the compact plan, the peer
 // table of the direct exchange) and folds the rest: the sharded stretch runs of the same shapes.
 template <int G, int V, int CH, int MOVE, int DPB, int LEAN = 0>
@@ -713,14 +715,14 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
     const int32_t* const thidev_ = LEAN == 1 ? nullptr : A.t_hi_dev;        // LEAN 2: the block-ownership exchanges (pull, direct)
     const double* const disp_ = LEAN ? nullptr : A.disp;
     const int skewsl_ = LEAN ? 0 : A.skew_sleep;
-    double* const declp_ = LEAN == 1 ? nullptr : A.declp;                  // LEAN 2: + the replay exchange's own pass
+    double* const declp_ = (LEAN == 0 || LEAN == 4) ? A.declp : nullptr;   // LEAN 4: + the replay exchange's own pass
     auto put_decision = [&](int idx, double v) {
         declp_[idx] = v;
         if (A.npush) {
             const PeerTable* __restrict__ T = A.push_peers;
-#pragma unroll
-            for (int q = 0; q < EMX_MAX_PEERS; ++q)
-                if (q < A.npush) const_cast<double*>(T->X[q])[A.push_off + idx] = v;
+#pragma nounroll
+            for (int q = 0; q < A.npush; ++q)                     // (rolled: eight peer pointers held in scalar registers across the
+                const_cast<double*>(T->X[q])[A.push_off + idx] = v;   // batch loop were half of the LEAN instantiations' spills)
         }
     };
     const int target_ = (LEAN && DPB > 0) ? (int)TGT_DENSE : A.target;

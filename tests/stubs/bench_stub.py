@@ -26,7 +26,7 @@ def install(bench):
                     return {"error": "no result within %.0f s (hung; child killed)" % timeout_s, "preflight": done}
                 done[e] = {"ok": e not in fail, "seconds": 0.01, "device_status": 0, "replicas_agree": e not in fail}
             return {"preflight": done}
-        time.sleep(0.01)
+        time.sleep(float(os.environ.get("EMX_BENCH_STUB_SLEEP", "0.01")))               # (a slow child: the time-budget test)
         wall = 1e-3 * speed.get(ex, 1.0) * args.steps
         return {"wall_s": wall, "gpu_ms": wall * 1e3, "blocks": 3, "comm": "stub", "exchange": ex, "accept_frac": 0.17, "status": 0,
                 "digest": "stub-digest", "replicas_agree": True, "rccl_ranks": int(short) if short else world,

@@ -58,6 +58,25 @@ def test_self_launch_runs_n_ranks_and_prints_one_line(tmp_path):
         assert e["xgmi_ingress_frac_of_cap"] == pytest.approx(e["xgmi_ingress_GBps_per_gpu"] / (7 * 76.8))
     assert c2["predicted_us_per_step"]["value"] > 0
     assert line["preflight"]["items"]["p2p"]["ok"] and not line["preflight"]["disabled"]
+    # the time budget: what the watchdogs alone would allow is stated, and the run stayed inside the budget
+    tb = line["time_budget"]
+    assert tb["time_budget_s"] == 840.0 and tb["unbounded_s"] > tb["time_budget_s"] and 0 < tb["used_s"] < tb["time_budget_s"]
+    assert line["preflight"]["time_budget"]["unbounded_s"] == tb["unbounded_s"]
+
+
+def test_a_spent_time_budget_skips_the_rest_and_says_so(tmp_path):
+    """--time-budget: with (almost) nothing left the orchestrator starts no further children; the headline configuration's first
+    protocols are measured, what was skipped is named -- on every rank alike (the ranks agree on the remaining time)"""
+    r, lines = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--time-budget", "40", "--no-preflight"], tmp_path,
+                    extra_env={"EMX_BENCH_STUB_SLEEP": "2.0"})          # 2 s per measurement: the budget's last 30 s are reached after ~5 of 18
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(lines[-1])
+    skipped = [(k, ex) for k, e in line["multi_gpu"].items() for ex, v in e["exchange"].items() if "time budget" in str(v.get("error", ""))]
+    measured = [(k, ex) for k, e in line["multi_gpu"].items() for ex, v in e["exchange"].items() if "ms_per_step" in v]
+    assert measured and skipped and line["value"] > 0
+    assert line["time_budget"]["used_s"] < 120.0
+    seen = _ranks_seen(tmp_path)
+    assert len({tuple((d["key"], d["ex"]) for d in v) for v in seen.values()}) == 1
 
 
 def test_torchrun_path_is_the_same_code(tmp_path):
