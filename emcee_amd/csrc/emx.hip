@@ -361,7 +361,7 @@ struct emx_ctx {
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
     int64_t tune_mt_device_min = 131072; // (measured: the host pipeline is faster below ~10^5 walkers, profiles/r04/mtdev_sizes.txt)
     int64_t tune_mt_lookahead = 2;       // batches the device producer is asked to run ahead of the consumer (0 .. 2)
-    int64_t tune_mt_tok_wshift = 12, tune_mt_tok_tail = 2048;      // the device tokenizer's window rule (emx_mtdev_kernels.hpp)
+    int64_t tune_mt_tok_wshift = 11, tune_mt_tok_tail = 2048;      // the device tokenizer's window rule (emx_mtdev_kernels.hpp)
     int64_t mtdev_steps_total = 0, mtdev_starts = 0;
     bool mtdev_defer_release = false;
     int64_t mtdev_release_pending = -1;

@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstring>
 
-#include "emx_mtdev_kernels.hpp"       // (-DEMX_TOK_PROFILE: walk / scan ticks of the tokenizer's first wave on stderr)
+#include "emx_mtdev_kernels.hpp"        // (-DEMX_TOK_PROFILE: where the first wave of the tokenizer spends a round, on stderr)       // (-DEMX_TOK_PROFILE: walk / scan ticks of the tokenizer's first wave on stderr)
 #include "emx_mtjump.hpp"
 
 namespace emx {
@@ -53,7 +53,7 @@ struct MtDevProducer::Impl {
     WalkRec* recs[2] = {nullptr, nullptr};     // [BATCH][maxrec] walk records of the tokenizer (per batch parity)
     uint32_t* nrec[2] = {nullptr, nullptr};    // [BATCH]
     int32_t maxrec = 0, nchunk = 0;
-    int32_t wshift = 12, tail = 2048;          // the tokenizer's window rule (emx_mtdev_kernels.hpp)
+    int32_t wshift = 11, tail = 2048;          // the tokenizer's window rule (emx_mtdev_kernels.hpp)
     uint32_t *fin_partial = nullptr, *fin_hist = nullptr;
     unsigned long long *tokpos[2] = {nullptr, nullptr}, *step_end[MTDEV_NBUF] = {};
     unsigned long long* h_end = nullptr;       // pinned [NBUF][BATCH]: step end positions of the batch in that buffer
@@ -146,7 +146,7 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         MTD_HIP(hipMalloc((void**)&m.polys, (size_t)(PMAX - 1) * MT_N * 4));
         MTD_HIP(hipMalloc((void**)&m.d_pos, 8));
         MTD_HIP(hipMalloc((void**)&m.d_err, 4));
-        MTD_HIP(hipMalloc((void**)&m.d_nwin, 96));
+        MTD_HIP(hipMalloc((void**)&m.d_nwin, 128));
         for (int k = 0; k < 2; ++k) {
             MTD_HIP(hipMalloc((void**)&m.J[k], (size_t)MTDEV_BATCH * N * 4));
             MTD_HIP(hipMalloc((void**)&m.rint[k], (size_t)MTDEV_BATCH * N * 4));
@@ -181,7 +181,7 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         const unsigned long long p0 = (unsigned long long)start.pos;
         MTD_HIP(hipMemcpy(m.d_pos, &p0, 8, hipMemcpyHostToDevice));
         MTD_HIP(hipMemset(m.d_err, 0, 4));
-        MTD_HIP(hipMemset(m.d_nwin, 0, 96));
+        MTD_HIP(hipMemset(m.d_nwin, 0, 128));
         m.known = -1;
         m.known_pos = p0;
         m.gen_words = 0;
@@ -216,8 +216,11 @@ MtDevProducer::~MtDevProducer() {
 void MtDevProducer::refresh_stats() {
     Impl& m = *im_;
     if (hipSetDevice(m.device) != hipSuccess || hipStreamSynchronize(m.s_tok) != hipSuccess) return;
-    unsigned long long nw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpy(nw, m.d_nwin, 96, hipMemcpyDeviceToHost) == hipSuccess) {
+    unsigned long long nw[16] = {};
+    if (hipMemcpy(nw, m.d_nwin, 128, hipMemcpyDeviceToHost) == hipSuccess) {
+#ifdef EMX_TOK_PROFILE
+        fprintf(stderr, "mtdev tok profile (10 ns ticks, wave 0): guess/loop %llu  walk %llu  scan+barrier %llu  check+barrier %llu  record %llu\n", nw[8], nw[9], nw[10], nw[11], nw[12]);
+#endif
         for (int k = 0; k < 4; ++k) st_.tok_ticks[k] = (int64_t)nw[4 + k];
 #ifdef EMX_TOK_PROFILE
         fprintf(stderr, "mtdev tok profile: wave-0 walks %llu, %llu ticks; scans %llu ticks\n", nw[8], nw[9], nw[10]);

@@ -151,7 +151,7 @@ static __global__ __launch_bounds__(256) void k_mt_gen(const GenArgs A) {
 // IS the serial result (thread 0 is exact at once, thread k once the threads before it are).  A thread recomputes only when its
 // count of earlier accepts has moved further than the smallest distance of any of its tests from the other decision (its margin).
 // How fast this settles is a matter of how many tests a unit shift flips: 2 x window / mask.  So the window shrinks with the mask
-// (wpt = 13, 7, 3, 1 -- odd: conflict-free LDS rows), and the last few thousand indices, where even 1024 words are too many, are
+// (wpt = 13, 7, 3, 1 -- odd: conflict-free LDS rows; wshift 11: 13 words a thread down to mask 2^15, 7 at 2^14, 3 at 2^13), and the last few thousand indices, where even 1024 words are too many, are
 // walked by ONE wave, 64 words at a time, the same fixed point taken with ballots instead of barriers.
 //
 // What it leaves behind for the (parallel) finisher are WALK RECORDS: for every window, where it starts and, per thread, the state
@@ -183,7 +183,7 @@ struct TokArgs {
     unsigned long long* step_end;      // [nb]: position after the step
     unsigned long long* stats;         // [8] windows | fixed-point rounds | tail groups | tail rounds | 10 ns ticks: waiting for a window | deciding chunk windows | the tail | whole kernel
     int32_t N, S, nb, randomize, maxrec;
-    int32_t wshift;                    // words per thread = (mask + 1) >> wshift, rounded down to 13 / 7 / 3 / 1
+    int32_t wshift;                    // words per thread = (mask + 1) >> wshift (default 11), rounded down to 13 / 7 / 3 / 1
     int32_t tail;                      // indices at or below this are walked by one wave
 };
 
@@ -297,6 +297,7 @@ __device__ __forceinline__ void tok_window_wait() { __builtin_amdgcn_s_waitcnt(0
 static __global__ __launch_bounds__(TOK_T) void k_mt_tok(const TokArgs A) {
     __shared__ uint32_t win2[2][TOK_W_MAX];
     __shared__ uint32_t sbuf[2][16];
+    __shared__ uint32_t sflag[2][16];
     __shared__ unsigned long long s_end;          // words consumed by the window that finished a scan
     __shared__ uint32_t s_i0;                     // the tail's index when it leaves a window
     const int tid = threadIdx.x, lane = tid & 63;
@@ -306,6 +307,12 @@ static __global__ __launch_bounds__(TOK_T) void k_mt_tok(const TokArgs A) {
     unsigned long long nwin = 0, nround = 0, ngroup = 0, ntround = 0;
     unsigned long long t_wait = 0, t_chunk = 0, t_tail = 0;
     const unsigned long long t_begin = wall_clock64();
+#ifdef EMX_TOK_PROFILE
+    unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}, pq = 0;
+#define TOKP(k_) do { const unsigned long long t_ = wall_clock64(); pf[k_] += t_ - pq; pq = t_; } while (0)
+#else
+#define TOKP(k_) do { } while (0)
+#endif
 #ifdef EMX_TOK_PROFILE
     unsigned long long t_walk0 = 0, n_walk0 = 0, t_scan0 = 0;
 #endif
@@ -395,6 +402,9 @@ static __global__ __launch_bounds__(TOK_T) void k_mt_tok(const TokArgs A) {
                     t_tail += wall_clock64() - tw1;
                     continue;
                 }
+#ifdef EMX_TOK_PROFILE
+                pq = wall_clock64();
+#endif
                 const uint32_t* mine = win + tid * wpt;
                 // a guess of the accepts before this thread's words: rate (i0 + 1) / (m + 1), falling as i does
                 uint32_t base;
@@ -407,41 +417,40 @@ static __global__ __launch_bounds__(TOK_T) void k_mt_tok(const TokArgs A) {
                 }
                 uint32_t cnt = 0, base_used = 0;
                 int margin = 0;
-                bool have = false, changed = true;
+                bool have = false;
                 uint32_t total = 0;
                 for (int iter = 0;; ++iter) {
-                    if (iter > 2 * TOK_T + 4) {                     // (cannot happen: thread k is exact after k + 1 rounds)
+                    if (iter > TOK_T + 4) {                         // (cannot happen: thread k is exact after k + 1 rounds)
                         dead = true;
                         break;
                     }
                     ++nround;
+                    TOKP(0);          // guess / loop overhead
+                    {
+                        const int dlt = (int)(base - base_used);
+                        const int adl = dlt < 0 ? -dlt : dlt;
+                        if (!have || (adl != 0 && (adl >= margin || (int)i0 - (int)base_used <= 0))) {
+                            cnt = tok_walk_count(mine, wpt, (int)i0 - (int)base, margin);
+                            base_used = base;
+                            have = true;
+                        }
+                    }
+                    TOKP(1);          // walk (this wave's)
+                    bool dummy;
+                    base = wg_exscan1024(cnt, false, sbuf[par], total, dummy);
+                    TOKP(2);          // scan + barrier (waits for the slowest wave's walk)
+                    par ^= 1;
+                    // Done when every thread's count still holds for the base the scan just gave it (inside its margin): the counts
+                    // then ARE those of these bases -- the fixed point -- and no further scan is needed to see it.
                     const int dlt = (int)(base - base_used);
                     const int adl = dlt < 0 ? -dlt : dlt;
-#ifdef EMX_TOK_PROFILE
-                    const unsigned long long tq0 = wall_clock64();
-                    const bool anyneed = __ballot(!have || (adl != 0 && (adl >= margin || (int)i0 - (int)base_used <= 0))) != 0ull;
-#endif
-                    if (!have || (adl != 0 && (adl >= margin || (int)i0 - (int)base_used <= 0))) {
-                        cnt = tok_walk_count(mine, wpt, (int)i0 - (int)base, margin);
-                        base_used = base;
-                        have = true;
-                    }
-#ifdef EMX_TOK_PROFILE
-                    const unsigned long long tq1 = wall_clock64();
-                    if (anyneed) {
-                        t_walk0 += tq1 - tq0;
-                        ++n_walk0;
-                    }
-#endif
-                    bool any;
-                    const uint32_t nb_ = wg_exscan1024(cnt, changed, sbuf[par], total, any);
-                    par ^= 1;
-#ifdef EMX_TOK_PROFILE
-                    t_scan0 += wall_clock64() - tq1;
-#endif
-                    if (iter > 0 && !any) break;                    // nobody's base moved last round: this scan repeats it -- the fixed point
-                    changed = nb_ != base;
-                    base = nb_;
+                    const bool again = adl != 0 && (adl >= margin || (int)i0 - (int)base_used <= 0);
+                    const unsigned long long bal = __ballot(again);
+                    if (lane == 0) sflag[par][tid >> 6] = bal != 0ull;
+                    __syncthreads();
+                    const bool any = (__ballot(sflag[par][lane & 15] != 0u) & 0xffffull) != 0ull;
+                    TOKP(3);          // margin check + barrier
+                    if (!any) break;
                 }
                 if (dead) break;
                 // the counts are now those of the serial scan
@@ -474,6 +483,7 @@ static __global__ __launch_bounds__(TOK_T) void k_mt_tok(const TokArgs A) {
                     p += (unsigned long long)W;
                     i0 -= total;
                 }
+                TOKP(4);              // record, bookkeeping
                 t_chunk += wall_clock64() - tw1;
             }
             tok_window_wait();                                      // (the dropped prefetch has landed before its buffer is used again)
@@ -571,6 +581,9 @@ static __global__ __launch_bounds__(TOK_T) void k_mt_tok(const TokArgs A) {
             A.stats[5] += t_chunk;
             A.stats[6] += t_tail;
             A.stats[7] += wall_clock64() - t_begin;
+#ifdef EMX_TOK_PROFILE
+            for (int k = 0; k < 5; ++k) A.stats[8 + k] += pf[k];
+#endif
 #ifdef EMX_TOK_PROFILE
             A.stats[8] += n_walk0;
             A.stats[9] += t_walk0;
