@@ -222,9 +222,6 @@ void MtDevProducer::refresh_stats() {
         fprintf(stderr, "mtdev tok profile (10 ns ticks, wave 0): guess/loop %llu  walk %llu  scan+barrier %llu  check+barrier %llu  record %llu\n", nw[8], nw[9], nw[10], nw[11], nw[12]);
 #endif
         for (int k = 0; k < 4; ++k) st_.tok_ticks[k] = (int64_t)nw[4 + k];
-#ifdef EMX_TOK_PROFILE
-        fprintf(stderr, "mtdev tok profile: wave-0 walks %llu, %llu ticks; scans %llu ticks\n", nw[8], nw[9], nw[10]);
-#endif
         st_.windows = (int64_t)nw[0];
         st_.tok_rounds = (int64_t)nw[1];
         st_.tail_groups = (int64_t)nw[2];
