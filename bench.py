@@ -351,12 +351,14 @@ def cpu_baseline(wl, budget_s=14.0):
 
 
 # ------------------------------------------------------------------------------------------------ single-GPU measurement
-def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=False, want_kernel=True, spin_s=0.15):
+def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=False, want_kernel=True, spin_s=0.15, tuning=None):
     """W warm-up steps, then K-step blocks (each: sync, hipEvent + wall clock around emx_run(K), sync) until >= 50 ms;
     median block.  Returns per-step times, per-launch event duration of the half-step kernel, accept fraction."""
     from emcee_amd.device import DeviceEnsemble
     ens = DeviceEnsemble(wl.N, wl.D, device=device)
     wl.install(ens, rng)
+    for key, val in (tuning or {}).items():
+        ens.set_tuning(key, val)
     if store:
         ens.chain_config(max(K, W))
     # untimed spin-up: the first ~50 ms on a fresh context run slower (clock ramp, first touch of the plan ring, lazy
@@ -401,6 +403,10 @@ def measure_single(wl, K, W, device=0, rng="philox", store=False, single_block=F
             res["pipeline"] = ens.pipeline_stats()
         except Exception as e:  # noqa: BLE001
             log("pipeline stats unavailable:", e)
+        try:
+            res["mtdev"] = dict(ens.mtdev_info(), tokenizer=ens.mtdev_tok_stats())
+        except Exception as e:  # noqa: BLE001
+            log("device producer stats unavailable:", e)
     if want_kernel:
         # per-launch hipEvent durations of the half-step kernel (separate pass: event records perturb)
         if persistent and rng == "philox":
@@ -531,6 +537,38 @@ def exact_mode_entry(wl, K, W, device):
                     "finisher threads -- six where the L3 domain has room -- confined to that domain, uploads on a side stream), so ms_per_step is the pipeline's rate; "
                     "pipeline_stage_us_per_step says which stage bounds it on THIS host (the stages run concurrently: the largest of "
                     "generator / tokenizer / finishers-summed over the thread count is the pipeline's floor)"}
+
+
+def exact_mode_large_entry(K, W, device):
+    """rng=mt19937 at C3's size (262 144 x 32 Rosenbrock): the ensemble size from which the plans of the reference's own stream are
+    made ON THE DEVICE (csrc/emx_mtdev.hpp: jump-ahead MT19937 segments, tokenizer and finisher kernels; no host thread touches a
+    draw), next to the host pipeline on the same box (tuning mt_device = 0)."""
+    wl = Workload("c3", 262144)
+    Kx = max(50, min(K, 200))
+    out = {"workload": wl.label + ", rng=mt19937 (NumPy legacy stream, chain identical to reference emcee's)", "steps": Kx}
+    B = wl.bytes_per_update(False)
+    for name, tune in (("device_producer", {"mt_device": 1}), ("host_pipeline", {"mt_device": 0})):
+        res = measure_single(wl, Kx, max(W, 10), device=device, rng="mt19937", spin_s=0.05, want_kernel=False, tuning=tune)
+        wu = wl.N * Kx / res["wall_s"]
+        e = {"ms_per_step": res["wall_s"] * 1e3 / Kx, "wu_per_s": wu, "blocks_timed": res["blocks"], "device_status": res["status"],
+             "roofline_frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS, "accept_frac": res["accept_frac"]}
+        md = res.get("mtdev") or {}
+        if name == "device_producer":
+            e["host_threads"] = 0
+            e["producer_used"] = bool(md.get("steps", 0) > 0)
+            tk = md.get("tokenizer") or {}
+            if tk.get("windows"):
+                steps = max(1, md.get("steps", 1))
+                e["tokenizer_us_per_step"] = tk["kernel_us"] / steps
+                e["tokenizer_rounds_per_window"] = tk["rounds"] / float(tk["windows"])
+        else:
+            e["pipeline_stage_us_per_step"] = res.get("pipeline")
+        out[name] = e
+    if "ms_per_step" in out.get("device_producer", {}) and "ms_per_step" in out.get("host_pipeline", {}):
+        out["speedup_device_over_host"] = out["host_pipeline"]["ms_per_step"] / out["device_producer"]["ms_per_step"]
+    out["note"] = ("the tokenizer (the masked rejection of random.shuffle, red_blue.py:80: the one serial part of a step) bounds the device "
+                   "producer; below ~10^5 walkers the host pipeline is faster and stays the default (profiles/r04/mtdev_sizes.txt)")
+    return out
 
 
 def quality_entry(device, rng="philox"):
@@ -1367,7 +1405,8 @@ def main(argv=None):
                     if key == "w128":     # fused: HBM roofline as for C2; the contraction is 5.4 flop per byte here (C2: 2.7)
                         fl = float(w2.D) ** 2 + 3.0 * w2.D
                         cfgs[name]["roofline"]["mfma_f64_frac_wall_clock"] = cfgs[name]["wu_per_s"] * fl / 1e12 / MFMA_F64_PEAK_TFLOPS
-                        cfgs[name]["roofline"]["kernel"] = "emx::k_halfstep<16,2,4,STRETCH,DPB=8,LEAN> (144 f64 MFMAs per 16-row tile)"
+                        cfgs[name]["roofline"]["kernel"] = ("emx::k_halfstep_slab<DPB=8,STRETCH> (csrc/emx_slab.hip: the tile's proposals in registers, a "
+                                                            "32-column LDS slab, eight waves a CU; 144 f64 MFMAs per 16-row tile)")
                 except Exception as e:  # noqa: BLE001
                     cfgs[name] = {"error": repr(e)}
                     log("config %s failed: %r" % (name, e))
@@ -1377,6 +1416,10 @@ def main(argv=None):
                     line["exact_mode"] = exact_mode_entry(wl, K, W, local_rank)
                 except Exception as e:  # noqa: BLE001
                     line["exact_mode"] = {"error": repr(e)}
+                try:
+                    line["exact_mode_c3"] = exact_mode_large_entry(K, W, local_rank)
+                except Exception as e:  # noqa: BLE001
+                    line["exact_mode_c3"] = {"error": repr(e)}
                 try:
                     line["quality"] = quality_entry(local_rank)
                 except Exception as e:  # noqa: BLE001

@@ -12,9 +12,10 @@ DEPS = SRCS + HOST_SRCS + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.
                                                                   "emx_mtpipe.hpp", "emx_internal.hpp", "emx_launch.hpp", "emx_mtdev.hpp", "emx_mtdev_kernels.hpp",
                                                                   "emx_mtjump.hpp")] + [
     os.path.join(os.path.dirname(HERE), "include", "emx.h")]
-HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread"]
+HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-fvisibility=hidden"]
 # -ffp-contract=off: the proposal arithmetic must round like NumPy's separate multiply/subtract.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-fPIC"]
+# -fvisibility=hidden: the library exports the C ABI of include/emx.h and nothing else (the extern "C" regions push default visibility)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-Wno-constant-logical-operand", "-fPIC", "-fvisibility=hidden"]
 # emx_hot.hip (the headline kernel alone): the ILP instruction scheduler, +2.2 % there (csrc/emx_launch.hpp says why not everywhere)
 EXTRA_FLAGS = {"emx_hot.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 

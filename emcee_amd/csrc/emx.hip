@@ -1010,6 +1010,7 @@ int emx_internal_fail(emx_ctx* c, int code, const char* msg) {
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+#pragma GCC visibility push(default)
 extern "C" {
 
 const char* emx_version(void) { return "emx 0.1 (gfx950)"; }
@@ -4704,3 +4705,4 @@ int64_t emx_host_pull_capacity(int64_t nwalkers, int32_t world, int32_t nsplits,
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -249,6 +249,7 @@ double norm2(const std::vector<double>& x) {
 
 }  // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 int emx_fft_load(const char* libhipfft_path) {
@@ -479,3 +480,4 @@ int emx_walkers_independent(int32_t device, const double* coords, int64_t N, int
 }
 
 }  // extern "C"
+#pragma GCC visibility pop
