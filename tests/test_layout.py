@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.emx_version().startswith(b"emx")
 
 
+def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
+    """bench.py and its pieces (tools/benchkit/): the oracle / the materialised reference are the CPU baseline's, nothing else's"""
+    files = [os.path.join(ROOT, "bench.py")] + [os.path.join(ROOT, "tools", "benchkit", f) for f in os.listdir(os.path.join(ROOT, "tools", "benchkit"))
+                                                if f.endswith(".py")]
+    for path in files:
+        txt = open(path).read()
+        uses = bool(re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M)) or "ref_shim" in txt
+        assert uses == path.endswith(os.path.join("benchkit", "cpu.py")), path
+
+
 def test_product_never_imports_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "emcee_amd")):
