@@ -151,7 +151,9 @@ def test_device_plans_equal_the_host_twin(N, D, S, randomize, a, seed):
 
 
 @pytest.mark.parametrize("N,D,target,nsteps,store", [(8192, 64, "dense", 53, True), (16384, 5, "iso", 37, False), (65536, 64, "dense", 40, False),
-                                                     (10000, 64, "dense", 21, True)])
+                                                     (10000, 64, "dense", 21, True),
+                                                     (8192, 4, "iso", 650, False),          # 82 batches: the stream ring wraps ~ 14 times
+                                                     (131072, 4, "iso", 90, False)])        # the default size rule's first size
 def test_runs_equal_the_host_pipelines(N, D, target, nsteps, store):
     """emx_run (two calls: the producer carries over) with device-made plans against the same run with the host pipeline's:
     coordinates, log-probs, chain, accept counters and the final generator state, bit for bit"""
