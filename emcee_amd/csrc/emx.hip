@@ -357,6 +357,8 @@ struct emx_ctx {
     // exact-mode plans made on the device (emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica
     MtDevProducer* mtdev = nullptr;
     int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
+    int64_t tune_persist_local = 1;      // 0: never the one-XCD form of the persistent kernel
+    int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
     int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
     int64_t tune_mt_device_min = 131072; // (measured: the host pipeline is faster below ~10^5 walkers, profiles/r04/mtdev_sizes.txt)
@@ -473,6 +475,9 @@ struct emx_ctx {
     };
     PersistCapture* persist_cap = nullptr;      // launch_split fills this instead of launching
     unsigned* persist_bar = nullptr;
+    unsigned persist_lepoch = 0;         // barriers passed on the one-XCD form's flags
+    unsigned persist_hepoch = 0;         // handshakes of the one-XCD form counted so far
+    int64_t persist_local_launches = 0;
     unsigned* persist_ver = nullptr;  // (N) stamp of the half-step that last moved the walker
     unsigned persist_epoch = 0;
     unsigned persist_grid = 0;        // workgroups of the launches the barrier counters have counted so far
@@ -1352,6 +1357,14 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
         c->tune_persist = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)
+        c->tune_persist_local = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_local_max_walkers")) {
+        c->tune_persist_local_max = v;
         return 0;
     }
     if (!strcmp(key, "persist_gauss_wpb")) {       // waves per workgroup of the persistent Gaussian kernel: 1, 2, 4 or 8 (0: automatic)
@@ -2898,6 +2911,23 @@ static int persist_shape_of(int64_t N, int nsplits, int64_t cu) {
     if (tiles / wpb < 8) return 0;                              // (the barrier counts arrivals per XCD: every one of the eight needs a workgroup)
     return wpb;
 }
+// The one-XCD form (k_persist<..., LOCAL>): every workgroup on the 32 CUs of one XCD, one workgroup per CU at most -- ensembles of up
+// to 32 x 8 tiles per half-step (8 192 walkers in two splits, 16 384 in the snooker move's four -- capped at tune_persist_local_max).
+// -> waves per workgroup, 0: not this form
+static int persist_shape_local_of(int64_t N, int nsplits, int64_t cu) {
+    if (nsplits < 2 || N < 2 || (N % nsplits) != 0) return 0;
+    const int64_t own = N / nsplits;
+    if ((own % 16) != 0) return 0;
+    const int64_t tiles = own / 16, per_xcd = std::max<int64_t>(1, cu / 8);
+    for (int wpb = 1; wpb <= 8; wpb <<= 1)
+        if ((tiles % wpb) == 0 && tiles / wpb <= per_xcd) return tiles / wpb >= 2 ? wpb : 0;
+    return 0;
+}
+static bool persist_local_ok(const emx_ctx* c, const emx_move_desc& m) {
+    const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
+    return c->tune_persist_local != 0 && known && c->N <= c->tune_persist_local_max &&
+           persist_shape_local_of(c->N, m.nsplits, c->num_cu) != 0;
+}
 static int persist_shape(const emx_ctx* c, int nsplits) { return persist_shape_of(c->N, nsplits, c->num_cu); }
 
 // the moves k_persist has an instantiation for (the other moves of a mixture run their steps through the per-half-step launches)
@@ -2918,6 +2948,7 @@ static bool persist_grid_fits(const emx_ctx* cc, const emx_move_desc& m, int wpb
 static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
     const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
     if (!known) return false;
+    if (persist_local_ok(c, m)) return true;            // (one workgroup per CU of one XCD by construction)
     const int wpb = persist_shape(c, m.nsplits);
     return wpb != 0 && persist_grid_fits(c, m, wpb);
 }
@@ -3046,8 +3077,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         }
     }
     if (!c->persist_bar) {
-        HIPOK(c, hipMalloc((void**)&c->persist_bar, 10 * 32 * sizeof(unsigned)));
-        HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 10 * 32 * sizeof(unsigned), c->stream));
+        HIPOK(c, hipMalloc((void**)&c->persist_bar, 12 * 32 * sizeof(unsigned)));
+        HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 12 * 32 * sizeof(unsigned), c->stream));
         c->persist_epoch = 0;
     }
     if (!c->persist_ver) {
@@ -3076,6 +3107,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     lg.store = store;
     int launch_move = -1;                // EMX_MOVE_STRETCH, _DE or _SNOOKER: the move of every step of this launch
     int launch_S = 2;
+    bool launch_local = false;           // the one-XCD form: an eight times larger grid of which every eighth workgroup works
     while (i0 + steps < total && n + launch_S <= PERSIST_MAX_ITERS) {
         if (devp) {
             if (steps > 0 && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) break;      // one produced batch per launch
@@ -3091,7 +3123,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         if (launch_move < 0) {
             launch_move = c->moves[mvi].kind;
             launch_S = S;
-            c->persist_wpb = persist_shape(c, S);
+            launch_local = persist_local_ok(c, c->moves[mvi]);
+            c->persist_wpb = launch_local ? persist_shape_local_of(c->N, S, c->num_cu) : persist_shape(c, S);
         }
         for (int s = 0; s < S; ++s) {
             cap.got = false;
@@ -3130,17 +3163,26 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         if (rc) return rc;
         ++steps;
     }
+    if (launch_local) grid.x *= 8;
     if (grid.x != c->persist_grid) {
         // the arrival counters count workgroups: another grid size (another move of a mixture, another ensemble shape) starts them
         // afresh -- on the stream, i.e. after every earlier launch has left the barrier
-        HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 10 * 32 * sizeof(unsigned), c->stream));
+        HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 12 * 32 * sizeof(unsigned), c->stream));
         c->persist_epoch = 0;
+        c->persist_lepoch = 0;
+        c->persist_hepoch = 0;
         c->persist_grid = grid.x;
     }
     P.niter = n;
     P.bar = c->persist_bar;
     P.ver = c->persist_ver;
     P.epoch0 = c->persist_epoch + (unsigned)c->tune_persist_test_skew;      // (tests: a barrier that is never met)
+    P.lepoch0 = c->persist_lepoch;
+    P.hepoch0 = c->persist_hepoch + (unsigned)c->tune_persist_test_skew;
+    if (launch_local) {
+        c->persist_lepoch += (unsigned)(n - 1);
+        c->persist_hepoch += 1u;
+    }
     P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
     c->persist_epoch += (unsigned)n;          // the handshake and the n - 1 barriers between the half-steps
     P.seq = ++c->persist_seq;
@@ -3161,7 +3203,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             if (g_persist_last[dev] && g_persist_last[dev] != c) HIPOK(c, hipStreamWaitEvent(c->stream, g_persist_ev[dev], 0));
         }
         if (prof) HIPOK(c, hipEventRecord(e0, c->stream));
-        const hipError_t e = launch_hot_persist_dense(c->Dp / 16, launch_move, grid, block, lds, c->stream, P);
+        const hipError_t e = launch_hot_persist_dense(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
+        if (launch_local) c->persist_local_launches++;
         if (e != hipSuccess) FAIL(c, -2, "persistent half-step launch failed: %s", hipGetErrorString(e));
         if (prof) {
             HIPOK(c, hipEventRecord(e1, c->stream));
@@ -3211,8 +3254,10 @@ static int persist_settle(emx_ctx* c) {
         if ((int)(e.seq - done_seq) > 0) redo.push_back(e);
     c->plog.clear();
     // the barrier words restart, the status bit is taken back: nothing is void
-    HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 10 * 32 * sizeof(unsigned), c->stream));
+    HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 12 * 32 * sizeof(unsigned), c->stream));
     c->persist_epoch = 0;
+    c->persist_lepoch = 0;
+    c->persist_hepoch = 0;
     c->persist_grid = 0;
     __atomic_store_n(&c->status_host[3], 0u, __ATOMIC_RELEASE);
     if (redo.empty()) return 0;
@@ -3221,7 +3266,10 @@ static int persist_settle(emx_ctx* c) {
     const uint64_t ph_end = c->ph_step;
     for (const auto& m : c->moves) NEED(c, m.kind != EMX_MOVE_GAUSS, "persistent launches to redo in a mixture with a Gaussian move");
     drop_prepared(c);                         // (the ring slots of plans made ahead are about to be reused)
-    c->tune_persist = 0;                      // and it stays off: whatever held the CUs may still be there ("persist" = 1 turns it back on)
+    if ((w[2] & (w[2] - 1u)) != 0u)
+        c->tune_persist_local = 0;            // the one-XCD form's workgroups did not share an XCD: that form stays off ("persist_local" = 1)
+    else
+        c->tune_persist = 0;                  // and it stays off: whatever held the CUs may still be there ("persist" = 1 turns it back on)
     c->ph_step = redo.front().ph_step;
     c->stored = redo.front().stored0;
     c->proposals = redo.front().proposals0;
@@ -3315,6 +3363,11 @@ int emx_persist_info(emx_ctx* c, int64_t out[4]) {
     out[1] = c->persist_launches;
     out[2] = c->persist_halfsteps;
     out[3] = c->persist_recovered;       // launches that gave up untouched and were redone on the per-half-step path (persist_settle)
+    return 0;
+}
+
+int emx_persist_local_launches(emx_ctx* c, int64_t* n) {
+    *n = c->persist_local_launches;
     return 0;
 }
 

@@ -11,9 +11,9 @@ hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t ld
     return launch_one<8, 2, 4, MOVE_STRETCH, 4, 1>(grid, block, lds, st, a);
 }
 
-template <int G, int V, int CH, int DPB, int MOVE>
+template <int G, int V, int CH, int DPB, int MOVE, bool LOCAL = false>
 static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-    auto kern = k_persist<G, V, CH, DPB, MOVE>;
+    auto kern = k_persist<G, V, CH, DPB, MOVE, LOCAL>;
     static size_t lds_granted[MAX_DEVICES] = {};
     int dev = 0;
     if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
@@ -26,7 +26,17 @@ static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t 
 }
 
 // padded ndim 16 * dpb, even ndim (two coordinates per lane): rows of 8 lanes, dpb = 1 ... 4
-hipError_t launch_hot_persist_dense(int dpb, int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+hipError_t launch_hot_persist_dense(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+    if (local) {          // the one-XCD form
+#define EMX_LCASE(b, ch)                                                                                           \
+    if (dpb == b)                                                                                                  \
+        return move == MOVE_DE        ? launch_persist<8, 2, ch, b, MOVE_DE, true>(grid, block, lds, st, P)        \
+               : move == MOVE_SNOOKER ? launch_persist<8, 2, ch, b, MOVE_SNOOKER, true>(grid, block, lds, st, P)   \
+                                      : launch_persist<8, 2, ch, b, MOVE_STRETCH, true>(grid, block, lds, st, P);
+        EMX_LCASE(1, 1) EMX_LCASE(2, 2) EMX_LCASE(3, 4) EMX_LCASE(4, 4)
+#undef EMX_LCASE
+        return hipErrorInvalidValue;
+    }
 #define EMX_CASE(b, ch)                                                                                            \
     if (dpb == b)                                                                                                  \
         return move == MOVE_DE        ? launch_persist<8, 2, ch, b, MOVE_DE>(grid, block, lds, st, P)              \

@@ -1194,7 +1194,8 @@ static __global__ __launch_bounds__(512) void k_halfstep(const HalfStepArgs A) {
 // With both, ordinary device memory is as good as uncached memory (profiles/r03/persist_coherence.txt).
 typedef unsigned int emx_u4 __attribute__((ext_vector_type(4)));
 constexpr int EMX_CPOL_SC1 = 16;
-template <int G, int V, int CH>
+// CPOL: EMX_CPOL_SC1 (agent scope) or 0 (plain: the one-XCD form's stores)
+template <int G, int V, int CH, int CPOL = EMX_CPOL_SC1>
 __device__ __forceinline__ void load_row_agent(Row<G, V, CH>& r, __amdgpu_buffer_rsrc_t rsrc, int row, int D, int gl) {
     static_assert(V == 2, "two coordinates per lane and chunk");
     const int base = row * D;
@@ -1202,7 +1203,7 @@ __device__ __forceinline__ void load_row_agent(Row<G, V, CH>& r, __amdgpu_buffer
     for (int c = 0; c < CH; ++c) {
         const int d = (c * G + gl) * V;
         if (d + 1 < D) {
-            const emx_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + d) * 8, 0, EMX_CPOL_SC1);
+            const emx_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (base + d) * 8, 0, CPOL);
             double2 t;
             __builtin_memcpy(&t, &w, 16);
             r.x[c][0] = t.x;
@@ -1213,7 +1214,7 @@ __device__ __forceinline__ void load_row_agent(Row<G, V, CH>& r, __amdgpu_buffer
         }
     }
 }
-template <int G, int V, int CH>
+template <int G, int V, int CH, int CPOL = EMX_CPOL_SC1>
 __device__ __forceinline__ void store_row_agent(const Row<G, V, CH>& r, __amdgpu_buffer_rsrc_t rsrc, int row, int D, int gl) {
     static_assert(V == 2, "two coordinates per lane and chunk");
     const int base = row * D;
@@ -1224,7 +1225,7 @@ __device__ __forceinline__ void store_row_agent(const Row<G, V, CH>& r, __amdgpu
             const double2 t = {r.x[c][0], r.x[c][1]};
             emx_u4 w;
             __builtin_memcpy(&w, &t, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (base + d) * 8, 0, EMX_CPOL_SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (base + d) * 8, 0, CPOL);
         }
     }
 }
@@ -1232,6 +1233,14 @@ template <typename T>
 __device__ __forceinline__ void store_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double load_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned load_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the same with the scope as a template parameter (LOCAL: the one-XCD form -- plain accesses)
+template <bool LOCAL, typename T>
+__device__ __forceinline__ void store_scope(T* p, T v) {
+    if constexpr (LOCAL)
+        *p = v;               // (plain: ordered before the barrier's flag store by the s_waitcnt in front of it)
+    else
+        store_agent(p, v);
+}
 
 constexpr int PERSIST_MAX_ITERS = 32;
 struct PersistIter {
@@ -1243,13 +1252,48 @@ struct PersistIter {
 struct PersistArgs {
     HalfStepArgs base;
     PersistIter it[PERSIST_MAX_ITERS];
-    unsigned* bar;                 // [8][32] per-XCD arrival counters | [32] global counter | [32] go word
+    unsigned* bar;                 // [8][32] per-XCD arrival counters | [32] global counter | [32] go word (go, dead, XCD mask, seq) | [32] [32] the one-XCD form's counter and go word
     unsigned* ver;                 // (N) stamp of the half-step that last moved the walker
     unsigned epoch0;               // barriers already passed on these counters
+    unsigned lepoch0;              // the one-XCD form: barriers already passed on ITS flags (the handshake does not count there)
+    unsigned hepoch0;              // the one-XCD form: handshakes already counted (they alone use the arrival counter)
     unsigned long long timeout_ticks;
     int32_t niter;
     unsigned seq;                  // number of this launch (left in the barrier block's fourth `go` word once its grid is known co-resident)
 };
+
+// The one-XCD form's barrier: every workgroup of the grid runs on ONE XCD (k_persist<..., LOCAL>), so its L2 is the point of
+// coherence.  What that allows was measured flavour by flavour (tools/exp/xcd_local_probe.hip, profiles/r04/xcd_local_probe.txt):
+// read-modify-write atomics are executed beyond the L2 (polls of the L2 never see them); plain or sc0 loads are served stale whatever
+// is invalidated; but a PLAIN store is in the L2 when it is acknowledged, and an agent-scope (sc1) load of a line this XCD wrote is
+// answered by that L2 -- 0.32 us for a whole flag barrier of 32 workgroups against 2.5 us device-wide.  So: workgroup g stores the
+// barrier's index into word g of one line, the first wave of every workgroup polls the line with sc1 loads, one word a lane.
+__device__ __forceinline__ void persist_barrier_local(const PersistArgs& P, unsigned k, unsigned bid, unsigned ngroups) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits have reached the L2
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const __amdgpu_buffer_rsrc_t Fr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.bar + 10 * 32), 0, 64 * 4, 0x00020000);
+        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(k, Fr, (int)bid * 4, 0, 0);
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+            // words 0 .. 31: the workgroups' flags; word 32: set by a workgroup whose wait timed out (the run is void: pass)
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(Fr, lane * 4, 0, EMX_CPOL_SC1);
+            const bool ok = lane < (int)ngroups ? (int)(v - k) >= 0 : true;
+            const bool dead = lane == 32 && v != 0u;
+            if (__ballot(ok) == ~0ull || __ballot(dead) != 0ull) break;
+            if (wall_clock64() - t0 > P.timeout_ticks) {
+                if (lane == 0) {
+                    raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
+                    __hip_atomic_store(P.bar + 9 * 32 + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // 2: in the middle of a launch
+                    __builtin_amdgcn_raw_buffer_store_b32(1u, Fr, 32 * 4, 0, 0);
+                }
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
 
 __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits (agent-scope stores) are visible to the device
@@ -1287,12 +1331,16 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
 // up with the ensemble untouched: the dead mark (1: clean) sends home the workgroups that start later and every launch queued
 // behind this one, and the host redoes those launches' steps on the per-half-step path (persist_recover, emx.hip).
 // -> false: leave without a store.
+// LOCAL (the one-XCD form): only the workgroups with blockIdx & 7 == 0 get here; they count in ONE agent-scope counter (once per
+// launch: it need not be cheap), each adds the XCD it really runs on to a mask, and the last arriver opens the barrier only when the
+// mask names a single XCD -- otherwise the launch gives up, untouched, exactly like a grid that could not become co-resident.
+template <bool LOCAL = false>
 __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
     __shared__ int ok_s;
     if (threadIdx.x == 0) {
-        const unsigned k = P.epoch0 + 1u;
-        const int xcd = blockIdx.x & 7;
-        const unsigned per = (gridDim.x + 7 - xcd) / 8;
+        const unsigned k = LOCAL ? P.hepoch0 + 1u : P.epoch0 + 1u;
+        const int xcd = LOCAL ? 0 : (int)(blockIdx.x & 7);
+        const unsigned per = LOCAL ? gridDim.x >> 3 : (gridDim.x + 7 - xcd) / 8;
         unsigned* xctr = P.bar + xcd * 32;
         unsigned* gctr = P.bar + 8 * 32;
         unsigned* go = P.bar + 9 * 32;
@@ -1301,10 +1349,27 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
         if ((v0 >> 32) != 0ull) {
             ok = 0;                                                 // an earlier launch gave up: not even counted
         } else {
+            if constexpr (LOCAL) {
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                __hip_atomic_fetch_or(go + 2, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the mark is in before this workgroup counts as arrived
+            }
             const unsigned old = __hip_atomic_fetch_add(xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == k * per - 1) {
-                const unsigned o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (o2 == k * 8 - 1) {
+                bool open = true;
+                unsigned o2 = k * 8 - 1;
+                if constexpr (LOCAL) {
+                    const unsigned m = __hip_atomic_load(go + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    open = (m & (m - 1u)) == 0u;                                   // one XCD
+                    if (!open) {                                                   // report it like a grid that never became co-resident
+                        raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
+                        __hip_atomic_store(go + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // 1: nothing was written
+                    }
+                } else {
+                    o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (open && o2 == k * 8 - 1) {
                     __hip_atomic_store(go + 3, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // this launch will run to its end
                     __hip_atomic_store(go, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1331,9 +1396,17 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
     return ok_s != 0;
 }
 
-template <int G, int V, int CH, int DPB, int MOVE = MOVE_STRETCH>
+template <int G, int V, int CH, int DPB, int MOVE = MOVE_STRETCH, bool LOCAL = false>
 static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     static_assert(MOVE == MOVE_STRETCH || MOVE == MOVE_DE || MOVE == MOVE_SNOOKER, "the red / blue moves");
+    // LOCAL: the one-XCD form for small ensembles.  The dispatcher deals workgroups to the eight XCDs in turn (workgroup i -> XCD
+    // i mod 8: tools/exp/cu_mask_probe.hip), so of an eight times larger grid only every eighth workgroup works -- all of them on one
+    // XCD, whose L2 then keeps the walker state coherent without agent-scope accesses (3.0 + 2.5 us of partner round trip and barrier
+    // per half-step in the device-wide form, profiles/r04/persist_phase_c2.txt).  The handshake checks that they really share one.
+    if (LOCAL && (blockIdx.x & 7u) != 0u) return;
+    const unsigned bid = LOCAL ? blockIdx.x >> 3 : blockIdx.x, ngroups = LOCAL ? gridDim.x >> 3 : gridDim.x;
+    constexpr int CPOL = EMX_CPOL_SC1;                       // loads: agent scope in both forms (answered by the L2 in the one-XCD form)
+    constexpr int CPOL_ST = LOCAL ? 0 : EMX_CPOL_SC1;       // stores: plain in the one-XCD form (in the L2 when acknowledged)
     constexpr bool DE = MOVE == MOVE_DE || MOVE == MOVE_SNOOKER;   // de.py:40-64: two partners, q = s + gamma (c[pair 1] - c[pair 0])
     constexpr bool SN = MOVE == MOVE_SNOOKER;          // de_snooker.py:31-46: three partners z, z1, z2 (one from each other set)
     constexpr bool DEFER = !DE;                        // chain rows one half-step later (the other forms have no registers to spare)
@@ -1363,8 +1436,8 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     }
     Row<G, V, CH> mu;
     load_row<G, V, CH>(mu, A.tp0, D, gl);
-    if (!persist_handshake(P)) return;                          // (also the workgroup barrier behind the image load)
-    const int wave = blockIdx.x * (blockDim.x >> 6) + wib;
+    if (!persist_handshake<LOCAL>(P)) return;                   // (also the workgroup barrier behind the image load)
+    const int wave = (int)bid * (blockDim.x >> 6) + wib;
     const int t0 = wave * 16;                                   // this wave's slots of every split
     // instrumented build only (tools/persist_phase_clock.py, -DEMX_OPT_STAMPS=1): where the first wave of every workgroup spends a
     // half-step -- ticks summed over the launch's half-steps: partner rows arrive | proposals + tile | MFMA + reductions |
@@ -1373,7 +1446,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     const bool prof = EMX_OPT_STAMPS && A.dbg && wib == 0;
     if (prof) {
         pt = __builtin_readcyclecounter();
-        if (lane == 0) A.dbg[(size_t)blockIdx.x * 16 + 11] = wall_clock64();
+        if (lane == 0) A.dbg[(size_t)bid * 16 + 11] = wall_clock64();
     }
 #define EMX_PSTAMP(k_)                                                   \
     do {                                                                 \
@@ -1406,7 +1479,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         my_i = I.order[pbase + myrow];
         my_logu = I.logu[pbase + myrow];
 #pragma unroll
-        for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH>(xi[k], Xr, wi[k], D, gl);
+        for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH, CPOL>(xi[k], Xr, wi[k], D, gl);
         my_lpo = load_agent(A.lp + my_i);
     }
     // stored steps: the rows (and log-probs) of a half-step leave one half-step later
@@ -1425,9 +1498,9 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         Row<G, V, CH> xa[PF], xb[DE ? PF : 1], xc[SN ? PF : 1];
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            load_row_agent<G, V, CH>(xa[k], Xr, ja[k], D, gl);
-            if constexpr (DE) load_row_agent<G, V, CH>(xb[k], Xr, jb[k], D, gl);
-            if constexpr (SN) load_row_agent<G, V, CH>(xc[k], Xr, jc[k], D, gl);
+            load_row_agent<G, V, CH, CPOL>(xa[k], Xr, ja[k], D, gl);
+            if constexpr (DE) load_row_agent<G, V, CH, CPOL>(xb[k], Xr, jb[k], D, gl);
+            if constexpr (SN) load_row_agent<G, V, CH, CPOL>(xc[k], Xr, jc[k], D, gl);
         }
         // -------- plan entries of the next half-step (written by the plan kernel before this launch) --------
         const bool more = n + 1 < P.niter;
@@ -1500,7 +1573,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         double my_lpo_n = 0.0;
         if (more) {
 #pragma unroll
-            for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH>(xi[k], Xr, wi_n[k], D, gl);
+            for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH, CPOL>(xi[k], Xr, wi_n[k], D, gl);
             my_lpo_n = load_agent(A.lp + my_i_n);
         }
         EMX_WAVE_SYNC();
@@ -1534,17 +1607,17 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);
             const double lnpdiff = facS[myrow] + lpn - my_lpo;
             acc = lnpdiff > my_logu;
-            store_agent(A.acc + my_i, (uint8_t)(acc ? 1 : 0));       // (a walker's mark is written by another XCD every step: write-through)
+            store_scope<LOCAL>(A.acc + my_i, (uint8_t)(acc ? 1 : 0));       // (a walker's mark is written by another XCD every step: write-through)
             if (acc) {
-                store_agent(A.lp + my_i, lpn);
-                store_agent(P.ver + my_i, stamp);
+                store_scope<LOCAL>(A.lp + my_i, lpn);
+                store_scope<LOCAL>(P.ver + my_i, stamp);
             }
             if (I.chain_lp) {
                 if constexpr (DEFER)
                     clp = acc ? lpn : my_lpo;
                 else
                     I.chain_lp[my_i] = acc ? lpn : my_lpo;
-                if (acc) store_agent(A.acc_count + my_i, load_agent(A.acc_count + my_i) + 1u);
+                if (acc) store_scope<LOCAL>(A.acc_count + my_i, load_agent(A.acc_count + my_i) + 1u);
             }
         }
         const unsigned long long am64 = __ballot(acc);           // bit (row & 3) * 16 + (row >> 2) <-> tile row
@@ -1553,7 +1626,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             const int row = pp * WPW + sub;
             const bool ac = (am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull;
             if (ac) {
-                store_row_agent<G, V, CH>(qk[pp], Xr, wi[pp], D, gl);
+                store_row_agent<G, V, CH, CPOL_ST>(qk[pp], Xr, wi[pp], D, gl);
                 if (I.chain) {
                     if constexpr (DEFER)
                         crow[pp] = qk[pp];
@@ -1576,7 +1649,10 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             EMX_PSTAMP(4);   // stores acknowledged (and the speculative own rows of the next half-step in)
         }
         if (!more) break;
-        persist_barrier(P, P.epoch0 + (unsigned)n + 2u);           // (+ 1: the handshake was this launch's first barrier)
+        if constexpr (LOCAL)
+            persist_barrier_local(P, P.lepoch0 + (unsigned)n + 1u, bid, ngroups);
+        else
+            persist_barrier(P, P.epoch0 + (unsigned)n + 2u);       // (+ 1: the handshake was this launch's first barrier)
         EMX_PSTAMP(5);       // device-wide barrier
         // -------- roll over --------
 #pragma unroll
@@ -1598,7 +1674,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             const unsigned vm = load_agent(P.ver + my_i);
 #pragma unroll
             for (int k = 0; k < PF; ++k)
-                if (vk[k] == stamp) load_row_agent<G, V, CH>(xi[k], Xr, wi[k], D, gl);
+                if (vk[k] == stamp) load_row_agent<G, V, CH, CPOL>(xi[k], Xr, wi[k], D, gl);
             if (vm == stamp) my_lpo = load_agent(A.lp + my_i);
         }
     }
@@ -1608,7 +1684,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         if (mine) cchain_lp[cmy_i] = clp;
     }
     if (prof && lane == 0) {
-        unsigned long long* o = A.dbg + (size_t)blockIdx.x * 16;
+        unsigned long long* o = A.dbg + (size_t)bid * 16;
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = pst[k];
         o[6] = (unsigned long long)P.niter;

@@ -566,7 +566,10 @@ class DeviceEnsemble:
         """persistent half-steps (include/emx.h emx_persist_info): does the configuration qualify, launches, half-steps they ran"""
         out = (C.c_int64 * 4)()
         self._ck(self.lib.emx_persist_info(self.ctx, out))
-        return {"qualifies": bool(out[0]), "launches": int(out[1]), "halfsteps": int(out[2]), "recovered": int(out[3])}
+        loc = C.c_int64(0)
+        self._ck(self.lib.emx_persist_local_launches(self.ctx, C.byref(loc)))
+        return {"qualifies": bool(out[0]), "launches": int(out[1]), "halfsteps": int(out[2]), "recovered": int(out[3]),
+                "local_launches": int(loc.value)}
 
     def mtdev_info(self):
         """exact-mode plans made on the device (include/emx.h emx_mtdev_info)"""

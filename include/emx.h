@@ -368,6 +368,11 @@ int emx_host_mt_jump(const uint32_t key[624], uint64_t stride_words, int32_t k, 
  *   out[0] 1 when the current configuration qualifies, out[1] persistent launches so far, out[2] half-steps they ran,
  *   out[3] reserved (0) */
 int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
+/* how many of those launches took the one-XCD form: ensembles of up to 8 192 walkers (stretch move, two splits) run an eight times
+ * larger grid of which every eighth workgroup works -- all on one XCD, whose L2 keeps the walker state coherent with plain accesses and
+ * a barrier of that XCD's own instead of agent-scope accesses and the device-wide barrier (tuning "persist_local" = 0: never;
+ * "persist_local_max_walkers"); same bits (red_blue.py:85,104: a half-step still sees every update of the one before) */
+int emx_persist_local_launches(emx_ctx* ctx, int64_t* n);
 /* host only: the grid the persistent kernel takes for `nwalkers` walkers updated in `nsplits` half-steps on a device of `num_cu`
  * CUs -- waves per workgroup (8 / 4 / 2 / 1; 0: no persistent grid, the per-half-step launches run) and workgroups */
 int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, int32_t* waves_per_group, int32_t* groups);

@@ -69,6 +69,42 @@ def test_persistent_kernel_gives_the_bits_of_the_launch_per_halfstep_path(N, D):
     assert np.array_equal(p["acc"], c["acc"])
 
 
+@pytest.mark.parametrize("N,D,store,thin_by,move", [(512, 64, False, 1, "stretch"), (1024, 64, True, 1, "stretch"), (2048, 32, False, 1, "stretch"),
+                                                    (4096, 48, True, 3, "stretch"), (8192, 64, False, 1, "stretch"), (8192, 16, False, 1, "stretch"),
+                                                    (1024, 62, False, 1, "stretch"), (6144, 64, True, 1, "stretch"),
+                                                    (1024, 64, False, 1, "de"), (4096, 32, True, 1, "de"), (8192, 64, False, 1, "de"),
+                                                    (2048, 64, False, 1, "snooker"), (8192, 48, True, 1, "snooker")])
+def test_one_xcd_form_and_device_wide_form_agree_with_the_launch_per_halfstep_path(N, D, store, thin_by, move):
+    """Ensembles of up to 8 192 walkers (stretch move) take the ONE-XCD form of the persistent kernel (k_persist<..., LOCAL>: an
+    eight times larger grid of which every eighth workgroup works, all on one XCD; plain stores, sc1 loads answered by that XCD's
+    L2, a flag barrier of its own -- include/emx.h emx_persist_local_launches); tuning persist_local = 0 keeps the device-wide
+    form.  Both must give the bits of the launch-per-half-step path: two calls of 37 steps (full and partial launches)."""
+    spec = full_spec(N, D, "dense", [S(move)], seed=3)
+    recs = {}
+    for name, persist, local in (("local", 1, 1), ("wide", 1, 0), ("plain", 0, 0)):
+        ens = native_ens(spec, persist)
+        ens.set_tuning("persist_local", local)
+        if store:
+            ens.chain_config(74)
+        for _ in range(2):
+            ens.run(37, thin_by, store)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=ens.persist_info())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, 74), chain_lp=ens.chain_read(1, 0, 74), counts=ens.accepted_counts())
+        ens.close()
+        recs[name] = rec
+    nl = recs["local"]["info"]
+    assert nl["local_launches"] == nl["launches"] > 0 and nl["recovered"] == 0
+    assert recs["wide"]["info"]["local_launches"] == 0 and recs["wide"]["info"]["launches"] > 0
+    assert recs["plain"]["info"]["launches"] == 0
+    for key in recs["plain"]:
+        if key != "info":
+            assert np.array_equal(recs["local"][key], recs["plain"][key]), "one-XCD form: " + key
+            assert np.array_equal(recs["wide"][key], recs["plain"][key]), "device-wide form: " + key
+
+
 @pytest.mark.parametrize("thin_by", [1, 3])
 def test_persistent_kernel_stores_the_chain(thin_by):
     """the chain row, its log-probs and the per-walker accept counters of stored steps (backend.py:229), two calls, thinning"""
@@ -270,9 +306,10 @@ def test_a_grid_that_cannot_become_co_resident_is_redone_not_void():
     again on the per-half-step path at the next sync / status / read: the same bits as a run that never tried, no status bit, no
     void state.  The wait is bounded by the wall clock (one time-out per run of launches, not one per barrier)."""
     import time
-    for store, thin_by in ((False, 1), (True, 2)):
+    for store, thin_by, local in ((False, 1, 1), (True, 2, 1), (False, 1, 0), (True, 2, 0)):       # (4 096 walkers: the one-XCD form unless told otherwise)
         spec = dense_spec(4096, 64, seed=11)
         ens = native_ens(spec, 1)
+        ens.set_tuning("persist_local", local)
         ref = native_ens(spec, 0)
         nst = 40
         for e in (ens, ref):
@@ -349,7 +386,8 @@ def test_sampler_runs_persistently(monkeypatch):
 
 
 @pytest.mark.parametrize("N,trials,store,thin_by", [(65536, 110, False, 1), (32768, 110, False, 1), (8192, 110, False, 1),
-                                                    (8192, 24, True, 1), (32768, 12, True, 3)])
+                                                    (8192, 24, True, 1), (32768, 12, True, 3),
+                                                    (2048, 150, False, 1), (512, 150, False, 1), (4096, 40, True, 1)])     # (<= 8192: the one-XCD form)
 def test_persistent_kernel_coherence_stress(N, trials, store, thin_by):
     """The class of bug profiles/r03/persist_coherence.txt records (a variant of k_persist's barrier / sc1 protocol that was wrong
     once in ~120 runs) does not show in a single 37-step run: many short runs do.  366 trials x 50 steps in all, fresh Philox
@@ -380,5 +418,6 @@ def test_persistent_kernel_coherence_stress(N, trials, store, thin_by):
             assert np.array_equal(a, b), "trial %d of %d: output %d of the persistent kernel differs from the per-half-step path" % (t, trials, k)
     p, c = ens[0].persist_info(), ens[1].persist_info()
     assert p["halfsteps"] == 2 * nsteps * thin_by * trials and c["launches"] == 0
+    assert (p["local_launches"] == p["launches"]) == (N <= 8192) and p["recovered"] == 0
     for e in ens:
         e.close()
