@@ -358,6 +358,7 @@ struct emx_ctx {
     MtDevProducer* mtdev = nullptr;
     int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
     int64_t tune_persist_local = 1;      // 0: never the one-XCD form of the persistent kernel
+    int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
     int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
     int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
@@ -861,6 +862,10 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
             return -1;
         }
     }
+    if (!dense && c->persist_cap) {          // k_persist_valu: a wave owns 16 slots of every split, persist_wpb waves a workgroup
+        spw = 16;
+        waves_per_block = c->persist_wpb;
+    }
     const int64_t nbatch = (nown + spw - 1) / spw;
     int64_t nblocks = (nbatch + waves_per_block - 1) / waves_per_block;
     if (dense) nblocks = std::min<int64_t>(nblocks, (int64_t)c->num_cu * c->tune_bpc);
@@ -1361,6 +1366,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)
         c->tune_persist_local = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_valu")) {      // 0: element-wise targets always on the per-half-step launches
+        c->tune_persist_valu = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "persist_local_max_walkers")) {
@@ -2949,6 +2958,7 @@ static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
     const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
     if (!known) return false;
     if (persist_local_ok(c, m)) return true;            // (one workgroup per CU of one XCD by construction)
+    if (c->target != EMX_TARGET_DENSE_GAUSS) return false;       // (element-wise targets: the one-XCD form or nothing)
     const int wpb = persist_shape(c, m.nsplits);
     return wpb != 0 && persist_grid_fits(c, m, wpb);
 }
@@ -2969,6 +2979,22 @@ static bool persist_wanted(const emx_ctx* c) {
     const Shape sh = pick_shape(c->D, c->Dp);
     const int dpb = c->Dp / 16;
     return sh.G == 8 && sh.V == 2 && sh.CH == (dpb == 1 ? 1 : dpb == 2 ? 2 : 4);
+}
+
+// The element-wise targets (csrc/emx_pvalu.hip): the one-XCD form only -- ensembles of up to 8 192 walkers, rows of 8 lanes per walker
+// (ndim <= 64 even, <= 32 odd), Philox plans, one replica, every move of the schedule one the kernel knows at a shape it can take.
+static bool persist_valu_wanted(const emx_ctx* c) {
+    if (!c->tune_persist || !c->tune_persist_local || !c->tune_persist_valu) return false;
+    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
+    if (c->target != EMX_TARGET_ISO_GAUSS && c->target != EMX_TARGET_DIAG_GAUSS && c->target != EMX_TARGET_ROSENBROCK && c->target != EMX_TARGET_BOX)
+        return false;
+    if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
+    if (c->N < c->tune_persist_min_walkers) return false;
+    const Shape sh = pick_shape(c->D, c->D);
+    if (sh.G != 8 || (sh.CH != 1 && sh.CH != 2 && sh.CH != 4)) return false;
+    bool any = false;
+    for (const auto& m : c->moves) any = any || persist_local_ok(c, m);
+    return any;
 }
 
 // The Gaussian Metropolis move alone (moves/gaussian.py + mh.py), fused dense target at an even ndim up to 64, Philox plans, one
@@ -3131,8 +3157,9 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             c->persist_cap = &cap;
             rc = do_halfstep(c, s, c->target);
             c->persist_cap = nullptr;
-            if (!rc && (!cap.got || !cap.dense || cap.dpb != c->Dp / 16 || cap.move != launch_move ||
-                        (int)cap.block.x != 64 * c->persist_wpb)) {
+            const bool valu = c->target != EMX_TARGET_DENSE_GAUSS;          // the element-wise targets' kernel (one-XCD form only)
+            if (!rc && (!cap.got || cap.dense == valu || (!valu && cap.dpb != c->Dp / 16) || cap.move != launch_move ||
+                        (int)cap.block.x != 64 * c->persist_wpb || (valu && !launch_local))) {
                 c->err = "persistent half-steps: launch shape not eligible";
                 rc = -1;
             }
@@ -3203,7 +3230,13 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             if (g_persist_last[dev] && g_persist_last[dev] != c) HIPOK(c, hipStreamWaitEvent(c->stream, g_persist_ev[dev], 0));
         }
         if (prof) HIPOK(c, hipEventRecord(e0, c->stream));
-        const hipError_t e = launch_hot_persist_dense(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
+        hipError_t e;
+        if (c->target != EMX_TARGET_DENSE_GAUSS) {
+            const Shape shv = pick_shape(c->D, c->D);
+            e = launch_persist_valu(shv.G, shv.V, shv.CH, launch_move, grid, block, c->stream, P);
+        } else {
+            e = launch_hot_persist_dense(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
+        }
         if (launch_local) c->persist_local_launches++;
         if (e != hipSuccess) FAIL(c, -2, "persistent half-step launch failed: %s", hipGetErrorString(e));
         if (prof) {
@@ -3359,7 +3392,7 @@ int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, in
 }
 
 int emx_persist_info(emx_ctx* c, int64_t out[4]) {
-    out[0] = (persist_wanted(c) || persist_gauss_wanted(c)) ? 1 : 0;
+    out[0] = (persist_wanted(c) || persist_gauss_wanted(c) || persist_valu_wanted(c)) ? 1 : 0;
     out[1] = c->persist_launches;
     out[2] = c->persist_halfsteps;
     out[3] = c->persist_recovered;       // launches that gave up untouched and were redone on the per-half-step path (persist_settle)
@@ -3405,8 +3438,12 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
     if (store) NEED(c, c->stored + nsteps <= c->cap, "chain capacity exhausted (call emx_chain_config)");
     const int64_t total = nsteps * thin_by;
     // (padded ndim 16 with a stored chain is the one measured shape the persistent kernel loses on: +5 %, profiles/r03/persist_dims.txt)
-    const bool persist_on = persist_wanted(c) && !small_eligible(c) && !(store && c->Dp == 16);
-    const bool persist_gauss_on = persist_gauss_wanted(c) && !small_eligible(c);
+    // (from 512 walkers on the one-XCD persistent kernel of the element-wise targets beats the one-workgroup kernel, whose step time
+    // grows with the ensemble: 512 x 5: 5.2 -> 3.6 us/step, 1 024 x 5: 9.9 -> 3.7; profiles/r04/persist_valu.txt)
+    const bool valu_on = persist_valu_wanted(c);
+    const bool small_on = small_eligible(c) && !valu_on;
+    const bool persist_on = (persist_wanted(c) && !small_on && !(store && c->Dp == 16)) || valu_on;
+    const bool persist_gauss_on = persist_gauss_wanted(c) && !small_on;
     bool ctr_synced = false;     // device-side graph counters equal the host's (ph_step, stored)
     int64_t next_mark = c->tune_throttle > 0 ? c->tune_throttle : total + 1;
     int marks = 0;
@@ -3424,7 +3461,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) 
             ++marks;
             next_mark += c->tune_throttle;
         }
-        if (small_eligible(c)) {
+        if (small_on) {
             // the ensemble fits one CU's LDS: up to 4096 steps per launch inside one workgroup
             drop_prepared(c);
             int64_t chunk = std::min<int64_t>(total - i, 4096);

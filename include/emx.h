@@ -371,7 +371,8 @@ int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
 /* how many of those launches took the one-XCD form: ensembles of up to 8 192 walkers (stretch move, two splits) run an eight times
  * larger grid of which every eighth workgroup works -- all on one XCD, whose L2 keeps the walker state coherent with plain accesses and
  * a barrier of that XCD's own instead of agent-scope accesses and the device-wide barrier (tuning "persist_local" = 0: never;
- * "persist_local_max_walkers"); same bits (red_blue.py:85,104: a half-step still sees every update of the one before) */
+ * "persist_local_max_walkers").  The element-wise targets (EMX_TARGET_ISO_GAUSS / _DIAG_GAUSS / _ROSENBROCK / _BOX, rows of 8 lanes:
+ * ndim <= 64 even, <= 32 odd) have this form only (csrc/emx_pvalu.hip; tuning "persist_valu" = 0: never); same bits (red_blue.py:85,104: a half-step still sees every update of the one before) */
 int emx_persist_local_launches(emx_ctx* ctx, int64_t* n);
 /* host only: the grid the persistent kernel takes for `nwalkers` walkers updated in `nsplits` half-steps on a device of `num_cu`
  * CUs -- waves per workgroup (8 / 4 / 2 / 1; 0: no persistent grid, the per-half-step launches run) and workgroups */

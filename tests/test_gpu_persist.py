@@ -105,6 +105,48 @@ def test_one_xcd_form_and_device_wide_form_agree_with_the_launch_per_halfstep_pa
             assert np.array_equal(recs["wide"][key], recs["plain"][key]), "device-wide form: " + key
 
 
+@pytest.mark.parametrize("N,D,target,moves,weights,store,thin_by", [
+    (2048, 10, "iso", [S("stretch")], None, False, 1),
+    (1024, 5, "iso", [S("stretch")], None, True, 1),                       # odd ndim: one coordinate per lane and chunk
+    (8192, 32, "rosenbrock", [S("stretch")], None, False, 1),
+    (4096, 64, "diag", [S("stretch")], None, True, 3),
+    (2048, 31, "diag", [S("de")], None, False, 1),
+    (4096, 16, "rosenbrock", [S("snooker")], None, True, 1),
+    (2048, 7, "box", [S("stretch")], None, False, 1),
+    (4096, 24, "iso", [S("stretch"), S("de")], [0.6, 0.4], True, 1),       # a mixture: runs of each move in launches of their own
+    (8192, 64, "iso", [S("de"), S("snooker")], [0.8, 0.2], False, 1),
+])
+def test_element_wise_targets_run_persistently_on_one_xcd(N, D, target, moves, weights, store, thin_by):
+    """csrc/emx_pvalu.hip: ensembles of up to 8 192 walkers on an element-wise target (isotropic / diagonal Gaussian, Rosenbrock, box)
+    take the one-XCD persistent kernel k_persist_valu -- rows, partners and log-probs by sc1 loads behind a flag barrier of that
+    XCD, proposal / target / decision / commit from registers, up to 32 half-steps a launch.  Same device functions in the same
+    order as k_halfstep: coordinates, log-probs, accept marks, chain rows and accept counters bit-equal to the per-half-step
+    launches (tuning persist = 0), over two calls of 37 steps."""
+    spec = full_spec(N, D, target, moves, weights=weights, seed=5, p0="rosen" if target == "rosenbrock" else ("uniform" if target == "box" else "randn"))
+    recs = []
+    for persist in (1, 0):
+        ens = native_ens(spec, persist)
+        ens.set_tuning("small_kernel", 0)
+        if store:
+            ens.chain_config(74)
+        for _ in range(2):
+            ens.run(37, thin_by, store)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=ens.persist_info())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, 74), chain_lp=ens.chain_read(1, 0, 74), counts=ens.accepted_counts())
+        ens.close()
+        recs.append(rec)
+    p, c = recs
+    assert p["info"]["qualifies"] and p["info"]["local_launches"] == p["info"]["launches"] > 0 and p["info"]["recovered"] == 0
+    assert c["info"]["launches"] == 0
+    assert p["acc"].any()
+    for key in c:
+        if key != "info":
+            assert np.array_equal(p[key], c[key]), key
+
+
 @pytest.mark.parametrize("thin_by", [1, 3])
 def test_persistent_kernel_stores_the_chain(thin_by):
     """the chain row, its log-probs and the per-walker accept counters of stored steps (backend.py:229), two calls, thinning"""
@@ -419,5 +461,32 @@ def test_persistent_kernel_coherence_stress(N, trials, store, thin_by):
     p, c = ens[0].persist_info(), ens[1].persist_info()
     assert p["halfsteps"] == 2 * nsteps * thin_by * trials and c["launches"] == 0
     assert (p["local_launches"] == p["launches"]) == (N <= 8192) and p["recovered"] == 0
+    for e in ens:
+        e.close()
+
+
+@pytest.mark.parametrize("N,D,target,trials", [(2048, 10, "iso", 150), (8192, 32, "rosenbrock", 60), (1024, 5, "iso", 150)])
+def test_element_wise_persistent_kernel_coherence_stress(N, D, target, trials):
+    """the one-XCD protocol of k_persist_valu (plain stores, sc1 loads, the flag barrier) under many short runs: 360 trials x 50 steps,
+    fresh Philox seed each, every trial bit-compared with the per-half-step path started from the same state"""
+    nsteps = 50
+    spec = full_spec(N, D, target, [S("stretch")], seed=17, p0="rosen" if target == "rosenbrock" else "randn")
+    ens = []
+    for persist in (1, 0):
+        e = native_ens(spec, persist)
+        e.set_tuning("small_kernel", 0)
+        ens.append(e)
+    for t in range(trials):
+        got = []
+        for e in ens:
+            e.set_philox(0xBEE000 + 104729 * t + N, 0)
+            e.run(nsteps, 1, False)
+            x, lp = e.get_state()
+            assert e.status() == 0
+            got.append([x, lp, e.accepted_mask()])
+        for k, (a, b) in enumerate(zip(*got)):
+            assert np.array_equal(a, b), "trial %d of %d: output %d of the persistent kernel differs from the per-half-step path" % (t, trials, k)
+    p, c = ens[0].persist_info(), ens[1].persist_info()
+    assert p["halfsteps"] == 2 * nsteps * trials and p["local_launches"] == p["launches"] and p["recovered"] == 0 and c["launches"] == 0
     for e in ens:
         e.close()
