@@ -33,7 +33,8 @@ namespace {
 std::string g_err;
 
 constexpr int PLAN_RING = 2 * NATIVE_BATCH_MAX;     // two native batches (the upper half serves the quarantined graph replay)
-constexpr int PIPE_SINKS = PLAN_RING < 16 ? PLAN_RING : 16;      // exact-mode plan pipeline: pinned staging buffers in flight
+constexpr int PIPE_SINKS = PLAN_RING < 16 ? PLAN_RING : 16;      // exact-mode plan pipeline: pinned staging buffers in flight (emx_ctx::pipe_nsinks: the
+                                                                 // whole ring for ensembles that take their steps eight per persistent launch)
 constexpr int MTDEV_SLOTS = MTDEV_NBUF * MTDEV_BATCH;            // exact-mode device producer: its plan slots follow the ring's, allocated on first use
 static_assert(MTDEV_BATCH == NATIVE_BATCH_MAX, "a produced batch is one persistent launch");
 constexpr int EMX_MAX_RANKS = 1024;      // pull / all-gather exchanges: counter storage
@@ -344,20 +345,34 @@ struct emx_ctx {
         double *s0 = nullptr, *uacc = nullptr, *logu = nullptr, *fac = nullptr;
         char* host = nullptr;  // pinned: [order|p0|p1|p2](int32 N each) [s0|uacc](double N each)
         hipEvent_t consumed = nullptr;
+        hipEvent_t consumed_ref = nullptr; // the event behind the kernels that last read this slot (its own, or a persistent launch's)
         hipEvent_t uploaded = nullptr;     // pipeline uploads: copy + logs done on the upload stream
+        hipEvent_t uploaded_ref = nullptr; // the event that says this slot's latest upload is done ...
+        unsigned last_seq = 0;             // the persistent launch that last read this slot's device copy (0: none since the pipeline started)
+        int64_t fetch_step = -1;           // ... or (>= 0) the step whose plan k_plan_fetch takes from it: done when *pipe_done > fetch_step
         bool busy = false, host_written = false;
     } ring[PLAN_RING + MTDEV_SLOTS];
     // exact-mode plan pipeline (emx_mtpipe.hpp): alive only inside emx_run
     MtPlanPipeline* pipe = nullptr;
     int64_t pipe_taken = 0;              // steps whose plan emx_step_begin has taken
     int pipe_ring0 = 0;                  // ring slot of pipeline step 0
+    int pipe_nsinks = PIPE_SINKS;        // slots the running pipeline cycles through
     std::deque<int64_t> pipe_uploads;    // steps whose upload is enqueued and not yet known to be complete
+    bool pipe_defer = false;             // run_persist (exact mode): pipe_take only hands the slot out; ONE fetch kernel uploads the launch's plans
+    std::vector<std::pair<int64_t, int>> pipe_deferred;    // (step, slot) taken but not yet fetched
+    hipEvent_t pipe_batch_ev[8] = {};    // [0,4): fetches done (upload stream); [4,8): launches done (consumer stream)
+    int pipe_batch_n = 0, pipe_cons_n = 0;
+    unsigned long long* pipe_done = nullptr;    // pinned: steps of the running pipeline that k_plan_fetch has read out of their staging buffers
+    unsigned* pipe_arrived = nullptr;           // device: k_plan_fetch's workgroup counter
     hipStream_t up_stream = nullptr;     // plan uploads overlap the previous step's kernels
     int64_t tune_mt_pipeline = -1;       // -1: on, finisher threads chosen from the core count; 0: off; k > 0: k finishers
     // exact-mode plans made on the device (emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica
     MtDevProducer* mtdev = nullptr;
     int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
     int64_t tune_persist_local = 1;      // 0: never the one-XCD form of the persistent kernel
+    int64_t tune_persist_exact_steps = 16;    // exact mode: steps per persistent launch (<= 16)
+    int64_t tune_fetch_delay_us = 0;     // tests: k_plan_fetch idles this long before it reads
+    int64_t tune_persist_exact = 1;      // 0: exact (MT19937) mode never takes the persistent kernels
     int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
     int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
     int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
@@ -476,6 +491,7 @@ struct emx_ctx {
     };
     PersistCapture* persist_cap = nullptr;      // launch_split fills this instead of launching
     unsigned* persist_bar = nullptr;
+    unsigned* persist_started = nullptr; // pinned: number of the latest persistent launch known to have STARTED (PersistArgs::started_host)
     unsigned persist_lepoch = 0;         // barriers passed on the one-XCD form's flags
     unsigned persist_hepoch = 0;         // handshakes of the one-XCD form counted so far
     int64_t persist_local_launches = 0;
@@ -1175,8 +1191,13 @@ int emx_destroy(emx_ctx* c) {
         if (s.order) hipFree(s.order);       // the slot's single block
         if (s.host) hipHostFree(s.host);
         if (s.uploaded) hipEventDestroy(s.uploaded);
+        s.uploaded_ref = nullptr;
         if (s.consumed) hipEventDestroy(s.consumed);
     }
+    for (auto& e : c->pipe_batch_ev)
+        if (e) hipEventDestroy(e);
+    if (c->pipe_done) hipHostFree(c->pipe_done);
+    if (c->pipe_arrived) hipFree(c->pipe_arrived);
     for (auto& g : c->gslot) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
@@ -1199,6 +1220,7 @@ int emx_destroy(emx_ctx* c) {
     if (c->noise_host) hipHostFree(c->noise_host);
     if (c->noise_ev) hipEventDestroy(c->noise_ev);
     if (c->persist_bar) hipFree(c->persist_bar);
+    if (c->persist_started) hipHostFree(c->persist_started);
     if (c->persist_ver) hipFree(c->persist_ver);
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_ctr) hipFree(c->d_ctr);
@@ -1366,6 +1388,19 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)
         c->tune_persist_local = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_exact")) {     // 0: exact mode always on the per-half-step launches
+        pipe_stop(c);
+        c->tune_persist_exact = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_exact_steps")) {
+        c->tune_persist_exact_steps = std::max<int64_t>(1, std::min<int64_t>(v, 16));
+        return 0;
+    }
+    if (!strcmp(key, "test_fetch_delay_us")) {     // tests: k_plan_fetch idles first (its consumers must wait for it)
+        c->tune_fetch_delay_us = std::max<int64_t>(0, std::min<int64_t>(v, 100000));
         return 0;
     }
     if (!strcmp(key, "persist_valu")) {      // 0: element-wise targets always on the per-half-step launches
@@ -1892,7 +1927,7 @@ static int acquire_slot(emx_ctx* c, emx_ctx::PlanSlot** out, bool host_written) 
     c->ring_pos = (c->ring_pos + 1) % PLAN_RING;
     auto& s = c->ring[c->ring_pos];
     if (s.busy && host_written) {
-        HIPOK(c, hipEventSynchronize(s.consumed));
+        HIPOK(c, hipEventSynchronize(s.consumed_ref));
         s.busy = false;
     }
     if (host_written && !s.host)   // pinned staging is only needed by the host-generated (exact / inputs) plans
@@ -1963,23 +1998,44 @@ static void pipe_poll(void* arg) {
     while (!c->pipe_uploads.empty()) {
         const int64_t n = c->pipe_uploads.front();
         if (c->cur.active && n == c->pipe_taken - 1) break;       // the open step's staging buffer may still be read (emx_plan_get)
-        auto& s = c->ring[(c->pipe_ring0 + n % PIPE_SINKS) % PLAN_RING];
-        if (hipEventQuery(s.uploaded) != hipSuccess) break;
+        auto& s = c->ring[(c->pipe_ring0 + n % c->pipe_nsinks) % PLAN_RING];
+        if (s.fetch_step >= 0) {
+            if (!c->pipe_done || __atomic_load_n(c->pipe_done, __ATOMIC_ACQUIRE) <= (unsigned long long)s.fetch_step) break;
+        } else if (!s.uploaded_ref || hipEventQuery(s.uploaded_ref) != hipSuccess) {
+            break;
+        }
         c->pipe->release(n);
         c->pipe_uploads.pop_front();
     }
 }
 
+static bool persist_exact_ok(const emx_ctx* c);
 static int pipe_start(emx_ctx* c) {
     const int64_t nsteps = (int64_t)1 << 60;       // it runs ahead (16 plans at most) until something retires it
     const size_t N = (size_t)c->N;
-    if (!c->up_stream) HIPOK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    if (!c->up_stream) {
+        // a queue of its own: streams of one priority share hardware queues, and an upload queued behind a persistent launch of
+        // the consumer's stream would wait for all of its steps
+        int lo = 0, hi = 0;
+        HIPOK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPOK(c, hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, hi));
+    }
     HIPOK(c, hipStreamSynchronize(c->stream));          // no earlier copy still reads a staging buffer
-    PlanSink sinks[PIPE_SINKS];
+    if (!c->pipe_done) {
+        HIPOK(c, hipHostMalloc((void**)&c->pipe_done, 64, hipHostMallocDefault));
+        HIPOK(c, hipMalloc((void**)&c->pipe_arrived, 64));
+        HIPOK(c, hipMemset(c->pipe_arrived, 0, 64));
+    }
+    HIPOK(c, hipStreamSynchronize(c->up_stream));
+    *c->pipe_done = 0ull;
+    PlanSink sinks[PLAN_RING];
+    c->pipe_nsinks = persist_exact_ok(c) ? PLAN_RING : PIPE_SINKS;      // (bursts of eight steps: the producers need the slack)
     c->pipe_ring0 = (c->ring_pos + 1) % PLAN_RING;
-    for (int r = 0; r < PIPE_SINKS; ++r) {
+    for (int r = 0; r < c->pipe_nsinks; ++r) {
         auto& s = c->ring[(c->pipe_ring0 + r) % PLAN_RING];
         s.busy = false;
+        s.last_seq = 0;
+        s.fetch_step = -1;
         if (!s.host) HIPOK(c, hipHostMalloc((void**)&s.host, N * 32, hipHostMallocDefault));
         if (!s.uploaded) HIPOK(c, hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
         const HostPlan hp(s.host, N);
@@ -1993,7 +2049,7 @@ static int pipe_start(emx_ctx* c) {
     c->pipe_taken = 0;
     c->pipe_uploads.clear();
     c->pipe = new MtPlanPipeline(c->mt, c->N, c->D, (int32_t)c->moves.size(), c->moves.data(), c->cdf.data(), nsteps, sinks,
-                                 PIPE_SINKS, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0));
+                                 c->pipe_nsinks, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0));
     return 0;
 }
 
@@ -2006,6 +2062,7 @@ static void pipe_stop(emx_ctx* c) {
     delete c->pipe;
     c->pipe = nullptr;
     c->pipe_uploads.clear();
+    c->pipe_deferred.clear();
 }
 
 // The pipeline is persistent: emx_run (or a single step of a large ensemble) starts it, it keeps running AHEAD of the steps
@@ -2092,27 +2149,40 @@ static int mtdev_take(emx_ctx* c) {
     return 0;
 }
 
+static bool persist_exact_ok(const emx_ctx* c);
 static bool pipe_eligible(const emx_ctx* c) {
-    return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_pipeline != 0 && !small_eligible(c) &&
+    return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_pipeline != 0 && (!small_eligible(c) || persist_exact_ok(c)) &&
            MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
 }
 
 // emx_step_begin's part: wait for the next plan, send it up on the upload stream, order the kernels behind it
+static inline double tr_now() { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int pipe_take(emx_ctx* c) {
     auto& cur = c->cur;
     const int64_t n = c->pipe_taken;
     PipeStepInfo info;
     pipe_poll(c);
     if (!c->pipe->wait_ready(n, info, pipe_poll, c)) FAIL(c, -7, "exact-mode plan pipeline stopped before step %lld", (long long)n);
-    const int slot = (int)((c->pipe_ring0 + n % PIPE_SINKS) % PLAN_RING);
+    const int slot = (int)((c->pipe_ring0 + n % c->pipe_nsinks) % PLAN_RING);
     auto& s = c->ring[slot];
     cur.move = info.move;
     cur.S = info.S;
     cur.slot = slot;
     cur.off.assign(info.off, info.off + info.S + 1);
     const size_t N = (size_t)c->N;
+    if (c->pipe_defer) {
+        // run_persist: the launch's plans go up together (pipe_fetch_deferred)
+        s.uploaded_ref = nullptr;
+        s.fetch_step = n;
+        s.host_written = true;
+        c->pipe_deferred.push_back({n, slot});
+        c->pipe_uploads.push_back(n);
+        c->pipe_taken = n + 1;
+        c->ring_pos = slot;
+        return 0;
+    }
     // the device copy of this slot was last read by the kernels of step n - PIPE_SINKS
-    if (s.busy) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed, 0));
+    if (s.busy) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed_ref, 0));
     const int stretch = c->moves[cur.move].kind == EMX_MOVE_STRETCH;
     HIPOK(c, hipMemcpyAsync(s.order, s.host, plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE),
                             hipMemcpyHostToDevice, c->up_stream));
@@ -2120,11 +2190,63 @@ static int pipe_take(emx_ctx* c) {
                        s.uacc, s.logu, s.fac);
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipEventRecord(s.uploaded, c->up_stream));
+    s.uploaded_ref = s.uploaded;
+    s.fetch_step = -1;
     HIPOK(c, hipStreamWaitEvent(c->stream, s.uploaded, 0));
     s.host_written = true;
     c->pipe_uploads.push_back(n);
     c->pipe_taken = n + 1;
     c->ring_pos = slot;
+    return 0;
+}
+
+// run_persist, exact mode: every plan taken since the last fetch goes up in one launch on the upload stream -- read straight from
+// the pinned staging buffers, logs included -- behind the kernels that last read those slots; the consumer's stream waits for it.
+static int pipe_fetch_deferred(emx_ctx* c) {
+    if (c->pipe_deferred.empty()) return 0;
+    NEED(c, c->pipe_deferred.size() <= 16, "more deferred plans than one fetch takes");
+    PlanFetchArgs F{};
+    F.N = (int32_t)c->N;
+    F.D = c->D;
+    F.n = (int)c->pipe_deferred.size();
+    // The device copies of these slots were last read by the launch four back.  An event wait for it (hipStreamWaitEvent on the upload
+    // stream) was measured to hold the fetch until the launch RUNNING now has ended -- the runtime learns of completions lazily and
+    // then orders behind the consumer stream's latest work -- which serialises fetch and kernels.  The kernels say it themselves
+    // instead: a launch leaves its number in a pinned word when it starts (PersistArgs::started_host), and a later launch having
+    // started means this one is over (one in-order stream).  Normally true long ago; otherwise the host waits here, which also
+    // bounds how far it runs ahead of the device.
+    hipEvent_t waited = nullptr;
+    for (int k = 0; k < F.n; ++k) {
+        auto& s = c->ring[c->pipe_deferred[k].second];
+        bool by_event = s.busy && s.consumed_ref != waited;
+        if (s.busy && s.last_seq != 0u && c->persist_started && (int)(c->persist_seq - s.last_seq) > 0) {
+            const double w0 = tr_now();
+            const double limit = 2e6 * (double)std::max<int64_t>(1, c->tune_persist_timeout_ms);
+            while ((int)(__atomic_load_n(c->persist_started, __ATOMIC_ACQUIRE) - s.last_seq) <= 0 && tr_now() - w0 < limit) {}
+            if ((int)(__atomic_load_n(c->persist_started, __ATOMIC_ACQUIRE) - s.last_seq) > 0) by_event = false;      // (else: launches that gave up -- the event)
+        }
+        if (by_event) {          // (the slots of one earlier launch share its event)
+            HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed_ref, 0));
+            waited = s.consumed_ref;
+        }
+        F.host[k] = s.host;
+        F.dev[k] = (char*)s.order;
+        F.stretch[k] = c->moves[0].kind == EMX_MOVE_STRETCH;       // (persist_exact_ok: one move)
+        F.peers[k] = !(F.stretch[k] && c->world == 1);
+    }
+    F.delay_ticks = (unsigned)(c->tune_fetch_delay_us * 100);
+    F.arrived = c->pipe_arrived;
+    F.host_done = c->pipe_done;
+    F.done_value = (unsigned long long)(c->pipe_deferred.back().first + 1);
+    hipLaunchKernelGGL(k_plan_fetch, dim3((unsigned)((c->N + 255) / 256), (unsigned)F.n), dim3(256), 0, c->up_stream, F);
+    HIPOK(c, hipGetLastError());
+    hipEvent_t& ev = c->pipe_batch_ev[c->pipe_batch_n & 3];
+    if (!ev) HIPOK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->pipe_batch_n++;
+    HIPOK(c, hipEventRecord(ev, c->up_stream));
+    HIPOK(c, hipStreamWaitEvent(c->stream, ev, 0));
+    for (auto& d : c->pipe_deferred) c->ring[d.second].uploaded_ref = ev;
+    c->pipe_deferred.clear();
     return 0;
 }
 
@@ -2214,7 +2336,7 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         }
         int rc = mtdev_take(c);
         if (rc) return rc;
-    } else if (c->rng_mode == EMX_RNG_MT19937 && forced_move < 0 && (c->pipe || (c->N >= 8192 && pipe_eligible(c)))) {
+    } else if (c->rng_mode == EMX_RNG_MT19937 && forced_move < 0 && (c->pipe || ((c->N >= 8192 || persist_exact_ok(c)) && pipe_eligible(c)))) {
         // exact mode: the plan of this step comes from the pipeline threads (same draws, same order as the inline producer)
         if (!c->pipe) {
             int rc0 = pipe_start(c);
@@ -2546,8 +2668,10 @@ int emx_step_end(emx_ctx* c) {
     NEED(c, cur.active, "emx_step_end without emx_step_begin");
     if (cur.slot >= 0) {
         auto& s = c->ring[cur.slot];
-        if (s.host_written) {
+        if (s.host_written && !c->pipe_defer) {      // (run_persist records it behind the launch that reads the slot)
             HIPOK(c, hipEventRecord(s.consumed, c->stream));
+            s.consumed_ref = s.consumed;
+            s.last_seq = 0;
             s.busy = true;
         }
     }
@@ -2963,12 +3087,21 @@ static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
     return wpb != 0 && persist_grid_fits(c, m, wpb);
 }
 
+// Exact (MT19937) mode with the one-XCD forms: the host pipeline's plans (csrc/emx_mtpipe.cpp) are uploaded eight steps ahead of the
+// launch that takes them -- one StretchMove / DEMove / DESnookerMove alone (a mixture's next move is only known once its plan has been
+// taken), ensembles of 512 ... 8 192 walkers.  The default rng of the Python layer: 25-33 -> 6-9 us/step (profiles/r04/exact_mid.txt).
+static bool persist_exact_ok(const emx_ctx* c) {
+    return c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_exact != 0 && c->moves.size() == 1 && c->tune_mt_pipeline != 0 &&
+           c->N >= c->tune_persist_min_walkers && persist_local_ok(c, c->moves[0]) && !mtdev_eligible(c) &&        // (the device producer: see persist_wanted)
+           MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
+}
+
 static bool persist_wanted(const emx_ctx* c) {
     if (!c->tune_persist) return false;
     // Philox plans only.  (The reference's own stream with its plans made on the device -- emx_mtdev.hpp -- has them in HBM in time
     // too, but its tokenizer is one 1024-thread, 107 KB workgroup that runs all the time: a persistent grid that holds every CU
     // leaves it none, and the two took turns -- k_persist 314 -> 1 150 us a launch, profiles/r04/mtdev_timeline.txt.)
-    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
+    if (!(c->rng_mode == EMX_RNG_PHILOX || persist_exact_ok(c)) || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
     if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || dense_is_wide(c)) return false;
     if (c->tune_ablate || (c->dbg && !EMX_OPT_STAMPS) || c->tune_spw || c->tune_wpb || c->tune_graph) return false;     // (an instrumented build stamps k_persist too)
     if (c->N < c->tune_persist_min_walkers) return false;
@@ -2985,7 +3118,7 @@ static bool persist_wanted(const emx_ctx* c) {
 // (ndim <= 64 even, <= 32 odd), Philox plans, one replica, every move of the schedule one the kernel knows at a shape it can take.
 static bool persist_valu_wanted(const emx_ctx* c) {
     if (!c->tune_persist || !c->tune_persist_local || !c->tune_persist_valu) return false;
-    if (c->rng_mode != EMX_RNG_PHILOX || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
+    if (!(c->rng_mode == EMX_RNG_PHILOX || persist_exact_ok(c)) || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
     if (c->target != EMX_TARGET_ISO_GAUSS && c->target != EMX_TARGET_DIAG_GAUSS && c->target != EMX_TARGET_ROSENBROCK && c->target != EMX_TARGET_BOX)
         return false;
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
@@ -3104,6 +3237,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     }
     if (!c->persist_bar) {
         HIPOK(c, hipMalloc((void**)&c->persist_bar, 12 * 32 * sizeof(unsigned)));
+        HIPOK(c, hipHostMalloc((void**)&c->persist_started, 64, hipHostMallocDefault));
+        *c->persist_started = 0u;
         HIPOK(c, hipMemsetAsync(c->persist_bar, 0, 12 * 32 * sizeof(unsigned), c->stream));
         c->persist_epoch = 0;
     }
@@ -3117,7 +3252,14 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     size_t lds = 0;
     int n = 0;
     int64_t steps = 0;
-    const bool devp = c->rng_mode == EMX_RNG_MT19937;       // plans from the device producer (persist_wanted saw to it)
+    const bool mtmode = c->rng_mode == EMX_RNG_MT19937;     // exact mode: the host pipeline's plans (persist_exact_ok), eight steps a launch
+    const bool devp = mtmode && mtdev_eligible(c);           // (plans from the device producer: not since it keeps the per-half-step launches)
+    std::vector<int> used_slots;
+    c->pipe_defer = mtmode && !devp;                         // the launch's plans are fetched by ONE kernel (pipe_fetch_deferred)
+    struct Undefer2 {
+        emx_ctx* c;
+        ~Undefer2() { c->pipe_defer = false; }
+    } undefer2{c};
     c->mtdev_defer_release = devp;                          // a batch's slots are released behind the LAUNCH that reads them, not behind the capture
     c->mtdev_release_pending = -1;
     struct Undefer {
@@ -3137,6 +3279,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     while (i0 + steps < total && n + launch_S <= PERSIST_MAX_ITERS) {
         if (devp) {
             if (steps > 0 && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) break;      // one produced batch per launch
+        } else if (mtmode) {
+            if (steps >= c->tune_persist_exact_steps) break;          // (k_plan_fetch takes sixteen plans; half of the pipeline's slots)
         } else {
             if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
             if (steps > 0 && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
@@ -3186,10 +3330,16 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             I.pos0 = cap.a.pos0;
             I.split = cap.a.split;
         }
+        if (mtmode && !devp && c->cur.slot >= 0) used_slots.push_back(c->cur.slot);
         rc = emx_step_end(c);
         if (rc) return rc;
         ++steps;
     }
+    if (mtmode && !devp) {
+        const int rcf = pipe_fetch_deferred(c);
+        if (rcf) return rcf;
+    }
+    c->pipe_defer = false;
     if (launch_local) grid.x *= 8;
     if (grid.x != c->persist_grid) {
         // the arrival counters count workgroups: another grid size (another move of a mixture, another ensemble shape) starts them
@@ -3202,6 +3352,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     }
     P.niter = n;
     P.bar = c->persist_bar;
+    P.started_host = c->persist_started;
     P.ver = c->persist_ver;
     P.epoch0 = c->persist_epoch + (unsigned)c->tune_persist_test_skew;      // (tests: a barrier that is never met)
     P.lepoch0 = c->persist_lepoch;
@@ -3215,7 +3366,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     P.seq = ++c->persist_seq;
     lg.seq = P.seq;
     lg.steps = steps;
-    if (!devp) c->plog.push_back(lg);         // (redoing a launch needs its plans again: a pure function of the step for Philox only)
+    if (!mtmode) c->plog.push_back(lg);       // (redoing a launch needs its plans again: a pure function of the step for Philox only)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max;
     if (prof) {
@@ -3248,6 +3399,20 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             g_persist_last[dev] = c;
         }
     }
+    // exact mode: the plan slots this launch reads were marked consumed when their steps were captured -- before the launch was
+    // enqueued; mark them again behind it (the pipeline's next upload into a slot waits for the event's latest record)
+    if (!used_slots.empty()) {
+        hipEvent_t& ev = c->pipe_batch_ev[4 + (c->pipe_cons_n & 3)];
+        if (!ev) HIPOK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->pipe_cons_n++;
+        HIPOK(c, hipEventRecord(ev, c->stream));
+        for (int sl : used_slots) {
+            c->ring[sl].consumed_ref = ev;
+            c->ring[sl].busy = true;
+            c->ring[sl].last_seq = P.seq;
+        }
+    }
+    if (mtmode && !devp) pipe_poll(c);         // (the fetch is usually done by now: its staging buffers go back to the producers)
     c->mtdev_defer_release = false;
     if (c->mtdev_release_pending >= 0 && c->mtdev) {
         const int rcr = c->mtdev->release_batch(c->mtdev_release_pending, c->stream);

@@ -1260,6 +1260,7 @@ struct PersistArgs {
     unsigned long long timeout_ticks;
     int32_t niter;
     unsigned seq;                  // number of this launch (left in the barrier block's fourth `go` word once its grid is known co-resident)
+    unsigned* started_host;        // pinned host word (or null): `seq` again, for the host -- launch k + 1 has started, so launch k is over
 };
 
 // The one-XCD form's barrier: every workgroup of the grid runs on ONE XCD (k_persist<..., LOCAL>), so its L2 is the point of
@@ -1371,6 +1372,7 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
                 }
                 if (open && o2 == k * 8 - 1) {
                     __hip_atomic_store(go + 3, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // this launch will run to its end
+                    if (P.started_host) __hip_atomic_store(P.started_host, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(go, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -2220,6 +2222,61 @@ static __global__ void k_plan_logs(int N, int D, int stretch, const double* __re
     if (pos >= N) return;
     logu[pos] = log(uacc[pos]);
     fac[pos] = stretch ? ((double)D - 1.0) * log(s0[pos]) : 0.0;
+}
+
+// The plans of up to sixteen steps fetched in ONE launch straight from the pipeline's pinned staging buffers (exact mode with the
+// persistent kernels: a copy + k_plan_logs + two event operations PER STEP cost the host 25 us a step, more than the kernels):
+// device slot <- [order | p0] [s0 | uacc] ([p1 | p2]), logu and fac as k_plan_logs computes them.
+struct PlanFetchArgs {
+    const char* host[16];     // pinned staging buffers (HostPlan layout: [order|p0] int32, [s0|uacc] f64, [p1|p2] int32)
+    char* dev[16];            // device slot blocks ([order|p0] [s0|uacc] [p1|p2] [logu|fac])
+    int32_t stretch[16];      // fac = (D-1) ln zz
+    int32_t peers[16];        // the [p1|p2] columns are part of the plan
+    int32_t N, D, n;
+    unsigned* arrived;        // device: workgroups of this launch that are done (the last one resets it)
+    unsigned long long* host_done;    // pinned host word: steps fetched so far, written by the LAST workgroup (an event query
+    unsigned delay_ticks;             // (tests: the kernel idles this long first -- 100 MHz ticks -- to show that its consumer waits for it)
+    unsigned long long done_value;    // shows the completion tens of us late: the staging buffers go back to the producers on this word)
+};
+static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, int b, int pos);
+static __global__ __launch_bounds__(256) void k_plan_fetch(const PlanFetchArgs A) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (A.delay_ticks) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < A.delay_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    if (pos < A.N) plan_fetch_rows(A, blockIdx.y, pos);
+    // every load of this workgroup has returned (its values were stored): count it; the last one tells the host
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned total = gridDim.x * gridDim.y;
+        if (atomicAdd(A.arrived, 1u) == total - 1u) {
+            *A.arrived = 0u;
+            __hip_atomic_store(A.host_done, A.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, int b, int pos) {
+    const size_t N = (size_t)A.N;
+    const int32_t* hi = reinterpret_cast<const int32_t*>(A.host[b]);
+    const double* hd = reinterpret_cast<const double*>(A.host[b] + N * 8);
+    int32_t* di = reinterpret_cast<int32_t*>(A.dev[b]);
+    double* dd = reinterpret_cast<double*>(A.dev[b] + N * 8);
+    const double z = hd[pos], u = hd[N + pos];
+    di[pos] = hi[pos];
+    di[N + pos] = hi[N + pos];
+    dd[pos] = z;
+    dd[N + pos] = u;
+    if (A.peers[b]) {
+        const int32_t* hp = reinterpret_cast<const int32_t*>(A.host[b] + N * 24);
+        int32_t* dp = reinterpret_cast<int32_t*>(A.dev[b] + N * 24);
+        dp[pos] = hp[pos];
+        dp[N + pos] = hp[N + pos];
+    }
+    double* dl = reinterpret_cast<double*>(A.dev[b] + N * 32);
+    dl[pos] = log(u);
+    dl[N + pos] = A.stretch[b] ? ((double)A.D - 1.0) * log(z) : 0.0;
 }
 
 // ----------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 #if defined(__linux__)
 #include <pthread.h>
 #include <sched.h>
+#include <sys/prctl.h>
 #endif
 
 namespace emx {
@@ -154,25 +155,40 @@ std::vector<int> distinct_cores(const CpuSet&) { return {}; }
 void confine(std::thread&, const CpuSet&, const std::vector<int>&, int) {}
 #endif
 
+// Waiting for a neighbouring stage: spin, then yield for ~2 ms, then sleep.  The consumer may take its steps in bursts (eight per
+// launch of the persistent kernels): a stage that went to sleep in between wakes 100+ us late (40 us + the timer slack), three stages in
+// a row 250 us -- more than the burst takes.  Hence the long yield phase, and the threads' timer slack set to 1 us (stage_thread_setup).
 struct Backoff {
     int n = 0;
+    uint64_t t0 = 0;
     inline void pause() {
         if (n < 256) {
             ++n;
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
-        } else if (n < 512) {
+            return;
+        }
+        const uint64_t now = now_ns();
+        if (n == 256) {
             ++n;
+            t0 = now;
+        }
+        const uint64_t waited = now - t0;
+        if (waited < 2000000ull) {
             std::this_thread::yield();
-        } else if (n < 3000) {
-            ++n;
+        } else if (waited < 150000000ull) {
             std::this_thread::sleep_for(std::chrono::microseconds(40));
         } else {
             std::this_thread::sleep_for(std::chrono::microseconds(500));      // a pipeline left idle between calls costs next to nothing
         }
     }
 };
+inline void stage_thread_setup() {
+#if defined(__linux__)
+    prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);       // (ns; the default 50 us is added to every sleep_for above)
+#endif
+}
 
 // ---- the MT19937 recurrence, out of place so that every loop is a plain vectorisable map -------------------------
 EMX_CLONES void twist_block(const uint32_t* __restrict o, uint32_t* __restrict n) {
@@ -341,6 +357,7 @@ struct WordStream {
 };
 
 void generator_main(WordStream* ws, const uint32_t* start_key) {
+    stage_thread_setup();
     // block 0 is the block the caller's generator currently stands in (no twist)
     alignas(64) uint32_t key[2][BLK + 16];          // + 16: the vector version reads one vector past word 607 + 1
     std::memset(key, 0, sizeof(key));
@@ -869,6 +886,7 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
 }
 
 void MtPlanPipeline::Impl::tokenizer_main() {
+    stage_thread_setup();
     Reader rd;
     rd.ws = &ws;
     rd.stop = &stop;
@@ -984,6 +1002,7 @@ void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) 
 }
 
 void MtPlanPipeline::Impl::finisher_main(int id) {
+    stage_thread_setup();
     std::vector<uint8_t> labels((size_t)N);
     for (int64_t n = id; n < nsteps; n += K) {
         Backoff bo;

@@ -314,10 +314,12 @@ def test_what_does_not_qualify():
         ens.run(16, 1, False)
         assert ens.persist_info()["launches"] == 0 and ens.status() == 0
         ens.close()
-    ens = native_ens(dense_spec(4096, 64), 1)
-    ens.set_rng_mode(_lib.RNG_MT19937)
-    assert not ens.persist_info()["qualifies"]
-    ens.close()
+    # exact (MT19937) mode: only where the one-XCD form runs (the host pipeline's plans, test_exact_mode_* below)
+    for N, want in ((4096, True), (16384, False)):
+        ens = native_ens(dense_spec(N, 64), 1)
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        assert ens.persist_info()["qualifies"] == want, N
+        ens.close()
 
 
 def test_two_ensembles_of_one_process_take_turns():
@@ -490,3 +492,92 @@ def test_element_wise_persistent_kernel_coherence_stress(N, D, target, trials):
     assert p["halfsteps"] == 2 * nsteps * trials and p["local_launches"] == p["launches"] and p["recovered"] == 0 and c["launches"] == 0
     for e in ens:
         e.close()
+
+
+@pytest.mark.parametrize("N,D,target,move,store,thin_by", [
+    (1024, 64, "dense", "stretch", True, 1), (4096, 64, "dense", "stretch", False, 1), (8192, 32, "dense", "de", False, 1),
+    (2048, 10, "iso", "stretch", True, 3), (1024, 5, "iso", "stretch", False, 1), (4096, 32, "rosenbrock", "stretch", True, 1),
+    (2048, 16, "diag", "snooker", False, 1), (512, 64, "dense", "stretch", False, 1),
+])
+def test_exact_mode_takes_the_one_xcd_persistent_kernels(N, D, target, move, store, thin_by):
+    """rng = MT19937 (the Python default: same seed => reference emcee's chain), one move, 512 ... 8 192 walkers: the host pipeline's
+    plans are uploaded eight steps ahead and the one-XCD persistent kernels (k_persist<..., LOCAL> / k_persist_valu) run them,
+    eight steps a launch.  Coordinates, log-probs, accept marks, chain rows, accept counters and the final generator state equal the
+    per-half-step exact path's (tuning persist_exact = 0) bit for bit over three calls of 21 steps."""
+    spec = full_spec(N, D, target, [S(move)], seed=9, p0="rosen" if target == "rosenbrock" else "randn")
+    state = np.random.RandomState(1234 + N).get_state()
+    recs = []
+    for pe in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        ens.set_mt19937(state)
+        ens.set_tuning("persist_exact", pe)
+        ens.set_tuning("persist_timeout_ms", 200)
+        if store:
+            ens.chain_config(63)
+        for _ in range(3):
+            ens.run(21, thin_by, store)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=ens.persist_info(), rng=ens.get_mt19937())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, 63), chain_lp=ens.chain_read(1, 0, 63), counts=ens.accepted_counts())
+        ens.close()
+        recs.append(rec)
+    p, c = recs
+    assert p["info"]["local_launches"] == p["info"]["launches"] > 0 and p["info"]["recovered"] == 0 and c["info"]["launches"] == 0
+    assert np.array_equal(p["rng"][1], c["rng"][1]) and p["rng"][2] == c["rng"][2]
+    for key in c:
+        if key not in ("info", "rng"):
+            assert np.array_equal(p[key], c[key]), key
+
+
+@pytest.mark.parametrize("N,D,target,steps_per_launch", [(1024, 64, "dense", 16), (512, 24, "iso", 16), (4096, 32, "dense", 5), (2048, 10, "iso", 1)])
+def test_exact_mode_persistent_long_run(N, D, target, steps_per_launch):
+    """700 steps of exact mode on the persistent kernels, the host enqueueing ahead of the device: every plan slot is rewritten
+    (k_plan_fetch) some twenty times, each time only after a LATER launch than the slot's last reader is known to have started
+    (PersistArgs::started_host).  Final coordinates, log-probs, accept counters and generator state equal the per-half-step path's."""
+    spec = full_spec(N, D, target, [S("stretch")], seed=21)
+    state = np.random.RandomState(99).get_state()
+    recs = []
+    for pe in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        ens.set_mt19937(state)
+        ens.set_tuning("persist_exact", pe)
+        ens.set_tuning("persist_exact_steps", steps_per_launch)
+        ens.run(700, 1, False)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        recs.append(dict(x=x, lp=lp, counts=ens.accepted_counts(), rng=ens.get_mt19937(), launches=ens.persist_info()["launches"]))
+        ens.close()
+    p, c = recs
+    assert p["launches"] >= 700 // 16 and c["launches"] == 0
+    assert np.array_equal(p["x"], c["x"]) and np.array_equal(p["lp"], c["lp"]) and np.array_equal(p["counts"], c["counts"])
+    assert np.array_equal(p["rng"][1], c["rng"][1]) and p["rng"][2] == c["rng"][2]
+
+
+def test_exact_mode_persistent_launch_waits_for_its_plans():
+    """The plans of a launch's eight steps are fetched by ONE kernel on the upload stream (k_plan_fetch, straight from the
+    pipeline's pinned staging buffers); the launch waits for it, and the fetch waits for the launch that last read the slots it
+    rewrites.  With the fetch made to idle 300 us before it reads -- ten times a launch -- the chain is still the per-half-step
+    path's bit for bit (a launch that did not wait would read the plans of 32 steps earlier, or nothing)."""
+    spec = full_spec(2048, 10, "iso", [S("stretch")], seed=4)
+    state = np.random.RandomState(77).get_state()
+    recs = []
+    for pe, delay in ((1, 300), (0, 0)):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        ens.set_mt19937(state)
+        ens.set_tuning("persist_exact", pe)
+        ens.set_tuning("test_fetch_delay_us", delay)
+        ens.chain_config(120)
+        ens.run(120, 1, True)
+        assert ens.status() == 0
+        recs.append(dict(chain=ens.chain_read(0, 0, 120), lp=ens.chain_read(1, 0, 120), launches=ens.persist_info()["launches"],
+                         rng=ens.get_mt19937()))
+        ens.close()
+    p, c = recs
+    assert p["launches"] >= 7 and c["launches"] == 0
+    assert np.array_equal(p["chain"], c["chain"]) and np.array_equal(p["lp"], c["lp"])
+    assert np.array_equal(p["rng"][1], c["rng"][1]) and p["rng"][2] == c["rng"][2]
