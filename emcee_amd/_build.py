@@ -4,7 +4,7 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip", "emx_hot.hip", "emx_wide.hip", "emx_mtdev.hip", "emx_slab.hip", "emx_pvalu.hip")]     # translation units, built in parallel
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip", "emx_hot.hip", "emx_wide.hip", "emx_mtdev.hip", "emx_slab.hip", "emx_pvalu.hip", "emx_pmix.hip")]     # translation units, built in parallel
 SRC = SRCS[0]
 LIB = os.path.join(HERE, "libemx.so")
 HOST_SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx_mtpipe.cpp", "emx_mtjump.cpp")]       # plain host C++ (threads, SIMD clones): no device pass

@@ -372,6 +372,8 @@ struct emx_ctx {
     int64_t tune_persist_local = 1;      // 0: never the one-XCD form of the persistent kernel
     int64_t tune_persist_exact_steps = 16;    // exact mode: steps per persistent launch (<= 16)
     int64_t tune_fetch_delay_us = 0;     // tests: k_plan_fetch idles this long before it reads
+    int64_t tune_persist_mix = 1;        // 0: a mixture's steps never share a launch (one run of one move per launch)
+    int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
     int64_t tune_persist_exact = 1;      // 0: exact (MT19937) mode never takes the persistent kernels
     int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
     int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
@@ -1403,6 +1405,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_fetch_delay_us = std::max<int64_t>(0, std::min<int64_t>(v, 100000));
         return 0;
     }
+    if (!strcmp(key, "persist_mix")) {       // 0: DE and snooker steps of a mixture in launches of their own
+        c->tune_persist_mix = v ? 1 : 0;
+        return 0;
+    }
     if (!strcmp(key, "persist_valu")) {      // 0: element-wise targets always on the per-half-step launches
         c->tune_persist_valu = v ? 1 : 0;
         return 0;
@@ -1692,6 +1698,7 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
     std::swap(c->tp1_full, ntpf);
     c->Dp = nDp;
     for (auto& f : c->persist_fits) f = -1;
+    c->persist_mix_fits = -1;
     graph_invalidate(c);
     c->graph_warm = false;
     c->target = kind;
@@ -1748,6 +1755,7 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
     c->moves.assign(moves, moves + nmoves);
     c->cdf.assign(cdf, cdf + nmoves);
     for (auto& f : c->persist_fits) f = -1;
+    c->persist_mix_fits = -1;
     for (double* p : c->mscale)
         if (p) {
             hipStreamSynchronize(c->stream);
@@ -3087,6 +3095,39 @@ static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
     return wpb != 0 && persist_grid_fits(c, m, wpb);
 }
 
+// A schedule that holds both a DEMove (two splits) and a DESnookerMove (four), dense Gaussian target: steps of either share launches
+// (k_persist<..., MOVE_MIX>, emx_pmix.hip).  Both moves must qualify on their own (persist_move_ok), the DE move's grid must hold the
+// mixed instantiation co-resident, and -- the one-XCD form -- both must be one-XCD moves.
+static bool persist_mix_member(const emx_move_desc& m) {
+    return (m.kind == EMX_MOVE_DE && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
+}
+static bool persist_mix_local(const emx_ctx* c) {
+    for (const auto& m : c->moves)
+        if (persist_mix_member(m) && !persist_local_ok(c, m)) return false;
+    return persist_shape_local_of(c->N, 2, c->num_cu) != 0;
+}
+static bool persist_mix_ok(const emx_ctx* cc) {
+    emx_ctx* c = const_cast<emx_ctx*>(cc);
+    if (!c->tune_persist_mix || c->target != EMX_TARGET_DENSE_GAUSS || c->rng_mode != EMX_RNG_PHILOX) return false;
+    bool de = false, sn = false;
+    for (const auto& m : c->moves) {
+        if (!persist_mix_member(m)) continue;
+        if (!persist_move_ok(c, m)) return false;
+        de = de || m.kind == EMX_MOVE_DE;
+        sn = sn || m.kind == EMX_MOVE_SNOOKER;
+    }
+    if (!de || !sn || (c->N % 64) != 0) return false;
+    if (persist_mix_local(c)) return true;
+    const int wpb = persist_shape(c, 2);
+    if (wpb == 0) return false;
+    if (c->persist_mix_fits < 0) {
+        int per_cu = 0;
+        const hipError_t e = persist_mix_occupancy(c->Dp / 16, 64 * wpb, dense_lds_bytes(c->Dp, wpb), &per_cu);
+        c->persist_mix_fits = (e != hipSuccess || (int64_t)per_cu * c->num_cu >= c->N / 2 / 16 / wpb) ? 1 : 0;
+    }
+    return c->persist_mix_fits != 0;
+}
+
 // Exact (MT19937) mode with the one-XCD forms: the host pipeline's plans (csrc/emx_mtpipe.cpp) are uploaded eight steps ahead of the
 // launch that takes them -- one StretchMove / DEMove / DESnookerMove alone (a mixture's next move is only known once its plan has been
 // taken), ensembles of 512 ... 8 192 walkers.  The default rng of the Python layer: 25-33 -> 6-9 us/step (profiles/r04/exact_mid.txt).
@@ -3276,14 +3317,19 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     int launch_move = -1;                // EMX_MOVE_STRETCH, _DE or _SNOOKER: the move of every step of this launch
     int launch_S = 2;
     bool launch_local = false;           // the one-XCD form: an eight times larger grid of which every eighth workgroup works
-    while (i0 + steps < total && n + launch_S <= PERSIST_MAX_ITERS) {
+    bool launch_mix = false;             // DE and snooker steps of a mixture in this launch (k_persist<..., MOVE_MIX>)
+    while (i0 + steps < total) {
+        int need = launch_S;               // half-steps of the step that would follow (a mixed launch: read off its plan)
+        if (launch_mix && steps > 0 && !c->prepared.empty()) need = c->moves[c->prepared.front().move].nsplits;
+        if (n + need > PERSIST_MAX_ITERS) break;
         if (devp) {
             if (steps > 0 && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) break;      // one produced batch per launch
         } else if (mtmode) {
             if (steps >= c->tune_persist_exact_steps) break;          // (k_plan_fetch takes sixteen plans; half of the pipeline's slots)
         } else {
             if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
-            if (steps > 0 && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
+            if (steps > 0 && !launch_mix && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
+            if (steps > 0 && launch_mix && !persist_mix_member(c->moves[c->prepared.front().move])) break;
         }
         c->prep_hint = NATIVE_BATCH_MAX;
         const int st = store && ((i0 + steps + 1) % thin_by == 0);          // ensemble.py:416
@@ -3295,6 +3341,13 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             launch_S = S;
             launch_local = persist_local_ok(c, c->moves[mvi]);
             c->persist_wpb = launch_local ? persist_shape_local_of(c->N, S, c->num_cu) : persist_shape(c, S);
+            if (persist_mix_ok(c) && (launch_move == EMX_MOVE_DE || launch_move == EMX_MOVE_SNOOKER)) {
+                // a schedule of DE (two splits) and snooker (four) moves: ONE launch for steps of either (k_persist<..., MOVE_MIX>), at
+                // the DE move's shape -- every other wave works in a snooker half-step
+                launch_mix = true;
+                launch_local = persist_mix_local(c);
+                c->persist_wpb = launch_local ? persist_shape_local_of(c->N, 2, c->num_cu) : persist_shape(c, 2);
+            }
         }
         for (int s = 0; s < S; ++s) {
             cap.got = false;
@@ -3302,7 +3355,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             rc = do_halfstep(c, s, c->target);
             c->persist_cap = nullptr;
             const bool valu = c->target != EMX_TARGET_DENSE_GAUSS;          // the element-wise targets' kernel (one-XCD form only)
-            if (!rc && (!cap.got || cap.dense == valu || (!valu && cap.dpb != c->Dp / 16) || cap.move != launch_move ||
+            const bool move_ok = launch_mix ? (cap.move == MOVE_DE || cap.move == MOVE_SNOOKER) : cap.move == launch_move;
+            if (!rc && (!cap.got || cap.dense == valu || (!valu && cap.dpb != c->Dp / 16) || !move_ok ||
                         (int)cap.block.x != 64 * c->persist_wpb || (valu && !launch_local))) {
                 c->err = "persistent half-steps: launch shape not eligible";
                 rc = -1;
@@ -3329,6 +3383,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             I.chain_lp = cap.a.chain_lp;
             I.pos0 = cap.a.pos0;
             I.split = cap.a.split;
+            I.kind = cap.move;
+            I.shift = (launch_mix && S == 4) ? 1 : 0;
         }
         if (mtmode && !devp && c->cur.slot >= 0) used_slots.push_back(c->cur.slot);
         rc = emx_step_end(c);
@@ -3340,6 +3396,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         if (rcf) return rcf;
     }
     c->pipe_defer = false;
+    if (launch_mix) grid = dim3((unsigned)(c->N / 2 / 16 / c->persist_wpb));       // (the DE move's grid, whatever the first step was)
     if (launch_local) grid.x *= 8;
     if (grid.x != c->persist_grid) {
         // the arrival counters count workgroups: another grid size (another move of a mixture, another ensemble shape) starts them
@@ -3385,6 +3442,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         if (c->target != EMX_TARGET_DENSE_GAUSS) {
             const Shape shv = pick_shape(c->D, c->D);
             e = launch_persist_valu(shv.G, shv.V, shv.CH, launch_move, grid, block, c->stream, P);
+        } else if (launch_mix) {
+            e = launch_persist_mix(c->Dp / 16, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
         } else {
             e = launch_hot_persist_dense(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
         }

@@ -55,7 +55,7 @@
 
 namespace emx {
 
-enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_GAUSS = 3, MOVE_EVAL = 4 };
+enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_GAUSS = 3, MOVE_EVAL = 4, MOVE_MIX = 8 /* k_persist_mix: DE and snooker steps in one launch */ };
 enum : int { GAUSS_VECTOR = 0, GAUSS_RANDOM = 1, GAUSS_SEQUENTIAL = 2 };
 enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5,
              TGT_REPLAY = 7 };      // (6 is EMX_TARGET_DEVICE_CALLBACK, a host-side three-pass target: never a kernel's)     // replay exchange: no target, no decision -- the slot is a peer's ACCEPTED update, its new log-prob comes with the plan
@@ -1248,6 +1248,7 @@ struct PersistIter {
     const double *s0, *logu, *fac;
     double *chain, *chain_lp;      // this step's row of the stored chain (backend.py:229), or nullptr
     int32_t pos0, split;
+    int32_t kind, shift;           // MOVE_MIX: the half-step's move; it has 2^-shift as many tiles as the grid has waves (k_persist_mix: mix_tile)
 };
 struct PersistArgs {
     HalfStepArgs base;

@@ -36,6 +36,9 @@ hipError_t launch_hot_persist_dense(int dpb, int move, int local, dim3 grid, dim
 hipError_t hot_persist_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu);
 // ... and the Gaussian Metropolis move's (k_persist_gauss: a wave keeps its walkers in registers; no barrier, any grid)
 hipError_t launch_hot_persist_gauss(int dpb, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistGaussArgs& P);
+// emx_pmix.hip: k_persist<..., MOVE_MIX> -- DEMove and DESnookerMove steps of a mixture in one launch (either form)
+hipError_t launch_persist_mix(int dpb, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
+hipError_t persist_mix_occupancy(int dpb, int threads, size_t lds, int* per_cu);
 // emx_pvalu.hip: the persistent kernel for the element-wise targets (one-XCD form)
 hipError_t launch_persist_valu(int G, int V, int CH, int move, dim3 grid, dim3 block, hipStream_t st, const PersistArgs& P);
 // emx_slab.hip: the fused dense half-step at padded ndim 80 ... 128 with the proposals in registers and a 32-column LDS slab

@@ -230,6 +230,57 @@ def test_gaussian_move_keeps_its_walkers_in_registers(N, D, mode, factor, store)
     assert 0.0 < p["acc"].mean() < 1.0
 
 
+@pytest.mark.parametrize("N,D,weights,store,thin_by", [
+    (65536, 64, [0.8, 0.2], False, 1),        # C4: the device-wide form, 8 waves a workgroup (4 of them work in a snooker half-step)
+    (32768, 48, [0.5, 0.5], True, 1),         # 4 waves a workgroup
+    (16384, 64, [0.3, 0.7], True, 1),
+    (8192, 64, [0.6, 0.4], True, 1),          # the one-XCD form from here on
+    (4096, 32, [0.7, 0.3], False, 1),
+    (2048, 64, [0.5, 0.5], False, 1),         # 2 waves a workgroup: the first of them
+    (1024, 16, [0.4, 0.6], False, 1),         # 1 wave a workgroup: every other workgroup
+    (1024, 32, [0.4, 0.6], True, 1),
+    (4096, 48, [0.5, 0.5], True, 3),
+    (512, 64, [0.8, 0.2], False, 1),
+])
+def test_de_and_snooker_steps_share_launches(N, D, weights, store, thin_by):
+    """A schedule of DEMove (two splits) and DESnookerMove (four) on the dense target: k_persist_mix takes the steps of both in ONE
+    launch -- the move of a half-step is a field of its descriptor, the grid is the DE move's and a snooker half-step uses half its
+    waves.  Bit-equal to launches of one move each (tuning persist_mix = 0) and to the per-half-step path, in far fewer launches."""
+    spec = full_spec(N, D, "dense", [S("de"), S("snooker")], weights=weights, seed=31)
+    nst = 45
+    recs = []
+    for persist, mix in ((1, 1), (1, 0), (0, 0)):
+        ens = native_ens(spec, persist)
+        ens.set_tuning("persist_mix", mix)
+        if store:
+            ens.chain_config(nst)
+        ens.run(nst, thin_by, store)               # (nst stored steps of thin_by proposals each)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=ens.persist_info())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, nst), chain_lp=ens.chain_read(1, 0, nst), counts=ens.accepted_counts())
+        ens.close()
+        recs.append(rec)
+    m, p, c = recs
+    assert m["info"]["halfsteps"] == p["info"]["halfsteps"] > 2 * nst and c["info"]["launches"] == 0 and m["info"]["recovered"] == 0
+    assert m["info"]["launches"] <= 8 * thin_by and m["info"]["launches"] < p["info"]["launches"]       # (32 half-steps a launch at most)
+    for key in c:
+        if key != "info":
+            assert np.array_equal(m[key], c[key]), "mixed launches: " + key
+            assert np.array_equal(p[key], c[key]), "one move per launch: " + key
+
+
+def test_three_move_mixture_shares_launches_where_it_can():
+    """StretchMove + DEMove + DESnookerMove: the stretch steps keep launches of their own (their kernel defers the chain rows), the
+    runs of DE / snooker steps between them share theirs; the chain is the per-half-step path's"""
+    spec = full_spec(4096, 64, "dense", [S("stretch"), S("de"), S("snooker")], weights=[0.2, 0.5, 0.3], seed=8)
+    p, c = run_both(spec, 60, store=True)
+    assert p["info"]["launches"] >= 3 and c["info"]["launches"] == 0
+    for key in ("x", "lp", "acc", "chain", "chain_lp", "counts"):
+        assert np.array_equal(p[key], c[key]), key
+
+
 def test_mixture_whose_moves_take_grids_of_different_sizes():
     """8 192 walkers: a DE half-step is 256 one-wave workgroups, a snooker half-step 128 -- the barrier's arrival counters start
     afresh when the grid changes (a barrier that waited for the other grid's count would time out: status bit 3)"""
