@@ -3317,7 +3317,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     int launch_move = -1;                // EMX_MOVE_STRETCH, _DE or _SNOOKER: the move of every step of this launch
     int launch_S = 2;
     bool launch_local = false;           // the one-XCD form: an eight times larger grid of which every eighth workgroup works
-    bool launch_mix = false;             // DE and snooker steps of a mixture in this launch (k_persist<..., MOVE_MIX>)
+    bool launch_mix = false;             // DE and snooker steps of a mixture in this launch (k_persist_mix)
+    double launch_gammas = 0.0;
     while (i0 + steps < total) {
         int need = launch_S;               // half-steps of the step that would follow (a mixed launch: read off its plan)
         if (launch_mix && steps > 0 && !c->prepared.empty()) need = c->moves[c->prepared.front().move].nsplits;
@@ -3329,6 +3330,8 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         } else {
             if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
             if (steps > 0 && !launch_mix && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
+            // (the snooker scale is a launch-wide kernel argument there: a second DESnookerMove with another `gammas` starts a launch of its own)
+            if (steps > 0 && !launch_mix && launch_move == EMX_MOVE_SNOOKER && c->moves[c->prepared.front().move].gammas != launch_gammas) break;
             if (steps > 0 && launch_mix && !persist_mix_member(c->moves[c->prepared.front().move])) break;
         }
         c->prep_hint = NATIVE_BATCH_MAX;
@@ -3338,6 +3341,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         if (rc) return rc;
         if (launch_move < 0) {
             launch_move = c->moves[mvi].kind;
+            launch_gammas = c->moves[mvi].gammas;
             launch_S = S;
             launch_local = persist_local_ok(c, c->moves[mvi]);
             c->persist_wpb = launch_local ? persist_shape_local_of(c->N, S, c->num_cu) : persist_shape(c, S);
@@ -3384,6 +3388,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             I.pos0 = cap.a.pos0;
             I.split = cap.a.split;
             I.kind = cap.move;
+            I.gammas = cap.a.gammas;
             I.shift = (launch_mix && S == 4) ? 1 : 0;
         }
         if (mtmode && !devp && c->cur.slot >= 0) used_slots.push_back(c->cur.slot);

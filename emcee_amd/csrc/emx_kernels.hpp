@@ -1248,6 +1248,7 @@ struct PersistIter {
     const double *s0, *logu, *fac;
     double *chain, *chain_lp;      // this step's row of the stored chain (backend.py:229), or nullptr
     int32_t pos0, split;
+    double gammas;                 // k_persist_mix: the snooker move's scale of THIS half-step (HalfStepArgs::gammas is the first captured step's)
     int32_t kind, shift;           // MOVE_MIX: the half-step's move; it has 2^-shift as many tiles as the grid has waves (k_persist_mix: mix_tile)
 };
 struct PersistArgs {

@@ -157,14 +157,15 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         }
         MTD_HIP(hipMalloc((void**)&m.fin_partial, (size_t)MTDEV_BATCH * m.nchunk * 4));
         MTD_HIP(hipMalloc((void**)&m.fin_hist, (size_t)MTDEV_BATCH * m.nchunk * m.S * 4));
+        const unsigned evf = getenv("EMX_X_EVTIMING") ? hipEventDefault : hipEventDisableTiming;
         for (int k = 0; k < MTDEV_NBUF; ++k) {
             MTD_HIP(hipMalloc((void**)&m.step_end[k], (size_t)MTDEV_BATCH * 8));
-            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].tok, hipEventDisableTiming));
-            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].fin, hipEventDisableTiming));
-            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].pos, hipEventDisableTiming));
-            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].released, hipEventDisableTiming));
+            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].tok, evf));
+            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].fin, evf));
+            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].pos, evf));
+            MTD_HIP(hipEventCreateWithFlags(&m.bt[k].released, evf));
         }
-        MTD_HIP(hipEventCreateWithFlags(&m.ev_gen, hipEventDisableTiming));
+        MTD_HIP(hipEventCreateWithFlags(&m.ev_gen, evf));
         MTD_HIP(hipHostMalloc((void**)&m.h_end, (size_t)MTDEV_NBUF * MTDEV_BATCH * 8, hipHostMallocDefault));
         MTD_HIP(hipMalloc((void**)&m.scratch, (size_t)MTDEV_BATCH * 5 * N * 4));
         MTD_HIP(hipMalloc((void**)&m.blk_words, (size_t)MTDEV_NBUF * MTDEV_BATCH * MT_N * 4));

@@ -184,7 +184,7 @@ static __global__ __launch_bounds__(512) void k_persist_mix(const PersistArgs P)
             Row<G, V, CH> q;
             if constexpr (MIX) {
                 if (sn)
-                    make_proposal<G, V, CH, MOVE_SNOOKER>(xi[k], xa[k], xb[k], xc[k], s0v[k], A.gammas, D, gl, q, factor, ja[k]);
+                    make_proposal<G, V, CH, MOVE_SNOOKER>(xi[k], xa[k], xb[k], xc[k], s0v[k], I.gammas, D, gl, q, factor, ja[k]);
                 else
                     make_proposal<G, V, CH, MOVE_DE>(xi[k], xa[k], xb[k], xc[k], s0v[k], A.gammas, D, gl, q, factor, ja[k]);
             } else {

@@ -356,7 +356,8 @@ int emx_host_mt_jump(const uint32_t key[624], uint64_t stride_words, int32_t k, 
  * DE-move steps (de.py:40-64) of two splits, snooker steps (de_snooker.py:31-46) of four, the
  * fused dense Gaussian target at an even ndim up to 64, Philox plans, one replica, nwalkers a multiple of 32 from 512 (tuning
  * "persist_min_walkers") to 256 x the CU count, i.e. one 16-walker tile per wave of a co-resident grid of about one workgroup
- * per CU -- up to 32 half-steps per kernel launch (in a mixture: the consecutive steps of one move; steps with another number of
+ * per CU -- up to 32 half-steps per kernel launch (in a mixture: the consecutive steps of one move -- the steps of a DEMove and a
+ * DESnookerMove share launches, k_persist_mix, tuning "persist_mix" = 0: never; steps with another number of
  * splits take the per-half-step launches): a device-wide barrier stands where the kernel
  * boundaries were, and the next half-step's plan entries and own rows are loaded while this one computes.  Same draws, same
  * arithmetic, same bits as the launch-per-half-step path.  Tuning "persist" = 0 turns it off; "persist_timeout_ms" bounds a
@@ -372,7 +373,12 @@ int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
  * larger grid of which every eighth workgroup works -- all on one XCD, whose L2 keeps the walker state coherent with plain accesses and
  * a barrier of that XCD's own instead of agent-scope accesses and the device-wide barrier (tuning "persist_local" = 0: never;
  * "persist_local_max_walkers").  The element-wise targets (EMX_TARGET_ISO_GAUSS / _DIAG_GAUSS / _ROSENBROCK / _BOX, rows of 8 lanes:
- * ndim <= 64 even, <= 32 odd) have this form only (csrc/emx_pvalu.hip; tuning "persist_valu" = 0: never); same bits (red_blue.py:85,104: a half-step still sees every update of the one before) */
+ * ndim <= 64 even, <= 32 odd) have this form only (csrc/emx_pvalu.hip; tuning "persist_valu" = 0: never); same bits (red_blue.py:85,104: a half-step still sees every update of the one before).
+ * EMX_RNG_MT19937 (the reference's own stream; ensemble.py:166-167) takes the one-XCD forms too when the context has ONE move: the
+ * host pipeline's plans of up to sixteen steps ("persist_exact_steps") are fetched from their pinned staging buffers by one kernel
+ * per launch (k_plan_fetch) -- tuning "persist_exact" = 0: the per-half-step launches with an upload per step.  (A launch of this
+ * mode that cannot become resident on one XCD is NOT redone -- its plans have left the pipeline: status bit 3, as for a barrier
+ * that timed out in the middle of a launch.) */
 int emx_persist_local_launches(emx_ctx* ctx, int64_t* n);
 /* host only: the grid the persistent kernel takes for `nwalkers` walkers updated in `nsplits` half-steps on a device of `num_cu`
  * CUs -- waves per workgroup (8 / 4 / 2 / 1; 0: no persistent grid, the per-half-step launches run) and workgroups */

@@ -246,7 +246,7 @@ def test_de_and_snooker_steps_share_launches(N, D, weights, store, thin_by):
     """A schedule of DEMove (two splits) and DESnookerMove (four) on the dense target: k_persist_mix takes the steps of both in ONE
     launch -- the move of a half-step is a field of its descriptor, the grid is the DE move's and a snooker half-step uses half its
     waves.  Bit-equal to launches of one move each (tuning persist_mix = 0) and to the per-half-step path, in far fewer launches."""
-    spec = full_spec(N, D, "dense", [S("de"), S("snooker")], weights=weights, seed=31)
+    spec = full_spec(N, D, "dense", [S("de", gammas=0.0), S("snooker", gammas=1.3)], weights=weights, seed=31)     # (the snooker scale is per half-step)
     nst = 45
     recs = []
     for persist, mix in ((1, 1), (1, 0), (0, 0)):
@@ -271,10 +271,24 @@ def test_de_and_snooker_steps_share_launches(N, D, weights, store, thin_by):
             assert np.array_equal(p[key], c[key]), "one move per launch: " + key
 
 
+@pytest.mark.parametrize("N,target", [(65536, "dense"), (2048, "dense"), (2048, "iso")])
+def test_two_snooker_moves_of_different_scale(N, target):
+    """DESnookerMove(gammas=1.7) and DESnookerMove(gammas=0.9) in one schedule (de_snooker.py:26-29): the scale is a launch-wide
+    argument of the one-move kernels, so a run of snooker steps ends where the scale changes; with a DEMove next to them the mixed
+    kernel takes the scale of every half-step from its descriptor.  The chain is the per-half-step path's."""
+    for moves, weights in (([S("snooker", gammas=1.7), S("snooker", gammas=0.9)], [0.5, 0.5]),
+                           ([S("de", gammas=0.0), S("snooker", gammas=1.7), S("snooker", gammas=0.9)], [0.4, 0.3, 0.3])):
+        spec = full_spec(N, 64 if target == "dense" else 24, target, moves, weights=weights, seed=17)
+        p, c = run_both(spec, 40, store=True)
+        assert p["info"]["launches"] >= 2 and c["info"]["launches"] == 0
+        for key in ("x", "lp", "acc", "chain", "chain_lp", "counts"):
+            assert np.array_equal(p[key], c[key]), key
+
+
 def test_three_move_mixture_shares_launches_where_it_can():
     """StretchMove + DEMove + DESnookerMove: the stretch steps keep launches of their own (their kernel defers the chain rows), the
     runs of DE / snooker steps between them share theirs; the chain is the per-half-step path's"""
-    spec = full_spec(4096, 64, "dense", [S("stretch"), S("de"), S("snooker")], weights=[0.2, 0.5, 0.3], seed=8)
+    spec = full_spec(4096, 64, "dense", [S("stretch"), S("de", gammas=0.0), S("snooker", gammas=2.1)], weights=[0.2, 0.5, 0.3], seed=8)
     p, c = run_both(spec, 60, store=True)
     assert p["info"]["launches"] >= 3 and c["info"]["launches"] == 0
     for key in ("x", "lp", "acc", "chain", "chain_lp", "counts"):

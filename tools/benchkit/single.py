@@ -236,6 +236,29 @@ def exact_mode_large_entry(K, W, device):
     return out
 
 
+def exact_mode_mid_entry(K, W, device):
+    """rng=mt19937 at the sizes of the reference's own suite (1 024 and 4 096 walkers x 64, dense Gaussian, StretchMove): the host
+    pipeline's plans fetched sixteen steps at a time by ONE kernel and run by the one-XCD persistent kernel (tuning persist_exact,
+    round 4) next to the launch-per-half-step path with its upload per step (persist_exact = 0), and the Philox rate of the same shape."""
+    out = {"what": "C2's target and move at mid-size ensembles, rng=mt19937 (chain identical to reference emcee's): ms_per_step of emx_run"}
+    Kx = max(200, min(K, 400))
+    for N in (1024, 4096):
+        wl = Workload("c2", N)
+        e = {}
+        for name, rng, tune in (("persistent_one_xcd", "mt19937", {"persist_exact": 1}), ("per_half_step", "mt19937", {"persist_exact": 0}),
+                                ("philox_same_shape", "philox", {})):
+            res = measure_single(wl, Kx, max(W, 10), device=device, rng=rng, spin_s=0.05, want_kernel=False, tuning=tune)
+            e[name] = {"ms_per_step": res["wall_s"] * 1e3 / Kx, "blocks_timed": res["blocks"], "device_status": res["status"],
+                       "accept_frac": res["accept_frac"]}
+            if rng == "mt19937":
+                e[name]["pipeline_stage_us_per_step"] = res.get("pipeline")
+        e["speedup"] = e["per_half_step"]["ms_per_step"] / e["persistent_one_xcd"]["ms_per_step"]
+        out["%dx64" % N] = e
+    out["note"] = ("profiles/r04/exact_mid.txt: what stood in the way (per-step uploads, sleeping stage threads, a shared hardware queue, "
+                   "lazily resolved events); from 4 096 walkers on the pipeline's generator thread is the bound")
+    return out
+
+
 def quality_entry(device, rng="philox"):
     """Acceptance fraction and integrated autocorrelation time (reference estimator, c=5) of the 64-dim correlated
     Gaussian, StretchMove a=2, in the configuration the reference itself was run in (tests/golden/quality_ref.json, made by
