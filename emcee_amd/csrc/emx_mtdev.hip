@@ -28,6 +28,9 @@ inline uint32_t untemper32(uint32_t y) {
 }
 }  // namespace
 
+enum { G_GEN = 0, G_TOK = 8, G_FIN = 16, G_REL = 24, G_STATS = 32, G_WORDS = 64 };          // (a 64-byte line each)
+constexpr unsigned long long GATE_TIMEOUT_TICKS = 100000000ull * 20ull;       // 20 s
+
 struct MtDevProducer::Impl {
     int device = 0;
     int64_t N = 0;
@@ -45,6 +48,9 @@ struct MtDevProducer::Impl {
     uint64_t gen_words = 0;            // words [0, gen_words) are generated (enqueued on s_gen)
     int64_t rounds = 0;
     hipEvent_t ev_gen = nullptr;       // after the latest round
+    // what each stage has completed, counted in device words (k_gate_signal / k_gate_wait: emx_mtdev_kernels.hpp)
+    unsigned long long* gates = nullptr;       // [G_GEN] rounds generated | [G_TOK] batches tokenised | [G_FIN] batches finished | [G_REL] batches the consumer released
+    bool use_gates = true;
     // tokenizer state
     unsigned long long* d_pos = nullptr;
     unsigned* d_err = nullptr;
@@ -57,6 +63,7 @@ struct MtDevProducer::Impl {
     uint32_t *fin_partial = nullptr, *fin_hist = nullptr;
     unsigned long long *tokpos[2] = {nullptr, nullptr}, *step_end[MTDEV_NBUF] = {};
     unsigned long long* h_end = nullptr;       // pinned [NBUF][BATCH]: step end positions of the batch in that buffer
+    unsigned long long* h_done = nullptr;      // pinned: number of batches whose positions are there
     uint32_t* scratch = nullptr;
     uint32_t* blk_words = nullptr;             // [NBUF][BATCH][624]: the (tempered) block every step of the batch ends in: finish() needs no ring
     // per batch bookkeeping
@@ -67,6 +74,9 @@ struct MtDevProducer::Impl {
     int64_t enq = 0;                   // batches enqueued so far
     int64_t known = -1;                // last batch whose end position the host has read
     uint64_t known_pos = 0;            // ... that position (batch -1: the start position)
+    uint64_t pos0 = 0;                 // the start position
+    static constexpr int END_HIST = 16;
+    uint64_t end_hist[END_HIST] = {};  // end positions of the last batches the host has read (h_end's slots are rewritten after NBUF batches)
     uint64_t wmax = 0, wmin = 0;       // words per step: bounds
     uint64_t slack = 0;                // the tokenizer asks for whole windows: words it may look at beyond what it consumes
 };
@@ -144,6 +154,9 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         MTD_HIP(hipMalloc((void**)&m.xwin, (size_t)WIN_BLOCKS * MT_N * 4));
         MTD_HIP(hipMalloc((void**)&m.partial, (size_t)(PMAX - 1) * JUMP_SPLIT * MT_N * 4));
         MTD_HIP(hipMalloc((void**)&m.polys, (size_t)(PMAX - 1) * MT_N * 4));
+        MTD_HIP(hipMalloc((void**)&m.gates, G_WORDS * 8));
+        MTD_HIP(hipMemset(m.gates, 0, G_WORDS * 8));
+        m.use_gates = getenv("EMX_MTDEV_EVENTS") == nullptr;       // (the event-ordered form, for comparison)
         MTD_HIP(hipMalloc((void**)&m.d_pos, 8));
         MTD_HIP(hipMalloc((void**)&m.d_err, 4));
         MTD_HIP(hipMalloc((void**)&m.d_nwin, 128));
@@ -157,7 +170,7 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         }
         MTD_HIP(hipMalloc((void**)&m.fin_partial, (size_t)MTDEV_BATCH * m.nchunk * 4));
         MTD_HIP(hipMalloc((void**)&m.fin_hist, (size_t)MTDEV_BATCH * m.nchunk * m.S * 4));
-        const unsigned evf = getenv("EMX_X_EVTIMING") ? hipEventDefault : hipEventDisableTiming;
+        const unsigned evf = hipEventDisableTiming;
         for (int k = 0; k < MTDEV_NBUF; ++k) {
             MTD_HIP(hipMalloc((void**)&m.step_end[k], (size_t)MTDEV_BATCH * 8));
             MTD_HIP(hipEventCreateWithFlags(&m.bt[k].tok, evf));
@@ -166,7 +179,9 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
             MTD_HIP(hipEventCreateWithFlags(&m.bt[k].released, evf));
         }
         MTD_HIP(hipEventCreateWithFlags(&m.ev_gen, evf));
-        MTD_HIP(hipHostMalloc((void**)&m.h_end, (size_t)MTDEV_NBUF * MTDEV_BATCH * 8, hipHostMallocDefault));
+        MTD_HIP(hipHostMalloc((void**)&m.h_end, (size_t)(MTDEV_NBUF * MTDEV_BATCH + 8) * 8, hipHostMallocDefault));
+        m.h_done = m.h_end + (size_t)MTDEV_NBUF * MTDEV_BATCH;       // batches whose end positions have arrived (k_pos_publish)
+        *m.h_done = 0ull;
         MTD_HIP(hipMalloc((void**)&m.scratch, (size_t)MTDEV_BATCH * 5 * N * 4));
         MTD_HIP(hipMalloc((void**)&m.blk_words, (size_t)MTDEV_NBUF * MTDEV_BATCH * MT_N * 4));
         // the jump polynomials t^(k SEG_WORDS) mod phi, k = 1 .. PMAX - 1 (once per process; ~70 ms)
@@ -185,6 +200,7 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         MTD_HIP(hipMemset(m.d_nwin, 0, 128));
         m.known = -1;
         m.known_pos = p0;
+        m.pos0 = p0;
         m.gen_words = 0;
         return 0;
     };
@@ -200,7 +216,7 @@ MtDevProducer::~MtDevProducer() {
             hipStreamSynchronize(s);
             hipStreamDestroy(s);
         }
-    void* bufs[] = {m.stream, m.base_key, m.xwin, m.partial, m.polys, m.d_pos, m.d_err, m.d_nwin, m.J[0], m.J[1], m.rint[0], m.rint[1],
+    void* bufs[] = {m.gates, m.stream, m.base_key, m.xwin, m.partial, m.polys, m.d_pos, m.d_err, m.d_nwin, m.J[0], m.J[1], m.rint[0], m.rint[1],
                     m.tokpos[0], m.tokpos[1], m.scratch, m.blk_words, m.recs[0], m.recs[1], m.nrec[0], m.nrec[1], m.fin_partial, m.fin_hist};
     for (void* p : bufs)
         if (p) hipFree(p);
@@ -217,6 +233,14 @@ MtDevProducer::~MtDevProducer() {
 void MtDevProducer::refresh_stats() {
     Impl& m = *im_;
     if (hipSetDevice(m.device) != hipSuccess || hipStreamSynchronize(m.s_tok) != hipSuccess) return;
+    if (getenv("EMX_MTDEV_TRACE")) {
+        unsigned long long gs[12] = {};
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(gs, m.gates + G_STATS, sizeof(gs), hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char* names[6] = {"generator<-finisher", "tokenizer<-generator", "tokenizer<-finisher", "finisher<-tokenizer", "finisher<-consumer", "consumer<-finisher"};
+            for (int k = 0; k < 6; ++k)
+                fprintf(stderr, "gate %-22s %8llu waits, %10.1f us in all, %8.1f us each\n", names[k], gs[2 * k + 1], gs[2 * k] * 0.01, gs[2 * k + 1] ? gs[2 * k] * 0.01 / gs[2 * k + 1] : 0.0);
+        }
+    }
     unsigned long long nw[16] = {};
     if (hipMemcpy(nw, m.d_nwin, 128, hipMemcpyDeviceToHost) == hipSuccess) {
 #ifdef EMX_TOK_PROFILE
@@ -235,11 +259,34 @@ void MtDevProducer::set_window_rule(int wshift, int tail) {
     if (tail >= 0) im_->tail = tail;
 }
 
+static double tr_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) {
     Impl& m = *im_;
+    static const bool TR = getenv("EMX_MTDEV_TRACE") != nullptr && atoi(getenv("EMX_MTDEV_TRACE")) > 1;
+    const double tr0 = tr_ms();
+    if (TR) fprintf(stderr, "ensure_batch(%lld) at %.3f ms: enq %lld known %lld\n", (long long)b, tr0, (long long)m.enq, (long long)m.known);
     if (!err_.empty()) return -1;
     MTD_HIP(hipSetDevice(m.device));
     lookahead = std::max(0, std::min(lookahead, MTDEV_NBUF - 2));
+    // the end positions of batch q have arrived in h_end (k_pos_publish on the tokenizer's stream)
+    auto wait_positions = [&](int64_t q) -> bool {
+        const double t0_ = tr_ms();
+        while ((int64_t)__atomic_load_n(m.h_done, __ATOMIC_ACQUIRE) <= q) {
+            if (tr_ms() - t0_ > 20000.0) {
+                err_ = "mtdev: the tokenizer did not finish a batch in 20 s";
+                return false;
+            }
+        }
+        return true;
+    };
+    // (site: 0 generator <- finisher, 1 tokenizer <- generator, 2 tokenizer <- finisher, 3 finisher <- tokenizer, 4 finisher <- consumer, 5 consumer <- finisher)
+    auto gate_wait = [&](hipStream_t st, int gate, unsigned long long value, int site) {
+        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, st, (const unsigned long long*)(m.gates + gate), value, GATE_TIMEOUT_TICKS, m.d_err,
+                           m.gates + G_STATS + 2 * site);
+    };
+    auto gate_signal = [&](hipStream_t st, int gate, unsigned long long value) {
+        hipLaunchKernelGGL(k_gate_signal, dim3(1), dim3(64), 0, st, m.gates + gate, value);
+    };
     while (m.enq <= b + lookahead) {
         const int64_t nbq = m.enq;
         const int buf = (int)(nbq % MTDEV_NBUF), par = (int)(nbq & 1);
@@ -255,14 +302,16 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
         // exact end positions of finished batches tighten the bounds; the host stays at most NBUF batches ahead of what it knows
         // (the pinned slot of batch nbq - NBUF is about to be rewritten, and the bounds below must stay inside the ring)
         while (m.known + 1 < nbq) {
-            hipEvent_t pe = m.bt[(m.known + 1) % MTDEV_NBUF].pos;
             if (m.known + 1 <= nbq - MTDEV_NBUF) {
-                MTD_HIP(hipEventSynchronize(pe));
-            } else if (hipEventQuery(pe) != hipSuccess) {
+                const double t_ = tr_ms();
+                if (!wait_positions(m.known + 1)) return -9;
+                if (TR) fprintf(stderr, "   wait A for pos(%lld): %.3f ms\n", (long long)m.known + 1, tr_ms() - t_);
+            } else if ((int64_t)__atomic_load_n(m.h_done, __ATOMIC_ACQUIRE) <= m.known + 1) {
                 break;
             }
             ++m.known;
             m.known_pos = m.h_end[(size_t)(m.known % MTDEV_NBUF) * MTDEV_BATCH + MTDEV_BATCH - 1];
+            m.end_hist[m.known % Impl::END_HIST] = m.known_pos;
         }
         // upper bound of where batch nbq ends (+ the window slack): that much of the stream must exist before its tokenizer starts
         const uint64_t hi_end = m.known_pos + (uint64_t)(nbq - m.known) * MTDEV_BATCH * m.wmax + m.slack;
@@ -286,14 +335,33 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
                         err_ = "mtdev: the stream ring is too small for this configuration";
                         return -1;
                     }
-                    MTD_HIP(hipEventSynchronize(m.bt[(m.known + 1) % MTDEV_NBUF].pos));
+                    const double t_ = tr_ms();
+                    if (!wait_positions(m.known + 1)) return -9;
+                    if (TR) fprintf(stderr, "   wait B for pos(%lld) for nbq %lld: %.3f ms\n", (long long)m.known + 1, (long long)nbq, tr_ms() - t_);
                     ++m.known;
                     m.known_pos = m.h_end[(size_t)(m.known % MTDEV_NBUF) * MTDEV_BATCH + MTDEV_BATCH - 1];
+                    m.end_hist[m.known % Impl::END_HIST] = m.known_pos;
                 }
+                int64_t qlast = -1;
                 for (int64_t q = std::max<int64_t>(0, m.enq - MTDEV_NBUF); q < m.enq; ++q) {
-                    const bool maybe_live = q <= m.known + 1 || m.known_pos + (uint64_t)(q - 1 - m.known) * MTDEV_BATCH * m.wmin < dead_below + MT_N;
-                    if (maybe_live) MTD_HIP(hipStreamWaitEvent(m.s_gen, m.bt[q % MTDEV_NBUF].fin, 0));
+                    // where batch q starts: exactly (the end of batch q - 1, when the host has read it and it is still in h_end), or
+                    // a lower bound from the last position known
+                    bool maybe_live = true;
+                    if (q == 0) {
+                        maybe_live = m.pos0 < dead_below + MT_N;
+                    } else if (q - 1 <= m.known) {
+                        if (q - 1 > m.known - Impl::END_HIST) maybe_live = m.end_hist[(q - 1) % Impl::END_HIST] < dead_below + MT_N;
+                    } else {
+                        maybe_live = m.known_pos + (uint64_t)(q - 1 - m.known) * MTDEV_BATCH * m.wmin < dead_below + MT_N;
+                    }
+                    if (!maybe_live) continue;
+                    if (m.use_gates)
+                        qlast = q;
+                    else
+                        MTD_HIP(hipStreamWaitEvent(m.s_gen, m.bt[q % MTDEV_NBUF].fin, 0));
                 }
+                if (TR) fprintf(stderr, "   gen round for batch %lld: dead_below %llu known %lld known_pos %llu -> waits for fin(%lld)\n", (long long)nbq, (unsigned long long)dead_below, (long long)m.known, (unsigned long long)m.known_pos, (long long)qlast);
+                if (qlast >= 0) gate_wait(m.s_gen, G_FIN, (unsigned long long)qlast + 1ull, 0);        // (finishers complete in order)
             }
             const bool first = m.rounds == 0;
             const uint64_t first_word = first ? MT_N : m.gen_words;       // (the base block of round 0 is words [0, 624))
@@ -314,12 +382,18 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
             MTD_HIP(hipEventRecord(m.ev_gen, m.s_gen));
             m.gen_words = first_word + (uint64_t)P * SEG_WORDS;
             ++m.rounds;
+            if (m.use_gates) gate_signal(m.s_gen, G_GEN, (unsigned long long)m.rounds);
             st_.rounds++;
             st_.segments += P;
         }
         // ---- tokenizer of batch nbq: after the stream it needs, and after the finisher that last read its J / rint / tokpos ----
-        MTD_HIP(hipStreamWaitEvent(m.s_tok, m.ev_gen, 0));
-        if (nbq >= 2) MTD_HIP(hipStreamWaitEvent(m.s_tok, m.bt[(nbq - 2) % MTDEV_NBUF].fin, 0));
+        if (m.use_gates) {
+            gate_wait(m.s_tok, G_GEN, (unsigned long long)m.rounds, 1);
+            if (nbq >= 2) gate_wait(m.s_tok, G_FIN, (unsigned long long)nbq - 1ull, 2);
+        } else {
+            MTD_HIP(hipStreamWaitEvent(m.s_tok, m.ev_gen, 0));
+            if (nbq >= 2) MTD_HIP(hipStreamWaitEvent(m.s_tok, m.bt[(nbq - 2) % MTDEV_NBUF].fin, 0));
+        }
         TokArgs ta{};
         ta.stream = m.stream;
         ta.smask = m.capw - 1;
@@ -343,11 +417,19 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
         hipLaunchKernelGGL(k_mt_tok, dim3(1), dim3(TOK_T), 0, m.s_tok, ta);
         MTD_HIP(hipGetLastError());
         MTD_HIP(hipEventRecord(m.bt[buf].tok, m.s_tok));
-        MTD_HIP(hipMemcpyAsync(m.h_end + (size_t)buf * MTDEV_BATCH, m.step_end[buf], (size_t)MTDEV_BATCH * 8, hipMemcpyDeviceToHost, m.s_tok));
+        hipLaunchKernelGGL(k_pos_publish, dim3(1), dim3(64), 0, m.s_tok, (const unsigned long long*)m.step_end[buf], m.h_end + (size_t)buf * MTDEV_BATCH,
+                           (int)MTDEV_BATCH, m.h_done, (unsigned long long)nbq + 1ull);
+        MTD_HIP(hipGetLastError());
         MTD_HIP(hipEventRecord(m.bt[buf].pos, m.s_tok));
+        if (m.use_gates) gate_signal(m.s_tok, G_TOK, (unsigned long long)nbq + 1ull);
         // ---- finisher: after the tokenizer, and after the consumer's last read of the plan slots it rewrites ----
-        MTD_HIP(hipStreamWaitEvent(m.s_fin, m.bt[buf].tok, 0));
-        if (m.bt[buf].has_released) MTD_HIP(hipStreamWaitEvent(m.s_fin, m.bt[buf].released, 0));
+        if (m.use_gates) {
+            gate_wait(m.s_fin, G_TOK, (unsigned long long)nbq + 1ull, 3);
+            if (m.bt[buf].has_released) gate_wait(m.s_fin, G_REL, (unsigned long long)(nbq - MTDEV_NBUF) + 1ull, 4);
+        } else {
+            MTD_HIP(hipStreamWaitEvent(m.s_fin, m.bt[buf].tok, 0));
+            if (m.bt[buf].has_released) MTD_HIP(hipStreamWaitEvent(m.s_fin, m.bt[buf].released, 0));
+        }
         m.bt[buf].has_released = false;
         FinArgs fa{};
         fa.stream = m.stream;
@@ -395,14 +477,22 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
         }
         MTD_HIP(hipGetLastError());
         MTD_HIP(hipEventRecord(m.bt[buf].fin, m.s_fin));
+        if (m.use_gates) gate_signal(m.s_fin, G_FIN, (unsigned long long)nbq + 1ull);
+        MTD_HIP(hipGetLastError());
         ++m.enq;
         st_.batches++;
+        if (TR) fprintf(stderr, "   enqueued batch %lld (gen_words %llu, known %lld) +%.3f ms\n", (long long)nbq, (unsigned long long)m.gen_words, (long long)m.known, tr_ms() - tr0);
     }
     if (m.enq <= b) {
         err_ = "mtdev: batch not produced";
         return -1;
     }
-    MTD_HIP(hipStreamWaitEvent(consumer, m.bt[b % MTDEV_NBUF].fin, 0));
+    if (m.use_gates) {
+        gate_wait(consumer, G_FIN, (unsigned long long)b + 1ull, 5);
+        MTD_HIP(hipGetLastError());
+    } else {
+        MTD_HIP(hipStreamWaitEvent(consumer, m.bt[b % MTDEV_NBUF].fin, 0));
+    }
     return 0;
 }
 
@@ -411,6 +501,10 @@ int MtDevProducer::release_batch(int64_t b, hipStream_t consumer) {
     MTD_HIP(hipSetDevice(m.device));
     const int buf = (int)(b % MTDEV_NBUF);
     MTD_HIP(hipEventRecord(m.bt[buf].released, consumer));
+    if (m.use_gates) {
+        hipLaunchKernelGGL(k_gate_signal, dim3(1), dim3(64), 0, consumer, m.gates + G_REL, (unsigned long long)b + 1ull);
+        MTD_HIP(hipGetLastError());
+    }
     m.bt[buf].has_released = true;
     return 0;
 }
@@ -426,6 +520,10 @@ int MtDevProducer::finish(int64_t steps_taken, MT19937Legacy& out) {
     if (steps_taken <= 0) return 0;
     unsigned e = 0;
     MTD_HIP(hipMemcpy(&e, m.d_err, 4, hipMemcpyDeviceToHost));
+    if (e & 4u) {
+        err_ = "mtdev: a stage of the producer waited 20 s for another (k_gate_wait): the run is void";
+        return -9;
+    }
     if (e) {
         err_ = "mtdev: the generated stream ran out under the tokenizer (status bit 2): the run is void";
         return -9;

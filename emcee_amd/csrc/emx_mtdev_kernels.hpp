@@ -55,6 +55,47 @@ __device__ __forceinline__ void twist_lds(const uint32_t* o, uint32_t* n, int ti
 }
 
 // ---- the window: WIN_BLOCKS blocks after the base state, untempered; optionally the base block itself into the stream ----------
+// ---- cross-stream dependencies without events --------------------------------------------------------------------------
+// The producer's stages live on streams of their own and used to wait for each other through hipStreamWaitEvent.  Measured
+// (profiles/r04/mtdev_gates.txt, and emx.hip: pipe_fetch_deferred): a wait on an event recorded several launches earlier does NOT
+// resolve to that record -- the runtime learns of completions lazily and orders the waiting stream behind the other stream's LATEST
+// work -- so "the tokenizer of batch n + 2 waits for the finisher of batch n" became "... of batch n + 1", the generator waited for
+// that finisher too, and the three stages ran one after the other (tokenizer 1 100 + finisher 285 + generator 196 us a batch).
+// Instead every stage counts what it has completed in a device word (k_gate_signal, the last kernel of the stage's work on its
+// in-order stream) and whoever depends on it starts with k_gate_wait: one wave that polls the word.  The kernel boundaries on
+// either side do the release / acquire.  A wait that is never met -- a stage that died -- raises bit 2 of the error word after
+// `timeout_ticks` (100 MHz) and lets its stream go on: the run is void and says so.
+static __global__ void k_gate_signal(unsigned long long* word, unsigned long long value) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __global__ void k_gate_wait(const unsigned long long* word, unsigned long long value, unsigned long long timeout_ticks, unsigned* err,
+                                   unsigned long long* waited) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
+        if (wall_clock64() - t0 > timeout_ticks) {
+            atomicOr(err, 4u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (waited) {          // (statistics: 10 ns ticks this site has waited, and how often)
+        atomicAdd(waited, wall_clock64() - t0);
+        atomicAdd(waited + 1, 1ull);
+    }
+}
+
+// the end positions of a tokenised batch, straight into pinned host memory, then the batch's number into a pinned word: the host
+// follows the tokenizer by reading that word (hipEventSynchronize on an event of this stream waited for the stream's LATEST
+// work -- the tokenizer of the batch just enqueued, 1.1 ms -- and kept the host from enqueueing ahead)
+static __global__ void k_pos_publish(const unsigned long long* __restrict__ step_end, unsigned long long* __restrict__ h_end, int n,
+                                     unsigned long long* h_done, unsigned long long value) {
+    if ((int)threadIdx.x < n) h_end[threadIdx.x] = step_end[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_done, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static __global__ __launch_bounds__(256) void k_mt_window(const uint32_t* __restrict__ base_key, uint32_t* __restrict__ xwin,
                                                           uint32_t* __restrict__ stream, unsigned long long smask,
                                                           unsigned long long base_word, int write_base_block) {
