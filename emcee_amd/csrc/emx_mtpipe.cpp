@@ -155,12 +155,20 @@ std::vector<int> distinct_cores(const CpuSet&) { return {}; }
 void confine(std::thread&, const CpuSet&, const std::vector<int>&, int) {}
 #endif
 
-// Waiting for a neighbouring stage: spin, then yield for ~2 ms, then sleep.  The consumer may take its steps in bursts (eight per
-// launch of the persistent kernels): a stage that went to sleep in between wakes 100+ us late (40 us + the timer slack), three stages in
-// a row 250 us -- more than the burst takes.  Hence the long yield phase, and the threads' timer slack set to 1 us (stage_thread_setup).
+// Waiting for a neighbouring stage: spin on PAUSE for a while, then sleep in short naps.  The consumer may take its steps in bursts
+// (sixteen per launch of the persistent kernels, 80-150 us apart): a stage that went to sleep in between woke 100+ us late (40 us + the
+// default 50 us timer slack), three stages in a row 250 us -- more than a burst takes.  Hence: the spin covers the gap between two
+// bursts, the naps are 20 us with the threads' timer slack set to 1 us (stage_thread_setup).  PAUSE, not sched_yield: on a host whose
+// logical CPUs are SMT pairs (the 16-CPU boxes) six finishers yielding in a loop next to the generator and the tokenizer cost those a
+// third of their rate (C2 exact mode 54 -> 87 us/step, profiles/r04/exact_mid.txt); PAUSE hands the core's issue slots to the sibling.
+// EMX_PIPE_SPIN_US overrides the spin window (default 150 us).
 struct Backoff {
     int n = 0;
     uint64_t t0 = 0;
+    static uint64_t spin_ns() {
+        static const uint64_t v = getenv("EMX_PIPE_SPIN_US") ? (uint64_t)atoll(getenv("EMX_PIPE_SPIN_US")) * 1000ull : 150000ull;
+        return v;
+    }
     inline void pause() {
         if (n < 256) {
             ++n;
@@ -175,10 +183,14 @@ struct Backoff {
             t0 = now;
         }
         const uint64_t waited = now - t0;
-        if (waited < 2000000ull) {
+        if (waited < spin_ns()) {
+#if defined(__x86_64__)
+            for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
+#else
             std::this_thread::yield();
+#endif
         } else if (waited < 150000000ull) {
-            std::this_thread::sleep_for(std::chrono::microseconds(40));
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
         } else {
             std::this_thread::sleep_for(std::chrono::microseconds(500));      // a pipeline left idle between calls costs next to nothing
         }
