@@ -3155,7 +3155,7 @@ static bool persist_wanted(const emx_ctx* c) {
     return sh.G == 8 && sh.V == 2 && sh.CH == (dpb == 1 ? 1 : dpb == 2 ? 2 : 4);
 }
 
-// The element-wise targets (csrc/emx_pvalu.hip): the one-XCD form only -- ensembles of up to 8 192 walkers, rows of 8 lanes per walker
+// The element-wise targets (csrc/emx_pvalu.hip): the one-XCD form only -- ensembles of up to 8 192 walkers, rows of 4 or 8 lanes per walker
 // (ndim <= 64 even, <= 32 odd), Philox plans, one replica, every move of the schedule one the kernel knows at a shape it can take.
 static bool persist_valu_wanted(const emx_ctx* c) {
     if (!c->tune_persist || !c->tune_persist_local || !c->tune_persist_valu) return false;
@@ -3165,7 +3165,7 @@ static bool persist_valu_wanted(const emx_ctx* c) {
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
     if (c->N < c->tune_persist_min_walkers) return false;
     const Shape sh = pick_shape(c->D, c->D);
-    if (sh.G != 8 || (sh.CH != 1 && sh.CH != 2 && sh.CH != 4)) return false;
+    if (!((sh.G == 8 && (sh.CH == 1 || sh.CH == 2 || sh.CH == 4)) || (sh.G == 4 && sh.CH == 1))) return false;      // (launch_persist_valu's instantiations)
     bool any = false;
     for (const auto& m : c->moves) any = any || persist_local_ok(c, m);
     return any;

@@ -174,8 +174,10 @@ static hipError_t launch_pv(int move, dim3 grid, dim3 block, hipStream_t st, con
     return hipGetLastError();
 }
 
-// row layouts of 8 lanes per walker: V = 2 (even ndim <= 64) / V = 1 (odd ndim <= 32), CH = 1, 2, 4
+// row layouts of 8 lanes per walker: V = 2 (even ndim 10 ... 64) / V = 1 (odd ndim 5 ... 32), CH = 1, 2, 4; of 4 lanes per walker:
+// ndim <= 4 and even ndim <= 8 (pick_shape: the dimensions of most real-world fits)
 hipError_t launch_persist_valu(int G, int V, int CH, int move, dim3 grid, dim3 block, hipStream_t st, const PersistArgs& P) {
+    if (G == 4 && CH == 1) return V == 2 ? launch_pv<4, 2, 1>(move, grid, block, st, P) : launch_pv<4, 1, 1>(move, grid, block, st, P);
     if (G != 8) return hipErrorInvalidValue;
 #define EMX_CASE(v, c) \
     if (V == v && CH == c) return launch_pv<8, v, c>(move, grid, block, st, P);

@@ -95,6 +95,11 @@ DIGEST_CASES = {
     "stretch_1024x256_dense": dict(N=1024, D=256, target="dense", moves=[_S("stretch")], nsteps=2, seed=405),
     "stretch_1100x520_dense": dict(N=1100, D=520, target="dense", moves=[_S("stretch")], nsteps=2, seed=406),
     "mix_de_snooker_1024x64_dense": dict(N=1024, D=64, target="dense", moves=[_S("de"), _S("snooker")], weights=[0.8, 0.2], nsteps=6, seed=404),
+    # round 4: long enough for several launches of the persistent kernels in exact mode (sixteen steps each: k_plan_fetch)
+    "stretch_1024x16_iso_40": dict(N=1024, D=16, target="iso", moves=[_S("stretch")], nsteps=40, seed=411),
+    "de_2048x8_diag_24": dict(N=2048, D=8, target="diag", moves=[_S("de")], nsteps=24, seed=412),
+    "snooker_1024x8_iso_20": dict(N=1024, D=8, target="iso", moves=[_S("snooker")], nsteps=20, seed=413),
+    "stretch_512x64_dense_35": dict(N=512, D=64, target="dense", moves=[_S("stretch")], nsteps=35, seed=414),
 }
 
 

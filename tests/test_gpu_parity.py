@@ -111,6 +111,11 @@ def test_exact_mode_mid_size_against_oracle(name):
     ens.chain_config(spec["nsteps"])
     ens.run(spec["nsteps"], thin_by=spec["thin_by"], store=True)
     assert ens.status() == 0
+    info = ens.persist_info()
+    if info["qualifies"]:          # one move, 512 ... 8 192 walkers: the one-XCD persistent kernels on the host pipeline's plans
+        assert info["launches"] >= (spec["nsteps"] + 15) // 16 and info["recovered"] == 0
+    if name.endswith(("_40", "_24", "_20", "_35")):
+        assert info["qualifies"], "the long mid-size cases are there for the persistent exact path"
     chain = ens.chain_read(0, 0, spec["nsteps"])
     assert np.array_equal(ens.accepted_counts(), out["accepted_count"])
     if has_snooker(spec):

@@ -115,6 +115,12 @@ def test_one_xcd_form_and_device_wide_form_agree_with_the_launch_per_halfstep_pa
     (2048, 7, "box", [S("stretch")], None, False, 1),
     (4096, 24, "iso", [S("stretch"), S("de")], [0.6, 0.4], True, 1),       # a mixture: runs of each move in launches of their own
     (8192, 64, "iso", [S("de"), S("snooker")], [0.8, 0.2], False, 1),
+    (1024, 8, "iso", [S("stretch")], None, True, 1),                       # rows of 4 lanes: ndim <= 4, even ndim <= 8
+    (2048, 3, "diag", [S("stretch")], None, True, 2),
+    (4096, 2, "rosenbrock", [S("stretch")], None, False, 1),
+    (2048, 6, "diag", [S("de")], None, True, 1),
+    (2048, 4, "iso", [S("snooker")], None, False, 1),
+    (512, 1, "box", [S("stretch")], None, True, 1),
 ])
 def test_element_wise_targets_run_persistently_on_one_xcd(N, D, target, moves, weights, store, thin_by):
     """csrc/emx_pvalu.hip: ensembles of up to 8 192 walkers on an element-wise target (isotropic / diagonal Gaussian, Rosenbrock, box)
