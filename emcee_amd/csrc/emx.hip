@@ -374,6 +374,7 @@ struct emx_ctx {
     int64_t tune_fetch_delay_us = 0;     // tests: k_plan_fetch idles this long before it reads
     int64_t tune_persist_mix = 1;        // 0: a mixture's steps never share a launch (one run of one move per launch)
     int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
+    int64_t call_steps = 1;              // steps of the emx_run call being served (1: emx_step_begin on its own)
     int64_t tune_persist_exact = 1;      // 0: exact (MT19937) mode never takes the persistent kernels
     int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
     int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
@@ -3132,6 +3133,9 @@ static bool persist_mix_ok(const emx_ctx* cc) {
 // launch that takes them -- one StretchMove / DEMove / DESnookerMove alone (a mixture's next move is only known once its plan has been
 // taken), ensembles of 512 ... 8 192 walkers.  The default rng of the Python layer: 25-33 -> 6-9 us/step (profiles/r04/exact_mid.txt).
 static bool persist_exact_ok(const emx_ctx* c) {
+    // (an ensemble the one-workgroup kernel can take, asked for a step or two at a time -- the sample() loop of a progress bar or a
+    // convergence check: that kernel's 10 us launch beats a fetch + a persistent launch per call, 49 against 72 us an iteration)
+    if (small_eligible(c) && c->call_steps < 4) return false;
     return c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_exact != 0 && c->moves.size() == 1 && c->tune_mt_pipeline != 0 &&
            c->N >= c->tune_persist_min_walkers && persist_local_ok(c, c->moves[0]) && !mtdev_eligible(c) &&        // (the device producer: see persist_wanted)
            MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
@@ -3638,6 +3642,7 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     NEED(c, thin_by >= 1, "Invalid thinning argument");
     NEED(c, !c->cur.active, "emx_run: a step begun with emx_step_begin is still open");
     const int64_t total = nsteps * thin_by;
+    c->call_steps = total;
     // exact mode, general path: the plans of the whole call come from the host pipeline (generator / tokenizer /
     // finisher threads) instead of being made inline, one step at a time, by this thread
     const bool devp = mtdev_eligible(c);
@@ -3649,6 +3654,7 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
         if (rc) return rc;
     }
     const int rc = run_impl(c, nsteps, thin_by, store);
+    c->call_steps = 1;                                       // (emx_step_begin on its own: one step at a time)
     if (rc && (c->pipe || c->mtdev)) pipe_stop(c);          // after an error the generator stands after the last plan taken
     return rc;
 }
