@@ -3330,7 +3330,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         if (devp) {
             if (steps > 0 && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) break;      // one produced batch per launch
         } else if (mtmode) {
-            if (steps >= c->tune_persist_exact_steps) break;          // (k_plan_fetch takes sixteen plans; half of the pipeline's slots)
+            if (steps >= std::min<int64_t>(c->tune_persist_exact_steps, c->pipe_nsinks / 2)) break;          // (k_plan_fetch takes sixteen plans; half of the pipeline's slots at most: the other half is produced meanwhile)
         } else {
             if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
             if (steps > 0 && !launch_mix && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
@@ -3625,7 +3625,10 @@ int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, in
 }
 
 int emx_persist_info(emx_ctx* c, int64_t out[4]) {
+    const int64_t keep = c->call_steps;
+    c->call_steps = (int64_t)1 << 40;          // "qualifies" is about an emx_run of many steps (exact mode: persist_exact_ok)
     out[0] = (persist_wanted(c) || persist_gauss_wanted(c) || persist_valu_wanted(c)) ? 1 : 0;
+    c->call_steps = keep;
     out[1] = c->persist_launches;
     out[2] = c->persist_halfsteps;
     out[3] = c->persist_recovered;       // launches that gave up untouched and were redone on the per-half-step path (persist_settle)
