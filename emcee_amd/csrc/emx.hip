@@ -370,6 +370,7 @@ struct emx_ctx {
     MtDevProducer* mtdev = nullptr;
     int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
     int64_t tune_persist_local = 1;      // 0: never the one-XCD form of the persistent kernel
+    int64_t tune_persist_exact_max = 32768;   // exact mode: largest ensemble that takes the device-wide persistent kernel
     int64_t tune_persist_exact_steps = 16;    // exact mode: steps per persistent launch (<= 16)
     int64_t tune_fetch_delay_us = 0;     // tests: k_plan_fetch idles this long before it reads
     int64_t tune_persist_mix = 1;        // 0: a mixture's steps never share a launch (one run of one move per launch)
@@ -1396,6 +1397,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "persist_exact")) {     // 0: exact mode always on the per-half-step launches
         pipe_stop(c);
         c->tune_persist_exact = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_exact_max_walkers")) {
+        pipe_stop(c);
+        c->tune_persist_exact_max = v;
         return 0;
     }
     if (!strcmp(key, "persist_exact_steps")) {
@@ -3136,9 +3142,14 @@ static bool persist_exact_ok(const emx_ctx* c) {
     // (an ensemble the one-workgroup kernel can take, asked for a step or two at a time -- the sample() loop of a progress bar or a
     // convergence check: that kernel's 10 us launch beats a fetch + a persistent launch per call, 49 against 72 us an iteration)
     if (small_eligible(c) && c->call_steps < 4) return false;
-    return c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_exact != 0 && c->moves.size() == 1 && c->tune_mt_pipeline != 0 &&
-           c->N >= c->tune_persist_min_walkers && persist_local_ok(c, c->moves[0]) && !mtdev_eligible(c) &&        // (the device producer: see persist_wanted)
-           MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
+    if (!(c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_exact != 0 && c->moves.size() == 1 && c->tune_mt_pipeline != 0 &&
+          c->N >= c->tune_persist_min_walkers && !mtdev_eligible(c) &&        // (the device producer: see persist_wanted)
+          MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data())))
+        return false;
+    if (persist_local_ok(c, c->moves[0])) return true;
+    // the device-wide form of the dense kernel up to "persist_exact_max_walkers" (32 768): beyond, the pipeline's generator thread
+    // bounds the step whatever runs it, and a launch's plans are 25 MB to fetch over PCIe
+    return c->target == EMX_TARGET_DENSE_GAUSS && c->N <= c->tune_persist_exact_max && persist_shape(c, c->moves[0].nsplits) != 0;
 }
 
 static bool persist_wanted(const emx_ctx* c) {

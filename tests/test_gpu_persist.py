@@ -386,7 +386,7 @@ def test_what_does_not_qualify():
         assert ens.persist_info()["launches"] == 0 and ens.status() == 0
         ens.close()
     # exact (MT19937) mode: only where the one-XCD form runs (the host pipeline's plans, test_exact_mode_* below)
-    for N, want in ((4096, True), (16384, False)):
+    for N, want in ((4096, True), (16384, True), (65536, False)):       # (device-wide form: up to persist_exact_max_walkers = 32 768)
         ens = native_ens(dense_spec(N, 64), 1)
         ens.set_rng_mode(_lib.RNG_MT19937)
         assert ens.persist_info()["qualifies"] == want, N
@@ -603,7 +603,8 @@ def test_exact_mode_takes_the_one_xcd_persistent_kernels(N, D, target, move, sto
             assert np.array_equal(p[key], c[key]), key
 
 
-@pytest.mark.parametrize("N,D,target,steps_per_launch", [(1024, 64, "dense", 16), (512, 24, "iso", 16), (4096, 32, "dense", 5), (2048, 10, "iso", 1)])
+@pytest.mark.parametrize("N,D,target,steps_per_launch", [(1024, 64, "dense", 16), (512, 24, "iso", 16), (4096, 32, "dense", 5), (2048, 10, "iso", 1),
+                                                         (16384, 64, "dense", 16), (32768, 48, "dense", 16)])       # (the device-wide form)
 def test_exact_mode_persistent_long_run(N, D, target, steps_per_launch):
     """700 steps of exact mode on the persistent kernels, the host enqueueing ahead of the device: every plan slot is rewritten
     (k_plan_fetch) some twenty times, each time only after a LATER launch than the slot's last reader is known to have started
