@@ -2044,7 +2044,8 @@ static int pipe_start(emx_ctx* c) {
     HIPOK(c, hipStreamSynchronize(c->up_stream));
     *c->pipe_done = 0ull;
     PlanSink sinks[PLAN_RING];
-    c->pipe_nsinks = persist_exact_ok(c) ? PLAN_RING : PIPE_SINKS;      // (bursts of eight steps: the producers need the slack)
+    c->pipe_nsinks = persist_exact_ok(c) ? PLAN_RING : PIPE_SINKS;      // (bursts of sixteen steps: the producers need the slack)
+    MtPlanPipeline::set_bursty_consumer(c->pipe_nsinks == PLAN_RING);
     c->pipe_ring0 = (c->ring_pos + 1) % PLAN_RING;
     for (int r = 0; r < c->pipe_nsinks; ++r) {
         auto& s = c->ring[(c->pipe_ring0 + r) % PLAN_RING];

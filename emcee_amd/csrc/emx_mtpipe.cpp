@@ -161,14 +161,14 @@ void confine(std::thread&, const CpuSet&, const std::vector<int>&, int) {}
 // bursts, the naps are 20 us with the threads' timer slack set to 1 us (stage_thread_setup).  PAUSE, not sched_yield: on a host whose
 // logical CPUs are SMT pairs (the 16-CPU boxes) six finishers yielding in a loop next to the generator and the tokenizer cost those a
 // third of their rate (C2 exact mode 54 -> 87 us/step, profiles/r04/exact_mid.txt); PAUSE hands the core's issue slots to the sibling.
-// EMX_PIPE_SPIN_US overrides the spin window (default 150 us).
+// The spin is for a consumer that takes its steps in bursts only (MtPlanPipeline::set_bursty_consumer: the persistent kernels); with a
+// consumer that takes a step at a time and orders its uploads with events, spinning stage threads made it SLOWER (26.8 -> 48.8 us/step
+// at 4 096 walkers, 68 -> 84 at 65 536: profiles/r04/exact_mid.txt) -- there the window is 0.  EMX_PIPE_SPIN_US overrides both.
+static std::atomic<uint64_t> g_spin_ns{0};
 struct Backoff {
     int n = 0;
     uint64_t t0 = 0;
-    static uint64_t spin_ns() {
-        static const uint64_t v = getenv("EMX_PIPE_SPIN_US") ? (uint64_t)atoll(getenv("EMX_PIPE_SPIN_US")) * 1000ull : 150000ull;
-        return v;
-    }
+    static uint64_t spin_ns() { return g_spin_ns.load(std::memory_order_relaxed); }
     inline void pause() {
         if (n < 256) {
             ++n;
@@ -177,20 +177,26 @@ struct Backoff {
 #endif
             return;
         }
+        const uint64_t spin = spin_ns();
+        if (spin == 0 && n < 512) {          // (a consumer that takes a step at a time: yield a little, then 40 us naps, as in rounds 1-3)
+            ++n;
+            std::this_thread::yield();
+            return;
+        }
         const uint64_t now = now_ns();
-        if (n == 256) {
+        if (n == 256 || (spin == 0 && n == 512)) {
             ++n;
             t0 = now;
         }
         const uint64_t waited = now - t0;
-        if (waited < spin_ns()) {
+        if (waited < spin) {
 #if defined(__x86_64__)
             for (int k = 0; k < 32; ++k) __builtin_ia32_pause();
 #else
             std::this_thread::yield();
 #endif
         } else if (waited < 150000000ull) {
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            std::this_thread::sleep_for(std::chrono::microseconds(spin ? 20 : 40));
         } else {
             std::this_thread::sleep_for(std::chrono::microseconds(500));      // a pipeline left idle between calls costs next to nothing
         }
@@ -198,7 +204,7 @@ struct Backoff {
 };
 inline void stage_thread_setup() {
 #if defined(__linux__)
-    prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);       // (ns; the default 50 us is added to every sleep_for above)
+    if (g_spin_ns.load(std::memory_order_relaxed) != 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);       // (ns; the default 50 us is added to every sleep_for above)
 #endif
 }
 
@@ -667,6 +673,11 @@ struct MtPlanPipeline::Impl {
     void finish_step(int64_t n, std::vector<uint8_t>& labels);
     void join_all();
 };
+
+void MtPlanPipeline::set_bursty_consumer(bool bursty) {
+    const char* e = getenv("EMX_PIPE_SPIN_US");
+    g_spin_ns.store(e ? (uint64_t)atoll(e) * 1000ull : (bursty ? 150000ull : 0ull), std::memory_order_relaxed);
+}
 
 bool MtPlanPipeline::supports(int32_t nmoves, const emx_move_desc* moves) {
     for (int i = 0; i < nmoves; ++i) {

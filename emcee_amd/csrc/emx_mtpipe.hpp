@@ -76,6 +76,9 @@ class MtPlanPipeline {
     void release(int64_t n);
     // Stop all threads; `out` receives the generator state after `steps_consumed` steps (NumPy get_state() semantics).
     void finish(int64_t steps_consumed, MT19937Legacy& out);
+    // the consumer takes its steps sixteen at a time (the persistent kernels): the stage threads spin through the gaps between bursts
+    // instead of napping (process-wide; set before the pipeline is constructed)
+    static void set_bursty_consumer(bool bursty);
     int workers() const;
     // microseconds per produced step: [0] wall, [1] generator busy, [2] tokenizer busy, [3] finishers busy (summed), [4] tokenizer
     // waiting for words, [5] tokenizer waiting for a free staging buffer
