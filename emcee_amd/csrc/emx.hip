@@ -373,6 +373,7 @@ struct emx_ctx {
     int64_t tune_persist_exact_max = 32768;   // exact mode: largest ensemble that takes the device-wide persistent kernel
     int64_t tune_persist_exact_steps = 16;    // exact mode: steps per persistent launch (<= 16)
     int64_t tune_fetch_delay_us = 0;     // tests: k_plan_fetch idles this long before it reads
+    int64_t tune_persist_span = 1;       // 0: a persistent launch ends with the batch of Philox plans it started in
     int64_t tune_persist_mix = 1;        // 0: a mixture's steps never share a launch (one run of one move per launch)
     int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
     int64_t call_steps = 1;              // steps of the emx_run call being served (1: emx_step_begin on its own)
@@ -1410,6 +1411,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "test_fetch_delay_us")) {     // tests: k_plan_fetch idles first (its consumers must wait for it)
         c->tune_fetch_delay_us = std::max<int64_t>(0, std::min<int64_t>(v, 100000));
+        return 0;
+    }
+    if (!strcmp(key, "persist_span")) {
+        c->tune_persist_span = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "persist_mix")) {       // 0: DE and snooker steps of a mixture in launches of their own
@@ -3336,19 +3341,25 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     bool launch_mix = false;             // DE and snooker steps of a mixture in this launch (k_persist_mix)
     double launch_gammas = 0.0;
     while (i0 + steps < total) {
-        int need = launch_S;               // half-steps of the step that would follow (a mixed launch: read off its plan)
-        if (launch_mix && steps > 0 && !c->prepared.empty()) need = c->moves[c->prepared.front().move].nsplits;
+        // the move of the step that would follow: off its plan, or -- the batch of plans is used up: the next one is made during this
+        // capture, i.e. enqueued BEFORE this launch, into the other half of the plan ring -- from the Philox stream directly
+        int next_move = -1;
+        if (steps > 0 && !mtmode)
+            next_move = !c->prepared.empty() ? c->prepared.front().move : philox_move_choice(c->ph_seed, c->ph_step, c->cdf.data(), (int)c->moves.size());
+        int need = launch_S;               // half-steps of the step that would follow
+        if (launch_mix && next_move >= 0) need = c->moves[next_move].nsplits;
         if (n + need > PERSIST_MAX_ITERS) break;
         if (devp) {
             if (steps > 0 && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) break;      // one produced batch per launch
         } else if (mtmode) {
             if (steps >= std::min<int64_t>(c->tune_persist_exact_steps, c->pipe_nsinks / 2)) break;          // (k_plan_fetch takes sixteen plans; half of the pipeline's slots at most: the other half is produced meanwhile)
         } else {
-            if (steps > 0 && c->prepared.empty()) break;          // one plan batch per launch: the next batch's plan kernel follows it
-            if (steps > 0 && !launch_mix && c->moves[c->prepared.front().move].kind != launch_move) break;       // a mixture: the run of this move ends here
+            if (steps > 0 && c->prepared.empty() && !c->tune_persist_span) break;          // (tuning persist_span = 0: one plan batch per launch)
+            if (steps > 0 && !launch_mix && c->moves[next_move].kind != launch_move) break;       // a mixture: the run of this move ends here
             // (the snooker scale is a launch-wide kernel argument there: a second DESnookerMove with another `gammas` starts a launch of its own)
-            if (steps > 0 && !launch_mix && launch_move == EMX_MOVE_SNOOKER && c->moves[c->prepared.front().move].gammas != launch_gammas) break;
-            if (steps > 0 && launch_mix && !persist_mix_member(c->moves[c->prepared.front().move])) break;
+            if (steps > 0 && !launch_mix && launch_move == EMX_MOVE_SNOOKER && c->moves[next_move].gammas != launch_gammas) break;
+            if (steps > 0 && launch_mix && !persist_mix_member(c->moves[next_move])) break;
+            if (steps > 0 && !persist_move_ok(c, c->moves[next_move])) break;
         }
         c->prep_hint = NATIVE_BATCH_MAX;
         const int st = store && ((i0 + steps + 1) % thin_by == 0);          // ensemble.py:416
