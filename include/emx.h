@@ -357,7 +357,8 @@ int emx_host_mt_jump(const uint32_t key[624], uint64_t stride_words, int32_t k, 
  * fused dense Gaussian target at an even ndim up to 64, Philox plans, one replica, nwalkers a multiple of 32 from 512 (tuning
  * "persist_min_walkers") to 256 x the CU count, i.e. one 16-walker tile per wave of a co-resident grid of about one workgroup
  * per CU -- up to 32 half-steps per kernel launch (in a mixture: the consecutive steps of one move -- the steps of a DEMove and a
- * DESnookerMove share launches, k_persist_mix, tuning "persist_mix" = 0: never; steps with another number of
+ * DESnookerMove share launches, k_persist_mix, tuning "persist_mix" = 0: never; a launch goes on into the next batch of sixteen
+ * steps of Philox plans, "persist_span" = 0: it ends with its batch; steps with another number of
  * splits take the per-half-step launches): a device-wide barrier stands where the kernel
  * boundaries were, and the next half-step's plan entries and own rows are loaded while this one computes.  Same draws, same
  * arithmetic, same bits as the launch-per-half-step path.  Tuning "persist" = 0 turns it off; "persist_timeout_ms" bounds a
