@@ -3099,11 +3099,22 @@ static bool persist_grid_fits(const emx_ctx* cc, const emx_move_desc& m, int wpb
     return c->persist_fits[m.kind] != 0;
 }
 
+// The element-wise targets' persistent kernel in its device-wide form (k_persist_valu<..., LOCAL = false>): exact mode only -- there a
+// launch takes the fetched plans of sixteen steps where the per-half-step path pays an upload and five API calls per step (16 384 x 64:
+// 33 -> ~21 us/step); with Philox plans the per-half-step launches of these small kernels are as fast.  No LDS, <= 512 threads, at most
+// two workgroups a CU (persist_shape): co-resident by construction.
+static bool persist_valu_wide_ok(const emx_ctx* c, const emx_move_desc& m) {
+    const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
+    const bool valu = c->target == EMX_TARGET_ISO_GAUSS || c->target == EMX_TARGET_DIAG_GAUSS || c->target == EMX_TARGET_ROSENBROCK || c->target == EMX_TARGET_BOX;
+    return known && valu && c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_valu != 0 && c->N <= c->tune_persist_exact_max &&
+           persist_shape(c, m.nsplits) != 0;
+}
+
 static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
     const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
     if (!known) return false;
     if (persist_local_ok(c, m)) return true;            // (one workgroup per CU of one XCD by construction)
-    if (c->target != EMX_TARGET_DENSE_GAUSS) return false;       // (element-wise targets: the one-XCD form or nothing)
+    if (c->target != EMX_TARGET_DENSE_GAUSS) return persist_valu_wide_ok(c, m);       // (element-wise targets: the one-XCD form, or -- exact mode -- the device-wide one)
     const int wpb = persist_shape(c, m.nsplits);
     return wpb != 0 && persist_grid_fits(c, m, wpb);
 }
@@ -3155,7 +3166,8 @@ static bool persist_exact_ok(const emx_ctx* c) {
     if (persist_local_ok(c, c->moves[0])) return true;
     // the device-wide form of the dense kernel up to "persist_exact_max_walkers" (32 768): beyond, the pipeline's generator thread
     // bounds the step whatever runs it, and a launch's plans are 25 MB to fetch over PCIe
-    return c->target == EMX_TARGET_DENSE_GAUSS && c->N <= c->tune_persist_exact_max && persist_shape(c, c->moves[0].nsplits) != 0;
+    if (c->N > c->tune_persist_exact_max || persist_shape(c, c->moves[0].nsplits) == 0) return false;
+    return c->target == EMX_TARGET_DENSE_GAUSS || persist_valu_wide_ok(c, c->moves[0]);
 }
 
 static bool persist_wanted(const emx_ctx* c) {
@@ -3188,7 +3200,7 @@ static bool persist_valu_wanted(const emx_ctx* c) {
     const Shape sh = pick_shape(c->D, c->D);
     if (!((sh.G == 8 && (sh.CH == 1 || sh.CH == 2 || sh.CH == 4)) || (sh.G == 4 && sh.CH == 1))) return false;      // (launch_persist_valu's instantiations)
     bool any = false;
-    for (const auto& m : c->moves) any = any || persist_local_ok(c, m);
+    for (const auto& m : c->moves) any = any || persist_local_ok(c, m) || persist_valu_wide_ok(c, m);
     return any;
 }
 
@@ -3388,7 +3400,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             const bool valu = c->target != EMX_TARGET_DENSE_GAUSS;          // the element-wise targets' kernel (one-XCD form only)
             const bool move_ok = launch_mix ? (cap.move == MOVE_DE || cap.move == MOVE_SNOOKER) : cap.move == launch_move;
             if (!rc && (!cap.got || cap.dense == valu || (!valu && cap.dpb != c->Dp / 16) || !move_ok ||
-                        (int)cap.block.x != 64 * c->persist_wpb || (valu && !launch_local))) {
+                        (int)cap.block.x != 64 * c->persist_wpb || (valu && !launch_local && !persist_valu_wide_ok(c, c->moves[mvi])))) {
                 c->err = "persistent half-steps: launch shape not eligible";
                 rc = -1;
             }
@@ -3473,7 +3485,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         hipError_t e;
         if (c->target != EMX_TARGET_DENSE_GAUSS) {
             const Shape shv = pick_shape(c->D, c->D);
-            e = launch_persist_valu(shv.G, shv.V, shv.CH, launch_move, grid, block, c->stream, P);
+            e = launch_persist_valu(shv.G, shv.V, shv.CH, launch_move, launch_local ? 1 : 0, grid, block, c->stream, P);
         } else if (launch_mix) {
             e = launch_persist_mix(c->Dp / 16, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
         } else {

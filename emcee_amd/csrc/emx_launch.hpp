@@ -40,7 +40,7 @@ hipError_t launch_hot_persist_gauss(int dpb, dim3 grid, dim3 block, size_t lds, 
 hipError_t launch_persist_mix(int dpb, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
 hipError_t persist_mix_occupancy(int dpb, int threads, size_t lds, int* per_cu);
 // emx_pvalu.hip: the persistent kernel for the element-wise targets (one-XCD form)
-hipError_t launch_persist_valu(int G, int V, int CH, int move, dim3 grid, dim3 block, hipStream_t st, const PersistArgs& P);
+hipError_t launch_persist_valu(int G, int V, int CH, int move, int local, dim3 grid, dim3 block, hipStream_t st, const PersistArgs& P);
 // emx_slab.hip: the fused dense half-step at padded ndim 80 ... 128 with the proposals in registers and a 32-column LDS slab
 hipError_t launch_slab_dense(int dpb, int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a);
 size_t slab_lds_bytes(int Dp, int waves);

@@ -56,14 +56,19 @@ __device__ __forceinline__ void pv_store_row(const Row<G, V, CH>& r, __amdgpu_bu
     }
 }
 
-template <int G, int V, int CH, int MOVE>
+template <int G, int V, int CH, int MOVE, bool LOCAL = true>
 static __global__ __launch_bounds__(512) void k_persist_valu(const PersistArgs P) {
     static_assert(MOVE == MOVE_STRETCH || MOVE == MOVE_DE || MOVE == MOVE_SNOOKER, "the red / blue moves");
     constexpr bool DE = MOVE == MOVE_DE || MOVE == MOVE_SNOOKER;
     constexpr bool SN = MOVE == MOVE_SNOOKER;
     constexpr int WPW = 64 / G, PF = 16 / WPW;          // a wave owns 16 plan slots of every split (as in k_persist)
-    if ((blockIdx.x & 7u) != 0u) return;                // the one-XCD form: every eighth workgroup of an eight times larger grid
-    const unsigned bid = blockIdx.x >> 3, ngroups = gridDim.x >> 3;
+    // LOCAL: the one-XCD form -- every eighth workgroup of an eight times larger grid, plain stores, that XCD's flag barrier.
+    // !LOCAL: the device-wide form (ensembles beyond 8 192 walkers: about a workgroup per CU) -- agent-scope stores and the device-wide
+    // barrier, as k_persist; in exact mode it takes the fetched plans of sixteen steps per launch where the per-half-step path pays an
+    // upload and five API calls per step.
+    if (LOCAL && (blockIdx.x & 7u) != 0u) return;
+    const unsigned bid = LOCAL ? blockIdx.x >> 3 : blockIdx.x, ngroups = LOCAL ? gridDim.x >> 3 : gridDim.x;
+    (void)ngroups;
     const HalfStepArgs& A = P.base;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, sub = lane / G, gl = lane % G;
     const int D = A.D;
@@ -76,11 +81,11 @@ static __global__ __launch_bounds__(512) void k_persist_valu(const PersistArgs P
         load_row<G, V, CH>(mu, A.tp0, D, gl);
         load_row<G, V, CH>(iv, A.tp1, D, gl);
     }
-    if (!persist_handshake<true>(P)) return;
+    if (!persist_handshake<LOCAL>(P)) return;
     const int wave = (int)bid * (blockDim.x >> 6) + wib;
     const int t0 = wave * 16;
     const __amdgpu_buffer_rsrc_t Xr = __builtin_amdgcn_make_buffer_rsrc((void*)A.X, 0, A.N * D * 8, 0x00020000);
-    constexpr int LD = EMX_CPOL_SC1, ST = 0;            // loads agent-scope (answered by this XCD's L2), stores plain
+    constexpr int LD = EMX_CPOL_SC1, ST = LOCAL ? 0 : EMX_CPOL_SC1;      // loads agent-scope (LOCAL: answered by this XCD's L2); stores plain / agent-scope
     int wi[PF], ja[PF], jb[DE ? PF : 1], jc[SN ? PF : 1];
     double s0v[PF], facv[PF], loguv[PF];
     auto plan_of = [&](const PersistIter& I, int (&w)[PF], int (&a)[PF], int (&b)[DE ? PF : 1], int (&c3)[SN ? PF : 1], double (&s)[PF],
@@ -137,19 +142,22 @@ static __global__ __launch_bounds__(512) void k_persist_valu(const PersistArgs P
             const int i = wi[k];
             if (accept) {
                 pv_store_row<G, V, CH, ST>(q, Xr, i, D, gl);        // move.py:33
-                if (gl == 0) A.lp[i] = lp_new;                       // move.py:34
+                if (gl == 0) store_scope<LOCAL>(A.lp + i, lp_new);   // move.py:34
             }
             if (gl == 0) {
-                A.acc[i] = accept ? 1 : 0;
+                store_scope<LOCAL>(A.acc + i, (uint8_t)(accept ? 1 : 0));
                 if (I.chain_lp) {
                     I.chain_lp[i] = accept ? lp_new : lpo[k];
-                    if (accept) A.acc_count[i] = load_agent(A.acc_count + i) + 1u;
+                    if (accept) store_scope<LOCAL>(A.acc_count + i, load_agent(A.acc_count + i) + 1u);
                 }
             }
             if (I.chain) store_row_stream<G, V, CH>(accept ? q : xi[k], I.chain + (size_t)i * D, D, gl);
         }
         if (!more) break;
-        persist_barrier_local(P, P.lepoch0 + (unsigned)n + 1u, bid, ngroups);
+        if constexpr (LOCAL)
+            persist_barrier_local(P, P.lepoch0 + (unsigned)n + 1u, bid, ngroups);
+        else
+            persist_barrier(P, P.epoch0 + (unsigned)n + 2u);       // (+ 1: the handshake was this launch's first barrier)
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             wi[k] = wi_n[k];
@@ -163,25 +171,25 @@ static __global__ __launch_bounds__(512) void k_persist_valu(const PersistArgs P
     }
 }
 
-template <int G, int V, int CH>
+template <int G, int V, int CH, bool LOCAL>
 static hipError_t launch_pv(int move, dim3 grid, dim3 block, hipStream_t st, const PersistArgs& P) {
     if (move == MOVE_DE)
-        hipLaunchKernelGGL((k_persist_valu<G, V, CH, MOVE_DE>), grid, block, 0, st, P);
+        hipLaunchKernelGGL((k_persist_valu<G, V, CH, MOVE_DE, LOCAL>), grid, block, 0, st, P);
     else if (move == MOVE_SNOOKER)
-        hipLaunchKernelGGL((k_persist_valu<G, V, CH, MOVE_SNOOKER>), grid, block, 0, st, P);
+        hipLaunchKernelGGL((k_persist_valu<G, V, CH, MOVE_SNOOKER, LOCAL>), grid, block, 0, st, P);
     else
-        hipLaunchKernelGGL((k_persist_valu<G, V, CH, MOVE_STRETCH>), grid, block, 0, st, P);
+        hipLaunchKernelGGL((k_persist_valu<G, V, CH, MOVE_STRETCH, LOCAL>), grid, block, 0, st, P);
     return hipGetLastError();
 }
 
 // row layouts of 8 lanes per walker: V = 2 (even ndim 10 ... 64) / V = 1 (odd ndim 5 ... 32), CH = 1, 2, 4; of 4 lanes per walker:
-// ndim <= 4 and even ndim <= 8 (pick_shape: the dimensions of most real-world fits)
-hipError_t launch_persist_valu(int G, int V, int CH, int move, dim3 grid, dim3 block, hipStream_t st, const PersistArgs& P) {
-    if (G == 4 && CH == 1) return V == 2 ? launch_pv<4, 2, 1>(move, grid, block, st, P) : launch_pv<4, 1, 1>(move, grid, block, st, P);
-    if (G != 8) return hipErrorInvalidValue;
-#define EMX_CASE(v, c) \
-    if (V == v && CH == c) return launch_pv<8, v, c>(move, grid, block, st, P);
-    EMX_CASE(2, 1) EMX_CASE(2, 2) EMX_CASE(2, 4) EMX_CASE(1, 1) EMX_CASE(1, 2) EMX_CASE(1, 4)
+// ndim <= 4 and even ndim <= 8 (pick_shape: the dimensions of most real-world fits); local: the one-XCD form (grid already x 8)
+hipError_t launch_persist_valu(int G, int V, int CH, int move, int local, dim3 grid, dim3 block, hipStream_t st, const PersistArgs& P) {
+#define EMX_CASE(g, v, c)                                                                  \
+    if (G == g && V == v && CH == c)                                                       \
+        return local ? launch_pv<g, v, c, true>(move, grid, block, st, P) : launch_pv<g, v, c, false>(move, grid, block, st, P);
+    EMX_CASE(4, 2, 1) EMX_CASE(4, 1, 1)
+    EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4)
 #undef EMX_CASE
     return hipErrorInvalidValue;
 }

@@ -375,8 +375,8 @@ int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
  * a barrier of that XCD's own instead of agent-scope accesses and the device-wide barrier (tuning "persist_local" = 0: never;
  * "persist_local_max_walkers").  The element-wise targets (EMX_TARGET_ISO_GAUSS / _DIAG_GAUSS / _ROSENBROCK / _BOX, rows of 4 or 8 lanes:
  * ndim <= 64 even, <= 32 odd) have this form only (csrc/emx_pvalu.hip; tuning "persist_valu" = 0: never); same bits (red_blue.py:85,104: a half-step still sees every update of the one before).
- * EMX_RNG_MT19937 (the reference's own stream; ensemble.py:166-167) takes the one-XCD forms too -- and, for the dense Gaussian, the
- * device-wide form up to 32 768 walkers ("persist_exact_max_walkers") -- when the context has ONE move: the
+ * EMX_RNG_MT19937 (the reference's own stream; ensemble.py:166-167) takes the one-XCD forms too -- and the device-wide forms of both
+ * kernels up to 32 768 walkers ("persist_exact_max_walkers") -- when the context has ONE move: the
  * host pipeline's plans of up to sixteen steps ("persist_exact_steps") are fetched from their pinned staging buffers by one kernel
  * per launch (k_plan_fetch) -- tuning "persist_exact" = 0: the per-half-step launches with an upload per step.  (A launch of this
  * mode that cannot become resident on one XCD is NOT redone -- its plans have left the pipeline: status bit 3, as for a barrier

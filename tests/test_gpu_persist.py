@@ -604,12 +604,13 @@ def test_exact_mode_takes_the_one_xcd_persistent_kernels(N, D, target, move, sto
 
 
 @pytest.mark.parametrize("N,D,target,steps_per_launch", [(1024, 64, "dense", 16), (512, 24, "iso", 16), (4096, 32, "dense", 5), (2048, 10, "iso", 1),
-                                                         (16384, 64, "dense", 16), (32768, 48, "dense", 16)])       # (the device-wide form)
+                                                         (16384, 64, "dense", 16), (32768, 48, "dense", 16),       # (the device-wide form)
+                                                         (16384, 16, "iso", 16), (32768, 5, "iso", 16), (16384, 32, "rosenbrock", 7), (24576, 8, "diag", 16)])
 def test_exact_mode_persistent_long_run(N, D, target, steps_per_launch):
     """700 steps of exact mode on the persistent kernels, the host enqueueing ahead of the device: every plan slot is rewritten
     (k_plan_fetch) some twenty times, each time only after a LATER launch than the slot's last reader is known to have started
     (PersistArgs::started_host).  Final coordinates, log-probs, accept counters and generator state equal the per-half-step path's."""
-    spec = full_spec(N, D, target, [S("stretch")], seed=21)
+    spec = full_spec(N, D, target, [S("stretch")], seed=21, p0="rosen" if target == "rosenbrock" else "randn")
     state = np.random.RandomState(99).get_state()
     recs = []
     for pe in (1, 0):
