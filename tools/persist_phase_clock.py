@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-_STAMPS = os.path.join(ROOT, "emcee_amd", "libemx_stamps.so")
+_STAMPS = os.environ.get("EMX_STAMPS_LIB") or os.path.join(ROOT, "emcee_amd", "libemx_stamps.so")
 if not os.path.exists(_STAMPS):
     subprocess.check_call(["bash", os.path.join(ROOT, "tools", "ab_variants.sh"), "stamps", "-DEMX_OPT_STAMPS=1"])
 os.environ["EMX_LIB"] = _STAMPS
@@ -20,14 +20,18 @@ from emcee_amd.device import DeviceEnsemble  # noqa: E402
 NAMES = ["partner rows + next plan entries arrive (sc1 round trip)", "proposals, tile written, next own rows issued",
          "LDS fragments + MFMA chain + row reductions", "decisions, commit stores issued", "stores acknowledged (vmcnt 0)",
          "device-wide barrier (arrive, poll)"]
+NAMES_P2P = ["tile words polled, moved rows loaded again (+ next plan entries)", "proposals, tile written, gate, next half-step's rows issued",
+             "LDS fragments + MFMA chain + row reductions", "decisions, commit stores issued",
+             "stores acknowledged, next half-step's rows in (vmcnt 0)", "word + arrival issued"]
 
 
-def main(N=65536, D=64, store=0):
+def main(N=65536, D=64, store=0, p2p=1):
     import torch
     from emcee_amd.parallel import _DevView
     wl = bench.Workload("c2" if D == 64 else "c3", N)
     ens = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(ens, "philox")
+    ens.set_tuning("persist_p2p", p2p)
     if store:
         ens.chain_config(4000)
     ens.run(200, 1, bool(store))
@@ -52,10 +56,13 @@ def main(N=65536, D=64, store=0):
     per = raw[:, :6] / niter[:, None] * ns_per_tick / 1e3          # us per half-step
     # the barrier is passed niter - 1 times a launch, the other phases niter times
     per[:, 5] *= niter / np.maximum(niter - 1, 1)
-    print("k_persist %d x %d%s: %d workgroup-launch samples (%d half-steps a launch), counter tick %.2f ns, persist launches so far %d"
-          % (N, D, ", stored chain" if store else "", len(raw), int(np.median(niter)), ns_per_tick, info["launches"]))
+    names = NAMES_P2P if info["p2p_launches"] else NAMES
+    if info["p2p_launches"]:
+        per[:, 4] *= niter / np.maximum(niter - 1, 1)
+    print("k_persist%s %d x %d%s: %d workgroup-launch samples (%d half-steps a launch), counter tick %.2f ns, persist launches so far %d"
+          % ("_p2p" if info["p2p_launches"] else "", N, D, ", stored chain" if store else "", len(raw), int(np.median(niter)), ns_per_tick, info["launches"]))
     print("  wave-0 lifetime per half-step: median %.2f us" % np.median(wall_ns / niter / 1e3))
-    for k, name in enumerate(NAMES):
+    for k, name in enumerate(names):
         print("  %-62s median %6.2f us   p10 %6.2f   p90 %6.2f   (%4.1f %%)"
               % (name, np.median(per[:, k]), np.percentile(per[:, k], 10), np.percentile(per[:, k], 90),
                  100 * np.median(per[:, k]) / np.median(per.sum(axis=1))))
@@ -64,4 +71,4 @@ def main(N=65536, D=64, store=0):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    main(int(a[0]) if a else 65536, int(a[1]) if len(a) > 1 else 64, int(a[2]) if len(a) > 2 else 0)
+    main(int(a[0]) if a else 65536, int(a[1]) if len(a) > 1 else 64, int(a[2]) if len(a) > 2 else 0, int(a[3]) if len(a) > 3 else 1)
