@@ -43,39 +43,55 @@ def stale():
         return True
 
 
+OBJCACHE = os.path.join(HERE, ".objcache")      # objects keyed by the hash of (translation unit, every header, flags): an edit of one
+                                                # .hip file recompiles that file alone (git-ignored and gpurun-ignored: the .so travels)
+
+
+def _unit_hash(src, flags):
+    import hashlib
+    h = hashlib.sha256((" ".join(flags)).encode())
+    for d in [src] + [x for x in DEPS if x.endswith((".hpp", ".h"))]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:20]
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    objs, procs = [], []
-    for src in SRCS:
-        obj = os.path.join(HERE, os.path.basename(src) + ".o")
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-        objs.append(obj)
     hostcxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(hostcxx):
         hostcxx = shutil.which("amdclang++") or shutil.which("clang++") or shutil.which("g++")
-    for src in HOST_SRCS:
-        obj = os.path.join(HERE, os.path.basename(src) + ".o")
-        cmd = [hostcxx] + HOST_FLAGS + ["-c", src, "-o", obj]
+    os.makedirs(OBJCACHE, exist_ok=True)
+    objs, procs = [], []
+    for src in SRCS + HOST_SRCS:
+        host = src in HOST_SRCS
+        flags = HOST_FLAGS if host else FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
+        obj = os.path.join(OBJCACHE, "%s.%s.o" % (os.path.basename(src), _unit_hash(src, flags)))
+        objs.append(obj)
+        if os.path.exists(obj) and not force:
+            continue
+        for old in os.listdir(OBJCACHE):                  # one object per translation unit
+            if old.startswith(os.path.basename(src) + "."):
+                os.remove(os.path.join(OBJCACHE, old))
+        cmd = [hostcxx if host else hipcc] + flags + ["-c", src, "-o", obj + ".tmp"]
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-        objs.append(obj)
-    for cmd, pr in procs:
+        procs.append((cmd, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    failed = None
+    for cmd, obj, pr in procs:
         _, err = pr.communicate()
         if pr.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + err[-4000:])
+            failed = failed or err
+        else:
+            os.replace(obj + ".tmp", obj)
+    if failed is not None:
+        raise RuntimeError("hipcc failed:\n" + failed[-4000:])
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl", "-pthread"]
     if verbose:
         print(" ".join(link))
     r = subprocess.run(link, capture_output=True, text=True)
-    for obj in objs:
-        if os.path.exists(obj):
-            os.remove(obj)
     if r.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + r.stderr[-4000:])
     with open(HASHFILE, "w") as f:

@@ -535,7 +535,12 @@ struct emx_ctx {
 
 static void graph_invalidate(emx_ctx* c);
 static void apply_env_tuning(emx_ctx* c);
-static void pipe_stop(emx_ctx* c);
+static int pipe_stop(emx_ctx* c);       // (rc != 0: the device producer of exact-mode plans failed -- see mtdev_stop)
+#define PIPE_STOP(ctx)                        \
+    do {                                      \
+        const int _rps = pipe_stop(ctx);      \
+        if (_rps) return _rps;                \
+    } while (0)
 static void direct_detach(emx_ctx* c);
 static int direct_ensure(emx_ctx* c);
 static void exchange_free(emx_ctx* c);
@@ -1304,7 +1309,7 @@ int emx_status(emx_ctx* c, uint32_t* bits) {
         if (rcs) return rcs;
     }
     uint32_t b = 0;
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 5; ++k)
         if (__atomic_exchange_n(&c->status_host[k], 0u, __ATOMIC_ACQ_REL)) b |= 1u << k;
     if (b & ST_EXCHANGE_TIMEOUT) c->direct_dead = true;      // sticky on the host too: emx_direct_halfstep / emx_run refuse from here on
     if (b & ST_EXCHANGE_TIMEOUT) c->persist_grid = 0;        // the persistent kernel's barrier words (counters, the dead mark) restart with its next launch
@@ -1331,7 +1336,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "small_kernel")) {
-        pipe_stop(c);
+        PIPE_STOP(c);
         c->tune_small = v;
         return 0;
     }
@@ -1344,7 +1349,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "mt_pipeline")) {   // exact mode: -1 auto, 0 plans made inline by the calling thread, k > 0 finisher threads
-        pipe_stop(c);
+        PIPE_STOP(c);
         c->tune_mt_pipeline = v;
         return 0;
     }
@@ -1374,17 +1379,17 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "mt_device")) {         // 0: exact-mode plans never from the device producer (emx_mtdev.hpp)
-        pipe_stop(c);
+        PIPE_STOP(c);
         c->tune_mt_device = v < 0 ? 0 : (v > 2 ? 2 : v);
         return 0;
     }
     if (!strcmp(key, "mt_device_min_walkers")) {
-        pipe_stop(c);
+        PIPE_STOP(c);
         c->tune_mt_device_min = v < 8192 ? 8192 : v;
         return 0;
     }
     if (!strcmp(key, "mt_tok_wshift") || !strcmp(key, "mt_tok_tail")) {       // the device tokenizer's window rule (takes effect when a producer starts)
-        pipe_stop(c);
+        PIPE_STOP(c);
         (key[7] == 'w' ? c->tune_mt_tok_wshift : c->tune_mt_tok_tail) = v;
         return 0;
     }
@@ -1410,12 +1415,12 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "persist_exact")) {     // 0: exact mode always on the per-half-step launches
-        pipe_stop(c);
+        PIPE_STOP(c);
         c->tune_persist_exact = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "persist_exact_max_walkers")) {
-        pipe_stop(c);
+        PIPE_STOP(c);
         c->tune_persist_exact_max = v;
         return 0;
     }
@@ -1574,7 +1579,7 @@ int emx_set_target_callback(emx_ctx* c, emx_device_log_prob_fn fn, void* user) {
     { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     HIPOK(c, hipSetDevice(c->device));
     NEED(c, fn != nullptr, "emx_set_target_callback: no function");
-    pipe_stop(c);
+    PIPE_STOP(c);
     drop_prepared(c);          // plans made ahead were shaped (lean or full) for the previous target
     HIPOK(c, hipStreamSynchronize(c->stream));
     c->cb_fn = fn;
@@ -1761,7 +1766,7 @@ int emx_eval_log_prob(emx_ctx* c, const double* coords, int64_t n, double* out) 
 int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const double* cdf) {
     { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     NEED(c, nmoves >= 1, "need at least one move");
-    pipe_stop(c);
+    PIPE_STOP(c);
     for (int i = 0; i < nmoves; ++i) {
         NEED(c, moves[i].kind >= 0 && moves[i].kind <= EMX_MOVE_GAUSS, "unknown move kind");
         if (moves[i].kind == EMX_MOVE_GAUSS) {
@@ -1799,7 +1804,7 @@ int emx_set_moves(emx_ctx* c, int32_t nmoves, const emx_move_desc* moves, const 
 int emx_set_rng_mode(emx_ctx* c, int32_t mode) {
     { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
     NEED(c, mode >= 0 && mode <= 2, "unknown rng mode");
-    pipe_stop(c);
+    PIPE_STOP(c);
     c->rng_mode = mode;
     drop_prepared(c);
     return 0;
@@ -1826,14 +1831,14 @@ int emx_get_move(emx_ctx* c, int32_t mi, emx_move_desc* out) {
 }
 
 int emx_rng_set_mt19937(emx_ctx* c, const uint32_t key[624], int32_t pos, int32_t hg, double cached) {
-    pipe_stop(c);
+    PIPE_STOP(c);
     NEED(c, pos >= 0 && pos <= 624, "bad MT19937 position");
     c->mt.set_state(key, pos, hg, cached);
     return 0;
 }
 
 int emx_rng_get_mt19937(emx_ctx* c, uint32_t key[624], int32_t* pos, int32_t* hg, double* cached) {
-    pipe_stop(c);          // the state after the last step taken (what the pipeline produced ahead is dropped)
+    PIPE_STOP(c);          // the state after the last step taken (what the pipeline produced ahead is dropped)
     memcpy(key, c->mt.key, sizeof(c->mt.key));
     *pos = c->mt.pos;
     *hg = c->mt.has_gauss;
@@ -2089,15 +2094,18 @@ static int pipe_start(emx_ctx* c) {
 }
 
 // stop the threads; the context's generator continues from the end of the last step taken
-static void mtdev_stop(emx_ctx* c);
-static void pipe_stop(emx_ctx* c) {
-    mtdev_stop(c);
-    if (!c->pipe) return;
+// (rc != 0: the device producer reports a stalled stage or a stream under-run -- the steps taken from it are void.  Status bit 4
+// is raised with it and every API entry point that retires the producer hands the rc on: PIPE_STOP.)
+static int mtdev_stop(emx_ctx* c);
+static int pipe_stop(emx_ctx* c) {
+    const int rc = mtdev_stop(c);
+    if (!c->pipe) return rc;
     c->pipe->finish(c->pipe_taken, c->mt);
     delete c->pipe;
     c->pipe = nullptr;
     c->pipe_uploads.clear();
     c->pipe_deferred.clear();
+    return rc;
 }
 
 // The pipeline is persistent: emx_run (or a single step of a large ensemble) starts it, it keeps running AHEAD of the steps
@@ -2149,20 +2157,23 @@ static int mtdev_start(emx_ctx* c) {
     return 0;
 }
 
-static void mtdev_stop(emx_ctx* c) {
-    if (!c->mtdev) return;
+static int mtdev_stop(emx_ctx* c) {
+    if (!c->mtdev) return 0;
     hipStreamSynchronize(c->stream);                    // the consumer's last reads of the plan slots
     MT19937Legacy after = c->mt;
     const int rc = c->mtdev->finish(c->mtdev_taken, after);
-    if (rc == 0)
+    if (rc == 0) {
         c->mt = after;
-    else
-        c->err = c->mtdev->error();                     // (a stream under-run also raised status bit 2: the run is void, loudly)
+    } else {
+        c->err = c->mtdev->error();                     // the run is void, loudly: the rc goes up, and the status bit stays
+        __atomic_store_n(&c->status_host[__builtin_ctz(ST_PLAN_PRODUCER)], 1u, __ATOMIC_RELEASE);      // for whoever reads emx_status
+    }
     c->mtdev_stats_last = c->mtdev->stats();
     c->mtdev_steps_total += c->mtdev_taken;
     delete c->mtdev;
     c->mtdev = nullptr;
     c->mtdev_taken = 0;
+    return rc;
 }
 
 // emx_step_begin's part: the next plan is (or will be, in stream order) in its slot
@@ -2370,8 +2381,11 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
     cur.devplan = false;
     const int nm = (int)c->moves.size();
     const bool devp = forced_move < 0 && mtdev_eligible(c);
-    if (c->mtdev && !devp) mtdev_stop(c);
-    if (c->pipe && (devp || forced_move >= 0 || !pipe_eligible(c))) pipe_stop(c);      // a forced move skips the choice draw: inline
+    if (c->mtdev && !devp) {
+        const int rcm = mtdev_stop(c);
+        if (rcm) return rcm;
+    }
+    if (c->pipe && (devp || forced_move >= 0 || !pipe_eligible(c))) PIPE_STOP(c);      // a forced move skips the choice draw: inline
     if (devp) {
         // exact mode, one stretch move: the plan of this step was (or is being) made on the device, from the same stream
         if (!c->mtdev) {
@@ -2891,7 +2905,7 @@ static bool small_eligible(const emx_ctx* c) {
 
 // `nsteps` full steps starting at step index i0 of the current emx_run call
 static int run_small(emx_ctx* c, int64_t i0, int64_t nsteps, int32_t thin_by, int32_t store) {
-    pipe_stop(c);                 // this path draws from the context's generator itself
+    PIPE_STOP(c);                 // this path draws from the context's generator itself
     const int nm = (int)c->moves.size();
     emx_ctx::BulkPlans* gauss_bulk = nullptr;
     const bool dense = c->target == EMX_TARGET_DENSE_GAUSS;
@@ -3757,9 +3771,12 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     // exact mode, general path: the plans of the whole call come from the host pipeline (generator / tokenizer /
     // finisher threads) instead of being made inline, one step at a time, by this thread
     const bool devp = mtdev_eligible(c);
-    if (c->mtdev && !devp) mtdev_stop(c);
+    if (c->mtdev && !devp) {
+        const int rcm = mtdev_stop(c);
+        if (rcm) return rcm;
+    }
     const bool piped = !devp && pipe_eligible(c) && c->target != EMX_TARGET_HOST && (c->pipe || total >= 2);
-    if (c->pipe && !piped) pipe_stop(c);
+    if (c->pipe && !piped) PIPE_STOP(c);
     if (piped && !c->pipe) {
         const int rc = pipe_start(c);
         if (rc) return rc;

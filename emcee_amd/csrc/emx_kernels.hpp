@@ -62,7 +62,8 @@ enum : int { MOVE_STRETCH = 0, MOVE_DE = 1, MOVE_SNOOKER = 2, MOVE_GAUSS = 3, MO
 enum : int { GAUSS_VECTOR = 0, GAUSS_RANDOM = 1, GAUSS_SEQUENTIAL = 2 };
 enum : int { TGT_NONE = 0, TGT_ISO = 1, TGT_DIAG = 2, TGT_DENSE = 3, TGT_ROSEN = 4, TGT_BOX = 5,
              TGT_REPLAY = 7 };      // (6 is EMX_TARGET_DEVICE_CALLBACK, a host-side three-pass target: never a kernel's)     // replay exchange: no target, no decision -- the slot is a peer's ACCEPTED update, its new log-prob comes with the plan
-enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u, ST_EXCHANGE_TIMEOUT = 8u };
+enum : uint32_t { ST_NAN_LOGP = 1u, ST_BAD_COORD = 2u, ST_EXCHANGE_OVERFLOW = 4u, ST_EXCHANGE_TIMEOUT = 8u,
+                  ST_PLAN_PRODUCER = 16u };     // bit 4: the device producer of exact-mode plans stalled or under-ran (emx_mtdev_kernels.hpp)
 constexpr int EMX_MAX_PEERS = 8;       // direct exchange: GPUs of one node
 
 // The sticky status lives in mapped host memory, one 32-bit flag per condition (index = bit number): raising one is

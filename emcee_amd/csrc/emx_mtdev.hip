@@ -282,7 +282,7 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
     // (site: 0 generator <- finisher, 1 tokenizer <- generator, 2 tokenizer <- finisher, 3 finisher <- tokenizer, 4 finisher <- consumer, 5 consumer <- finisher)
     auto gate_wait = [&](hipStream_t st, int gate, unsigned long long value, int site) {
         hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, st, (const unsigned long long*)(m.gates + gate), value, GATE_TIMEOUT_TICKS, m.d_err,
-                           m.gates + G_STATS + 2 * site);
+                           m.gates + G_STATS + 2 * site, m.status);
     };
     auto gate_signal = [&](hipStream_t st, int gate, unsigned long long value) {
         hipLaunchKernelGGL(k_gate_signal, dim3(1), dim3(64), 0, st, m.gates + gate, value);
@@ -521,11 +521,11 @@ int MtDevProducer::finish(int64_t steps_taken, MT19937Legacy& out) {
     unsigned e = 0;
     MTD_HIP(hipMemcpy(&e, m.d_err, 4, hipMemcpyDeviceToHost));
     if (e & 4u) {
-        err_ = "mtdev: a stage of the producer waited 20 s for another (k_gate_wait): the run is void";
+        err_ = "mtdev: a stage of the producer waited 20 s for another (k_gate_wait, status bit 4): the run is void";
         return -9;
     }
     if (e) {
-        err_ = "mtdev: the generated stream ran out under the tokenizer (status bit 2): the run is void";
+        err_ = "mtdev: the generated stream ran out under the tokenizer (status bit 4): the run is void";
         return -9;
     }
     const int64_t bq = (steps_taken - 1) / MTDEV_BATCH;

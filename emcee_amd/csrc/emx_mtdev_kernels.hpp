@@ -21,7 +21,8 @@ constexpr int PMAX = 128;                        // segments per round at most (
 constexpr int FIN_T = 256;
 constexpr int FIN_CHUNK = 4096;                  // elements per workgroup of the finisher's scans (16 per thread)
 constexpr int FIN_MAX_S = 64;
-constexpr unsigned ST_MT_UNDERRUN = 4u;          // status bit 2 (shared with the pull exchange's overflow): the stream ran out -- the run is void
+constexpr unsigned ST_MT_PRODUCER = 16u;         // status bit 4 (ST_PLAN_PRODUCER of emx_kernels.hpp): the stream ran out under the tokenizer, or a stage
+                                                 // waited for another beyond the bound -- either way the steps taken from the producer are void
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);
@@ -64,17 +65,19 @@ __device__ __forceinline__ void twist_lds(const uint32_t* o, uint32_t* n, int ti
 // Instead every stage counts what it has completed in a device word (k_gate_signal, the last kernel of the stage's work on its
 // in-order stream) and whoever depends on it starts with k_gate_wait: one wave that polls the word.  The kernel boundaries on
 // either side do the release / acquire.  A wait that is never met -- a stage that died -- raises bit 2 of the error word after
-// `timeout_ticks` (100 MHz) and lets its stream go on: the run is void and says so.
+// `timeout_ticks` (100 MHz), status bit 4 of the context with it, and lets its stream go on: the run is void and says so
+// (emx_status; every call that retires the producer returns the error as well).
 static __global__ void k_gate_signal(unsigned long long* word, unsigned long long value) {
     if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 static __global__ void k_gate_wait(const unsigned long long* word, unsigned long long value, unsigned long long timeout_ticks, unsigned* err,
-                                   unsigned long long* waited) {
+                                   unsigned long long* waited, uint32_t* status) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
         if (wall_clock64() - t0 > timeout_ticks) {
-            atomicOr(err, 4u);
+            atomicOr(err, 4u);           // (the finisher kernels return at once from here on: emx_mtdev.hip reads it in finish())
+            __hip_atomic_store(&status[__builtin_ctz(ST_MT_PRODUCER)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // the context's sticky status
             break;
         }
         __builtin_amdgcn_s_sleep(32);
@@ -609,7 +612,7 @@ static __global__ __launch_bounds__(TOK_T) void k_mt_tok(const TokArgs A) {
     if (tid == 0) {
         if (dead) {
             *A.err = 1u;
-            __hip_atomic_store(&A.status[__builtin_ctz(ST_MT_UNDERRUN)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&A.status[__builtin_ctz(ST_MT_PRODUCER)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             *A.pos = p;
         }

@@ -17,6 +17,7 @@ _STATUS_NAN_LOGP = 1
 _STATUS_BAD_COORD = 2
 _STATUS_EXCHANGE_OVERFLOW = 4
 _STATUS_EXCHANGE_TIMEOUT = 8
+_STATUS_PLAN_PRODUCER = 16
 
 
 def _as_f64(a, shape=None):
@@ -141,6 +142,10 @@ class DeviceEnsemble:
     def raise_on_status(self):
         """Mirror the reference's ValueErrors (ensemble.py:476-479, 550-551)."""
         bits = self.status()
+        if bits & _STATUS_PLAN_PRODUCER:
+            raise EmxError("exact-mode plans (rng='mt19937'): the device producer stalled or its stream ran out under the tokenizer; "
+                           "the steps taken from it are void and the generator stands where it stood before the run -- "
+                           "EMX_TUNE=mt_device=0 selects the host pipeline")
         if bits & _STATUS_EXCHANGE_OVERFLOW:
             raise EmxError("pull exchange: record capacity exceeded; the sharded run is invalid")
         if bits & _STATUS_EXCHANGE_TIMEOUT:

@@ -76,7 +76,10 @@ int emx_sync(emx_ctx* ctx);
 /* sticky device status: bit0 NaN log-prob (ensemble.py:550-551), bit1 non-finite coordinate
  * (ensemble.py:476-479), bit2 pull-exchange record capacity exceeded (a >8 sigma event: the run is
  * invalid, never silently wrong), bit3 direct / replay exchange: a peer did not reach the device-side barrier in time
- * (raised again by every later barrier of that attachment).  Reading clears it. */
+ * (raised again by every later barrier of that attachment), bit4 the device producer of exact-mode plans (rng mode MT19937,
+ * large ensembles) stalled -- a stage waited 20 s for another -- or its stream ran out under the tokenizer: the steps taken from
+ * it are void; the call that retires the producer (emx_run's next start, emx_rng_get_mt19937, emx_set_moves ...) returns the
+ * error as well and leaves the generator where it stood before the producer started.  Reading clears it. */
 int emx_status(emx_ctx* ctx, uint32_t* bits);
 /* keys: "spw", "blocks_per_cu", "waves_per_block", "prep_hint", "graph", "throttle", "gauss_materialize",
  * "small_kernel" (1: ensembles that fit one CU's LDS run whole emx_run calls in one workgroup; default),

@@ -1,17 +1,15 @@
 #!/bin/bash
-# round 5: k_persist_p2p variants (scalar polls; speculative partner rows or not) -- A/B + phase clocks + parity subset
+# round 5, session b: the device-side exchange tests between processes (0 skips), the device producer's tests after the status-bit
+# change, host facts of the GPU box, host -> device rates at plan-upload sizes
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r05
 O=$PWD/gpurun_out/r05
 export TMPDIR=/tmp
-for v in "" p10 p00; do
-  L=$PWD/emcee_amd/libemx${v:+_$v}.so
-  EMX_LIB=$L timeout 300 python tools/exp/p2p_ab.py 800 3 1 2>&1 | grep -v amdgpu.ids | tee -a $O/p2p_ab_variants.txt
-done
-timeout 300 python tools/persist_phase_clock.py 65536 64 0 1 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_c2_p2p_11.txt
-sed -i 's/libemx_stamps.so/libemx_p10s.so/' tools/persist_phase_clock.py
-timeout 300 python tools/persist_phase_clock.py 65536 64 0 1 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_c2_p2p_10.txt
-( time timeout 600 python -m pytest tests/test_gpu_persist.py -q -x -p no:cacheprovider -k "without_a_barrier or persistent_kernel_coherence_stress or headline" ) > $O/p2p_tests_b.log 2>&1; echo "p2p tests (default lib) rc=$?" | tee -a $O/summary_b.txt
-tail -n 4 $O/p2p_tests_b.log
-( time EMX_LIB=$PWD/emcee_amd/libemx_p10.so timeout 600 python -m pytest tests/test_gpu_persist.py -q -x -p no:cacheprovider -k "without_a_barrier or persistent_kernel_coherence_stress or headline" ) > $O/p2p_tests_b10.log 2>&1; echo "p2p tests (p10) rc=$?" | tee -a $O/summary_b.txt
-tail -n 4 $O/p2p_tests_b10.log
+( lscpu; echo; nproc; cat /sys/devices/system/cpu/cpu0/cache/index3/shared_cpu_list; cat /sys/devices/system/cpu/cpu0/topology/thread_siblings_list; free -g ) > $O/host_facts.txt 2>&1
+timeout 120 tools/ubench/bin/h2d_rate > $O/h2d_rate.txt 2>&1; echo "h2d rc=$?" | tee -a $O/summary_b.txt
+cat $O/h2d_rate.txt
+( time timeout 900 python -m pytest tests/test_gpu_sharded.py -q -x -p no:cacheprovider -k "device_side" ) > $O/device_side_tests.log 2>&1; echo "device_side tests rc=$?" | tee -a $O/summary_b.txt
+tail -n 25 $O/device_side_tests.log
+( time timeout 600 python -m pytest tests/test_gpu_mtdev.py tests/test_gpu_direct_ipc.py -q -x -p no:cacheprovider ) > $O/mtdev_tests.log 2>&1; echo "mtdev+ipc tests rc=$?" | tee -a $O/summary_b.txt
+tail -n 8 $O/mtdev_tests.log
+head -n 30 $O/host_facts.txt
