@@ -365,6 +365,8 @@ struct emx_ctx {
     unsigned long long* pipe_done = nullptr;    // pinned: steps of the running pipeline that k_plan_fetch has read out of their staging buffers
     unsigned* pipe_arrived = nullptr;           // device: k_plan_fetch's workgroup counter
     hipStream_t up_stream = nullptr;     // plan uploads overlap the previous step's kernels
+    int64_t tune_mt_device_finish = 1;   // 1: stretch steps of the host pipeline are finished on the device (k_plan_raw); 0: by the finisher threads
+    int64_t pipe_raw_steps = 0;          // steps taken that way (emx_pipe_stage_times)
     int64_t tune_mt_pipeline = -1;       // -1: on, finisher threads chosen from the core count; 0: off; k > 0: k finishers
     // exact-mode plans made on the device (emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica
     MtDevProducer* mtdev = nullptr;
@@ -381,6 +383,7 @@ struct emx_ctx {
     int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
     int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
     int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
+    int64_t tune_slab_skew = 1;          // 1: the second wave of every SIMD starts its first tile's row loads when its sibling's rows have arrived
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
     int64_t tune_mt_device_min = 131072; // (measured: the host pipeline is faster below ~10^5 walkers, profiles/r04/mtdev_sizes.txt)
     int64_t tune_mt_lookahead = 2;       // batches the device producer is asked to run ahead of the consumer (0 .. 2)
@@ -1002,7 +1005,9 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         const int wpb = 8;
         const int64_t ntile = (nown + 15) / 16;
         const int64_t nb = std::min<int64_t>((ntile + wpb - 1) / wpb, (int64_t)c->num_cu * c->tune_bpc);
-        e = launch_slab_dense(c->Dp / 16, move, dim3((unsigned)nb), dim3(64 * wpb), slab_lds_bytes(c->Dp, wpb), c->stream, a);
+        HalfStepArgs as = a;
+        as.ablate = c->tune_slab_skew ? 256 | (int32_t)((c->tune_slab_skew - 1) << 9) : 0;     // (lean launches carry no ablation mask: bit 8 = skewed start, bits 9-10 = when the sibling starts)
+        e = launch_slab_dense(c->Dp / 16, move, dim3((unsigned)nb), dim3(64 * wpb), slab_lds_bytes(c->Dp, wpb), c->stream, as);
     } else {
         e = dispatch_halfstep(move, dense, c->Dp / 16, sh, dim3((unsigned)nblocks), dim3(64 * waves_per_block), lds, c->stream, a);
     }
@@ -1399,6 +1404,15 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "slab")) {              // 0: the per-tile kernel at every padded ndim (parity tests, A/B); 1: slab form from padded 112; 2: from padded 80
         c->tune_slab = v < 0 ? 0 : (v > 2 ? 2 : v);
+        return 0;
+    }
+    if (!strcmp(key, "mt_device_finish")) {      // 0: the host pipeline's finisher threads convert every draw themselves (rounds 1-4)
+        PIPE_STOP(c);
+        c->tune_mt_device_finish = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "slab_skew")) {
+        c->tune_slab_skew = v < 0 ? 0 : (v > 4 ? 4 : v);
         return 0;
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
@@ -2088,8 +2102,14 @@ static int pipe_start(emx_ctx* c) {
     }
     c->pipe_taken = 0;
     c->pipe_uploads.clear();
+    // The ring of generator state words lives in pinned memory: with device finish (one replica whose plans nobody but the fused
+    // kernels reads, step-at-a-time uploads) the fetch kernel reads a stretch step's uniforms straight out of it.
+    // device finish (one replica whose plans nobody but the fused kernels reads, step-at-a-time uploads): the finishers pass a stretch
+    // step's uniforms on as generator words, k_plan_raw converts them in place behind the upload
+    const bool devfin = c->tune_mt_device_finish != 0 && c->pipe_nsinks == PIPE_SINKS && c->world == 1 && !c->comm && !c->sendbuf &&
+                        !c->peers_ready && c->target != EMX_TARGET_HOST && !c->tune_full_plan;
     c->pipe = new MtPlanPipeline(c->mt, c->N, c->D, (int32_t)c->moves.size(), c->moves.data(), c->cdf.data(), nsteps, sinks,
-                                 c->pipe_nsinks, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0));
+                                 c->pipe_nsinks, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0), false, devfin);
     return 0;
 }
 
@@ -2232,8 +2252,23 @@ static int pipe_take(emx_ctx* c) {
     const int stretch = c->moves[cur.move].kind == EMX_MOVE_STRETCH;
     HIPOK(c, hipMemcpyAsync(s.order, s.host, plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE),
                             hipMemcpyHostToDevice, c->up_stream));
-    hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->up_stream, (int)N, (int)c->D, stretch, s.s0,
-                       s.uacc, s.logu, s.fac);
+    if (info.raw) {
+        // device finish: the columns hold `order` and generator words (or accepted randint values); converted in place
+        PlanRawArgs R{};
+        R.dev = reinterpret_cast<char*>(s.order);
+        R.a = c->moves[cur.move].a;
+        R.N = (int32_t)N;
+        R.D = c->D;
+        R.S = info.S;
+        R.wr_words = info.wr_ring;
+        for (int k = 0; k <= info.S; ++k) R.off[k] = info.off[k];
+        hipLaunchKernelGGL(k_plan_raw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->up_stream, R);
+        c->pipe_raw_steps++;
+        cur.devplan = true;                 // (emx_plan_get: the finished columns exist on the device only)
+    } else {
+        hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->up_stream, (int)N, (int)c->D, stretch, s.s0,
+                           s.uacc, s.logu, s.fac);
+    }
     HIPOK(c, hipGetLastError());
     HIPOK(c, hipEventRecord(s.uploaded, c->up_stream));
     s.uploaded_ref = s.uploaded;

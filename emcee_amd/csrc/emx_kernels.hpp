@@ -2294,6 +2294,55 @@ static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, i
     dl[N + pos] = A.stretch[b] ? ((double)A.D - 1.0) * log(z) : 0.0;
 }
 
+// Device finish of an exact-mode stretch plan (round 5; csrc/emx_mtpipe.hpp, PipeStepInfo::raw).  The host pipeline hands over what
+// only it can make -- `order` (the shuffled split, red_blue.py:76-85) and, where the complement's size is not a power of two, the
+// accepted randint values -- and passes every fixed-length draw on as it left the generator: MT19937 STATE words, copied into the
+// plan's own columns (the two words of a walker's stretch uniform where its s0 will stand, those of its accept uniform in uacc, the
+// randint word in p0).  The upload is the one copy it always was; this kernel then tempers, converts exactly like
+// RandomState.random_sample, resolves the partner through `order` (stretch.py:27,32) and writes the logs k_plan_logs would -- in place.
+// Same arithmetic as the host finisher (emx_mtpipe.cpp: convert_pairs, convert_pairs_zz): IEEE multiply / add / divide, no contraction.
+constexpr int PLAN_RAW_SPLITS = 8;
+struct PlanRawArgs {
+    char* dev;                         // device slot block ([order|p0] [s0|uacc] [p1|p2] [logu|fac])
+    double a;                          // the stretch scale (stretch.py:30)
+    int32_t off[PLAN_RAW_SPLITS + 1];
+    int32_t N, D, S, wr_words;         // wr_words: p0 holds generator words (power-of-two complement), else accepted randint values
+};
+static __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+static __device__ __forceinline__ double mt_pair_double(uint32_t w0, uint32_t w1) {
+    const int32_t a = (int32_t)(mt_temper(w0) >> 5), b = (int32_t)(mt_temper(w1) >> 6);
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+static __global__ __launch_bounds__(256) void k_plan_raw(const PlanRawArgs A) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= A.N) return;
+    const size_t N = (size_t)A.N;
+    int s = 0;
+    while (s + 1 < A.S && pos >= A.off[s + 1]) ++s;
+    const int base = A.off[s], ns = A.off[s + 1] - base;
+    int32_t* di = reinterpret_cast<int32_t*>(A.dev);
+    double* dd = reinterpret_cast<double*>(A.dev + N * 8);
+    double* dl = reinterpret_cast<double*>(A.dev + N * 32);
+    const uint2 wz = reinterpret_cast<const uint2*>(dd)[pos], wu = reinterpret_cast<const uint2*>(dd)[N + pos];
+    const double u = mt_pair_double(wz.x, wz.y);
+    const double tt = (A.a - 1.0) * u + 1.0;                    // stretch.py:30  ((a - 1) * rand + 1) ** 2 / a
+    const double zz = tt * tt / A.a;
+    const double ua = mt_pair_double(wu.x, wu.y);               // red_blue.py:100
+    const uint32_t w = (uint32_t)di[N + pos];
+    const int32_t r = A.wr_words ? (int32_t)(mt_temper(w) & (uint32_t)(A.N - ns - 1)) : (int32_t)w;          // stretch.py:32 randint(Nc)
+    di[N + pos] = r < base ? di[r] : di[r + ns];                // stretch.py:27: c = the other sets' members in plan order
+    dd[pos] = zz;
+    dd[N + pos] = ua;
+    dl[pos] = log(ua);
+    dl[N + pos] = ((double)A.D - 1.0) * log(zz);
+}
+
 // ----------------------------------------------------------------------------------------
 // Split-phase accept/commit (target evaluated on the host: arbitrary Python log_prob_fn).
 // new_lp[t], fout[t], qout[t] are slot-indexed; red_blue.py:96-104.

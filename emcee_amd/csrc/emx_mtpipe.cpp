@@ -28,7 +28,10 @@ namespace {
 #endif
 
 constexpr int BLK = 624;
-constexpr uint64_t NBLK = 256;           // generator ring: 256 blocks = 160 k words (640 KB): stays cache resident between the two threads
+constexpr uint64_t AHEAD_BLKS = 256;     // the generator runs at most this far ahead of the tokenizer: 160 k words (640 KB) stay cache resident between the two threads
+constexpr uint64_t RING_BLKS = AHEAD_BLKS + 32;      // the ring: the lead + the bursts in flight
+constexpr uint64_t GEN_BURST = 8;        // blocks per publication (generator_main)
+constexpr int RING_MIRROR = 16;          // words [0, 16) of the ring repeated behind its end: a word pair or vector that straddles the wrap reads on
 constexpr int MAX_SPLITS = 64;
 
 inline uint64_t now_ns() {
@@ -227,30 +230,40 @@ EMX_CLONES void twist_block(const uint32_t* __restrict o, uint32_t* __restrict n
     n[623] = n[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & MATRIX);
 }
 
-EMX_CLONES void temper_block(const uint32_t* __restrict k, uint32_t* __restrict out) {
-    for (int i = 0; i < BLK; ++i) {
-        uint32_t y = k[i];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        out[i] = y;
-    }
+// MT19937's output tempering.  The ring holds the generator's STATE words (round 5): the recurrence is the one serial thing in this
+// file and tempering is half of the vector work of a block, so it moved to the consumers -- the tokenizer tempers the words it
+// tests, the finishers (K threads) the words they convert.
+inline uint32_t temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
 }
 
 #if defined(__x86_64__) && defined(__clang__)
 #include <immintrin.h>
 #define EMX_HAVE_AVX512_GEN 1
+__attribute__((target("avx512f"))) inline __m512i temper_v(__m512i r) {
+    const __m512i TB = _mm512_set1_epi32((int)0x9d2c5680u), TC = _mm512_set1_epi32((int)0xefc60000u);
+    __m512i t = _mm512_xor_si512(r, _mm512_srli_epi32(r, 11));
+    t = _mm512_xor_si512(t, _mm512_and_si512(_mm512_slli_epi32(t, 7), TB));
+    t = _mm512_xor_si512(t, _mm512_and_si512(_mm512_slli_epi32(t, 15), TC));
+    return _mm512_xor_si512(t, _mm512_srli_epi32(t, 18));
+}
 // The whole block in registers: 39 vectors of 16 words.  Word kk of the new block needs new word kk - 227 (for
 // kk >= 227), i.e. a vector that starts 13 words into new vector i - 15: instead of storing the new words and
 // re-loading them unaligned (a load that straddles two just-issued stores cannot be forwarded and waits for both to
 // retire -- the dependency that holds the auto-vectorised loops at 0.16 ns/word), the last 15 result vectors stay in
-// registers and the straddling vector is made with one valignd.  Tempering happens on the way out.
-__attribute__((target("avx512f"))) void twist_temper_avx512(const uint32_t* __restrict o, uint32_t* __restrict n,
-                                                            uint32_t* __restrict out) {
-    const __m512i UPPER = _mm512_set1_epi32((int)0x80000000u), ONE = _mm512_set1_epi32(1),
-                  MATRIX = _mm512_set1_epi32((int)0x9908b0dfu), TB = _mm512_set1_epi32((int)0x9d2c5680u),
-                  TC = _mm512_set1_epi32((int)0xefc60000u);
+// registers and the straddling vector is made with one valignd.  The new state words go to `n` (the private buffer the next block is
+// made from) and to `out` (64-byte aligned).  STREAM: with non-temporal stores -- for a ring too large to stay in the last-level
+// cache, whose lines are cold whenever the generator comes round again and would first be READ from memory by a plain store (the
+// caller fences before it publishes).  A ring that does stay cached takes plain stores: measured on the MI355X host, the
+// non-temporal form held the generator at 53 us per step of 65 536 walkers (32 GB/s of write-combining), plain stores into a
+// cache-resident ring at 37.
+template <bool STREAM>
+__attribute__((target("avx512f"))) void twist_avx512(const uint32_t* __restrict o, uint32_t* __restrict n, uint32_t* __restrict out) {
+    const __m512i UPPER = _mm512_set1_epi32((int)0x80000000u), ONE = _mm512_set1_epi32(1), MATRIX = _mm512_set1_epi32((int)0x9908b0dfu);
     __m512i N[39];
     const __m512i Olast = _mm512_loadu_si512(o + 608);
 #pragma unroll
@@ -275,27 +288,27 @@ __attribute__((target("avx512f"))) void twist_temper_avx512(const uint32_t* __re
         r = _mm512_mask_xor_epi32(r, odd, r, MATRIX);
         N[i] = r;
         _mm512_storeu_si512(n + 16 * i, r);
-        __m512i t = _mm512_xor_si512(r, _mm512_srli_epi32(r, 11));
-        t = _mm512_xor_si512(t, _mm512_and_si512(_mm512_slli_epi32(t, 7), TB));
-        t = _mm512_xor_si512(t, _mm512_and_si512(_mm512_slli_epi32(t, 15), TC));
-        t = _mm512_xor_si512(t, _mm512_srli_epi32(t, 18));
-        _mm512_storeu_si512(out + 16 * i, t);
+        if (STREAM) _mm512_stream_si512(reinterpret_cast<__m512i*>(out + 16 * i), r);
     }
+    // (not streamed: the block is copied out in one piece.  Stores into the ring from inside the loop -- into lines the tokenizer's
+    // core is reading -- held the generator at 78-87 us per step of 65 536 walkers against 36 this way: the loop's loads and
+    // ALU work wait behind a store buffer full of ownership requests)
+    if (!STREAM) std::memcpy(out, n, BLK * 4);
 }
 #endif
-
-// one generator step: new state words and their tempered outputs
-using TwistFn = void (*)(const uint32_t*, uint32_t*, uint32_t*);
-void twist_temper_generic(const uint32_t* o, uint32_t* n, uint32_t* out) {
+void twist_generic(const uint32_t* o, uint32_t* n, uint32_t* out) {
     twist_block(o, n);
-    temper_block(n, out);
+    std::memcpy(out, n, BLK * 4);
 }
 
+// one generator step: the new state words from the old ones (out of place)
+using TwistFn = void (*)(const uint32_t*, uint32_t*, uint32_t*);
+
 // the register-resident AVX-512 version where the CPU has it and it reproduces the generic one on a test block
-TwistFn pick_twist() {
+TwistFn pick_twist(bool stream) {
 #ifdef EMX_HAVE_AVX512_GEN
     if (__builtin_cpu_supports("avx512f") && !getenv("EMX_PIPE_NO_AVX512")) {
-        alignas(64) uint32_t o[BLK + 16], a[BLK + 16], b[BLK + 16], ta[BLK], tb[BLK];
+        alignas(64) uint32_t o[BLK + 16], a[BLK + 16], b[BLK + 16];
         uint32_t x = 0x9e3779b9u;
         for (int i = 0; i < BLK + 16; ++i) {
             x ^= x << 13;
@@ -303,18 +316,20 @@ TwistFn pick_twist() {
             x ^= x << 5;
             o[i] = x;
         }
-        twist_temper_generic(o, a, ta);
-        twist_temper_avx512(o, b, tb);
-        if (!std::memcmp(a, b, BLK * 4) && !std::memcmp(ta, tb, BLK * 4)) return twist_temper_avx512;
+        alignas(64) uint32_t oa[BLK + 16], ob[BLK + 16];
+        twist_generic(o, a, oa);
+        twist_avx512<true>(o, b, ob);
+        _mm_sfence();
+        if (!std::memcmp(a, b, BLK * 4) && !std::memcmp(oa, ob, BLK * 4)) return stream ? twist_avx512<true> : twist_avx512<false>;
     }
 #endif
-    return twist_temper_generic;
+    return twist_generic;
 }
 
-// random_sample() of consecutive word pairs
+// random_sample() of consecutive word pairs (w: state words, tempered here)
 EMX_CLONES void convert_pairs(const uint32_t* __restrict w, double* __restrict dst, int64_t n) {
     for (int64_t e = 0; e < n; ++e) {
-        const int32_t a = (int32_t)(w[2 * e] >> 5), b = (int32_t)(w[2 * e + 1] >> 6);
+        const int32_t a = (int32_t)(temper(w[2 * e]) >> 5), b = (int32_t)(temper(w[2 * e + 1]) >> 6);
         dst[e] = (a * 67108864.0 + b) / 9007199254740992.0;
     }
 }
@@ -322,7 +337,7 @@ EMX_CLONES void convert_pairs(const uint32_t* __restrict w, double* __restrict d
 // stretch.py:30  zz = ((a - 1) * rand(Ns) + 1) ** 2 / a, straight from the word pairs
 EMX_CLONES void convert_pairs_zz(const uint32_t* __restrict w, double* __restrict dst, int64_t n, double a) {
     for (int64_t e = 0; e < n; ++e) {
-        const int32_t hi = (int32_t)(w[2 * e] >> 5), lo = (int32_t)(w[2 * e + 1] >> 6);
+        const int32_t hi = (int32_t)(temper(w[2 * e]) >> 5), lo = (int32_t)(temper(w[2 * e + 1]) >> 6);
         const double u = (hi * 67108864.0 + lo) / 9007199254740992.0;
         const double tt = (a - 1.0) * u + 1.0;
         dst[e] = tt * tt / a;
@@ -334,12 +349,39 @@ EMX_CLONES void convert_pairs_zz(const uint32_t* __restrict w, double* __restric
 // word <= i - 16 is accepted and a word > i rejected whatever the others do, and that is nearly every word (the rest,
 // 16 values out of the mask range, send the vector to the scalar loop).  Accepted values are compressed in stream order
 // into jr[(n - 1) - i ...]: the reversed layout makes their addresses ascend.  Returns the words consumed.
-__attribute__((target("avx512f"))) size_t shuffle_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i,
-                                                              int64_t lo, uint32_t* jr, int64_t nm1) {
+// (p: state words, tempered here.)
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt"))) size_t shuffle_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i,
+                                                                                       int64_t lo, uint32_t* jr, int64_t nm1) {
     const __m512i vmask = _mm512_set1_epi32((int)mask);
     size_t used = 0;
+    // Four vectors per trip while the band is wide (round 5).  The loop carries i through broadcast -> compare -> mask -> popcount,
+    // some 15 cycles whatever the width; against (i - 64, i] the four vectors' tests are independent of each other, and a word in
+    // that range -- 64 values out of the mask range -- sends the trip to the one-vector loop below.
+    if (mask >= (1u << 14)) {
+        while (navail - used >= 64 && i - 64 > lo) {
+            const __m512i hi = _mm512_set1_epi32((int)(uint32_t)i), lo64 = _mm512_set1_epi32((int)(uint32_t)(i - 64));
+            const __m512i v0 = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used)), vmask);
+            const __m512i v1 = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used + 16)), vmask);
+            const __m512i v2 = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used + 32)), vmask);
+            const __m512i v3 = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used + 48)), vmask);
+            const __mmask16 a0 = _mm512_cmple_epu32_mask(v0, lo64), a1 = _mm512_cmple_epu32_mask(v1, lo64),
+                            a2 = _mm512_cmple_epu32_mask(v2, lo64), a3 = _mm512_cmple_epu32_mask(v3, lo64);
+            const __mmask16 r0 = _mm512_cmpgt_epu32_mask(v0, hi), r1 = _mm512_cmpgt_epu32_mask(v1, hi), r2 = _mm512_cmpgt_epu32_mask(v2, hi),
+                            r3 = _mm512_cmpgt_epu32_mask(v3, hi);
+            if ((__mmask16)((a0 | r0) & (a1 | r1) & (a2 | r2) & (a3 | r3)) != (__mmask16)0xffff) break;
+            uint32_t* dst = jr + (nm1 - i);
+            const int c0 = __builtin_popcount((unsigned)a0), c1 = __builtin_popcount((unsigned)a1), c2 = __builtin_popcount((unsigned)a2),
+                      c3 = __builtin_popcount((unsigned)a3);
+            _mm512_storeu_si512(dst, _mm512_maskz_compress_epi32(a0, v0));                     // (16 slots of slack behind jr: a later
+            _mm512_storeu_si512(dst + c0, _mm512_maskz_compress_epi32(a1, v1));                //  store overwrites the zero tail of
+            _mm512_storeu_si512(dst + c0 + c1, _mm512_maskz_compress_epi32(a2, v2));           //  the one before it)
+            _mm512_storeu_si512(dst + c0 + c1 + c2, _mm512_maskz_compress_epi32(a3, v3));
+            i -= (int64_t)(c0 + c1 + c2 + c3);
+            used += 64;
+        }
+    }
     while (navail - used >= 16 && i - 16 > lo) {
-        const __m512i v = _mm512_and_si512(_mm512_loadu_si512(p + used), vmask);
+        const __m512i v = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used)), vmask);
         const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)(i - 16)));
         const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)i));
         if ((__mmask16)(acc | rej) != (__mmask16)0xffff) break;             // a word in (i - 16, i]: order matters, scalar
@@ -351,53 +393,64 @@ __attribute__((target("avx512f"))) size_t shuffle_scan_avx512(const uint32_t* p,
 }
 #endif
 
-// inverse of MT19937's output tempering: the generator state words behind a block of outputs
-inline uint32_t untemper(uint32_t y) {
-    y ^= y >> 18;                                   // an involution: 2 * 18 >= 32
-    y ^= (y << 15) & 0xefc60000u;                   // an involution: the mask shifted by 15 again has no bit left in it
-    uint32_t t = y;                                 // y ^= (y << 7) & B: each round recovers 7 more low bits
-    t = y ^ ((t << 7) & 0x9d2c5680u);
-    t = y ^ ((t << 7) & 0x9d2c5680u);
-    t = y ^ ((t << 7) & 0x9d2c5680u);
-    t = y ^ ((t << 7) & 0x9d2c5680u);
-    y = t;
-    y ^= y >> 11;                                   // y ^= y >> 11: y1 ^ y1 >> 11 ^ y1 >> 22
-    y ^= y >> 22;
-    return y;
-}
-
+// The ring of state words (round 5: consumers temper): small enough to stay in the generator's and the tokenizer's caches.
+// (Measured and dropped, round 5: a ring of several steps that the finishers read the fixed-length draws from directly, so that
+// the tokenizer need not copy them.  Plain stores into such a ring while six other cores read it held the generator at 90 us per
+// step of 65 536 walkers, non-temporal stores at 53 -- against 36 into this one, which only the tokenizer reads;
+// profiles/r05/exact_c2.md.)
 struct WordStream {
-    std::vector<uint32_t> ring;      // tempered words, NBLK blocks
+    uint32_t* ring = nullptr;        // nblk * BLK + RING_MIRROR state words
+    uint64_t nblk = 0;
+    std::vector<uint32_t> own;       // (the ring's memory when the caller gave none)
     alignas(64) std::atomic<uint64_t> produced{0};     // blocks produced
-    alignas(64) std::atomic<uint64_t> keep{0};         // lowest block the reader may still touch
-    std::atomic<bool> stop{false};
+    alignas(64) std::atomic<uint64_t> keep{0};         // lowest block anybody may still read (the oldest step not retired)
+    std::atomic<uint64_t> rdblk{0};                    // block the tokenizer stands in
+    alignas(64) std::atomic<bool> stop{false};
     std::atomic<uint64_t> gen_wait_ns{0}, gen_blocks{0}, rd_wait_ns{0};     // read by stage_times() while the threads run
+    uint64_t words() const { return nblk * BLK; }
 };
 
 void generator_main(WordStream* ws, const uint32_t* start_key) {
     stage_thread_setup();
     // block 0 is the block the caller's generator currently stands in (no twist)
-    alignas(64) uint32_t key[2][BLK + 16];          // + 16: the vector version reads one vector past word 607 + 1
-    std::memset(key, 0, sizeof(key));
-    std::memcpy(key[0], start_key, BLK * 4);
-    const TwistFn twist_temper = pick_twist();
-    temper_block(key[0], &ws->ring[0]);
+    const uint64_t NBLK = ws->nblk;
+    const TwistFn twist = pick_twist(NBLK * BLK * 4 > (24ull << 20));
+    std::memcpy(&ws->ring[0], start_key, BLK * 4);
+    std::memcpy(&ws->ring[NBLK * BLK], start_key, RING_MIRROR * 4);
     ws->produced.store(1, std::memory_order_release);
+    // The recurrence runs in a private double buffer and every block goes out to the ring as well: making block b from block b - 1
+    // IN the ring -- one store per vector -- was 1.6x SLOWER (124 against 75 ms per 400 steps of 65 536 walkers on the build host):
+    // the lines of block b - 1 are being pulled by the tokenizer's core just then.
+    alignas(64) uint32_t pkey[2][BLK + 16];
+    std::memcpy(pkey[0], start_key, BLK * 4);
     Backoff bo;
+    // A block is 50-150 ns of work; the shared words (`keep`, the reader's block, this thread's `produced`) each cost a cache-line
+    // transfer between cores when touched, so they are touched once per GEN_BURST blocks: space for a burst is checked once, the
+    // burst is published once.  (Round 5; before, every block loaded `keep`, published `produced` and wrote a sequentially
+    // consistent statistics word -- about as long as the twist itself.)
+    uint64_t keep_seen = ws->keep.load(std::memory_order_acquire), rd_seen = ws->rdblk.load(std::memory_order_acquire);
     for (uint64_t b = 1; !ws->stop.load(std::memory_order_relaxed);) {
-        if (b - ws->keep.load(std::memory_order_acquire) >= NBLK - 1) {
-            const uint64_t t0 = now_ns();
-            bo.pause();
-            ws->gen_wait_ns += now_ns() - t0;
-            continue;
+        const auto blocked = [&] { return b + GEN_BURST - keep_seen >= NBLK || (b > rd_seen && b - rd_seen > AHEAD_BLKS); };
+        if (blocked()) {
+            keep_seen = ws->keep.load(std::memory_order_acquire);
+            rd_seen = ws->rdblk.load(std::memory_order_acquire);
+            if (blocked()) {
+                const uint64_t t0 = now_ns();
+                bo.pause();
+                ws->gen_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+                continue;
+            }
         }
         bo.n = 0;
-        ws->gen_blocks = b;
-        const uint32_t* prev = key[(b - 1) & 1];
-        uint32_t* cur = key[b & 1];
-        twist_temper(prev, cur, &ws->ring[(b % NBLK) * BLK]);
-        ws->produced.store(b + 1, std::memory_order_release);
-        ++b;
+        for (uint64_t e = b + GEN_BURST; b < e; ++b) {
+            twist(pkey[(b - 1) & 1], pkey[b & 1], &ws->ring[(b % NBLK) * BLK]);
+            if ((b % NBLK) == 0) std::memcpy(&ws->ring[NBLK * BLK], pkey[b & 1], RING_MIRROR * 4);
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_sfence();                           // the non-temporal stores above are ordered before the publication below
+#endif
+        ws->gen_blocks.store(b - 1, std::memory_order_relaxed);
+        ws->produced.store(b, std::memory_order_release);
     }
 }
 
@@ -416,31 +469,47 @@ struct Reader {
         base = cur = end = nullptr;
     }
 
-    // make at least one word available at the current position (waits for the generator)
-    void refill() {
-        const uint64_t a = pos();
+    // what the generator may overwrite and how far it may run ahead
+    void publish(uint64_t a) {
         ws->keep.store(a > 0 ? (a - 1) / BLK : 0, std::memory_order_release);
+        ws->rdblk.store(a / BLK, std::memory_order_release);
+    }
+
+    // wait until the words below position `a` exist
+    bool wait_produced(uint64_t a) {
+        if (ws->produced.load(std::memory_order_acquire) * BLK >= a) return true;
         Backoff bo;
-        uint64_t prod;
-        if (ws->produced.load(std::memory_order_acquire) * BLK <= a) {
-            const uint64_t t0 = now_ns();
-            while (ws->produced.load(std::memory_order_acquire) * BLK <= a && !stop->load(std::memory_order_relaxed)) bo.pause();
-            ws->rd_wait_ns += now_ns() - t0;
-        }
-        while ((prod = ws->produced.load(std::memory_order_acquire)) * BLK <= a) {
-            if (stop->load(std::memory_order_relaxed)) {
+        const uint64_t t0 = now_ns();
+        while (ws->produced.load(std::memory_order_acquire) * BLK < a) {
+            // (ten seconds without a word: the generator is held by a ring that cannot take this step -- step_words_bound exceeded,
+            // which does not happen -- and the pipeline fails loudly instead of hanging)
+            if (stop->load(std::memory_order_relaxed) || now_ns() - t0 > 10000000000ull) {
                 dead = true;
-                static const uint32_t zeros[2] = {0, 0};
-                base = cur = zeros;
-                end = zeros + 2;
-                a_base = a;
-                return;
+                break;
             }
             bo.pause();
         }
-        const uint64_t ring_words = NBLK * BLK;
+        ws->rd_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+        return !dead;
+    }
+
+    // make at least one word available at the current position (waits for the generator)
+    void refill() {
+        const uint64_t a = pos();
+        publish(a);
+        if (dead || !wait_produced(a + 1)) {
+            static const uint32_t zeros[2] = {0, 0};
+            base = cur = zeros;
+            end = zeros + 2;
+            a_base = a;
+            return;
+        }
+        const uint64_t prod = ws->produced.load(std::memory_order_acquire);
+        const uint64_t ring_words = ws->words();
         const uint64_t off = a % ring_words;
-        const uint64_t n = std::min<uint64_t>(prod * BLK - a, ring_words - off);
+        // (at most 32 blocks at a time: the shared words are published here only, and a reader that took everything produced kept the
+        // generator out of the ring until it had consumed all of it: the two took turns)
+        const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(prod * BLK - a, ring_words - off), 32ull * BLK);
         base = cur = &ws->ring[off];
         end = cur + n;
         a_base = a;
@@ -451,7 +520,7 @@ struct Reader {
     }
     inline uint32_t next32() {
         if (__builtin_expect(cur == end, 0)) refill();
-        return *cur++;
+        return temper(*cur++);
     }
     inline uint64_t next64() {
         const uint64_t hi = next32();
@@ -557,7 +626,7 @@ struct Reader {
         if (mask == (uint32_t)rng) {         // power-of-two bound: no rejection, a masked copy
             while (k < n && !dead) {
                 const int64_t take = std::min<int64_t>((int64_t)avail(), n - k);
-                for (int64_t e = 0; e < take; ++e) dst[k + e] = (int32_t)(cur[e] & mask);
+                for (int64_t e = 0; e < take; ++e) dst[k + e] = (int32_t)(temper(cur[e]) & mask);
                 cur += take;
                 k += take;
             }
@@ -568,7 +637,7 @@ struct Reader {
             const uint32_t* p = cur;
             const uint32_t* pe = cur + av;
             while (p < pe && k < n) {
-                const uint32_t v = *p++ & mask;
+                const uint32_t v = temper(*p++) & mask;
                 dst[k] = (int32_t)v;          // branch-free compaction: a rejected value is overwritten by the next
                 k += (v <= (uint32_t)rng);
             }
@@ -601,7 +670,7 @@ struct Reader {
 #endif
                 int budget = 16;                                // one vector's worth, then the fast path is tried again
                 while (p < pe && i > lo && budget-- > 0) {
-                    const uint32_t v = *p++ & mask;
+                    const uint32_t v = temper(*p++) & mask;
                     jr[nm1 - i] = v;                            // a rejected draw is overwritten by the next one
                     i -= (int64_t)(v <= (uint32_t)i);
                 }
@@ -610,7 +679,7 @@ struct Reader {
         }
         (void)vec;
     }
-    // n raw stream words, verbatim (fixed-length draws are converted by the finishers)
+    // n state words, verbatim (fixed-length draws are tempered and converted by the finishers -- or by the consumer's kernel)
     void copy_words(uint32_t* dst, int64_t n) {
         int64_t k = 0;
         while (k < n && !dead) {
@@ -627,8 +696,9 @@ inline bool pow2_bound(uint64_t bound) { return bound >= 2 && bound <= 0x8000000
 
 struct RawStep {               // tokens of one step that do not already sit in the plan sink
     std::vector<uint32_t> j;   // Fisher-Yates targets, reversed: j[(N - 1) - i] for i = N-1 .. 1 (+ 16 slots of slack)
-    std::vector<uint32_t> wz, wr, wu;   // raw stream words of the fixed-length draws, converted by the finisher: rand(Ns) of the
-                                        // stretch factor (2 per walker), power-of-two randint (1), the accept uniforms (2)
+    std::vector<uint32_t> wz, wr, wu;   // state words of the fixed-length draws, converted by the finisher: rand(Ns) of the stretch factor
+                                        // (2 per walker), power-of-two randint (1), the accept uniforms (2).  (A raw step's go straight
+                                        // into the sink: PipeStepInfo::raw.)
     std::vector<uint64_t> k64; // DE: pair codes (de.py:49)
     std::vector<double> gx, gr2;  // DE: polar-method tokens of randn (de.py:56): normal = gx * sqrt(-2 ln r2 / r2), r2 < 0: gx itself
     std::vector<uint8_t> perm; // snooker: shuffle(w) draws, j2 | j1 << 2
@@ -661,7 +731,7 @@ struct MtPlanPipeline::Impl {
     bool joined = false;
     uint64_t t_start = 0, tok_done_ns = 0;
     std::atomic<uint64_t> tok_wait_sink_ns{0}, tok_busy_ns{0};                 // read by stage_times() while the threads run
-    bool vec_scan = false, stats = false, fill_unused = false;
+    bool vec_scan = false, stats = false, fill_unused = false, device_finish = false;
     uint64_t tok_shuffle_ns = 0;
     std::atomic<int64_t> tok_steps{0};             // steps tokenised so far
     std::vector<uint64_t> fin_wait_ns;
@@ -690,7 +760,7 @@ bool MtPlanPipeline::supports(int32_t nmoves, const emx_move_desc* moves) {
 
 MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves,
                                const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers,
-                               bool fill_unused_fields)
+                               bool fill_unused_fields, bool device_finish)
     : impl_(new Impl()) {
     Impl& m = *impl_;
     m.N = N;
@@ -719,7 +789,10 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     m.NR = K + 2;
     m.NSNAP = nsinks + 4;
     m.start = start;
-    m.ws.ring.resize(NBLK * BLK);
+    m.device_finish = device_finish;
+    m.ws.nblk = RING_BLKS;
+    m.ws.own.resize(m.ws.nblk * BLK + RING_MIRROR + 16);
+    m.ws.ring = reinterpret_cast<uint32_t*>(((uintptr_t)m.ws.own.data() + 63) & ~(uintptr_t)63);      // (the vector twist stores whole lines)
     m.raws.resize(m.NR);
     bool any_shuffle = false, any_de = false, any_sn = false, any_stretch = false;
     for (auto& mv : m.moves) {
@@ -845,17 +918,21 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
     for (int s = 0; s < S; ++s) info.off[s + 1] = info.off[s] + (int32_t)((N - s + S - 1) / S);   // label counts survive the shuffle
     RawStep& raw = raws[n % NR];
     const PlanSink& sk = sinks[n % nsinks];
+    info.raw = (device_finish && mv.kind == EMX_MOVE_STRETCH && S <= PIPE_RAW_SPLITS) ? 1 : 0;
+    info.wr_ring = 1;
     const uint64_t ts0 = stats ? now_ns() : 0;
     if (mv.randomize_split) rd.shuffle_targets(raw.j.data(), N, vec_scan);                        // red_blue.py:80
     if (stats) tok_shuffle_ns += now_ns() - ts0;
     for (int split = 0; split < S && !rd.dead; ++split) {
         const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
         if (mv.kind == EMX_MOVE_STRETCH) {
-            rd.copy_words(raw.wz.data() + 2 * base, 2 * ns);                                       // stretch.py:30 rand(Ns): fixed length
-            if (pow2_bound((uint64_t)nc))                                                          // stretch.py:32 randint(Nc, Ns):
-                rd.copy_words(raw.wr.data() + base, ns);                                           //   no rejection: fixed length too
+            // stretch.py:30 rand(Ns): fixed length.  stretch.py:32 randint(Nc, Ns): fixed length too where Nc is a power of two (no
+            // rejection), else the rejection decides the position.  A raw step's words go where their values will stand.
+            rd.copy_words(info.raw ? reinterpret_cast<uint32_t*>(sk.s0 + base) : raw.wz.data() + 2 * base, 2 * ns);
+            if (pow2_bound((uint64_t)nc))
+                rd.copy_words(info.raw ? reinterpret_cast<uint32_t*>(sk.p0 + base) : raw.wr.data() + base, ns);
             else
-                rd.fill_randint32(sk.p0 + base, ns, (uint64_t)nc);                                 //   rejection decides the position
+                rd.fill_randint32(sk.p0 + base, ns, (uint64_t)nc);
         } else if (mv.kind == EMX_MOVE_DE) {
             const uint64_t pop = (uint64_t)nc * (uint64_t)(nc - 1);
             for (int64_t t = 0; t < ns; ++t) raw.k64[base + t] = rd.randint(pop);                  // de.py:49
@@ -904,7 +981,8 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
                 raw.perm[base + t] = (uint8_t)(j2 | (j1 << 2));
             }
         }
-        rd.copy_words(raw.wu.data() + 2 * base, 2 * ns);                                           // red_blue.py:100 rand() x Ns
+        rd.copy_words(info.raw ? reinterpret_cast<uint32_t*>(sk.uacc + base) : raw.wu.data() + 2 * base, 2 * ns);      // red_blue.py:100 rand() x Ns
+        if (info.raw && !pow2_bound((uint64_t)nc)) info.wr_ring = 0;       // (S > 2 with N % S != 0: set sizes differ, so may this)
     }
 }
 
@@ -940,10 +1018,7 @@ void MtPlanPipeline::Impl::tokenizer_main() {
             const uint64_t blk = a > 0 ? (a - 1) / BLK : 0;
             MT19937Legacy& sn = snaps[n % NSNAP];
             // the block is still retained: keep <= (a - 1) / BLK and the generator never overwrites blocks >= keep
-            uint32_t key[BLK];
-            const uint32_t* out = &ws.ring[(blk % NBLK) * BLK];
-            for (int i = 0; i < BLK; ++i) key[i] = untemper(out[i]);
-            sn.set_state(key, (int)(a - blk * BLK), has_gauss, gauss);
+            sn.set_state(&ws.ring[(blk % ws.nblk) * BLK], (int)(a - blk * BLK), has_gauss, gauss);      // (the ring holds the state words themselves)
         }
         raw_ready[n % NR].v.store(n, std::memory_order_release);
         tok_steps.store(n + 1, std::memory_order_relaxed);
@@ -977,13 +1052,22 @@ void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) 
     for (int split = 0; split < S; ++split) {
         const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
         auto comp = [&](uint64_t r) -> int32_t { return (int64_t)r < base ? order[r] : order[r + ns]; };   // stretch.py:27
+        if (info.raw) {
+            // device finish: the tokenizer put the words where their values will stand (PipeStepInfo::raw); only a step whose splits
+            // drew their partners both ways (set sizes that are and are not powers of two) has values to make here
+            if (!info.wr_ring && pow2_bound((uint64_t)nc)) {
+                const uint32_t msk = (uint32_t)(nc - 1);
+                for (int64_t t = 0; t < ns; ++t) sk.p0[base + t] = (int32_t)(temper((uint32_t)sk.p0[base + t]) & msk);
+            }
+            continue;
+        }
         convert_pairs(raw.wu.data() + 2 * base, sk.uacc + base, ns);                             // red_blue.py:100
         if (mv.kind == EMX_MOVE_STRETCH) {
             convert_pairs_zz(raw.wz.data() + 2 * base, sk.s0 + base, ns, mv.a);                    // stretch.py:30
             if (pow2_bound((uint64_t)nc)) {
                 const uint32_t msk = (uint32_t)(nc - 1);
                 const uint32_t* wr = raw.wr.data() + base;
-                for (int64_t t = 0; t < ns; ++t) sk.p0[base + t] = (int32_t)(wr[t] & msk);
+                for (int64_t t = 0; t < ns; ++t) sk.p0[base + t] = (int32_t)(temper(wr[t]) & msk);
             }
             // p1 / p2 carry no information for a stretch step (one partner): the kernels never read them and the upload
             // stops before them; they are filled only for consumers that compare whole plans (fill_unused)

@@ -6,10 +6,12 @@
 // (b) the *position* in the stream, which rejection sampling (shuffle, non-power-of-two randint, polar normals)
 // makes data dependent.  The pipeline splits the work accordingly:
 //
-//   generator  (1 thread)  twists + tempers 624-word blocks into a ring, SIMD (AVX-512 / AVX2 clones)
+//   generator  (1 thread)  twists 624-word blocks of generator STATE words into a ring, SIMD (AVX-512 / AVX2 clones); tempering is
+//                          the consumers' (round 5: half of the vector work of a block)
 //   tokenizer  (1 thread)  walks the stream once, in the reference's draw order, and does ONLY what decides the
 //                          stream position: the rejection tests.  It emits tokens: accepted Fisher-Yates targets
-//                          j_i, accepted randint values, converted uniforms, accepted polar pairs (x, r2)
+//                          j_i, accepted randint values, accepted polar pairs (x, r2) -- and the POSITIONS of the fixed-length
+//                          draws, which stay in the ring (no copy)
 //   finishers  (K threads) one step each, independent of each other (labels are re-initialised every step,
 //                          red_blue.py:78): apply the swaps, counting-sort the split into plan order, resolve
 //                          complement indices to walkers, decode DE pairs, finish the polar normals -- straight into
@@ -54,15 +56,25 @@ struct PlanSink {
 struct PipeStepInfo {
     int32_t move = 0, S = 0;
     int32_t off[66] = {0};
+    // raw (a stretch step of a pipeline constructed with device_finish, S <= PIPE_RAW_SPLITS): the sink holds `order`; the fixed-length
+    // draws are passed on as the MT19937 STATE words they were made of (tempering is the reader's), in plan order, in the columns
+    // they will stand in -- s0: the two words of rand() for the stretch factor (stretch.py:30), uacc: the two of the accept uniform
+    // (red_blue.py:100), p0: the word of a power-of-two randint (stretch.py:32; wr_ring = 1) or the accepted randint value itself
+    // (wr_ring = 0); p0 is a member number of the complement either way, not yet a walker.  The consumer converts (k_plan_raw).
+    int32_t raw = 0, wr_ring = 0;
 };
+constexpr int PIPE_RAW_SPLITS = 8;
 
 class MtPlanPipeline {
    public:
     // `sinks`: nsinks staging buffers used round-robin (step n -> sinks[n % nsinks]); a sink is rewritten only after
     // release(n - nsinks).  moves must all be stretch / DE / snooker.  nworkers <= 0: chosen from the core count.
+    // device_finish: stretch steps are handed over raw (PipeStepInfo::raw) -- the finishers apply the swaps, build `order` and copy
+    // the step's generator words into the sink; conversions and partner resolution are the consumer's.
     MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves,
                    const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers,
-                   bool fill_unused_fields = false);      // true: a stretch plan's p1 / p2 are set to the walker itself
+                   bool fill_unused_fields = false,       // true: a stretch plan's p1 / p2 are set to the walker itself
+                   bool device_finish = false);
     ~MtPlanPipeline();
     MtPlanPipeline(const MtPlanPipeline&) = delete;
     MtPlanPipeline& operator=(const MtPlanPipeline&) = delete;

@@ -46,18 +46,25 @@ static __global__ __launch_bounds__(512) void k_halfstep_slab(const HalfStepArgs
         double2* dst = reinterpret_cast<double2*>(smem);
         for (int e = threadIdx.x; e < IMG2; e += blockDim.x) dst[e] = img[e];
     }
-    Row<G, V, CH> mu;
-    load_row<G, V, CH>(mu, A.tp0, D, gl);
+    // (mu is read from its LDS image slab by slab -- muS[j] = mu[j], zero beyond ndim, exactly what load_row gives: sixteen VGPRs
+    // the DE instantiations need, round 5: 72-104 B of scratch before)
     const int wave = blockIdx.x * (blockDim.x >> 6) + wib, nwaves = gridDim.x * (blockDim.x >> 6);
     const int nslot = A.t_hi - A.t_lo;                 // (t_lo == 0: lean_kind)
     const int ntile = (nslot + 15) / 16;
     const int myrow = (lane >> 4) + 4 * (lane & 3);    // decision lanes: (lane & 15) < 4 decide tile row myrow
+    // Skewed start (A.ablate bit 8, tuning "slab_skew"): with one tile per wave -- 65 536 walkers on 256 CUs -- every wave of the chip
+    // loads, then every wave multiplies: the HBM phase (2 KB of rows per update at ndim 128) and the MFMA phase (144 f64 MFMAs per
+    // tile) run back to back chip-wide.  The second wave of every SIMD (wib >= 4) therefore issues its first tile's row loads only
+    // when its sibling's rows have arrived (a word in the sibling's LDS region), so one wave's MFMA chain covers the other's loads.
+    const bool skew_on = (A.ablate & 256) != 0 && blockDim.x == 512;
+    int* sigw = reinterpret_cast<int*>(muS + Dp + (size_t)(wib & 3) * (16 * SLAB_RT + 32) + 16 * SLAB_RT + 16);     // (facS uses 16 of the 32 spare doubles)
+    if (skew_on && wib < 4 && lane == 0) *sigw = wave < ntile ? 0 : 1;      // a wave without a tile never holds its sibling
     bool staged = false;
     for (int T = wave; T < ntile; T += nwaves) {
         const int tb = T * 16, pbase = A.pos0 + tb;
         // -------- plan entries, then every row of the tile --------
         int wi[PPT], ja[PPT], jb[DE ? PPT : 1], jc[SN ? PPT : 1];
-        double s0v[PPT], facv[PPT];
+        double s0v[PPT];
         bool live[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -69,12 +76,14 @@ static __global__ __launch_bounds__(512) void k_halfstep_slab(const HalfStepArgs
             if constexpr (DE) jb[k] = A.p1[pos];
             if constexpr (SN) jc[k] = A.p2[pos];
             s0v[k] = SN ? 0.0 : A.s0[pos];
-            facv[k] = A.fac[pos];
         }
         const bool mine = (lane & 15) < 4 && tb + myrow < nslot;
         const int mypos = pbase + (tb + myrow < nslot ? myrow : 0);
-        const int my_i = A.order[mypos];
-        const double my_logu = A.logu[mypos];
+        if (skew_on && wib >= 4 && !staged) {
+            __syncthreads();                            // (the image; the sibling's word is initialised)
+            staged = true;
+            while (__hip_atomic_load(sigw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
+        }
         Row<G, V, CH> xi[PPT], xa[PPT], xb[DE ? PPT : 1], xc[SN ? PPT : 1];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -83,17 +92,30 @@ static __global__ __launch_bounds__(512) void k_halfstep_slab(const HalfStepArgs
             if constexpr (DE) load_row<G, V, CH>(xb[k], A.X + (size_t)jb[k] * D, D, gl);
             if constexpr (SN) load_row<G, V, CH>(xc[k], A.X + (size_t)jc[k] * D, D, gl);
         }
-        const double my_lpo = A.lp[my_i];
         if (!staged) {                                  // the rows are in flight; the barrier only waits for the image
             __syncthreads();
             staged = true;
+            if (skew_on && wib < 4) {
+                // most of this wave's rows are here: the sibling may load now.  Not "all": its first row would then arrive a whole
+                // memory latency after this wave's last -- returns are in order, so requests queued behind the tail keep the pipe full
+                // (A.ablate bits 9-10, tuning "slab_skew" 1 ... 4: the sibling starts when all / three quarters / half / a quarter
+                // of this wave's row loads have returned)
+                constexpr int NL = (DE ? 3 : 2) * PPT * CH;        // row loads of a tile (16 bytes a lane each)
+                switch ((A.ablate >> 9) & 3) {
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL / 4) : "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL / 2) : "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NL / 4) : "memory"); break;
+                }
+                if (lane == 0) __hip_atomic_store(sigw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         // -------- proposals: kept in registers (R = Q - mu goes to LDS slab by slab below) --------
         Row<G, V, CH> qk[PPT];
         bool ok[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            double factor = facv[k];
+            double factor = 0.0;
             make_proposal<G, V, CH, MOVE>(xi[k], xa[k], xb[DE ? k : 0], xc[SN ? k : 0], s0v[k], A.gammas, D, gl, qk[k], factor, ja[k]);
             bool bl = false;
 #pragma unroll
@@ -103,10 +125,15 @@ static __global__ __launch_bounds__(512) void k_halfstep_slab(const HalfStepArgs
             const bool badq = group_any<G>(bl, sub);      // non-finite proposal -> sticky error (ensemble.py:476-479), rejected
             if (live[k] && badq && gl == 0) raise_status(A.status, ST_BAD_COORD);
             ok[k] = live[k] && !badq;
-            if (gl == 0) facS[k * WPW + sub] = badq ? -__builtin_inf() : factor;
+            if (gl == 0) facS[k * WPW + sub] = badq ? -__builtin_inf() : 0.0;       // (+ my_fac below: exact, x + 0 = x)
             // stored step: the current row goes out now (fire and forget); an accepted proposal overwrites it after the decision
             if (live[k] && A.chain) store_row_stream<G, V, CH>(xi[k], A.chain + (size_t)wi[k] * D, D, gl);
         }
+        // the deciding lanes' own entries: asked for here, under the MFMA chain (seven VGPRs the row phase does not have to spare)
+        const int my_i = A.order[mypos];
+        const double my_logu = A.logu[mypos];
+        const double my_fac = A.fac[mypos];             // (stretch: (D - 1) ln z, DE: 0 -- neither move changes it: read by the deciding lane alone)
+        const double my_lpo = A.lp[my_i];
         // -------- Y = R L, slab by slab; column block nb takes the k-steps kk >= 4 nb (L is lower triangular) --------
         typedef double d4 __attribute__((ext_vector_type(4)));
         d4 accv[DPB];
@@ -117,11 +144,12 @@ static __global__ __launch_bounds__(512) void k_halfstep_slab(const HalfStepArgs
         for (int c = 0; c < CH; ++c) {
             if (32 * c < Dp) {
                 EMX_WAVE_SYNC();                        // every lane has read the slab before
+                const double2 muc = *reinterpret_cast<const double2*>(muS + 32 * c + 2 * gl);
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     double2 r;
-                    r.x = ok[k] ? qk[k].x[c][0] - mu.x[c][0] : 0.0;            // dead row: zero residual
-                    r.y = ok[k] ? qk[k].x[c][1] - mu.x[c][1] : 0.0;
+                    r.x = ok[k] ? qk[k].x[c][0] - muc.x : 0.0;            // dead row: zero residual
+                    r.y = ok[k] ? qk[k].x[c][1] - muc.y : 0.0;
                     *reinterpret_cast<double2*>(tile + (k * WPW + sub) * SLAB_RT + gl * 2) = r;
                 }
                 EMX_WAVE_SYNC();                        // this wave's slab is visible to all of its lanes
@@ -150,7 +178,7 @@ static __global__ __launch_bounds__(512) void k_halfstep_slab(const HalfStepArgs
         if (mine) {
             const double lpn = -0.5 * my_qf;
             if (lpn != lpn) raise_status(A.status, ST_NAN_LOGP);
-            const double lnpdiff = facS[myrow] + lpn - my_lpo;
+            const double lnpdiff = (facS[myrow] + my_fac) + lpn - my_lpo;
             acc = lnpdiff > my_logu;
             A.acc[my_i] = acc ? 1 : 0;
             if (acc) A.lp[my_i] = lpn;

@@ -144,12 +144,14 @@ def test_role_split_log_prob_kernel_equals_the_single_role_one(N, D, moves):
 def test_slab_kernel_equals_per_tile_kernel_bit_for_bit(N, D, moves, weights, store):
     """padded ndim 80 ... 128, even ndim: k_halfstep_slab (csrc/emx_slab.hip: the tile's proposals in registers, a 32-column LDS
     slab, eight waves a CU) against k_halfstep<16, 2, 4, MOVE, DPB, 1> (tuning key slab = 0): same arithmetic in the same order,
-    so coordinates, log-probs, accept masks, chain rows and accept counters must agree bit for bit"""
+    so coordinates, log-probs, accept masks, chain rows and accept counters must agree bit for bit -- with and without the skewed
+    start of the second wave of every SIMD (tuning key slab_skew, round 5)"""
     spec = _spec(N, D, moves, weights)
     outs = []
-    for slab in (2, 0):                                    # 2: the slab form from padded ndim 80 on (by default it starts at 112)
+    for slab, skew in ((2, 1), (2, 0), (0, 0)):            # 2: the slab form from padded ndim 80 on (by default it starts at 112)
         ens = make_ens(spec, spec["p0"])
         ens.set_tuning("slab", slab)
+        ens.set_tuning("slab_skew", skew)
         ens.set_tuning("small_kernel", 0)
         ens.set_tuning("graph", 0)
         ens.eval_state_log_prob()
@@ -165,7 +167,8 @@ def test_slab_kernel_equals_per_tile_kernel_bit_for_bit(N, D, moves, weights, st
             rec.update(chain=ens.chain_read(0, 0, nst), clp=ens.chain_read(1, 0, nst), cnt=ens.accepted_counts())
         outs.append(rec)
         ens.close()
-    a, b = outs
+    a, a0, b = outs
     assert a["acc"].any() and not a["acc"].all()
     for key in a:
         assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(a0[key], b[key]), key

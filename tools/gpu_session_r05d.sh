@@ -1,13 +1,12 @@
 #!/bin/bash
-# round 5: k_persist_p2p variants with a sleep between polls -- A/B + phase clocks
+# round 5, session d: slab skew threshold sweep; host pipeline after the generator bursts; exact mode at C2
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r05
 O=$PWD/gpurun_out/r05
 export TMPDIR=/tmp
-rm -f $O/p2p_ab_variants3.txt
-for v in A B C D E; do
-  L=$PWD/emcee_amd/libemx_$v.so
-  EMX_LIB=$L timeout 300 python tools/exp/p2p_ab.py 800 3 1 2>&1 | grep -v amdgpu.ids | tee -a $O/p2p_ab_variants3.txt
-done
-EMX_STAMPS_LIB=$PWD/emcee_amd/libemx_Bs.so timeout 300 python tools/persist_phase_clock.py 65536 64 0 1 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_c2_p2p_B.txt
-EMX_STAMPS_LIB=$PWD/emcee_amd/libemx_Ds.so timeout 300 python tools/persist_phase_clock.py 65536 64 0 1 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_c2_p2p_D.txt
+timeout 300 python tools/exp/slab_ab.py slab_skew 3 0,1,2,3,4 > $O/slab_skew_sweep.txt 2>&1; echo "slab sweep rc=$?" | tee -a $O/summary_d.txt
+cat $O/slab_skew_sweep.txt
+( EMX_PIPE_STATS=1 timeout 120 python tools/mt_pipe_bench.py 65536 400 0 ) > $O/mt_pipe_host_d.txt 2>&1
+grep -E "workers=6|workers [0-9] rc" $O/mt_pipe_host_d.txt
+timeout 300 python tools/exact_mode_probe.py > $O/exact_c2_d.txt 2>&1; echo "exact rc=$?" | tee -a $O/summary_d.txt
+tail -n 3 $O/exact_c2_d.txt

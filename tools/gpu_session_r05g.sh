@@ -1,8 +1,9 @@
 #!/bin/bash
+# round 5, session g: device finish: kernel statistics of the exact-mode run at C2
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r05
 O=$PWD/gpurun_out/r05
 export TMPDIR=/tmp
-AB_KEY=persist_flat timeout 600 python tools/exp/p2p_ab.py 1600 4 0 2>&1 | grep -v amdgpu.ids | tee $O/flat_barrier_ab.txt
-( time timeout 600 python -m pytest tests/test_gpu_persist.py -q -x -p no:cacheprovider -k "without_a_barrier or gives_the_bits" ) > $O/p2p_tests_g.log 2>&1; echo "tests rc=$?"
-tail -n 4 $O/p2p_tests_g.log
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_exact_g -o x -- python $GRAFT_REPO_ROOT/tools/exact_mode_probe.py > $O/prof_exact_g.log 2>&1; cd $GRAFT_REPO_ROOT
+f=$(find $O/prof_exact_g -name "*kernel_stats.csv" | head -1); head -n 12 "$f" | cut -c1-200
+grep ms_per_step $O/prof_exact_g.log | cut -c1-300
