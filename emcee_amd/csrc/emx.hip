@@ -346,7 +346,8 @@ struct emx_ctx {
         char* host = nullptr;  // pinned: [order|p0|p1|p2](int32 N each) [s0|uacc](double N each)
         hipEvent_t consumed = nullptr;
         hipEvent_t consumed_ref = nullptr; // the event behind the kernels that last read this slot (its own, or a persistent launch's)
-        hipEvent_t uploaded = nullptr;     // pipeline uploads: copy + logs done on the upload stream
+        hipEvent_t uploaded = nullptr;     // pipeline uploads: the copy is done (upload stream)
+        hipEvent_t uploaded2 = nullptr, uploaded_ref2 = nullptr;     // ... its second half (second upload stream), where it went up in two
         hipEvent_t uploaded_ref = nullptr; // the event that says this slot's latest upload is done ...
         unsigned last_seq = 0;             // the persistent launch that last read this slot's device copy (0: none since the pipeline started)
         int64_t fetch_step = -1;           // ... or (>= 0) the step whose plan k_plan_fetch takes from it: done when *pipe_done > fetch_step
@@ -366,6 +367,8 @@ struct emx_ctx {
     unsigned* pipe_arrived = nullptr;           // device: k_plan_fetch's workgroup counter
     hipStream_t up_stream = nullptr;     // plan uploads overlap the previous step's kernels
     int64_t tune_mt_device_finish = 1;   // 1: stretch steps of the host pipeline are finished on the device (k_plan_raw); 0: by the finisher threads
+    int64_t tune_mt_upload_split = 0;    // 1: plans of >= 16 384 walkers go up in two halves on two streams (measured slower: 59-89 against 47 us per step at 65 536 walkers)
+    hipStream_t up_stream2 = nullptr;
     int64_t pipe_raw_steps = 0;          // steps taken that way (emx_pipe_stage_times)
     int64_t tune_mt_pipeline = -1;       // -1: on, finisher threads chosen from the core count; 0: off; k > 0: k finishers
     // exact-mode plans made on the device (emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica
@@ -1197,6 +1200,7 @@ int emx_destroy(emx_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm), c->comm = nullptr;
     if (c->status_host) hipHostFree(c->status_host);
+    if (c->up_stream2) hipStreamDestroy(c->up_stream2);
     if (c->xfer_host) hipHostFree(c->xfer_host);
     for (int k = 0; k < 2; ++k) {
         if (c->bounce[k]) hipHostFree(c->bounce[k]);
@@ -1214,6 +1218,7 @@ int emx_destroy(emx_ctx* c) {
         if (s.order) hipFree(s.order);       // the slot's single block
         if (s.host) hipHostFree(s.host);
         if (s.uploaded) hipEventDestroy(s.uploaded);
+        if (s.uploaded2) hipEventDestroy(s.uploaded2);
         s.uploaded_ref = nullptr;
         if (s.consumed) hipEventDestroy(s.consumed);
     }
@@ -1404,6 +1409,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "slab")) {              // 0: the per-tile kernel at every padded ndim (parity tests, A/B); 1: slab form from padded 112; 2: from padded 80
         c->tune_slab = v < 0 ? 0 : (v > 2 ? 2 : v);
+        return 0;
+    }
+    if (!strcmp(key, "mt_upload_split")) {
+        c->tune_mt_upload_split = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "mt_device_finish")) {      // 0: the host pipeline's finisher threads convert every draw themselves (rounds 1-4)
@@ -2054,7 +2063,7 @@ static void pipe_poll(void* arg) {
         auto& s = c->ring[(c->pipe_ring0 + n % c->pipe_nsinks) % PLAN_RING];
         if (s.fetch_step >= 0) {
             if (!c->pipe_done || __atomic_load_n(c->pipe_done, __ATOMIC_ACQUIRE) <= (unsigned long long)s.fetch_step) break;
-        } else if (!s.uploaded_ref || hipEventQuery(s.uploaded_ref) != hipSuccess) {
+        } else if (!s.uploaded_ref || hipEventQuery(s.uploaded_ref) != hipSuccess || (s.uploaded_ref2 && hipEventQuery(s.uploaded_ref2) != hipSuccess)) {
             break;
         }
         c->pipe->release(n);
@@ -2239,6 +2248,7 @@ static int pipe_take(emx_ctx* c) {
     if (c->pipe_defer) {
         // run_persist: the launch's plans go up together (pipe_fetch_deferred)
         s.uploaded_ref = nullptr;
+        s.uploaded_ref2 = nullptr;
         s.fetch_step = n;
         s.host_written = true;
         c->pipe_deferred.push_back({n, slot});
@@ -2247,11 +2257,32 @@ static int pipe_take(emx_ctx* c) {
         c->ring_pos = slot;
         return 0;
     }
-    // the device copy of this slot was last read by the kernels of step n - PIPE_SINKS
-    if (s.busy) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed_ref, 0));
+    // the device copy of this slot was last read by the kernels of step n - PIPE_SINKS.  (Asked of the event first: it is over long
+    // ago, and a stream wait on this runtime orders behind the other stream's LATEST work -- the kernels just enqueued.)
+    const bool still_read = s.busy && hipEventQuery(s.consumed_ref) != hipSuccess;
+    if (still_read) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed_ref, 0));
     const int stretch = c->moves[cur.move].kind == EMX_MOVE_STRETCH;
-    HIPOK(c, hipMemcpyAsync(s.order, s.host, plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE),
-                            hipMemcpyHostToDevice, c->up_stream));
+    const bool two = c->tune_mt_upload_split != 0 && N >= 16384;
+    const size_t bytes = plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE), half = two ? (bytes / 2) & ~(size_t)255 : bytes;
+    // The upload stream carries copies only: the conversion kernel behind a copy made every step's upload wait for a compute unit
+    // the half-step kernels hold (54 us per step of 65 536 walkers whatever the pipeline did; profiles/r05/exact_c2.md) -- it now
+    // runs on the consumer's stream, in front of the half-steps that need it.  A large plan goes up in two halves on two streams:
+    // one copy engine moves 1.57 MB in 37 us, two in 30 (profiles/r05/h2d_rate.txt).
+    HIPOK(c, hipMemcpyAsync(s.order, s.host, half, hipMemcpyHostToDevice, c->up_stream));
+    HIPOK(c, hipEventRecord(s.uploaded, c->up_stream));
+    HIPOK(c, hipStreamWaitEvent(c->stream, s.uploaded, 0));
+    if (two) {
+        if (!c->up_stream2) {
+            int lo = 0, hi = 0;
+            HIPOK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPOK(c, hipStreamCreateWithPriority(&c->up_stream2, hipStreamNonBlocking, hi));
+        }
+        if (!s.uploaded2) HIPOK(c, hipEventCreateWithFlags(&s.uploaded2, hipEventDisableTiming));
+        if (still_read) HIPOK(c, hipStreamWaitEvent(c->up_stream2, s.consumed_ref, 0));
+        HIPOK(c, hipMemcpyAsync(reinterpret_cast<char*>(s.order) + half, s.host + half, bytes - half, hipMemcpyHostToDevice, c->up_stream2));
+        HIPOK(c, hipEventRecord(s.uploaded2, c->up_stream2));
+        HIPOK(c, hipStreamWaitEvent(c->stream, s.uploaded2, 0));
+    }
     if (info.raw) {
         // device finish: the columns hold `order` and generator words (or accepted randint values); converted in place
         PlanRawArgs R{};
@@ -2262,18 +2293,17 @@ static int pipe_take(emx_ctx* c) {
         R.S = info.S;
         R.wr_words = info.wr_ring;
         for (int k = 0; k <= info.S; ++k) R.off[k] = info.off[k];
-        hipLaunchKernelGGL(k_plan_raw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->up_stream, R);
+        hipLaunchKernelGGL(k_plan_raw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, R);
         c->pipe_raw_steps++;
         cur.devplan = true;                 // (emx_plan_get: the finished columns exist on the device only)
     } else {
-        hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->up_stream, (int)N, (int)c->D, stretch, s.s0,
+        hipLaunchKernelGGL(k_plan_logs, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, (int)N, (int)c->D, stretch, s.s0,
                            s.uacc, s.logu, s.fac);
     }
     HIPOK(c, hipGetLastError());
-    HIPOK(c, hipEventRecord(s.uploaded, c->up_stream));
     s.uploaded_ref = s.uploaded;
+    s.uploaded_ref2 = two ? s.uploaded2 : nullptr;
     s.fetch_step = -1;
-    HIPOK(c, hipStreamWaitEvent(c->stream, s.uploaded, 0));
     s.host_written = true;
     c->pipe_uploads.push_back(n);
     c->pipe_taken = n + 1;
@@ -2326,7 +2356,10 @@ static int pipe_fetch_deferred(emx_ctx* c) {
     c->pipe_batch_n++;
     HIPOK(c, hipEventRecord(ev, c->up_stream));
     HIPOK(c, hipStreamWaitEvent(c->stream, ev, 0));
-    for (auto& d : c->pipe_deferred) c->ring[d.second].uploaded_ref = ev;
+    for (auto& d : c->pipe_deferred) {
+        c->ring[d.second].uploaded_ref = ev;
+        c->ring[d.second].uploaded_ref2 = nullptr;
+    }
     c->pipe_deferred.clear();
     return 0;
 }

@@ -350,46 +350,149 @@ EMX_CLONES void convert_pairs_zz(const uint32_t* __restrict w, double* __restric
 // 16 values out of the mask range, send the vector to the scalar loop).  Accepted values are compressed in stream order
 // into jr[(n - 1) - i ...]: the reversed layout makes their addresses ascend.  Returns the words consumed.
 // (p: state words, tempered here.)
-__attribute__((target("avx512f,avx512vl,avx512bw,popcnt"))) size_t shuffle_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i,
-                                                                                       int64_t lo, uint32_t* jr, int64_t nm1) {
+// Compaction of the accepted lanes of one vector to dst, in lane order.  Two forms: vpcompressd (one instruction, but tens of cycles
+// on some cores) and two 8-lane table permutes (vpermd through a 256-entry table of lane lists).  pick_compaction() times both once.
+struct CompactLut {
+    alignas(32) uint32_t idx[256][8];
+    CompactLut() {
+        for (int m = 0; m < 256; ++m) {
+            int k = 0;
+            for (int b = 0; b < 8; ++b)
+                if (m & (1 << b)) idx[m][k++] = (uint32_t)b;
+            for (; k < 8; ++k) idx[m][k] = 0;
+        }
+    }
+};
+static const CompactLut g_compact_lut;
+static int g_compaction = -1;      // 0: vpcompressd, 1: table permutes, 2: none (tools/ubench/mt_scan_bench.cpp only: timing without it)
+template <int MODE>
+__attribute__((target("avx512f,avx512vl,avx512bw,avx2,popcnt"))) inline int compact_store(uint32_t* dst, __mmask16 a, __m512i v) {
+    if (MODE == 0) {
+        _mm512_storeu_si512(dst, _mm512_maskz_compress_epi32(a, v));
+        return __builtin_popcount((unsigned)a);
+    } else if (MODE == 1) {
+        const unsigned ml = (unsigned)a & 0xffu, mh = ((unsigned)a >> 8) & 0xffu;
+        const int cl = __builtin_popcount(ml);
+        const __m256i lo8 = _mm512_castsi512_si256(v), hi8 = _mm512_extracti64x4_epi64(v, 1);
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst), _mm256_permutevar8x32_epi32(lo8, _mm256_load_si256(reinterpret_cast<const __m256i*>(g_compact_lut.idx[ml]))));
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + cl), _mm256_permutevar8x32_epi32(hi8, _mm256_load_si256(reinterpret_cast<const __m256i*>(g_compact_lut.idx[mh]))));
+        return cl + __builtin_popcount(mh);
+    } else {
+        return __builtin_popcount((unsigned)a);
+    }
+}
+
+template <int MODE>
+__attribute__((target("avx512f,avx512vl,avx512bw,avx2,popcnt"))) size_t shuffle_scan_avx512_t(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i,
+                                                                                              int64_t lo, uint32_t* jr, int64_t nm1) {
     const __m512i vmask = _mm512_set1_epi32((int)mask);
     size_t used = 0;
-    // Four vectors per trip while the band is wide (round 5).  The loop carries i through broadcast -> compare -> mask -> popcount,
-    // some 15 cycles whatever the width; against (i - 64, i] the four vectors' tests are independent of each other, and a word in
-    // that range -- 64 values out of the mask range -- sends the trip to the one-vector loop below.
+    // Four vectors per trip while the band is wide (round 5), tested against thresholds made from the value i had one trip EARLIER:
+    // the loop used to carry i through broadcast -> compare -> mask -> popcount -> subtract, some 15-20 cycles a trip whatever its
+    // width.  With i' >= i the i of the trip before, a word > i' is rejected and a word <= i' - 128 accepted whatever the others do
+    // (i' - 64 <= i at the start of this trip, at most 63 accepted before a word inside it); a word in between -- 128 values out of
+    // the mask range -- sends the trip to the one-vector loop below.  The compares of a trip then depend on nothing the trip before
+    // it computes, and consecutive trips overlap.
     if (mask >= (1u << 14)) {
+        int64_t stale = i;
         while (navail - used >= 64 && i - 64 > lo) {
-            const __m512i hi = _mm512_set1_epi32((int)(uint32_t)i), lo64 = _mm512_set1_epi32((int)(uint32_t)(i - 64));
+            const __m512i hi = _mm512_set1_epi32((int)(uint32_t)stale), lo128 = _mm512_set1_epi32((int)(uint32_t)(stale - 128));
+            stale = i;
             const __m512i v0 = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used)), vmask);
             const __m512i v1 = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used + 16)), vmask);
             const __m512i v2 = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used + 32)), vmask);
             const __m512i v3 = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used + 48)), vmask);
-            const __mmask16 a0 = _mm512_cmple_epu32_mask(v0, lo64), a1 = _mm512_cmple_epu32_mask(v1, lo64),
-                            a2 = _mm512_cmple_epu32_mask(v2, lo64), a3 = _mm512_cmple_epu32_mask(v3, lo64);
+            __mmask16 a0 = _mm512_cmple_epu32_mask(v0, lo128), a1 = _mm512_cmple_epu32_mask(v1, lo128),
+                      a2 = _mm512_cmple_epu32_mask(v2, lo128), a3 = _mm512_cmple_epu32_mask(v3, lo128);
             const __mmask16 r0 = _mm512_cmpgt_epu32_mask(v0, hi), r1 = _mm512_cmpgt_epu32_mask(v1, hi), r2 = _mm512_cmpgt_epu32_mask(v2, hi),
                             r3 = _mm512_cmpgt_epu32_mask(v3, hi);
-            if ((__mmask16)((a0 | r0) & (a1 | r1) & (a2 | r2) & (a3 | r3)) != (__mmask16)0xffff) break;
-            uint32_t* dst = jr + (nm1 - i);
-            const int c0 = __builtin_popcount((unsigned)a0), c1 = __builtin_popcount((unsigned)a1), c2 = __builtin_popcount((unsigned)a2),
-                      c3 = __builtin_popcount((unsigned)a3);
-            _mm512_storeu_si512(dst, _mm512_maskz_compress_epi32(a0, v0));                     // (16 slots of slack behind jr: a later
-            _mm512_storeu_si512(dst + c0, _mm512_maskz_compress_epi32(a1, v1));                //  store overwrites the zero tail of
-            _mm512_storeu_si512(dst + c0 + c1, _mm512_maskz_compress_epi32(a2, v2));           //  the one before it)
-            _mm512_storeu_si512(dst + c0 + c1 + c2, _mm512_maskz_compress_epi32(a3, v3));
+            if ((__mmask16)((a0 | r0) & (a1 | r1) & (a2 | r2) & (a3 | r3)) != (__mmask16)0xffff) {
+                // some lane lies between the thresholds (one trip in eight at the top of the range): decided exactly here, in stream
+                // order -- the lanes before it in its vector are all certain -- unless a vector has two of them (the loop below)
+                unsigned am[4] = {(unsigned)a0, (unsigned)a1, (unsigned)a2, (unsigned)a3};
+                const unsigned un[4] = {(unsigned)(__mmask16)~(a0 | r0), (unsigned)(__mmask16)~(a1 | r1), (unsigned)(__mmask16)~(a2 | r2), (unsigned)(__mmask16)~(a3 | r3)};
+                alignas(64) uint32_t lanes[64];
+                _mm512_store_si512(lanes, v0);
+                _mm512_store_si512(lanes + 16, v1);
+                _mm512_store_si512(lanes + 32, v2);
+                _mm512_store_si512(lanes + 48, v3);
+                int64_t ic = i;
+                bool two = false;
+                for (int k = 0; k < 4; ++k) {
+                    if (un[k]) {
+                        if (un[k] & (un[k] - 1u)) {
+                            two = true;
+                            break;
+                        }
+                        const int l = __builtin_ctz(un[k]);
+                        const int before = __builtin_popcount(am[k] & ((1u << l) - 1u));
+                        if ((int64_t)lanes[16 * k + l] <= ic - before) am[k] |= 1u << l;
+                    }
+                    ic -= __builtin_popcount(am[k]);
+                }
+                if (two) break;
+                a0 = (__mmask16)am[0];
+                a1 = (__mmask16)am[1];
+                a2 = (__mmask16)am[2];
+                a3 = (__mmask16)am[3];
+            }
+            uint32_t* dst = jr + (nm1 - i);                   // (16 slots of slack behind jr: a later store overwrites the tail of the one before it)
+            const int c0 = compact_store<MODE>(dst, a0, v0);
+            const int c1 = compact_store<MODE>(dst + c0, a1, v1);
+            const int c2 = compact_store<MODE>(dst + c0 + c1, a2, v2);
+            const int c3 = compact_store<MODE>(dst + c0 + c1 + c2, a3, v3);
             i -= (int64_t)(c0 + c1 + c2 + c3);
             used += 64;
         }
     }
     while (navail - used >= 16 && i - 16 > lo) {
         const __m512i v = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used)), vmask);
-        const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)(i - 16)));
+        __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)(i - 16)));
         const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)i));
-        if ((__mmask16)(acc | rej) != (__mmask16)0xffff) break;             // a word in (i - 16, i]: order matters, scalar
-        _mm512_storeu_si512(jr + (nm1 - i), _mm512_maskz_compress_epi32(acc, v));       // 16 slots of slack behind jr
-        i -= (int64_t)__builtin_popcount((unsigned)acc);
+        if ((__mmask16)(acc | rej) != (__mmask16)0xffff) {                  // a word in (i - 16, i]: order matters
+            const unsigned un = (unsigned)(__mmask16)~(acc | rej);
+            if (un & (un - 1u)) break;                                      // two of them: scalar
+            alignas(64) uint32_t lanes[16];
+            _mm512_store_si512(lanes, v);
+            const int l = __builtin_ctz(un);
+            if ((int64_t)lanes[l] <= i - __builtin_popcount((unsigned)acc & ((1u << l) - 1u))) acc = (__mmask16)((unsigned)acc | (1u << l));
+        }
+        i -= (int64_t)compact_store<MODE>(jr + (nm1 - i), acc, v);          // 16 slots of slack behind jr
         used += 16;
     }
     return used;
+}
+// which compaction this CPU does faster: both forms over the same 64 K pseudo-random words, once per process
+int pick_compaction() {
+    if (g_compaction >= 0) return g_compaction;
+    if (const char* e = getenv("EMX_PIPE_COMPACTION")) return g_compaction = atoi(e) ? 1 : 0;
+    std::vector<uint32_t> w(65536 + 64), out(65536 + 64);
+    uint32_t x = 0x2545f491u;
+    for (auto& v : w) {
+        x ^= x << 13;
+        x ^= x >> 17;
+        x ^= x << 5;
+        v = x;
+    }
+    uint64_t best[2] = {~0ull, ~0ull};
+    for (int rep = 0; rep < 3; ++rep)
+        for (int mode = 0; mode < 2; ++mode) {
+            int64_t i = 60000;
+            const uint64_t t0 = now_ns();
+            if (mode == 0)
+                shuffle_scan_avx512_t<0>(w.data(), 40000, 65535u, i, 32767, out.data(), 65535);
+            else
+                shuffle_scan_avx512_t<1>(w.data(), 40000, 65535u, i, 32767, out.data(), 65535);
+            best[mode] = std::min<uint64_t>(best[mode], now_ns() - t0);
+        }
+    return g_compaction = best[1] < best[0] ? 1 : 0;
+}
+inline size_t shuffle_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i, int64_t lo, uint32_t* jr, int64_t nm1) {
+    switch (g_compaction) {
+        case 1: return shuffle_scan_avx512_t<1>(p, navail, mask, i, lo, jr, nm1);
+        case 2: return shuffle_scan_avx512_t<2>(p, navail, mask, i, lo, jr, nm1);
+        default: return shuffle_scan_avx512_t<0>(p, navail, mask, i, lo, jr, nm1);
+    }
 }
 #endif
 
@@ -826,7 +929,8 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     }
     for (int s = 0; s < nsinks; ++s) m.sink_ready[s].v.store(-1);
 #ifdef EMX_HAVE_AVX512_GEN
-    m.vec_scan = __builtin_cpu_supports("avx512f") && !getenv("EMX_PIPE_NO_AVX512");
+    m.vec_scan = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx2") && !getenv("EMX_PIPE_NO_AVX512");
+    if (m.vec_scan) pick_compaction();
 #endif
     m.stats = getenv("EMX_PIPE_STATS") != nullptr;
     m.fill_unused = fill_unused_fields;

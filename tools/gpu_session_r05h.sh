@@ -1,12 +1,12 @@
 #!/bin/bash
-# round 5, session h: host pipeline + device finish: rates only
+# round 5, session h: the pipeline's inner loops alone on this host; exact mode at C2
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r05
 O=$PWD/gpurun_out/r05
 export TMPDIR=/tmp
-( EMX_PIPE_STATS=1 timeout 120 python tools/mt_pipe_bench.py 65536 400 0 ) > $O/mt_pipe_host_h.txt 2>&1
-grep -E "workers=[46]|workers [0-9] rc" $O/mt_pipe_host_h.txt | cut -c1-400
-timeout 300 python tools/exact_mode_probe.py > $O/exact_c2_h.txt 2>&1; echo "exact rc=$?" | tee -a $O/summary_h.txt
-tail -n 2 $O/exact_c2_h.txt
-EMX_TUNE=mt_device_finish=0 timeout 300 python tools/exact_mode_probe.py > $O/exact_c2_h_hostfinish.txt 2>&1
-tail -n 2 $O/exact_c2_h_hostfinish.txt
+for n in 65536 16384; do tools/ubench/bin/mt_scan_bench $n; done > $O/mt_scan_bench.txt 2>&1
+cat $O/mt_scan_bench.txt
+for cfg in "EMX_TUNE=mt_pipeline=6" "EMX_TUNE=mt_pipeline=4" "EMX_TUNE=mt_pipeline=5"; do
+  echo "== $cfg" | tee -a $O/exact_c2_h3.txt
+  env $cfg timeout 300 python tools/exact_mode_probe.py 2>&1 | tail -n 1 | cut -c1-600 | tee -a $O/exact_c2_h3.txt
+done
