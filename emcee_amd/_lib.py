@@ -108,6 +108,7 @@ SIGNATURES = {
     "emx_fft_load": (C.c_int, [C.c_char_p]),
     "emx_autocorr": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_double, _dp, _ip, C.POINTER(C.c_int64)]),
     "emx_walkers_independent": (C.c_int, [C.c_int32, _dp, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "emx_walkers_independent_resident": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "emx_host_pull_capacity": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "emx_comm_load": (C.c_int, [C.c_char_p]),
     "emx_comm_get_unique_id": (C.c_int, [_u8p]),

@@ -553,6 +553,7 @@ static void exchange_free(emx_ctx* c);
 static int replay_ensure(emx_ctx* c);
 static int flags_ensure(emx_ctx* c);
 static int persist_settle(emx_ctx* c);
+static hipError_t wait_stream(hipStream_t s);
 
 // forget native plans evaluated ahead of time; the Gaussian sequential cursors they advanced go back
 static void drop_prepared(emx_ctx* c) {
@@ -1048,6 +1049,21 @@ int emx_internal_chain_view(emx_ctx* c, EmxChainView* v) {
     v->stored = c->stored;
     v->stream = c->stream;
     v->device = c->device;
+    return 0;
+}
+
+int emx_internal_state_view(emx_ctx* c, const double** X, int64_t* N, int32_t* D, int* device) {
+    if (!c) {
+        g_err = "null context";
+        return -1;
+    }
+    { const int rcs_ = persist_settle(c); if (rcs_) return rcs_; }
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, wait_stream(c->stream));
+    *X = c->X;
+    *N = c->N;
+    *D = c->D;
+    *device = c->device;
     return 0;
 }
 
@@ -2092,7 +2108,6 @@ static int pipe_start(emx_ctx* c) {
     *c->pipe_done = 0ull;
     PlanSink sinks[PLAN_RING];
     c->pipe_nsinks = persist_exact_ok(c) ? PLAN_RING : PIPE_SINKS;      // (bursts of sixteen steps: the producers need the slack)
-    MtPlanPipeline::set_bursty_consumer(c->pipe_nsinks == PLAN_RING);
     c->pipe_ring0 = (c->ring_pos + 1) % PLAN_RING;
     for (int r = 0; r < c->pipe_nsinks; ++r) {
         auto& s = c->ring[(c->pipe_ring0 + r) % PLAN_RING];
@@ -2118,7 +2133,7 @@ static int pipe_start(emx_ctx* c) {
     const bool devfin = c->tune_mt_device_finish != 0 && c->pipe_nsinks == PIPE_SINKS && c->world == 1 && !c->comm && !c->sendbuf &&
                         !c->peers_ready && c->target != EMX_TARGET_HOST && !c->tune_full_plan;
     c->pipe = new MtPlanPipeline(c->mt, c->N, c->D, (int32_t)c->moves.size(), c->moves.data(), c->cdf.data(), nsteps, sinks,
-                                 c->pipe_nsinks, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0), false, devfin);
+                                 c->pipe_nsinks, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0), false, devfin, c->pipe_nsinks == PLAN_RING);
     return 0;
 }
 
@@ -3179,7 +3194,8 @@ static int persist_shape_local_of(int64_t N, int nsplits, int64_t cu) {
     if (nsplits < 2 || N < 2 || (N % nsplits) != 0) return 0;
     const int64_t own = N / nsplits;
     if ((own % 16) != 0) return 0;
-    const int64_t tiles = own / 16, per_xcd = std::max<int64_t>(1, cu / 8);
+    // (at most 32 working groups: persist_barrier_local keeps one flag word per group in words 0..31 of a line, word 32 is the dead mark)
+    const int64_t tiles = own / 16, per_xcd = std::min<int64_t>(32, std::max<int64_t>(1, cu / 8));
     for (int wpb = 1; wpb <= 8; wpb <<= 1)
         if ((tiles % wpb) == 0 && tiles / wpb <= per_xcd) return tiles / wpb >= 2 ? wpb : 0;
     return 0;
@@ -3266,6 +3282,17 @@ static bool persist_exact_ok(const emx_ctx* c) {
     // (an ensemble the one-workgroup kernel can take, asked for a step or two at a time -- the sample() loop of a progress bar or a
     // convergence check: that kernel's 10 us launch beats a fetch + a persistent launch per call, 49 against 72 us an iteration)
     if (small_eligible(c) && c->call_steps < 4) return false;
+    {   // a target one of the persistent kernels takes (k_persist: dense Gaussian up to padded ndim 64; k_persist_valu: the element-wise
+        // targets at the row shapes it is instantiated for) -- otherwise no persistent launch can follow, and the pipeline must not
+        // be started, sized or paced (bursty consumer) for one
+        const bool dense = c->target == EMX_TARGET_DENSE_GAUSS && c->Dp <= 64 && !dense_is_wide(c);
+        bool valu = c->target == EMX_TARGET_ISO_GAUSS || c->target == EMX_TARGET_DIAG_GAUSS || c->target == EMX_TARGET_ROSENBROCK || c->target == EMX_TARGET_BOX;
+        if (valu) {
+            const Shape sh = pick_shape(c->D, c->D);
+            valu = (sh.G == 8 && (sh.CH == 1 || sh.CH == 2 || sh.CH == 4)) || (sh.G == 4 && sh.CH == 1);
+        }
+        if (!dense && !valu) return false;
+    }
     if (!(c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_exact != 0 && c->moves.size() == 1 && c->tune_mt_pipeline != 0 &&
           c->N >= c->tune_persist_min_walkers && !mtdev_eligible(c) &&        // (the device producer: see persist_wanted)
           MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data())))

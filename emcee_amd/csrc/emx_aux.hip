@@ -382,12 +382,14 @@ int emx_autocorr(emx_ctx* c, int64_t discard, int64_t thin, double cwin, double*
     return 0;
 }
 
-int emx_walkers_independent(int32_t device, const double* coords, int64_t N, int32_t D, int32_t* independent, double* cond_out) {
+// coords: the (N, D) matrix on the host -- or, with on_device, already in this device's memory (the resident state of a context)
+static int walkers_independent_impl(int32_t device, const double* coords, bool on_device, int64_t N, int32_t D, int32_t* independent, double* cond_out) {
     if (!coords || !independent || N < 1 || D < 1) return emx_internal_fail(nullptr, -1, "emx_walkers_independent: bad arguments");
     *independent = 0;
     if (cond_out) *cond_out = INFINITY;
-    for (int64_t i = 0; i < N * (int64_t)D; ++i)
-        if (!std::isfinite(coords[i])) return 0;                      // ensemble.py:654-655
+    if (!on_device)
+        for (int64_t i = 0; i < N * (int64_t)D; ++i)
+            if (!std::isfinite(coords[i])) return 0;                  // ensemble.py:654-655 (a resident state: the factor's entries below)
     if (N < D) return 0;                                              // fewer walkers than dimensions: rank deficient
     AUX_HIP(nullptr, hipSetDevice(device));
     double *x = nullptr, *ct = nullptr, *R = nullptr, *scal = nullptr;
@@ -403,15 +405,15 @@ int emx_walkers_independent(int32_t device, const double* coords, int64_t N, int
         return emx_internal_fail(nullptr, -2, b);
     };
     hipError_t e;
-    if ((e = hipMalloc((void**)&x, (size_t)N * D * 8)) != hipSuccess) return fail(e, "allocation");
+    if (!on_device && (e = hipMalloc((void**)&x, (size_t)N * D * 8)) != hipSuccess) return fail(e, "allocation");
     if ((e = hipMalloc((void**)&ct, (size_t)N * D * 8)) != hipSuccess) return fail(e, "allocation");
     if ((e = hipMalloc((void**)&R, (size_t)D * D * 8)) != hipSuccess) return fail(e, "allocation");
     if ((e = hipMalloc((void**)&scal, 64)) != hipSuccess) return fail(e, "allocation");
     if ((e = hipMalloc((void**)&bad, 4)) != hipSuccess) return fail(e, "allocation");
-    if ((e = hipMemcpy(x, coords, (size_t)N * D * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
+    if (!on_device && (e = hipMemcpy(x, coords, (size_t)N * D * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
     hipMemset(bad, 0, 4);
     hipMemset(R, 0, (size_t)D * D * 8);
-    hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((N + 63) / 64), (unsigned)((D + 63) / 64)), dim3(256), 0, 0, x, ct, N, D);
+    hipLaunchKernelGGL(k_transpose_in, dim3((unsigned)((N + 63) / 64), (unsigned)((D + 63) / 64)), dim3(256), 0, 0, on_device ? coords : x, ct, N, D);
     hipLaunchKernelGGL(k_condition_column, dim3((unsigned)D), dim3(1024), 0, 0, ct, N, bad);
     // Householder QR of the (N, D) matrix, column by column; R's singular values are the matrix's (backward stable, like the
     // SVD the reference takes; a Gram matrix would square the condition number and could not resolve the 1e8 threshold)
@@ -477,6 +479,20 @@ int emx_walkers_independent(int32_t device, const double* coords, int64_t N, int
     if (cond_out) *cond_out = cond;
     *independent = cond <= 1e8 ? 1 : 0;                               // ensemble.py:663
     return 0;
+}
+
+int emx_walkers_independent(int32_t device, const double* coords, int64_t N, int32_t D, int32_t* independent, double* cond_out) {
+    return walkers_independent_impl(device, coords, false, N, D, independent, cond_out);
+}
+
+int emx_walkers_independent_resident(emx_ctx* c, int32_t* independent, double* cond_out) {
+    const double* X = nullptr;
+    int64_t N = 0;
+    int32_t D = 0;
+    int device = 0;
+    const int rc = emx_internal_state_view(c, &X, &N, &D, &device);
+    if (rc) return rc;
+    return walkers_independent_impl(device, X, true, N, D, independent, cond_out);
 }
 
 }  // extern "C"

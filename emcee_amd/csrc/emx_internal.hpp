@@ -18,4 +18,5 @@ struct EmxChainView {
 
 // implemented in emx.hip
 int emx_internal_chain_view(emx_ctx* c, EmxChainView* v);
+int emx_internal_state_view(emx_ctx* c, const double** X, int64_t* N, int32_t* D, int* device);      // settles and synchronises the context first
 int emx_internal_fail(emx_ctx* c, int code, const char* msg);      // records the message for emx_last_error, returns code

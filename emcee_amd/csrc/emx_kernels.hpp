@@ -1378,7 +1378,9 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
                 if constexpr (LOCAL) {
                     const unsigned m = __hip_atomic_load(go + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     open = (m & (m - 1u)) == 0u;                                   // one XCD
-                    if (!open) {                                                   // report it like a grid that never became co-resident
+                    if (open) {                                                    // (every workgroup of this launch has marked; the next launch starts clean)
+                        __hip_atomic_store(go + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {                                                   // report it like a grid that never became co-resident
                         raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
                         __hip_atomic_store(go + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // 1: nothing was written
                     }

@@ -164,14 +164,15 @@ void confine(std::thread&, const CpuSet&, const std::vector<int>&, int) {}
 // bursts, the naps are 20 us with the threads' timer slack set to 1 us (stage_thread_setup).  PAUSE, not sched_yield: on a host whose
 // logical CPUs are SMT pairs (the 16-CPU boxes) six finishers yielding in a loop next to the generator and the tokenizer cost those a
 // third of their rate (C2 exact mode 54 -> 87 us/step, profiles/r04/exact_mid.txt); PAUSE hands the core's issue slots to the sibling.
-// The spin is for a consumer that takes its steps in bursts only (MtPlanPipeline::set_bursty_consumer: the persistent kernels); with a
+// The spin is for a consumer that takes its steps in bursts only (the constructor's bursty_consumer: the persistent kernels); with a
 // consumer that takes a step at a time and orders its uploads with events, spinning stage threads made it SLOWER (26.8 -> 48.8 us/step
 // at 4 096 walkers, 68 -> 84 at 65 536: profiles/r04/exact_mid.txt) -- there the window is 0.  EMX_PIPE_SPIN_US overrides both.
-static std::atomic<uint64_t> g_spin_ns{0};
 struct Backoff {
     int n = 0;
     uint64_t t0 = 0;
-    static uint64_t spin_ns() { return g_spin_ns.load(std::memory_order_relaxed); }
+    uint64_t spin = 0;            // the owning pipeline's spin window (a field of the pipeline, not of the process: round 5)
+    explicit Backoff(uint64_t spin_window_ns) : spin(spin_window_ns) {}
+    uint64_t spin_ns() const { return spin; }
     inline void pause() {
         if (n < 256) {
             ++n;
@@ -205,9 +206,9 @@ struct Backoff {
         }
     }
 };
-inline void stage_thread_setup() {
+inline void stage_thread_setup(uint64_t spin_window_ns) {
 #if defined(__linux__)
-    if (g_spin_ns.load(std::memory_order_relaxed) != 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);       // (ns; the default 50 us is added to every sleep_for above)
+    if (spin_window_ns != 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);       // (ns; the default 50 us is added to every sleep_for above)
 #endif
 }
 
@@ -510,11 +511,12 @@ struct WordStream {
     std::atomic<uint64_t> rdblk{0};                    // block the tokenizer stands in
     alignas(64) std::atomic<bool> stop{false};
     std::atomic<uint64_t> gen_wait_ns{0}, gen_blocks{0}, rd_wait_ns{0};     // read by stage_times() while the threads run
+    uint64_t spin_ns = 0;            // Backoff's spin window for this pipeline's threads
     uint64_t words() const { return nblk * BLK; }
 };
 
 void generator_main(WordStream* ws, const uint32_t* start_key) {
-    stage_thread_setup();
+    stage_thread_setup(ws->spin_ns);
     // block 0 is the block the caller's generator currently stands in (no twist)
     const uint64_t NBLK = ws->nblk;
     const TwistFn twist = pick_twist(NBLK * BLK * 4 > (24ull << 20));
@@ -526,7 +528,7 @@ void generator_main(WordStream* ws, const uint32_t* start_key) {
     // the lines of block b - 1 are being pulled by the tokenizer's core just then.
     alignas(64) uint32_t pkey[2][BLK + 16];
     std::memcpy(pkey[0], start_key, BLK * 4);
-    Backoff bo;
+    Backoff bo(ws->spin_ns);
     // A block is 50-150 ns of work; the shared words (`keep`, the reader's block, this thread's `produced`) each cost a cache-line
     // transfer between cores when touched, so they are touched once per GEN_BURST blocks: space for a burst is checked once, the
     // burst is published once.  (Round 5; before, every block loaded `keep`, published `produced` and wrote a sequentially
@@ -581,7 +583,7 @@ struct Reader {
     // wait until the words below position `a` exist
     bool wait_produced(uint64_t a) {
         if (ws->produced.load(std::memory_order_acquire) * BLK >= a) return true;
-        Backoff bo;
+        Backoff bo(ws->spin_ns);
         const uint64_t t0 = now_ns();
         while (ws->produced.load(std::memory_order_acquire) * BLK < a) {
             // (ten seconds without a word: the generator is held by a ring that cannot take this step -- step_words_bound exceeded,
@@ -847,11 +849,6 @@ struct MtPlanPipeline::Impl {
     void join_all();
 };
 
-void MtPlanPipeline::set_bursty_consumer(bool bursty) {
-    const char* e = getenv("EMX_PIPE_SPIN_US");
-    g_spin_ns.store(e ? (uint64_t)atoll(e) * 1000ull : (bursty ? 150000ull : 0ull), std::memory_order_relaxed);
-}
-
 bool MtPlanPipeline::supports(int32_t nmoves, const emx_move_desc* moves) {
     for (int i = 0; i < nmoves; ++i) {
         const int k = moves[i].kind;
@@ -863,9 +860,13 @@ bool MtPlanPipeline::supports(int32_t nmoves, const emx_move_desc* moves) {
 
 MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves,
                                const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers,
-                               bool fill_unused_fields, bool device_finish)
+                               bool fill_unused_fields, bool device_finish, bool bursty_consumer)
     : impl_(new Impl()) {
     Impl& m = *impl_;
+    {
+        const char* e = getenv("EMX_PIPE_SPIN_US");
+        m.ws.spin_ns = e ? (uint64_t)atoll(e) * 1000ull : (bursty_consumer ? 150000ull : 0ull);
+    }
     m.N = N;
     m.D = D;
     m.nsteps = nsteps;
@@ -1091,7 +1092,7 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
 }
 
 void MtPlanPipeline::Impl::tokenizer_main() {
-    stage_thread_setup();
+    stage_thread_setup(ws.spin_ns);
     Reader rd;
     rd.ws = &ws;
     rd.stop = &stop;
@@ -1099,7 +1100,7 @@ void MtPlanPipeline::Impl::tokenizer_main() {
     int has_gauss = start.has_gauss;
     double gauss = start.gauss;
     for (int64_t n = 0; n < nsteps; ++n) {
-        Backoff bo;
+        Backoff bo(ws.spin_ns);
         // the sink of step n is free once step n - nsinks has been uploaded; the raw slot once its finisher is done
         if (n >= released.load(std::memory_order_acquire) + nsinks || raw_done[n % NR].v.load(std::memory_order_acquire) != n - NR) {
             const uint64_t t0 = now_ns();
@@ -1213,10 +1214,10 @@ void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) 
 }
 
 void MtPlanPipeline::Impl::finisher_main(int id) {
-    stage_thread_setup();
+    stage_thread_setup(ws.spin_ns);
     std::vector<uint8_t> labels((size_t)N);
     for (int64_t n = id; n < nsteps; n += K) {
-        Backoff bo;
+        Backoff bo(ws.spin_ns);
         const uint64_t t0 = now_ns();
         while (raw_ready[n % NR].v.load(std::memory_order_acquire) != n && !stop.load(std::memory_order_relaxed)) bo.pause();
         if (stop.load(std::memory_order_relaxed)) return;
@@ -1232,7 +1233,7 @@ void MtPlanPipeline::Impl::finisher_main(int id) {
 bool MtPlanPipeline::wait_ready(int64_t n, PipeStepInfo& info, void (*poll)(void*), void* poll_arg) {
     Impl& m = *impl_;
     if (n < 0 || n >= m.nsteps) return false;
-    Backoff bo;
+    Backoff bo(m.ws.spin_ns);
     int spins = 0;
     while (m.sink_ready[n % m.nsinks].v.load(std::memory_order_acquire) != n) {
         if (m.failed.load() || m.stop.load()) return false;

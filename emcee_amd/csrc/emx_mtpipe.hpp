@@ -74,7 +74,9 @@ class MtPlanPipeline {
     MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves,
                    const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers,
                    bool fill_unused_fields = false,       // true: a stretch plan's p1 / p2 are set to the walker itself
-                   bool device_finish = false);
+                   bool device_finish = false,
+                   bool bursty_consumer = false);        // the consumer takes its steps sixteen at a time (the persistent kernels): the stage threads
+                                                         // spin through the gaps between bursts instead of napping
     ~MtPlanPipeline();
     MtPlanPipeline(const MtPlanPipeline&) = delete;
     MtPlanPipeline& operator=(const MtPlanPipeline&) = delete;
@@ -88,9 +90,6 @@ class MtPlanPipeline {
     void release(int64_t n);
     // Stop all threads; `out` receives the generator state after `steps_consumed` steps (NumPy get_state() semantics).
     void finish(int64_t steps_consumed, MT19937Legacy& out);
-    // the consumer takes its steps sixteen at a time (the persistent kernels): the stage threads spin through the gaps between bursts
-    // instead of napping (process-wide; set before the pipeline is constructed)
-    static void set_bursty_consumer(bool bursty);
     int workers() const;
     // microseconds per produced step: [0] wall, [1] generator busy, [2] tokenizer busy, [3] finishers busy (summed), [4] tokenizer
     // waiting for words, [5] tokenizer waiting for a free staging buffer

@@ -242,6 +242,12 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_set_target_callback(self.ctx, fn, C.c_void_p(user_ptr) if not isinstance(user_ptr, C.c_void_p) else user_ptr))
         self._target_kind = _lib.TARGET_CALLBACK
 
+    def walkers_independent(self):
+        """The reference's initial-state check (ensemble.py:653-663) on the ensemble this context holds: nothing crosses PCIe."""
+        verdict = C.c_int32(0)
+        self._ck(self.lib.emx_walkers_independent_resident(self.ctx, C.byref(verdict), None))
+        return bool(verdict.value)
+
     def eval_state_log_prob(self):
         self._touch()
         self._ck(self.lib.emx_eval_state_log_prob(self.ctx))

@@ -525,10 +525,7 @@ class EnsembleSampler(object):
             resident = initial_state
         if resident is not None:
             state = resident
-            # No conditioning check here: this state is the output of a run whose own initial state passed it (or whose caller
-            # waived it), and checking would download the whole ensemble (33 MB at 65 536 x 64) on a path whose point is that
-            # nothing crosses PCIe.  (The reference re-checks a continuation, ensemble.py:316-323; an affine-invariant move
-            # cannot make an independent ensemble dependent except by numerical collapse, which the next explicit state would show.)
+            # (the reference's conditioning check of a continuation, ensemble.py:316-323: below, on the ensemble where it lives)
         else:
             state = State(initial_state, copy=True)
             if self._dist is not None:
@@ -550,6 +547,14 @@ class EnsembleSampler(object):
         ens = self._configure_device(descs, True)
         if resident is not None and (resident._is_device_state(ens) or resident._restore_on_device(ens)):
             lp0 = None                # log-probs of a state a run produced: finite by construction (NaN proposals are rejected)
+            # The reference re-checks a continuation too (ensemble.py:316-323).  Here on the device (emx_walkers_independent_resident:
+            # Householder QR where the ensemble is, ndim^2 numbers come back): nothing crosses PCIe on a path whose point is that.
+            if (not kw.get("skip_initial_state_check", False)) and (not ens.walkers_independent()):
+                raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
+                                 "linearly independent for the best performance")
+        elif resident is not None and (not kw.get("skip_initial_state_check", False)) and (not walkers_independent(state.coords)):
+            raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
+                             "linearly independent for the best performance")
         elif state.log_prob is None:
             ens.set_state(state.coords)
             ens.eval_state_log_prob()

@@ -319,6 +319,10 @@ int emx_autocorr(emx_ctx* ctx, int64_t discard, int64_t thin, double c, double* 
  * *cond_out (or NULL): the condition number (inf for a constant coordinate, non-finite input, n < ndim or a singular factor). */
 int emx_walkers_independent(int32_t device, const double* coords, int64_t n, int32_t ndim, int32_t* independent,
                             double* cond_out);
+/* The same check on the state a context holds (a run continued from the State the previous run returned: the reference re-checks
+ * every sample() call, ensemble.py:316-323) -- the ensemble is read where it is, nothing crosses PCIe.  A non-finite coordinate
+ * shows as a non-finite entry of the factor (verdict 0). */
+int emx_walkers_independent_resident(emx_ctx* ctx, int32_t* independent, double* cond_out);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 int emx_timer_start(emx_ctx* ctx);                 /* hipEventRecord on the context stream */

@@ -80,3 +80,41 @@ def test_device_path_agrees_with_host(nw, nd):
         if name not in ("offset 10/eps",):                   # quantised to multiples of 8: full rank again when nw is large
             assert dev == expect, name
         assert walkers_independent(m) == host, name          # the public entry point takes the device path here
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw,nd", [(64, 5), (4096, 33)])
+def test_resident_state_check_agrees_with_the_c_abi_on_host_coordinates(nw, nd):
+    """emx_walkers_independent_resident (round 5): the check on the ensemble a context holds -- what a run continued from the
+    State the previous run returned is checked with (reference: every sample() call, ensemble.py:316-323) -- gives the verdict
+    and the condition number of emx_walkers_independent on the same coordinates; and the sampler raises the reference's
+    ValueError when such a continuation starts from a collapsed ensemble."""
+    import ctypes as C
+    from emcee_amd import _lib, EnsembleSampler
+    from emcee_amd.device import DeviceEnsemble
+    lib = _lib.load()
+    rs = np.random.RandomState(nd)
+    for name, m, expect in _cases(nw, nd, rs):
+        if name == "nan":
+            continue                                      # (a context refuses a non-finite state at set_state)
+        x = np.ascontiguousarray(m, dtype=np.float64)
+        ens = DeviceEnsemble(nw, nd)
+        ens.set_target(_lib.TARGET_ISO)
+        ens.set_state(x)
+        v0, c0, v1, c1 = C.c_int32(-1), C.c_double(), C.c_int32(-1), C.c_double()
+        assert lib.emx_walkers_independent(0, x, nw, nd, C.byref(v0), C.byref(c0)) == 0
+        assert lib.emx_walkers_independent_resident(ens.ctx, C.byref(v1), C.byref(c1)) == 0
+        assert v0.value == v1.value == int(expect), name
+        if expect:
+            assert c0.value == c1.value, name
+        assert ens.walkers_independent() == expect
+        ens.close()
+    # the drop-in path: a continuation from the State the sampler itself returned, after the ensemble has been collapsed behind its back
+    from emcee_amd import targets
+    sampler = EnsembleSampler(nw, nd, targets.IsotropicGaussian(nd), rng="philox", seed=3)
+    st = sampler.run_mcmc(rs.randn(nw, nd), 5)
+    sampler.run_mcmc(st, 3)                                # independent: runs
+    sampler._ens.set_state(np.ones((nw, nd)))              # every walker the same point
+    with pytest.raises(ValueError, match="large condition number"):
+        sampler.run_mcmc(None, 3)
+    sampler.run_mcmc(None, 3, skip_initial_state_check=True)
