@@ -352,6 +352,7 @@ struct emx_ctx {
         unsigned last_seq = 0;             // the persistent launch that last read this slot's device copy (0: none since the pipeline started)
         int64_t fetch_step = -1;           // ... or (>= 0) the step whose plan k_plan_fetch takes from it: done when *pipe_done > fetch_step
         bool busy = false, host_written = false;
+        int move_idx = 0;                  // exact-mode pipeline: the move of the step whose plan the slot holds
     } ring[PLAN_RING + MTDEV_SLOTS];
     // exact-mode plan pipeline (emx_mtpipe.hpp): alive only inside emx_run
     MtPlanPipeline* pipe = nullptr;
@@ -367,6 +368,7 @@ struct emx_ctx {
     unsigned* pipe_arrived = nullptr;           // device: k_plan_fetch's workgroup counter
     hipStream_t up_stream = nullptr;     // plan uploads overlap the previous step's kernels
     int64_t tune_mt_device_finish = 1;   // 1: stretch steps of the host pipeline are finished on the device (k_plan_raw); 0: by the finisher threads
+    int64_t tune_persist_exact_mix = 1;  // 0: exact mode takes the persistent kernels with ONE move only (round 4)
     int64_t tune_mt_upload_split = 0;    // 1: plans of >= 16 384 walkers go up in two halves on two streams (measured slower: 59-89 against 47 us per step at 65 536 walkers)
     hipStream_t up_stream2 = nullptr;
     int64_t pipe_raw_steps = 0;          // steps taken that way (emx_pipe_stage_times)
@@ -1427,6 +1429,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_slab = v < 0 ? 0 : (v > 2 ? 2 : v);
         return 0;
     }
+    if (!strcmp(key, "persist_exact_mix")) {
+        PIPE_STOP(c);
+        c->tune_persist_exact_mix = v ? 1 : 0;
+        return 0;
+    }
     if (!strcmp(key, "mt_upload_split")) {
         c->tune_mt_upload_split = v ? 1 : 0;
         return 0;
@@ -2259,6 +2266,7 @@ static int pipe_take(emx_ctx* c) {
     cur.S = info.S;
     cur.slot = slot;
     cur.off.assign(info.off, info.off + info.S + 1);
+    s.move_idx = info.move;
     const size_t N = (size_t)c->N;
     if (c->pipe_defer) {
         // run_persist: the launch's plans go up together (pipe_fetch_deferred)
@@ -2357,7 +2365,7 @@ static int pipe_fetch_deferred(emx_ctx* c) {
         }
         F.host[k] = s.host;
         F.dev[k] = (char*)s.order;
-        F.stretch[k] = c->moves[0].kind == EMX_MOVE_STRETCH;       // (persist_exact_ok: one move)
+        F.stretch[k] = c->moves[(size_t)std::max(0, s.move_idx)].kind == EMX_MOVE_STRETCH;       // (the step's own move: a mixture's steps share launches)
         F.peers[k] = !(F.stretch[k] && c->world == 1);
     }
     F.delay_ticks = (unsigned)(c->tune_fetch_delay_us * 100);
@@ -3255,7 +3263,8 @@ static bool persist_mix_local(const emx_ctx* c) {
 }
 static bool persist_mix_ok(const emx_ctx* cc) {
     emx_ctx* c = const_cast<emx_ctx*>(cc);
-    if (!c->tune_persist_mix || c->target != EMX_TARGET_DENSE_GAUSS || c->rng_mode != EMX_RNG_PHILOX) return false;
+    if (!c->tune_persist_mix || c->target != EMX_TARGET_DENSE_GAUSS) return false;
+    if (c->rng_mode != EMX_RNG_PHILOX && !(c->rng_mode == EMX_RNG_MT19937 && persist_exact_ok(c))) return false;
     bool de = false, sn = false;
     for (const auto& m : c->moves) {
         if (!persist_mix_member(m)) continue;
@@ -3293,15 +3302,22 @@ static bool persist_exact_ok(const emx_ctx* c) {
         }
         if (!dense && !valu) return false;
     }
-    if (!(c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_exact != 0 && c->moves.size() == 1 && c->tune_mt_pipeline != 0 &&
+    if (!(c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_exact != 0 && !c->moves.empty() && c->tune_mt_pipeline != 0 &&
           c->N >= c->tune_persist_min_walkers && !mtdev_eligible(c) &&        // (the device producer: see persist_wanted)
           MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data())))
         return false;
-    if (persist_local_ok(c, c->moves[0])) return true;
-    // the device-wide form of the dense kernel up to "persist_exact_max_walkers" (32 768): beyond, the pipeline's generator thread
-    // bounds the step whatever runs it, and a launch's plans are 25 MB to fetch over PCIe
-    if (c->N > c->tune_persist_exact_max || persist_shape(c, c->moves[0].nsplits) == 0) return false;
-    return c->target == EMX_TARGET_DENSE_GAUSS || persist_valu_wide_ok(c, c->moves[0]);
+    if (c->moves.size() > 1 && !c->tune_persist_exact_mix) return false;
+    // EVERY move of the schedule (round 5: a mixture's next move is read off the pipeline's plan before it is taken, run_persist):
+    // the one-XCD form, or the device-wide form of the dense kernel up to "persist_exact_max_walkers" (32 768) -- beyond, the
+    // pipeline's generator thread bounds the step whatever runs it, and a launch's plans are 25 MB to fetch over PCIe
+    for (const auto& m : c->moves) {
+        const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
+        if (!known && c->moves.size() > 1) return false;       // (one move: persist_local_ok / persist_move_ok say the same, later)
+        if (persist_local_ok(c, m)) continue;
+        if (c->N > c->tune_persist_exact_max || persist_shape(c, m.nsplits) == 0) return false;
+        if (!(c->target == EMX_TARGET_DENSE_GAUSS || persist_valu_wide_ok(c, m))) return false;
+    }
+    return true;
 }
 
 static bool persist_wanted(const emx_ctx* c) {
@@ -3499,6 +3515,13 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         int next_move = -1;
         if (steps > 0 && !mtmode)
             next_move = !c->prepared.empty() ? c->prepared.front().move : philox_move_choice(c->ph_seed, c->ph_step, c->cdf.data(), (int)c->moves.size());
+        if (steps > 0 && mtmode && !devp && c->moves.size() > 1) {
+            // exact mode, a mixture: the pipeline has made (or is making) the next step's plan -- its move is read off it without taking it
+            PipeStepInfo peek;
+            if (!c->pipe || !c->pipe->wait_ready(c->pipe_taken, peek, pipe_poll, c))
+                FAIL(c, -7, "exact-mode plan pipeline stopped before step %lld", (long long)c->pipe_taken);
+            next_move = peek.move;
+        }
         int need = launch_S;               // half-steps of the step that would follow
         if (launch_mix && next_move >= 0) need = c->moves[next_move].nsplits;
         if (n + need > PERSIST_MAX_ITERS) break;
@@ -3506,6 +3529,12 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             if (steps > 0 && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) break;      // one produced batch per launch
         } else if (mtmode) {
             if (steps >= std::min<int64_t>(c->tune_persist_exact_steps, c->pipe_nsinks / 2)) break;          // (k_plan_fetch takes sixteen plans; half of the pipeline's slots at most: the other half is produced meanwhile)
+            if (steps > 0 && next_move >= 0) {               // a mixture: the same rules as with Philox plans (below)
+                if (!launch_mix && c->moves[next_move].kind != launch_move) break;
+                if (!launch_mix && launch_move == EMX_MOVE_SNOOKER && c->moves[next_move].gammas != launch_gammas) break;
+                if (launch_mix && !persist_mix_member(c->moves[next_move])) break;
+                if (!persist_move_ok(c, c->moves[next_move])) break;
+            }
         } else {
             if (steps > 0 && c->prepared.empty() && !c->tune_persist_span) break;          // (tuning persist_span = 0: one plan batch per launch)
             if (steps > 0 && !launch_mix && c->moves[next_move].kind != launch_move) break;       // a mixture: the run of this move ends here

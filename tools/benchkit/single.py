@@ -144,6 +144,16 @@ def config_entry(wl, res, K, store):
         out["roofline"]["avg_launch_us_is"] = "hipEvent time of the timed region / half-steps (persistent launches counted by their half-steps)"
     state_mb = wl.N * wl.D * 8 / 1e6
     traffic = None
+    if state_mb <= 256.0:
+        # the cache-resident configurations: HBM bytes per walker-update from the round-5 counter passes (tools/pmc_r05.sh, static:
+        # the driver does not run rocprofv3), per launch = x walker-updates of a launch
+        per_wu = pmc_r05_traffic(wl, store)
+        if per_wu:
+            traffic = per_wu * wl.N / lps
+            out["roofline"].update({"traffic": traffic, "traffic_bytes_per_walker_update": per_wu,
+                                    "traffic_source": "profiles/r05/pmc_traffic_r05.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py "
+                                                      "in the builder's session of round 5, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over all half-step kernels / walker-updates; "
+                                                      "not re-measured by this run)"})
     if state_mb > 256.0:
         traffic = hbm_traffic(wl.key)
         out["roofline"].update({"state_MB": state_mb, "beyond_infinity_cache": True,
@@ -153,6 +163,19 @@ def config_entry(wl, res, K, store):
     if state_mb > 256.0:
         out["roofline"]["frac_moved_of_achievable_6300"] = out["roofline"]["achieved_moved"] / HBM_ACHIEVABLE_GBPS
     return out
+
+
+def pmc_r05_traffic(wl, store):
+    """HBM bytes per walker-update of a bench configuration at its BASELINE size (profiles/r05/pmc_traffic_r05.json), or None."""
+    key = {"c2": "c2_store" if store else "c2", "c3": "c3", "c4": "c4", "c5": "c5", "w128": "w128"}.get(wl.key)
+    sizes = {"c2": 65536, "c3": 262144, "c4": 65536, "c5": 16384, "w128": 65536}
+    if key is None or wl.N != sizes.get(wl.key) or (store and wl.key != "c2"):
+        return None
+    try:
+        cfg = json.load(open(os.path.join(ROOT, "profiles", "r05", "pmc_traffic_r05.json")))["configs"][key]
+        return float(cfg["bytes_per_walker_update"])
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def hbm_traffic(key):
