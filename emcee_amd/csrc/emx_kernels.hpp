@@ -661,44 +661,37 @@ __device__ __forceinline__ void make_proposal(const Row<G, V, CH>& xi, const Row
                 q.x[c][v] = xi.x[c][v] + prod;                  // s + ...
             }
     } else if constexpr (MOVE == MOVE_SNOOKER) {
-        // xa = z, xb = z1, xc = z2
-        double n2 = 0.0;
+        // xa = z, xb = z1, xc = z2.  de_snooker.py:41-45: delta = s - z, u = delta / |delta|, q = s + u gammas (u.z1 - u.z2),
+        // metropolis = ln|q - z| - ln|delta|.  ONE pass and one round of group reductions (round 5; three dependent ones before): the
+        // three sums |delta|^2, delta.z1, delta.z2 are taken together -- u.z = (delta.z) / |delta| -- and |q - z| needs none:
+        // q - z = u (|delta| + gammas (u.z1 - u.z2)) with |u| = 1.  Same quantities as the reference's, rounded differently in the
+        // last place (the snooker move's coordinates were never bit-equal to NumPy's pairwise sums: tolerance 1e-9, accept masks equal).
+        double n2 = 0.0, e1 = 0.0, e2 = 0.0;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const double dl = xi.x[c][v] - xa.x[c][v];     // delta = s[i] - z
                 n2 = fma(dl, dl, n2);
+                e1 = fma(dl, xb.x[c][v], e1);
+                e2 = fma(dl, xc.x[c][v], e2);
             }
-        const double norm = sqrt(group_sum<G>(n2));
-        double d1 = 0.0, d2 = 0.0;
-        Row<G, V, CH> uu;                                    // u = delta / norm, computed once (de_snooker.py:42)
+        n2 = group_sum<G>(n2);
+        e1 = group_sum<G>(e1);
+        e2 = group_sum<G>(e2);
+        const double norm = sqrt(n2);
+        const double dd = e1 / norm - e2 / norm;                // dot(u, z1) - dot(u, z2)
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const double u = (xi.x[c][v] - xa.x[c][v]) / norm;
-                uu.x[c][v] = u;
-                d1 = fma(u, xb.x[c][v], d1);
-                d2 = fma(u, xc.x[c][v], d2);
-            }
-        d1 = group_sum<G>(d1);
-        d2 = group_sum<G>(d2);
-        const double dd = d1 - d2;
-        double m2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const double u = uu.x[c][v];
                 const double ug = u * gammas;                   // u * gammas
                 const double prod = ug * dd;                    // * (dot(u,z1) - dot(u,z2))
                 const int d = (c * G + gl) * V + v;
                 q.x[c][v] = d < D ? xi.x[c][v] + prod : 0.0;
-                const double e = q.x[c][v] - xa.x[c][v];
-                m2 = fma(e, e, m2);
             }
-        const double nq = sqrt(group_sum<G>(m2));
+        const double nq = fabs(norm + gammas * dd);             // |q - z|
         factor = ((double)D - 1.0) * (log(nq) - log(norm));
     } else {
         q = xi;
