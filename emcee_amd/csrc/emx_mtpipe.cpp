@@ -655,6 +655,25 @@ struct Reader {
         }
         return value;
     }
+    // the smallest all-ones mask covering v
+    static inline uint64_t mask_of(uint64_t v) {
+        v |= v >> 1;
+        v |= v >> 2;
+        v |= v >> 4;
+        v |= v >> 8;
+        v |= v >> 16;
+        v |= v >> 32;
+        return v;
+    }
+    // randint(0, rng + 1) / random_interval(rng) with the mask made once by the caller (rng <= 2^32 - 2, mask = mask_of(rng)):
+    // the per-walker loops of the DE and snooker moves draw from the same few ranges over and over
+    inline uint32_t masked32(uint32_t rng, uint32_t mask) {
+        uint32_t val;
+        do {
+            val = next32() & mask;
+        } while (val > rng && !dead);
+        return val;
+    }
     // RandomState.randint(0, n) element
     inline uint64_t randint(uint64_t n) {
         const uint64_t rng = n - 1;
@@ -1040,7 +1059,12 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
                 rd.fill_randint32(sk.p0 + base, ns, (uint64_t)nc);
         } else if (mv.kind == EMX_MOVE_DE) {
             const uint64_t pop = (uint64_t)nc * (uint64_t)(nc - 1);
-            for (int64_t t = 0; t < ns; ++t) raw.k64[base + t] = rd.randint(pop);                  // de.py:49
+            if (pop - 1 != 0 && pop - 1 < 0xffffffffull) {                                         // de.py:49 (the mask made once)
+                const uint32_t rng = (uint32_t)(pop - 1), msk = (uint32_t)Reader::mask_of(pop - 1);
+                for (int64_t t = 0; t < ns; ++t) raw.k64[base + t] = rd.masked32(rng, msk);
+            } else {
+                for (int64_t t = 0; t < ns; ++t) raw.k64[base + t] = rd.randint(pop);
+            }
             // de.py:56 randn(ns, 1): legacy polar method, the second value of a pair is cached for the next call
             int64_t t = 0;
             while (t < ns && !rd.dead) {
@@ -1077,13 +1101,27 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
                 if (s != split) cs[q++] = s;
             const uint64_t nj[3] = {(uint64_t)(info.off[cs[0] + 1] - info.off[cs[0]]), (uint64_t)(info.off[cs[1] + 1] - info.off[cs[1]]),
                                     (uint64_t)(info.off[cs[2] + 1] - info.off[cs[2]])};
-            for (int64_t t = 0; t < ns && !rd.dead; ++t) {
-                sk.p0[base + t] = (int32_t)rd.randint(nj[0]);
-                sk.p1[base + t] = (int32_t)rd.randint(nj[1]);
-                sk.p2[base + t] = (int32_t)rd.randint(nj[2]);
-                const uint32_t j2 = (uint32_t)rd.random_interval(2);
-                const uint32_t j1 = (uint32_t)rd.random_interval(1);
-                raw.perm[base + t] = (uint8_t)(j2 | (j1 << 2));
+            const bool small = nj[0] >= 2 && nj[1] >= 2 && nj[2] >= 2 && nj[0] < 0xffffffffull && nj[1] < 0xffffffffull && nj[2] < 0xffffffffull;
+            if (small) {                                                                          // (the masks made once per split)
+                const uint32_t r0 = (uint32_t)(nj[0] - 1), r1 = (uint32_t)(nj[1] - 1), r2 = (uint32_t)(nj[2] - 1);
+                const uint32_t m0 = (uint32_t)Reader::mask_of(r0), m1 = (uint32_t)Reader::mask_of(r1), m2 = (uint32_t)Reader::mask_of(r2);
+                for (int64_t t = 0; t < ns && !rd.dead; ++t) {
+                    sk.p0[base + t] = (int32_t)rd.masked32(r0, m0);
+                    sk.p1[base + t] = (int32_t)rd.masked32(r1, m1);
+                    sk.p2[base + t] = (int32_t)rd.masked32(r2, m2);
+                    const uint32_t j2 = rd.masked32(2u, 3u);                                       // random_interval(2)
+                    const uint32_t j1 = rd.next32() & 1u;                                          // random_interval(1): the mask rejects nothing
+                    raw.perm[base + t] = (uint8_t)(j2 | (j1 << 2));
+                }
+            } else {
+                for (int64_t t = 0; t < ns && !rd.dead; ++t) {
+                    sk.p0[base + t] = (int32_t)rd.randint(nj[0]);
+                    sk.p1[base + t] = (int32_t)rd.randint(nj[1]);
+                    sk.p2[base + t] = (int32_t)rd.randint(nj[2]);
+                    const uint32_t j2 = (uint32_t)rd.random_interval(2);
+                    const uint32_t j1 = (uint32_t)rd.random_interval(1);
+                    raw.perm[base + t] = (uint8_t)(j2 | (j1 << 2));
+                }
             }
         }
         rd.copy_words(info.raw ? reinterpret_cast<uint32_t*>(sk.uacc + base) : raw.wu.data() + 2 * base, 2 * ns);      // red_blue.py:100 rand() x Ns
