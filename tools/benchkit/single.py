@@ -221,10 +221,13 @@ def exact_mode_entry(wl, K, W, device):
             "block_spread": float(np.max(res["walls_s"]) / np.min(res["walls_s"])),
             "pipeline_stage_us_per_step": res.get("pipeline"),
             "note": "host_plan_ms = one step's plan made inline by ONE host thread (emx_host_plan_mt, no GPU) -- round 1's path; emx_run "
-                    "now takes its plans from the host pipeline (csrc/emx_mtpipe.cpp: MT19937 generator thread, tokenizer thread, "
-                    "finisher threads -- six where the L3 domain has room -- confined to that domain, uploads on a side stream), so ms_per_step is the pipeline's rate; "
-                    "pipeline_stage_us_per_step says which stage bounds it on THIS host (the stages run concurrently: the largest of "
-                    "generator / tokenizer / finishers-summed over the thread count is the pipeline's floor)"}
+                    "takes its plans from the host pipeline (csrc/emx_mtpipe.cpp: generator thread twisting MT19937 STATE words into a cache-"
+                    "resident ring, tokenizer thread deciding the rejections and copying the fixed-length draws out, finisher threads -- six where "
+                    "the L3 domain has room -- for the swaps and `order`); round 5: a stretch step's uniforms go up as those generator words, "
+                    "in the plan's columns, one copy per step on an upload stream of its own, and k_plan_raw tempers / converts / resolves "
+                    "partners / takes the logs on the consumer's stream (profiles/r05/exact_c2.md: 57.8 -> 45.8 us/step and the variants "
+                    "dropped).  pipeline_stage_us_per_step says which stage bounds it on THIS host (the stages run concurrently: the largest "
+                    "of generator / tokenizer / finishers-summed over the thread count is the pipeline's floor; box to box 45.8 ... 54)"}
 
 
 def exact_mode_large_entry(K, W, device):
@@ -277,8 +280,19 @@ def exact_mode_mid_entry(K, W, device):
                 e[name]["pipeline_stage_us_per_step"] = res.get("pipeline")
         e["speedup"] = e["per_half_step"]["ms_per_step"] / e["persistent_one_xcd"]["ms_per_step"]
         out["%dx64" % N] = e
+    # round 5: a move MIXTURE in exact mode (the reference's recommended usage, docs/tutorials/moves.ipynb) on the persistent kernels --
+    # the next step's move is read off the pipeline's plan before it is taken; DE + snooker share launches (k_persist_mix)
+    wl = Workload("c4", 1024)
+    e = {}
+    for name, tune in (("persistent", {"persist_exact_mix": 1}), ("upload_per_step", {"persist_exact_mix": 0})):
+        res = measure_single(wl, Kx, max(W, 10), device=device, rng="mt19937", spin_s=0.05, want_kernel=False, tuning=tune)
+        e[name] = {"ms_per_step": res["wall_s"] * 1e3 / Kx, "blocks_timed": res["blocks"], "device_status": res["status"],
+                   "accept_frac": res["accept_frac"], "pipeline_stage_us_per_step": res.get("pipeline")}
+    e["speedup"] = e["upload_per_step"]["ms_per_step"] / e["persistent"]["ms_per_step"]
+    out["mix_de0.8_snooker0.2_1024x64"] = e
     out["note"] = ("profiles/r04/exact_mid.txt: what stood in the way (per-step uploads, sleeping stage threads, a shared hardware queue, "
-                   "lazily resolved events); from 4 096 walkers on the pipeline's generator thread is the bound")
+                   "lazily resolved events); from 4 096 walkers on the pipeline's generator thread is the bound; mixtures: profiles/r05/exact_mix_probe.txt "
+                   "(the tokenizer's scalar DE / snooker draws bound them from ~4 096 walkers on)")
     return out
 
 

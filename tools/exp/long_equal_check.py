@@ -42,10 +42,18 @@ ST = [_lib.MoveDesc(0, 2, 1, 0, 2.0, 1e-5, 0.2, 1.7)]
 MIX = [_lib.MoveDesc(1, 2, 1, 0, 2.0, 1e-5, g0, 0.0), _lib.MoveDesc(2, 4, 1, 0, 2.0, 1e-5, g0, 1.4)]
 cases = [(1024, 64, "dense", ST, [1.0], "mt", 20000), (4096, 16, "iso", ST, [1.0], "mt", 12000), (8192, 8, "iso", ST, [1.0], "mt", 6000),
          (512, 5, "iso", ST, [1.0], "mt", 20000), (2048, 4, "iso", [_lib.MoveDesc(2, 4, 1, 0, 2.0, 1e-5, 0.3, 1.7)], [1.0], "mt", 8000),
-         (65536, 64, "dense", MIX, [0.8, 0.2], "philox", 3000), (2048, 64, "dense", MIX, [0.5, 0.5], "philox", 12000), (1024, 32, "dense", MIX, [0.3, 0.7], "philox", 12000)]
+         (65536, 64, "dense", MIX, [0.8, 0.2], "philox", 3000), (2048, 64, "dense", MIX, [0.5, 0.5], "philox", 12000), (1024, 32, "dense", MIX, [0.3, 0.7], "philox", 12000),
+         # round 5: exact mode with move mixtures on the persistent kernels; exact mode at the headline size (device finish, an upload per step)
+         (1024, 64, "dense", MIX, [0.8, 0.2], "mt", 6000), (4096, 64, "dense", ST + MIX[:1], [0.5, 0.5], "mt", 4000), (2048, 10, "iso", ST + MIX, [0.4, 0.4, 0.2], "mt", 4000),
+         (65536, 64, "dense", ST, [1.0], "mt-finish", 1500)]
 for N, D, tgt, mv, w, rng, steps in cases:
-    a = run(N, D, tgt, mv, w, rng, steps, {})
-    b = run(N, D, tgt, mv, w, rng, steps, {"persist": 0})
+    if rng == "mt-finish":               # device finish (k_plan_raw) against the finisher threads' own conversions
+        rng = "mt"
+        a = run(N, D, tgt, mv, w, rng, steps, {})
+        b = run(N, D, tgt, mv, w, rng, steps, {"mt_device_finish": 0})
+    else:
+        a = run(N, D, tgt, mv, w, rng, steps, {})
+        b = run(N, D, tgt, mv, w, rng, steps, {"persist": 0})
     ok = np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and (a[2] is None or np.array_equal(a[2], b[2])) and a[3] == 0 and b[3] == 0
     print("%6d x %2d %-5s %-6s %5d steps: %s  (persistent %d launches, %d recovered, %.2f s; per-half-step %.2f s)" % (
         N, D, tgt, rng, steps, "EQUAL" if ok else "DIFFERENT  status %r %r" % (a[3], b[3]), a[4]["launches"], a[4]["recovered"], a[5], b[5]), flush=True)
