@@ -526,6 +526,8 @@ struct emx_ctx {
         uint64_t ph_step;
         int64_t i0, steps, stored0, proposals0;
         int32_t thin_by, store;
+        int64_t pipe_step0 = -1;          // exact mode: steps the host pipeline had handed out before this launch's first ...
+        const void* pipe_id = nullptr;    // ... and which pipeline that was
     };
     std::deque<PersistLog> plog;
     unsigned persist_seq = 0;
@@ -3503,6 +3505,10 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     lg.proposals0 = c->proposals;
     lg.thin_by = thin_by;
     lg.store = store;
+    if (mtmode && !devp) {
+        lg.pipe_step0 = c->pipe ? c->pipe_taken : 0;
+        lg.pipe_id = c->pipe;
+    }
     int launch_move = -1;                // EMX_MOVE_STRETCH, _DE or _SNOOKER: the move of every step of this launch
     int launch_S = 2;
     bool launch_local = false;           // the one-XCD form: an eight times larger grid of which every eighth workgroup works
@@ -3668,7 +3674,9 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     P.seq = ++c->persist_seq;
     lg.seq = P.seq;
     lg.steps = steps;
-    if (!mtmode) c->plog.push_back(lg);       // (redoing a launch needs its plans again: a pure function of the step for Philox only)
+    // (redoing a launch needs its plans again: a pure function of the step for Philox; in exact mode the pipeline is taken back to
+    // the generator state in front of the launch -- persist_settle -- which the device producer's batches do not offer)
+    if (!mtmode || (!devp && lg.pipe_id != nullptr)) c->plog.push_back(lg);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = c->prof_max > 0 && c->prof_n < c->prof_max;
     if (prof) {
@@ -3759,6 +3767,13 @@ static int persist_settle(emx_ctx* c) {
     for (const auto& e : c->plog)
         if ((int)(e.seq - done_seq) > 0) redo.push_back(e);
     c->plog.clear();
+    // Exact mode (round 5): the steps of the launches to redo have left the host pipeline, but it keeps the generator state behind
+    // each of its last 64 + steps (NumPy get_state() semantics): the pipeline is retired at the state in front of the first such
+    // launch and the steps are drawn again, by a new pipeline, on the per-half-step path.  Not possible (another pipeline since, or
+    // too far back): as before -- the status bit stays, the run is void and says so.
+    const bool exact_redo = !redo.empty() && redo.front().pipe_step0 >= 0;
+    if (exact_redo && (c->pipe == nullptr || c->pipe != redo.front().pipe_id || c->pipe_taken - redo.front().pipe_step0 > 60 || c->cur.active))
+        return 0;
     // the barrier words restart, the status bit is taken back: nothing is void
     HIPOK(c, hipMemsetAsync(c->persist_bar, 0, PERSIST_BAR_WORDS * sizeof(unsigned), c->stream));
     c->persist_epoch = 0;
@@ -3777,12 +3792,21 @@ static int persist_settle(emx_ctx* c) {
         c->tune_persist_local = 0;            // the one-XCD form's workgroups did not share an XCD: that form stays off ("persist_local" = 1)
     else
         c->tune_persist = 0;                  // and it stays off: whatever held the CUs may still be there ("persist" = 1 turns it back on)
+    if (exact_redo) {
+        MT19937Legacy before = c->mt;
+        c->pipe->finish(redo.front().pipe_step0, before);
+        delete c->pipe;
+        c->pipe = nullptr;
+        c->pipe_uploads.clear();
+        c->pipe_deferred.clear();
+        c->mt = before;                       // the next emx_step_begin starts a pipeline from here
+    }
     c->ph_step = redo.front().ph_step;
     c->stored = redo.front().stored0;
     c->proposals = redo.front().proposals0;
     int rc = 0;
     for (const auto& e : redo) {
-        NEED(c, c->ph_step == e.ph_step && c->stored == e.stored0, "persistent launches to redo are not consecutive");
+        NEED(c, (exact_redo || c->ph_step == e.ph_step) && c->stored == e.stored0, "persistent launches to redo are not consecutive");
         for (int64_t k = 0; k < e.steps && !rc; ++k) {
             const int st = e.store && ((e.i0 + k + 1) % e.thin_by == 0);          // ensemble.py:416
             int mvi, S;
@@ -3796,7 +3820,7 @@ static int persist_settle(emx_ctx* c) {
         c->persist_recovered++;
     }
     if (rc) return rc;
-    NEED(c, c->ph_step == ph_end && c->stored == stored_end && c->proposals == proposals_end, "redone steps do not add up");
+    NEED(c, (exact_redo || c->ph_step == ph_end) && c->stored == stored_end && c->proposals == proposals_end, "redone steps do not add up");
     HIPOK(c, wait_stream(c->stream));
     return 0;
 }

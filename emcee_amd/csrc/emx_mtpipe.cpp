@@ -910,7 +910,7 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(K, nsinks), nsteps));
     m.K = K;
     m.NR = K + 2;
-    m.NSNAP = nsinks + 4;
+    m.NSNAP = nsinks + 68;          // (generator states behind the last steps: emx.hip's persist_settle takes the pipeline back up to 60 steps)
     m.start = start;
     m.device_finish = device_finish;
     m.ws.nblk = RING_BLKS;

@@ -385,9 +385,11 @@ int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
  * EMX_RNG_MT19937 (the reference's own stream; ensemble.py:166-167) takes the one-XCD forms too -- and the device-wide forms of both
  * kernels up to 32 768 walkers ("persist_exact_max_walkers") -- when the context has ONE move: the
  * host pipeline's plans of up to sixteen steps ("persist_exact_steps") are fetched from their pinned staging buffers by one kernel
- * per launch (k_plan_fetch) -- tuning "persist_exact" = 0: the per-half-step launches with an upload per step.  (A launch of this
- * mode that cannot become resident on one XCD is NOT redone -- its plans have left the pipeline: status bit 3, as for a barrier
- * that timed out in the middle of a launch.) */
+ * per launch (k_plan_fetch) -- tuning "persist_exact" = 0: the per-half-step launches with an upload per step.  Move mixtures too
+ * (round 5: the next step's move is read off the pipeline's plan before it is taken; "persist_exact_mix" = 0: one move only).  A
+ * launch of this mode that cannot become resident is redone like a Philox one (round 5): the pipeline keeps the generator state
+ * behind each of its last 64 steps and is taken back to the one in front of the launch; only when that is not possible (further
+ * back than that) does status bit 3 stay, as for a barrier that timed out in the middle of a launch. */
 int emx_persist_local_launches(emx_ctx* ctx, int64_t* n);
 /* ... and how many took the form WITHOUT a barrier between the half-steps (csrc/emx_persist_p2p.hpp): the stretch move
  * (moves/stretch.py:26-33) on the fused dense Gaussian in the device-wide form with EMX_RNG_PHILOX plans -- BASELINE's headline

@@ -748,3 +748,45 @@ def test_exact_mode_mixtures_take_the_persistent_kernels(N, D, target, moves, we
     for key in c:
         if key not in ("info", "rng"):
             assert np.array_equal(p[key], c[key]), key
+
+
+@pytest.mark.parametrize("N,D,target,moves,weights", [(4096, 64, "dense", [S("stretch")], None), (2048, 10, "iso", [S("stretch")], None),
+                                                      (1024, 64, "dense", [S("de"), S("snooker")], [0.7, 0.3])])
+def test_exact_mode_launches_that_cannot_become_resident_are_redone(N, D, target, moves, weights):
+    """Round 5: the give-up path in exact mode.  A persistent launch whose handshake is not met (here: the test skews the count it
+    waits for; in the field: another process's persistent grid holds the CUs -- two processes per GPU) leaves the ensemble untouched,
+    and so do the launches queued behind it; their steps have left the host pipeline, but the pipeline keeps the generator state behind
+    each of its last steps: it is taken back to the state in front of the first such launch, and the steps are drawn again on the
+    per-half-step path.  Same bits -- coordinates, log-probs, chain, accept counters, the generator state handed back -- as a run
+    that never tried; no status bit, no void state (round 4: status bit 3)."""
+    spec = full_spec(N, D, target, moves, weights=weights, seed=17)
+    state = np.random.RandomState(777 + N).get_state()
+    recs = []
+    nst = 40
+    for pe in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        ens.set_mt19937(state)
+        ens.set_tuning("persist_exact", pe)
+        ens.chain_config(3 * nst)
+        ens.run(nst, 1, True)                                # a first call both ways: the second starts from a moved state
+        if pe:
+            assert ens.persist_info()["launches"] > 0
+            ens.set_tuning("persist_timeout_ms", 20)
+            ens.set_tuning("persist_test_skew", 1000)
+        ens.run(nst, 1, True)                                # the first launch times out, the others see the mark
+        ens.sync()                                           # ... and all of them are redone here
+        if pe:
+            assert ens.persist_info()["recovered"] >= 1
+            ens.set_tuning("persist_test_skew", 0)
+        ens.run(nst, 1, True)                                # (the persistent path stays off for this context: per-half-step from here on)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        recs.append(dict(x=x, lp=lp, chain=ens.chain_read(0, 0, 3 * nst), chain_lp=ens.chain_read(1, 0, 3 * nst), counts=ens.accepted_counts(),
+                         rng=ens.get_mt19937()))
+        ens.close()
+    p, c = recs
+    assert np.array_equal(p["rng"][1], c["rng"][1]) and p["rng"][2] == c["rng"][2]
+    for key in c:
+        if key != "rng":
+            assert np.array_equal(p[key], c[key]), key
