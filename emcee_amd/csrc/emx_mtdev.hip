@@ -1,6 +1,7 @@
 // Device-side exact-plan producer: the host driver of the kernels in emx_mtdev_kernels.hpp (design: emx_mtdev.hpp).
 #include "emx_mtdev.hpp"
 
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -29,7 +30,20 @@ inline uint32_t untemper32(uint32_t y) {
 }  // namespace
 
 enum { G_GEN = 0, G_TOK = 8, G_FIN = 16, G_REL = 24, G_STATS = 32, G_WORDS = 64 };          // (a 64-byte line each)
-constexpr unsigned long long GATE_TIMEOUT_TICKS = 100000000ull * 20ull;       // 20 s
+constexpr unsigned long long GATE_TIMEOUT_TICKS_DEFAULT = 100000000ull * 20ull;       // 20 s (EMX_MTDEV_GATE_TIMEOUT_MS shortens it)
+static unsigned long long gate_timeout_ticks() {
+    static const unsigned long long t = [] {
+        const char* e = getenv("EMX_MTDEV_GATE_TIMEOUT_MS");
+        const long long ms = e ? atoll(e) : 0;
+        return ms > 0 ? (unsigned long long)ms * 100000ull : GATE_TIMEOUT_TICKS_DEFAULT;
+    }();
+    return t;
+}
+// Producers alive in this process.  A gate wait spins on a hardware queue; the runtime multiplexes a process's streams onto a few
+// queues, and with more than one producer (or context) alive a wait can sit in front of the very kernel that would signal it, until
+// it times out.  One producer per process -- the deployment, and all that was measured -- orders its stages through gates; a second
+// one takes the event-ordered form (slower: an event wait resolves to the other stream's latest work, but it cannot deadlock).
+static std::atomic<int> g_live_producers{0};
 
 struct MtDevProducer::Impl {
     int device = 0;
@@ -54,6 +68,7 @@ struct MtDevProducer::Impl {
     // tokenizer state
     unsigned long long* d_pos = nullptr;
     unsigned* d_err = nullptr;
+    bool counted = false;             // this producer is in g_live_producers
     unsigned long long* d_nwin = nullptr;
     uint32_t *J[2] = {nullptr, nullptr}, *rint[2] = {nullptr, nullptr};        // per batch parity
     WalkRec* recs[2] = {nullptr, nullptr};     // [BATCH][maxrec] walk records of the tokenizer (per batch parity)
@@ -156,7 +171,9 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
         MTD_HIP(hipMalloc((void**)&m.polys, (size_t)(PMAX - 1) * MT_N * 4));
         MTD_HIP(hipMalloc((void**)&m.gates, G_WORDS * 8));
         MTD_HIP(hipMemset(m.gates, 0, G_WORDS * 8));
-        m.use_gates = getenv("EMX_MTDEV_EVENTS") == nullptr;       // (the event-ordered form, for comparison)
+        m.use_gates = getenv("EMX_MTDEV_EVENTS") == nullptr && g_live_producers.load() == 0;       // (the event-ordered form: for comparison, and for every producer but the first)
+        g_live_producers.fetch_add(1);
+        m.counted = true;
         MTD_HIP(hipMalloc((void**)&m.d_pos, 8));
         MTD_HIP(hipMalloc((void**)&m.d_err, 4));
         MTD_HIP(hipMalloc((void**)&m.d_nwin, 128));
@@ -210,6 +227,7 @@ MtDevProducer::MtDevProducer(int device, const MT19937Legacy& start, int64_t N, 
 MtDevProducer::~MtDevProducer() {
     if (!im_) return;
     Impl& m = *im_;
+    if (m.counted) g_live_producers.fetch_sub(1);
     hipSetDevice(m.device);
     for (hipStream_t s : {m.s_gen, m.s_tok, m.s_fin})
         if (s) {
@@ -281,7 +299,7 @@ int MtDevProducer::ensure_batch(int64_t b, hipStream_t consumer, int lookahead) 
     };
     // (site: 0 generator <- finisher, 1 tokenizer <- generator, 2 tokenizer <- finisher, 3 finisher <- tokenizer, 4 finisher <- consumer, 5 consumer <- finisher)
     auto gate_wait = [&](hipStream_t st, int gate, unsigned long long value, int site) {
-        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, st, (const unsigned long long*)(m.gates + gate), value, GATE_TIMEOUT_TICKS, m.d_err,
+        hipLaunchKernelGGL(k_gate_wait, dim3(1), dim3(64), 0, st, (const unsigned long long*)(m.gates + gate), value, gate_timeout_ticks(), m.d_err,
                            m.gates + G_STATS + 2 * site, m.status);
     };
     auto gate_signal = [&](hipStream_t st, int gate, unsigned long long value) {

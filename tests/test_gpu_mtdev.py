@@ -202,3 +202,33 @@ def test_sampler_default_rng_takes_the_device_producer():
         finally:
             os.environ.pop("EMX_TUNE", None)
     assert np.array_equal(chains[0], chains[1])
+
+
+def test_two_producers_in_one_process():
+    """Two contexts of one process, each with a device producer alive at the same time, their runs interleaved (the
+    stages of a producer order themselves through words that one-wave kernels spin on, and the runtime puts a process's streams onto
+    a few hardware queues -- with two producers a wait can sit in front of the kernel that would signal it).  The second producer of
+    a process therefore takes the event-ordered form; both give the host pipeline's chain and generator state."""
+    md = stretch_desc()
+    cfgs = [(16384, 5, "iso", 101), (8192, 64, "dense", 202)]
+    states = [np.random.RandomState(seed).get_state() for _, _, _, seed in cfgs]
+    ens = [make(N, D, md, st, device_plans=1, target=tg) for (N, D, tg, _), st in zip(cfgs, states)]
+    for _ in range(3):
+        for e in ens:
+            e.run(23, 1, False)
+    got = []
+    for e in ens:
+        assert e.status() == 0
+        assert e.mtdev_info()["steps"] == 69
+        x, lp = e.get_state()
+        got.append((x, lp, e.get_mt19937()))
+    for e in ens:
+        e.close()
+    for (N, D, tg, _), st, g in zip(cfgs, states, got):
+        h = make(N, D, md, st, device_plans=0, target=tg)
+        h.run(69, 1, False)
+        x, lp = h.get_state()
+        r = h.get_mt19937()
+        h.close()
+        assert np.array_equal(g[0], x) and np.array_equal(g[1], lp)
+        assert np.array_equal(g[2][1], r[1]) and g[2][2] == r[2]
