@@ -390,7 +390,8 @@ struct emx_ctx {
     int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
     int64_t tune_slab_skew = 1;          // 1: the second wave of every SIMD starts its first tile's row loads when its sibling's rows have arrived
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
-    int64_t tune_mt_device_min = 131072; // (measured: the host pipeline is faster below ~10^5 walkers, profiles/r04/mtdev_sizes.txt)
+    int64_t tune_mt_device_min = 147456; // (measured: the host pipeline is faster up to 131 072 walkers since round 5 -- 90-102 against 106 us/step there, 214
+                                         //  against 175 at 262 144 -- profiles/r05/mtdev_sizes_r05.txt; round 4: 131 072, profiles/r04/mtdev_sizes.txt)
     int64_t tune_mt_lookahead = 2;       // batches the device producer is asked to run ahead of the consumer (0 .. 2)
     int64_t tune_mt_tok_wshift = 11, tune_mt_tok_tail = 2048;      // the device tokenizer's window rule (emx_mtdev_kernels.hpp)
     int64_t mtdev_steps_total = 0, mtdev_starts = 0;

@@ -488,6 +488,22 @@ int pick_compaction() {
         }
     return g_compaction = best[1] < best[0] ? 1 : 0;
 }
+// randint(0, rng + 1) values by masked rejection, 16 stream words at a time (the acceptance test does not depend on the position:
+// plain order-preserving compaction); stops in front of the vector that could overshoot n.  Returns the words consumed.
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt"))) size_t randint_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, uint32_t rng,
+                                                                                      int32_t* dst, int64_t& k, int64_t n) {
+    const __m512i vmask = _mm512_set1_epi32((int)mask), vr = _mm512_set1_epi32((int)rng);
+    size_t used = 0;
+    while (navail - used >= 16 && k + 16 <= n) {
+        const __m512i v = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used)), vmask);
+        const __mmask16 acc = _mm512_cmple_epu32_mask(v, vr);
+        const int c = __builtin_popcount((unsigned)acc);
+        _mm512_mask_storeu_epi32(dst + k, (__mmask16)((1u << c) - 1u), _mm512_maskz_compress_epi32(acc, v));
+        k += c;
+        used += 16;
+    }
+    return used;
+}
 inline size_t shuffle_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i, int64_t lo, uint32_t* jr, int64_t nm1) {
     switch (g_compaction) {
         case 1: return shuffle_scan_avx512_t<1>(p, navail, mask, i, lo, jr, nm1);
@@ -566,6 +582,7 @@ struct Reader {
     uint64_t a_base = 0;          // absolute index of *base
     const std::atomic<bool>* stop;
     bool dead = false;
+    bool vec_ok = false;          // the AVX-512 scans may be used (MtPlanPipeline::Impl::vec_scan)
 
     uint64_t pos() const { return a_base + (uint64_t)(cur - base); }
 
@@ -760,7 +777,11 @@ struct Reader {
             const size_t av = avail();
             const uint32_t* p = cur;
             const uint32_t* pe = cur + av;
-            while (p < pe && k < n) {
+#ifdef EMX_HAVE_AVX512_GEN
+            if (vec_ok) p += randint_scan_avx512(p, av, mask, (uint32_t)rng, dst, k, n);
+#endif
+            int budget = 64;                  // (the tail, and the words between two refills; then the vector path is tried again)
+            while (p < pe && k < n && budget-- > 0) {
                 const uint32_t v = temper(*p++) & mask;
                 dst[k] = (int32_t)v;          // branch-free compaction: a rejected value is overwritten by the next
                 k += (v <= (uint32_t)rng);
@@ -1135,6 +1156,7 @@ void MtPlanPipeline::Impl::tokenizer_main() {
     rd.ws = &ws;
     rd.stop = &stop;
     rd.seek((uint64_t)start.pos);
+    rd.vec_ok = vec_scan;
     int has_gauss = start.has_gauss;
     double gauss = start.gauss;
     for (int64_t n = 0; n < nsteps; ++n) {

@@ -337,10 +337,10 @@ int emx_profile_read(emx_ctx* ctx, float* ms_out, int32_t* n_inout);
 int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int32_t* finisher_threads);
 
 /* Exact (MT19937) mode with the plans made ON THE DEVICE (csrc/emx_mtdev.hpp): one StretchMove, one replica, ensembles of
- * 131 072 walkers or more -- where the serial host stages of "same seed => same chain as the reference" (ensemble.py:166-167,406,
+ * 147 456 walkers or more (round 5; 131 072 before) -- where the serial host stages of "same seed => same chain as the reference" (ensemble.py:166-167,406,
  * moves/red_blue.py:76-80,100, moves/stretch.py:30-32) cost more than the kernels do.  MT19937 segments by jump-ahead, the rejection
  * tests of random.shuffle / randint and the Fisher-Yates swaps all run in kernels; no host thread touches a draw.  Tuning key
- * "mt_device": 0 = always the host pipeline, 1 (default) = from "mt_device_min_walkers" (131 072) on, 2 = from 8 192 walkers on
+ * "mt_device": 0 = always the host pipeline, 1 (default) = from "mt_device_min_walkers" (147 456) on, 2 = from 8 192 walkers on
  * (measured, MI355X, 64-dim dense Gaussian: 65 536 walkers 94 us/step against the host pipeline's 69; 262 144 x 32: 192 against 316;
  * 1 048 576: 602 against 1 347 -- profiles/r04/mtdev_sizes.txt).
  *   out[0] 1 when the current configuration takes this producer, [1] 1 while one is alive, [2] steps taken from producers so far,

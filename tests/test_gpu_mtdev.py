@@ -29,7 +29,7 @@ def make(N, D, md, state, device_plans=1, target="iso"):
     ens.set_state(np.random.RandomState(N + D).randn(N, D))
     ens.eval_state_log_prob()
     ens.set_rng_mode(_lib.RNG_MT19937)
-    ens.set_tuning("mt_device", 2 if device_plans else 0)          # 2: whatever the size (1, the default, starts at 131 072 walkers)
+    ens.set_tuning("mt_device", 2 if device_plans else 0)          # 2: whatever the size (1, the default, starts at 147 456 walkers)
     ens.set_mt19937(state)
     return ens
 
@@ -153,7 +153,7 @@ def test_device_plans_equal_the_host_twin(N, D, S, randomize, a, seed):
 @pytest.mark.parametrize("N,D,target,nsteps,store", [(8192, 64, "dense", 53, True), (16384, 5, "iso", 37, False), (65536, 64, "dense", 40, False),
                                                      (10000, 64, "dense", 21, True),
                                                      (8192, 4, "iso", 650, False),          # 82 batches: the stream ring wraps ~ 14 times
-                                                     (131072, 4, "iso", 90, False)])        # the default size rule's first size
+                                                     (131072, 4, "iso", 90, False)])        # (round 4: the default size rule's first size)
 def test_runs_equal_the_host_pipelines(N, D, target, nsteps, store):
     """emx_run (two calls: the producer carries over) with device-made plans against the same run with the host pipeline's:
     coordinates, log-probs, chain, accept counters and the final generator state, bit for bit"""
@@ -184,7 +184,7 @@ def test_runs_equal_the_host_pipelines(N, D, target, nsteps, store):
 
 def test_sampler_default_rng_takes_the_device_producer():
     """EnsembleSampler(rng="mt19937", the default) at 8192 walkers with EMX_TUNE mt_device=2 (the producer at any size; by default it
-    starts at 131 072 walkers, where it overtakes the host pipeline): same chain as with mt_device=0, producer used"""
+    starts at 147 456 walkers, where it overtakes the host pipeline): same chain as with mt_device=0, producer used"""
     import emcee_amd
     from emcee_amd import targets
     p0 = np.random.RandomState(3).randn(8192, 6)
