@@ -16,6 +16,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <sys/prctl.h>
+#include <unistd.h>
 #endif
 
 namespace emx {
@@ -1016,7 +1017,13 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     const std::vector<int> all_cores = distinct_cores(cs);
     const bool pin_gt = !pin_all && !pin_none && all_cores.size() >= 5;
     const std::vector<int> cores = pin_all ? all_cores : std::vector<int>();
-    const std::vector<int> gt = pin_gt ? std::vector<int>{all_cores[0], all_cores[1]} : std::vector<int>();
+    // (which two: rotated by the process id among the domain's cores but the caller's, so that two processes that share an L3
+    // domain -- ranks of one node -- rarely choose the same pair)
+    std::vector<int> gt;
+    if (pin_gt) {
+        const size_t n1 = all_cores.size() - 1, i0 = (size_t)getpid() % n1;
+        gt = {all_cores[i0], all_cores[(i0 + 1) % n1]};
+    }
     const CpuSet rest = pin_gt ? without_cores_of(cs, gt) : cs;
     m.gen = std::thread(generator_main, &m.ws, m.start.key);
     confine(m.gen, cs, pin_gt ? std::vector<int>{gt[0], gt[0], gt[0]} : cores, 0);
