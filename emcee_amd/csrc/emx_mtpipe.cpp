@@ -16,7 +16,6 @@
 #include <pthread.h>
 #include <sched.h>
 #include <sys/prctl.h>
-#include <unistd.h>
 #endif
 
 namespace emx {
@@ -140,28 +139,6 @@ std::vector<int> distinct_cores(const CpuSet& cs) {
     return reps;
 }
 
-// the set without the physical cores (every SMT sibling) of the given CPUs
-CpuSet without_cores_of(const CpuSet& cs, const std::vector<int>& cpus) {
-    CpuSet r = cs;
-    if (!cs.valid) return r;
-    for (int c : cpus) {
-        char path[128], buf[256];
-        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
-        CPU_CLR(c, &r.set);
-        if (FILE* f = fopen(path, "r")) {
-            const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
-            fclose(f);
-            buf[n] = 0;
-            cpu_set_t sib;
-            if (parse_cpu_list(buf, sib))
-                for (int k = 0; k < CPU_SETSIZE; ++k)
-                    if (CPU_ISSET(k, &sib)) CPU_CLR(k, &r.set);
-        }
-    }
-    r.valid = CPU_COUNT(&r.set) >= 2;
-    return r;
-}
-
 void confine(std::thread& t, const CpuSet& cs, const std::vector<int>& cores, int slot) {
     if (!cs.valid) return;
     if ((int)cores.size() >= 3 && slot >= 0) {
@@ -178,7 +155,6 @@ struct CpuSet {
 };
 CpuSet pipeline_cpus() { return CpuSet(); }
 std::vector<int> distinct_cores(const CpuSet&) { return {}; }
-CpuSet without_cores_of(const CpuSet& cs, const std::vector<int>&) { return cs; }
 void confine(std::thread&, const CpuSet&, const std::vector<int>&, int) {}
 #endif
 
@@ -1006,35 +982,14 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     // One physical core per thread is the fastest placement on an idle host (0.080 vs 0.100 ms/step at 65 536 walkers) and the
     // slowest when another tenant of the machine occupies one of the chosen cores (0.19 seen): opt-in (EMX_PIPE_CORE_PINNING=1);
     // by default the threads may move inside the L3 domain.
-    // Placement inside the L3 domain.  The generator and the tokenizer are the critical pair, and both run AVX-512 loops: when the
-    // scheduler puts either of them on the SMT sibling of another busy thread it halves -- the same code measured 45.8 us/step at
-    // 65 536 walkers in some sessions and 62-83 (generator 65-84) in others (profiles/r05/exact_c2.md).  Default since round 5
-    // ("gt"): those two get a physical core each (not the caller's), the finishers everything else of the domain but those cores'
-    // siblings.  EMX_PIPE_CORE_PINNING=1: one physical core per thread (fastest on an idle host, slowest when another tenant sits on
-    // a chosen core: 0.19 ms/step seen); =0: no placement beyond the L3 domain.
-    const char* pin = getenv("EMX_PIPE_CORE_PINNING");
-    const bool pin_all = pin && atoi(pin) == 1, pin_none = pin && atoi(pin) == 0 && pin[0] == '0';
-    const std::vector<int> all_cores = distinct_cores(cs);
-    const bool pin_gt = !pin_all && !pin_none && all_cores.size() >= 5;
-    const std::vector<int> cores = pin_all ? all_cores : std::vector<int>();
-    // (which two: rotated by the process id among the domain's cores but the caller's, so that two processes that share an L3
-    // domain -- ranks of one node -- rarely choose the same pair)
-    std::vector<int> gt;
-    if (pin_gt) {
-        const size_t n1 = all_cores.size() - 1, i0 = (size_t)getpid() % n1;
-        gt = {all_cores[i0], all_cores[(i0 + 1) % n1]};
-    }
-    const CpuSet rest = pin_gt ? without_cores_of(cs, gt) : cs;
+    const std::vector<int> cores = getenv("EMX_PIPE_CORE_PINNING") ? distinct_cores(cs) : std::vector<int>();
     m.gen = std::thread(generator_main, &m.ws, m.start.key);
-    confine(m.gen, cs, pin_gt ? std::vector<int>{gt[0], gt[0], gt[0]} : cores, 0);
+    confine(m.gen, cs, cores, 0);
     m.tok = std::thread([&m] { m.tokenizer_main(); });
-    confine(m.tok, cs, pin_gt ? std::vector<int>{gt[1], gt[1], gt[1]} : cores, pin_gt ? 0 : 1);
+    confine(m.tok, cs, cores, 1);
     for (int k = 0; k < K; ++k) {
         m.fin.emplace_back([&m, k] { m.finisher_main(k); });
-        if (pin_gt)
-            confine(m.fin.back(), rest, std::vector<int>(), -1);
-        else
-            confine(m.fin.back(), cs, cores, (int)cores.size() >= 3 + k ? 2 + k : -1);     // out of cores: anywhere in the L3 domain
+        confine(m.fin.back(), cs, cores, (int)cores.size() >= 3 + k ? 2 + k : -1);     // out of cores: anywhere in the L3 domain
     }
 }
 
