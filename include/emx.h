@@ -89,7 +89,13 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  * the single-role log-prob kernel even where the role-split one applies; parity tests),
  * "full_plan" (1: native plans carry every column; default 0: only the ones the fused kernel of the step's move reads),
  * "direct_timeout_ms" (device-side barriers of the direct and replay exchanges; the first barrier of an emx_run waits 6x longer),
- * "ablate" (timing experiments: bits 0-7 half-step phases, bits 8.. plan kernel), "phase_clock" (instrumented builds).
+ * "ablate" (timing experiments: bits 0-7 half-step phases, bits 8.. plan kernel), "phase_clock" (instrumented builds),
+ * round 5: "mt_device_finish" (1, default: a stretch step of the host pipeline goes up as `order` + the MT19937 state words of its
+ * uniforms, in the plan's own columns, and k_plan_raw tempers / converts / resolves partners / takes the logs on the device; 0: the
+ * finisher threads do), "persist_exact_mix" (1, default: exact mode takes the persistent kernels with move mixtures too),
+ * "slab_skew" (0 ... 4; 1 default: in the slab form of the fused dense half-step, padded ndim 112 / 128, the second wave of
+ * every SIMD starts its first tile's row loads when its sibling's have arrived), "mt_upload_split" (1: plans of >= 16 384 walkers
+ * go up in two halves on two streams; measured slower, default 0).
  * The environment variable EMX_TUNE="key=value,key=value" applies keys to every context at creation (A/B measurements through
  * unmodified callers).  After a barrier timeout (status bit 3) the context refuses further sharded half-steps until the peers are
  * attached again (emx_direct_export / _import or _attach on every rank). */
