@@ -223,7 +223,7 @@ def exact_mode_entry(wl, K, W, device):
             "note": "host_plan_ms = one step's plan made inline by ONE host thread (emx_host_plan_mt, no GPU) -- round 1's path; emx_run "
                     "takes its plans from the host pipeline (csrc/emx_mtpipe.cpp: generator thread twisting MT19937 STATE words into a cache-"
                     "resident ring, tokenizer thread deciding the rejections and copying the fixed-length draws out, finisher threads -- six where "
-                    "the L3 domain has room -- for the swaps and `order`); round 5: a stretch step's uniforms go up as those generator words, "
+                    "the L3 domain has room, five with device finish: one thread per core of an eight-core domain -- for the swaps and `order`); round 5: a stretch step's uniforms go up as those generator words, "
                     "in the plan's columns, one copy per step on an upload stream of its own, and k_plan_raw tempers / converts / resolves "
                     "partners / takes the logs on the consumer's stream (profiles/r05/exact_c2.md: 57.8 -> 45.8 us/step and the variants "
                     "dropped).  pipeline_stage_us_per_step says which stage bounds it on THIS host (the stages run concurrently: the largest "
