@@ -388,6 +388,7 @@ struct emx_ctx {
     int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
     int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
     int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
+    int64_t tune_wide_fuse = 1;          // 1: the wide dense path makes the stretch proposal inside its role-split log-prob kernel (no propose launch)
     int64_t tune_slab_skew = 1;          // 1: the second wave of every SIMD starts its first tile's row loads when its sibling's rows have arrived
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
     int64_t tune_mt_device_min = 147456; // (measured: the host pipeline is faster up to 131 072 walkers since round 5 -- 90-102 against 106 us/step there, 214
@@ -827,10 +828,18 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         const bool prof = prof_max > 0 && c->prof_n < prof_max;
         c->prof_max = 0;
         double* const declp = c->launch_declp;      // the commit kernel below writes the decisions, not the propose pass
-        c->launch_declp = nullptr;
-        int rc = launch_split(c, move, EMX_TARGET_HOST, S, split, pos0, ns, t_lo, t_hi, mv, ps, order, X, lp, nullptr, nullptr,
+        // Round 5: for the stretch move on ensembles that take the role-split log-prob kernel, the propose pass is made INSIDE it
+        // (WideLpArgs::fuse: the loader waves make the proposal on its way into LDS and store it to qout) -- one launch of memory-
+        // bound work less per half-step (65 536 x 512: 61.8 of 255 us).  Tuning "wide_fuse" = 0: the three launches.
+        const bool fuse = c->tune_wide_fuse != 0 && !callback && move == MOVE_STRETCH && !t_hi_dev && !sendbuf && c->world == 1 &&
+                          !order && wide_lp_takes_role_split(t_hi - t_lo, c->num_cu, c->Dp, c->tune_dense_wide == 2);
+        int rc = 0;
+        if (!fuse) {
+            c->launch_declp = nullptr;
+            rc = launch_split(c, move, EMX_TARGET_HOST, S, split, pos0, ns, t_lo, t_hi, mv, ps, order, X, lp, nullptr, nullptr,
                               nullptr, nullptr, t_hi_dev);
-        c->launch_declp = declp;
+            c->launch_declp = declp;
+        }
         c->prof_max = prof_max;
         if (rc) return rc;
         w.rows = c->qout;
@@ -838,6 +847,14 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         w.out = c->newlp;
         w.scatter = 0;
         w.check_bad = 1;
+        if (fuse) {
+            w.fuse = 1;
+            w.fX = X;
+            w.fq = c->qout;
+            w.fi = ps->order;
+            w.fa = ps->p0;
+            w.fz = ps->s0;
+        }
         WideCommitArgs k{};
         k.X = X;
         k.lp = lp;
@@ -847,7 +864,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         k.chain_lp = chain_lp;
         k.sendbuf = sendbuf;
         k.qout = c->qout;
-        k.fout = c->fout;
+        k.fout = fuse ? ps->fac + pos0 : c->fout;       // (the stretch move's factor is the plan's: (D - 1) ln z, stretch.py:31)
         k.newlp = c->newlp;
         k.order = order ? order : ps->order;
         k.logu = ps->logu;
@@ -1444,6 +1461,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "mt_device_finish")) {      // 0: the host pipeline's finisher threads convert every draw themselves (rounds 1-4)
         PIPE_STOP(c);
         c->tune_mt_device_finish = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "wide_fuse")) {
+        c->tune_wide_fuse = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "slab_skew")) {
