@@ -24,6 +24,7 @@
 
 #include <cstdint>
 
+#include "emx_planlog.hpp"
 #include "emx_rng.hpp"
 
 // build-time experiment switches (tools/ab_variants.sh builds variants, tools/ab_bench.sh alternates them on one
@@ -250,19 +251,21 @@ __host__ __device__ inline void native_slot(const NativeArgs& na, int N, int S, 
     uacc = u53(A.v[2], A.v[3]);
     if (MOVE == MOVE_EVAL) return;
     const Philox4 B = philox4x32_10((uint32_t)i, 1u, sl, sh, k0, k1);
-    const int ns_own = (N - split + S - 1) / S;
+    const SplitSizes sz = split_sizes(N, S);
+    const int ns_own = sz.of(split);
     const int64_t Nc = (int64_t)N - ns_own;
     if (MOVE == MOVE_STRETCH) {
         const double u = u53(A.v[0], A.v[1]);
         const double tt_ = (a - 1.0) * u + 1.0;
-        s0 = tt_ * tt_ / a;
+        double inva;
+        s0 = pow2_reciprocal(a, inva) ? tt_ * tt_ * inva : tt_ * tt_ / a;        // the same bits either way (emx_rng.hpp)
         const int64_t r = (int64_t)bounded64(B.v[0], B.v[1], (uint64_t)Nc);
         int j = 0, tt = 0;
         // inline comp_locate (host+device)
         int64_t rr = r;
         for (int s = 0; s < S; ++s) {
             if (s == split) continue;
-            const int n = (N - s + S - 1) / S;
+            const int n = sz.of(s);
             if (rr < n) { j = s; tt = (int)rr; break; }
             rr -= n;
         }
@@ -279,7 +282,7 @@ __host__ __device__ inline void native_slot(const NativeArgs& na, int N, int S, 
             int64_t x = rr[q];
             for (int s = 0; s < S; ++s) {
                 if (s == split) continue;
-                const int n = (N - s + S - 1) / S;
+                const int n = sz.of(s);
                 if (x < n) { pw[q] = (int)perm_inv((uint32_t)((int)x * S + s), na.pk); break; }
                 x -= n;
             }
@@ -300,7 +303,7 @@ __host__ __device__ inline void native_slot(const NativeArgs& na, int N, int S, 
         int q = 0;
         for (int s = 0; s < S && q < 3; ++s) {
             if (s == split) continue;
-            const int n = (N - s + S - 1) / S;
+            const int n = sz.of(s);
             const int tt = (int)bounded64(wa[q], wb[q], (uint64_t)n);
             w[q] = (int)perm_inv((uint32_t)(tt * S + s), na.pk);
             ++q;
@@ -1915,15 +1918,16 @@ template <int MOVE>
 __device__ __forceinline__ void small_plan_entry(const NativeArgs& na, int N, int D, int S, int pos, double a, double sigma,
                                                  double g0, int& i, int& a0, int& a1, int& a2, double& z, double& lu, double& fc) {
     int split = 0, t = pos;
+    const SplitSizes sz = split_sizes(N, S);
     for (int k = 0; k < S; ++k) {
-        const int n = (N - k + S - 1) / S;
+        const int n = sz.of(k);
         if (t < n) { split = k; break; }
         t -= n;
     }
     double u;
     native_slot<MOVE>(na, N, S, split, t, a, sigma, g0, i, a0, a1, a2, z, u);
-    lu = log(u);
-    fc = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
+    lu = plan_log_uniform(u);
+    fc = (MOVE == MOVE_STRETCH) ? ((double)D - 1.0) * plan_log(z) : 0.0;
 }
 
 // one group's (walker's) update inside a half-step: the general kernel's element-wise-target branch
@@ -2045,8 +2049,8 @@ static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A)
                 p1s[e] = hi[2 * N + pos];
                 p2s[e] = hi[3 * N + pos];
                 s0s[e] = z;
-                logus[e] = log(u);
-                facs[e] = (kind == MOVE_STRETCH) ? ((double)D - 1.0) * log(z) : 0.0;
+                logus[e] = plan_log(u);
+                facs[e] = (kind == MOVE_STRETCH) ? ((double)D - 1.0) * plan_log(z) : 0.0;
                 continue;
             }
             NativeArgs na;
@@ -2059,7 +2063,7 @@ static __global__ __launch_bounds__(1024) void k_small_run(const SmallRunArgs A)
             if (MOVESEL == MOVE_GAUSS || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_GAUSS)) {
                 double u;
                 native_gauss_slot(na, D, A.gmode[m], A.step_col ? A.step_col[sb + b] : 0, pos, i, a0, a1, a2, z, u);
-                lu = log(u);
+                lu = plan_log_uniform(u);
             } else
             if (MOVESEL == MOVE_STRETCH || (MOVESEL == SMALL_ANY_MOVE && kind == MOVE_STRETCH))
                 small_plan_entry<MOVE_STRETCH>(na, N, D, S, pos, A.a[m], A.sigma[m], A.g0[m], i, a0, a1, a2, z, lu, fc);
@@ -2230,8 +2234,8 @@ static __global__ void k_plan_logs(int N, int D, int stretch, const double* __re
                             double* __restrict__ logu, double* __restrict__ fac) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= N) return;
-    logu[pos] = log(uacc[pos]);
-    fac[pos] = stretch ? ((double)D - 1.0) * log(s0[pos]) : 0.0;
+    logu[pos] = plan_log(uacc[pos]);
+    fac[pos] = stretch ? ((double)D - 1.0) * plan_log(s0[pos]) : 0.0;
 }
 
 // The plans of up to sixteen steps fetched in ONE launch straight from the pipeline's pinned staging buffers (exact mode with the
@@ -2285,8 +2289,8 @@ static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, i
         dp[N + pos] = hp[N + pos];
     }
     double* dl = reinterpret_cast<double*>(A.dev[b] + N * 32);
-    dl[pos] = log(u);
-    dl[N + pos] = A.stretch[b] ? ((double)A.D - 1.0) * log(z) : 0.0;
+    dl[pos] = plan_log(u);
+    dl[N + pos] = A.stretch[b] ? ((double)A.D - 1.0) * plan_log(z) : 0.0;
 }
 
 // Device finish of an exact-mode stretch plan (round 5; csrc/emx_mtpipe.hpp, PipeStepInfo::raw).  The host pipeline hands over what
@@ -2334,8 +2338,8 @@ static __global__ __launch_bounds__(256) void k_plan_raw(const PlanRawArgs A) {
     di[N + pos] = r < base ? di[r] : di[r + ns];                // stretch.py:27: c = the other sets' members in plan order
     dd[pos] = zz;
     dd[N + pos] = ua;
-    dl[pos] = log(ua);
-    dl[N + pos] = ((double)A.D - 1.0) * log(zz);
+    dl[pos] = plan_log(ua);
+    dl[N + pos] = ((double)A.D - 1.0) * plan_log(zz);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2368,7 +2372,7 @@ static __global__ __launch_bounds__(256) void k_accept(const AcceptArgs A) {
     const double lp_old = A.lp[i];
     if (nlp != nlp) raise_status(A.status, ST_NAN_LOGP);
     const double lnpdiff = A.fout[t] + nlp - lp_old;
-    const bool accept = lnpdiff > log(uacc);
+    const bool accept = lnpdiff > plan_log(uacc);
     const double* q = A.qout + (size_t)t * A.D;
     double* xr = A.X + (size_t)i * A.D;
     if (accept)
@@ -2468,8 +2472,9 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
     if (pos >= B.N || (B.ablate & 4)) return;
     const int N = B.N, S = B.S[b];
     int split = 0, t = pos;
+    const SplitSizes sz = split_sizes(N, S);
     for (int s = 0; s < S; ++s) {
-        const int n = (N - s + S - 1) / S;
+        const int n = sz.of(s);
         if (t < n) { split = s; break; }
         t -= n;
     }
@@ -2538,8 +2543,8 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
     if (full || mv == MOVE_SNOOKER) B.p2[b][pos] = a2;
     if (full || mv != MOVE_SNOOKER) B.s0[b][pos] = z;
     if (full) B.uacc[b][pos] = u;
-    B.logu[b][pos] = log(u);
-    B.fac[b][pos] = (mv == MOVE_STRETCH) ? ((double)B.D - 1.0) * log(z) : 0.0;
+    B.logu[b][pos] = plan_log_uniform(u);
+    B.fac[b][pos] = (mv == MOVE_STRETCH) ? ((double)B.D - 1.0) * plan_log(z) : 0.0;
 }
 
 static __global__ void k_graph_set(GraphCounters* ctr, unsigned long long step_base, long long stored_base) {

@@ -9,6 +9,7 @@
 #include <cstdint>
 
 #include "emx_mtjump.hpp"      // MT_N
+#include "emx_planlog.hpp"
 
 namespace emx {
 namespace mtdev {
@@ -943,13 +944,13 @@ static __global__ __launch_bounds__(FIN_T) void k_fin_plan(const FinArgs A) {
         const double tt = (a - 1.0) * u + 1.0;
         const double zz = tt * tt / a;
         A.s0[b][t] = zz;
-        A.fac[b][t] = dm1 * log(zz);
+        A.fac[b][t] = dm1 * plan_log(zz);
     }
     {
         const uint32_t w0 = A.stream[(pu + 2ull * tl) & A.smask], w1 = A.stream[(pu + 2ull * tl + 1ull) & A.smask];
         const double u = ((double)(int)(w0 >> 5) * 67108864.0 + (double)(int)(w1 >> 6)) / 9007199254740992.0;
         A.uacc[b][t] = u;
-        A.logu[b][t] = log(u);
+        A.logu[b][t] = plan_log(u);
     }
 }
 

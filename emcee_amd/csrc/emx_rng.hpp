@@ -27,6 +27,16 @@ EMX_HD void mul_hilo32(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
     lo = (uint32_t)r;
 }
 
+// a ^ b ^ c: one v_bitop3_b32 on the device (the compiler leaves two v_xor_b32 when one operand is a scalar: 40 of a stretch
+// plan entry's ~470 vector instructions)
+EMX_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 struct Philox4 {
     uint32_t v[4];
 };
@@ -42,9 +52,9 @@ EMX_HD Philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
         uint32_t hi0, lo0, hi1, lo1;
         mul_hilo32(M0, c0, hi0, lo0);
         mul_hilo32(M1, c2, hi1, lo1);
-        c0 = hi1 ^ c1 ^ k0;
+        c0 = xor3(hi1, c1, k0);
         c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
+        c2 = xor3(hi0, c3, k1);
         c3 = lo0;
         k0 += W0;
         k1 += W1;
@@ -66,8 +76,57 @@ EMX_HD double u53(uint32_t a, uint32_t b) {
     return (double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+// x / a for a power of two a is x * (1 / a) in every bit (both are the one rounding of the same real number); the reciprocal
+// comes from the exponent field -- integer work on a launch-uniform value, scalar on the device -- and replaces the ~25
+// instructions of an f64 division per plan entry (StretchMove's default a = 2).  False: a is not a power of two whose
+// reciprocal is normal.
+EMX_HD bool pow2_reciprocal(double a, double& inv) {
+    uint64_t b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = (uint64_t)__double_as_longlong(a);
+#else
+    __builtin_memcpy(&b, &a, 8);
+#endif
+    const uint64_t e = b >> 52;                         // sign included: a negative a fails the range test
+    if ((b & 0x000fffffffffffffull) != 0 || e < 1 || e > 2045) return false;
+    const uint64_t ib = (2046 - e) << 52;
+#if defined(__HIP_DEVICE_COMPILE__)
+    inv = __longlong_as_double((long long)ib);
+#else
+    __builtin_memcpy(&inv, &ib, 8);
+#endif
+    return true;
+}
+
+// Sizes of the S sub-ensembles of N walkers, `arange(N) % S` (red_blue.py:78): set s has (N - s + S - 1) / S = N / S + (s < N % S)
+// members.  One division per plan entry instead of one per set looked at (the device has no scalar divide: each is ~25
+// instructions through the vector unit and back).
+struct SplitSizes {
+    int q, r;
+    EMX_HD int of(int s) const { return q + (s < r ? 1 : 0); }
+};
+
+EMX_HD SplitSizes split_sizes(int N, int S) {
+    SplitSizes z;
+    if (S == 2) {
+        z.q = N >> 1;
+        z.r = N & 1;
+    } else {
+        z.q = N / S;
+        z.r = N - z.q * S;
+    }
+    return z;
+}
+
 // Unbiased-enough bounded integer in [0, n): 64-bit multiply-high (bias < n / 2^64).
 EMX_HD uint64_t bounded64(uint32_t a, uint32_t b, uint64_t n) {
+    // every caller's n is a walker count (< 2^32; emx_create refuses more than 2^31 walkers): the high 64 bits of the 64 x 64
+    // product are then (a n + ((b n) >> 32)) >> 32 -- no overflow: a n + 2^32 - 1 <= 2^64 - 2^32 -- two wide multiplies
+    // instead of the four of a general 64 x 64 multiply-high
+    if ((n >> 32) == 0) {
+        const uint64_t n32 = n;
+        return ((uint64_t)a * n32 + (((uint64_t)b * n32) >> 32)) >> 32;
+    }
     const uint64_t r = ((uint64_t)a << 32) | (uint64_t)b;
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umul64hi(r, n);
@@ -108,15 +167,32 @@ EMX_HD uint32_t unxorshift(uint32_t y, uint32_t s, uint32_t bits) {
     return x;
 }
 
-EMX_HD uint32_t perm_unmix(uint32_t x, const PermKey& k) {
-    x = unxorshift(x, k.s1, k.bits);
-    x = ((x - k.c3) * k.m3inv) & k.mask;
-    x = unxorshift(x, k.s2, k.bits);
-    x = ((x - k.c2) * k.m2inv) & k.mask;
-    x = unxorshift(x, k.s1, k.bits);
-    x = ((x - k.c1) * k.m1inv) & k.mask;
+// the low 32 bits of a product whose low k <= 24 bits are all that is kept: v_mul_u32_u24 (full rate; it reads the low 24 bits
+// of each operand, which decide the low 24 of the product) in place of the quarter-rate v_mul_lo_u32
+template <bool SMALL>
+EMX_HD uint32_t mul_kept_bits(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SMALL) return __umul24(a, b);
+#endif
+    return a * b;
+}
+
+// make_perm_key's shifts are s1 = ceil(bits / 2) and s2 = ceil(bits / 3), so unxorshift's loop has at most one resp. two trips
+// and a value below 2^bits shifted by 2 s1 (3 s2) is zero: the closed forms below are the loop, without the loop -- as a loop
+// with a launch-uniform, unknown trip count each of the six inversions of a plan entry cost ~40 scalar instructions (a
+// division for the unroller's trip count among them) around its two vector ones.
+template <bool SMALL>
+EMX_HD uint32_t perm_unmix_t(uint32_t x, const PermKey& k) {
+    x ^= x >> k.s1;                                                   // == unxorshift(x, k.s1, k.bits)
+    x = mul_kept_bits<SMALL>(x - k.c3, k.m3inv) & k.mask;
+    x = x ^ (x >> k.s2) ^ (x >> (2u * k.s2));                         // == unxorshift(x, k.s2, k.bits)   (2 s2 <= 22)
+    x = mul_kept_bits<SMALL>(x - k.c2, k.m2inv) & k.mask;
+    x ^= x >> k.s1;
+    x = mul_kept_bits<SMALL>(x - k.c1, k.m1inv) & k.mask;
     return x;
 }
+
+EMX_HD uint32_t perm_unmix(uint32_t x, const PermKey& k) { return perm_unmix_t<false>(x, k); }
 
 EMX_HD uint32_t perm_fwd(uint32_t w, const PermKey& k) {
     uint32_t x = perm_mix(w, k);
@@ -125,8 +201,13 @@ EMX_HD uint32_t perm_fwd(uint32_t w, const PermKey& k) {
 }
 
 EMX_HD uint32_t perm_inv(uint32_t p, const PermKey& k) {
-    uint32_t x = perm_unmix(p, k);
-    while (x >= k.n) x = perm_unmix(x, k);
+    if (k.bits <= 24) {                                   // uniform: ensembles of up to 2^24 walkers
+        uint32_t x = perm_unmix_t<true>(p, k);
+        while (x >= k.n) x = perm_unmix_t<true>(x, k);
+        return x;
+    }
+    uint32_t x = perm_unmix_t<false>(p, k);
+    while (x >= k.n) x = perm_unmix_t<false>(x, k);
     return x;
 }
 

@@ -3,7 +3,7 @@
 import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (rocprofv3 runs it from /tmp)
 import bench  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -35,7 +35,7 @@ def main():
     names = list(meta)
     dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
     for name, d in zip(names, dem):
-        d = re.sub(r"\(.*", "", d).replace("emx::", "")
+        d = re.sub(r"\(.*", "", d.replace("(anonymous namespace)::", "")).replace("emx::", "")
         if not filt.search(d):
             continue
         m = re.search(r"^%s:[^\n]*\n(.*?)s_endpgm" % re.escape(name), text, re.S | re.M)
