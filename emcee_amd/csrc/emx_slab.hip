@@ -40,11 +40,41 @@ static __global__ __launch_bounds__(512) void k_halfstep_slab(const HalfStepArgs
     double* muS = smem + dense_img_doubles(Dp);
     double* tile = muS + Dp + (size_t)wib * (16 * SLAB_RT + 32);
     double* facS = tile + 16 * SLAB_RT;
-    {   // the image of the target (emx_set_target): once per workgroup
+    // Skewed start (A.ablate bit 8, tuning "slab_skew"): with one tile per wave -- 65 536 walkers on 256 CUs -- every wave of the chip
+    // loads, then every wave multiplies: the HBM phase (2 KB of rows per update at ndim 128) and the MFMA phase (144 f64 MFMAs per
+    // tile) run back to back chip-wide.  The second wave of every SIMD (wib >= 4) therefore issues its first tile's row loads only
+    // when its sibling's rows have arrived (a word in the sibling's LDS region), so one wave's MFMA chain covers the other's loads.
+    const bool skew_on = (A.ablate & 256) != 0 && blockDim.x == 512;
+    {   // The image of the target (emx_set_target), once per workgroup.  Its loads are all in flight before the first is written
+        // to LDS: as `for (e ...) dst[e] = img[e]` the compiler made a load - wait - store loop, TEN dependent L2 round trips in
+        // front of every half-step's first row load (rounds 4 and 5 until this).  With the skewed start the second waves -- which
+        // have nothing else to do until their siblings' rows are back -- stage all of it (19 double2 a lane, registers no row
+        // occupies yet); the first waves go straight to their plan entries and rows.
         constexpr int IMG2 = (dense_img_doubles(Dp) + Dp) / 2;
+        constexpr int NB = (IMG2 + 255) / 256;
         const double2* img = reinterpret_cast<const double2*>(A.tp1);
         double2* dst = reinterpret_cast<double2*>(smem);
-        for (int e = threadIdx.x; e < IMG2; e += blockDim.x) dst[e] = img[e];
+        if (skew_on) {
+            if (wib >= 4) {
+                const int tx = (int)threadIdx.x - 256;
+                double2 stg[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) stg[j] = img[min(tx + j * 256, IMG2 - 1)];
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (tx + j * 256 < IMG2) dst[tx + j * 256] = stg[j];
+            }
+        } else {
+            constexpr int NG = 10;                      // any block size, no skew: ten loads in flight per round
+            for (int base = threadIdx.x; base < IMG2; base += NG * blockDim.x) {
+                double2 stg[NG];
+#pragma unroll
+                for (int j = 0; j < NG; ++j) stg[j] = img[min(base + j * (int)blockDim.x, IMG2 - 1)];
+#pragma unroll
+                for (int j = 0; j < NG; ++j)            // straight-line: beyond the end the last element is rewritten with itself
+                    dst[min(base + j * (int)blockDim.x, IMG2 - 1)] = stg[j];
+            }
+        }
     }
     // (mu is read from its LDS image slab by slab -- muS[j] = mu[j], zero beyond ndim, exactly what load_row gives: sixteen VGPRs
     // the DE instantiations need, round 5: 72-104 B of scratch before)
@@ -52,11 +82,6 @@ static __global__ __launch_bounds__(512) void k_halfstep_slab(const HalfStepArgs
     const int nslot = A.t_hi - A.t_lo;                 // (t_lo == 0: lean_kind)
     const int ntile = (nslot + 15) / 16;
     const int myrow = (lane >> 4) + 4 * (lane & 3);    // decision lanes: (lane & 15) < 4 decide tile row myrow
-    // Skewed start (A.ablate bit 8, tuning "slab_skew"): with one tile per wave -- 65 536 walkers on 256 CUs -- every wave of the chip
-    // loads, then every wave multiplies: the HBM phase (2 KB of rows per update at ndim 128) and the MFMA phase (144 f64 MFMAs per
-    // tile) run back to back chip-wide.  The second wave of every SIMD (wib >= 4) therefore issues its first tile's row loads only
-    // when its sibling's rows have arrived (a word in the sibling's LDS region), so one wave's MFMA chain covers the other's loads.
-    const bool skew_on = (A.ablate & 256) != 0 && blockDim.x == 512;
     int* sigw = reinterpret_cast<int*>(muS + Dp + (size_t)(wib & 3) * (16 * SLAB_RT + 32) + 16 * SLAB_RT + 16);     // (facS uses 16 of the 32 spare doubles)
     if (skew_on && wib < 4 && lane == 0) *sigw = wave < ntile ? 0 : 1;      // a wave without a tile never holds its sibling
     bool staged = false;
