@@ -446,6 +446,29 @@ __attribute__((target("avx512f,avx512vl,avx512bw,avx2,popcnt"))) size_t shuffle_
             used += 64;
         }
     }
+    // The same idea one vector per trip for the narrower bands (ensembles of a few thousand walkers never reach the loop above):
+    // thresholds from the i of the trip before -- a word > i' is rejected, a word <= i' - 32 accepted (i' - 16 <= i at the start of
+    // this trip, at most 15 accepted in front of a word inside it), one word in between is decided in place, two leave the loop.
+    if (mask >= (1u << 9)) {
+        int64_t stale = i;
+        while (navail - used >= 16 && i - 16 > lo) {
+            const __m512i hi = _mm512_set1_epi32((int)(uint32_t)stale), lo32 = _mm512_set1_epi32((int)(uint32_t)(stale - 32));
+            stale = i;
+            const __m512i v = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used)), vmask);
+            __mmask16 acc = _mm512_cmple_epu32_mask(v, lo32);
+            const __mmask16 rej = _mm512_cmpgt_epu32_mask(v, hi);
+            if ((__mmask16)(acc | rej) != (__mmask16)0xffff) {
+                const unsigned un = (unsigned)(__mmask16)~(acc | rej);
+                if (un & (un - 1u)) break;
+                alignas(64) uint32_t lanes[16];
+                _mm512_store_si512(lanes, v);
+                const int l = __builtin_ctz(un);
+                if ((int64_t)lanes[l] <= i - __builtin_popcount((unsigned)acc & ((1u << l) - 1u))) acc = (__mmask16)((unsigned)acc | (1u << l));
+            }
+            i -= (int64_t)compact_store<MODE>(jr + (nm1 - i), acc, v);
+            used += 16;
+        }
+    }
     while (navail - used >= 16 && i - 16 > lo) {
         const __m512i v = _mm512_and_si512(temper_v(_mm512_loadu_si512(p + used)), vmask);
         __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(uint32_t)(i - 16)));
@@ -501,6 +524,75 @@ __attribute__((target("avx512f,avx512vl,avx512bw,popcnt"))) size_t randint_scan_
         _mm512_mask_storeu_epi32(dst + k, (__mmask16)((1u << c) - 1u), _mm512_maskz_compress_epi32(acc, v));
         k += c;
         used += 16;
+    }
+    return used;
+}
+// legacy_gauss candidates (RandomState.randn, de.py:56): x1 = 2 double - 1, x2 = 2 double - 1, r2 = x1 x1 + x2 x2, kept when
+// 0 < r2 < 1 -- four stream words a candidate whatever its fate, so four candidates a vector and an order-preserving compaction.
+// An accepted candidate gives two normals, f x2 first and the cached f x1 behind it (f = sqrt(-2 ln r2 / r2), made by the
+// finishers): the tokens (x2, x1) go to gx[t], gx[t + 1], r2 to both gr2.  Every operation is the scalar loop's, rounded alike
+// (products and sum separately; 2 d - 1 is exact either way).  Stops in front of the vector that could pass n entries.
+__attribute__((target("avx512f,avx512vl,avx512bw,avx512dq,popcnt"))) size_t polar_scan_avx512(const uint32_t* p, size_t navail, double* gx, double* gr2,
+                                                                                             int64_t& t, int64_t n) {
+    const __m512i lo32 = _mm512_set1_epi64(0xffffffffll);
+    const __m512d sc = _mm512_set1_pd(0x1p-52), one = _mm512_set1_pd(1.0), zero = _mm512_setzero_pd();
+    size_t used = 0;
+    while (navail - used >= 16 && t + 8 <= n) {
+        const __m512i q = temper_v(_mm512_loadu_si512(p + used));              // qword k = word 2 k | word 2 k + 1 << 32: one double
+        const __m512i a = _mm512_srli_epi64(_mm512_and_si512(q, lo32), 5), b = _mm512_srli_epi64(q, 38);
+        const __m512d d = _mm512_cvtepi64_pd(_mm512_or_si512(_mm512_slli_epi64(a, 26), b));      // (a 2^26 + b) < 2^53: exact
+        const __m512d x = _mm512_sub_pd(_mm512_mul_pd(d, sc), one);            // lanes (x1, x2) of candidate 0, 1, 2, 3
+        const __m512d sq = _mm512_mul_pd(x, x);
+        const __m512d r2 = _mm512_add_pd(sq, _mm512_permute_pd(sq, 0x55));     // both lanes of a pair: x1 x1 + x2 x2
+        const __mmask8 m = (__mmask8)(_mm512_cmp_pd_mask(r2, one, _CMP_LT_OQ) & _mm512_cmp_pd_mask(r2, zero, _CMP_NEQ_OQ));
+        _mm512_storeu_pd(gx + t, _mm512_maskz_compress_pd(m, _mm512_permute_pd(x, 0x55)));      // (x2, x1); t + 8 <= n: room for all
+        _mm512_storeu_pd(gr2 + t, _mm512_maskz_compress_pd(m, r2));
+        t += __builtin_popcount((unsigned)m);
+        used += 16;
+    }
+    return used;
+}
+// The snooker move's draws (de_snooker.py:37-40), per walker: randint(n0), randint(n1), randint(n2), then shuffle(w) =
+// random_interval(2), random_interval(1): five masked-rejection draws whose ranges come round in a fixed order.  A window of 16
+// tempered words and one acceptance mask per range; a walker's draws are the first set bits of the masks taken in turn, each
+// behind the one before.  Walkers are taken from a window while it lasts; one whose draws do not fit a fresh window is left to
+// the scalar loop.  r / m: the three ranges (n - 1) and their masks.
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt,bmi"))) size_t snooker_scan_avx512(const uint32_t* p, size_t navail, const uint32_t* r, const uint32_t* m,
+                                                                                         int32_t* p0, int32_t* p1, int32_t* p2, uint8_t* perm, int64_t& t,
+                                                                                         int64_t n) {
+    const __m512i m0 = _mm512_set1_epi32((int)m[0]), m1 = _mm512_set1_epi32((int)m[1]), m2 = _mm512_set1_epi32((int)m[2]), m3 = _mm512_set1_epi32(3);
+    const __m512i r0 = _mm512_set1_epi32((int)r[0]), r1 = _mm512_set1_epi32((int)r[1]), r2 = _mm512_set1_epi32((int)r[2]), r3 = _mm512_set1_epi32(2);
+    alignas(64) uint32_t tw[16];
+    size_t used = 0;
+    while (t < n && navail - used >= 16) {
+        const __m512i v = temper_v(_mm512_loadu_si512(p + used));
+        _mm512_store_si512(tw, v);
+        const unsigned A0 = _mm512_cmple_epu32_mask(_mm512_and_si512(v, m0), r0), A1 = _mm512_cmple_epu32_mask(_mm512_and_si512(v, m1), r1);
+        const unsigned A2 = _mm512_cmple_epu32_mask(_mm512_and_si512(v, m2), r2), A3 = _mm512_cmple_epu32_mask(_mm512_and_si512(v, m3), r3);
+        unsigned o = 0;                           // words of the window already consumed
+        while (t < n) {
+            unsigned a = A0 & (~0u << o);
+            if (!a) break;
+            const unsigned i0 = (unsigned)__builtin_ctz(a);
+            a = A1 & (~0u << (i0 + 1));
+            if (!a) break;
+            const unsigned i1 = (unsigned)__builtin_ctz(a);
+            a = A2 & (~0u << (i1 + 1));
+            if (!a) break;
+            const unsigned i2 = (unsigned)__builtin_ctz(a);
+            a = A3 & (~0u << (i2 + 1));
+            if (!a) break;
+            const unsigned i3 = (unsigned)__builtin_ctz(a), i4 = i3 + 1;      // random_interval(1): mask 1 rejects nothing
+            if (i4 >= 16) break;
+            p0[t] = (int32_t)(tw[i0] & m[0]);
+            p1[t] = (int32_t)(tw[i1] & m[1]);
+            p2[t] = (int32_t)(tw[i2] & m[2]);
+            perm[t] = (uint8_t)((tw[i3] & 3u) | ((tw[i4] & 1u) << 2));
+            ++t;
+            o = i4 + 1;
+        }
+        if (o == 0) break;                        // not even one walker fits this window
+        used += o;
     }
     return used;
 }
@@ -583,6 +675,7 @@ struct Reader {
     const std::atomic<bool>* stop;
     bool dead = false;
     bool vec_ok = false;          // the AVX-512 scans may be used (MtPlanPipeline::Impl::vec_scan)
+    bool vec_dq = false;          // ... and the one that needs AVX-512 DQ (polar_scan_avx512: 64-bit integer -> double)
 
     uint64_t pos() const { return a_base + (uint64_t)(cur - base); }
 
@@ -824,6 +917,66 @@ struct Reader {
         }
         (void)vec;
     }
+    // n consecutive randn() draws of the legacy polar method as tokens (RawStep::gx / gr2): the cached second normal of an earlier
+    // call first, then pairs from accepted candidates; a last odd draw leaves its pair's second normal cached
+    void fill_polar(double* gx, double* gr2, int64_t n, int& has_gauss, double& gauss) {
+        int64_t t = 0;
+        if (has_gauss && n > 0) {
+            gx[0] = gauss;
+            gr2[0] = -1.0;
+            has_gauss = 0;
+            gauss = 0.0;
+            t = 1;
+        }
+        while (t < n && !dead) {
+#ifdef EMX_HAVE_AVX512_GEN
+            if (vec_dq && t + 8 <= n) {
+                const size_t av = avail();
+                cur += polar_scan_avx512(cur, av, gx, gr2, t, n);
+                if (t >= n) break;                       // (an even count met exactly: nothing is cached)
+            }
+#endif
+            // one accepted candidate the scalar way: the words between two refills, and the end of the draws
+            double x1, x2, r2;
+            do {
+                x1 = 2.0 * next_double() - 1.0;
+                x2 = 2.0 * next_double() - 1.0;
+                r2 = x1 * x1 + x2 * x2;
+            } while ((r2 >= 1.0 || r2 == 0.0) && !dead);
+            gx[t] = x2;                                  // this call returns f * x2 ...
+            gr2[t] = r2;
+            ++t;
+            if (t < n) {                                 // ... and the next one the cached f * x1
+                gx[t] = x1;
+                gr2[t] = r2;
+                ++t;
+            } else {
+                const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+                gauss = f * x1;
+                has_gauss = 1;
+            }
+        }
+    }
+    // the snooker move's five draws per walker, n walkers (ranges r[k] = n_k - 1 <= 2^32 - 2 with masks m[k]; perm = j2 | j1 << 2)
+    void fill_snooker(int32_t* p0, int32_t* p1, int32_t* p2, uint8_t* perm, int64_t n, const uint32_t* r, const uint32_t* m) {
+        int64_t t = 0;
+        while (t < n && !dead) {
+#ifdef EMX_HAVE_AVX512_GEN
+            if (vec_ok) {
+                const size_t av = avail();
+                cur += snooker_scan_avx512(cur, av, r, m, p0, p1, p2, perm, t, n);
+                if (t >= n) break;
+            }
+#endif
+            p0[t] = (int32_t)masked32(r[0], m[0]);
+            p1[t] = (int32_t)masked32(r[1], m[1]);
+            p2[t] = (int32_t)masked32(r[2], m[2]);
+            const uint32_t j2 = masked32(2u, 3u);                                              // random_interval(2)
+            const uint32_t j1 = next32() & 1u;                                                 // random_interval(1): the mask rejects nothing
+            perm[t] = (uint8_t)(j2 | (j1 << 2));
+            ++t;
+        }
+    }
     // n state words, verbatim (fixed-length draws are tempered and converted by the finishers -- or by the consumer's kernel)
     void copy_words(uint32_t* dst, int64_t n) {
         int64_t k = 0;
@@ -835,6 +988,10 @@ struct Reader {
         }
     }
 };
+
+// de.py:49: a DE step's pair codes are drawn from [0, pop), pop = nc (nc - 1); below 2^32 they are 32-bit draws and travel in the
+// sink's p0 column from the tokenizer to the finisher
+inline bool de_codes_fit_32(uint64_t pop) { return pop - 1 != 0 && pop - 1 < 0xffffffffull; }
 
 // randint(0, bound) draws exactly one word per value when bound is a power of two (the mask rejects nothing)
 inline bool pow2_bound(uint64_t bound) { return bound >= 2 && bound <= 0x80000000ull && (bound & (bound - 1)) == 0; }
@@ -1086,42 +1243,15 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
                 rd.fill_randint32(sk.p0 + base, ns, (uint64_t)nc);
         } else if (mv.kind == EMX_MOVE_DE) {
             const uint64_t pop = (uint64_t)nc * (uint64_t)(nc - 1);
-            if (pop - 1 != 0 && pop - 1 < 0xffffffffull) {                                         // de.py:49 (the mask made once)
-                const uint32_t rng = (uint32_t)(pop - 1), msk = (uint32_t)Reader::mask_of(pop - 1);
-                for (int64_t t = 0; t < ns; ++t) raw.k64[base + t] = rd.masked32(rng, msk);
+            if (de_codes_fit_32(pop)) {
+                // de.py:49: the pair codes are randint(0, pop) draws, 32-bit here: they wait in the sink's p0 column (which the
+                // finisher overwrites with the partners they decode to), made 16 words at a time
+                rd.fill_randint32(sk.p0 + base, ns, pop);
             } else {
                 for (int64_t t = 0; t < ns; ++t) raw.k64[base + t] = rd.randint(pop);
             }
             // de.py:56 randn(ns, 1): legacy polar method, the second value of a pair is cached for the next call
-            int64_t t = 0;
-            while (t < ns && !rd.dead) {
-                if (has_gauss) {
-                    raw.gx[base + t] = gauss;
-                    raw.gr2[base + t] = -1.0;
-                    has_gauss = 0;
-                    gauss = 0.0;
-                    ++t;
-                    continue;
-                }
-                double x1, x2, r2;
-                do {
-                    x1 = 2.0 * rd.next_double() - 1.0;
-                    x2 = 2.0 * rd.next_double() - 1.0;
-                    r2 = x1 * x1 + x2 * x2;
-                } while ((r2 >= 1.0 || r2 == 0.0) && !rd.dead);
-                raw.gx[base + t] = x2;                       // this call returns f * x2 ...
-                raw.gr2[base + t] = r2;
-                ++t;
-                if (t < ns) {                                // ... and the next one the cached f * x1
-                    raw.gx[base + t] = x1;
-                    raw.gr2[base + t] = r2;
-                    ++t;
-                } else {
-                    const double f = std::sqrt(-2.0 * std::log(r2) / r2);
-                    gauss = f * x1;
-                    has_gauss = 1;
-                }
-            }
+            rd.fill_polar(raw.gx.data() + base, raw.gr2.data() + base, ns, has_gauss, gauss);
         } else {   // snooker: de_snooker.py:37-40 per walker
             int cs[3], q = 0;
             for (int s = 0; s < S && q < 3; ++s)
@@ -1130,16 +1260,9 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
                                     (uint64_t)(info.off[cs[2] + 1] - info.off[cs[2]])};
             const bool small = nj[0] >= 2 && nj[1] >= 2 && nj[2] >= 2 && nj[0] < 0xffffffffull && nj[1] < 0xffffffffull && nj[2] < 0xffffffffull;
             if (small) {                                                                          // (the masks made once per split)
-                const uint32_t r0 = (uint32_t)(nj[0] - 1), r1 = (uint32_t)(nj[1] - 1), r2 = (uint32_t)(nj[2] - 1);
-                const uint32_t m0 = (uint32_t)Reader::mask_of(r0), m1 = (uint32_t)Reader::mask_of(r1), m2 = (uint32_t)Reader::mask_of(r2);
-                for (int64_t t = 0; t < ns && !rd.dead; ++t) {
-                    sk.p0[base + t] = (int32_t)rd.masked32(r0, m0);
-                    sk.p1[base + t] = (int32_t)rd.masked32(r1, m1);
-                    sk.p2[base + t] = (int32_t)rd.masked32(r2, m2);
-                    const uint32_t j2 = rd.masked32(2u, 3u);                                       // random_interval(2)
-                    const uint32_t j1 = rd.next32() & 1u;                                          // random_interval(1): the mask rejects nothing
-                    raw.perm[base + t] = (uint8_t)(j2 | (j1 << 2));
-                }
+                const uint32_t rr[3] = {(uint32_t)(nj[0] - 1), (uint32_t)(nj[1] - 1), (uint32_t)(nj[2] - 1)};
+                const uint32_t mm[3] = {(uint32_t)Reader::mask_of(rr[0]), (uint32_t)Reader::mask_of(rr[1]), (uint32_t)Reader::mask_of(rr[2])};
+                rd.fill_snooker(sk.p0 + base, sk.p1 + base, sk.p2 + base, raw.perm.data() + base, ns, rr, mm);
             } else {
                 for (int64_t t = 0; t < ns && !rd.dead; ++t) {
                     sk.p0[base + t] = (int32_t)rd.randint(nj[0]);
@@ -1163,6 +1286,7 @@ void MtPlanPipeline::Impl::tokenizer_main() {
     rd.stop = &stop;
     rd.seek((uint64_t)start.pos);
     rd.vec_ok = vec_scan;
+    rd.vec_dq = vec_scan && __builtin_cpu_supports("avx512dq");
     int has_gauss = start.has_gauss;
     double gauss = start.gauss;
     for (int64_t n = 0; n < nsteps; ++n) {
@@ -1246,17 +1370,22 @@ void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) 
                 for (int64_t t = 0; t < ns; ++t) sk.p1[base + t] = sk.p2[base + t] = order[base + t];
             for (int64_t t = 0; t < ns; ++t) sk.p0[base + t] = comp((uint32_t)sk.p0[base + t]);
         } else if (mv.kind == EMX_MOVE_DE) {
+            const bool k32 = de_codes_fit_32((uint64_t)nc * (uint64_t)(nc - 1));
+            double last_r2 = -1.0, last_fac = 0.0;                 // the two normals of a polar pair share r2, hence the factor
             for (int64_t t = 0; t < ns; ++t) {
                 uint64_t f, s;
-                de_pair(raw.k64[base + t], (uint64_t)nc, f, s);
+                de_pair(k32 ? (uint64_t)(uint32_t)sk.p0[base + t] : raw.k64[base + t], (uint64_t)nc, f, s);
                 sk.p0[base + t] = comp(f);
                 sk.p1[base + t] = comp(s);
                 sk.p2[base + t] = order[base + t];
                 const double r2 = raw.gr2[base + t];
                 double g = raw.gx[base + t];
                 if (r2 >= 0.0) {
-                    const double fac = std::sqrt(-2.0 * std::log(r2) / r2);
-                    g = fac * g;
+                    if (r2 != last_r2) {
+                        last_fac = std::sqrt(-2.0 * std::log(r2) / r2);
+                        last_r2 = r2;
+                    }
+                    g = last_fac * g;
                 }
                 sk.s0[base + t] = mv.g0 * (1.0 + mv.sigma * g);
             }

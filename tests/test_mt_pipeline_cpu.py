@@ -60,6 +60,13 @@ CASES = [
     ("snooker_odd", 131, 3, [md("snooker", S=5)], None, 6, 300, False),
     ("mixture", 300, 5, [md("stretch"), md("de"), md("snooker")], [0.5, 0.3, 0.2], 24, 5, True),
     ("tiny", 4, 1, [md("stretch")], None, 40, None, False),
+    # sizes at which the tokenizer's 16-word scans of the DE and snooker draws run (pair codes, polar candidates, the snooker move's
+    # five draws a walker), with and without rejection in the ranges, odd set sizes, a cached normal across steps
+    ("de_4096", 4096, 4, [md("de")], None, 7, None, False),
+    ("de_5003_three_sets", 5003, 4, [md("de", S=3)], None, 7, 611, True),
+    ("snooker_4096", 4096, 4, [md("snooker")], None, 7, None, False),
+    ("snooker_5003_five_sets", 5003, 3, [md("snooker", S=5)], None, 6, 77, False),
+    ("mixture_3000", 3000, 5, [md("stretch"), md("de"), md("snooker")], [0.3, 0.4, 0.3], 30, 5, True),
 ]
 
 
