@@ -553,37 +553,63 @@ __attribute__((target("avx512f,avx512vl,avx512bw,avx512dq,popcnt"))) size_t pola
     return used;
 }
 // The snooker move's draws (de_snooker.py:37-40), per walker: randint(n0), randint(n1), randint(n2), then shuffle(w) =
-// random_interval(2), random_interval(1): five masked-rejection draws whose ranges come round in a fixed order.  A window of 16
-// tempered words and one acceptance mask per range; a walker's draws are the first set bits of the masks taken in turn, each
-// behind the one before.  Walkers are taken from a window while it lasts; one whose draws do not fit a fresh window is left to
-// the scalar loop.  r / m: the three ranges (n - 1) and their masks.
+// random_interval(2), random_interval(1): five masked-rejection draws whose ranges come round in a fixed order.  A window of 64
+// tempered words and one 64-bit acceptance mask per range; a walker's draws are the first set bits of the masks taken in turn, each
+// behind the one before (a dozen walkers a window: the vector work -- tempering, sixteen compares -- is shared among them, the rest
+// is five shift / and / count-trailing-zeros steps a walker).  A walker whose draws do not end inside the window starts the next
+// one; one that does not fit a fresh window is left to the scalar loop.  r / m: the three ranges (n - 1) and their masks.
 __attribute__((target("avx512f,avx512vl,avx512bw,popcnt,bmi"))) size_t snooker_scan_avx512(const uint32_t* p, size_t navail, const uint32_t* r, const uint32_t* m,
                                                                                          int32_t* p0, int32_t* p1, int32_t* p2, uint8_t* perm, int64_t& t,
                                                                                          int64_t n) {
     const __m512i m0 = _mm512_set1_epi32((int)m[0]), m1 = _mm512_set1_epi32((int)m[1]), m2 = _mm512_set1_epi32((int)m[2]), m3 = _mm512_set1_epi32(3);
     const __m512i r0 = _mm512_set1_epi32((int)r[0]), r1 = _mm512_set1_epi32((int)r[1]), r2 = _mm512_set1_epi32((int)r[2]), r3 = _mm512_set1_epi32(2);
-    alignas(64) uint32_t tw[16];
+    alignas(64) uint32_t tw[64];
+    const bool pow2 = r[0] == m[0] && r[1] == m[1] && r[2] == m[2];      // set sizes that are powers of two: their masks reject nothing
     size_t used = 0;
-    while (t < n && navail - used >= 16) {
-        const __m512i v = temper_v(_mm512_loadu_si512(p + used));
-        _mm512_store_si512(tw, v);
-        const unsigned A0 = _mm512_cmple_epu32_mask(_mm512_and_si512(v, m0), r0), A1 = _mm512_cmple_epu32_mask(_mm512_and_si512(v, m1), r1);
-        const unsigned A2 = _mm512_cmple_epu32_mask(_mm512_and_si512(v, m2), r2), A3 = _mm512_cmple_epu32_mask(_mm512_and_si512(v, m3), r3);
-        unsigned o = 0;                           // words of the window already consumed
-        while (t < n) {
-            unsigned a = A0 & (~0u << o);
+    while (t < n && navail - used >= 64) {
+        uint64_t A0 = 0, A1 = 0, A2 = 0, A3 = 0;
+        for (int q = 0; q < 4; ++q) {
+            const __m512i v = temper_v(_mm512_loadu_si512(p + used + 16 * q));
+            _mm512_store_si512(tw + 16 * q, v);
+            A0 |= (uint64_t)_mm512_cmple_epu32_mask(_mm512_and_si512(v, m0), r0) << (16 * q);
+            A1 |= (uint64_t)_mm512_cmple_epu32_mask(_mm512_and_si512(v, m1), r1) << (16 * q);
+            A2 |= (uint64_t)_mm512_cmple_epu32_mask(_mm512_and_si512(v, m2), r2) << (16 * q);
+            A3 |= (uint64_t)_mm512_cmple_epu32_mask(_mm512_and_si512(v, m3), r3) << (16 * q);
+        }
+        unsigned o = 0;                           // words of the window already consumed (a walker needs five at least)
+        if (pow2) {
+            // nothing but random_interval(2) rejects: a walker's first three words are its partners, one dependent
+            // shift - count - add per walker instead of four
+            while (t < n && o <= 59) {
+                const uint64_t a = A3 >> (o + 3);
+                if (!a) break;
+                const unsigned i3 = o + 3 + (unsigned)__builtin_ctzll(a), i4 = i3 + 1;
+                if (i4 > 63) break;
+                p0[t] = (int32_t)(tw[o] & m[0]);
+                p1[t] = (int32_t)(tw[o + 1] & m[1]);
+                p2[t] = (int32_t)(tw[o + 2] & m[2]);
+                perm[t] = (uint8_t)((tw[i3] & 3u) | ((tw[i4] & 1u) << 2));
+                ++t;
+                o = i4 + 1;
+            }
+        }
+        while (!pow2 && t < n && o <= 59) {
+            uint64_t a = A0 & (~0ull << o);
             if (!a) break;
-            const unsigned i0 = (unsigned)__builtin_ctz(a);
-            a = A1 & (~0u << (i0 + 1));
+            const unsigned i0 = (unsigned)__builtin_ctzll(a);
+            if (i0 > 59) break;
+            a = A1 & (~0ull << (i0 + 1));
             if (!a) break;
-            const unsigned i1 = (unsigned)__builtin_ctz(a);
-            a = A2 & (~0u << (i1 + 1));
+            const unsigned i1 = (unsigned)__builtin_ctzll(a);
+            if (i1 > 60) break;
+            a = A2 & (~0ull << (i1 + 1));
             if (!a) break;
-            const unsigned i2 = (unsigned)__builtin_ctz(a);
-            a = A3 & (~0u << (i2 + 1));
+            const unsigned i2 = (unsigned)__builtin_ctzll(a);
+            if (i2 > 61) break;
+            a = A3 & (~0ull << (i2 + 1));
             if (!a) break;
-            const unsigned i3 = (unsigned)__builtin_ctz(a), i4 = i3 + 1;      // random_interval(1): mask 1 rejects nothing
-            if (i4 >= 16) break;
+            const unsigned i3 = (unsigned)__builtin_ctzll(a), i4 = i3 + 1;    // random_interval(1): mask 1 rejects nothing
+            if (i4 > 63) break;
             p0[t] = (int32_t)(tw[i0] & m[0]);
             p1[t] = (int32_t)(tw[i1] & m[1]);
             p2[t] = (int32_t)(tw[i2] & m[2]);
@@ -595,6 +621,40 @@ __attribute__((target("avx512f,avx512vl,avx512bw,popcnt,bmi"))) size_t snooker_s
         used += o;
     }
     return used;
+}
+// The DE move's pair codes decoded eight at a time (de.py:44-52, de_pair in emx_mtpipe.hpp): code k of [0, nc (nc - 1)) is the k-th
+// ordered pair of distinct complement members -- k < T = nc (nc - 1) / 2: (i, j) with j < i the kk-th pair of the lower triangle, else
+// (j, i) for kk = k - T -- and the two members go through the complement's order (stretch.py:27 comp).  i is the one integer with
+// i (i - 1) / 2 <= kk < (i + 1) i / 2: a square root and one correction either way find it, the inequality is checked, and a vector
+// with a lane that fails it (none seen) is left to the scalar decoder -- so the result is de_pair's whatever the root's rounding.
+// codes32: the codes in p0's own slots (32-bit draws); else codes64.  Returns the entries done (a multiple of 8).
+__attribute__((target("avx512f,avx512vl,avx512bw,avx512dq"))) int64_t de_decode_avx512(const uint64_t* codes64, bool codes32, int64_t n, uint64_t nc, int64_t base,
+                                                                                     int64_t ns, const int32_t* order, int32_t* p0, int32_t* p1) {
+    const __m512i T = _mm512_set1_epi64((long long)(nc * (nc - 1) / 2)), one = _mm512_set1_epi64(1);
+    const __m512i vbase = _mm512_set1_epi64((long long)base), vns = _mm512_set1_epi64((long long)ns);
+    const __m512d d1 = _mm512_set1_pd(1.0), d8 = _mm512_set1_pd(8.0), dh = _mm512_set1_pd(0.5);
+#define EMX_TRI(i_) _mm512_srli_epi64(_mm512_mullo_epi64((i_), _mm512_sub_epi64((i_), one)), 1)      /* i (i - 1) / 2 */
+    int64_t t = 0;
+    for (; t + 8 <= n; t += 8) {
+        const __m512i k = codes32 ? _mm512_cvtepu32_epi64(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p0 + t))) : _mm512_loadu_si512(codes64 + t);
+        const __mmask8 lower = _mm512_cmplt_epu64_mask(k, T);
+        const __m512i kk = _mm512_mask_sub_epi64(k, (__mmask8)~lower, k, T);
+        const __m512d x = _mm512_mul_pd(_mm512_add_pd(d1, _mm512_sqrt_pd(_mm512_add_pd(d1, _mm512_mul_pd(d8, _mm512_cvtepu64_pd(kk))))), dh);
+        __m512i i = _mm512_cvttpd_epu64(x);
+        i = _mm512_mask_sub_epi64(i, _mm512_cmpgt_epu64_mask(EMX_TRI(i), kk), i, one);
+        const __m512i up = _mm512_add_epi64(i, one);
+        i = _mm512_mask_mov_epi64(i, _mm512_cmple_epu64_mask(EMX_TRI(up), kk), up);
+        const __m512i lo = EMX_TRI(i);
+        if ((__mmask8)(_mm512_cmple_epu64_mask(lo, kk) & _mm512_cmpgt_epu64_mask(EMX_TRI(_mm512_add_epi64(i, one)), kk)) != (__mmask8)0xff) break;
+        const __m512i j = _mm512_sub_epi64(kk, lo);
+        const __m512i f = _mm512_mask_blend_epi64(lower, j, i), sd = _mm512_mask_blend_epi64(lower, i, j);
+        const __m512i fi = _mm512_mask_add_epi64(f, _mm512_cmpge_epu64_mask(f, vbase), f, vns);
+        const __m512i si = _mm512_mask_add_epi64(sd, _mm512_cmpge_epu64_mask(sd, vbase), sd, vns);
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(p0 + t), _mm512_i64gather_epi32(fi, order, 4));
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(p1 + t), _mm512_i64gather_epi32(si, order, 4));
+    }
+    return t;
+#undef EMX_TRI
 }
 inline size_t shuffle_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i, int64_t lo, uint32_t* jr, int64_t nm1) {
     switch (g_compaction) {
@@ -1033,7 +1093,7 @@ struct MtPlanPipeline::Impl {
     bool joined = false;
     uint64_t t_start = 0, tok_done_ns = 0;
     std::atomic<uint64_t> tok_wait_sink_ns{0}, tok_busy_ns{0};                 // read by stage_times() while the threads run
-    bool vec_scan = false, stats = false, fill_unused = false, device_finish = false;
+    bool vec_scan = false, vec_dq = false, stats = false, fill_unused = false, device_finish = false;
     uint64_t tok_shuffle_ns = 0;
     std::atomic<int64_t> tok_steps{0};             // steps tokenised so far
     std::vector<uint64_t> fin_wait_ns;
@@ -1134,6 +1194,7 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
     for (int s = 0; s < nsinks; ++s) m.sink_ready[s].v.store(-1);
 #ifdef EMX_HAVE_AVX512_GEN
     m.vec_scan = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx2") && !getenv("EMX_PIPE_NO_AVX512");
+    m.vec_dq = m.vec_scan && __builtin_cpu_supports("avx512dq");
     if (m.vec_scan) pick_compaction();
 #endif
     m.stats = getenv("EMX_PIPE_STATS") != nullptr;
@@ -1286,7 +1347,7 @@ void MtPlanPipeline::Impl::tokenizer_main() {
     rd.stop = &stop;
     rd.seek((uint64_t)start.pos);
     rd.vec_ok = vec_scan;
-    rd.vec_dq = vec_scan && __builtin_cpu_supports("avx512dq");
+    rd.vec_dq = vec_dq;
     int has_gauss = start.has_gauss;
     double gauss = start.gauss;
     for (int64_t n = 0; n < nsteps; ++n) {
@@ -1371,12 +1432,19 @@ void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) 
             for (int64_t t = 0; t < ns; ++t) sk.p0[base + t] = comp((uint32_t)sk.p0[base + t]);
         } else if (mv.kind == EMX_MOVE_DE) {
             const bool k32 = de_codes_fit_32((uint64_t)nc * (uint64_t)(nc - 1));
-            double last_r2 = -1.0, last_fac = 0.0;                 // the two normals of a polar pair share r2, hence the factor
-            for (int64_t t = 0; t < ns; ++t) {
+            int64_t t0 = 0;
+#ifdef EMX_HAVE_AVX512_GEN
+            if (vec_dq && nc < (1ll << 31))
+                t0 = de_decode_avx512(raw.k64.data() + base, k32, ns, (uint64_t)nc, base, ns, order, sk.p0 + base, sk.p1 + base);
+#endif
+            for (int64_t t = t0; t < ns; ++t) {
                 uint64_t f, s;
                 de_pair(k32 ? (uint64_t)(uint32_t)sk.p0[base + t] : raw.k64[base + t], (uint64_t)nc, f, s);
                 sk.p0[base + t] = comp(f);
                 sk.p1[base + t] = comp(s);
+            }
+            double last_r2 = -1.0, last_fac = 0.0;                 // the two normals of a polar pair share r2, hence the factor
+            for (int64_t t = 0; t < ns; ++t) {
                 sk.p2[base + t] = order[base + t];
                 const double r2 = raw.gr2[base + t];
                 double g = raw.gx[base + t];

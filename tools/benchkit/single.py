@@ -282,17 +282,22 @@ def exact_mode_mid_entry(K, W, device):
         out["%dx64" % N] = e
     # round 5: a move MIXTURE in exact mode (the reference's recommended usage, docs/tutorials/moves.ipynb) on the persistent kernels --
     # the next step's move is read off the pipeline's plan before it is taken; DE + snooker share launches (k_persist_mix)
-    wl = Workload("c4", 1024)
-    e = {}
-    for name, tune in (("persistent", {"persist_exact_mix": 1}), ("upload_per_step", {"persist_exact_mix": 0})):
-        res = measure_single(wl, Kx, max(W, 10), device=device, rng="mt19937", spin_s=0.05, want_kernel=False, tuning=tune)
-        e[name] = {"ms_per_step": res["wall_s"] * 1e3 / Kx, "blocks_timed": res["blocks"], "device_status": res["status"],
-                   "accept_frac": res["accept_frac"], "pipeline_stage_us_per_step": res.get("pipeline")}
-    e["speedup"] = e["upload_per_step"]["ms_per_step"] / e["persistent"]["ms_per_step"]
-    out["mix_de0.8_snooker0.2_1024x64"] = e
+    for N in (1024, 4096):
+        wl = Workload("c4", N)
+        e = {}
+        for name, rng, tune in (("persistent", "mt19937", {"persist_exact_mix": 1}), ("upload_per_step", "mt19937", {"persist_exact_mix": 0}),
+                                ("philox_same_shape", "philox", {})):
+            res = measure_single(wl, Kx, max(W, 10), device=device, rng=rng, spin_s=0.05, want_kernel=False, tuning=tune)
+            e[name] = {"ms_per_step": res["wall_s"] * 1e3 / Kx, "blocks_timed": res["blocks"], "device_status": res["status"],
+                       "accept_frac": res["accept_frac"]}
+            if rng == "mt19937":
+                e[name]["pipeline_stage_us_per_step"] = res.get("pipeline")
+        e["speedup"] = e["upload_per_step"]["ms_per_step"] / e["persistent"]["ms_per_step"]
+        out["mix_de0.8_snooker0.2_%dx64" % N] = e
     out["note"] = ("profiles/r04/exact_mid.txt: what stood in the way (per-step uploads, sleeping stage threads, a shared hardware queue, "
-                   "lazily resolved events); from 4 096 walkers on the pipeline's generator thread is the bound; mixtures: profiles/r05/exact_mix_probe.txt "
-                   "(the tokenizer's scalar DE / snooker draws bound them from ~4 096 walkers on)")
+                   "lazily resolved events); mixtures: profiles/r05/exact_mix_probe.txt -- the tokenizer makes the DE move's pair codes and "
+                   "polar candidates and the snooker move's draws 16 stream words at a time (round 5: 4 096 x 64 DE + snooker 29.8 -> 16.5 "
+                   "us/step); what is left there is the consumer (compare philox_same_shape)")
     return out
 
 
