@@ -379,6 +379,7 @@ struct emx_ctx {
     int64_t tune_persist_local = 1;      // 0: never the one-XCD form of the persistent kernel
     int64_t tune_persist_exact_max = 32768;   // exact mode: largest ensemble that takes the device-wide persistent kernel
     int64_t tune_persist_exact_steps = 16;    // exact mode: steps per persistent launch (<= 16)
+    int64_t tune_fetch_avoid = 1;             // k_plan_fetch keeps off the XCD a one-XCD persistent launch lives on
     int64_t tune_fetch_delay_us = 0;     // tests: k_plan_fetch idles this long before it reads
     int64_t tune_persist_span = 1;       // 0: a persistent launch ends with the batch of Philox plans it started in
     int64_t tune_persist_mix = 1;        // 0: a mixture's steps never share a launch (one run of one move per launch)
@@ -1498,6 +1499,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_persist_exact_steps = std::max<int64_t>(1, std::min<int64_t>(v, 16));
         return 0;
     }
+    if (!strcmp(key, "fetch_avoid")) {             // k_plan_fetch's workgroups decline on the XCD of a one-XCD persistent launch
+        c->tune_fetch_avoid = v ? 1 : 0;
+        return 0;
+    }
     if (!strcmp(key, "test_fetch_delay_us")) {     // tests: k_plan_fetch idles first (its consumers must wait for it)
         c->tune_fetch_delay_us = std::max<int64_t>(0, std::min<int64_t>(v, 100000));
         return 0;
@@ -2394,6 +2399,7 @@ static int pipe_fetch_deferred(emx_ctx* c) {
     }
     F.delay_ticks = (unsigned)(c->tune_fetch_delay_us * 100);
     F.arrived = c->pipe_arrived;
+    F.avoid_xcc = (c->persist_bar && c->tune_fetch_avoid) ? c->persist_bar + 9 * 32 + 4 : nullptr;
     F.host_done = c->pipe_done;
     F.done_value = (unsigned long long)(c->pipe_deferred.back().first + 1);
     hipLaunchKernelGGL(k_plan_fetch, dim3((unsigned)((c->N + 255) / 256), (unsigned)F.n), dim3(256), 0, c->up_stream, F);

@@ -1361,8 +1361,8 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
         if ((v0 >> 32) != 0ull) {
             ok = 0;                                                 // an earlier launch gave up: not even counted
         } else {
+            unsigned xcc = 0;
             if constexpr (LOCAL) {
-                unsigned xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                 __hip_atomic_fetch_or(go + 2, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the mark is in before this workgroup counts as arrived
@@ -1384,6 +1384,8 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
                     o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (open && o2 == k * 8 - 1) {
+                    // where a one-XCD launch lives (XCC_ID + 1; 0: everywhere), for k_plan_fetch, which keeps off that XCD
+                    __hip_atomic_store(go + 4, LOCAL ? (xcc & 15u) + 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(go + 3, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // this launch will run to its end
                     if (P.started_host) __hip_atomic_store(P.started_host, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __hip_atomic_store(go, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2247,28 +2249,66 @@ struct PlanFetchArgs {
     int32_t stretch[16];      // fac = (D-1) ln zz
     int32_t peers[16];        // the [p1|p2] columns are part of the plan
     int32_t N, D, n;
-    unsigned* arrived;        // device: workgroups of this launch that are done (the last one resets it)
+    unsigned* arrived;        // device: [0] workgroups of this launch that are done, [1] tickets handed out (the last one resets both)
+    const unsigned* avoid_xcc;        // device word: XCC_ID + 1 of the XCD a one-XCD persistent launch lives on (0: none), or null
     unsigned long long* host_done;    // pinned host word: steps fetched so far, written by the LAST workgroup (an event query
     unsigned delay_ticks;             // (tests: the kernel idles this long first -- 100 MHz ticks -- to show that its consumer waits for it)
     unsigned long long done_value;    // shows the completion tens of us late: the staging buffers go back to the producers on this word)
 };
 static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, int b, int pos);
+// The work -- gridDim.x * gridDim.y pieces of 256 entries -- is handed out by TICKET (A.arrived[1]), not by blockIdx, so that a
+// workgroup may decline: one that finds itself on the XCD a one-XCD persistent launch lives on (A.avoid_xcc, written by that
+// launch's handshake) leaves at once.  This kernel runs on the upload stream while the consumer's launches start and end, and a
+// persistent workgroup takes every vector register of its CU (k_persist_mix: 8 waves x 249): a CU that holds as much as one wave
+// of this kernel -- waiting 2 us and more for pinned memory -- cannot take it, and the launch's first barrier waits for the whole
+// fetch (measured: 4 096 walkers, DE + snooker, persistent launches 209 us each against 178 with Philox plans).  The last
+// workgroup to arrive does whatever tickets are left (none, unless every other one declined) before it tells the host.
 static __global__ __launch_bounds__(256) void k_plan_fetch(const PlanFetchArgs A) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned tk_s;
+    const unsigned total = gridDim.x * gridDim.y;
     if (A.delay_ticks) {
         const unsigned long long t0 = wall_clock64();
         while (wall_clock64() - t0 < A.delay_ticks) __builtin_amdgcn_s_sleep(8);
     }
-    if (pos < A.N) plan_fetch_rows(A, blockIdx.y, pos);
-    // every load of this workgroup has returned (its values were stored): count it; the last one tells the host
+    bool decline = false;
+    if (A.avoid_xcc && total >= 16u) {                          // uniform
+        const unsigned want = __hip_atomic_load(A.avoid_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        decline = want != 0u && (xcc & 15u) + 1u == want;
+    }
+    bool last = false;
+    for (;;) {
+        if (!decline) {
+            for (;;) {
+                if (threadIdx.x == 0) tk_s = atomicAdd(A.arrived + 1, 1u);
+                __syncthreads();
+                const unsigned tk = tk_s;
+                __syncthreads();
+                if (tk >= total) break;
+                const int pos = (int)(tk % gridDim.x) * (int)blockDim.x + (int)threadIdx.x;
+                if (pos < A.N) plan_fetch_rows(A, (int)(tk / gridDim.x), pos);
+            }
+        }
+        if (last) break;
+        // every load of this workgroup has returned (its values were stored): count it; the last one tells the host
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            tk_s = atomicAdd(A.arrived, 1u) == total - 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        last = tk_s != 0u;
+        __syncthreads();
+        if (!last) return;
+        decline = false;                                        // the last arriver sweeps up (normally: no ticket left)
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        const unsigned total = gridDim.x * gridDim.y;
-        if (atomicAdd(A.arrived, 1u) == total - 1u) {
-            *A.arrived = 0u;
-            __hip_atomic_store(A.host_done, A.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        A.arrived[0] = 0u;
+        A.arrived[1] = 0u;
+        __hip_atomic_store(A.host_done, A.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, int b, int pos) {
