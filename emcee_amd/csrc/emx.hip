@@ -2446,10 +2446,12 @@ static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int for
         B.Sprev0 = c->moves[philox_move_choice(c->ph_seed, first_step - 1, c->cdf.data(), nm)].nsplits;
         B.pkprev0 = make_perm_key((uint64_t)c->N, c->ph_seed, first_step - 1);
     }
+    bool only_stretch = true;
     for (int b = 0; b < nb; ++b) {
         const uint64_t step = first_step + (uint64_t)b;
         const int mi = forced_move >= 0 ? forced_move : philox_move_choice(c->ph_seed, step, c->cdf.data(), nm);
         const emx_move_desc& m = c->moves[mi];
+        only_stretch = only_stretch && m.kind == EMX_MOVE_STRETCH;
         emx_ctx::PlanSlot* ps;
         int rc = acquire_slot(c, &ps, false);
         if (rc) return rc;
@@ -2486,7 +2488,10 @@ static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int for
         B.move[b] = m.kind;
         B.S[b] = m.nsplits;
     }
-    hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), (unsigned)nb), dim3(256), 0, st, B);
+    if (only_stretch && B.lean && !B.deps && !B.ablate && !B.desc)       // (the same arithmetic without the other moves' branches: 32 VGPRs against 80)
+        hipLaunchKernelGGL(k_native_plan_batch_stretch, dim3((unsigned)((c->N + 255) / 256), (unsigned)nb), dim3(256), 0, st, B);
+    else
+        hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), (unsigned)nb), dim3(256), 0, st, B);
     HIPOK(c, hipGetLastError());
     return 0;
 }

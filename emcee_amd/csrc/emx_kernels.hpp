@@ -2506,10 +2506,11 @@ struct NativeBatchArgs {
     const StepDesc* desc;   // graph replay: per-step NativeArgs from device memory instead of nat[]
 };
 
-static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs B) {
+template <bool ONLY_STRETCH>
+static __device__ __forceinline__ void native_plan_batch_body(const NativeBatchArgs& B) {
     const int b = blockIdx.y;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= B.N || (B.ablate & 4)) return;
+    if (pos >= B.N || (!ONLY_STRETCH && (B.ablate & 4))) return;
     const int N = B.N, S = B.S[b];
     int split = 0, t = pos;
     const SplitSizes sz = split_sizes(N, S);
@@ -2520,8 +2521,8 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
     }
     int i, a0, a1, a2, dep_j = -1, dep_tt = -1;
     double z, u;
-    const int mv = B.move[b];
-    const NativeArgs nat = B.desc ? B.desc[b].nat : B.nat[b];
+    const int mv = ONLY_STRETCH ? MOVE_STRETCH : B.move[b];
+    const NativeArgs nat = (!ONLY_STRETCH && B.desc) ? B.desc[b].nat : B.nat[b];      // (graph replay: descriptors in device memory)
     if (mv == MOVE_GAUSS)
         native_gauss_slot(nat, B.D, B.gmode[b], B.gcol[b], pos, i, a0, a1, a2, z, u);
     else if (mv == MOVE_STRETCH)
@@ -2537,12 +2538,12 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
     // split-phase and sharded paths) gets a full plan.  (Streaming stores for these columns -- written once, read once -- were
     // measured: the half-step then fetches its plan entries from HBM instead of the Infinity Cache, C2 23.61 -> 24.19 us/step,
     // C3 stored 57.5 -> 61.5; profiles/r03/ab_nt_plan_stores.txt.)
-    const bool full = !B.lean;
-    if (B.ablate & 2) {                                  // timing experiments: keep the arithmetic alive, write one word
+    const bool full = ONLY_STRETCH ? false : !B.lean;      // (the stretch-only form: lean plans without dependency columns, no timing switches)
+    if (!ONLY_STRETCH && (B.ablate & 2)) {                                  // timing experiments: keep the arithmetic alive, write one word
         if (i + a0 + a1 + a2 == -12345 && z + u == 1.2345e-300) B.order[b][pos] = i;
         return;
     }
-    if (B.ablate & 1) {
+    if (!ONLY_STRETCH && (B.ablate & 1)) {
         B.order[b][pos] = i;
         B.p0[b][pos] = a0;
         B.s0[b][pos] = z;
@@ -2552,7 +2553,7 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
     }
     B.order[b][pos] = i;
     B.p0[b][pos] = a0;
-    if (!full && B.deps && mv == MOVE_STRETCH) {
+    if (!ONLY_STRETCH && !full && B.deps && mv == MOVE_STRETCH) {
         // k_persist_p2p: which tile's word of the half-step BEFORE this one decides about the partner's row (p1) and about this
         // walker's own row (p2) -- the slot (tile = slot >> 4, row = slot & 15) the walker had in that half-step's update set, or
         // -1 when it was not in it.  Split k > 0: the half-step before is split k - 1 of this step -- the partner is member
@@ -2586,6 +2587,15 @@ static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBa
     B.logu[b][pos] = plan_log_uniform(u);
     B.fac[b][pos] = (mv == MOVE_STRETCH) ? ((double)B.D - 1.0) * plan_log(z) : 0.0;
 }
+
+static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs B) { native_plan_batch_body<false>(B); }
+
+// The same plans for a batch of lean stretch steps alone, without the other moves' branches, the dependency columns and the
+// descriptor path: 32 vector registers against 80.  (Round 5 also ran it on a low-priority stream of its own NEXT to the resident
+// persistent launch that reads the batch before -- it fits the 48 registers per SIMD a CU has left beside a k_persist workgroup --
+// with launches ending at batch boundaries: the kernel stretches from 14 to 59 us, the persistent launches slow down by what it
+// no longer costs in front of them, C2 21.07-21.11 against 20.94-21.09 us/step; profiles/r05/plan_side_ab.txt.  Dropped.)
+static __global__ __launch_bounds__(256) void k_native_plan_batch_stretch(const NativeBatchArgs B) { native_plan_batch_body<true>(B); }
 
 static __global__ void k_graph_set(GraphCounters* ctr, unsigned long long step_base, long long stored_base) {
     ctr->step_base = step_base;
