@@ -389,7 +389,7 @@ struct emx_ctx {
     int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
     int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
     int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
-    int64_t tune_wide_fuse = 1;          // 1: the wide dense path makes the stretch proposal inside its role-split log-prob kernel (no propose launch)
+    int64_t tune_wide_fuse = 0;          // 1: the wide dense path makes the stretch proposal inside its role-split log-prob kernel (no propose launch): bit-equal, SLOWER (profiles/r05/wide_fuse_ab.txt)
     int64_t tune_slab_skew = 1;          // 1: the second wave of every SIMD starts its first tile's row loads when its sibling's rows have arrived
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
     int64_t tune_mt_device_min = 147456; // (measured: the host pipeline is faster up to 131 072 walkers since round 5 -- 90-102 against 106 us/step there, 214
@@ -829,9 +829,10 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         const bool prof = prof_max > 0 && c->prof_n < prof_max;
         c->prof_max = 0;
         double* const declp = c->launch_declp;      // the commit kernel below writes the decisions, not the propose pass
-        // Round 5: for the stretch move on ensembles that take the role-split log-prob kernel, the propose pass is made INSIDE it
-        // (WideLpArgs::fuse: the loader waves make the proposal on its way into LDS and store it to qout) -- one launch of memory-
-        // bound work less per half-step (65 536 x 512: 61.8 of 255 us).  Tuning "wide_fuse" = 0: the three launches.
+        // Round 5, tuning "wide_fuse" = 1 (off by default): for the stretch move on ensembles that take the role-split log-prob kernel
+        // the propose pass is made INSIDE it (WideLpArgs::fuse: the loader waves make the proposal on its way into LDS and store it to
+        // qout).  Bit-equal and slower: the gathers of partner pieces, 128 bytes at a time, all fall into the first macro block's
+        // pass (65 536 x 512: 180 -> 281-289 us per launch for 61.8 us of propose pass saved; 508 -> 591-605 us/step).
         const bool fuse = c->tune_wide_fuse != 0 && !callback && move == MOVE_STRETCH && !t_hi_dev && !sendbuf && c->world == 1 &&
                           !order && wide_lp_takes_role_split(t_hi - t_lo, c->num_cu, c->Dp, c->tune_dense_wide == 2);
         int rc = 0;

@@ -262,6 +262,10 @@ __device__ __forceinline__ void slab_mfma2(double4_t (&acc0)[8], double4_t (&acc
     }
 }
 
+// FUSE: the stretch proposal made by the loader waves (WideLpArgs::fuse).  A compile-time switch: as a run-time one its registers
+// (the walker's and the partner's pieces, pointers, factors) pushed the loaders into scratch and cost the UNFUSED launches a quarter
+// of their speed (65 536 x 512: 179.6 -> 224 us per launch, 509 -> 598 us/step; profiles/r05/wide_fuse_ab.txt).
+template <bool FUSE>
 __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];      // slab[2][SLAB] | A tiles [2][8][16][ART] | mu[Dp] | bad[8][16][8]
     typedef double4_t d4;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
             bool rlive[4];
             int aoff[4], apc[4];
             bool bad[4] = {false, false, false, false};
-            const bool fuse = A.fuse != 0;
+            constexpr bool fuse = FUSE;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int e = lt + r * WS_NLT, chunk = e >> 5, within = e & 31;
@@ -733,11 +737,15 @@ hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipS
         static size_t lds_granted[MAX_DEVICES] = {};
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
-            const hipError_t e = hipFuncSetAttribute((const void*)k_wide_lp_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)k_wide_lp_ws<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_wide_lp_ws<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             lds_granted[dev] = lds;
         }
-        hipLaunchKernelGGL(k_wide_lp_ws, grid, dim3(WS_NT), lds, st, a);
+        if (a.fuse)
+            hipLaunchKernelGGL(k_wide_lp_ws<true>, grid, dim3(WS_NT), lds, st, a);
+        else
+            hipLaunchKernelGGL(k_wide_lp_ws<false>, grid, dim3(WS_NT), lds, st, a);
         return hipGetLastError();
     }
     switch (W) {

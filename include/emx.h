@@ -93,7 +93,7 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  * round 5: "mt_device_finish" (1, default: a stretch step of the host pipeline goes up as `order` + the MT19937 state words of its
  * uniforms, in the plan's own columns, and k_plan_raw tempers / converts / resolves partners / takes the logs on the device; 0: the
  * finisher threads do), "persist_exact_mix" (1, default: exact mode takes the persistent kernels with move mixtures too),
- * "wide_fuse" (1, default: the wide dense path makes the stretch proposal inside its role-split log-prob kernel; 0: a propose launch of its own),
+ * "wide_fuse" (0, default: a propose launch of its own; 1: the wide dense path makes the stretch proposal inside its role-split log-prob kernel -- the same bits, measured slower),
  * "slab_skew" (0 ... 4; 1 default: in the slab form of the fused dense half-step, padded ndim 112 / 128, the second wave of
  * every SIMD starts its first tile's row loads when its sibling's have arrived), "mt_upload_split" (1: plans of >= 16 384 walkers
  * go up in two halves on two streams; measured slower, default 0).
