@@ -14,6 +14,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --pmc --no-extras --no-cpu-baseline > $O/bench_n1_pmc.json 2> $O/bench_n1_pmc.err; echo "bench pmc rc=$?" | tee -a $O/summary.txt
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_c2 -o c2 -f csv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/trace_c2.log 2>&1; echo "trace c2 rc=$?" | tee -a $O/summary.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_c3 -o c3 -f csv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --config c3 --no-cpu-baseline > $O/trace_c3.log 2>&1; echo "trace c3 rc=$?" | tee -a $O/summary.txt
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_all -o all -f csv -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/trace_all.log 2>&1; echo "trace all rc=$?" | tee -a $O/summary.txt
 cd $R
 find $O -name "*kernel_trace.csv" -size +2M -exec sh -c 'head -300 "$1" > "$1.head"; rm "$1"' _ {} \;
