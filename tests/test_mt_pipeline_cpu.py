@@ -107,3 +107,37 @@ def test_pipeline_at_the_headline_size_and_its_throughput():
             assert np.array_equal(pa[key], pb[key]), key
     assert same_state(want_state, got_state)
     print("pipeline: %.3f ms per step of 65536 walkers (thread start-up included)" % (sec * 1e3 / nsteps))
+
+
+def test_pipeline_random_shapes_equal_the_serial_twin():
+    """Random ensemble sizes (8 ... 40 000, powers of two among them), set counts, moves, thread and slot counts, start positions in
+    the generator's block, with and without a cached normal: the boundaries of the tokenizer's vector scans (refills of the ring,
+    windows that end inside a walker's draws, batches met exactly) fall differently in every case."""
+    rs0 = np.random.RandomState(20260925)
+    for it in range(16):
+        N = int(rs0.choice([rs0.randint(8, 300), rs0.randint(300, 5000), rs0.randint(5000, 40000), 2 ** rs0.randint(5, 16)]))
+        kind = rs0.choice(["de", "snooker", "stretch", "mix"])
+        S = int(rs0.choice([2, 3, 4, 5]))
+        if kind == "snooker" and S < 4:
+            S = 4
+        N = max(N, 4 * S + 8)
+        moves = {"de": [md("de", S=S)], "snooker": [md("snooker", S=S)], "stretch": [md("stretch", S=S)],
+                 "mix": [md("stretch", S=2), md("de", S=S), md("snooker", S=max(4, S))]}[kind]
+        w = np.ones(len(moves))
+        cdf = np.cumsum(w / w.sum())
+        cdf /= cdf[-1]
+        rs = np.random.RandomState(rs0.randint(1 << 30))
+        if rs0.rand() < 0.5:
+            rs.randn(1)
+        st = list(rs.get_state())
+        st[2] = int(rs0.randint(0, 625))
+        st = tuple(st)
+        nsteps = int(rs0.randint(3, 7))
+        workers, nsinks = int(rs0.choice([1, 2, 3, 6])), int(rs0.choice([2, 4, 16]))
+        want, want_state = serial(st, N, 4, moves, cdf, nsteps)
+        got, got_state, _ = stream(st, N, 4, moves, cdf, nsteps, workers, nsinks)
+        for n, ((ka, pa), (kb, pb)) in enumerate(zip(want, got)):
+            assert ka == kb, (it, kind, N, S, n)
+            for key in ["order", "p0", "uacc", "s0"] + (["p1", "p2"] if moves[ka].kind != 0 else []):
+                assert np.array_equal(pa[key], pb[key]), (it, kind, N, S, n, key)
+        assert same_state(want_state, got_state), (it, kind, N, S)
