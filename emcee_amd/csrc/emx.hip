@@ -380,6 +380,8 @@ struct emx_ctx {
     int64_t tune_persist_exact_max = 32768;   // exact mode: largest ensemble that takes the device-wide persistent kernel
     int64_t tune_persist_exact_steps = 16;    // exact mode: steps per persistent launch (<= 16)
     int64_t tune_fetch_avoid = 1;             // k_plan_fetch keeps off the XCD a one-XCD persistent launch lives on
+    int64_t tune_fetch_blocks = 64;           // ... and beside a device-wide launch runs as this many workgroups (0: one per piece of 256 entries)
+    bool pipe_fetch_local = false;            // the launch being captured is a one-XCD one (run_persist -> pipe_fetch_deferred)
     int64_t tune_fetch_delay_us = 0;     // tests: k_plan_fetch idles this long before it reads
     int64_t tune_persist_span = 1;       // 0: a persistent launch ends with the batch of Philox plans it started in
     int64_t tune_persist_mix = 1;        // 0: a mixture's steps never share a launch (one run of one move per launch)
@@ -1500,6 +1502,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_persist_exact_steps = std::max<int64_t>(1, std::min<int64_t>(v, 16));
         return 0;
     }
+    if (!strcmp(key, "fetch_blocks")) {            // k_plan_fetch's workgroups beside a device-wide persistent launch (0: one per piece)
+        c->tune_fetch_blocks = std::max<int64_t>(0, std::min<int64_t>(v, 65536));
+        return 0;
+    }
     if (!strcmp(key, "fetch_avoid")) {             // k_plan_fetch's workgroups decline on the XCD of a one-XCD persistent launch
         c->tune_fetch_avoid = v ? 1 : 0;
         return 0;
@@ -2403,7 +2409,10 @@ static int pipe_fetch_deferred(emx_ctx* c) {
     F.avoid_xcc = (c->persist_bar && c->tune_fetch_avoid) ? c->persist_bar + 9 * 32 + 4 : nullptr;
     F.host_done = c->pipe_done;
     F.done_value = (unsigned long long)(c->pipe_deferred.back().first + 1);
-    hipLaunchKernelGGL(k_plan_fetch, dim3((unsigned)((c->N + 255) / 256), (unsigned)F.n), dim3(256), 0, c->up_stream, F);
+    F.pieces_x = (int32_t)((c->N + 255) / 256);
+    unsigned nwg = (unsigned)F.pieces_x * (unsigned)F.n;
+    if (!c->pipe_fetch_local && c->tune_fetch_blocks > 0) nwg = std::min<unsigned>(nwg, (unsigned)c->tune_fetch_blocks);
+    hipLaunchKernelGGL(k_plan_fetch, dim3(nwg), dim3(256), 0, c->up_stream, F);
     HIPOK(c, hipGetLastError());
     hipEvent_t& ev = c->pipe_batch_ev[c->pipe_batch_n & 3];
     if (!ev) HIPOK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -3647,6 +3656,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         ++steps;
     }
     if (mtmode && !devp) {
+        c->pipe_fetch_local = launch_local;
         const int rcf = pipe_fetch_deferred(c);
         if (rcf) return rcf;
     }

@@ -2251,6 +2251,7 @@ struct PlanFetchArgs {
     int32_t N, D, n;
     unsigned* arrived;        // device: [0] workgroups of this launch that are done, [1] tickets handed out (the last one resets both)
     const unsigned* avoid_xcc;        // device word: XCC_ID + 1 of the XCD a one-XCD persistent launch lives on (0: none), or null
+    int32_t pieces_x;                 // the work: pieces_x * n pieces of 256 entries (tickets), whatever the grid
     unsigned long long* host_done;    // pinned host word: steps fetched so far, written by the LAST workgroup (an event query
     unsigned delay_ticks;             // (tests: the kernel idles this long first -- 100 MHz ticks -- to show that its consumer waits for it)
     unsigned long long done_value;    // shows the completion tens of us late: the staging buffers go back to the producers on this word)
@@ -2263,15 +2264,21 @@ static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, i
 // of this kernel -- waiting 2 us and more for pinned memory -- cannot take it, and the launch's first barrier waits for the whole
 // fetch (measured: 4 096 walkers, DE + snooker, persistent launches 209 us each against 178 with Philox plans).  The last
 // workgroup to arrive does whatever tickets are left (none, unless every other one declined) before it tells the host.
+// Beside a DEVICE-WIDE launch (no XCD to stay off) the host starts few workgroups instead (tuning "fetch_blocks"): each of them
+// -- four waves of 32 registers, one a SIMD -- fits next to a k_persist workgroup (464 of a SIMD's 512 registers), two on one CU do
+// not, and a grid of a thousand workgroups keeps arriving on whatever CU has room until the fetch is over: the launch then starts
+// when the fetch ends (16 384 x 64, exact mode: 6.3 MB of plans per launch, 126 us over PCIe).  (The copy engine instead -- one
+// hipMemcpyAsync per step, the logarithms from the device copies -- was measured too: slower than 64 workgroups,
+// profiles/r05/exact_mix_probe.txt.)
 static __global__ __launch_bounds__(256) void k_plan_fetch(const PlanFetchArgs A) {
     __shared__ unsigned tk_s;
-    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned total = (unsigned)A.pieces_x * (unsigned)A.n, nwg = gridDim.x;      // tickets | workgroups (a 1-D grid)
     if (A.delay_ticks) {
         const unsigned long long t0 = wall_clock64();
         while (wall_clock64() - t0 < A.delay_ticks) __builtin_amdgcn_s_sleep(8);
     }
     bool decline = false;
-    if (A.avoid_xcc && total >= 16u) {                          // uniform
+    if (A.avoid_xcc && nwg >= 16u) {                            // uniform
         const unsigned want = __hip_atomic_load(A.avoid_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -2286,8 +2293,8 @@ static __global__ __launch_bounds__(256) void k_plan_fetch(const PlanFetchArgs A
                 const unsigned tk = tk_s;
                 __syncthreads();
                 if (tk >= total) break;
-                const int pos = (int)(tk % gridDim.x) * (int)blockDim.x + (int)threadIdx.x;
-                if (pos < A.N) plan_fetch_rows(A, (int)(tk / gridDim.x), pos);
+                const int pos = (int)(tk % (unsigned)A.pieces_x) * (int)blockDim.x + (int)threadIdx.x;
+                if (pos < A.N) plan_fetch_rows(A, (int)(tk / (unsigned)A.pieces_x), pos);
             }
         }
         if (last) break;
@@ -2295,7 +2302,7 @@ static __global__ __launch_bounds__(256) void k_plan_fetch(const PlanFetchArgs A
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence();
-            tk_s = atomicAdd(A.arrived, 1u) == total - 1u ? 1u : 0u;
+            tk_s = atomicAdd(A.arrived, 1u) == nwg - 1u ? 1u : 0u;
         }
         __syncthreads();
         last = tk_s != 0u;

@@ -392,7 +392,8 @@ int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
  * EMX_RNG_MT19937 (the reference's own stream; ensemble.py:166-167) takes the one-XCD forms too -- and the device-wide forms of both
  * kernels up to 32 768 walkers ("persist_exact_max_walkers") -- when the context has ONE move: the
  * host pipeline's plans of up to sixteen steps ("persist_exact_steps") are fetched from their pinned staging buffers by one kernel
- * per launch (k_plan_fetch; its workgroups leave the XCD a one-XCD launch lives on alone, tuning "fetch_avoid" = 0: they do not)
+ * per launch (k_plan_fetch; its workgroups leave the XCD a one-XCD launch lives on alone, tuning "fetch_avoid" = 0: they do not; beside a
+ * device-wide launch it runs as "fetch_blocks" = 64 workgroups, 0: one per 256 entries)
  * -- tuning "persist_exact" = 0: the per-half-step launches with an upload per step.  Move mixtures too
  * (round 5: the next step's move is read off the pipeline's plan before it is taken; "persist_exact_mix" = 0: one move only).  A
  * launch of this mode that cannot become resident is redone like a Philox one (round 5): the pipeline keeps the generator state
