@@ -1,4 +1,5 @@
 #!/bin/bash
+# (ran on the build that had the tuning key plan_side -- commit history: "Plan kernel for batches of lean stretch steps alone ..."; the key is gone: profiles/r05/plan_side_ab.txt)
 # round 5, session y: Philox plans of the next batch on a side stream next to the resident persistent launch (tuning plan_side):
 # the Philox persistent tests, the A/B at the headline (alternating fresh processes), kernel statistics with it on
 cd "$GRAFT_REPO_ROOT" || exit 1
