@@ -8,9 +8,9 @@ SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx
 SRC = SRCS[0]
 LIB = os.path.join(HERE, "libemx.so")
 HOST_SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx_mtpipe.cpp", "emx_mtjump.cpp")]       # plain host C++ (threads, SIMD clones): no device pass
-DEPS = SRCS + HOST_SRCS + [os.path.join(HERE, "csrc", f) for f in ("emx_kernels.hpp", "emx_rng.hpp", "mt19937_legacy.hpp",
-                                                                  "emx_mtpipe.hpp", "emx_internal.hpp", "emx_launch.hpp", "emx_mtdev.hpp", "emx_mtdev_kernels.hpp",
-                                                                  "emx_mtjump.hpp", "emx_persist_p2p.hpp", "emx_persist_mix.hpp")] + [
+# every header of csrc/ (globbed: round 5's emx_planlog.hpp / emx_logtab.hpp were missing from a hand-kept list, so an edit of the
+# kernels' logarithm rebuilt nothing) + the C ABI
+DEPS = SRCS + HOST_SRCS + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hpp", ".h"))) + [
     os.path.join(os.path.dirname(HERE), "include", "emx.h")]
 HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-fvisibility=hidden"]
 # -ffp-contract=off: the proposal arithmetic must round like NumPy's separate multiply/subtract.

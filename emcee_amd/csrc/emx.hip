@@ -2305,7 +2305,10 @@ static int pipe_take(emx_ctx* c) {
     s.move_idx = info.move;
     const size_t N = (size_t)c->N;
     if (c->pipe_defer) {
-        // run_persist: the launch's plans go up together (pipe_fetch_deferred)
+        // run_persist: the launch's plans go up together (pipe_fetch_deferred).  k_plan_fetch reads FINISHED columns: a pipeline
+        // with device finish (raw generator words, pipe_start) must never feed it -- emx_run restarts such a pipeline; fail loudly
+        // should any path get here all the same
+        NEED(c, !info.raw, "exact-mode plan pipeline: a raw (device-finish) step reached the persistent launch's fetch");
         s.uploaded_ref = nullptr;
         s.uploaded_ref2 = nullptr;
         s.fetch_step = n;
@@ -3969,6 +3972,12 @@ int emx_run(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store) {
     }
     const bool piped = !devp && pipe_eligible(c) && c->target != EMX_TARGET_HOST && (c->pipe || total >= 2);
     if (c->pipe && !piped) PIPE_STOP(c);
+    // A running pipeline was sized and configured for ONE consumer (pipe_start: the persistent launches' sixteen-step bursts and
+    // finished plans, or step-at-a-time uploads with device finish, i.e. RAW generator words in the plan columns).  Whether the
+    // persistent kernels take this call is asked per call -- target, tuning keys and the call's length decide -- so a pipeline
+    // started for the other consumer is retired and started again (round-5 advisor: raw steps fetched by k_plan_fetch were read as
+    // doubles).  The generator continues from the last step taken: the chain does not notice.
+    if (c->pipe && persist_exact_ok(c) != (c->pipe_nsinks == PLAN_RING)) PIPE_STOP(c);
     if (piped && !c->pipe) {
         const int rc = pipe_start(c);
         if (rc) return rc;

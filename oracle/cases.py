@@ -87,19 +87,23 @@ HOST_MOVE_CASES = {
     "kde_40x2_iso": dict(N=40, D=2, target="iso", moves=[_S("kde")], nsteps=8, seed=521),
 }
 
-# Larger cases: only a digest of the reference output is committed.
+# Larger cases: only a digest of the reference output is committed.  Their start state must be the SAME BITS on every CPU, or the
+# reference digest cannot be asserted there (round-5 verdict: the dense cases built p0 through a BLAS matmul with the Cholesky
+# factor, the digest was applied "if p0 matches" and silently was not on the GPU box).  So the dense cases here start from
+# p0 = mu + randn (p0="mu_randn": element-wise arithmetic only, no BLAS / LAPACK in the start state); the equilibrium start
+# (through the Cholesky factor) is covered by the fixtures above, whose p0 is stored.
 DIGEST_CASES = {
-    "stretch_4096x64_dense": dict(N=4096, D=64, target="dense", moves=[_S("stretch")], nsteps=3, seed=401),
+    "stretch_4096x64_dense": dict(N=4096, D=64, target="dense", p0="mu_randn", moves=[_S("stretch")], nsteps=3, seed=401),
     "stretch_2048x32_rosen": dict(N=2048, D=32, target="rosenbrock", moves=[_S("stretch")], nsteps=3, seed=402, p0="rosen"),
     "stretch_2048x1024_diag": dict(N=2048, D=1024, target="diag", moves=[_S("stretch")], nsteps=2, seed=403),
-    "stretch_1024x256_dense": dict(N=1024, D=256, target="dense", moves=[_S("stretch")], nsteps=2, seed=405),
-    "stretch_1100x520_dense": dict(N=1100, D=520, target="dense", moves=[_S("stretch")], nsteps=2, seed=406),
-    "mix_de_snooker_1024x64_dense": dict(N=1024, D=64, target="dense", moves=[_S("de"), _S("snooker")], weights=[0.8, 0.2], nsteps=6, seed=404),
+    "stretch_1024x256_dense": dict(N=1024, D=256, target="dense", p0="mu_randn", moves=[_S("stretch")], nsteps=2, seed=405),
+    "stretch_1100x520_dense": dict(N=1100, D=520, target="dense", p0="mu_randn", moves=[_S("stretch")], nsteps=2, seed=406),
+    "mix_de_snooker_1024x64_dense": dict(N=1024, D=64, target="dense", p0="mu_randn", moves=[_S("de"), _S("snooker")], weights=[0.8, 0.2], nsteps=6, seed=404),
     # round 4: long enough for several launches of the persistent kernels in exact mode (sixteen steps each: k_plan_fetch)
     "stretch_1024x16_iso_40": dict(N=1024, D=16, target="iso", moves=[_S("stretch")], nsteps=40, seed=411),
     "de_2048x8_diag_24": dict(N=2048, D=8, target="diag", moves=[_S("de")], nsteps=24, seed=412),
     "snooker_1024x8_iso_20": dict(N=1024, D=8, target="iso", moves=[_S("snooker")], nsteps=20, seed=413),
-    "stretch_512x64_dense_35": dict(N=512, D=64, target="dense", moves=[_S("stretch")], nsteps=35, seed=414),
+    "stretch_512x64_dense_35": dict(N=512, D=64, target="dense", p0="mu_randn", moves=[_S("stretch")], nsteps=35, seed=414),
 }
 
 
@@ -121,6 +125,8 @@ def build(name):
         p0 = rs.rand(N, D)
     elif p0kind == "rosen":
         p0 = 1.0 + 0.1 * rs.randn(N, D)
+    elif p0kind == "mu_randn":
+        p0 = desc["mu"] + rs.randn(N, D)
     elif kind == "dense":
         p0 = desc["mu"] + rs.randn(N, D) @ np.linalg.cholesky(desc["cov"]).T
     elif kind == "diag":

@@ -14,11 +14,17 @@ ROOT = os.path.dirname(HERE)
 
 def _run(cmd, tmp_path, extra_env=None, timeout=300):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update({"EMX_BENCH_STUB": "tests.stubs.bench_stub", "EMX_BENCH_STUB_DIR": str(tmp_path), "PYTHONPATH": ROOT})
+    env.update({"EMX_BENCH_STUB": "tests.stubs.bench_stub", "EMX_BENCH_STUB_DIR": str(tmp_path), "PYTHONPATH": ROOT,
+                "EMX_BENCH_DETAIL": os.path.join(str(tmp_path), "bench_detail.json")})
     env.update(extra_env or {})
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     return r, lines
+
+
+def _detail(tmp_path):
+    """the full record (the stdout line is its compact summary: tools/benchkit/emit.py, tests/test_bench_line_cpu.py)"""
+    return json.load(open(os.path.join(str(tmp_path), "bench_detail.json")))
 
 
 def _ranks_seen(tmp_path):
@@ -46,6 +52,8 @@ def test_self_launch_runs_n_ranks_and_prints_one_line(tmp_path):
     # ... that went through the same sequence of measurements (they agree through the gloo group they formed)
     seqs = {tuple((d["key"], d["ex"]) for d in v) for v in seen.values()}
     assert len(seqs) == 1
+    assert len(lines[0]) < 8192 and line["multi_gpu"]["c2_weak_65536_per_gpu"]["predicted_us_per_step"] > 0
+    line = _detail(tmp_path)
     multi = line["multi_gpu"]
     assert set(multi) == {"c2_weak_65536_per_gpu", "c3_262144x32_rosen_sharded", "c5_16384x1024_strong", "wide_65536x512_dense_weak"}
     assert set(multi["wide_65536x512_dense_weak"]["exchange"]) == {"replay", "replay_push", "logprob"}       # the protocols that share out the evaluation
@@ -71,6 +79,8 @@ def test_a_spent_time_budget_skips_the_rest_and_says_so(tmp_path):
                     extra_env={"EMX_BENCH_STUB_SLEEP": "2.0"})          # 2 s per measurement: the budget's last 30 s are reached after ~5 of 18
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(lines[-1])
+    assert line["value"] > 0 and any("time budget" in str(v) for e in line["multi_gpu"].values() for v in e["us_per_step_by_exchange"].values())
+    line = _detail(tmp_path)
     skipped = [(k, ex) for k, e in line["multi_gpu"].items() for ex, v in e["exchange"].items() if "time budget" in str(v.get("error", ""))]
     measured = [(k, ex) for k, e in line["multi_gpu"].items() for ex, v in e["exchange"].items() if "ms_per_step" in v]
     assert measured and skipped and line["value"] > 0
@@ -104,8 +114,8 @@ def test_a_census_that_disagrees_is_never_reported_as_n_gpus(tmp_path):
     r, lines = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c2"], tmp_path,
                     {"EMX_BENCH_STUB_RANKS": "1"})
     line = json.loads(lines[-1])
-    assert line["value"] is None
-    assert "rank census failed" in json.dumps(line["error"])
+    assert line["value"] is None and "no exchange protocol" in line["error"]
+    assert "rank census failed" in json.dumps(_detail(tmp_path)["multi_gpu"])
 
 
 def test_preflight_disables_failing_and_hanging_protocols(tmp_path):
@@ -113,6 +123,8 @@ def test_preflight_disables_failing_and_hanging_protocols(tmp_path):
                     {"EMX_BENCH_STUB_FAIL": "pull", "EMX_BENCH_STUB_HANG": "direct"})
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(lines[-1])
+    assert set(line["preflight"]["disabled"]) == {"pull", "direct"} and line["preflight"]["ok"]["allgather"]
+    line = _detail(tmp_path)
     dis = line["preflight"]["disabled"]
     assert "pull" in dis and "direct" in dis and "allgather" not in dis
     ex = line["multi_gpu"]["c2_weak_65536_per_gpu"]["exchange"]

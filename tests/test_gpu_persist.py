@@ -683,6 +683,41 @@ def test_exact_mode_persistent_long_run(N, D, target, steps_per_launch):
     assert np.array_equal(p["rng"][1], c["rng"][1]) and p["rng"][2] == c["rng"][2]
 
 
+@pytest.mark.parametrize("N,D,target", [(4096, 64, "dense"), (2048, 10, "iso"), (16384, 64, "dense")])
+def test_exact_mode_pipeline_is_restarted_when_its_consumer_changes(N, D, target):
+    """Round-5 advisor (medium): the host pipeline is configured once, when it starts -- for step-at-a-time uploads with device finish
+    (RAW generator words in the plan columns, finished by k_plan_raw) or for the persistent launches' fetch kernel (finished
+    columns) -- while "do the persistent kernels take this call" is asked per emx_run and depends on tuning keys and the target.  A
+    pipeline started for one consumer used to go on feeding the other: k_plan_fetch read generator words as doubles.  emx_run now
+    retires and restarts it (the generator continues behind the last step taken).  Three calls, the consumer switched between
+    them, against one consumer throughout: same chain, same accept counters, same final generator state."""
+    spec = full_spec(N, D, target, [S("stretch")], seed=13)
+    state = np.random.RandomState(4321).get_state()
+    recs = []
+    for schedule in ((0, 1, 0), (1, 0, 1), (0, 0, 0)):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        ens.set_mt19937(state)
+        ens.set_tuning("persist_timeout_ms", 200)
+        ens.chain_config(66)
+        launches = []
+        for pe in schedule:
+            ens.set_tuning("persist_exact", pe)
+            before = ens.persist_info()["launches"]
+            ens.run(22, 1, True)
+            launches.append(ens.persist_info()["launches"] - before)
+        assert ens.status() == 0
+        assert [n > 0 for n in launches] == [bool(pe) for pe in schedule]          # each call really took the consumer asked for
+        x, lp = ens.get_state()
+        recs.append(dict(x=x, lp=lp, chain=ens.chain_read(0, 0, 66), counts=ens.accepted_counts(), rng=ens.get_mt19937()))
+        ens.close()
+    ref = recs[-1]
+    for r in recs[:-1]:
+        assert np.array_equal(r["rng"][1], ref["rng"][1]) and r["rng"][2] == ref["rng"][2]
+        for key in ("x", "lp", "chain", "counts"):
+            assert np.array_equal(r[key], ref[key]), key
+
+
 def test_exact_mode_persistent_launch_waits_for_its_plans():
     """The plans of a launch's eight steps are fetched by ONE kernel on the upload stream (k_plan_fetch, straight from the
     pipeline's pinned staging buffers); the launch waits for it, and the fetch waits for the launch that last read the slots it

@@ -66,8 +66,9 @@ def test_oracle_reproduces_host_move_fixture(name):
 def test_oracle_digest_cases(name):
     d = load_digests()[name]
     spec = cases.build(name)
-    if digest(spec["p0"]) != d.get("p0"):
-        pytest.skip("p0 differs at ULP level on this CPU (BLAS); digest not comparable")
+    # the start state of every digest case is element-wise arithmetic on RandomState draws (oracle/cases.py: no BLAS), hence the
+    # same bits on every CPU: the reference's digest is ALWAYS comparable (no skip -- round-5 verdict)
+    assert digest(spec["p0"]) == d["p0"], "the start state of a digest case must not depend on the CPU"
     out = run_oracle(spec, spec["p0"], rng_for_case(spec))
     assert digest(out["chain"]) == d["chain"]
     assert digest(out["accepted_count"]) == d["accepted_count"]

@@ -28,7 +28,8 @@ def _free_port():
 
 def error_line(args, msg, extra=None):
     line = {"metric": "walker-updates/sec (whole node), 64-dim correlated Gaussian, StretchMove a=2", "value": None,
-            "unit": "walker-updates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": msg}
+            "unit": "walker-updates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+            "higher_is_better": True, "dtype": "f64", "data": "synthetic", "error": msg}
     if extra:
         line.update(extra)
     return line
@@ -50,9 +51,7 @@ def self_launch(args, argv):
         except Exception as e:  # noqa: BLE001
             log("device count unavailable:", e)
         if ndev is not None and ndev < N:
-            out.write(json.dumps(error_line(args, "--gpus %d but only %d HIP device(s) are visible" % (N, ndev),
-                                            {"devices_visible": ndev})) + "\n")
-            out.flush()
+            emit_line(error_line(args, "--gpus %d but only %d HIP device(s) are visible" % (N, ndev), {"devices_visible": ndev}))
             return 2
     port = _free_port()
     env0 = dict(os.environ)
@@ -90,9 +89,8 @@ def self_launch(args, argv):
     rcs = [p.returncode for p in procs]
     text = [ln for ln in (line0 or "").splitlines() if ln.strip().startswith("{")]
     if not text:
-        out.write(json.dumps(error_line(args, "the ranks produced no result line (exit codes %s%s)"
-                                        % (rcs, "; timed out after %.0f s" % args.launch_timeout if line0 is None else ""))) + "\n")
-        out.flush()
+        emit_line(error_line(args, "the ranks produced no result line (exit codes %s%s)"
+                             % (rcs, "; timed out after %.0f s" % args.launch_timeout if line0 is None else "")))
         return 1
     try:
         line = json.loads(text[-1])
@@ -106,6 +104,6 @@ def self_launch(args, argv):
 
 # ------------------------------------------------------------------------------------------------ main
 def emit_line(line):
-    out = _claim_stdout()
-    out.write(json.dumps(line) + "\n")
-    out.flush()
+    """every line goes out through tools/benchkit/emit.py: the compact summary on stdout, the full record beside it"""
+    from tools.benchkit.emit import emit_record
+    emit_record(line)

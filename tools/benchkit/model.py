@@ -13,8 +13,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0      # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
 HBM_ACHIEVABLE_GBPS = 6300.0   # what a streaming kernel sustains on this part (same guide): the second yardstick of the beyond-MALL configs
 MFMA_F64_PEAK_TFLOPS = 78.6    # dense f64 matrix peak (v_mfma_f64_16x16x4_f64: 256 flop x 4 SIMD x 256 CU x 2.4 GHz / 8 passes)
-MIN_TIMED_MS = 50.0
-MAX_BLOCKS = 400
+MIN_TIMED_MS = 1000.0       # of timed K-step blocks per measurement (round-5 verdict: 50 ms was 1.8 % of the command's time)
+MAX_BLOCKS = 4000
 
 
 # ------------------------------------------------------------------------------------------------ workloads
