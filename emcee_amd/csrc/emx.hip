@@ -406,7 +406,6 @@ struct emx_ctx {
     struct Prepared {   // native plans already evaluated on the device, in step order
         int move, S, slot;
         bool lean;          // only the columns the fused half-step reads were written
-        bool deps;          // lean stretch plan whose p1 / p2 columns carry k_persist_p2p's dependencies (k_native_plan_batch)
         int gcol;           // Gaussian sequential mode: the coordinate this step moves
         uint64_t step;
         NativeArgs nat;
@@ -422,7 +421,6 @@ struct emx_ctx {
         bool store = false;
         bool native = false;
         bool lean = false;     // native plan without the columns nothing on the fused path reads (emx_plan_get completes it)
-        bool deps = false;     // ... whose p1 / p2 columns carry k_persist_p2p's dependencies
         bool devplan = false;  // exact-mode plan written by the device producer: there is no host copy of it
         int gcol = 0;
         std::vector<int32_t> off;
@@ -516,12 +514,6 @@ struct emx_ctx {
     unsigned persist_hepoch = 0;         // handshakes of the one-XCD form counted so far
     int64_t persist_local_launches = 0;
     unsigned* persist_ver = nullptr;  // (N) stamp of the half-step that last moved the walker
-    unsigned long long* persist_tw = nullptr;   // k_persist_p2p: [2][persist_tw_stride] tile words
-    unsigned persist_tw_stride = 0;
-    unsigned persist_pepoch = 0;      // k_persist_p2p: half-steps every workgroup has counted on its arrival counters
-    int64_t persist_p2p_launches = 0;
-    int64_t tune_persist_p2p = 0;     // 1: the stretch move's device-wide launches take k_persist_p2p (no barrier between the half-steps: measured SLOWER, profiles/r05/p2p.md)
-    int8_t persist_p2p_fits = -1;     // k_persist_p2p's grid fits the device (occupancy query), -1: not asked yet
     unsigned persist_epoch = 0;
     unsigned persist_grid = 0;        // workgroups of the launches the barrier counters have counted so far
     // what a persistent launch did, kept until the stream is known to have run it: a launch whose grid could not become co-resident
@@ -1292,7 +1284,6 @@ int emx_destroy(emx_ctx* c) {
     if (c->persist_bar) hipFree(c->persist_bar);
     if (c->persist_started) hipHostFree(c->persist_started);
     if (c->persist_ver) hipFree(c->persist_ver);
-    if (c->persist_tw) hipFree(c->persist_tw);
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_ctr) hipFree(c->d_ctr);
     if (c->h_ctr) hipHostFree(c->h_ctr);
@@ -1477,11 +1468,6 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
         c->tune_persist = v ? 1 : 0;
-        return 0;
-    }
-    if (!strcmp(key, "persist_p2p")) {       // 0: never k_persist_p2p (the headline shape keeps k_persist's device-wide barrier)
-        if ((v ? 1 : 0) != c->tune_persist_p2p) drop_prepared(c);      // (plans made ahead carry -- or lack -- its dependency columns)
-        c->tune_persist_p2p = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)
@@ -2443,7 +2429,6 @@ int emx_step_begin_with(emx_ctx* c, int32_t store, int32_t move_index, int32_t* 
 // to c->prepared in step order.  (Measured and dropped, rounds 2 and 3: the NEXT batch on a second, low-priority stream next to
 // this batch's half-steps, with and without raised wave priority for the half-step kernel -- the co-resident plan waves slow
 // every half-step launch by 0.8 us: C2 23.69 -> 24.40 us/step, C3 38.65 -> 39.5; profiles/r03/ab_side_stream.txt.)
-static bool persist_p2p_wanted(const emx_ctx* c);
 static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int forced_move, hipStream_t st) {
     const int nm = (int)c->moves.size();
     NativeBatchArgs B{};
@@ -2453,12 +2438,6 @@ static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int for
     // single replica, fused device target: nobody but the half-step kernel reads these plans
     B.lean = (c->target != EMX_TARGET_HOST && c->world == 1 && !c->sendbuf && !c->comm && !c->tune_full_plan) ? 1 : 0;
     B.ablate = (int32_t)(c->tune_ablate >> 8);
-    // k_persist_p2p's dependency columns (p1 / p2 of lean stretch plans): wherever its launches can follow
-    B.deps = (B.lean && forced_move < 0 && persist_p2p_wanted(c)) ? 1 : 0;
-    if (B.deps && first_step > 0) {
-        B.Sprev0 = c->moves[philox_move_choice(c->ph_seed, first_step - 1, c->cdf.data(), nm)].nsplits;
-        B.pkprev0 = make_perm_key((uint64_t)c->N, c->ph_seed, first_step - 1);
-    }
     bool only_stretch = true;
     for (int b = 0; b < nb; ++b) {
         const uint64_t step = first_step + (uint64_t)b;
@@ -2478,7 +2457,6 @@ static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int for
         pr.nat.pk = make_perm_key((uint64_t)c->N, c->ph_seed, step);
         pr.cursor_before = m.gammas;
         pr.lean = B.lean != 0;
-        pr.deps = B.deps != 0 && m.kind == EMX_MOVE_STRETCH;
         if (m.kind == EMX_MOVE_GAUSS) {
             B.gmode[b] = m.reserved;
             B.gcol[b] = (int32_t)((int64_t)m.gammas % c->D);
@@ -2501,7 +2479,7 @@ static int native_prepare_batch(emx_ctx* c, uint64_t first_step, int nb, int for
         B.move[b] = m.kind;
         B.S[b] = m.nsplits;
     }
-    if (only_stretch && B.lean && !B.deps && !B.ablate && !B.desc)       // (the same arithmetic without the other moves' branches: 32 VGPRs against 80)
+    if (only_stretch && B.lean && !B.ablate && !B.desc)       // (the same arithmetic without the other moves' branches: 32 VGPRs against 80)
         hipLaunchKernelGGL(k_native_plan_batch_stretch, dim3((unsigned)((c->N + 255) / 256), (unsigned)nb), dim3(256), 0, st, B);
     else
         hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), (unsigned)nb), dim3(256), 0, st, B);
@@ -2516,7 +2494,6 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
     auto& cur = c->cur;
     cur.store = store != 0;
     cur.native = false;
-    cur.deps = false;
     cur.devplan = false;
     const int nm = (int)c->moves.size();
     const bool devp = forced_move < 0 && mtdev_eligible(c);
@@ -2593,7 +2570,6 @@ static int step_begin_impl(emx_ctx* c, int32_t store, int32_t forced_move, int32
         cur.S = pr.S;
         cur.native = true;
         cur.lean = pr.lean;
-        cur.deps = pr.deps;
         cur.gcol = pr.gcol;
         cur.nat = pr.nat;
         cur.slot = pr.slot;
@@ -2651,7 +2627,6 @@ static int complete_lean_plan(emx_ctx* c) {
     hipLaunchKernelGGL(k_native_plan_batch, dim3((unsigned)((c->N + 255) / 256), 1u), dim3(256), 0, c->stream, B);
     HIPOK(c, hipGetLastError());
     cur.lean = false;
-    cur.deps = false;
     return 0;
 }
 
@@ -3386,12 +3361,6 @@ static bool persist_wanted(const emx_ctx* c) {
     return sh.G == 8 && sh.V == 2 && sh.CH == (dpb == 1 ? 1 : dpb == 2 ? 2 : 4);
 }
 
-// k_persist_p2p (emx_persist_p2p.hpp) can follow: Philox plans on the persistent path of the fused dense target (which launches take
-// it is decided per launch, run_persist); native_prepare_batch then writes its dependency columns into the lean stretch plans
-static bool persist_p2p_wanted(const emx_ctx* c) {
-    return c->tune_persist_p2p != 0 && c->rng_mode == EMX_RNG_PHILOX && persist_wanted(c);
-}
-
 // The element-wise targets (csrc/emx_pvalu.hip): the one-XCD form only -- ensembles of up to 8 192 walkers, rows of 4 or 8 lanes per walker
 // (ndim <= 64 even, <= 32 odd), Philox plans, one replica, every move of the schedule one the kernel knows at a shape it can take.
 static bool persist_valu_wanted(const emx_ctx* c) {
@@ -3560,7 +3529,6 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     bool launch_local = false;           // the one-XCD form: an eight times larger grid of which every eighth workgroup works
     bool launch_mix = false;             // DE and snooker steps of a mixture in this launch (k_persist_mix)
     double launch_gammas = 0.0;
-    bool all_deps = true;                // every step's plan carries k_persist_p2p's dependency columns
     while (i0 + steps < total) {
         // the move of the step that would follow: off its plan, or -- the batch of plans is used up: the next one is made during this
         // capture, i.e. enqueued BEFORE this launch, into the other half of the plan ring -- from the Philox stream directly
@@ -3600,7 +3568,6 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         int mvi, S;
         int rc = emx_step_begin(c, st, &mvi, &S);
         if (rc) return rc;
-        all_deps = all_deps && c->cur.deps;
         if (launch_move < 0) {
             launch_move = c->moves[mvi].kind;
             launch_gammas = c->moves[mvi].gammas;
@@ -3666,25 +3633,6 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     c->pipe_defer = false;
     if (launch_mix) grid = dim3((unsigned)(c->N / 2 / 16 / c->persist_wpb));       // (the DE move's grid, whatever the first step was)
     if (launch_local) grid.x *= 8;
-    // the headline shape (stretch move, device-wide form, Philox plans with the dependency columns): no barrier between the half-steps
-    bool launch_p2p = all_deps && !mtmode && !launch_local && !launch_mix && launch_move == EMX_MOVE_STRETCH && launch_S >= 2 &&
-                      c->target == EMX_TARGET_DENSE_GAUSS && c->tune_persist_p2p != 0;
-    if (launch_p2p && c->persist_p2p_fits < 0) {
-        int per_cu = 0;
-        const hipError_t eo = hot_persist_p2p_occupancy(c->Dp / 16, (int)block.x, lds, &per_cu);
-        c->persist_p2p_fits = (eo != hipSuccess || (int64_t)per_cu * c->num_cu >= (int64_t)grid.x) ? 1 : 0;
-    }
-    launch_p2p = launch_p2p && c->persist_p2p_fits != 0;
-    if (launch_p2p && (!c->persist_tw || c->persist_tw_stride < ((unsigned)(c->N / 16 + 64) << P2P_WSHIFT))) {
-        if (c->persist_tw) {
-            HIPOK(c, wait_stream(c->stream));
-            hipFree(c->persist_tw);
-            c->persist_tw = nullptr;
-        }
-        c->persist_tw_stride = (unsigned)(c->N / 16 + 64) << P2P_WSHIFT;      // (a tile's word every 256 bytes: emx_persist_p2p.hpp)
-        HIPOK(c, hipMalloc((void**)&c->persist_tw, (size_t)c->persist_tw_stride * 2 * sizeof(unsigned long long)));
-        HIPOK(c, hipMemsetAsync(c->persist_tw, 0xff, (size_t)c->persist_tw_stride * 2 * sizeof(unsigned long long), c->stream));
-    }
     if (grid.x != c->persist_grid) {
         // the arrival counters count workgroups: another grid size (another move of a mixture, another ensemble shape) starts them
         // afresh -- on the stream, i.e. after every earlier launch has left the barrier
@@ -3692,7 +3640,6 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         c->persist_epoch = 0;
         c->persist_lepoch = 0;
         c->persist_hepoch = 0;
-        c->persist_pepoch = 0;
         c->persist_grid = grid.x;
     }
     P.niter = n;
@@ -3707,17 +3654,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         c->persist_hepoch += 1u;
     }
     P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
-    P.tw = c->persist_tw;
-    P.tw_stride = c->persist_tw_stride;
-    P.pctr = c->persist_bar + 12 * 32;
-    P.pepoch0 = c->persist_pepoch;
-    if (launch_p2p) {
-        c->persist_epoch += 1u;               // the handshake; the half-steps count on counters of their own (PersistArgs::pctr)
-        c->persist_pepoch += (unsigned)(n - 1);
-        c->persist_p2p_launches++;
-    } else {
-        c->persist_epoch += (unsigned)n;      // the handshake and the n - 1 barriers between the half-steps
-    }
+    c->persist_epoch += (unsigned)n;          // the handshake and the n - 1 barriers between the half-steps
     P.seq = ++c->persist_seq;
     lg.seq = P.seq;
     lg.steps = steps;
@@ -3744,10 +3681,6 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             e = launch_persist_valu(shv.G, shv.V, shv.CH, launch_move, launch_local ? 1 : 0, grid, block, c->stream, P);
         } else if (launch_mix) {
             e = launch_persist_mix(c->Dp / 16, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
-        } else if (launch_p2p) {
-            int chain = 0;
-            for (int q = 0; q < n; ++q) chain |= (P.it[q].chain != nullptr || P.it[q].chain_lp != nullptr) ? 1 : 0;
-            e = launch_hot_persist_p2p(c->Dp / 16, chain, grid, block, lds, c->stream, P);
         } else {
             e = launch_hot_persist_dense(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
         }
@@ -3826,7 +3759,6 @@ static int persist_settle(emx_ctx* c) {
     c->persist_epoch = 0;
     c->persist_lepoch = 0;
     c->persist_hepoch = 0;
-    c->persist_pepoch = 0;
     c->persist_grid = 0;
     __atomic_store_n(&c->status_host[3], 0u, __ATOMIC_RELEASE);
     if (redo.empty()) return 0;
@@ -3949,11 +3881,6 @@ int emx_persist_info(emx_ctx* c, int64_t out[4]) {
 
 int emx_persist_local_launches(emx_ctx* c, int64_t* n) {
     *n = c->persist_local_launches;
-    return 0;
-}
-
-int emx_persist_p2p_launches(emx_ctx* c, int64_t* n) {
-    *n = c->persist_p2p_launches;
     return 0;
 }
 

@@ -1,7 +1,6 @@
 // The headline kernel's translation unit (see emx_launch.hpp): k_halfstep<8, 2, 4, STRETCH, 4, LEAN> for LEAN = 1 (single
 // replica) and 2 (block-ownership exchanges), compiled with the ILP instruction scheduler.
 #include "emx_launch.hpp"
-#include "emx_persist_p2p.hpp"
 
 namespace emx {
 
@@ -43,44 +42,6 @@ hipError_t launch_hot_persist_dense(int dpb, int move, int local, dim3 grid, dim
         return move == MOVE_DE        ? launch_persist<8, 2, ch, b, MOVE_DE>(grid, block, lds, st, P)              \
                : move == MOVE_SNOOKER ? launch_persist<8, 2, ch, b, MOVE_SNOOKER>(grid, block, lds, st, P)         \
                                       : launch_persist<8, 2, ch, b, MOVE_STRETCH>(grid, block, lds, st, P);
-    EMX_CASE(1, 1) EMX_CASE(2, 2) EMX_CASE(3, 4) EMX_CASE(4, 4)
-#undef EMX_CASE
-    return hipErrorInvalidValue;
-}
-
-// k_persist_p2p (emx_persist_p2p.hpp): the stretch move's device-wide form without a barrier between the half-steps
-template <int CH, int DPB, bool CHAIN>
-static hipError_t launch_p2p(dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-    auto kern = k_persist_p2p<8, 2, CH, DPB, CHAIN>;
-    static size_t lds_granted[MAX_DEVICES] = {};
-    int dev = 0;
-    if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_granted[dev] = lds;
-    }
-    hipLaunchKernelGGL(kern, grid, block, lds, st, P);
-    return hipGetLastError();
-}
-
-hipError_t launch_hot_persist_p2p(int dpb, int chain, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-#define EMX_CASE(b, ch) \
-    if (dpb == b) return chain ? launch_p2p<ch, b, true>(grid, block, lds, st, P) : launch_p2p<ch, b, false>(grid, block, lds, st, P);
-    EMX_CASE(1, 1) EMX_CASE(2, 2) EMX_CASE(3, 4) EMX_CASE(4, 4)
-#undef EMX_CASE
-    return hipErrorInvalidValue;
-}
-
-hipError_t hot_persist_p2p_occupancy(int dpb, int threads, size_t lds, int* per_cu) {
-#define EMX_CASE(b, ch)                                                                                                  \
-    if (dpb == b) {                                                                                                      \
-        auto kern = k_persist_p2p<8, 2, ch, b, true>;                                                                    \
-        if (lds > 48 * 1024) {                                                                                           \
-            const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e;                                                                               \
-        }                                                                                                                \
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, threads, lds);                                 \
-    }
     EMX_CASE(1, 1) EMX_CASE(2, 2) EMX_CASE(3, 4) EMX_CASE(4, 4)
 #undef EMX_CASE
     return hipErrorInvalidValue;

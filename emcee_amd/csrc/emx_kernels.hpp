@@ -241,7 +241,7 @@ __device__ __forceinline__ bool group_any(bool pred, int sub) {
 template <int MOVE>
 __host__ __device__ inline void native_slot(const NativeArgs& na, int N, int S, int split, int t, double a,
                                             double sigma, double g0, int& i, int& p0, int& p1, int& p2, double& s0,
-                                            double& uacc, int* part_set = nullptr, int* part_slot = nullptr) {
+                                            double& uacc) {
     const uint32_t k0 = (uint32_t)na.seed, k1 = (uint32_t)(na.seed >> 32);
     const uint32_t sl = (uint32_t)na.step, sh = (uint32_t)(na.step >> 32);
     i = (int)perm_inv((uint32_t)(t * S + split), na.pk);
@@ -270,8 +270,6 @@ __host__ __device__ inline void native_slot(const NativeArgs& na, int N, int S, 
             rr -= n;
         }
         p0 = (int)perm_inv((uint32_t)(tt * S + j), na.pk);
-        if (part_set) *part_set = j;              // the partner is member `tt` of set `j` (k_native_plan_batch: the tile that updates it)
-        if (part_slot) *part_slot = tt;
     } else if (MOVE == MOVE_DE) {
         int64_t r1 = (int64_t)bounded64(B.v[0], B.v[1], (uint64_t)Nc);
         int64_t r2 = (int64_t)bounded64(B.v[2], B.v[3], (uint64_t)(Nc - 1));
@@ -1245,8 +1243,7 @@ __device__ __forceinline__ void store_scope(T* p, T v) {
 }
 
 constexpr int PERSIST_MAX_ITERS = 32;
-constexpr int P2P_WSHIFT = 5;                   // k_persist_p2p: a tile's word at index tile << 5 of PersistArgs::tw (emx_persist_p2p.hpp)
-constexpr int PERSIST_BAR_WORDS = 20 * 32;   // PersistArgs::bar (12 x 32 words) and, behind it, PersistArgs::pctr (8 x 32)
+constexpr int PERSIST_BAR_WORDS = 12 * 32;   // PersistArgs::bar
 struct PersistIter {
     const int32_t *order, *p0, *p1, *p2;  // (p1: the DE move's second partner; p1, p2: the snooker move's z1, z2)
     const double *s0, *logu, *fac;
@@ -1267,11 +1264,6 @@ struct PersistArgs {
     int32_t niter;
     unsigned seq;                  // number of this launch (left in the barrier block's fourth `go` word once its grid is known co-resident)
     unsigned* started_host;        // pinned host word (or null): `seq` again, for the host -- launch k + 1 has started, so launch k is over
-    // k_persist_p2p (emx_persist_p2p.hpp): no barrier between the half-steps -- a word per tile and half-step, one lagging gate
-    unsigned long long* tw;        // [2][tw_stride]: {launch, half-step | 16 accept bits} of every tile, by the parity of the half-step
-    unsigned* pctr;                // [8][32]: workgroups that have finished a half-step, counted per blockIdx & 7 (nobody waits where it arrives)
-    unsigned pepoch0;              // half-steps every workgroup had counted on pctr before this launch
-    unsigned tw_stride;
 };
 
 // The one-XCD form's barrier: every workgroup of the grid runs on ONE XCD (k_persist<..., LOCAL>), so its L2 is the point of
@@ -2506,9 +2498,6 @@ struct NativeBatchArgs {
     int32_t gmode[NATIVE_BATCH_MAX], gcol[NATIVE_BATCH_MAX];   // Gaussian move: mode, the sequential mode's column
     int32_t N, D, nb;
     int32_t lean;           // 1: only the columns the fused half-step kernel of the step's move reads are written (below)
-    int32_t deps;           // lean stretch plans: columns p1 / p2 carry what k_persist_p2p waits for (below) instead of staying unwritten
-    int32_t Sprev0;         // ... the number of splits of the step BEFORE the batch's first (0: there is none), and its permutation
-    PermKey pkprev0;
     int32_t ablate;         // timing experiments only (tuning "ablate" bits 8..): 1 no logs, 2 no stores, 4 return at once; 0 in production
     const StepDesc* desc;   // graph replay: per-step NativeArgs from device memory instead of nat[]
 };
@@ -2526,14 +2515,14 @@ static __device__ __forceinline__ void native_plan_batch_body(const NativeBatchA
         if (t < n) { split = s; break; }
         t -= n;
     }
-    int i, a0, a1, a2, dep_j = -1, dep_tt = -1;
+    int i, a0, a1, a2;
     double z, u;
     const int mv = ONLY_STRETCH ? MOVE_STRETCH : B.move[b];
     const NativeArgs nat = (!ONLY_STRETCH && B.desc) ? B.desc[b].nat : B.nat[b];      // (graph replay: descriptors in device memory)
     if (mv == MOVE_GAUSS)
         native_gauss_slot(nat, B.D, B.gmode[b], B.gcol[b], pos, i, a0, a1, a2, z, u);
     else if (mv == MOVE_STRETCH)
-        native_slot<MOVE_STRETCH>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u, &dep_j, &dep_tt);
+        native_slot<MOVE_STRETCH>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
     else if (mv == MOVE_DE)
         native_slot<MOVE_DE>(nat, N, S, split, t, B.a[b], B.sigma[b], B.g0[b], i, a0, a1, a2, z, u);
     else
@@ -2545,7 +2534,7 @@ static __device__ __forceinline__ void native_plan_batch_body(const NativeBatchA
     // split-phase and sharded paths) gets a full plan.  (Streaming stores for these columns -- written once, read once -- were
     // measured: the half-step then fetches its plan entries from HBM instead of the Infinity Cache, C2 23.61 -> 24.19 us/step,
     // C3 stored 57.5 -> 61.5; profiles/r03/ab_nt_plan_stores.txt.)
-    const bool full = ONLY_STRETCH ? false : !B.lean;      // (the stretch-only form: lean plans without dependency columns, no timing switches)
+    const bool full = ONLY_STRETCH ? false : !B.lean;      // (the stretch-only form: lean plans, no timing switches)
     if (!ONLY_STRETCH && (B.ablate & 2)) {                                  // timing experiments: keep the arithmetic alive, write one word
         if (i + a0 + a1 + a2 == -12345 && z + u == 1.2345e-300) B.order[b][pos] = i;
         return;
@@ -2560,33 +2549,6 @@ static __device__ __forceinline__ void native_plan_batch_body(const NativeBatchA
     }
     B.order[b][pos] = i;
     B.p0[b][pos] = a0;
-    if (!ONLY_STRETCH && !full && B.deps && mv == MOVE_STRETCH) {
-        // k_persist_p2p: which tile's word of the half-step BEFORE this one decides about the partner's row (p1) and about this
-        // walker's own row (p2) -- the slot (tile = slot >> 4, row = slot & 15) the walker had in that half-step's update set, or
-        // -1 when it was not in it.  Split k > 0: the half-step before is split k - 1 of this step -- the partner is member
-        // dep_tt of set dep_j (stretch.py:30-32), the own walker was not updated.  Split 0: the last split of the step before,
-        // one evaluation of THAT step's keyed permutation per walker (perm_fwd: position = slot * S + split).
-        if (split > 0) {
-            a1 = dep_j == split - 1 ? dep_tt : -1;
-            a2 = -1;
-        } else {
-            const int Sp = b > 0 ? B.S[b - 1] : B.Sprev0;
-            a1 = a2 = -1;
-            if (Sp > 0) {
-                const PermKey& pkp = b > 0 ? (B.desc ? B.desc[b - 1].nat.pk : B.nat[b - 1].pk) : B.pkprev0;
-                const uint32_t pp = perm_fwd((uint32_t)a0, pkp), pi = perm_fwd((uint32_t)i, pkp);
-                if (Sp == 2) {
-                    a1 = (pp & 1u) ? (int)(pp >> 1) : -1;
-                    a2 = (pi & 1u) ? (int)(pi >> 1) : -1;
-                } else {
-                    a1 = (int)(pp % (uint32_t)Sp) == Sp - 1 ? (int)(pp / (uint32_t)Sp) : -1;
-                    a2 = (int)(pi % (uint32_t)Sp) == Sp - 1 ? (int)(pi / (uint32_t)Sp) : -1;
-                }
-            }
-        }
-        B.p1[b][pos] = a1;
-        B.p2[b][pos] = a2;
-    }
     if (full || mv == MOVE_DE || mv == MOVE_SNOOKER) B.p1[b][pos] = a1;
     if (full || mv == MOVE_SNOOKER) B.p2[b][pos] = a2;
     if (full || mv != MOVE_SNOOKER) B.s0[b][pos] = z;
@@ -2597,7 +2559,7 @@ static __device__ __forceinline__ void native_plan_batch_body(const NativeBatchA
 
 static __global__ __launch_bounds__(256) void k_native_plan_batch(const NativeBatchArgs B) { native_plan_batch_body<false>(B); }
 
-// The same plans for a batch of lean stretch steps alone, without the other moves' branches, the dependency columns and the
+// The same plans for a batch of lean stretch steps alone, without the other moves' branches and the
 // descriptor path: 32 vector registers against 80.  (Round 5 also ran it on a low-priority stream of its own NEXT to the resident
 // persistent launch that reads the batch before -- it fits the 48 registers per SIMD a CU has left beside a k_persist workgroup --
 // with launches ending at batch boundaries: the kernel stretches from 14 to 59 us, the persistent launches slow down by what it

@@ -32,9 +32,6 @@ hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t ld
 // half-steps in one launch.  The grid must be co-resident
 // (one workgroup per CU at most).
 hipError_t launch_hot_persist_dense(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
-// ... and the stretch move's form without a barrier between the half-steps (k_persist_p2p, emx_persist_p2p.hpp)
-hipError_t launch_hot_persist_p2p(int dpb, int chain, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
-hipError_t hot_persist_p2p_occupancy(int dpb, int threads, size_t lds, int* per_cu);
 // workgroups of that k_persist instantiation a CU holds at once, by the runtime's occupancy calculator
 hipError_t hot_persist_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu);
 // ... and the Gaussian Metropolis move's (k_persist_gauss: a wave keeps its walkers in registers; no barrier, any grid)

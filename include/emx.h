@@ -400,13 +400,6 @@ int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
  * behind each of its last 64 steps and is taken back to the one in front of the launch; only when that is not possible (further
  * back than that) does status bit 3 stay, as for a barrier that timed out in the middle of a launch. */
 int emx_persist_local_launches(emx_ctx* ctx, int64_t* n);
-/* ... and how many took the form WITHOUT a barrier between the half-steps (csrc/emx_persist_p2p.hpp): the stretch move
- * (moves/stretch.py:26-33) on the fused dense Gaussian in the device-wide form with EMX_RNG_PHILOX plans -- BASELINE's headline
- * configuration.  red_blue.py:85,104 (split k + 1 sees every update of split k) holds row by row instead of launch-wide: a tile
- * publishes {half-step | 16 accept bits} once its commits are acknowledged, the plan names the tile whose word decides about every
- * row a slot reads, all rows are loaded speculatively one half-step ahead and only the rows that moved are loaded again.  Same
- * bits as the other forms; tuning "persist_p2p" = 0: the device-wide barrier instead. */
-int emx_persist_p2p_launches(emx_ctx* ctx, int64_t* n);
 /* host only: the grid the persistent kernel takes for `nwalkers` walkers updated in `nsplits` half-steps on a device of `num_cu`
  * CUs -- waves per workgroup (8 / 4 / 2 / 1; 0: no persistent grid, the per-half-step launches run) and workgroups */
 int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, int32_t* waves_per_group, int32_t* groups);

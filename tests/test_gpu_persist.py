@@ -69,49 +69,12 @@ def test_persistent_kernel_gives_the_bits_of_the_launch_per_halfstep_path(N, D):
     assert np.array_equal(p["acc"], c["acc"])
 
 
-@pytest.mark.parametrize("N,D,store,thin_by,local", [(65536, 64, False, 1, 1), (65536, 64, True, 2, 1), (49152, 64, False, 1, 1), (32768, 64, True, 1, 1),
-                                                     (16384, 50, False, 1, 1), (65536, 32, True, 1, 1), (16384, 24, False, 1, 1), (65536, 16, False, 1, 1),
-                                                     (8192, 64, True, 1, 0), (2080, 64, False, 1, 0), (1024, 48, True, 3, 0), (512, 64, False, 1, 0),
-                                                     (24576, 62, True, 1, 1), (40960, 64, False, 1, 1)])
-def test_form_without_a_barrier_between_the_half_steps(N, D, store, thin_by, local):
-    """csrc/emx_persist_p2p.hpp (include/emx.h emx_persist_p2p_launches): the stretch move's device-wide launches publish a word per
-    tile and half-step instead of meeting at a device-wide barrier, load every row one half-step ahead and re-load the rows whose
-    accept bit is set.  Two calls of 37 steps (full and partial launches, launches spanning plan batches), with and without a
-    stored chain: coordinates, log-probs, accept marks, chain rows and accept counters bit-equal to the barrier form (tuning
-    persist_p2p = 0) and to the launch-per-half-step path (persist = 0); the sizes cover workgroups of 8, 4, 2 and 1 waves and every
-    row layout (`local` = 0: sizes that would otherwise take the one-XCD form)."""
-    spec = dense_spec(N, D)
-    recs = {}
-    for name, persist, p2p in (("p2p", 1, 1), ("barrier", 1, 0), ("plain", 0, 0)):
-        ens = native_ens(spec, persist)
-        ens.set_tuning("persist_p2p", p2p)
-        ens.set_tuning("persist_local", local)
-        if store:
-            ens.chain_config(74)
-        for _ in range(2):
-            ens.run(37, thin_by, store)
-        assert ens.status() == 0
-        x, lp = ens.get_state()
-        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=ens.persist_info())
-        if store:
-            rec.update(chain=ens.chain_read(0, 0, 74), chain_lp=ens.chain_read(1, 0, 74), counts=ens.accepted_counts())
-        ens.close()
-        recs[name] = rec
-    ip = recs["p2p"]["info"]
-    assert ip["p2p_launches"] == ip["launches"] > 0 and ip["halfsteps"] == 2 * 74 * thin_by and ip["recovered"] == 0
-    assert recs["barrier"]["info"]["p2p_launches"] == 0 and recs["barrier"]["info"]["launches"] > 0
-    assert recs["plain"]["info"]["launches"] == 0
-    for key in recs["plain"]:
-        if key != "info":
-            assert np.array_equal(recs["p2p"][key], recs["plain"][key]), "without a barrier: " + key
-            assert np.array_equal(recs["barrier"][key], recs["plain"][key]), "barrier form: " + key
-
-
 @pytest.mark.parametrize("N,trials,store,thin_by", [(65536, 60, False, 1), (32768, 60, False, 1), (16384, 40, True, 1)])
 def test_barrier_form_coherence_stress(N, trials, store, thin_by):
-    """k_persist's device-wide barrier form (what the DE / snooker / exact-mode launches still run; tuning persist_p2p = 0 for the
-    stretch move) under many short runs, as test_persistent_kernel_coherence_stress below does for the default forms"""
-    _stress(N, trials, store, thin_by, p2p=0)
+    """k_persist's device-wide barrier of arrival counters (read-modify-write atomics beyond the L2; tuning persist_hier = 0 -- what
+    a grid of more than 256 workgroups still runs) under many short runs, as test_persistent_kernel_coherence_stress below does for
+    the default, hierarchical barrier"""
+    _stress(N, trials, store, thin_by, hier=0)
 
 
 @pytest.mark.parametrize("N,D,store,thin_by,move", [(512, 64, False, 1, "stretch"), (1024, 64, True, 1, "stretch"), (2048, 32, False, 1, "stretch"),
@@ -553,18 +516,18 @@ def test_persistent_kernel_coherence_stress(N, trials, store, thin_by):
     once in ~120 runs) does not show in a single 37-step run: many short runs do.  366 trials x 50 steps in all, fresh Philox
     seed each, every trial bit-compared with the launch-per-half-step path started from the same state (both ensembles carry
     their own state from trial to trial: one differing bit fails the trial it appears in).  ~30 s.  Above 8 192 walkers the
-    persistent form is the one without a barrier (k_persist_p2p): its words, speculative loads and lagging gate are what is
-    stressed there."""
-    _stress(N, trials, store, thin_by, p2p=1)
+    device-wide form runs its hierarchical barrier (round 6, persist_barrier_hier: flag words inside an XCD, one word per XCD
+    across): its plain-store / sc1-load protocol is what is stressed there."""
+    _stress(N, trials, store, thin_by, hier=1)
 
 
-def _stress(N, trials, store, thin_by, p2p):
+def _stress(N, trials, store, thin_by, hier):
     nsteps = 50
     spec = dense_spec(N, 64, seed=11)
     ens = []
     for persist in (1, 0):
         e = native_ens(spec, persist)
-        e.set_tuning("persist_p2p", p2p)
+        e.set_tuning("persist_hier", hier)
         if store:
             e.chain_config(nsteps)
         ens.append(e)
@@ -586,7 +549,7 @@ def _stress(N, trials, store, thin_by, p2p):
     p, c = ens[0].persist_info(), ens[1].persist_info()
     assert p["halfsteps"] == 2 * nsteps * thin_by * trials and c["launches"] == 0
     assert (p["local_launches"] == p["launches"]) == (N <= 8192) and p["recovered"] == 0
-    assert p["p2p_launches"] == (p["launches"] if (p2p and N > 8192) else 0)
+    assert p["hier_launches"] == (p["launches"] if (hier and N > 8192) else 0)
     for e in ens:
         e.close()
 
