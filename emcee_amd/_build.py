@@ -6,7 +6,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip", "emx_hot.hip", "emx_wide.hip", "emx_mtdev.hip", "emx_slab.hip", "emx_pvalu.hip", "emx_pmix.hip")]     # translation units, built in parallel
 SRC = SRCS[0]
-LIB = os.path.join(HERE, "libemx.so")
+# EMX_BUILD_FLAVOUR=exp: the experiments flavour (-DEMX_EXPERIMENTS=1: the timing experiments' skip-phase switches, tuning "ablate",
+# tools/ablate.py) as libemx_exp.so beside the product library; load it with EMX_LIB=<path>.  The product is built without them.
+FLAVOUR = os.environ.get("EMX_BUILD_FLAVOUR", "")
+LIB = os.path.join(HERE, "libemx_exp.so" if FLAVOUR == "exp" else "libemx.so")
 HOST_SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx_mtpipe.cpp", "emx_mtjump.cpp")]       # plain host C++ (threads, SIMD clones): no device pass
 # every header of csrc/ (globbed: round 5's emx_planlog.hpp / emx_logtab.hpp were missing from a hand-kept list, so an edit of the
 # kernels' logarithm rebuilt nothing) + the C ABI
@@ -15,7 +18,8 @@ DEPS = SRCS + HOST_SRCS + sorted(os.path.join(HERE, "csrc", f) for f in os.listd
 HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread", "-fvisibility=hidden"]
 # -ffp-contract=off: the proposal arithmetic must round like NumPy's separate multiply/subtract.
 # -fvisibility=hidden: the library exports the C ABI of include/emx.h and nothing else (the extern "C" regions push default visibility)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-Wno-constant-logical-operand", "-fPIC", "-fvisibility=hidden"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-Wno-constant-logical-operand", "-fPIC", "-fvisibility=hidden"] + (
+    ["-DEMX_EXPERIMENTS=1"] if FLAVOUR == "exp" else [])
 # emx_hot.hip (the headline kernel alone): the ILP instruction scheduler, +2.2 % there (csrc/emx_launch.hpp says why not everywhere)
 EXTRA_FLAGS = {"emx_hot.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 

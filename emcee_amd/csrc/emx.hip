@@ -347,7 +347,6 @@ struct emx_ctx {
         hipEvent_t consumed = nullptr;
         hipEvent_t consumed_ref = nullptr; // the event behind the kernels that last read this slot (its own, or a persistent launch's)
         hipEvent_t uploaded = nullptr;     // pipeline uploads: the copy is done (upload stream)
-        hipEvent_t uploaded2 = nullptr, uploaded_ref2 = nullptr;     // ... its second half (second upload stream), where it went up in two
         hipEvent_t uploaded_ref = nullptr; // the event that says this slot's latest upload is done ...
         unsigned last_seq = 0;             // the persistent launch that last read this slot's device copy (0: none since the pipeline started)
         int64_t fetch_step = -1;           // ... or (>= 0) the step whose plan k_plan_fetch takes from it: done when *pipe_done > fetch_step
@@ -369,8 +368,6 @@ struct emx_ctx {
     hipStream_t up_stream = nullptr;     // plan uploads overlap the previous step's kernels
     int64_t tune_mt_device_finish = 1;   // 1: stretch steps of the host pipeline are finished on the device (k_plan_raw); 0: by the finisher threads
     int64_t tune_persist_exact_mix = 1;  // 0: exact mode takes the persistent kernels with ONE move only (round 4)
-    int64_t tune_mt_upload_split = 0;    // 1: plans of >= 16 384 walkers go up in two halves on two streams (measured slower: 59-89 against 47 us per step at 65 536 walkers)
-    hipStream_t up_stream2 = nullptr;
     int64_t pipe_raw_steps = 0;          // steps taken that way (emx_pipe_stage_times)
     int64_t tune_mt_pipeline = -1;       // -1: on, finisher threads chosen from the core count; 0: off; k > 0: k finishers
     // exact-mode plans made on the device (emx_mtdev.hpp): one StretchMove, >= 8192 walkers, one replica
@@ -391,7 +388,6 @@ struct emx_ctx {
     int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
     int64_t tune_persist_local_max = 8192;    // largest ensemble that takes it
     int64_t tune_slab = 1;               // 0: never the slab form of the fused dense half-step (emx_slab.hip)
-    int64_t tune_wide_fuse = 0;          // 1: the wide dense path makes the stretch proposal inside its role-split log-prob kernel (no propose launch): bit-equal, SLOWER (profiles/r05/wide_fuse_ab.txt)
     int64_t tune_slab_skew = 1;          // 1: the second wave of every SIMD starts its first tile's row loads when its sibling's rows have arrived
     int64_t tune_mt_device = 1;          // 0: never (the host pipeline / the inline producer instead); 1: from tune_mt_device_min walkers on; 2: from 8192 on
     int64_t tune_mt_device_min = 147456; // (measured: the host pipeline is faster up to 131 072 walkers since round 5 -- 90-102 against 106 us/step there, 214
@@ -498,6 +494,11 @@ struct emx_ctx {
     int64_t tune_persist_gauss_wpb = 0;       // waves per workgroup of k_persist_gauss (0: four)
     int64_t tune_persist_test_skew = 0;      // tests only: added to the barrier count the next launches wait for
     int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_walkers = 512;
+    int64_t tune_persist_hier = 1;       // device-wide persistent launches: 1 / 2 the hierarchical barrier (persist_barrier_hier: leaders release their XCD /
+                                         // every workgroup polls the eight XCD words), 0 the arrival counters.  Set to 0 by persist_settle when a launch found
+                                         // the workgroups of a class blockIdx & 7 on more than one XCD
+    unsigned persist_stamp = 0;          // PersistArgs::stamp0: half-steps the context's persistent launches have run (never reset)
+    int64_t persist_hier_launches = 0;
     int persist_wpb = 8;
     int64_t persist_launches = 0, persist_halfsteps = 0;
     struct PersistCapture {
@@ -823,19 +824,10 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         const bool prof = prof_max > 0 && c->prof_n < prof_max;
         c->prof_max = 0;
         double* const declp = c->launch_declp;      // the commit kernel below writes the decisions, not the propose pass
-        // Round 5, tuning "wide_fuse" = 1 (off by default): for the stretch move on ensembles that take the role-split log-prob kernel
-        // the propose pass is made INSIDE it (WideLpArgs::fuse: the loader waves make the proposal on its way into LDS and store it to
-        // qout).  Bit-equal and slower: the gathers of partner pieces, 128 bytes at a time, all fall into the first macro block's
-        // pass (65 536 x 512: 180 -> 281-289 us per launch for 61.8 us of propose pass saved; 508 -> 591-605 us/step).
-        const bool fuse = c->tune_wide_fuse != 0 && !callback && move == MOVE_STRETCH && !t_hi_dev && !sendbuf && c->world == 1 &&
-                          !order && wide_lp_takes_role_split(t_hi - t_lo, c->num_cu, c->Dp, c->tune_dense_wide == 2);
-        int rc = 0;
-        if (!fuse) {
-            c->launch_declp = nullptr;
-            rc = launch_split(c, move, EMX_TARGET_HOST, S, split, pos0, ns, t_lo, t_hi, mv, ps, order, X, lp, nullptr, nullptr,
+        c->launch_declp = nullptr;
+        int rc = launch_split(c, move, EMX_TARGET_HOST, S, split, pos0, ns, t_lo, t_hi, mv, ps, order, X, lp, nullptr, nullptr,
                               nullptr, nullptr, t_hi_dev);
-            c->launch_declp = declp;
-        }
+        c->launch_declp = declp;
         c->prof_max = prof_max;
         if (rc) return rc;
         w.rows = c->qout;
@@ -843,14 +835,6 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         w.out = c->newlp;
         w.scatter = 0;
         w.check_bad = 1;
-        if (fuse) {
-            w.fuse = 1;
-            w.fX = X;
-            w.fq = c->qout;
-            w.fi = ps->order;
-            w.fa = ps->p0;
-            w.fz = ps->s0;
-        }
         WideCommitArgs k{};
         k.X = X;
         k.lp = lp;
@@ -860,7 +844,7 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         k.chain_lp = chain_lp;
         k.sendbuf = sendbuf;
         k.qout = c->qout;
-        k.fout = fuse ? ps->fac + pos0 : c->fout;       // (the stretch move's factor is the plan's: (D - 1) ln z, stretch.py:31)
+        k.fout = c->fout;
         k.newlp = c->newlp;
         k.order = order ? order : ps->order;
         k.logu = ps->logu;
@@ -1234,7 +1218,6 @@ int emx_destroy(emx_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm), c->comm = nullptr;
     if (c->status_host) hipHostFree(c->status_host);
-    if (c->up_stream2) hipStreamDestroy(c->up_stream2);
     if (c->xfer_host) hipHostFree(c->xfer_host);
     for (int k = 0; k < 2; ++k) {
         if (c->bounce[k]) hipHostFree(c->bounce[k]);
@@ -1252,7 +1235,6 @@ int emx_destroy(emx_ctx* c) {
         if (s.order) hipFree(s.order);       // the slot's single block
         if (s.host) hipHostFree(s.host);
         if (s.uploaded) hipEventDestroy(s.uploaded);
-        if (s.uploaded2) hipEventDestroy(s.uploaded2);
         s.uploaded_ref = nullptr;
         if (s.consumed) hipEventDestroy(s.consumed);
     }
@@ -1408,7 +1390,8 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->prep_hint = v > 0 ? v : 1;
         return 0;
     }
-    if (!strcmp(key, "ablate")) {
+    if (!strcmp(key, "ablate")) {       // timing experiments (tools/ablate.py): compiled into the experiments flavour only
+        NEED(c, EMX_EXPERIMENTS || v == 0, "tuning \"ablate\" needs the experiments build of the library (EMX_BUILD_FLAVOUR=exp python -m emcee_amd._build; EMX_LIB=.../libemx_exp.so)");
         c->tune_ablate = v;
         return 0;
     }
@@ -1449,17 +1432,9 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_persist_exact_mix = v ? 1 : 0;
         return 0;
     }
-    if (!strcmp(key, "mt_upload_split")) {
-        c->tune_mt_upload_split = v ? 1 : 0;
-        return 0;
-    }
     if (!strcmp(key, "mt_device_finish")) {      // 0: the host pipeline's finisher threads convert every draw themselves (rounds 1-4)
         PIPE_STOP(c);
         c->tune_mt_device_finish = v ? 1 : 0;
-        return 0;
-    }
-    if (!strcmp(key, "wide_fuse")) {
-        c->tune_wide_fuse = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "slab_skew")) {
@@ -1468,6 +1443,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
         c->tune_persist = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_hier")) {      // the device-wide form's barrier: 0 arrival counters, 1 hierarchical (leaders release), 2 hierarchical (everyone polls)
+        c->tune_persist_hier = (v == 1 || v == 2) ? v : 0;
         return 0;
     }
     if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)
@@ -2108,7 +2087,7 @@ static void pipe_poll(void* arg) {
         auto& s = c->ring[(c->pipe_ring0 + n % c->pipe_nsinks) % PLAN_RING];
         if (s.fetch_step >= 0) {
             if (!c->pipe_done || __atomic_load_n(c->pipe_done, __ATOMIC_ACQUIRE) <= (unsigned long long)s.fetch_step) break;
-        } else if (!s.uploaded_ref || hipEventQuery(s.uploaded_ref) != hipSuccess || (s.uploaded_ref2 && hipEventQuery(s.uploaded_ref2) != hipSuccess)) {
+        } else if (!s.uploaded_ref || hipEventQuery(s.uploaded_ref) != hipSuccess) {
             break;
         }
         c->pipe->release(n);
@@ -2296,7 +2275,6 @@ static int pipe_take(emx_ctx* c) {
         // should any path get here all the same
         NEED(c, !info.raw, "exact-mode plan pipeline: a raw (device-finish) step reached the persistent launch's fetch");
         s.uploaded_ref = nullptr;
-        s.uploaded_ref2 = nullptr;
         s.fetch_step = n;
         s.host_written = true;
         c->pipe_deferred.push_back({n, slot});
@@ -2310,27 +2288,14 @@ static int pipe_take(emx_ctx* c) {
     const bool still_read = s.busy && hipEventQuery(s.consumed_ref) != hipSuccess;
     if (still_read) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed_ref, 0));
     const int stretch = c->moves[cur.move].kind == EMX_MOVE_STRETCH;
-    const bool two = c->tune_mt_upload_split != 0 && N >= 16384;
-    const size_t bytes = plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE), half = two ? (bytes / 2) & ~(size_t)255 : bytes;
+    const size_t bytes = plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE);
     // The upload stream carries copies only: the conversion kernel behind a copy made every step's upload wait for a compute unit
     // the half-step kernels hold (54 us per step of 65 536 walkers whatever the pipeline did; profiles/r05/exact_c2.md) -- it now
-    // runs on the consumer's stream, in front of the half-steps that need it.  A large plan goes up in two halves on two streams:
-    // one copy engine moves 1.57 MB in 37 us, two in 30 (profiles/r05/h2d_rate.txt).
-    HIPOK(c, hipMemcpyAsync(s.order, s.host, half, hipMemcpyHostToDevice, c->up_stream));
+    // runs on the consumer's stream, in front of the half-steps that need it.  (A large plan in two halves on two streams -- one
+    // copy engine moves 1.57 MB in 37 us, two in 30, profiles/r05/h2d_rate.txt -- was slower end to end and is gone: round 6.)
+    HIPOK(c, hipMemcpyAsync(s.order, s.host, bytes, hipMemcpyHostToDevice, c->up_stream));
     HIPOK(c, hipEventRecord(s.uploaded, c->up_stream));
     HIPOK(c, hipStreamWaitEvent(c->stream, s.uploaded, 0));
-    if (two) {
-        if (!c->up_stream2) {
-            int lo = 0, hi = 0;
-            HIPOK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPOK(c, hipStreamCreateWithPriority(&c->up_stream2, hipStreamNonBlocking, hi));
-        }
-        if (!s.uploaded2) HIPOK(c, hipEventCreateWithFlags(&s.uploaded2, hipEventDisableTiming));
-        if (still_read) HIPOK(c, hipStreamWaitEvent(c->up_stream2, s.consumed_ref, 0));
-        HIPOK(c, hipMemcpyAsync(reinterpret_cast<char*>(s.order) + half, s.host + half, bytes - half, hipMemcpyHostToDevice, c->up_stream2));
-        HIPOK(c, hipEventRecord(s.uploaded2, c->up_stream2));
-        HIPOK(c, hipStreamWaitEvent(c->stream, s.uploaded2, 0));
-    }
     if (info.raw) {
         // device finish: the columns hold `order` and generator words (or accepted randint values); converted in place
         PlanRawArgs R{};
@@ -2350,7 +2315,6 @@ static int pipe_take(emx_ctx* c) {
     }
     HIPOK(c, hipGetLastError());
     s.uploaded_ref = s.uploaded;
-    s.uploaded_ref2 = two ? s.uploaded2 : nullptr;
     s.fetch_step = -1;
     s.host_written = true;
     c->pipe_uploads.push_back(n);
@@ -2410,7 +2374,6 @@ static int pipe_fetch_deferred(emx_ctx* c) {
     HIPOK(c, hipStreamWaitEvent(c->stream, ev, 0));
     for (auto& d : c->pipe_deferred) {
         c->ring[d.second].uploaded_ref = ev;
-        c->ring[d.second].uploaded_ref2 = nullptr;
     }
     c->pipe_deferred.clear();
     return 0;
@@ -3654,7 +3617,17 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         c->persist_hepoch += 1u;
     }
     P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
-    c->persist_epoch += (unsigned)n;          // the handshake and the n - 1 barriers between the half-steps
+    // the device-wide form's barrier between the half-steps: hierarchical when every class blockIdx & 7 has at most 64 workgroups
+    // (two flag lines per class: every grid persist_shape_of makes); the arrival counters then count the handshake alone
+    P.hier = (!launch_local && grid.x >= 8u && grid.x <= 512u) ? (int32_t)c->tune_persist_hier : 0;
+    P.stamp0 = c->persist_stamp;
+    c->persist_stamp += (unsigned)n;
+    if (P.hier) {
+        c->persist_epoch += 1u;
+        c->persist_hier_launches++;
+    } else {
+        c->persist_epoch += (unsigned)n;      // the handshake and the n - 1 barriers between the half-steps
+    }
     P.seq = ++c->persist_seq;
     lg.seq = P.seq;
     lg.steps = steps;
@@ -3736,7 +3709,7 @@ static int persist_settle(emx_ctx* c) {
         c->plog.clear();
         return 0;
     }
-    unsigned w[4] = {0, 0, 0, 0};
+    unsigned w[6] = {0, 0, 0, 0, 0, 0};
     HIPOK(c, hipMemcpy(w, c->persist_bar + 9 * 32, sizeof(w), hipMemcpyDeviceToHost));
     if (w[1] != 1u) {           // not (only) a clean handshake time-out: a direct-exchange barrier, or the middle of a launch
         c->plog.clear();
@@ -3767,7 +3740,9 @@ static int persist_settle(emx_ctx* c) {
     const uint64_t ph_end = c->ph_step;
     for (const auto& m : c->moves) NEED(c, m.kind != EMX_MOVE_GAUSS, "persistent launches to redo in a mixture with a Gaussian move");
     drop_prepared(c);                         // (the ring slots of plans made ahead are about to be reused)
-    if ((w[2] & (w[2] - 1u)) != 0u)
+    if (w[5] != 0u)
+        c->tune_persist_hier = 0;             // the workgroups of a class blockIdx & 7 did not share an XCD: the arrival-counter barrier from here on ("persist_hier" = 1)
+    else if ((w[2] & (w[2] - 1u)) != 0u)
         c->tune_persist_local = 0;            // the one-XCD form's workgroups did not share an XCD: that form stays off ("persist_local" = 1)
     else
         c->tune_persist = 0;                  // and it stays off: whatever held the CUs may still be there ("persist" = 1 turns it back on)
@@ -3881,6 +3856,11 @@ int emx_persist_info(emx_ctx* c, int64_t out[4]) {
 
 int emx_persist_local_launches(emx_ctx* c, int64_t* n) {
     *n = c->persist_local_launches;
+    return 0;
+}
+
+int emx_persist_hier_launches(emx_ctx* c, int64_t* n) {
+    *n = c->persist_hier_launches;
     return 0;
 }
 

@@ -56,18 +56,7 @@ struct WideLpArgs {
     const int32_t* t_hi_dev;     // device-side slot count (block-ownership exchanges), or nullptr
     int32_t D, Dp, pos0, t_lo, t_hi, scatter, check_bad;
     int32_t single_role;         // 1: never the role-split kernel (tuning "dense_wide" = 2: parity tests of the two kernels)
-    // Fused propose (round 5, the role-split kernel only, stretch move): `rows` = qout is WRITTEN here -- in the pass over the first
-    // macro block, which visits every 16-column block of a row once, the loader waves read the walker's and its partner's pieces
-    // from X, make the proposal (stretch.py:33, make_proposal's arithmetic), store it to qout and hand it on; the later macro
-    // blocks read qout back.  The separate propose launch (read two rows, write one: at the HBM roofline) disappears under the MFMAs.
-    int32_t fuse;
-    const double* fX;            // the ensemble
-    double* fq;                  // qout (== rows)
-    const int32_t* fi;           // plan: walker of slot t at fi[pos0 + t] ...
-    const int32_t* fa;           // ... its partner at fa[pos0 + t] ...
-    const double* fz;            // ... the stretch factor at fz[pos0 + t]
 };
-bool wide_lp_takes_role_split(int nrows_bound, int num_cu, int Dp, int single_role);
 struct WideCommitArgs {
     double* X;
     double* lp;

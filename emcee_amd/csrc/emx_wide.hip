@@ -262,10 +262,9 @@ __device__ __forceinline__ void slab_mfma2(double4_t (&acc0)[8], double4_t (&acc
     }
 }
 
-// FUSE: the stretch proposal made by the loader waves (WideLpArgs::fuse).  A compile-time switch: as a run-time one its registers
-// (the walker's and the partner's pieces, pointers, factors) pushed the loaders into scratch and cost the UNFUSED launches a quarter
-// of their speed (65 536 x 512: 179.6 -> 224 us per launch, 509 -> 598 us/step; profiles/r05/wide_fuse_ab.txt).
-template <bool FUSE>
+// (Round 5 built the stretch proposal INTO the loader waves -- one launch fewer per half-step -- bit-equal and 16-19 % slower: the
+// gathers of partner pieces all fall into the first macro block's pass; profiles/r05/wide_fuse_ab.txt.  Removed in round 6; git
+// history has it: `git show 8adb33a:emcee_amd/csrc/emx_wide.hip`.)
 __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];      // slab[2][SLAB] | A tiles [2][8][16][ART] | mu[Dp] | bad[8][16][8]
     typedef double4_t d4;
@@ -298,12 +297,9 @@ __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
             int boff[4], bj[4];
             // row pieces: (tile w, row, 16-byte piece) number e of 8 x 16 x 8
             const double* rbase[4];
-            const double *xibase[4], *xabase[4];                // fused propose: the walker's and its partner's rows
-            double zr[4];
             bool rlive[4];
             int aoff[4], apc[4];
             bool bad[4] = {false, false, false, false};
-            constexpr bool fuse = FUSE;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int e = lt + r * WS_NLT, chunk = e >> 5, within = e & 31;
@@ -315,42 +311,15 @@ __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
                 rbase[r] = A.rows + (size_t)(rlive[r] ? (A.order ? A.order[A.pos0 + t] : t) : 0) * D;
                 aoff[r] = (w * 16 + row) * ART + 2 * pc;
                 apc[r] = 2 * pc;
-                if (fuse) {
-                    const int pos = A.pos0 + (rlive[r] ? t : A.t_lo);
-                    xibase[r] = A.fX + (size_t)A.fi[pos] * D;
-                    xabase[r] = A.fX + (size_t)A.fa[pos] * D;
-                    zr[r] = A.fz[pos];
-                } else {
-                    xibase[r] = xabase[r] = rbase[r];
-                    zr[r] = 0.0;
-                }
             }
-            double2 bn[4], xn[4], xan[4];
-            bool pend_fused = false;                            // what `issue` loaded last: the two pieces of a proposal still to be made
+            double2 bn[4], xn[4];
             auto issue = [&](int nbb, int sp) {                // raw loads only; first use one slab later
                 const int ncb = min(8, DPB - 8 * nbb), kb = 8 * nbb + sp;
                 const double2* src = img2 + ((size_t)(8 * nbb) * KK + 4 * kb) * 32;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bn[r] = bj[r] < ncb ? src[boff[r]] : double2{0.0, 0.0};
                 const int k0 = 16 * kb;
-                pend_fused = fuse && nbb == 0;                 // (the first macro block's pass meets every k block once)
-                if (pend_fused) {
-                    if (k0 + 16 <= D) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double2_a8 v = *reinterpret_cast<const double2_a8*>(xibase[r] + k0 + apc[r]);
-                            const double2_a8 u = *reinterpret_cast<const double2_a8*>(xabase[r] + k0 + apc[r]);
-                            xn[r] = double2{v.x, v.y};
-                            xan[r] = double2{u.x, u.y};
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            xn[r] = double2{xibase[r][min(k0 + apc[r], D - 1)], xibase[r][min(k0 + apc[r] + 1, D - 1)]};
-                            xan[r] = double2{xabase[r][min(k0 + apc[r], D - 1)], xabase[r][min(k0 + apc[r] + 1, D - 1)]};
-                        }
-                    }
-                } else if (k0 + 16 <= D) {                     // uniform: the whole k block lies inside the rows
+                if (k0 + 16 <= D) {                            // uniform: the whole k block lies inside the rows
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double2_a8 v = *reinterpret_cast<const double2_a8*>(rbase[r] + k0 + apc[r]);
@@ -370,19 +339,6 @@ __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
                 for (int r = 0; r < 4; ++r) {
                     bdst[lt + r * WS_NLT] = bn[r];
                     const int k = k0 + apc[r];
-                    if (pend_fused) {
-                        // stretch.py:33  q = c[rint] - (c[rint] - s) * zz, rounded operation by operation as make_proposal does
-                        const double d0 = xan[r].x - xn[r].x, d1 = xan[r].y - xn[r].y;
-                        const double p0 = d0 * zr[r], p1 = d1 * zr[r];
-                        xn[r] = double2{xan[r].x - p0, xan[r].y - p1};
-                        if (rlive[r]) {
-                            double* qd = A.fq + (rbase[r] - A.rows) + k;
-                            if (k + 1 < D)
-                                *reinterpret_cast<double2_a8*>(qd) = double2_a8{xn[r].x, xn[r].y};
-                            else if (k < D)
-                                qd[0] = xn[r].x;
-                        }
-                    }
                     const double x0 = (rlive[r] && k < D) ? xn[r].x : 0.0, x1 = (rlive[r] && k + 1 < D) ? xn[r].y : 0.0;
                     bad[r] |= (__double2hiint(x0) & 0x7ff00000) == 0x7ff00000 || (__double2hiint(x1) & 0x7ff00000) == 0x7ff00000;
                     *reinterpret_cast<double2*>(adst + aoff[r]) = double2{x0 - muS[k], x1 - muS[k + 1]};
@@ -405,7 +361,6 @@ __global__ __launch_bounds__(WS_NT) void k_wide_lp_ws(const WideLpArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 badS[lt + r * WS_NLT] = bad[r] ? 1 : 0;
-                if (fuse && bad[r] && rlive[r]) raise_status(A.status, ST_BAD_COORD);      // (the propose pass raised it: ensemble.py:476-479)
             }
             __syncthreads();                                   // the flags are visible to the deciding lanes
             __syncthreads();                                   // ... and read before the next pass overwrites anything
@@ -702,14 +657,6 @@ hipError_t launch_lp(const WideLpArgs& a, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-// the rule below, for the caller that wants to fuse the propose pass into the role-split kernel
-bool wide_lp_takes_role_split(int nrows_bound, int num_cu, int Dp, int single_role) {
-    if (nrows_bound <= 0 || single_role) return false;
-    const int ntiles = (nrows_bound + 15) / 16, nmacro = (Dp / 16 + 7) / 8;
-    if (nmacro >= 2 && ntiles < num_cu * (nmacro >= 4 ? 5 : 3)) return false;
-    return ntiles >= 8 * num_cu;
-}
-
 hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipStream_t st) {
     if (nrows_bound <= 0) return hipSuccess;
     const int ntiles = (nrows_bound + 15) / 16;
@@ -737,15 +684,11 @@ hipError_t launch_wide_lp(const WideLpArgs& a, int nrows_bound, int num_cu, hipS
         static size_t lds_granted[MAX_DEVICES] = {};
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_wide_lp_ws<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_wide_lp_ws<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const hipError_t e = hipFuncSetAttribute((const void*)k_wide_lp_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             lds_granted[dev] = lds;
         }
-        if (a.fuse)
-            hipLaunchKernelGGL(k_wide_lp_ws<true>, grid, dim3(WS_NT), lds, st, a);
-        else
-            hipLaunchKernelGGL(k_wide_lp_ws<false>, grid, dim3(WS_NT), lds, st, a);
+        hipLaunchKernelGGL(k_wide_lp_ws, grid, dim3(WS_NT), lds, st, a);
         return hipGetLastError();
     }
     switch (W) {

@@ -81,25 +81,53 @@ int emx_sync(emx_ctx* ctx);
  * it are void; the call that retires the producer (emx_run's next start, emx_rng_get_mt19937, emx_set_moves ...) returns the
  * error as well and leaves the generator where it stood before the producer started.  Reading clears it. */
 int emx_status(emx_ctx* ctx, uint32_t* bits);
-/* keys: "spw", "blocks_per_cu", "waves_per_block", "prep_hint", "graph", "throttle", "gauss_materialize",
- * "small_kernel" (1: ensembles that fit one CU's LDS run whole emx_run calls in one workgroup; default),
- * "mt_pipeline" (MT19937 mode, emx_run: -1 plans from the threaded host pipeline, finisher threads chosen from the core
- * count (default); k > 0: k finisher threads; 0: plans made inline by the calling thread),
- * "dense_wide" (1: dense targets take the propose / log-prob / commit path of wide targets whatever the ndim; 2: the same with
- * the single-role log-prob kernel even where the role-split one applies; parity tests),
- * "full_plan" (1: native plans carry every column; default 0: only the ones the fused kernel of the step's move reads),
- * "direct_timeout_ms" (device-side barriers of the direct and replay exchanges; the first barrier of an emx_run waits 6x longer),
- * "ablate" (timing experiments: bits 0-7 half-step phases, bits 8.. plan kernel), "phase_clock" (instrumented builds),
- * round 5: "mt_device_finish" (1, default: a stretch step of the host pipeline goes up as `order` + the MT19937 state words of its
- * uniforms, in the plan's own columns, and k_plan_raw tempers / converts / resolves partners / takes the logs on the device; 0: the
- * finisher threads do), "persist_exact_mix" (1, default: exact mode takes the persistent kernels with move mixtures too),
- * "wide_fuse" (0, default: a propose launch of its own; 1: the wide dense path makes the stretch proposal inside its role-split log-prob kernel -- the same bits, measured slower),
- * "slab_skew" (0 ... 4; 1 default: in the slab form of the fused dense half-step, padded ndim 112 / 128, the second wave of
- * every SIMD starts its first tile's row loads when its sibling's have arrived), "mt_upload_split" (1: plans of >= 16 384 walkers
- * go up in two halves on two streams; measured slower, default 0).
- * The environment variable EMX_TUNE="key=value,key=value" applies keys to every context at creation (A/B measurements through
- * unmodified callers).  After a barrier timeout (status bit 3) the context refuses further sharded half-steps until the peers are
- * attached again (emx_direct_export / _import or _attach on every rank). */
+/* Tuning keys (A/B measurements, parity tests; defaults are what the product runs).  An unknown key is an error.  The environment
+ * variable EMX_TUNE="key=value,key=value" applies keys to every context at creation.  One table -- nothing measured-and-rejected is
+ * left behind a key (round 6: the p2p form, the fused wide propose and the split upload were removed from the library):
+ *
+ *   key                        default   meaning
+ *   -- launch shape of the per-half-step kernels --
+ *   "spw"                      0 (auto)  slots per wave                      "blocks_per_cu"     2         workgroups a CU is given
+ *   "waves_per_block"          0 (auto)  1 / 2 / 4 / 8                       "throttle"          0         half-steps in flight (0: unbounded)
+ *   "graph"                    0         1: a 16-step block of Philox launches replayed as a hipGraph
+ *   "prep_hint"                1         steps a caller of emx_step_begin will take (Philox plan batch size)
+ *   "full_plan"                0         1: Philox plans carry every column (default: the ones the step's fused kernel reads)
+ *   "small_kernel"             1         ensembles that fit one workgroup's LDS run whole emx_run calls in one workgroup
+ *   "gauss_materialize"        0         Gaussian move: 1: proposals through memory (parity tests of the register form)
+ *   -- dense targets --
+ *   "dense_wide"               0         1: the propose / log-prob / commit path whatever the ndim; 2: ... with the single-role log-prob kernel
+ *   "slab"                     1         0: never the slab form (emx_slab.hip); 1: from padded ndim 112; 2: from padded ndim 80
+ *   "slab_skew"                1         0 ... 4: when the second wave of a SIMD starts its first tile's row loads
+ *   -- persistent kernels (emx_persist_info) --
+ *   "persist"                  1         0: never a persistent launch
+ *   "persist_hier"             1         device-wide form: 1: the hierarchical barrier (flag words inside an XCD, one word per XCD across;
+ *                                        leaders release their XCD), 2: ... every workgroup polls the eight XCD words itself, 0: arrival counters
+ *   "persist_local"            1         0: never the one-XCD form        "persist_local_max_walkers"  8192
+ *   "persist_valu"             1         0: element-wise targets on the per-half-step launches
+ *   "persist_mix"              1         0: DE and snooker steps of a mixture in launches of their own
+ *   "persist_span"             1         0: a launch ends with its Philox plan batch
+ *   "persist_min_walkers"      512       smallest ensemble             "persist_timeout_ms"   2000      bound of a barrier wait
+ *   "persist_gauss_wpb"        0 (auto)  waves per workgroup of k_persist_gauss
+ *   "persist_exact"            1         0: exact mode (EMX_RNG_MT19937) on the per-half-step launches with an upload per step
+ *   "persist_exact_mix"        1         0: ... for one move only      "persist_exact_steps"  16        steps per launch (<= 16)
+ *   "persist_exact_max_walkers" 32768    largest ensemble of the device-wide form in exact mode
+ *   "fetch_blocks"             64        k_plan_fetch's workgroups beside a device-wide launch (0: one per 256 entries)
+ *   "fetch_avoid"              1         k_plan_fetch's workgroups decline on the XCD of a one-XCD launch
+ *   -- exact-mode plan producers --
+ *   "mt_pipeline"              -1        -1: host pipeline, finisher threads from the core count; k > 0: k finishers; 0: inline, calling thread
+ *   "mt_device_finish"         1         0: the finisher threads convert every draw (1: k_plan_raw does, on the device)
+ *   "mt_device"                1         0: never the device producer; 1: from "mt_device_min_walkers" (147456) on; 2: from 8192 on
+ *   "mt_tok_wshift" / "mt_tok_tail"  11 / 2048   the device tokenizer's window rule    "mt_device_lookahead"  batches ahead
+ *   -- exchanges --
+ *   "direct_timeout_ms"        bound of the device-side barriers of the direct and replay exchanges (the first of an emx_run: 6x)
+ *   "replay_two_pass"          0         1: the replay exchange's own pass and replay pass as separate launches
+ *   -- tests / instrumented builds only --
+ *   "persist_test_skew", "test_fetch_delay_us"   make a barrier unmeetable / a fetch late (tests of the give-up and wait paths)
+ *   "phase_clock"              0         instrumented builds (-DEMX_OPT_STAMPS=1): phase timestamps of every launch
+ *   "ablate"                   0         experiments flavour only (EMX_BUILD_FLAVOUR=exp, -DEMX_EXPERIMENTS=1): skip-phase masks; refused otherwise
+ *
+ * After a barrier timeout (status bit 3) the context refuses further sharded half-steps until the peers are attached again
+ * (emx_direct_export / _import or _attach on every rank). */
 int emx_set_tuning(emx_ctx* ctx, const char* key, int64_t value);
 
 /* ---- state: State(coords, log_prob) (state.py:10-45) ---------------------------------- */
@@ -400,6 +428,13 @@ int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
  * behind each of its last 64 steps and is taken back to the one in front of the launch; only when that is not possible (further
  * back than that) does status bit 3 stay, as for a barrier that timed out in the middle of a launch. */
 int emx_persist_local_launches(emx_ctx* ctx, int64_t* n);
+/* ... and how many device-wide launches ran the HIERARCHICAL barrier between their half-steps (round 6; red_blue.py:85,104: split
+ * k + 1 sees every update of split k -- the barrier is where the reference's Python loop has its sequence point): workgroup i of a
+ * launch runs on XCD i mod 8 (verified per launch by the handshake; a launch that finds otherwise gives up untouched, is redone,
+ * and the context keeps to the arrival counters), so arrival is collected inside an XCD through flag words in its L2 (plain
+ * stores, sc1 loads), exchanged across the eight XCDs through one word each, and released per XCD the same way.  Tuning
+ * "persist_hier" = 0: two levels of arrival counters (read-modify-write atomics beyond the L2) as in rounds 3-5.  Same bits. */
+int emx_persist_hier_launches(emx_ctx* ctx, int64_t* n);
 /* host only: the grid the persistent kernel takes for `nwalkers` walkers updated in `nsplits` half-steps on a device of `num_cu`
  * CUs -- waves per workgroup (8 / 4 / 2 / 1; 0: no persistent grid, the per-half-step launches run) and workgroups */
 int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, int32_t* waves_per_group, int32_t* groups);

@@ -174,35 +174,3 @@ def test_slab_kernel_equals_per_tile_kernel_bit_for_bit(N, D, moves, weights, st
         assert np.array_equal(a0[key], b[key]), key
 
 
-@pytest.mark.parametrize("N,D,store", [(65536, 130, False), (65536 + 48, 200, True), (131072, 144, False), (65536, 64, True)])
-def test_propose_made_inside_the_log_prob_kernel_gives_the_same_bits(N, D, store):
-    """Round 5: on ensembles that take the role-split log-prob kernel (>= 8 row tiles per CU) the stretch move's propose pass is made
-    by that kernel's loader waves (WideLpArgs::fuse): the walker's and its partner's pieces come from X, the proposal --
-    stretch.py:33, rounded operation by operation like make_proposal -- goes to qout and into LDS.  Against the three launches
-    (tuning wide_fuse = 0): coordinates, log-probs, accept marks, chain rows and counters bit for bit; a non-finite proposal still
-    raises the bad-coordinate bit.  (ndim 64 goes through the same path with tuning dense_wide = 1.)"""
-    spec = _spec(N, D, [_S("stretch")], seed=29)
-    outs = []
-    nst = 4
-    for fuse in (1, 0):
-        ens = make_ens(spec, spec["p0"])
-        if D <= 128:
-            ens.set_tuning("dense_wide", 1)
-        ens.set_tuning("wide_fuse", fuse)
-        ens.eval_state_log_prob()
-        ens.set_rng_mode(_lib.RNG_PHILOX)
-        ens.set_philox(77, 0)
-        if store:
-            ens.chain_config(nst)
-        ens.run(nst, 1, store)
-        assert ens.status() == 0
-        x, lp = ens.get_state()
-        rec = dict(x=x, lp=lp, acc=ens.accepted_mask().copy())
-        if store:
-            rec.update(chain=ens.chain_read(0, 0, nst), clp=ens.chain_read(1, 0, nst), cnt=ens.accepted_counts())
-        outs.append(rec)
-        ens.close()
-    a, b = outs
-    assert a["acc"].any() and not a["acc"].all()
-    for key in a:
-        assert np.array_equal(a[key], b[key]), key
