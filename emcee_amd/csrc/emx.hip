@@ -494,9 +494,8 @@ struct emx_ctx {
     int64_t tune_persist_gauss_wpb = 0;       // waves per workgroup of k_persist_gauss (0: four)
     int64_t tune_persist_test_skew = 0;      // tests only: added to the barrier count the next launches wait for
     int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_walkers = 512;
-    int64_t tune_persist_hier = 1;       // device-wide persistent launches: 1 / 2 the hierarchical barrier (persist_barrier_hier: leaders release their XCD /
-                                         // every workgroup polls the eight XCD words), 0 the arrival counters.  Set to 0 by persist_settle when a launch found
-                                         // the workgroups of a class blockIdx & 7 on more than one XCD
+    int64_t tune_persist_hier = 1;       // device-wide persistent launches: 1 the hierarchical barrier (persist_barrier_hier), 0 the arrival counters.  Set to 0
+                                         // by persist_settle when a launch found the workgroups of a class blockIdx & 7 on more than one XCD
     unsigned persist_stamp = 0;          // PersistArgs::stamp0: half-steps the context's persistent launches have run (never reset)
     int64_t persist_hier_launches = 0;
     int persist_wpb = 8;
@@ -1445,8 +1444,8 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_persist = v ? 1 : 0;
         return 0;
     }
-    if (!strcmp(key, "persist_hier")) {      // the device-wide form's barrier: 0 arrival counters, 1 hierarchical (leaders release), 2 hierarchical (everyone polls)
-        c->tune_persist_hier = (v == 1 || v == 2) ? v : 0;
+    if (!strcmp(key, "persist_hier")) {      // the device-wide form's barrier: 0 arrival counters, 1 hierarchical
+        c->tune_persist_hier = (v == 1 || v == 2) ? v : 0;      // (2: the flat form, persist_barrier_flat)
         return 0;
     }
     if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)

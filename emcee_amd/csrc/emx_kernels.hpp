@@ -1250,7 +1250,8 @@ constexpr int PERSIST_HIER_BASE = 12 * 32;   // words of PersistArgs::bar in fro
 constexpr int PERSIST_HIER_REL = 8 * 64;     // ... in that block: [8][64] flag words | [8][32] release lines | [8][32] XCD words | [32] XCC masks
 constexpr int PERSIST_HIER_XW = PERSIST_HIER_REL + 8 * 32;
 constexpr int PERSIST_HIER_MASK = PERSIST_HIER_XW + 8 * 32;
-constexpr int PERSIST_HIER_WORDS = PERSIST_HIER_MASK + 32;
+constexpr int PERSIST_HIER_FLAT = PERSIST_HIER_MASK + 32;      // ... | [8][64] the flat form's words (persist_barrier_flat: written through, never by plain stores)
+constexpr int PERSIST_HIER_WORDS = PERSIST_HIER_FLAT + 8 * 64;
 constexpr int PERSIST_BAR_WORDS = PERSIST_HIER_BASE + PERSIST_HIER_WORDS;   // PersistArgs::bar
 struct PersistIter {
     const int32_t *order, *p0, *p1, *p2;  // (p1: the DE move's second partner; p1, p2: the snooker move's z1, z2)
@@ -1273,7 +1274,7 @@ struct PersistArgs {
     int32_t niter;
     unsigned seq;                  // number of this launch (left in the barrier block's fourth `go` word once its grid is known co-resident)
     unsigned stamp0;               // PersistArgs::ver stamps of this launch's half-steps start behind this (unique per half-step of the context)
-    int32_t hier;                  // device-wide form: 0 arrival counters (persist_barrier), 1 / 2 the hierarchical barrier (persist_barrier_hier)
+    int32_t hier;                  // device-wide form: 0 arrival counters (persist_barrier), 1 the hierarchical barrier (persist_barrier_hier)
     unsigned* started_host;        // pinned host word (or null): `seq` again, for the host -- launch k + 1 has started, so launch k is over
 };
 
@@ -1319,9 +1320,8 @@ __device__ __forceinline__ void persist_barrier_local(const PersistArgs& P, unsi
 //               lines (plain store); the class's leader (j = 0) polls them with sc1 loads, one word a lane;
 //   exchange -- across XCDs: the leader stores the tag into its class's OWN line of eight (agent scope: write-through); nobody
 //               reads a line of this group that its own XCD's plain stores ever touched, so an sc1 load of it comes from memory;
-//   release  -- hier = 1: the leaders poll the other seven lines, then each releases its XCD through a release line of the class
-//               (plain store, polled by the members with sc1 loads: that XCD's L2 again);
-//               hier = 2: every workgroup polls the eight lines itself (one hop less, 32 times the pollers on the memory side).
+//   release  -- every workgroup polls the eight lines itself.  (Measured against it, profiles/r06/hier_barrier_ab.txt: the leaders
+//               poll the other seven lines and release their XCD through a line of the class -- one hop more, 2 % slower.)
 // Tags are (launch number << 6 | barrier of the launch): no epoch to keep in step with the arrival counters, which the handshake
 // alone still uses.  Every wait is bounded by the wall clock; a wait that times out (or a dead mark seen) marks the run void
 // (status bit 3, `dead` = 2) and opens every later wait of the launch at once: the class's release line carries a dead word for
@@ -1336,7 +1336,7 @@ __device__ __forceinline__ void persist_barrier_hier(const PersistArgs& P, unsig
         const int per = (int)((gridDim.x + 7u - xcd) >> 3);       // workgroups of this class (<= 64: the host's rule)
         unsigned* const hb = P.bar + PERSIST_HIER_BASE;
         unsigned* const dead_g = P.bar + 9 * 32 + 1;
-        // one descriptor over the block: flags [8][64] | release lines [8][32] (word 0 the tag let through, word 1 the class's dead word)
+        // one descriptor over the block: flags [8][64] | a line per class whose word 1 is the class's dead word
         // | the eight classes' words, a line each
         const __amdgpu_buffer_rsrc_t Hr = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, PERSIST_HIER_WORDS * 4, 0x00020000);
         const int F0 = (int)xcd * 256, L0 = PERSIST_HIER_REL * 4 + (int)xcd * 128, X0 = PERSIST_HIER_XW * 4;
@@ -1368,7 +1368,7 @@ __device__ __forceinline__ void persist_barrier_hier(const PersistArgs& P, unsig
         } else if (lane == 0) {
             __builtin_amdgcn_raw_buffer_store_b32(want, Hr, F0 + (int)j * 4, 0, 0);
         }
-        if (j == 0 || P.hier == 2) {
+        {
             while (!open) {      // exchange: the eight classes' words, one line each (lane 8: the device-wide dead mark)
                 unsigned v = want;
                 if (lane < 8 && !(j == 0 && lane == (int)xcd))
@@ -1384,22 +1384,50 @@ __device__ __forceinline__ void persist_barrier_hier(const PersistArgs& P, unsig
                 }
                 if (wall_clock64() - t0 > P.timeout_ticks) give_up();
             }
-            if (j == 0 && lane == 0) {      // release the class (hier = 2: nobody waits here; the dead word still serves later collects)
-                if (open) __builtin_amdgcn_raw_buffer_store_b32(1u, Hr, L0 + 4, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(want, Hr, L0, 0, 0);
+            // a run that is void: the class's dead word opens the leader's later collects at once (its members see the device-wide mark)
+            if (open && j == 0 && lane == 0) __builtin_amdgcn_raw_buffer_store_b32(1u, Hr, L0 + 4, 0, 0);
+        }
+    }
+    __syncthreads();
+}
+
+// The same without the collect inside an XCD (hier = 2): every workgroup stores its tag into a word of its own (agent scope:
+// written through; [class][slot], so a line is written by one XCD's workgroups only) and polls all of them, eight words a lane --
+// one store on its way to the memory side and one read back instead of four hops.  (Round 5 measured a flat barrier of ARRIVAL
+// COUNTERS -- thirty-two read-modify-writes queueing on each of eight words -- at 23.8 against 21 us/step; profiles/r05/p2p.md.)
+__device__ __forceinline__ void persist_barrier_flat(const PersistArgs& P, unsigned n1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned want = (P.seq << 6) | n1;
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        unsigned* const fw = P.bar + PERSIST_HIER_BASE + PERSIST_HIER_FLAT;
+        unsigned* const dead_g = P.bar + 9 * 32 + 1;
+        if (lane == 0) __hip_atomic_store(fw + xcd * 64 + j, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const __amdgpu_buffer_rsrc_t Fr = __builtin_amdgcn_make_buffer_rsrc((void*)fw, 0, 8 * 64 * 4, 0x00020000);
+        const int cls = lane >> 3, s0 = (lane & 7) * 8;           // this lane's eight words: slots s0 .. s0 + 7 of class cls
+        const int per = (int)((gridDim.x + 7u - (unsigned)cls) >> 3);
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            u4 a = {want, want, want, want}, b = a;
+            if (s0 < per) a = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(Fr, (cls * 64 + s0) * 4, 0, EMX_CPOL_SC1));
+            if (s0 + 4 < per) b = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(Fr, (cls * 64 + s0 + 4) * 4, 0, EMX_CPOL_SC1));
+            const unsigned dv = lane == 0 ? __hip_atomic_load(dead_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ok = ok && (s0 + q >= per || (int)(a[q] - want) >= 0);
+                ok = ok && (s0 + 4 + q >= per || (int)(b[q] - want) >= 0);
             }
-        } else {
-            for (;;) {           // release: word 0 the tag the leader let through, word 1 the class's dead word
-                unsigned v = 0u;
-                if (lane < 2) v = __builtin_amdgcn_raw_buffer_load_b32(Hr, L0 + lane * 4, 0, EMX_CPOL_SC1);
-                const bool ok = lane == 0 && (int)(v - want) >= 0;
-                const bool dead = lane == 1 && v != 0u;
-                if (__ballot(ok) != 0ull || __ballot(dead) != 0ull) break;
-                if (wall_clock64() - t0 > P.timeout_ticks) {
-                    give_up();
-                    if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(1u, Hr, L0 + 4, 0, 0);
-                    break;
+            if (__ballot(ok) == ~0ull || __ballot(dv != 0u) != 0ull) break;
+            if (wall_clock64() - t0 > P.timeout_ticks) {
+                if (lane == 0) {
+                    raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
+                    __hip_atomic_store(dead_g, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // 2: in the middle of a launch
                 }
+                break;
             }
         }
     }
@@ -1409,7 +1437,9 @@ __device__ __forceinline__ void persist_barrier_hier(const PersistArgs& P, unsig
 // which barrier a device-wide launch runs between its half-steps (uniform: a kernel argument)
 __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k);
 __device__ __forceinline__ void persist_barrier_wide(const PersistArgs& P, unsigned n) {       // n: the half-step just finished
-    if (P.hier)
+    if (P.hier == 2)
+        persist_barrier_flat(P, n + 1u);
+    else if (P.hier)
         persist_barrier_hier(P, n + 1u);
     else
         persist_barrier(P, P.epoch0 + n + 2u);                // (+ 1: the handshake was this launch's first barrier)

@@ -100,8 +100,8 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   "slab_skew"                1         0 ... 4: when the second wave of a SIMD starts its first tile's row loads
  *   -- persistent kernels (emx_persist_info) --
  *   "persist"                  1         0: never a persistent launch
- *   "persist_hier"             1         device-wide form: 1: the hierarchical barrier (flag words inside an XCD, one word per XCD across;
- *                                        leaders release their XCD), 2: ... every workgroup polls the eight XCD words itself, 0: arrival counters
+ *   "persist_hier"             1         device-wide form: 1: the hierarchical barrier (flag words inside an XCD, one word per XCD across,
+ *                                        polled by every workgroup), 0: two levels of arrival counters
  *   "persist_local"            1         0: never the one-XCD form        "persist_local_max_walkers"  8192
  *   "persist_valu"             1         0: element-wise targets on the per-half-step launches
  *   "persist_mix"              1         0: DE and snooker steps of a mixture in launches of their own
@@ -432,7 +432,7 @@ int emx_persist_local_launches(emx_ctx* ctx, int64_t* n);
  * k + 1 sees every update of split k -- the barrier is where the reference's Python loop has its sequence point): workgroup i of a
  * launch runs on XCD i mod 8 (verified per launch by the handshake; a launch that finds otherwise gives up untouched, is redone,
  * and the context keeps to the arrival counters), so arrival is collected inside an XCD through flag words in its L2 (plain
- * stores, sc1 loads), exchanged across the eight XCDs through one word each, and released per XCD the same way.  Tuning
+ * stores, sc1 loads), exchanged across the eight XCDs through one word each, which every workgroup polls.  Tuning
  * "persist_hier" = 0: two levels of arrival counters (read-modify-write atomics beyond the L2) as in rounds 3-5.  Same bits. */
 int emx_persist_hier_launches(emx_ctx* ctx, int64_t* n);
 /* host only: the grid the persistent kernel takes for `nwalkers` walkers updated in `nsplits` half-steps on a device of `num_cu`

@@ -1,7 +1,7 @@
 """Where a half-step of the persistent kernel (k_persist) goes: in-kernel timestamps of the first wave of every workgroup, summed
 over the half-steps of a launch (instrumented build, -DEMX_OPT_STAMPS=1: tools/ab_variants.sh stamps "-DEMX_OPT_STAMPS=1").
 
-  usage: python tools/persist_phase_clock.py [nwalkers] [ndim] [store]"""
+  usage: python tools/persist_phase_clock.py [nwalkers] [ndim] [store] [persist_hier]"""
 import os
 import subprocess
 import sys
@@ -20,18 +20,15 @@ from emcee_amd.device import DeviceEnsemble  # noqa: E402
 NAMES = ["partner rows + next plan entries arrive (sc1 round trip)", "proposals, tile written, next own rows issued",
          "LDS fragments + MFMA chain + row reductions", "decisions, commit stores issued", "stores acknowledged (vmcnt 0)",
          "device-wide barrier (arrive, poll)"]
-NAMES_P2P = ["tile words polled, moved rows loaded again (+ next plan entries)", "proposals, tile written, gate, next half-step's rows issued",
-             "LDS fragments + MFMA chain + row reductions", "decisions, commit stores issued",
-             "stores acknowledged, next half-step's rows in (vmcnt 0)", "word + arrival issued"]
 
 
-def main(N=65536, D=64, store=0, p2p=1):
+def main(N=65536, D=64, store=0, hier=1):
     import torch
     from emcee_amd.parallel import _DevView
     wl = bench.Workload("c2" if D == 64 else "c3", N)
     ens = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(ens, "philox")
-    ens.set_tuning("persist_p2p", p2p)
+    ens.set_tuning("persist_hier", hier)      # the device-wide barrier: 0 arrival counters, 1 hierarchical, 2 flat words
     if store:
         ens.chain_config(4000)
     ens.run(200, 1, bool(store))
@@ -56,11 +53,9 @@ def main(N=65536, D=64, store=0, p2p=1):
     per = raw[:, :6] / niter[:, None] * ns_per_tick / 1e3          # us per half-step
     # the barrier is passed niter - 1 times a launch, the other phases niter times
     per[:, 5] *= niter / np.maximum(niter - 1, 1)
-    names = NAMES_P2P if info["p2p_launches"] else NAMES
-    if info["p2p_launches"]:
-        per[:, 4] *= niter / np.maximum(niter - 1, 1)
-    print("k_persist%s %d x %d%s: %d workgroup-launch samples (%d half-steps a launch), counter tick %.2f ns, persist launches so far %d"
-          % ("_p2p" if info["p2p_launches"] else "", N, D, ", stored chain" if store else "", len(raw), int(np.median(niter)), ns_per_tick, info["launches"]))
+    names = NAMES
+    print("k_persist (persist_hier = %d) %d x %d%s: %d workgroup-launch samples (%d half-steps a launch), counter tick %.2f ns, persist launches so far %d (%d with the hierarchical barrier)"
+          % (hier, N, D, ", stored chain" if store else "", len(raw), int(np.median(niter)), ns_per_tick, info["launches"], info["hier_launches"]))
     print("  wave-0 lifetime per half-step: median %.2f us" % np.median(wall_ns / niter / 1e3))
     for k, name in enumerate(names):
         print("  %-62s median %6.2f us   p10 %6.2f   p90 %6.2f   (%4.1f %%)"
