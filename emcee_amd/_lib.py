@@ -121,7 +121,6 @@ SIGNATURES = {
     "emx_mtdev_debug": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_void_p, C.c_int64]),
     "emx_mtdev_tok_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "emx_persist_local_launches": (C.c_int, [_P, C.POINTER(C.c_int64)]),
-    "emx_persist_hier_launches": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "emx_host_mt_jump": (C.c_int, [_u32p, C.c_uint64, C.c_int32, _u32p]),
     "emx_host_persist_shape": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "emx_timer_start": (C.c_int, [_P]),

@@ -494,10 +494,6 @@ struct emx_ctx {
     int64_t tune_persist_gauss_wpb = 0;       // waves per workgroup of k_persist_gauss (0: four)
     int64_t tune_persist_test_skew = 0;      // tests only: added to the barrier count the next launches wait for
     int64_t tune_persist = 1, tune_persist_timeout_ms = 2000, tune_persist_min_walkers = 512;
-    int64_t tune_persist_hier = 1;       // device-wide persistent launches: 1 the hierarchical barrier (persist_barrier_hier), 0 the arrival counters.  Set to 0
-                                         // by persist_settle when a launch found the workgroups of a class blockIdx & 7 on more than one XCD
-    unsigned persist_stamp = 0;          // PersistArgs::stamp0: half-steps the context's persistent launches have run (never reset)
-    int64_t persist_hier_launches = 0;
     int persist_wpb = 8;
     int64_t persist_launches = 0, persist_halfsteps = 0;
     struct PersistCapture {
@@ -1442,10 +1438,6 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
         c->tune_persist = v ? 1 : 0;
-        return 0;
-    }
-    if (!strcmp(key, "persist_hier")) {      // the device-wide form's barrier: 0 arrival counters, 1 hierarchical
-        c->tune_persist_hier = (v == 1 || v == 2) ? v : 0;      // (2: the flat form, persist_barrier_flat)
         return 0;
     }
     if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)
@@ -3616,17 +3608,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         c->persist_hepoch += 1u;
     }
     P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
-    // the device-wide form's barrier between the half-steps: hierarchical when every class blockIdx & 7 has at most 64 workgroups
-    // (two flag lines per class: every grid persist_shape_of makes); the arrival counters then count the handshake alone
-    P.hier = (!launch_local && grid.x >= 8u && grid.x <= 512u) ? (int32_t)c->tune_persist_hier : 0;
-    P.stamp0 = c->persist_stamp;
-    c->persist_stamp += (unsigned)n;
-    if (P.hier) {
-        c->persist_epoch += 1u;
-        c->persist_hier_launches++;
-    } else {
-        c->persist_epoch += (unsigned)n;      // the handshake and the n - 1 barriers between the half-steps
-    }
+    c->persist_epoch += (unsigned)n;          // the handshake and the n - 1 barriers between the half-steps
     P.seq = ++c->persist_seq;
     lg.seq = P.seq;
     lg.steps = steps;
@@ -3708,7 +3690,7 @@ static int persist_settle(emx_ctx* c) {
         c->plog.clear();
         return 0;
     }
-    unsigned w[6] = {0, 0, 0, 0, 0, 0};
+    unsigned w[4] = {0, 0, 0, 0};
     HIPOK(c, hipMemcpy(w, c->persist_bar + 9 * 32, sizeof(w), hipMemcpyDeviceToHost));
     if (w[1] != 1u) {           // not (only) a clean handshake time-out: a direct-exchange barrier, or the middle of a launch
         c->plog.clear();
@@ -3739,9 +3721,7 @@ static int persist_settle(emx_ctx* c) {
     const uint64_t ph_end = c->ph_step;
     for (const auto& m : c->moves) NEED(c, m.kind != EMX_MOVE_GAUSS, "persistent launches to redo in a mixture with a Gaussian move");
     drop_prepared(c);                         // (the ring slots of plans made ahead are about to be reused)
-    if (w[5] != 0u)
-        c->tune_persist_hier = 0;             // the workgroups of a class blockIdx & 7 did not share an XCD: the arrival-counter barrier from here on ("persist_hier" = 1)
-    else if ((w[2] & (w[2] - 1u)) != 0u)
+    if ((w[2] & (w[2] - 1u)) != 0u)
         c->tune_persist_local = 0;            // the one-XCD form's workgroups did not share an XCD: that form stays off ("persist_local" = 1)
     else
         c->tune_persist = 0;                  // and it stays off: whatever held the CUs may still be there ("persist" = 1 turns it back on)
@@ -3855,11 +3835,6 @@ int emx_persist_info(emx_ctx* c, int64_t out[4]) {
 
 int emx_persist_local_launches(emx_ctx* c, int64_t* n) {
     *n = c->persist_local_launches;
-    return 0;
-}
-
-int emx_persist_hier_launches(emx_ctx* c, int64_t* n) {
-    *n = c->persist_hier_launches;
     return 0;
 }
 

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/emx.h"
@@ -382,6 +383,16 @@ int emx_autocorr(emx_ctx* c, int64_t discard, int64_t thin, double cwin, double*
     return 0;
 }
 
+// Scratch of the conditioning check, kept per device between calls (round-5 advisor: every continuation of run_mcmc on a resident
+// State runs the check -- ensemble.py:316-323 -- and paid four hipMalloc / hipFree pairs for it; a loop of short run_mcmc(None, k)
+// calls, a convergence check, saw them on its fast path).  One arena per device, grown when a larger ensemble asks, never shrunk.
+struct CondArena {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+static std::mutex g_cond_mu;
+static CondArena g_cond_arena[64];
+
 // coords: the (N, D) matrix on the host -- or, with on_device, already in this device's memory (the resident state of a context)
 static int walkers_independent_impl(int32_t device, const double* coords, bool on_device, int64_t N, int32_t D, int32_t* independent, double* cond_out) {
     if (!coords || !independent || N < 1 || D < 1) return emx_internal_fail(nullptr, -1, "emx_walkers_independent: bad arguments");
@@ -394,10 +405,8 @@ static int walkers_independent_impl(int32_t device, const double* coords, bool o
     AUX_HIP(nullptr, hipSetDevice(device));
     double *x = nullptr, *ct = nullptr, *R = nullptr, *scal = nullptr;
     int32_t* bad = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {(void*)x, (void*)ct, (void*)R, (void*)scal, (void*)bad})
-            if (p) hipFree(p);
-    };
+    std::lock_guard<std::mutex> arena_lock(g_cond_mu);                // (one check at a time per process: they share the arena and the NULL stream)
+    auto cleanup = [&]() {};
     auto fail = [&](hipError_t e, const char* what) -> int {
         cleanup();
         char b[256];
@@ -405,11 +414,30 @@ static int walkers_independent_impl(int32_t device, const double* coords, bool o
         return emx_internal_fail(nullptr, -2, b);
     };
     hipError_t e;
-    if (!on_device && (e = hipMalloc((void**)&x, (size_t)N * D * 8)) != hipSuccess) return fail(e, "allocation");
-    if ((e = hipMalloc((void**)&ct, (size_t)N * D * 8)) != hipSuccess) return fail(e, "allocation");
-    if ((e = hipMalloc((void**)&R, (size_t)D * D * 8)) != hipSuccess) return fail(e, "allocation");
-    if ((e = hipMalloc((void**)&scal, 64)) != hipSuccess) return fail(e, "allocation");
-    if ((e = hipMalloc((void**)&bad, 4)) != hipSuccess) return fail(e, "allocation");
+    {
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t nd = up((size_t)N * D * 8), need = (on_device ? 0 : nd) + nd + up((size_t)D * D * 8) + 256 + 256;
+        CondArena& ar = g_cond_arena[device >= 0 && device < 64 ? device : 0];
+        if (ar.bytes < need) {
+            if (ar.p) hipFree(ar.p);
+            ar.p = nullptr;
+            ar.bytes = 0;
+            if ((e = hipMalloc(&ar.p, need)) != hipSuccess) return fail(e, "allocation");
+            ar.bytes = need;
+        }
+        char* q = static_cast<char*>(ar.p);
+        if (!on_device) {
+            x = reinterpret_cast<double*>(q);
+            q += nd;
+        }
+        ct = reinterpret_cast<double*>(q);
+        q += nd;
+        R = reinterpret_cast<double*>(q);
+        q += up((size_t)D * D * 8);
+        scal = reinterpret_cast<double*>(q);
+        q += 256;
+        bad = reinterpret_cast<int32_t*>(q);
+    }
     if (!on_device && (e = hipMemcpy(x, coords, (size_t)N * D * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload");
     hipMemset(bad, 0, 4);
     hipMemset(R, 0, (size_t)D * D * 8);

@@ -1246,13 +1246,7 @@ __device__ __forceinline__ void store_scope(T* p, T v) {
 }
 
 constexpr int PERSIST_MAX_ITERS = 32;
-constexpr int PERSIST_HIER_BASE = 12 * 32;   // words of PersistArgs::bar in front of the hierarchical barrier's block (persist_barrier_hier)
-constexpr int PERSIST_HIER_REL = 8 * 64;     // ... in that block: [8][64] flag words | [8][32] release lines | [8][32] XCD words | [32] XCC masks
-constexpr int PERSIST_HIER_XW = PERSIST_HIER_REL + 8 * 32;
-constexpr int PERSIST_HIER_MASK = PERSIST_HIER_XW + 8 * 32;
-constexpr int PERSIST_HIER_FLAT = PERSIST_HIER_MASK + 32;      // ... | [8][64] the flat form's words (persist_barrier_flat: written through, never by plain stores)
-constexpr int PERSIST_HIER_WORDS = PERSIST_HIER_FLAT + 8 * 64;
-constexpr int PERSIST_BAR_WORDS = PERSIST_HIER_BASE + PERSIST_HIER_WORDS;   // PersistArgs::bar
+constexpr int PERSIST_BAR_WORDS = 12 * 32;   // PersistArgs::bar
 struct PersistIter {
     const int32_t *order, *p0, *p1, *p2;  // (p1: the DE move's second partner; p1, p2: the snooker move's z1, z2)
     const double *s0, *logu, *fac;
@@ -1264,8 +1258,8 @@ struct PersistIter {
 struct PersistArgs {
     HalfStepArgs base;
     PersistIter it[PERSIST_MAX_ITERS];
-    unsigned* bar;                 // [8][32] per-XCD arrival counters | [32] global counter | [32] go word (go, dead, XCD mask, seq, one-XCD launch's XCD, hier placement failed)
-                                   // | [32] [32] the one-XCD form's counter and go word | persist_barrier_hier: [8][64] flags | [8][32] release lines | [8][32] XCD words | [32] XCC masks
+    unsigned* bar;                 // [8][32] per-XCD arrival counters | [32] global counter | [32] go word (go, dead, XCD mask, seq, one-XCD launch's XCD)
+                                   // | [32] [32] the one-XCD form's counter and go word
     unsigned* ver;                 // (N) stamp of the half-step that last moved the walker
     unsigned epoch0;               // barriers already passed on these counters
     unsigned lepoch0;              // the one-XCD form: barriers already passed on ITS flags (the handshake does not count there)
@@ -1273,8 +1267,6 @@ struct PersistArgs {
     unsigned long long timeout_ticks;
     int32_t niter;
     unsigned seq;                  // number of this launch (left in the barrier block's fourth `go` word once its grid is known co-resident)
-    unsigned stamp0;               // PersistArgs::ver stamps of this launch's half-steps start behind this (unique per half-step of the context)
-    int32_t hier;                  // device-wide form: 0 arrival counters (persist_barrier), 1 the hierarchical barrier (persist_barrier_hier)
     unsigned* started_host;        // pinned host word (or null): `seq` again, for the host -- launch k + 1 has started, so launch k is over
 };
 
@@ -1311,140 +1303,12 @@ __device__ __forceinline__ void persist_barrier_local(const PersistArgs& P, unsi
     __syncthreads();
 }
 
-// The device-wide barrier, hierarchical (round 6).  The arrival-counter barrier below costs 2.5 us of a 9.6 us half-step at the
-// headline shape (profiles/r04/persist_phase_c2.txt): two dependent read-modify-write atomics, executed beyond the L2, then a poll.
-// Round 4 found what ONE XCD's L2 offers (persist_barrier_local: a plain store is in the L2 when acknowledged, an sc1 load of a line
-// this XCD wrote is answered by that L2 -- 0.32 us for a flag barrier of 32 workgroups).  Workgroup i of a launch runs on XCD i mod 8
-// (the handshake VERIFIES it per launch: persist_handshake), so:
-//   collect  -- inside an XCD: workgroup j of class x = blockIdx & 7 stores the barrier's tag into word j of the class's two flag
-//               lines (plain store); the class's leader (j = 0) polls them with sc1 loads, one word a lane;
-//   exchange -- across XCDs: the leader stores the tag into its class's OWN line of eight (agent scope: write-through); nobody
-//               reads a line of this group that its own XCD's plain stores ever touched, so an sc1 load of it comes from memory;
-//   release  -- every workgroup polls the eight lines itself.  (Measured against it, profiles/r06/hier_barrier_ab.txt: the leaders
-//               poll the other seven lines and release their XCD through a line of the class -- one hop more, 2 % slower.)
-// Tags are (launch number << 6 | barrier of the launch): no epoch to keep in step with the arrival counters, which the handshake
-// alone still uses.  Every wait is bounded by the wall clock; a wait that times out (or a dead mark seen) marks the run void
-// (status bit 3, `dead` = 2) and opens every later wait of the launch at once: the class's release line carries a dead word for
-// its members, the leaders see the global one.
-__device__ __forceinline__ void persist_barrier_hier(const PersistArgs& P, unsigned n1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits (agent-scope stores) are visible to the device
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const unsigned want = (P.seq << 6) | n1;
-        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        const int per = (int)((gridDim.x + 7u - xcd) >> 3);       // workgroups of this class (<= 64: the host's rule)
-        unsigned* const hb = P.bar + PERSIST_HIER_BASE;
-        unsigned* const dead_g = P.bar + 9 * 32 + 1;
-        // one descriptor over the block: flags [8][64] | a line per class whose word 1 is the class's dead word
-        // | the eight classes' words, a line each
-        const __amdgpu_buffer_rsrc_t Hr = __builtin_amdgcn_make_buffer_rsrc((void*)hb, 0, PERSIST_HIER_WORDS * 4, 0x00020000);
-        const int F0 = (int)xcd * 256, L0 = PERSIST_HIER_REL * 4 + (int)xcd * 128, X0 = PERSIST_HIER_XW * 4;
-        const unsigned long long t0 = wall_clock64();
-        bool open = false;                                        // a wait was left without being met (dead mark or time-out)
-        auto give_up = [&]() {
-            if (lane == 0) {
-                raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
-                __hip_atomic_store(dead_g, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // 2: in the middle of a launch
-            }
-            open = true;
-        };
-        if (j == 0) {
-            for (;;) {           // collect: the class's flags (words 1 .. per - 1); lane 0 -- the leader itself -- reads the class's dead word
-                const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(Hr, lane == 0 ? L0 + 4 : F0 + lane * 4, 0, EMX_CPOL_SC1);
-                const bool ok = (lane >= 1 && lane < per) ? (int)(v - want) >= 0 : true;
-                const bool dead = lane == 0 && v != 0u;
-                if (__ballot(ok) == ~0ull) break;
-                if (__ballot(dead) != 0ull) {
-                    open = true;
-                    break;
-                }
-                if (wall_clock64() - t0 > P.timeout_ticks) {
-                    give_up();
-                    break;
-                }
-            }
-            if (lane == 0) __hip_atomic_store(hb + PERSIST_HIER_XW + xcd * 32, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (lane == 0) {
-            __builtin_amdgcn_raw_buffer_store_b32(want, Hr, F0 + (int)j * 4, 0, 0);
-        }
-        {
-            while (!open) {      // exchange: the eight classes' words, one line each (lane 8: the device-wide dead mark)
-                unsigned v = want;
-                if (lane < 8 && !(j == 0 && lane == (int)xcd))
-                    v = __builtin_amdgcn_raw_buffer_load_b32(Hr, X0 + lane * 128, 0, EMX_CPOL_SC1);
-                else if (lane == 8)
-                    v = __hip_atomic_load(dead_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = lane < 8 ? (int)(v - want) >= 0 : true;
-                const bool dead = lane == 8 && v != 0u;
-                if (__ballot(ok) == ~0ull) break;
-                if (__ballot(dead) != 0ull) {
-                    open = true;
-                    break;
-                }
-                if (wall_clock64() - t0 > P.timeout_ticks) give_up();
-            }
-            // a run that is void: the class's dead word opens the leader's later collects at once (its members see the device-wide mark)
-            if (open && j == 0 && lane == 0) __builtin_amdgcn_raw_buffer_store_b32(1u, Hr, L0 + 4, 0, 0);
-        }
-    }
-    __syncthreads();
-}
-
-// The same without the collect inside an XCD (hier = 2): every workgroup stores its tag into a word of its own (agent scope:
-// written through; [class][slot], so a line is written by one XCD's workgroups only) and polls all of them, eight words a lane --
-// one store on its way to the memory side and one read back instead of four hops.  (Round 5 measured a flat barrier of ARRIVAL
-// COUNTERS -- thirty-two read-modify-writes queueing on each of eight words -- at 23.8 against 21 us/step; profiles/r05/p2p.md.)
-__device__ __forceinline__ void persist_barrier_flat(const PersistArgs& P, unsigned n1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const unsigned want = (P.seq << 6) | n1;
-        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        unsigned* const fw = P.bar + PERSIST_HIER_BASE + PERSIST_HIER_FLAT;
-        unsigned* const dead_g = P.bar + 9 * 32 + 1;
-        if (lane == 0) __hip_atomic_store(fw + xcd * 64 + j, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const __amdgpu_buffer_rsrc_t Fr = __builtin_amdgcn_make_buffer_rsrc((void*)fw, 0, 8 * 64 * 4, 0x00020000);
-        const int cls = lane >> 3, s0 = (lane & 7) * 8;           // this lane's eight words: slots s0 .. s0 + 7 of class cls
-        const int per = (int)((gridDim.x + 7u - (unsigned)cls) >> 3);
-        const unsigned long long t0 = wall_clock64();
-        for (;;) {
-            typedef unsigned u4 __attribute__((ext_vector_type(4)));
-            u4 a = {want, want, want, want}, b = a;
-            if (s0 < per) a = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(Fr, (cls * 64 + s0) * 4, 0, EMX_CPOL_SC1));
-            if (s0 + 4 < per) b = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(Fr, (cls * 64 + s0 + 4) * 4, 0, EMX_CPOL_SC1));
-            const unsigned dv = lane == 0 ? __hip_atomic_load(dead_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            bool ok = true;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ok = ok && (s0 + q >= per || (int)(a[q] - want) >= 0);
-                ok = ok && (s0 + 4 + q >= per || (int)(b[q] - want) >= 0);
-            }
-            if (__ballot(ok) == ~0ull || __ballot(dv != 0u) != 0ull) break;
-            if (wall_clock64() - t0 > P.timeout_ticks) {
-                if (lane == 0) {
-                    raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
-                    __hip_atomic_store(dead_g, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // 2: in the middle of a launch
-                }
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// which barrier a device-wide launch runs between its half-steps (uniform: a kernel argument)
-__device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k);
-__device__ __forceinline__ void persist_barrier_wide(const PersistArgs& P, unsigned n) {       // n: the half-step just finished
-    if (P.hier == 2)
-        persist_barrier_flat(P, n + 1u);
-    else if (P.hier)
-        persist_barrier_hier(P, n + 1u);
-    else
-        persist_barrier(P, P.epoch0 + n + 2u);                // (+ 1: the handshake was this launch's first barrier)
-}
-
+// The device-wide barrier: two levels of arrival counters, then a poll of one word.  2.5-2.7 us of a 10 us half-step at the headline
+// shape (profiles/r04/persist_phase_c2.txt, profiles/r06/persist_phase_hier.txt).  Round 6 built two forms that replace the
+// read-modify-write atomics by words -- hierarchical (flag words polled inside an XCD's L2, one word per XCD across: 2.55 us, the
+// step time unchanged within 0.5 %) and flat (a word per workgroup, everybody polls all of them: 4.6 us) -- both bit-equal, neither
+// faster; they were removed again (profiles/r06/hier_barrier.md names the commits that hold them).
+// What the barrier costs is three trips to the memory side whichever instruction makes them.
 __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits (agent-scope stores) are visible to the device
     __syncthreads();
@@ -1500,16 +1364,10 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
             ok = 0;                                                 // an earlier launch gave up: not even counted
         } else {
             unsigned xcc = 0;
-            unsigned* const hmask = P.bar + PERSIST_HIER_BASE + PERSIST_HIER_MASK;        // persist_barrier_hier: XCDs seen per class blockIdx & 7
             if constexpr (LOCAL) {
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                 __hip_atomic_fetch_or(go + 2, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the mark is in before this workgroup counts as arrived
-            } else if (P.hier) {
-                // the hierarchical barrier rests on "the workgroups of a class share an XCD": every workgroup reports where it runs
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                __hip_atomic_fetch_or(hmask + xcd, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             const unsigned old = __hip_atomic_fetch_add(xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == k * per - 1) {
@@ -1526,20 +1384,6 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
                     }
                 } else {
                     o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (P.hier && o2 == k * 8 - 1) {
-                        // the last arriver of all: one XCD per class, or the launch gives up untouched (the host then redoes its
-                        // steps and keeps to the arrival-counter barrier: persist_settle reads go[5])
-                        for (int x = 0; x < 8; ++x) {
-                            const unsigned m = __hip_atomic_load(hmask + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            open = open && (m & (m - 1u)) == 0u;
-                            __hip_atomic_store(hmask + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (the next launch starts clean)
-                        }
-                        if (!open) {
-                            raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
-                            __hip_atomic_store(go + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(go + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // 1: nothing was written
-                        }
-                    }
                 }
                 if (open && o2 == k * 8 - 1) {
                     // where a one-XCD launch lives (XCC_ID + 1; 0: everywhere), for k_plan_fetch, which keeps off that XCD
@@ -1681,7 +1525,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         const bool more = n + 1 < P.niter;
         const PersistIter& J = P.it[more ? n + 1 : n];
         const bool pre = more && J.split != 0;                   // its own walkers are this half-step's complement
-        const unsigned stamp = P.stamp0 + (unsigned)n + 1u;      // of this half-step (unique in the context: never 0 before the counter wraps)
+        const unsigned stamp = P.epoch0 + (unsigned)n + 1u;      // of this half-step (never 0 before the counters wrap)
         int wi_n[PF], ja_n[PF], jb_n[DE ? PF : 1], jc_n[SN ? PF : 1], my_i_n;
         double s0_n[PF], fac_n[PF], my_logu_n;
         {
@@ -1827,7 +1671,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         if constexpr (LOCAL)
             persist_barrier_local(P, P.lepoch0 + (unsigned)n + 1u, bid, ngroups);
         else
-            persist_barrier_wide(P, (unsigned)n);
+            persist_barrier(P, P.epoch0 + (unsigned)n + 2u);       // (+ 1: the handshake was this launch's first barrier)
         EMX_PSTAMP(5);       // device-wide barrier
         // -------- roll over --------
 #pragma unroll

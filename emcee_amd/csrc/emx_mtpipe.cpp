@@ -365,7 +365,7 @@ struct CompactLut {
     }
 };
 static const CompactLut g_compact_lut;
-static int g_compaction = -1;      // 0: vpcompressd, 1: table permutes, 2: none (tools/ubench/mt_scan_bench.cpp only: timing without it)
+static std::atomic<int> g_compaction{-1};      // 0: vpcompressd, 1: table permutes, 2: none (tools/ubench/mt_scan_bench.cpp only: timing without it)
 template <int MODE>
 __attribute__((target("avx512f,avx512vl,avx512bw,avx2,popcnt"))) inline int compact_store(uint32_t* dst, __mmask16 a, __m512i v) {
     if (MODE == 0) {
@@ -488,8 +488,14 @@ __attribute__((target("avx512f,avx512vl,avx512bw,avx2,popcnt"))) size_t shuffle_
 }
 // which compaction this CPU does faster: both forms over the same 64 K pseudo-random words, once per process
 int pick_compaction() {
-    if (g_compaction >= 0) return g_compaction;
-    if (const char* e = getenv("EMX_PIPE_COMPACTION")) return g_compaction = atoi(e) ? 1 : 0;
+    // (contexts may be created concurrently: an atomic, and a measurement taken twice gives the same kind of answer)
+    const int known = g_compaction.load(std::memory_order_relaxed);
+    if (known >= 0) return known;
+    if (const char* e = getenv("EMX_PIPE_COMPACTION")) {
+        const int v = atoi(e) ? 1 : 0;
+        g_compaction.store(v, std::memory_order_relaxed);
+        return v;
+    }
     std::vector<uint32_t> w(65536 + 64), out(65536 + 64);
     uint32_t x = 0x2545f491u;
     for (auto& v : w) {
@@ -509,7 +515,9 @@ int pick_compaction() {
                 shuffle_scan_avx512_t<1>(w.data(), 40000, 65535u, i, 32767, out.data(), 65535);
             best[mode] = std::min<uint64_t>(best[mode], now_ns() - t0);
         }
-    return g_compaction = best[1] < best[0] ? 1 : 0;
+    const int pick = best[1] < best[0] ? 1 : 0;
+    g_compaction.store(pick, std::memory_order_relaxed);
+    return pick;
 }
 // randint(0, rng + 1) values by masked rejection, 16 stream words at a time (the acceptance test does not depend on the position:
 // plain order-preserving compaction); stops in front of the vector that could overshoot n.  Returns the words consumed.
@@ -657,7 +665,7 @@ __attribute__((target("avx512f,avx512vl,avx512bw,avx512dq"))) int64_t de_decode_
 #undef EMX_TRI
 }
 inline size_t shuffle_scan_avx512(const uint32_t* p, size_t navail, uint32_t mask, int64_t& i, int64_t lo, uint32_t* jr, int64_t nm1) {
-    switch (g_compaction) {
+    switch (g_compaction.load(std::memory_order_relaxed)) {
         case 1: return shuffle_scan_avx512_t<1>(p, navail, mask, i, lo, jr, nm1);
         case 2: return shuffle_scan_avx512_t<2>(p, navail, mask, i, lo, jr, nm1);
         default: return shuffle_scan_avx512_t<0>(p, navail, mask, i, lo, jr, nm1);
@@ -755,14 +763,32 @@ struct Reader {
         if (ws->produced.load(std::memory_order_acquire) * BLK >= a) return true;
         Backoff bo(ws->spin_ns);
         const uint64_t t0 = now_ns();
-        while (ws->produced.load(std::memory_order_acquire) * BLK < a) {
-            // (ten seconds without a word: the generator is held by a ring that cannot take this step -- step_words_bound exceeded,
-            // which does not happen -- and the pipeline fails loudly instead of hanging)
-            if (stop->load(std::memory_order_relaxed) || now_ns() - t0 > 10000000000ull) {
+        // The pipeline fails loudly instead of hanging when the generator can make no progress at all (a ring that cannot take this
+        // step: step_words_bound exceeded, which does not happen).  "No progress" is asked of the GENERATOR, not of the wall clock
+        // (round-5 advisor: a process stopped under a debugger, a stalled VM or an oversubscribed host turned ten seconds of wall
+        // clock into a failed run): the limit -- EMX_PIPE_STALL_MS, default 10 s -- restarts whenever a block appears, and a
+        // sample taken later than a second after the one before it (this thread was not running either) restarts it as well.
+        static const uint64_t stall_ns = [] {
+            const char* e = getenv("EMX_PIPE_STALL_MS");
+            const long long ms = e ? atoll(e) : 10000;
+            return (uint64_t)(ms > 0 ? ms : 10000) * 1000000ull;
+        }();
+        uint64_t seen = ws->produced.load(std::memory_order_acquire), t_seen = t0, t_prev = t0;
+        while (seen * BLK < a) {
+            if (stop->load(std::memory_order_relaxed)) {
                 dead = true;
                 break;
             }
             bo.pause();
+            const uint64_t now = now_ns(), prod = ws->produced.load(std::memory_order_acquire);
+            if (prod != seen || now - t_prev > 1000000000ull) {
+                seen = prod;
+                t_seen = now;
+            } else if (now - t_seen > stall_ns) {
+                dead = true;
+                break;
+            }
+            t_prev = now;
         }
         ws->rd_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
         return !dead;

@@ -132,7 +132,7 @@ static __global__ __launch_bounds__(512) void k_persist_mix(const PersistArgs P)
         const bool more = n + 1 < P.niter;
         const PersistIter& J = P.it[more ? n + 1 : n];
         const bool pre = more && J.split != 0;                   // its own walkers are this half-step's complement
-        const unsigned stamp = P.stamp0 + (unsigned)n + 1u;      // of this half-step (unique in the context: never 0 before the counter wraps)
+        const unsigned stamp = P.epoch0 + (unsigned)n + 1u;      // of this half-step (never 0 before the counters wrap)
         int wi_n[PF], ja_n[PF], jb_n[DE ? PF : 1], jc_n[SNA ? PF : 1], my_i_n = 0;
         double s0_n[PF], fac_n[PF], my_logu_n = 0.0, my_lpo_n = 0.0;
         bool act_n = true;
@@ -306,7 +306,7 @@ static __global__ __launch_bounds__(512) void k_persist_mix(const PersistArgs P)
         if constexpr (LOCAL)
             persist_barrier_local(P, P.lepoch0 + (unsigned)n + 1u, bid, ngroups);
         else
-            persist_barrier_wide(P, (unsigned)n);
+            persist_barrier(P, P.epoch0 + (unsigned)n + 2u);       // (+ 1: the handshake was this launch's first barrier)
         EMX_PSTAMP(5);       // device-wide barrier
         // -------- roll over --------
 #pragma unroll

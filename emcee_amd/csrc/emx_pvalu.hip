@@ -157,7 +157,7 @@ static __global__ __launch_bounds__(512) void k_persist_valu(const PersistArgs P
         if constexpr (LOCAL)
             persist_barrier_local(P, P.lepoch0 + (unsigned)n + 1u, bid, ngroups);
         else
-            persist_barrier_wide(P, (unsigned)n);
+            persist_barrier(P, P.epoch0 + (unsigned)n + 2u);       // (+ 1: the handshake was this launch's first barrier)
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             wi[k] = wi_n[k];

@@ -579,10 +579,8 @@ class DeviceEnsemble:
         self._ck(self.lib.emx_persist_info(self.ctx, out))
         loc = C.c_int64(0)
         self._ck(self.lib.emx_persist_local_launches(self.ctx, C.byref(loc)))
-        hier = C.c_int64(0)
-        self._ck(self.lib.emx_persist_hier_launches(self.ctx, C.byref(hier)))
         return {"qualifies": bool(out[0]), "launches": int(out[1]), "halfsteps": int(out[2]), "recovered": int(out[3]),
-                "local_launches": int(loc.value), "hier_launches": int(hier.value)}
+                "local_launches": int(loc.value)}
 
     def mtdev_info(self):
         """exact-mode plans made on the device (include/emx.h emx_mtdev_info)"""

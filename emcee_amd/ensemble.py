@@ -545,26 +545,30 @@ class EnsembleSampler(object):
         self.random_state = state.random_state
         self._refuse_partial_chain(store)
         ens = self._configure_device(descs, True)
-        if resident is not None and (resident._is_device_state(ens) or resident._restore_on_device(ens)):
+        check = not kw.get("skip_initial_state_check", False)
+        ill = ("Initial state has a large condition number. Make sure that your walkers are "
+               "linearly independent for the best performance")
+        on_device = resident is not None and (resident._is_device_state(ens) or resident._restore_on_device(ens))
+        # The reference re-checks a continuation too (ensemble.py:316-323): every path below checks first, then installs the state.
+        if on_device:
+            # on the device (emx_walkers_independent_resident: Householder QR where the ensemble is, ndim^2 numbers come back):
+            # nothing crosses PCIe on a path whose point is that
+            if check and not ens.walkers_independent():
+                raise ValueError(ill)
             lp0 = None                # log-probs of a state a run produced: finite by construction (NaN proposals are rejected)
-            # The reference re-checks a continuation too (ensemble.py:316-323).  Here on the device (emx_walkers_independent_resident:
-            # Householder QR where the ensemble is, ndim^2 numbers come back): nothing crosses PCIe on a path whose point is that.
-            if (not kw.get("skip_initial_state_check", False)) and (not ens.walkers_independent()):
-                raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
-                                 "linearly independent for the best performance")
-        elif resident is not None and (not kw.get("skip_initial_state_check", False)) and (not walkers_independent(state.coords)):
-            raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
-                             "linearly independent for the best performance")
-        elif state.log_prob is None:
-            ens.set_state(state.coords)
-            ens.eval_state_log_prob()
-            ens.raise_on_status()
-            lp0 = ens.get_state(coords=False)[1]
         else:
-            lp0 = np.asarray(state.log_prob, dtype=np.float64)
-            if np.shape(lp0) != (self.nwalkers,):
-                raise ValueError("incompatible input dimensions")
-            ens.set_state(state.coords, lp0)
+            if resident is not None and check and not walkers_independent(state.coords):
+                raise ValueError(ill)
+            if state.log_prob is None:
+                ens.set_state(state.coords)
+                ens.eval_state_log_prob()
+                ens.raise_on_status()
+                lp0 = ens.get_state(coords=False)[1]
+            else:
+                lp0 = np.asarray(state.log_prob, dtype=np.float64)
+                if np.shape(lp0) != (self.nwalkers,):
+                    raise ValueError("incompatible input dimensions")
+                ens.set_state(state.coords, lp0)
         if lp0 is not None and np.any(np.isnan(lp0)):
             raise ValueError("The initial log_prob was NaN")
         if store:

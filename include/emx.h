@@ -100,8 +100,6 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   "slab_skew"                1         0 ... 4: when the second wave of a SIMD starts its first tile's row loads
  *   -- persistent kernels (emx_persist_info) --
  *   "persist"                  1         0: never a persistent launch
- *   "persist_hier"             1         device-wide form: 1: the hierarchical barrier (flag words inside an XCD, one word per XCD across,
- *                                        polled by every workgroup), 0: two levels of arrival counters
  *   "persist_local"            1         0: never the one-XCD form        "persist_local_max_walkers"  8192
  *   "persist_valu"             1         0: element-wise targets on the per-half-step launches
  *   "persist_mix"              1         0: DE and snooker steps of a mixture in launches of their own
@@ -425,16 +423,11 @@ int emx_persist_info(emx_ctx* ctx, int64_t out[4]);
  * -- tuning "persist_exact" = 0: the per-half-step launches with an upload per step.  Move mixtures too
  * (round 5: the next step's move is read off the pipeline's plan before it is taken; "persist_exact_mix" = 0: one move only).  A
  * launch of this mode that cannot become resident is redone like a Philox one (round 5): the pipeline keeps the generator state
- * behind each of its last 64 steps and is taken back to the one in front of the launch; only when that is not possible (further
- * back than that) does status bit 3 stay, as for a barrier that timed out in the middle of a launch. */
+ * behind each of its last 64 steps and is taken back to the one in front of the launch.  Status bit 3 stays -- the run is void,
+ * as for a barrier that timed out in the middle of a launch -- when that is not possible: more than 60 steps of launches have
+ * been enqueued since the launch that gave up and are still unsettled, another pipeline has been started since, or a step begun
+ * with emx_step_begin is open when the failure is noticed. */
 int emx_persist_local_launches(emx_ctx* ctx, int64_t* n);
-/* ... and how many device-wide launches ran the HIERARCHICAL barrier between their half-steps (round 6; red_blue.py:85,104: split
- * k + 1 sees every update of split k -- the barrier is where the reference's Python loop has its sequence point): workgroup i of a
- * launch runs on XCD i mod 8 (verified per launch by the handshake; a launch that finds otherwise gives up untouched, is redone,
- * and the context keeps to the arrival counters), so arrival is collected inside an XCD through flag words in its L2 (plain
- * stores, sc1 loads), exchanged across the eight XCDs through one word each, which every workgroup polls.  Tuning
- * "persist_hier" = 0: two levels of arrival counters (read-modify-write atomics beyond the L2) as in rounds 3-5.  Same bits. */
-int emx_persist_hier_launches(emx_ctx* ctx, int64_t* n);
 /* host only: the grid the persistent kernel takes for `nwalkers` walkers updated in `nsplits` half-steps on a device of `num_cu`
  * CUs -- waves per workgroup (8 / 4 / 2 / 1; 0: no persistent grid, the per-half-step launches run) and workgroups */
 int emx_host_persist_shape(int64_t nwalkers, int32_t nsplits, int32_t num_cu, int32_t* waves_per_group, int32_t* groups);

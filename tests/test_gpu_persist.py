@@ -69,14 +69,6 @@ def test_persistent_kernel_gives_the_bits_of_the_launch_per_halfstep_path(N, D):
     assert np.array_equal(p["acc"], c["acc"])
 
 
-@pytest.mark.parametrize("N,trials,store,thin_by", [(65536, 60, False, 1), (32768, 60, False, 1), (16384, 40, True, 1)])
-def test_barrier_form_coherence_stress(N, trials, store, thin_by):
-    """k_persist's device-wide barrier of arrival counters (read-modify-write atomics beyond the L2; tuning persist_hier = 0 -- what
-    a grid of more than 256 workgroups still runs) under many short runs, as test_persistent_kernel_coherence_stress below does for
-    the default, hierarchical barrier"""
-    _stress(N, trials, store, thin_by, hier=0)
-
-
 @pytest.mark.parametrize("N,D,store,thin_by,move", [(512, 64, False, 1, "stretch"), (1024, 64, True, 1, "stretch"), (2048, 32, False, 1, "stretch"),
                                                     (4096, 48, True, 3, "stretch"), (8192, 64, False, 1, "stretch"), (8192, 16, False, 1, "stretch"),
                                                     (1024, 62, False, 1, "stretch"), (6144, 64, True, 1, "stretch"),
@@ -515,19 +507,16 @@ def test_persistent_kernel_coherence_stress(N, trials, store, thin_by):
     """The class of bug profiles/r03/persist_coherence.txt records (a variant of k_persist's barrier / sc1 protocol that was wrong
     once in ~120 runs) does not show in a single 37-step run: many short runs do.  366 trials x 50 steps in all, fresh Philox
     seed each, every trial bit-compared with the launch-per-half-step path started from the same state (both ensembles carry
-    their own state from trial to trial: one differing bit fails the trial it appears in).  ~30 s.  Above 8 192 walkers the
-    device-wide form runs its hierarchical barrier (round 6, persist_barrier_hier: flag words inside an XCD, one word per XCD
-    across): its plain-store / sc1-load protocol is what is stressed there."""
-    _stress(N, trials, store, thin_by, hier=1)
+    their own state from trial to trial: one differing bit fails the trial it appears in).  ~30 s."""
+    _stress(N, trials, store, thin_by)
 
 
-def _stress(N, trials, store, thin_by, hier):
+def _stress(N, trials, store, thin_by):
     nsteps = 50
     spec = dense_spec(N, 64, seed=11)
     ens = []
     for persist in (1, 0):
         e = native_ens(spec, persist)
-        e.set_tuning("persist_hier", hier)
         if store:
             e.chain_config(nsteps)
         ens.append(e)
@@ -549,7 +538,6 @@ def _stress(N, trials, store, thin_by, hier):
     p, c = ens[0].persist_info(), ens[1].persist_info()
     assert p["halfsteps"] == 2 * nsteps * thin_by * trials and c["launches"] == 0
     assert (p["local_launches"] == p["launches"]) == (N <= 8192) and p["recovered"] == 0
-    assert p["hier_launches"] == (p["launches"] if (hier and N > 8192) else 0)
     for e in ens:
         e.close()
 

@@ -1,7 +1,7 @@
 """Where a half-step of the persistent kernel (k_persist) goes: in-kernel timestamps of the first wave of every workgroup, summed
 over the half-steps of a launch (instrumented build, -DEMX_OPT_STAMPS=1: tools/ab_variants.sh stamps "-DEMX_OPT_STAMPS=1").
 
-  usage: python tools/persist_phase_clock.py [nwalkers] [ndim] [store] [persist_hier]"""
+  usage: python tools/persist_phase_clock.py [nwalkers] [ndim] [store]"""
 import os
 import subprocess
 import sys
@@ -22,13 +22,12 @@ NAMES = ["partner rows + next plan entries arrive (sc1 round trip)", "proposals,
          "device-wide barrier (arrive, poll)"]
 
 
-def main(N=65536, D=64, store=0, hier=1):
+def main(N=65536, D=64, store=0):
     import torch
     from emcee_amd.parallel import _DevView
     wl = bench.Workload("c2" if D == 64 else "c3", N)
     ens = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(ens, "philox")
-    ens.set_tuning("persist_hier", hier)      # the device-wide barrier: 0 arrival counters, 1 hierarchical, 2 flat words
     if store:
         ens.chain_config(4000)
     ens.run(200, 1, bool(store))
@@ -54,8 +53,8 @@ def main(N=65536, D=64, store=0, hier=1):
     # the barrier is passed niter - 1 times a launch, the other phases niter times
     per[:, 5] *= niter / np.maximum(niter - 1, 1)
     names = NAMES
-    print("k_persist (persist_hier = %d) %d x %d%s: %d workgroup-launch samples (%d half-steps a launch), counter tick %.2f ns, persist launches so far %d (%d with the hierarchical barrier)"
-          % (hier, N, D, ", stored chain" if store else "", len(raw), int(np.median(niter)), ns_per_tick, info["launches"], info["hier_launches"]))
+    print("k_persist %d x %d%s: %d workgroup-launch samples (%d half-steps a launch), counter tick %.2f ns, persist launches so far %d"
+          % (N, D, ", stored chain" if store else "", len(raw), int(np.median(niter)), ns_per_tick, info["launches"]))
     print("  wave-0 lifetime per half-step: median %.2f us" % np.median(wall_ns / niter / 1e3))
     for k, name in enumerate(names):
         print("  %-62s median %6.2f us   p10 %6.2f   p90 %6.2f   (%4.1f %%)"
@@ -66,4 +65,4 @@ def main(N=65536, D=64, store=0, hier=1):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    main(int(a[0]) if a else 65536, int(a[1]) if len(a) > 1 else 64, int(a[2]) if len(a) > 2 else 0, int(a[3]) if len(a) > 3 else 1)
+    main(int(a[0]) if a else 65536, int(a[1]) if len(a) > 1 else 64, int(a[2]) if len(a) > 2 else 0)
