@@ -241,8 +241,12 @@ def main(argv=None):
                     if key == "w128":     # fused: HBM roofline as for C2; the contraction is 5.4 flop per byte here (C2: 2.7)
                         fl = float(w2.D) ** 2 + 3.0 * w2.D
                         cfgs[name]["roofline"]["mfma_f64_frac_wall_clock"] = cfgs[name]["wu_per_s"] * fl / 1e12 / MFMA_F64_PEAK_TFLOPS
-                        cfgs[name]["roofline"]["kernel"] = ("emx::k_halfstep_slab<DPB=8,STRETCH> (csrc/emx_slab.hip: the tile's proposals in registers, a "
-                                                            "32-column LDS slab, eight waves a CU; 144 f64 MFMAs per 16-row tile)")
+                        if r2.get("halfsteps_per_launch", 1.0) > 1.0:
+                            cfgs[name]["roofline"]["kernel"] = ("emx::k_persist_slab<DPB=8,STRETCH> (csrc/emx_pslab.hip: %.1f half-steps per launch; the tile's proposals in "
+                                                                "registers, a 32-column LDS slab, eight waves a CU; 144 f64 MFMAs per 16-row tile)" % r2["halfsteps_per_launch"])
+                        else:
+                            cfgs[name]["roofline"]["kernel"] = ("emx::k_halfstep_slab<DPB=8,STRETCH> (csrc/emx_slab.hip: the tile's proposals in registers, a "
+                                                                "32-column LDS slab, eight waves a CU; 144 f64 MFMAs per 16-row tile)")
                 except Exception as e:  # noqa: BLE001
                     cfgs[name] = {"error": repr(e)}
                     log("config %s failed: %r" % (name, e))

@@ -4,7 +4,7 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip", "emx_hot.hip", "emx_wide.hip", "emx_mtdev.hip", "emx_slab.hip", "emx_pvalu.hip", "emx_pmix.hip")]     # translation units, built in parallel
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("emx.hip", "emx_small.hip", "emx_aux.hip", "emx_hot.hip", "emx_wide.hip", "emx_mtdev.hip", "emx_slab.hip", "emx_pvalu.hip", "emx_pmix.hip", "emx_pslab.hip", "emx_podd.hip")]     # translation units, built in parallel
 SRC = SRCS[0]
 # EMX_BUILD_FLAVOUR=exp: the experiments flavour (-DEMX_EXPERIMENTS=1: the timing experiments' skip-phase switches, tuning "ablate",
 # tools/ablate.py) as libemx_exp.so beside the product library; load it with EMX_LIB=<path>.  The product is built without them.

@@ -383,6 +383,11 @@ struct emx_ctx {
     int64_t tune_persist_span = 1;       // 0: a persistent launch ends with the batch of Philox plans it started in
     int64_t tune_persist_mix = 1;        // 0: a mixture's steps never share a launch (one run of one move per launch)
     int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
+    int64_t tune_persist_slab = 1;       // 0: dense targets of padded ndim 80 ... 128 never take the persistent slab kernel (emx_pslab.hip)
+    int64_t persist_slab_launches = 0;
+    int64_t tune_persist_odd = 1;        // 0: dense targets of odd ndim never take k_persist (emx_podd.hip)
+    int64_t tune_persist_slab_skew = 1;  // k_persist_slab: the second wave of a SIMD starts its row loads when its sibling's have arrived (0: at once; 2 ... 4: earlier)
+    int64_t tune_persist_slab_local_max = 4096;      // largest ensemble that takes the one-XCD form of k_persist_slab (beyond: the device-wide form; measured, profiles/r06/pslab.txt)
     int64_t call_steps = 1;              // steps of the emx_run call being served (1: emx_step_begin on its own)
     int64_t tune_persist_exact = 1;      // 0: exact (MT19937) mode never takes the persistent kernels
     int64_t tune_persist_valu = 1;       // 0: never the persistent kernel of the element-wise targets (emx_pvalu.hip)
@@ -893,8 +898,9 @@ int launch_split(emx_ctx* c, int move, int target, int S, int split, int pos0, i
         // (24.0 vs 26.5 us/step, tools/wpb_sweep.py)
         waves_per_block = c->tune_wpb > 0 ? (int)c->tune_wpb : (ntiles >= 2048 && move != MOVE_GAUSS ? 8 : 4);
         if (c->persist_cap) waves_per_block = c->persist_wpb;            // k_persist: about one workgroup per CU (persist_shape)
-        while (waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
-        lds = dense_lds_bytes(c->Dp, waves_per_block);
+        const bool pslab = c->persist_cap && c->Dp > 64;                 // k_persist_slab: a 32-column slab per wave instead of a whole tile
+        while (!pslab && waves_per_block > 1 && dense_lds_bytes(c->Dp, waves_per_block) > 160 * 1024) waves_per_block >>= 1;
+        lds = pslab ? slab_lds_bytes(c->Dp, waves_per_block) : dense_lds_bytes(c->Dp, waves_per_block);
         if (lds > 160 * 1024) {
             c->err = "dense Gaussian target: ndim too large for the LDS-resident precision matrix (max 128)";
             return -1;
@@ -1438,6 +1444,22 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     }
     if (!strcmp(key, "persist")) {           // 0: never the persistent half-step kernel (k_persist)
         c->tune_persist = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_slab_skew")) {
+        c->tune_persist_slab_skew = v < 0 ? 0 : (v > 4 ? 4 : v);
+        return 0;
+    }
+    if (!strcmp(key, "persist_slab_local_max_walkers")) {
+        c->tune_persist_slab_local_max = v;
+        return 0;
+    }
+    if (!strcmp(key, "persist_odd")) {       // 0: odd ndim on the per-half-step launches
+        c->tune_persist_odd = v ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "persist_slab")) {      // 0: padded ndim 80 ... 128 on the per-half-step launches (k_halfstep_slab / k_halfstep)
+        c->tune_persist_slab = v ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)
@@ -3187,10 +3209,26 @@ static int persist_shape_local_of(int64_t N, int nsplits, int64_t cu) {
 }
 static bool persist_local_ok(const emx_ctx* c, const emx_move_desc& m) {
     const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
-    return c->tune_persist_local != 0 && known && c->N <= c->tune_persist_local_max &&
+    // (the slab form's 109 KB workgroups: one XCD holds 32 of them, 4 096 walkers' worth at eight waves each run well there, 8 192 do
+    // not -- 34.0 against 17.9 us/step at ndim 128)
+    const int64_t lmax = (c->target == EMX_TARGET_DENSE_GAUSS && c->Dp > 64) ? std::min(c->tune_persist_local_max, c->tune_persist_slab_local_max)
+                                                                               : c->tune_persist_local_max;
+    return c->tune_persist_local != 0 && known && c->N <= lmax &&
            persist_shape_local_of(c->N, m.nsplits, c->num_cu) != 0;
 }
 static int persist_shape(const emx_ctx* c, int nsplits) { return persist_shape_of(c->N, nsplits, c->num_cu); }
+// the row layouts k_persist_valu is instantiated for (launch_persist_valu): rows of 8 lanes (ndim <= 64 even, <= 32 odd), of 4 lanes
+// (ndim <= 4, even ndim <= 8), of 16 lanes with one coordinate a lane and chunk (odd ndim 33 ... 63)
+static bool persist_valu_shape(const Shape& sh) {
+    return (sh.G == 8 && (sh.CH == 1 || sh.CH == 2 || sh.CH == 4)) || (sh.G == 4 && sh.CH == 1) || (sh.G == 16 && sh.V == 1 && sh.CH == 4);
+}
+// The fused dense Gaussian at padded ndim 80 ... 128 (even ndim 66 ... 128: rows of 16 lanes, two coordinates a lane and chunk): the
+// persistent form of the slab kernel (k_persist_slab, emx_pslab.hip; the stretch and DE moves) -- round 6
+static bool persist_slab_ok(const emx_ctx* c) {
+    if (!c->tune_persist_slab || c->target != EMX_TARGET_DENSE_GAUSS || dense_is_wide(c) || c->Dp < 80 || c->Dp > 128) return false;
+    const Shape sh = pick_shape(c->D, c->Dp);
+    return sh.G == 16 && sh.V == 2 && sh.CH == 4;
+}
 
 // the moves k_persist has an instantiation for (the other moves of a mixture run their steps through the per-half-step launches)
 // Checked, not assumed: the runtime's occupancy figure for this instantiation, block size and LDS need x the CU count must cover
@@ -3201,7 +3239,9 @@ static bool persist_grid_fits(const emx_ctx* cc, const emx_move_desc& m, int wpb
     if (c->persist_fits[m.kind] < 0) {
         const int64_t groups = c->N / m.nsplits / 16 / wpb;
         int per_cu = 0;
-        const hipError_t e = hot_persist_occupancy(c->Dp / 16, m.kind, 64 * wpb, dense_lds_bytes(c->Dp, wpb), &per_cu);
+        const hipError_t e = c->Dp > 64 ? persist_slab_occupancy(c->Dp / 16, m.kind, 64 * wpb, slab_lds_bytes(c->Dp, wpb), &per_cu)
+                             : (c->D & 1) ? persist_dense_odd_occupancy(c->Dp / 16, m.kind, 64 * wpb, dense_lds_bytes(c->Dp, wpb), &per_cu)
+                                        : hot_persist_occupancy(c->Dp / 16, m.kind, 64 * wpb, dense_lds_bytes(c->Dp, wpb), &per_cu);
         c->persist_fits[m.kind] = (e != hipSuccess || (int64_t)per_cu * c->num_cu >= groups) ? 1 : 0;     // (no answer: as before)
     }
     return c->persist_fits[m.kind] != 0;
@@ -3221,6 +3261,7 @@ static bool persist_valu_wide_ok(const emx_ctx* c, const emx_move_desc& m) {
 static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
     const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
     if (!known) return false;
+    if (c->target == EMX_TARGET_DENSE_GAUSS && c->Dp > 64 && (m.kind == EMX_MOVE_SNOOKER || !persist_slab_ok(c))) return false;       // (k_persist_slab: stretch and DE)
     if (persist_local_ok(c, m)) return true;            // (one workgroup per CU of one XCD by construction)
     if (c->target != EMX_TARGET_DENSE_GAUSS) return persist_valu_wide_ok(c, m);       // (element-wise targets: the one-XCD form, or -- exact mode -- the device-wide one)
     const int wpb = persist_shape(c, m.nsplits);
@@ -3240,7 +3281,7 @@ static bool persist_mix_local(const emx_ctx* c) {
 }
 static bool persist_mix_ok(const emx_ctx* cc) {
     emx_ctx* c = const_cast<emx_ctx*>(cc);
-    if (!c->tune_persist_mix || c->target != EMX_TARGET_DENSE_GAUSS) return false;
+    if (!c->tune_persist_mix || c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || (c->D & 1)) return false;      // (k_persist_mix: even ndim up to 64)
     if (c->rng_mode != EMX_RNG_PHILOX && !(c->rng_mode == EMX_RNG_MT19937 && persist_exact_ok(c))) return false;
     bool de = false, sn = false;
     for (const auto& m : c->moves) {
@@ -3271,11 +3312,11 @@ static bool persist_exact_ok(const emx_ctx* c) {
     {   // a target one of the persistent kernels takes (k_persist: dense Gaussian up to padded ndim 64; k_persist_valu: the element-wise
         // targets at the row shapes it is instantiated for) -- otherwise no persistent launch can follow, and the pipeline must not
         // be started, sized or paced (bursty consumer) for one
-        const bool dense = c->target == EMX_TARGET_DENSE_GAUSS && c->Dp <= 64 && !dense_is_wide(c);
+        const bool dense = c->target == EMX_TARGET_DENSE_GAUSS && (c->Dp <= 64 || persist_slab_ok(c)) && !dense_is_wide(c);
         bool valu = c->target == EMX_TARGET_ISO_GAUSS || c->target == EMX_TARGET_DIAG_GAUSS || c->target == EMX_TARGET_ROSENBROCK || c->target == EMX_TARGET_BOX;
         if (valu) {
             const Shape sh = pick_shape(c->D, c->D);
-            valu = (sh.G == 8 && (sh.CH == 1 || sh.CH == 2 || sh.CH == 4)) || (sh.G == 4 && sh.CH == 1);
+            valu = persist_valu_shape(sh);
         }
         if (!dense && !valu) return false;
     }
@@ -3303,15 +3344,18 @@ static bool persist_wanted(const emx_ctx* c) {
     // too, but its tokenizer is one 1024-thread, 107 KB workgroup that runs all the time: a persistent grid that holds every CU
     // leaves it none, and the two took turns -- k_persist 314 -> 1 150 us a launch, profiles/r04/mtdev_timeline.txt.)
     if (!(c->rng_mode == EMX_RNG_PHILOX || persist_exact_ok(c)) || c->world != 1 || c->comm || c->sendbuf || c->peers_ready || c->moves.empty()) return false;
-    if (c->target != EMX_TARGET_DENSE_GAUSS || c->Dp > 64 || dense_is_wide(c)) return false;
+    if (c->target != EMX_TARGET_DENSE_GAUSS || dense_is_wide(c) || (c->Dp > 64 && !persist_slab_ok(c))) return false;
     if (c->tune_ablate || (c->dbg && !EMX_OPT_STAMPS) || c->tune_spw || c->tune_wpb || c->tune_graph) return false;     // (an instrumented build stamps k_persist too)
     if (c->N < c->tune_persist_min_walkers) return false;
     bool any = false;
     for (const auto& m : c->moves) any = any || persist_move_ok(c, m);
     if (!any) return false;
-    // even ndim up to 64 (two coordinates per lane, rows of 8 lanes): the row layouts k_persist is instantiated for
+    if (c->Dp > 64) return true;           // (persist_slab_ok: rows of 16 lanes, even ndim 66 ... 128)
+    // ndim up to 64: the row layouts k_persist is instantiated for -- even ndim: two coordinates per lane, rows of 8 lanes (emx_hot.hip);
+    // odd ndim (round 6, emx_podd.hip): one coordinate per lane, rows of 8 lanes up to padded ndim 32, of 16 lanes beyond
     const Shape sh = pick_shape(c->D, c->Dp);
     const int dpb = c->Dp / 16;
+    if (sh.V == 1) return c->tune_persist_odd != 0 && (dpb <= 2 ? (sh.G == 8 && sh.CH == 2 * dpb) : (sh.G == 16 && sh.CH == 4));
     return sh.G == 8 && sh.V == 2 && sh.CH == (dpb == 1 ? 1 : dpb == 2 ? 2 : 4);
 }
 
@@ -3325,7 +3369,7 @@ static bool persist_valu_wanted(const emx_ctx* c) {
     if (c->tune_ablate || c->dbg || c->tune_spw || c->tune_wpb || c->tune_graph) return false;
     if (c->N < c->tune_persist_min_walkers) return false;
     const Shape sh = pick_shape(c->D, c->D);
-    if (!((sh.G == 8 && (sh.CH == 1 || sh.CH == 2 || sh.CH == 4)) || (sh.G == 4 && sh.CH == 1))) return false;      // (launch_persist_valu's instantiations)
+    if (!persist_valu_shape(sh)) return false;      // (launch_persist_valu's instantiations)
     bool any = false;
     for (const auto& m : c->moves) any = any || persist_local_ok(c, m) || persist_valu_wide_ok(c, m);
     return any;
@@ -3635,6 +3679,14 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             e = launch_persist_valu(shv.G, shv.V, shv.CH, launch_move, launch_local ? 1 : 0, grid, block, c->stream, P);
         } else if (launch_mix) {
             e = launch_persist_mix(c->Dp / 16, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
+        } else if (c->Dp > 64) {
+            // (lean launches carry no ablation mask: bit 8 = skewed start, bits 9-10 = when the sibling starts -- as k_halfstep_slab;
+            // tuning "persist_slab_skew": 0 off, 1 ... 4)
+            P.base.ablate = c->tune_persist_slab_skew ? 256 | (int32_t)((c->tune_persist_slab_skew - 1) << 9) : 0;
+            e = launch_persist_slab(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
+            c->persist_slab_launches++;
+        } else if (c->D & 1) {
+            e = launch_persist_dense_odd(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
         } else {
             e = launch_hot_persist_dense(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
         }

@@ -1200,8 +1200,24 @@ constexpr int EMX_CPOL_SC1 = 16;
 // CPOL: EMX_CPOL_SC1 (agent scope) or 0 (plain: the one-XCD form's stores)
 template <int G, int V, int CH, int CPOL = EMX_CPOL_SC1>
 __device__ __forceinline__ void load_row_agent(Row<G, V, CH>& r, __amdgpu_buffer_rsrc_t rsrc, int row, int D, int gl) {
-    static_assert(V == 2, "two coordinates per lane and chunk");
+    static_assert(V == 2 || V == 1, "two coordinates per lane and chunk (even ndim), or one (odd ndim: rows are 8-byte aligned only)");
     const int base = row * D;
+    if constexpr (V == 1) {
+        typedef unsigned int emx_u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int d = c * G + gl;
+            if (d < D) {
+                const emx_u2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (base + d) * 8, 0, CPOL);
+                double t;
+                __builtin_memcpy(&t, &w, 8);
+                r.x[c][0] = t;
+            } else {
+                r.x[c][0] = 0.0;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int d = (c * G + gl) * V;
@@ -1219,8 +1235,22 @@ __device__ __forceinline__ void load_row_agent(Row<G, V, CH>& r, __amdgpu_buffer
 }
 template <int G, int V, int CH, int CPOL = EMX_CPOL_SC1>
 __device__ __forceinline__ void store_row_agent(const Row<G, V, CH>& r, __amdgpu_buffer_rsrc_t rsrc, int row, int D, int gl) {
-    static_assert(V == 2, "two coordinates per lane and chunk");
+    static_assert(V == 2 || V == 1, "two coordinates per lane and chunk (even ndim), or one (odd ndim)");
     const int base = row * D;
+    if constexpr (V == 1) {
+        typedef unsigned int emx_u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int d = c * G + gl;
+            if (d < D) {
+                emx_u2 w;
+                const double t = r.x[c][0];
+                __builtin_memcpy(&w, &t, 8);
+                __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, (base + d) * 8, 0, CPOL);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int d = (c * G + gl) * V;

@@ -44,6 +44,12 @@ hipError_t launch_persist_valu(int G, int V, int CH, int move, int local, dim3 g
 // emx_slab.hip: the fused dense half-step at padded ndim 80 ... 128 with the proposals in registers and a 32-column LDS slab
 hipError_t launch_slab_dense(int dpb, int move, dim3 grid, dim3 block, size_t lds, hipStream_t st, const HalfStepArgs& a);
 size_t slab_lds_bytes(int Dp, int waves);
+// emx_podd.hip: k_persist for odd ndim up to 63 (one coordinate per lane and chunk)
+hipError_t launch_persist_dense_odd(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
+hipError_t persist_dense_odd_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu);
+// emx_pslab.hip: its persistent form (k_persist_slab: device-wide and one-XCD; the stretch and DE moves) -- same LDS layout
+hipError_t launch_persist_slab(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
+hipError_t persist_slab_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu);
 
 // Wide dense Gaussian targets (padded ndim > 112, emx_wide.hip): log-probs of a block of rows, and the decision + commit
 // of a half-step whose proposals sit in qout / fout.

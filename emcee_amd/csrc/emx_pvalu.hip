@@ -9,7 +9,8 @@
 // (eval_valu_target), decides (red_blue.py:96-101) and commits (move.py:29-45), then meets the other workgroups at the flag barrier
 // -- up to 32 half-steps a launch.  Same device functions in the same order as k_halfstep, hence the same bits
 // (tests/test_gpu_persist.py).  Ensembles of up to 8 192 walkers, Philox plans, one replica; row layouts of 8 lanes per walker
-// (ndim <= 64 even, <= 32 odd); everything else keeps the per-half-step launches.
+// (ndim <= 64 even, <= 32 odd) and of 16 lanes with one coordinate a lane (odd ndim 33 ... 63, round 6); everything else keeps the
+// per-half-step launches.
 #include "emx_launch.hpp"
 
 namespace emx {
@@ -190,6 +191,8 @@ hipError_t launch_persist_valu(int G, int V, int CH, int move, int local, dim3 g
         return local ? launch_pv<g, v, c, true>(move, grid, block, st, P) : launch_pv<g, v, c, false>(move, grid, block, st, P);
     EMX_CASE(4, 2, 1) EMX_CASE(4, 1, 1)
     EMX_CASE(8, 2, 1) EMX_CASE(8, 2, 2) EMX_CASE(8, 2, 4) EMX_CASE(8, 1, 1) EMX_CASE(8, 1, 2) EMX_CASE(8, 1, 4)
+    EMX_CASE(16, 1, 4)        // round 6: odd ndim 33 ... 63 (rows of 16 lanes, one coordinate a lane and chunk: 192-237 VGPRs.  Even ndim
+                              // 66 ... 128 would be <16, 2, 4>: 33-242 spilled registers -- those shapes keep the per-half-step launches)
 #undef EMX_CASE
     return hipErrorInvalidValue;
 }

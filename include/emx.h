@@ -102,6 +102,9 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   "persist"                  1         0: never a persistent launch
  *   "persist_local"            1         0: never the one-XCD form        "persist_local_max_walkers"  8192
  *   "persist_valu"             1         0: element-wise targets on the per-half-step launches
+ *   "persist_slab"             1         0: dense targets of padded ndim 80 ... 128 on the per-half-step launches (1: k_persist_slab, emx_pslab.hip)
+ *   "persist_slab_skew"        1         k_persist_slab: 0 ... 4, as "slab_skew"   "persist_slab_local_max_walkers"  4096   its one-XCD form's largest ensemble
+ *   "persist_odd"              1         0: dense targets of odd ndim on the per-half-step launches (1: k_persist with one coordinate per lane, emx_podd.hip)
  *   "persist_mix"              1         0: DE and snooker steps of a mixture in launches of their own
  *   "persist_span"             1         0: a launch ends with its Philox plan batch
  *   "persist_min_walkers"      512       smallest ensemble             "persist_timeout_ms"   2000      bound of a barrier wait
