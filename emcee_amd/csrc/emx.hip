@@ -1459,7 +1459,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "persist_slab")) {      // 0: padded ndim 80 ... 128 on the per-half-step launches (k_halfstep_slab / k_halfstep)
-        c->tune_persist_slab = v ? 1 : 0;
+        c->tune_persist_slab = (v == 1 || v == 2) ? v : 0;          // (2: also where the per-half-step slab kernel is level -- persist_slab_ok)
         return 0;
     }
     if (!strcmp(key, "persist_local")) {     // 0: never the one-XCD form (k_persist<..., LOCAL>)
@@ -3226,6 +3226,11 @@ static bool persist_valu_shape(const Shape& sh) {
 // persistent form of the slab kernel (k_persist_slab, emx_pslab.hip; the stretch and DE moves) -- round 6
 static bool persist_slab_ok(const emx_ctx* c) {
     if (!c->tune_persist_slab || c->target != EMX_TARGET_DENSE_GAUSS || dense_is_wide(c) || c->Dp < 80 || c->Dp > 128) return false;
+    // Where the launch-per-half-step slab kernel fills the chip -- padded ndim 112 / 128 with eight tiles or more per CU and half-step
+    // (65 536 walkers on 256 CUs) -- the persistent form is level or 1-4 % behind (43.7 against 43.3 us/step at ndim 128, 38.9 / 37.8
+    // at 112, DE 53.5 / 51.5: its barrier and agent-scope accesses cost what the launch gap and the image staging did;
+    // profiles/r06/pslab.txt): those shapes keep the launches.  Tuning "persist_slab" = 2 takes the persistent form there too (tests).
+    if (c->tune_persist_slab != 2 && c->Dp >= 112 && c->N / 2 / 16 >= 8 * (int64_t)c->num_cu) return false;
     const Shape sh = pick_shape(c->D, c->Dp);
     return sh.G == 16 && sh.V == 2 && sh.CH == 4;
 }

@@ -52,7 +52,7 @@ def test_device_wide_form_gives_the_bits_of_the_per_half_step_path(N, D, move, s
     """two calls of 21 steps (full and partial launches: 16 + 5), every workgroup shape of the persistent grid (8, 4, 2 waves), every
     padded ndim the kernel is instantiated for (80, 96, 112, 128), even ndim that is not a multiple of 16"""
     spec = full_spec(N, D, "dense", [S(move)], seed=7)
-    p = _run(spec, 1, 2, 21, thin_by, store, local=0)
+    p = _run(spec, 1, 2, 21, thin_by, store, local=0, tuning={"persist_slab": 2})      # (2: also at 65 536 x 112 / 128, where the launches are level)
     c = _run(spec, 0, 2, 21, thin_by, store)
     assert p["info"]["qualifies"] and p["info"]["launches"] >= 4 and p["info"]["halfsteps"] == 84 * thin_by and p["info"]["local_launches"] == 0
     assert c["info"]["launches"] == 0 and p["acc"].any()
@@ -87,12 +87,17 @@ def test_mixture_of_stretch_and_de_and_what_does_not_qualify():
         ens.run(5, 1, False)
         assert ens.persist_info()["launches"] == 0 and ens.status() == 0
         ens.close()
-    # tuning persist_slab = 0: the per-half-step launches
+    # tuning persist_slab = 0: the per-half-step launches; and by default 65 536 x 128 keeps them (level there: persist_slab_ok)
     spec = full_spec(4096, 128, "dense", [S("stretch")], seed=10)
     ens = native_ens(spec, 1)
     ens.set_tuning("persist_slab", 0)
     ens.run(5, 1, False)
     assert ens.persist_info()["launches"] == 0
+    ens.close()
+    spec = full_spec(65536, 128, "dense", [S("stretch")], seed=10)
+    ens = native_ens(spec, 1)
+    ens.run(5, 1, False)
+    assert ens.persist_info()["launches"] == 0 and not ens.persist_info()["qualifies"]
     ens.close()
 
 
@@ -129,6 +134,7 @@ def test_coherence_stress(N, trials):
     (the class of bug that shows once in a hundred runs: profiles/r03/persist_coherence.txt)"""
     spec = full_spec(N, 128, "dense", [S("stretch")], seed=12)
     ens = [native_ens(spec, persist) for persist in (1, 0)]
+    ens[0].set_tuning("persist_slab", 2)
     for t in range(trials):
         got = []
         for e in ens:
@@ -148,7 +154,7 @@ def test_coherence_stress(N, trials):
 @pytest.mark.parametrize("N,D,move,store,thin_by,local", [
     (65536, 63, "stretch", False, 1, 0), (65536, 33, "de", True, 1, 0), (32768, 47, "snooker", False, 1, 0), (16384, 17, "stretch", True, 2, 0),
     (16384, 5, "stretch", False, 1, 0), (8192, 63, "stretch", True, 1, 1), (4096, 33, "snooker", False, 1, 1), (2048, 49, "de", True, 1, 1),
-    (1024, 31, "stretch", False, 1, 1), (512, 9, "de", True, 3, 1), (4096, 33, "stretch", False, 1, 0),
+    (1024, 31, "stretch", False, 1, 1), (1024, 9, "de", True, 3, 1), (4096, 33, "stretch", False, 1, 0),
 ])
 def test_odd_ndim_runs_persistently(N, D, move, store, thin_by, local):
     """csrc/emx_podd.hip (round 6): k_persist in the row layouts of an odd ndim -- one coordinate per lane and chunk (rows of an odd

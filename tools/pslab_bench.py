@@ -31,7 +31,7 @@ for move in ("stretch", "de"):
             wl = WL(N, D, move)
             out = []
             for ps in (1, 0):
-                r = bench.measure_single(wl, K, 10, want_kernel=False, spin_s=0.05, tuning={"persist_slab": ps})
+                r = bench.measure_single(wl, K, 10, want_kernel=False, spin_s=0.05, tuning={"persist_slab": 2 * ps})
                 out.append((r["wall_s"] * 1e6 / K, r.get("halfsteps_per_launch", 1.0)))
             B = wl.bytes_per_update(False)
             print("%-28s %9.2f us %9.2f us %7.2fx   %.3f   (%.0f half-steps a launch)" % (
