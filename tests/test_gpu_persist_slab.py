@@ -20,6 +20,7 @@ S = so.MoveSpec
 
 def _run(spec, persist, calls, nsteps, thin_by, store, local=1, tuning=None):
     ens = native_ens(spec, persist)
+    ens.set_tuning("small_kernel", 0)          # (an ensemble that fits one workgroup's LDS -- 1 024 x 9 -- would take k_small_run)
     ens.set_tuning("persist_local", local)
     for k, v in (tuning or {}).items():
         ens.set_tuning(k, v)
