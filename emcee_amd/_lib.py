@@ -116,6 +116,7 @@ SIGNATURES = {
     "emx_comm_destroy": (C.c_int, [_P]),
     "emx_comm_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "emx_pipeline_stats": (C.c_int, [_P, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "emx_pipeline_handovers": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "emx_persist_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "emx_mtdev_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "emx_mtdev_debug": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_void_p, C.c_int64]),

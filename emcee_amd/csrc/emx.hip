@@ -385,6 +385,9 @@ struct emx_ctx {
     int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
     int64_t tune_persist_slab = 1;       // 0: dense targets of padded ndim 80 ... 128 never take the persistent slab kernel (emx_pslab.hip)
     int64_t persist_slab_launches = 0;
+    int64_t tune_mt_regen_min = 16384;   // exact mode, host pipeline with device finish: from this many walkers on a stretch step's fixed-length draws are made again
+                                         // on the device from the generator's state (k_plan_regen) instead of crossing PCIe; 0: never
+    int64_t pipe_regen_steps = 0;
     int64_t tune_persist_odd = 1;        // 0: dense targets of odd ndim never take k_persist (emx_podd.hip)
     int64_t tune_persist_slab_skew = 1;  // k_persist_slab: the second wave of a SIMD starts its row loads when its sibling's have arrived (0: at once; 2 ... 4: earlier)
     int64_t tune_persist_slab_local_max = 4096;      // largest ensemble that takes the one-XCD form of k_persist_slab (beyond: the device-wide form; measured, profiles/r06/pslab.txt)
@@ -1458,6 +1461,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_persist_odd = v ? 1 : 0;
         return 0;
     }
+    if (!strcmp(key, "mt_regen_min_walkers")) {      // 0: never k_plan_regen (takes effect when a pipeline starts)
+        PIPE_STOP(c);
+        c->tune_mt_regen_min = v < 0 ? 0 : v;
+        return 0;
+    }
     if (!strcmp(key, "persist_slab")) {      // 0: padded ndim 80 ... 128 on the per-half-step launches (k_halfstep_slab / k_halfstep)
         c->tune_persist_slab = (v == 1 || v == 2) ? v : 0;          // (2: also where the per-half-step slab kernel is level -- persist_slab_ok)
         return 0;
@@ -2154,7 +2162,8 @@ static int pipe_start(emx_ctx* c) {
     const bool devfin = c->tune_mt_device_finish != 0 && c->pipe_nsinks == PIPE_SINKS && c->world == 1 && !c->comm && !c->sendbuf &&
                         !c->peers_ready && c->target != EMX_TARGET_HOST && !c->tune_full_plan;
     c->pipe = new MtPlanPipeline(c->mt, c->N, c->D, (int32_t)c->moves.size(), c->moves.data(), c->cdf.data(), nsteps, sinks,
-                                 c->pipe_nsinks, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0), false, devfin, c->pipe_nsinks == PLAN_RING);
+                                 c->pipe_nsinks, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0), false, devfin, c->pipe_nsinks == PLAN_RING,
+                                 devfin ? c->tune_mt_regen_min : 0);
     return 0;
 }
 
@@ -2301,7 +2310,9 @@ static int pipe_take(emx_ctx* c) {
     const bool still_read = s.busy && hipEventQuery(s.consumed_ref) != hipSuccess;
     if (still_read) HIPOK(c, hipStreamWaitEvent(c->up_stream, s.consumed_ref, 0));
     const int stretch = c->moves[cur.move].kind == EMX_MOVE_STRETCH;
-    const size_t bytes = plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE);
+    // (a regen step: `order` and, in the p0 column's place right behind it, the generator states -- PipeStepInfo::regen)
+    const size_t bytes = info.regen ? ((N * 4 + (size_t)info.regen_nseg * 624 * 4 + 255) & ~(size_t)255)
+                                    : plan_upload_bytes(N, stretch && c->world == 1 ? EMX_MOVE_STRETCH : EMX_MOVE_DE);
     // The upload stream carries copies only: the conversion kernel behind a copy made every step's upload wait for a compute unit
     // the half-step kernels hold (54 us per step of 65 536 walkers whatever the pipeline did; profiles/r05/exact_c2.md) -- it now
     // runs on the consumer's stream, in front of the half-steps that need it.  (A large plan in two halves on two streams -- one
@@ -2319,6 +2330,18 @@ static int pipe_take(emx_ctx* c) {
         R.S = info.S;
         R.wr_words = info.wr_ring;
         for (int k = 0; k <= info.S; ++k) R.off[k] = info.off[k];
+        if (info.regen) {
+            // the fixed-length draws made again from the generator states the upload brought (k_plan_regen), then converted as ever
+            PlanRegenArgs G{};
+            G.dev = R.dev;
+            G.N = (int32_t)N;
+            G.ns0 = info.off[1] - info.off[0];
+            G.off = info.regen_off;
+            G.nseg = info.regen_nseg;
+            hipLaunchKernelGGL(k_plan_regen, dim3((unsigned)info.regen_nseg), dim3(256), 0, c->stream, G);
+            R.wr_p1 = 1;
+            c->pipe_regen_steps++;
+        }
         hipLaunchKernelGGL(k_plan_raw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, R);
         c->pipe_raw_steps++;
         cur.devplan = true;                 // (emx_plan_get: the finished columns exist on the device only)
@@ -5144,6 +5167,12 @@ int emx_pipeline_stats(emx_ctx* c, double out[6], int64_t* steps_produced, int32
     return 0;
 }
 
+int emx_pipeline_handovers(emx_ctx* c, int64_t* raw_steps, int64_t* regen_steps) {
+    if (raw_steps) *raw_steps = c->pipe_raw_steps;
+    if (regen_steps) *regen_steps = c->pipe_regen_steps;
+    return 0;
+}
+
 int emx_comm_count(emx_ctx* c, int32_t* ranks_out) {
     *ranks_out = 0;
     if (!c->comm) return 0;
@@ -5225,6 +5254,72 @@ int emx_host_plan_mt(emx_mt* m, int64_t N, int32_t D, const emx_move_desc* mv, i
     return make_exact_plan(m->mt, N, D, *mv, labels, off, order, p0, p1, p2, s0, uacc);
 }
 
+// Host twins of k_plan_regen and k_plan_raw, for emx_host_plan_mt_stream's test mode (EMX_TEST_PIPE_DEVFIN): what the consumer's
+// kernels do with a raw / regen step, in plain C++ -- so that the tokenizer's hand-over (which states, which offset) is checked against
+// the serial twin without a GPU (tests/test_mt_pipeline_cpu.py).
+static inline uint32_t host_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+static inline uint32_t host_mix(uint32_t u, uint32_t v) {
+    const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu);
+}
+static void host_regen_twin(const PipeStepInfo& info, const PlanSink& sk, int64_t N, std::vector<uint32_t>& wr) {
+    const int64_t ns0 = info.off[1] - info.off[0], F0 = 5 * ns0, F = 5 * N;
+    uint32_t* wz = reinterpret_cast<uint32_t*>(sk.s0);
+    uint32_t* wu = reinterpret_cast<uint32_t*>(sk.uacc);
+    wr.assign((size_t)N, 0u);
+    const uint32_t* keys = reinterpret_cast<const uint32_t*>(sk.p0);
+    uint32_t a[624], b[624];
+    for (int seg = 0; seg < info.regen_nseg; ++seg) {
+        memcpy(a, keys + (size_t)seg * 624, sizeof(a));
+        for (int blk = 0; blk < PIPE_REGEN_SB; ++blk) {
+            const int64_t r0 = ((int64_t)seg * PIPE_REGEN_SB + blk) * 624 - info.regen_off;
+            if (r0 >= F) break;
+            for (int i = 0; i < 624; ++i) {
+                const int64_t r = r0 + i;
+                if (r < 0 || r >= F) continue;
+                const bool split = r >= F0;
+                const int64_t q = split ? r - F0 : r, base = split ? ns0 : 0, ns = split ? N - ns0 : ns0;
+                if (q < 2 * ns)
+                    wz[2 * base + q] = a[i];
+                else if (q < 3 * ns)
+                    wr[(size_t)(base + q - 2 * ns)] = a[i];
+                else
+                    wu[2 * base + (q - 3 * ns)] = a[i];
+            }
+            for (int kk = 0; kk < 227; ++kk) b[kk] = a[kk + 397] ^ host_mix(a[kk], a[kk + 1]);
+            for (int kk = 227; kk < 623; ++kk) b[kk] = b[kk - 227] ^ host_mix(a[kk], a[kk + 1]);
+            b[623] = b[396] ^ host_mix(a[623], b[0]);
+            memcpy(a, b, sizeof(a));
+        }
+    }
+}
+static void host_raw_twin(const PipeStepInfo& info, const PlanSink& sk, int64_t N, double a, const std::vector<uint32_t>* wr_from) {
+    for (int s = 0; s < info.S; ++s) {
+        const int64_t base = info.off[s], ns = info.off[s + 1] - info.off[s];
+        for (int64_t t = base; t < base + ns; ++t) {
+            const uint32_t* wz = reinterpret_cast<const uint32_t*>(sk.s0 + t);
+            const uint32_t* wu = reinterpret_cast<const uint32_t*>(sk.uacc + t);
+            auto dbl = [](uint32_t w0, uint32_t w1) {
+                const int32_t hi = (int32_t)(host_temper(w0) >> 5), lo = (int32_t)(host_temper(w1) >> 6);
+                return ((double)hi * 67108864.0 + (double)lo) / 9007199254740992.0;
+            };
+            const double u = dbl(wz[0], wz[1]), ua = dbl(wu[0], wu[1]);
+            const double tt = (a - 1.0) * u + 1.0;
+            const uint32_t w = wr_from ? (*wr_from)[(size_t)t] : (uint32_t)sk.p0[t];
+            const int32_t r = info.wr_ring ? (int32_t)(host_temper(w) & (uint32_t)(N - ns - 1)) : (int32_t)w;
+            sk.p0[t] = r < base ? sk.order[r] : sk.order[r + ns];
+            sk.s0[t] = tt * tt / a;
+            sk.uacc[t] = ua;
+        }
+    }
+}
+
 int emx_host_plan_mt_stream(emx_mt* m, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves, const double* cdf,
                             int64_t nsteps, int32_t nworkers, int32_t nsinks, int32_t* moves_out, int32_t* order, int32_t* p0,
                             int32_t* p1, int32_t* p2, double* s0, double* uacc, double* seconds_out) {
@@ -5246,13 +5341,23 @@ int emx_host_plan_mt_stream(emx_mt* m, int64_t N, int32_t D, int32_t nmoves, con
     const auto t0 = std::chrono::steady_clock::now();
     // fill_unused_fields: a stretch plan's p1 / p2 carry the walker itself, as emx_host_plan_mt's do (the header promises the
     // same plans; emx_run's own pipeline leaves those columns alone because nothing reads or uploads them)
-    MtPlanPipeline pipe(m->mt, N, D, nmoves, moves, cdf, nsteps, sinks.data(), nsinks, nworkers, true);
+    // test mode, EMX_TEST_PIPE_DEVFIN = <regen_min_walkers> (0: raw steps only): the pipeline in its device-finish configuration, the
+    // consumer's kernels played by their host twins above
+    const char* tdf = getenv("EMX_TEST_PIPE_DEVFIN");
+    MtPlanPipeline pipe(m->mt, N, D, nmoves, moves, cdf, nsteps, sinks.data(), nsinks, nworkers, true, tdf != nullptr, false, tdf ? atoll(tdf) : 0);
     int64_t n = 0;
+    std::vector<uint32_t> wr;
     for (; n < nsteps; ++n) {
         PipeStepInfo info;
         if (!pipe.wait_ready(n, info)) break;
         if (moves_out) moves_out[n] = info.move;
         const PlanSink& sk = sinks[n % nsinks];
+        if (info.raw) {
+            if (info.regen) host_regen_twin(info, sk, N, wr);
+            host_raw_twin(info, sk, N, moves[info.move].a, info.regen ? &wr : nullptr);
+            if (moves_out) moves_out[n] |= 256 | (info.regen ? 512 : 0);          // (test mode only: how the step was handed over)
+            for (int64_t t = 0; t < N; ++t) sk.p1[t] = sk.p2[t] = sk.order[t];        // (fill_unused_fields: raw steps leave them to the consumer)
+        }
         const size_t o = (size_t)n * (size_t)N;
         if (order) memcpy(order + o, sk.order, (size_t)N * 4);
         if (p0) memcpy(p0 + o, sk.p0, (size_t)N * 4);

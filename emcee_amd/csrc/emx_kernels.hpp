@@ -2372,6 +2372,77 @@ static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, i
     dl[N + pos] = A.stretch[b] ? ((double)A.D - 1.0) * plan_log(z) : 0.0;
 }
 
+// Exact mode, large ensembles (round 6): the fixed-length draws of a stretch step MADE AGAIN on the device.  The 5 N words behind the
+// shuffle -- per split rand(Ns), randint(Nc, Ns) with Nc a power of two, Ns x rand(): stretch.py:30-32, red_blue.py:100, contiguous in
+// the reference's stream -- used to cross from the generator's core to the tokenizer's, into the pinned staging buffer and over PCIe
+// (1.3 MB a step at 65 536 walkers: what bounded the host pipeline, profiles/r05/exact_c2.md).  Now the tokenizer steps over them and
+// passes on the generator STATE at every REGEN_SB-th block of the region (the plan's p0 column holds them: 624 words each); one
+// workgroup per state runs MT19937's recurrence REGEN_SB - 1 blocks forward and drops every word where k_plan_raw expects it,
+// untempered: the pairs of rand() in the s0 / uacc columns, the randint words in the p1 column (p0 is being read).  Same words, same
+// places as the host finisher's copies: the plans stay bit-identical (tests/test_gpu_regen.py).
+constexpr int REGEN_SB = 8;            // (= PIPE_REGEN_SB, emx_mtpipe.hpp)
+struct PlanRegenArgs {
+    char* dev;                         // device slot block ([order|p0] [s0|uacc] [p1|p2] [logu|fac])
+    int32_t N, ns0;                    // walkers; members of split 0 (split 1: N - ns0)
+    int32_t off;                       // the region's first word inside the first state's block
+    int32_t nseg;
+};
+static __device__ __forceinline__ uint32_t regen_mix(uint32_t u, uint32_t v) {
+    const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu);
+}
+static __global__ __launch_bounds__(256) void k_plan_regen(const PlanRegenArgs A) {
+    __shared__ uint32_t key[2][624];
+    const int tid = threadIdx.x, seg = blockIdx.x;
+    const size_t N = (size_t)A.N;
+    const uint32_t* keys = reinterpret_cast<const uint32_t*>(A.dev + N * 4);
+    for (int i = tid; i < 624; i += 256) key[0][i] = keys[(size_t)seg * 624 + i];
+    __syncthreads();
+    uint32_t* wz = reinterpret_cast<uint32_t*>(A.dev + N * 8);        // s0 column: two words a slot
+    uint32_t* wu = reinterpret_cast<uint32_t*>(A.dev + N * 16);       // uacc column
+    uint32_t* wr = reinterpret_cast<uint32_t*>(A.dev + N * 24);       // p1 column: one word a slot
+    const long long F0 = 5ll * A.ns0, F = 5ll * (long long)A.N;
+    int cur = 0;
+    for (int b = 0; b < REGEN_SB; ++b) {
+        const long long r0 = ((long long)seg * REGEN_SB + b) * 624 - A.off;     // region index of this block's first word
+        if (r0 >= F) break;                                                      // (uniform)
+        for (int i = tid; i < 624; i += 256) {
+            const long long r = r0 + i;
+            if (r < 0 || r >= F) continue;
+            const int split = r >= F0;
+            const long long q = split ? r - F0 : r;
+            const int base = split ? A.ns0 : 0, ns = split ? A.N - A.ns0 : A.ns0;
+            const uint32_t w = key[cur][i];
+            if (q < 2ll * ns)
+                wz[2 * (size_t)base + (size_t)q] = w;                  // stretch.py:30 rand(Ns)
+            else if (q < 3ll * ns)
+                wr[(size_t)base + (size_t)(q - 2ll * ns)] = w;         // stretch.py:32 randint(Nc, Ns)
+            else
+                wu[2 * (size_t)base + (size_t)(q - 3ll * ns)] = w;     // red_blue.py:100 rand() per walker
+        }
+        if (b + 1 < REGEN_SB) {
+            // one twist: three dependent phases of <= 227 words (word kk needs the NEW word kk - 227)
+            const uint32_t* o = key[cur];
+            uint32_t* n = key[cur ^ 1];
+            if (tid < 227) n[tid] = o[tid + 397] ^ regen_mix(o[tid], o[tid + 1]);
+            __syncthreads();
+            if (tid < 227) {
+                const int kk = tid + 227;
+                n[kk] = n[kk - 227] ^ regen_mix(o[kk], o[kk + 1]);
+            }
+            __syncthreads();
+            if (tid < 169) {
+                const int kk = tid + 454;
+                n[kk] = n[kk - 227] ^ regen_mix(o[kk], o[kk + 1]);
+            } else if (tid == 169) {
+                n[623] = n[396] ^ regen_mix(o[623], n[0]);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+}
+
 // Device finish of an exact-mode stretch plan (round 5; csrc/emx_mtpipe.hpp, PipeStepInfo::raw).  The host pipeline hands over what
 // only it can make -- `order` (the shuffled split, red_blue.py:76-85) and, where the complement's size is not a power of two, the
 // accepted randint values -- and passes every fixed-length draw on as it left the generator: MT19937 STATE words, copied into the
@@ -2385,6 +2456,7 @@ struct PlanRawArgs {
     double a;                          // the stretch scale (stretch.py:30)
     int32_t off[PLAN_RAW_SPLITS + 1];
     int32_t N, D, S, wr_words;         // wr_words: p0 holds generator words (power-of-two complement), else accepted randint values
+    int32_t wr_p1;                     // 1: the randint words stand in the p1 column (k_plan_regen put them there: p0 held the generator states)
 };
 static __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     y ^= (y >> 11);
@@ -2412,7 +2484,7 @@ static __global__ __launch_bounds__(256) void k_plan_raw(const PlanRawArgs A) {
     const double tt = (A.a - 1.0) * u + 1.0;                    // stretch.py:30  ((a - 1) * rand + 1) ** 2 / a
     const double zz = tt * tt / A.a;
     const double ua = mt_pair_double(wu.x, wu.y);               // red_blue.py:100
-    const uint32_t w = (uint32_t)di[N + pos];
+    const uint32_t w = A.wr_p1 ? reinterpret_cast<const uint32_t*>(A.dev + N * 24)[pos] : (uint32_t)di[N + pos];
     const int32_t r = A.wr_words ? (int32_t)(mt_temper(w) & (uint32_t)(A.N - ns - 1)) : (int32_t)w;          // stretch.py:32 randint(Nc)
     di[N + pos] = r < base ? di[r] : di[r + ns];                // stretch.py:27: c = the other sets' members in plan order
     dd[pos] = zz;

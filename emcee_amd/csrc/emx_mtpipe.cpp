@@ -1063,6 +1063,26 @@ struct Reader {
             ++t;
         }
     }
+    // The next F words are fixed-length draws the consumer makes again from the generator's STATE (PipeStepInfo::regen): the state --
+    // the ring's block itself: it holds state words -- at every SB-th block of the region goes to `keys`, the words are stepped over.
+    // Nothing but those blocks crosses to this core.  -> false: the pipeline is dead.
+    bool skip_region_keys(uint64_t F, int SB, uint32_t* keys, int32_t& off, int32_t& nseg) {
+        const uint64_t p = pos();
+        const uint64_t b0 = p / BLK, b1 = (p + F - 1) / BLK;
+        off = (int32_t)(p - b0 * BLK);
+        nseg = 0;
+        for (uint64_t b = b0; b <= b1 && !dead; b += (uint64_t)SB) {
+            publish(std::max<uint64_t>(p, b * BLK));          // block b stays in the ring; the generator may run its lead beyond it
+            if (!wait_produced((b + 1) * BLK)) return false;
+            std::memcpy(keys + (size_t)nseg * BLK, &ws->ring[(b % ws->nblk) * BLK], (size_t)BLK * 4);
+            ++nseg;
+        }
+        // the region's last block exists -- and stays -- before anybody takes the generator state behind it (tokenizer_main's snapshot)
+        publish(p + F);
+        if (dead || !wait_produced(p + F)) return false;
+        seek(p + F);
+        return true;
+    }
     // n state words, verbatim (fixed-length draws are tempered and converted by the finishers -- or by the consumer's kernel)
     void copy_words(uint32_t* dst, int64_t n) {
         int64_t k = 0;
@@ -1120,6 +1140,7 @@ struct MtPlanPipeline::Impl {
     uint64_t t_start = 0, tok_done_ns = 0;
     std::atomic<uint64_t> tok_wait_sink_ns{0}, tok_busy_ns{0};                 // read by stage_times() while the threads run
     bool vec_scan = false, vec_dq = false, stats = false, fill_unused = false, device_finish = false;
+    int64_t regen_min = 0;                         // > 0: eligible steps go out as generator states (PipeStepInfo::regen)
     uint64_t tok_shuffle_ns = 0;
     std::atomic<int64_t> tok_steps{0};             // steps tokenised so far
     std::vector<uint64_t> fin_wait_ns;
@@ -1143,9 +1164,10 @@ bool MtPlanPipeline::supports(int32_t nmoves, const emx_move_desc* moves) {
 
 MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D, int32_t nmoves, const emx_move_desc* moves,
                                const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers,
-                               bool fill_unused_fields, bool device_finish, bool bursty_consumer)
+                               bool fill_unused_fields, bool device_finish, bool bursty_consumer, int64_t regen_min_walkers)
     : impl_(new Impl()) {
     Impl& m = *impl_;
+    m.regen_min = device_finish ? regen_min_walkers : 0;
     {
         const char* e = getenv("EMX_PIPE_SPIN_US");
         m.ws.spin_ns = e ? (uint64_t)atoll(e) * 1000ull : (bursty_consumer ? 150000ull : 0ull);
@@ -1318,6 +1340,17 @@ void MtPlanPipeline::Impl::tokenize(Reader& rd, int64_t n, int& has_gauss, doubl
     const uint64_t ts0 = stats ? now_ns() : 0;
     if (mv.randomize_split) rd.shuffle_targets(raw.j.data(), N, vec_scan);                        // red_blue.py:80
     if (stats) tok_shuffle_ns += now_ns() - ts0;
+    info.regen = 0;
+    if (info.raw && regen_min > 0 && N >= regen_min && S == 2 && (N % 2) == 0 && pow2_bound((uint64_t)(N / 2))) {
+        // both splits' draws are fixed-length and contiguous: 2 x (2 Ns + Ns + 2 Ns) = 5 N words.  The states must fit the p0 column.
+        const uint64_t F = 5ull * (uint64_t)N;
+        const uint64_t nblk_max = F / BLK + 2, nseg_max = (nblk_max + PIPE_REGEN_SB - 1) / PIPE_REGEN_SB;
+        if (nseg_max * BLK <= (uint64_t)N) {
+            info.regen = 1;
+            if (!rd.skip_region_keys(F, PIPE_REGEN_SB, reinterpret_cast<uint32_t*>(sk.p0), info.regen_off, info.regen_nseg)) return;
+            return;
+        }
+    }
     for (int split = 0; split < S && !rd.dead; ++split) {
         const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
         if (mv.kind == EMX_MOVE_STRETCH) {
@@ -1434,6 +1467,7 @@ void MtPlanPipeline::Impl::finish_step(int64_t n, std::vector<uint8_t>& labels) 
     for (int split = 0; split < S; ++split) {
         const int64_t base = info.off[split], ns = info.off[split + 1] - info.off[split], nc = N - ns;
         auto comp = [&](uint64_t r) -> int32_t { return (int64_t)r < base ? order[r] : order[r + ns]; };   // stretch.py:27
+        if (info.regen) continue;          // (the consumer makes the draws again from the generator states in the sink: k_plan_regen)
         if (info.raw) {
             // device finish: the tokenizer put the words where their values will stand (PipeStepInfo::raw); only a step whose splits
             // drew their partners both ways (set sizes that are and are not powers of two) has values to make here

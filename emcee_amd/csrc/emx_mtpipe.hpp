@@ -62,8 +62,16 @@ struct PipeStepInfo {
     // (red_blue.py:100), p0: the word of a power-of-two randint (stretch.py:32; wr_ring = 1) or the accepted randint value itself
     // (wr_ring = 0); p0 is a member number of the complement either way, not yet a walker.  The consumer converts (k_plan_raw).
     int32_t raw = 0, wr_ring = 0;
+    // regen (round 6; a raw stretch step of two splits whose complements are powers of two, ensembles of `regen_min_walkers` and more):
+    // the 5 N fixed-length words behind the shuffle -- rand(Ns), randint(Nc, Ns), Ns x rand() per split, stretch.py:30-32 and
+    // red_blue.py:100, contiguous in the stream -- do not cross to the tokenizer's core, the staging buffer and PCIe at all: the sink
+    // holds `order` and, in the place of its p0 column, the generator STATE (624 words) at every PIPE_REGEN_SB-th block of that
+    // region; the consumer runs the recurrence forward from each (k_plan_regen, csrc/emx_kernels.hpp) and drops the words where
+    // k_plan_raw expects them.  regen_off: the region's first word inside the first state's block; regen_nseg: states in the sink.
+    int32_t regen = 0, regen_off = 0, regen_nseg = 0;
 };
 constexpr int PIPE_RAW_SPLITS = 8;
+constexpr int PIPE_REGEN_SB = 8;          // stream blocks (of 624 words) regenerated from one state: one workgroup of k_plan_regen each
 
 class MtPlanPipeline {
    public:
@@ -75,8 +83,10 @@ class MtPlanPipeline {
                    const double* cdf, int64_t nsteps, const PlanSink* sinks, int32_t nsinks, int32_t nworkers,
                    bool fill_unused_fields = false,       // true: a stretch plan's p1 / p2 are set to the walker itself
                    bool device_finish = false,
-                   bool bursty_consumer = false);        // the consumer takes its steps sixteen at a time (the persistent kernels): the stage threads
+                   bool bursty_consumer = false,         // the consumer takes its steps sixteen at a time (the persistent kernels): the stage threads
                                                          // spin through the gaps between bursts instead of napping
+                   int64_t regen_min_walkers = 0);       // > 0 (with device_finish): eligible steps of ensembles this large are handed over as
+                                                         // generator states (PipeStepInfo::regen); 0: never
     ~MtPlanPipeline();
     MtPlanPipeline(const MtPlanPipeline&) = delete;
     MtPlanPipeline& operator=(const MtPlanPipeline&) = delete;

@@ -573,6 +573,12 @@ class DeviceEnsemble:
         return {"steps_produced": n.value, "finisher_threads": k.value, "wall_us": out[0], "generator_us": out[1], "tokenizer_us": out[2],
                 "finishers_us_summed": out[3], "tokenizer_waited_for_words_us": out[4], "tokenizer_waited_for_consumer_us": out[5]}
 
+    def pipeline_handovers(self):
+        """stretch steps the exact-mode host pipeline handed over raw / as generator states (include/emx.h emx_pipeline_handovers)"""
+        raw, regen = C.c_int64(0), C.c_int64(0)
+        self._ck(self.lib.emx_pipeline_handovers(self.ctx, C.byref(raw), C.byref(regen)))
+        return {"raw_steps": int(raw.value), "regen_steps": int(regen.value)}
+
     def persist_info(self):
         """persistent half-steps (include/emx.h emx_persist_info): does the configuration qualify, launches, half-steps they ran"""
         out = (C.c_int64 * 4)()

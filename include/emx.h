@@ -117,6 +117,7 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   -- exact-mode plan producers --
  *   "mt_pipeline"              -1        -1: host pipeline, finisher threads from the core count; k > 0: k finishers; 0: inline, calling thread
  *   "mt_device_finish"         1         0: the finisher threads convert every draw (1: k_plan_raw does, on the device)
+ *   "mt_regen_min_walkers"     16384     stretch steps of ensembles this large go up as generator STATES (k_plan_regen makes the draws again); 0: never
  *   "mt_device"                1         0: never the device producer; 1: from "mt_device_min_walkers" (147456) on; 2: from 8192 on
  *   "mt_tok_wshift" / "mt_tok_tail"  11 / 2048   the device tokenizer's window rule    "mt_device_lookahead"  batches ahead
  *   -- exchanges --
@@ -371,6 +372,12 @@ int emx_profile_read(emx_ctx* ctx, float* ms_out, int32_t* n_inout);
  * clock, [1] generator (twist + temper), [2] tokenizer (the serial walk of the stream: rejection tests), [3] finishers (summed
  * over the threads), [4] tokenizer waiting for words, [5] tokenizer waiting for a free staging buffer (i.e. for the consumer) */
 int emx_pipeline_stats(emx_ctx* ctx, double out[6], int64_t* steps_produced, int32_t* finisher_threads);
+/* how the host pipeline handed its stretch steps over so far (EMX_RNG_MT19937; moves/stretch.py:30-32, moves/red_blue.py:100 -- the
+ * fixed-length draws of a step): raw_steps -- the draws as the generator words they are, in the plan's columns, finished on the
+ * device (k_plan_raw; tuning "mt_device_finish"); of those, regen_steps -- not even the words: `order` and the generator's STATE at
+ * every eighth block of the draws' region of the stream, from which the device makes the words again (k_plan_regen, round 6:
+ * ensembles of "mt_regen_min_walkers" = 16 384 and more whose half is a power of two; 0: never).  Same plans bit for bit. */
+int emx_pipeline_handovers(emx_ctx* ctx, int64_t* raw_steps, int64_t* regen_steps);
 
 /* Exact (MT19937) mode with the plans made ON THE DEVICE (csrc/emx_mtdev.hpp): one StretchMove, one replica, ensembles of
  * 147 456 walkers or more (round 5; 131 072 before) -- where the serial host stages of "same seed => same chain as the reference" (ensemble.py:166-167,406,

@@ -141,3 +141,45 @@ def test_pipeline_random_shapes_equal_the_serial_twin():
             for key in ["order", "p0", "uacc", "s0"] + (["p1", "p2"] if moves[ka].kind != 0 else []):
                 assert np.array_equal(pa[key], pb[key]), (it, kind, N, S, n, key)
         assert same_state(want_state, got_state), (it, kind, N, S)
+
+
+@pytest.mark.parametrize("N,moves,w,pos,regen_min", [
+    (65536, [md("stretch")], None, None, 16384),           # BASELINE configs[1]: every step a regen step
+    (16384, [md("stretch")], None, 623, 16384),
+    (32768, [md("stretch")], None, 1, 16384),
+    (16384, [md("stretch"), md("de")], [0.6, 0.4], 300, 16384),      # a mixture: regen for its stretch steps only
+    (24576, [md("stretch")], None, 77, 16384),             # half an ensemble that is no power of two: raw, with accepted randint values
+    (8192, [md("stretch")], None, None, 4096),             # a lower threshold
+    (4096, [md("stretch")], None, 5, 0),                   # regen off: raw steps
+    (1001, [md("stretch", S=3)], None, 17, 16),            # three splits: raw, never regen
+])
+def test_device_finish_hand_over_through_the_host_twins(monkeypatch, N, moves, w, pos, regen_min):
+    """Round 6: with device finish the pipeline hands a stretch step over as generator WORDS in the plan's columns (raw) or -- ensembles
+    of `mt_regen_min_walkers` and more whose half is a power of two -- as `order` plus the generator's STATE at every eighth block of
+    the region of the stream the step's 5 N fixed-length draws stand in (regen); the consumer's kernels (k_plan_regen, k_plan_raw) make
+    the plan from that.  Their host twins (csrc/emx.hip, test mode EMX_TEST_PIPE_DEVFIN of emx_host_plan_mt_stream) are run here: the
+    plans and the final generator state must be the serial twin's bit for bit -- i.e. the tokenizer handed over the right states, the
+    right offset, and stepped over exactly the right words."""
+    monkeypatch.setenv("EMX_TEST_PIPE_DEVFIN", str(regen_min))
+    nsteps = 9
+    st = list(np.random.RandomState(N + 7).get_state())
+    if pos is not None:
+        st[2] = pos
+    st = tuple(st)
+    wts = np.ones(len(moves)) if w is None else np.asarray(w, dtype=float)
+    cdf = np.cumsum(wts / wts.sum())
+    cdf /= cdf[-1]
+    want, want_state = serial(st, N, 4, moves, cdf, nsteps)
+    got, got_state, _ = stream(st, N, 4, moves, cdf, nsteps, 3, 4)
+    nregen = nraw = 0
+    for n, ((ka, pa), (kb, pb)) in enumerate(zip(want, got)):
+        assert ka == (kb & 255), (n, ka, kb)
+        nraw += bool(kb & 256)
+        nregen += bool(kb & 512)
+        for key in ["order", "p0", "uacc", "s0"] + (["p1", "p2"] if moves[ka].kind != 0 else []):
+            assert np.array_equal(pa[key], pb[key]), (N, n, key, bool(kb & 512))
+    assert same_state(want_state, got_state)
+    nstretch = sum(1 for k, _ in want if moves[k].kind == 0)
+    assert nraw == nstretch
+    half_pow2 = N % 2 == 0 and (N // 2) & (N // 2 - 1) == 0 and moves[0].nsplits == 2
+    assert nregen == (nstretch if (regen_min and N >= regen_min and half_pow2) else 0)
