@@ -352,6 +352,7 @@ struct emx_ctx {
         int64_t fetch_step = -1;           // ... or (>= 0) the step whose plan k_plan_fetch takes from it: done when *pipe_done > fetch_step
         bool busy = false, host_written = false;
         int move_idx = 0;                  // exact-mode pipeline: the move of the step whose plan the slot holds
+        PipeStepInfo pinfo;                // ... and how it was handed over (raw / regen: pipe_fetch_deferred finishes it on the device)
     } ring[PLAN_RING + MTDEV_SLOTS];
     // exact-mode plan pipeline (emx_mtpipe.hpp): alive only inside emx_run
     MtPlanPipeline* pipe = nullptr;
@@ -375,6 +376,7 @@ struct emx_ctx {
     int64_t mtdev_taken = 0;             // steps whose plan emx_step_begin has taken from it
     int64_t tune_persist_local = 1;      // 0: never the one-XCD form of the persistent kernel
     int64_t tune_persist_exact_max = 32768;   // exact mode: largest ensemble that takes the device-wide persistent kernel
+    int64_t tune_persist_exact_regen_max = 131072;     // ... when its stretch steps are regen steps (regen_ctx_ok)
     int64_t tune_persist_exact_steps = 16;    // exact mode: steps per persistent launch (<= 16)
     int64_t tune_fetch_avoid = 1;             // k_plan_fetch keeps off the XCD a one-XCD persistent launch lives on
     int64_t tune_fetch_blocks = 64;           // ... and beside a device-wide launch runs as this many workgroups (0: one per piece of 256 entries)
@@ -1462,6 +1464,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_persist_odd = v ? 1 : 0;
         return 0;
     }
+    if (!strcmp(key, "persist_exact_regen_max_walkers")) {
+        PIPE_STOP(c);
+        c->tune_persist_exact_regen_max = v;
+        return 0;
+    }
     if (!strcmp(key, "mt_regen_side")) {
         c->tune_mt_regen_side = v < 0 ? 0 : (v > 2 ? 2 : v);
         return 0;
@@ -2122,6 +2129,7 @@ static void pipe_poll(void* arg) {
 }
 
 static bool persist_exact_ok(const emx_ctx* c);
+static bool regen_ctx_ok(const emx_ctx* c);
 static int pipe_start(emx_ctx* c) {
     const int64_t nsteps = (int64_t)1 << 60;       // it runs ahead (16 plans at most) until something retires it
     const size_t N = (size_t)c->N;
@@ -2164,7 +2172,9 @@ static int pipe_start(emx_ctx* c) {
     // kernels reads, step-at-a-time uploads) the fetch kernel reads a stretch step's uniforms straight out of it.
     // device finish (one replica whose plans nobody but the fused kernels reads, step-at-a-time uploads): the finishers pass a stretch
     // step's uniforms on as generator words, k_plan_raw converts them in place behind the upload
-    const bool devfin = c->tune_mt_device_finish != 0 && c->pipe_nsinks == PIPE_SINKS && c->world == 1 && !c->comm && !c->sendbuf &&
+    // (round 6: the persistent launches' fetch takes raw / regen steps too -- where the ensemble's stretch steps will be regen steps,
+    // regen_ctx_ok, the pipeline of a persistent consumer hands them over that way as well)
+    const bool devfin = c->tune_mt_device_finish != 0 && (c->pipe_nsinks == PIPE_SINKS || regen_ctx_ok(c)) && c->world == 1 && !c->comm && !c->sendbuf &&
                         !c->peers_ready && c->target != EMX_TARGET_HOST && !c->tune_full_plan;
     c->pipe = new MtPlanPipeline(c->mt, c->N, c->D, (int32_t)c->moves.size(), c->moves.data(), c->cdf.data(), nsteps, sinks,
                                  c->pipe_nsinks, (int32_t)(c->tune_mt_pipeline > 0 ? c->tune_mt_pipeline : 0), false, devfin, c->pipe_nsinks == PLAN_RING,
@@ -2275,6 +2285,13 @@ static int mtdev_take(emx_ctx* c) {
 }
 
 static bool persist_exact_ok(const emx_ctx* c);
+// the stretch steps of this context's host pipeline will be regen steps (emx_mtpipe.cpp, tokenize): device finish on, an ensemble of
+// "mt_regen_min_walkers" or more whose half is a power of two
+static bool regen_ctx_ok(const emx_ctx* c) {
+    const int64_t h = c->N / 2;
+    return c->tune_mt_device_finish != 0 && c->tune_mt_regen_min > 0 && c->N >= c->tune_mt_regen_min && (c->N % 2) == 0 && h >= 2 && (h & (h - 1)) == 0 &&
+           c->world == 1 && !c->comm && !c->sendbuf && !c->peers_ready && c->target != EMX_TARGET_HOST && !c->tune_full_plan;
+}
 static bool pipe_eligible(const emx_ctx* c) {
     return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_pipeline != 0 && (!small_eligible(c) || persist_exact_ok(c)) &&
            MtPlanPipeline::supports((int32_t)c->moves.size(), c->moves.data());
@@ -2297,10 +2314,11 @@ static int pipe_take(emx_ctx* c) {
     s.move_idx = info.move;
     const size_t N = (size_t)c->N;
     if (c->pipe_defer) {
-        // run_persist: the launch's plans go up together (pipe_fetch_deferred).  k_plan_fetch reads FINISHED columns: a pipeline
-        // with device finish (raw generator words, pipe_start) must never feed it -- emx_run restarts such a pipeline; fail loudly
-        // should any path get here all the same
-        NEED(c, !info.raw, "exact-mode plan pipeline: a raw (device-finish) step reached the persistent launch's fetch");
+        // run_persist: the launch's plans go up together (pipe_fetch_deferred).  (Round 5: k_plan_fetch read FINISHED columns only and a
+        // raw step here was an error; round 6: the fetch takes raw and regen steps as they are and the batched k_plan_regen / k_plan_raw
+        // behind it finish them -- which is what lets 65 536 walkers take the persistent kernel in exact mode.)
+        s.pinfo = info;                     // (a raw / regen step: the fetch copies it as it is and finishes it behind the copy)
+        cur.devplan = info.raw != 0;
         s.uploaded_ref = nullptr;
         s.fetch_step = n;
         s.host_written = true;
@@ -2380,6 +2398,10 @@ static int pipe_fetch_deferred(emx_ctx* c) {
     if (c->pipe_deferred.empty()) return 0;
     NEED(c, c->pipe_deferred.size() <= 16, "more deferred plans than one fetch takes");
     PlanFetchArgs F{};
+    PlanRawBatchArgs RB{};               // (a step handed over finished keeps N = 0 / nseg = 0: its blocks of the batched kernels return at once)
+    PlanRegenBatchArgs GB{};
+    bool any_raw = false;
+    int max_nseg = 0;
     F.N = (int32_t)c->N;
     F.D = c->D;
     F.n = (int)c->pipe_deferred.size();
@@ -2407,6 +2429,32 @@ static int pipe_fetch_deferred(emx_ctx* c) {
         F.dev[k] = (char*)s.order;
         F.stretch[k] = c->moves[(size_t)std::max(0, s.move_idx)].kind == EMX_MOVE_STRETCH;       // (the step's own move: a mixture's steps share launches)
         F.peers[k] = !(F.stretch[k] && c->world == 1);
+        const PipeStepInfo& pi = s.pinfo;
+        F.kind[k] = pi.regen ? 2 : (pi.raw ? 1 : 0);
+        F.nkey[k] = pi.regen ? pi.regen_nseg * 624 : 0;
+        if (pi.raw) {
+            any_raw = true;
+            PlanRawArgs& R = RB.st[k];
+            R.dev = (char*)s.order;
+            R.a = c->moves[(size_t)std::max(0, s.move_idx)].a;
+            R.N = (int32_t)c->N;
+            R.D = c->D;
+            R.S = pi.S;
+            R.wr_words = pi.wr_ring;
+            R.wr_p1 = pi.regen ? 1 : 0;
+            for (int q = 0; q <= pi.S && q <= PLAN_RAW_SPLITS; ++q) R.off[q] = pi.off[q];
+            c->pipe_raw_steps++;
+        }
+        if (pi.regen) {
+            PlanRegenArgs& G = GB.st[k];
+            G.dev = (char*)s.order;
+            G.N = (int32_t)c->N;
+            G.ns0 = pi.off[1] - pi.off[0];
+            G.off = pi.regen_off;
+            G.nseg = pi.regen_nseg;
+            max_nseg = std::max(max_nseg, pi.regen_nseg);
+            c->pipe_regen_steps++;
+        }
     }
     F.delay_ticks = (unsigned)(c->tune_fetch_delay_us * 100);
     F.arrived = c->pipe_arrived;
@@ -2417,6 +2465,10 @@ static int pipe_fetch_deferred(emx_ctx* c) {
     unsigned nwg = (unsigned)F.pieces_x * (unsigned)F.n;
     if (!c->pipe_fetch_local && c->tune_fetch_blocks > 0) nwg = std::min<unsigned>(nwg, (unsigned)c->tune_fetch_blocks);
     hipLaunchKernelGGL(k_plan_fetch, dim3(nwg), dim3(256), 0, c->up_stream, F);
+    // raw / regen steps: made into plans behind the copy, for all steps of the launch at once (30 registers a lane: these workgroups
+    // find room beside a running persistent launch's)
+    if (max_nseg > 0) hipLaunchKernelGGL(k_plan_regen_batch, dim3((unsigned)max_nseg, (unsigned)F.n), dim3(256), 0, c->up_stream, GB);
+    if (any_raw) hipLaunchKernelGGL(k_plan_raw_batch, dim3((unsigned)F.pieces_x, (unsigned)F.n), dim3(256), 0, c->up_stream, RB);
     HIPOK(c, hipGetLastError());
     hipEvent_t& ev = c->pipe_batch_ev[c->pipe_batch_n & 3];
     if (!ev) HIPOK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -3375,7 +3427,10 @@ static bool persist_exact_ok(const emx_ctx* c) {
         const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
         if (!known && c->moves.size() > 1) return false;       // (one move: persist_local_ok / persist_move_ok say the same, later)
         if (persist_local_ok(c, m)) continue;
-        if (c->N > c->tune_persist_exact_max || persist_shape(c, m.nsplits) == 0) return false;
+        // (a regen ensemble's plans are `order` and a few generator states a step -- 6.8 MB a launch at 65 536 walkers where finished
+        // plans were 25 MB: it takes the device-wide form up to "persist_exact_regen_max_walkers")
+        const int64_t nmax = (regen_ctx_ok(c) && m.kind == EMX_MOVE_STRETCH) ? std::max(c->tune_persist_exact_max, c->tune_persist_exact_regen_max) : c->tune_persist_exact_max;
+        if (c->N > nmax || persist_shape(c, m.nsplits) == 0) return false;
         if (!(c->target == EMX_TARGET_DENSE_GAUSS || persist_valu_wide_ok(c, m))) return false;
     }
     return true;

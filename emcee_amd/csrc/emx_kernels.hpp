@@ -2280,6 +2280,10 @@ struct PlanFetchArgs {
     char* dev[16];            // device slot blocks ([order|p0] [s0|uacc] [p1|p2] [logu|fac])
     int32_t stretch[16];      // fac = (D-1) ln zz
     int32_t peers[16];        // the [p1|p2] columns are part of the plan
+    int32_t kind[16];         // 0: a finished plan (values; the logs are taken here); 1: a raw step -- generator words in the columns, copied as
+                              // they are (k_plan_raw_batch converts them behind this kernel); 2: a regen step -- `order` and, in p0's place,
+                              // nkey[b] words of generator states (k_plan_regen_batch, then k_plan_raw_batch)
+    int32_t nkey[16];
     int32_t N, D, n;
     unsigned* arrived;        // device: [0] workgroups of this launch that are done, [1] tickets handed out (the last one resets both)
     const unsigned* avoid_xcc;        // device word: XCC_ID + 1 of the XCD a one-XCD persistent launch lives on (0: none), or null
@@ -2356,6 +2360,18 @@ static __device__ __forceinline__ void plan_fetch_rows(const PlanFetchArgs& A, i
     const double* hd = reinterpret_cast<const double*>(A.host[b] + N * 8);
     int32_t* di = reinterpret_cast<int32_t*>(A.dev[b]);
     double* dd = reinterpret_cast<double*>(A.dev[b] + N * 8);
+    if (A.kind[b] == 2) {                       // (uniform per step)
+        di[pos] = hi[pos];
+        if (pos < A.nkey[b]) di[N + pos] = hi[N + pos];
+        return;
+    }
+    if (A.kind[b] == 1) {
+        di[pos] = hi[pos];
+        di[N + pos] = hi[N + pos];
+        reinterpret_cast<uint2*>(dd)[pos] = reinterpret_cast<const uint2*>(hd)[pos];            // (words, not doubles: no floating-point move)
+        reinterpret_cast<uint2*>(dd)[N + pos] = reinterpret_cast<const uint2*>(hd)[N + pos];
+        return;
+    }
     const double z = hd[pos], u = hd[N + pos];
     di[pos] = hi[pos];
     di[N + pos] = hi[N + pos];
@@ -2391,8 +2407,7 @@ static __device__ __forceinline__ uint32_t regen_mix(uint32_t u, uint32_t v) {
     const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
     return (y >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu);
 }
-static __global__ __launch_bounds__(256) void k_plan_regen(const PlanRegenArgs A) {
-    __shared__ uint32_t key[2][624];
+static __device__ __forceinline__ void plan_regen_body(const PlanRegenArgs& A, uint32_t (*key)[624]) {
     const int tid = threadIdx.x, seg = blockIdx.x;
     const size_t N = (size_t)A.N;
     const uint32_t* keys = reinterpret_cast<const uint32_t*>(A.dev + N * 4);
@@ -2442,6 +2457,20 @@ static __global__ __launch_bounds__(256) void k_plan_regen(const PlanRegenArgs A
         }
     }
 }
+static __global__ __launch_bounds__(256) void k_plan_regen(const PlanRegenArgs A) {
+    __shared__ uint32_t key[2][624];
+    plan_regen_body(A, key);
+}
+// ... of up to sixteen steps at once (the persistent launches' fetch: blockIdx.y = step; a step that is no regen step has nseg = 0)
+struct PlanRegenBatchArgs {
+    PlanRegenArgs st[16];
+};
+static __global__ __launch_bounds__(256) void k_plan_regen_batch(const PlanRegenBatchArgs B) {
+    __shared__ uint32_t key[2][624];
+    const PlanRegenArgs& A = B.st[blockIdx.y];
+    if ((int)blockIdx.x >= A.nseg) return;          // (uniform)
+    plan_regen_body(A, key);
+}
 
 // Device finish of an exact-mode stretch plan (round 5; csrc/emx_mtpipe.hpp, PipeStepInfo::raw).  The host pipeline hands over what
 // only it can make -- `order` (the shuffled split, red_blue.py:76-85) and, where the complement's size is not a power of two, the
@@ -2469,7 +2498,7 @@ static __device__ __forceinline__ double mt_pair_double(uint32_t w0, uint32_t w1
     const int32_t a = (int32_t)(mt_temper(w0) >> 5), b = (int32_t)(mt_temper(w1) >> 6);
     return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
-static __global__ __launch_bounds__(256) void k_plan_raw(const PlanRawArgs A) {
+static __device__ __forceinline__ void plan_raw_body(const PlanRawArgs& A) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= A.N) return;
     const size_t N = (size_t)A.N;
@@ -2492,6 +2521,12 @@ static __global__ __launch_bounds__(256) void k_plan_raw(const PlanRawArgs A) {
     dl[pos] = plan_log(ua);
     dl[N + pos] = ((double)A.D - 1.0) * plan_log(zz);
 }
+static __global__ __launch_bounds__(256) void k_plan_raw(const PlanRawArgs A) { plan_raw_body(A); }
+// ... of up to sixteen steps at once (blockIdx.y = step; a step that was handed over finished has N = 0)
+struct PlanRawBatchArgs {
+    PlanRawArgs st[16];
+};
+static __global__ __launch_bounds__(256) void k_plan_raw_batch(const PlanRawBatchArgs B) { plan_raw_body(B.st[blockIdx.y]); }
 
 // ----------------------------------------------------------------------------------------
 // Split-phase accept/commit (target evaluated on the host: arbitrary Python log_prob_fn).

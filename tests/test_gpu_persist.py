@@ -387,7 +387,9 @@ def test_what_does_not_qualify():
         assert ens.persist_info()["launches"] == 0 and ens.status() == 0
         ens.close()
     # exact (MT19937) mode: only where the one-XCD form runs (the host pipeline's plans, test_exact_mode_* below)
-    for N, want in ((4096, True), (16384, True), (65536, False)):       # (device-wide form: up to persist_exact_max_walkers = 32 768)
+    # (device-wide form: up to persist_exact_max_walkers = 32 768 for plans that travel finished -- 49 152: half an ensemble that is no
+    # power of two -- and up to persist_exact_regen_max_walkers where the stretch steps go up as generator states, round 6: 65 536)
+    for N, want in ((4096, True), (16384, True), (65536, True), (49152, False)):
         ens = native_ens(dense_spec(N, 64), 1)
         ens.set_rng_mode(_lib.RNG_MT19937)
         assert ens.persist_info()["qualifies"] == want, N

@@ -75,3 +75,46 @@ def test_regen_against_the_oracle_and_in_a_mixture():
     assert np.array_equal(a["rng"][1], b["rng"][1]) and a["rng"][2] == b["rng"][2]
     for key in ("x", "lp", "chain", "counts"):
         assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("N,D,target", [(65536, 64, "dense"), (32768, 64, "dense"), (16384, 32, "dense"), (65536, 16, "iso"), (32768, 33, "dense"), (16384, 128, "dense")])
+def test_persistent_launches_take_regen_steps(N, D, target):
+    """Round 6, second half: the persistent launches' fetch (k_plan_fetch) takes regen steps as they are -- `order` and the generator
+    states -- and the batched k_plan_regen / k_plan_raw behind it finish all steps of a launch at once.  A launch's plans are 6.8 MB at
+    65 536 walkers where finished plans were 25 MB, so BASELINE's C2 runs the persistent kernel in exact mode now (persist_exact_max_walkers
+    = 32 768 stays the bound for plans that travel finished).  Three ways to the same chain: persistent + regen, per-step uploads + regen,
+    per-step uploads with the words copied."""
+    spec = full_spec(N, D, target, [S("stretch")], seed=41)
+    st = np.random.RandomState(77 + N).get_state()
+    a = _run(spec, st, 16384, 3, 23, {"persist_timeout_ms": 400})
+    b = _run(spec, st, 16384, 3, 23, {"persist_exact": 0})
+    c = _run(spec, st, 0, 3, 23, {"persist_exact": 0})
+    assert a["info"]["launches"] >= 6 and a["hand"]["regen_steps"] == 69 and a["info"]["recovered"] == 0
+    assert b["info"]["launches"] == 0 and b["hand"]["regen_steps"] == 69
+    assert c["info"]["launches"] == 0 and c["hand"]["regen_steps"] == 0
+    for other in (b, c):
+        assert np.array_equal(a["rng"][1], other["rng"][1]) and a["rng"][2] == other["rng"][2]
+        for key in ("x", "lp", "chain", "counts"):
+            assert np.array_equal(a[key], other[key]), key
+
+
+def test_long_exact_run_on_the_persistent_kernel_at_the_headline_size():
+    """BASELINE configs[1] in the Python default RNG mode: 600 steps, the host enqueueing ahead of the device, every plan slot fetched
+    and finished on the device some twenty times -- final state, accept counters and generator state equal the per-step path's"""
+    spec = full_spec(65536, 64, "dense", [S("stretch")], seed=42)
+    st = np.random.RandomState(4).get_state()
+    recs = []
+    for pe in (1, 0):
+        ens = make_ens(spec, spec["p0"])
+        ens.set_rng_mode(_lib.RNG_MT19937)
+        ens.set_mt19937(st)
+        ens.set_tuning("persist_exact", pe)
+        ens.run(600, 1, False)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        recs.append(dict(x=x, lp=lp, counts=ens.accepted_counts(), rng=ens.get_mt19937(), info=ens.persist_info(), hand=ens.pipeline_handovers()))
+        ens.close()
+    p, c = recs
+    assert p["info"]["launches"] >= 600 // 16 and c["info"]["launches"] == 0 and p["hand"]["regen_steps"] == 600
+    assert np.array_equal(p["x"], c["x"]) and np.array_equal(p["lp"], c["lp"]) and np.array_equal(p["counts"], c["counts"])
+    assert np.array_equal(p["rng"][1], c["rng"][1]) and p["rng"][2] == c["rng"][2]
