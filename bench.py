@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 from tools.benchkit.model import *  # noqa: E402,F401,F403
 from tools.benchkit.out import _claim_stdout, log  # noqa: E402,F401
 from tools.benchkit.cpu import cpu_baseline, usable_cores  # noqa: E402,F401
-from tools.benchkit.single import (MAX_BLOCKS, MIN_TIMED_MS, config_entry, exact_mode_entry, exact_mode_large_entry, exact_mode_mid_entry, hbm_traffic,  # noqa: E402,F401
+from tools.benchkit.single import (MAX_BLOCKS, MIN_TIMED_MS, config_entry, exact_mode_c4_entry, exact_mode_entry, exact_mode_large_entry, exact_mode_mid_entry, hbm_traffic,  # noqa: E402,F401
                                    measure_single, quality_entry, refresh_pmc_traffic, wide_entry)
 from tools.benchkit import sharded as _sharded  # noqa: E402
 from tools.benchkit.sharded import (ALL_EXCHANGES, EXCHANGES, HEAVY_EXCHANGES, _DEADLINE, agreed_remaining, child_main, measure_sharded,  # noqa: E402,F401
@@ -256,6 +256,10 @@ def main(argv=None):
                     line["exact_mode"] = exact_mode_entry(wl, K, W, local_rank)
                 except Exception as e:  # noqa: BLE001
                     line["exact_mode"] = {"error": repr(e)}
+                try:
+                    line["exact_mode_c4"] = exact_mode_c4_entry(K, W, local_rank)
+                except Exception as e:  # noqa: BLE001
+                    line["exact_mode_c4"] = {"error": repr(e)}
                 try:
                     line["exact_mode_c3"] = exact_mode_large_entry(K, W, local_rank)
                 except Exception as e:  # noqa: BLE001

@@ -3349,8 +3349,9 @@ static bool persist_grid_fits(const emx_ctx* cc, const emx_move_desc& m, int wpb
 static bool persist_valu_wide_ok(const emx_ctx* c, const emx_move_desc& m) {
     const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
     const bool valu = c->target == EMX_TARGET_ISO_GAUSS || c->target == EMX_TARGET_DIAG_GAUSS || c->target == EMX_TARGET_ROSENBROCK || c->target == EMX_TARGET_BOX;
-    return known && valu && c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_valu != 0 && c->N <= c->tune_persist_exact_max &&
-           persist_shape(c, m.nsplits) != 0;
+    // (stretch steps that go up as generator states -- regen_ctx_ok -- lift the bound of plans that travel finished: persist_exact_ok)
+    const int64_t nmax = (regen_ctx_ok(c) && m.kind == EMX_MOVE_STRETCH) ? std::max(c->tune_persist_exact_max, c->tune_persist_exact_regen_max) : c->tune_persist_exact_max;
+    return known && valu && c->rng_mode == EMX_RNG_MT19937 && c->tune_persist_valu != 0 && c->N <= nmax && persist_shape(c, m.nsplits) != 0;
 }
 
 static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {

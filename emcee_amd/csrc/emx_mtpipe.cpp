@@ -1197,7 +1197,9 @@ MtPlanPipeline::MtPlanPipeline(const MT19937Legacy& start, int64_t N, int32_t D,
         // outlier in five fresh processes each (45.7-47.1 us/step; six: 45.3-46.5 and one 60.7 with the generator on a busy core's
         // sibling; four: 46.6-48.3; profiles/r05/exact_c2_finisher_count.txt)
         // (up to 131 072 walkers: beyond, the finishers' swaps bound the step and six are faster -- 262 144 walkers 214 against 324 us/step)
-        if (device_finish && K == 6 && hw <= 16 && N <= 131072) K = 5;
+        // (a bursty consumer -- the persistent launches: one enqueue per sixteen steps -- leaves the caller's core idle: the sixth finisher
+        // has it; with regen steps the finishers are what bounds the step there, 171 us of swaps and `order` per step of 65 536 walkers)
+        if (device_finish && K == 6 && hw <= 16 && N <= 131072 && !bursty_consumer) K = 5;
     }
     K = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(K, nsinks), nsteps));
     m.K = K;

@@ -225,7 +225,11 @@ def exact_mode_entry(wl, K, W, device):
             "roofline_frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS,
             "block_spread": float(np.max(res["walls_s"]) / np.min(res["walls_s"])),
             "pipeline_stage_us_per_step": res.get("pipeline"),
-            "note": "host_plan_ms = one step's plan made inline by ONE host thread (emx_host_plan_mt, no GPU) -- round 1's path; emx_run "
+            "persistent_halfsteps_per_launch": res.get("halfsteps_per_launch"),
+            "note": "round 6: the step's 5 N fixed-length draws are made again ON THE DEVICE from the generator's state (k_plan_regen; the host "
+                    "pipeline hands over `order` and the state at every eighth block of their region of the stream) and the persistent kernel "
+                    "takes the plans sixteen steps a launch (profiles/r06/exact_regen.md: 45-52 -> 34 us/step).  "
+                    "host_plan_ms = one step's plan made inline by ONE host thread (emx_host_plan_mt, no GPU) -- round 1's path; emx_run "
                     "takes its plans from the host pipeline (csrc/emx_mtpipe.cpp: generator thread twisting MT19937 STATE words into a cache-"
                     "resident ring, tokenizer thread deciding the rejections and copying the fixed-length draws out, finisher threads -- six where "
                     "the L3 domain has room, five with device finish: one thread per core of an eight-core domain -- for the swaps and `order`); round 5: a stretch step's uniforms go up as those generator words, "
@@ -233,6 +237,20 @@ def exact_mode_entry(wl, K, W, device):
                     "partners / takes the logs on the consumer's stream (profiles/r05/exact_c2.md: 57.8 -> 45.8 us/step and the variants "
                     "dropped).  pipeline_stage_us_per_step says which stage bounds it on THIS host (the stages run concurrently: the largest "
                     "of generator / tokenizer / finishers-summed over the thread count is the pipeline's floor; box to box 45.8 ... 54)"}
+
+
+def exact_mode_c4_entry(K, W, device):
+    """BASELINE configs[3] (65 536 x 64, DEMove 0.8 + DESnookerMove 0.2) under rng=mt19937: the reference's own draws for these moves --
+    pair codes and polar normals (de.py:46-56), three randint and a shuffle per walker (de_snooker.py:36-39) -- are finished by the
+    host pipeline's threads; round-5 verdict asked for the number in the line."""
+    wl = Workload("c4", 65536)
+    Kx = max(50, min(K, 200))
+    res = measure_single(wl, Kx, max(W, 10), device=device, rng="mt19937", spin_s=0.05, want_kernel=False)
+    B = wl.bytes_per_update(False)
+    wu = wl.N * Kx / res["wall_s"]
+    return {"workload": wl.label + ", rng=mt19937", "steps": Kx, "blocks_timed": res["blocks"], "ms_per_step": res["wall_s"] * 1e3 / Kx, "wu_per_s": wu,
+            "roofline_frac_wall_clock": wu * B / 1e9 / HBM_PEAK_GBPS, "accept_frac": res["accept_frac"], "device_status": res["status"],
+            "pipeline_stage_us_per_step": res.get("pipeline")}
 
 
 def exact_mode_large_entry(K, W, device):
