@@ -387,6 +387,7 @@ struct emx_ctx {
     int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
     int64_t tune_persist_slab = 1;       // 0: dense targets of padded ndim 80 ... 128 never take the persistent slab kernel (emx_pslab.hip)
     int64_t persist_slab_launches = 0;
+    int64_t tune_mt_device_min_regen = 786432;      // the device producer's first ensemble size where the host pipeline's stretch steps are regen steps (mtdev_eligible)
     int64_t tune_mt_regen_min = 16384;   // exact mode, host pipeline with device finish: from this many walkers on a stretch step's fixed-length draws are made again
                                          // on the device from the generator's state (k_plan_regen) instead of crossing PCIe; 0: never
     int64_t pipe_regen_steps = 0;
@@ -1469,6 +1470,11 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_persist_exact_regen_max = v;
         return 0;
     }
+    if (!strcmp(key, "mt_device_min_walkers_regen")) {
+        PIPE_STOP(c);
+        c->tune_mt_device_min_regen = v;
+        return 0;
+    }
     if (!strcmp(key, "mt_regen_side")) {
         c->tune_mt_regen_side = v < 0 ? 0 : (v > 2 ? 2 : v);
         return 0;
@@ -2207,7 +2213,12 @@ static int pipe_stop(emx_ctx* c) {
 // depend on the walkers), retired -- the context's generator set to the state after the last step TAKEN -- by whatever retires
 // the pipeline (pipe_stop calls mtdev_stop).
 static bool mtdev_eligible(const emx_ctx* c) {
-    return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_device != 0 && c->N >= (c->tune_mt_device == 2 ? 8192 : c->tune_mt_device_min) && c->world == 1 && !c->comm && !c->sendbuf &&
+    // Round 6: where the host pipeline hands its stretch steps over as generator states (regen_ctx_ok: half the ensemble a power of two)
+    // it is the faster producer up to half a million walkers -- 131 072: 70 against 108 us/step, 262 144: 120-195 against 179,
+    // 524 288: 250-350 against 315-360, 1 048 576: 760-800 against 524-571 (profiles/r06/mtdev_sizes_r06.txt) -- so the device
+    // producer starts at "mt_device_min_walkers_regen" there
+    const int64_t dmin = c->tune_mt_device == 2 ? 8192 : (regen_ctx_ok(c) ? std::max(c->tune_mt_device_min, c->tune_mt_device_min_regen) : c->tune_mt_device_min);
+    return c->rng_mode == EMX_RNG_MT19937 && c->tune_mt_device != 0 && c->N >= dmin && c->world == 1 && !c->comm && !c->sendbuf &&
            !c->peers_ready && !small_eligible(c) && MtDevProducer::supports(c->N, (int32_t)c->moves.size(), c->moves.data());
 }
 

@@ -118,7 +118,10 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   "mt_pipeline"              -1        -1: host pipeline, finisher threads from the core count; k > 0: k finishers; 0: inline, calling thread
  *   "mt_device_finish"         1         0: the finisher threads convert every draw (1: k_plan_raw does, on the device)
  *   "mt_regen_min_walkers"     16384     stretch steps of ensembles this large go up as generator STATES (k_plan_regen makes the draws again); 0: never
- *   "mt_device"                1         0: never the device producer; 1: from "mt_device_min_walkers" (147456) on; 2: from 8192 on
+ *   "mt_device"                1         0: never the device producer; 1: from "mt_device_min_walkers" (147456) on -- from "mt_device_min_walkers_regen"
+ *                                        (786432) where the host pipeline's stretch steps are regen steps; 2: from 8192 on
+ *   "persist_exact_regen_max_walkers"  131072   exact mode: largest ensemble of the device-wide persistent form when its plans go up as generator states
+ *   "mt_regen_side"            0         per-step uploads: 1 / 2: k_plan_regen (and k_plan_raw) on the upload stream, under the step before
  *   "mt_tok_wshift" / "mt_tok_tail"  11 / 2048   the device tokenizer's window rule    "mt_device_lookahead"  batches ahead
  *   -- exchanges --
  *   "direct_timeout_ms"        bound of the device-side barriers of the direct and replay exchanges (the first of an emx_run: 6x)

@@ -261,7 +261,9 @@ def exact_mode_large_entry(K, W, device):
     Kx = max(50, min(K, 200))
     out = {"workload": wl.label + ", rng=mt19937 (NumPy legacy stream, chain identical to reference emcee's)", "steps": Kx}
     B = wl.bytes_per_update(False)
-    for name, tune in (("device_producer", {"mt_device": 1}), ("host_pipeline", {"mt_device": 0})):
+    # (round 6: at this size the host pipeline -- its stretch steps go up as generator states -- is the default again, the device producer
+    # starts at 786 432 walkers; mt_device = 2 forces it here)
+    for name, tune in (("device_producer", {"mt_device": 2}), ("host_pipeline", {"mt_device": 0})):
         res = measure_single(wl, Kx, max(W, 10), device=device, rng="mt19937", spin_s=0.05, want_kernel=False, tuning=tune)
         wu = wl.N * Kx / res["wall_s"]
         e = {"ms_per_step": res["wall_s"] * 1e3 / Kx, "wu_per_s": wu, "blocks_timed": res["blocks"], "device_status": res["status"],
@@ -281,7 +283,7 @@ def exact_mode_large_entry(K, W, device):
     if "ms_per_step" in out.get("device_producer", {}) and "ms_per_step" in out.get("host_pipeline", {}):
         out["speedup_device_over_host"] = out["host_pipeline"]["ms_per_step"] / out["device_producer"]["ms_per_step"]
     out["note"] = ("the tokenizer (the masked rejection of random.shuffle, red_blue.py:80: the one serial part of a step) bounds the device "
-                   "producer; below ~10^5 walkers the host pipeline is faster and stays the default (profiles/r04/mtdev_sizes.txt)")
+                   "producer; the host pipeline with regen steps is the faster one up to half a million walkers (profiles/r06/mtdev_sizes_r06.txt)")
     return out
 
 
