@@ -3332,8 +3332,11 @@ static bool persist_slab_ok(const emx_ctx* c) {
     // at 112, DE 53.5 / 51.5: its barrier and agent-scope accesses cost what the launch gap and the image staging did;
     // profiles/r06/pslab.txt): those shapes keep the launches.  Tuning "persist_slab" = 2 takes the persistent form there too (tests).
     if (c->tune_persist_slab != 2 && c->Dp >= 112 && c->N / 2 / 16 >= 8 * (int64_t)c->num_cu) return false;
+    // even ndim 66 ... 128 (pick_shape: rows of 16 lanes, two coordinates a lane); odd ndim 65 ... 127 (pick_shape: rows of 32 lanes, one
+    // coordinate a lane, for the launch-per-half-step kernels -- the persistent kernel keeps the 16-lane register layout and moves the
+    // rows 8 bytes at a time, emx_pslab.hip)
     const Shape sh = pick_shape(c->D, c->Dp);
-    return sh.G == 16 && sh.V == 2 && sh.CH == 4;
+    return (sh.G == 16 && sh.V == 2 && sh.CH == 4) || (c->tune_persist_odd != 0 && sh.G == 32 && sh.V == 1 && sh.CH == 4);
 }
 
 // the moves k_persist has an instantiation for (the other moves of a mixture run their steps through the per-half-step launches)
@@ -3345,7 +3348,7 @@ static bool persist_grid_fits(const emx_ctx* cc, const emx_move_desc& m, int wpb
     if (c->persist_fits[m.kind] < 0) {
         const int64_t groups = c->N / m.nsplits / 16 / wpb;
         int per_cu = 0;
-        const hipError_t e = c->Dp > 64 ? persist_slab_occupancy(c->Dp / 16, m.kind, 64 * wpb, slab_lds_bytes(c->Dp, wpb), &per_cu)
+        const hipError_t e = c->Dp > 64 ? persist_slab_occupancy(c->Dp / 16, m.kind, c->D & 1, 64 * wpb, slab_lds_bytes(c->Dp, wpb), &per_cu)
                              : (c->D & 1) ? persist_dense_odd_occupancy(c->Dp / 16, m.kind, 64 * wpb, dense_lds_bytes(c->Dp, wpb), &per_cu)
                                         : hot_persist_occupancy(c->Dp / 16, m.kind, 64 * wpb, dense_lds_bytes(c->Dp, wpb), &per_cu);
         c->persist_fits[m.kind] = (e != hipSuccess || (int64_t)per_cu * c->num_cu >= groups) ? 1 : 0;     // (no answer: as before)
@@ -3369,6 +3372,7 @@ static bool persist_move_ok(const emx_ctx* c, const emx_move_desc& m) {
     const bool known = ((m.kind == EMX_MOVE_STRETCH || m.kind == EMX_MOVE_DE) && m.nsplits == 2) || (m.kind == EMX_MOVE_SNOOKER && m.nsplits == 4);
     if (!known) return false;
     if (c->target == EMX_TARGET_DENSE_GAUSS && c->Dp > 64 && (m.kind == EMX_MOVE_SNOOKER || !persist_slab_ok(c))) return false;       // (k_persist_slab: stretch and DE)
+    if (c->target == EMX_TARGET_DENSE_GAUSS && c->Dp > 64 && (c->D & 1) && m.kind != EMX_MOVE_STRETCH) return false;                 // (... at an odd ndim: stretch)
     if (persist_local_ok(c, m)) return true;            // (one workgroup per CU of one XCD by construction)
     if (c->target != EMX_TARGET_DENSE_GAUSS) return persist_valu_wide_ok(c, m);       // (element-wise targets: the one-XCD form, or -- exact mode -- the device-wide one)
     const int wpb = persist_shape(c, m.nsplits);
@@ -3460,7 +3464,7 @@ static bool persist_wanted(const emx_ctx* c) {
     bool any = false;
     for (const auto& m : c->moves) any = any || persist_move_ok(c, m);
     if (!any) return false;
-    if (c->Dp > 64) return true;           // (persist_slab_ok: rows of 16 lanes, even ndim 66 ... 128)
+    if (c->Dp > 64) return true;           // (persist_slab_ok: even ndim 66 ... 128, odd 65 ... 127)
     // ndim up to 64: the row layouts k_persist is instantiated for -- even ndim: two coordinates per lane, rows of 8 lanes (emx_hot.hip);
     // odd ndim (round 6, emx_podd.hip): one coordinate per lane, rows of 8 lanes up to padded ndim 32, of 16 lanes beyond
     const Shape sh = pick_shape(c->D, c->Dp);
@@ -3793,7 +3797,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
             // (lean launches carry no ablation mask: bit 8 = skewed start, bits 9-10 = when the sibling starts -- as k_halfstep_slab;
             // tuning "persist_slab_skew": 0 off, 1 ... 4)
             P.base.ablate = c->tune_persist_slab_skew ? 256 | (int32_t)((c->tune_persist_slab_skew - 1) << 9) : 0;
-            e = launch_persist_slab(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
+            e = launch_persist_slab(c->Dp / 16, launch_move, launch_local ? 1 : 0, c->D & 1, grid, block, lds, c->stream, P);
             c->persist_slab_launches++;
         } else if (c->D & 1) {
             e = launch_persist_dense_odd(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);

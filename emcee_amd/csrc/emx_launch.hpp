@@ -48,8 +48,9 @@ size_t slab_lds_bytes(int Dp, int waves);
 hipError_t launch_persist_dense_odd(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
 hipError_t persist_dense_odd_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu);
 // emx_pslab.hip: its persistent form (k_persist_slab: device-wide and one-XCD; the stretch and DE moves) -- same LDS layout
-hipError_t launch_persist_slab(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
-hipError_t persist_slab_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu);
+// (odd: an odd ndim, 65 ... 127 -- 8-byte-granular row accesses in the same register layout)
+hipError_t launch_persist_slab(int dpb, int move, int local, int odd, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
+hipError_t persist_slab_occupancy(int dpb, int move, int odd, int threads, size_t lds, int* per_cu);
 
 // Wide dense Gaussian targets (padded ndim > 112, emx_wide.hip): log-probs of a block of rows, and the decision + commit
 // of a half-step whose proposals sit in qout / fout.

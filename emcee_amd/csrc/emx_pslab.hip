@@ -18,7 +18,71 @@ namespace emx {
 
 constexpr int PSLAB_RT = 34;         // slab row stride in doubles (emx_slab.hip: SLAB_RT)
 
-template <int DPB, int MOVE, bool LOCAL>
+// Row accesses of the (G = 16, V = 2, CH = 4) layout for an ODD ndim (65 ... 127): a row of an odd number of doubles is 8-byte aligned
+// only, so the two coordinates of a lane and chunk travel as two 8-byte accesses instead of one of 16.  The values in the registers --
+// and everything made from them -- are those of the even layout: the kernel body is one.  (The launch-per-half-step path runs such
+// an ndim in rows of 32 lanes, one coordinate a lane: the same proposals element by element, the same tile in LDS, the same bits.)
+typedef unsigned int pslab_u2 __attribute__((ext_vector_type(2)));
+template <bool ODD, int CPOL>
+__device__ __forceinline__ void pslab_load_row(Row<16, 2, 4>& r, __amdgpu_buffer_rsrc_t rsrc, int row, int D, int gl) {
+    if constexpr (!ODD) {
+        load_row_agent<16, 2, 4, CPOL>(r, rsrc, row, D, gl);
+    } else {
+        const int base = row * D;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int d = (c * 16 + gl) * 2;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                if (d + v < D) {
+                    const pslab_u2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (base + d + v) * 8, 0, CPOL);
+                    double t;
+                    __builtin_memcpy(&t, &w, 8);
+                    r.x[c][v] = t;
+                } else {
+                    r.x[c][v] = 0.0;
+                }
+            }
+        }
+    }
+}
+template <bool ODD, int CPOL>
+__device__ __forceinline__ void pslab_store_row(const Row<16, 2, 4>& r, __amdgpu_buffer_rsrc_t rsrc, int row, int D, int gl) {
+    if constexpr (!ODD) {
+        store_row_agent<16, 2, 4, CPOL>(r, rsrc, row, D, gl);
+    } else {
+        const int base = row * D;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int d = (c * 16 + gl) * 2;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                if (d + v < D) {
+                    pslab_u2 w;
+                    const double t = r.x[c][v];
+                    __builtin_memcpy(&w, &t, 8);
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, (base + d + v) * 8, 0, CPOL);
+                }
+            }
+        }
+    }
+}
+template <bool ODD>
+__device__ __forceinline__ void pslab_store_stream(const Row<16, 2, 4>& r, double* __restrict__ base, int D, int gl) {
+    if constexpr (!ODD) {
+        store_row_stream<16, 2, 4>(r, base, D, gl);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int d = (c * 16 + gl) * 2;
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                if (d + v < D) __builtin_nontemporal_store(r.x[c][v], base + d + v);
+        }
+    }
+}
+
+template <int DPB, int MOVE, bool LOCAL, bool ODD = false>
 static __global__ __launch_bounds__(512) void k_persist_slab(const PersistArgs P) {
     static_assert(MOVE == MOVE_STRETCH || MOVE == MOVE_DE, "the slab form takes the stretch and DE moves");
     if (LOCAL && (blockIdx.x & 7u) != 0u) return;       // (k_persist: of an eight times larger grid every eighth workgroup works -- one XCD)
@@ -100,9 +164,9 @@ static __global__ __launch_bounds__(512) void k_persist_slab(const PersistArgs P
         Row<G, V, CH> xi[PPT], xa[PPT], xb[DE ? PPT : 1];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            load_row_agent<G, V, CH, CPOL>(xi[k], Xr, wi[k], D, gl);
-            load_row_agent<G, V, CH, CPOL>(xa[k], Xr, ja[k], D, gl);
-            if constexpr (DE) load_row_agent<G, V, CH, CPOL>(xb[k], Xr, jb[k], D, gl);
+            pslab_load_row<ODD, CPOL>(xi[k], Xr, wi[k], D, gl);
+            pslab_load_row<ODD, CPOL>(xa[k], Xr, ja[k], D, gl);
+            if constexpr (DE) pslab_load_row<ODD, CPOL>(xb[k], Xr, jb[k], D, gl);
         }
         if (skew_on && wib < 4) {
             // most of this wave's rows are here: the sibling may load now (bits 9-10: all / three quarters / half / a quarter of them)
@@ -132,7 +196,7 @@ static __global__ __launch_bounds__(512) void k_persist_slab(const PersistArgs P
             ok[k] = !badq;
             if (gl == 0) facS[k * WPW + sub] = badq ? -__builtin_inf() : 0.0;       // (+ my_fac below: exact, x + 0 = x)
             // stored step: the current row goes out now (fire and forget); an accepted proposal overwrites it after the decision
-            if (I.chain) store_row_stream<G, V, CH>(xi[k], I.chain + (size_t)wi[k] * D, D, gl);
+            if (I.chain) pslab_store_stream<ODD>(xi[k], I.chain + (size_t)wi[k] * D, D, gl);
         }
         // the deciding lanes' own entries, and the next half-step's plan entries: asked for here, under the MFMA chain
         const int my_i = I.order[mypos];
@@ -212,8 +276,8 @@ static __global__ __launch_bounds__(512) void k_persist_slab(const PersistArgs P
             const int row = pp * WPW + sub;
             const bool ac = (am64 >> ((row & 3) * 16 + (row >> 2))) & 1ull;
             if (ac) {
-                store_row_agent<G, V, CH, CPOL_ST>(qk[pp], Xr, wi[pp], D, gl);
-                if (I.chain) store_row_stream<G, V, CH>(qk[pp], I.chain + (size_t)wi[pp] * D, D, gl);
+                pslab_store_row<ODD, CPOL_ST>(qk[pp], Xr, wi[pp], D, gl);
+                if (I.chain) pslab_store_stream<ODD>(qk[pp], I.chain + (size_t)wi[pp] * D, D, gl);
             }
         }
         EMX_WAVE_SYNC();                                // (facS and the slab are rewritten by the next half-step)
@@ -233,9 +297,9 @@ static __global__ __launch_bounds__(512) void k_persist_slab(const PersistArgs P
     }
 }
 
-template <int DPB, int MOVE, bool LOCAL>
+template <int DPB, int MOVE, bool LOCAL, bool ODD>
 static hipError_t launch_pslab(dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-    auto kern = k_persist_slab<DPB, MOVE, LOCAL>;
+    auto kern = k_persist_slab<DPB, MOVE, LOCAL, ODD>;
     static size_t lds_granted[MAX_DEVICES] = {};
     int dev = 0;
     if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
@@ -247,19 +311,27 @@ static hipError_t launch_pslab(dim3 grid, dim3 block, size_t lds, hipStream_t st
     return hipGetLastError();
 }
 
-hipError_t launch_persist_slab(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-#define EMX_CASE(b)                                                                                                                 \
-    if (dpb == b) {                                                                                                                 \
-        if (move == MOVE_DE) return local ? launch_pslab<b, MOVE_DE, true>(grid, block, lds, st, P) : launch_pslab<b, MOVE_DE, false>(grid, block, lds, st, P); \
-        return local ? launch_pslab<b, MOVE_STRETCH, true>(grid, block, lds, st, P) : launch_pslab<b, MOVE_STRETCH, false>(grid, block, lds, st, P);          \
+template <int DPB, bool ODD>
+static hipError_t launch_pslab_pick(int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+    if constexpr (ODD) {
+        if (move == MOVE_DE) return hipErrorInvalidValue;       // (the DE move's third row a walker: 39 spilled registers at padded ndim 128 -- not instantiated; the host's rule keeps it off)
+    } else {
+        if (move == MOVE_DE) return local ? launch_pslab<DPB, MOVE_DE, true, ODD>(grid, block, lds, st, P) : launch_pslab<DPB, MOVE_DE, false, ODD>(grid, block, lds, st, P);
     }
+    return local ? launch_pslab<DPB, MOVE_STRETCH, true, ODD>(grid, block, lds, st, P) : launch_pslab<DPB, MOVE_STRETCH, false, ODD>(grid, block, lds, st, P);
+}
+
+// odd: ndim is odd (65 ... 127): the 8-byte-granular row accesses
+hipError_t launch_persist_slab(int dpb, int move, int local, int odd, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+#define EMX_CASE(b) \
+    if (dpb == b) return odd ? launch_pslab_pick<b, true>(move, local, grid, block, lds, st, P) : launch_pslab_pick<b, false>(move, local, grid, block, lds, st, P);
     EMX_CASE(5) EMX_CASE(6) EMX_CASE(7) EMX_CASE(8)
 #undef EMX_CASE
     return hipErrorInvalidValue;
 }
 
 // workgroups of the device-wide instantiation a CU holds at once (block size, dynamic LDS): the co-residency check of persist_grid_fits
-hipError_t persist_slab_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu) {
+hipError_t persist_slab_occupancy(int dpb, int move, int odd, int threads, size_t lds, int* per_cu) {
 #define EMX_OCC(kern_)                                                                                                          \
     {                                                                                                                           \
         auto kern = kern_;                                                                                                      \
@@ -269,10 +341,14 @@ hipError_t persist_slab_occupancy(int dpb, int move, int threads, size_t lds, in
         }                                                                                                                       \
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, threads, lds);                                        \
     }
-#define EMX_CASE(b)                                                  \
-    if (dpb == b) {                                                  \
-        if (move == MOVE_DE) EMX_OCC((k_persist_slab<b, MOVE_DE, false>)) \
-        EMX_OCC((k_persist_slab<b, MOVE_STRETCH, false>))            \
+#define EMX_CASE(b)                                                                                      \
+    if (dpb == b) {                                                                                      \
+        if (move == MOVE_DE) {                                                                           \
+            if (odd) return hipErrorInvalidValue;                                                        \
+            EMX_OCC((k_persist_slab<b, MOVE_DE, false, false>))                                          \
+        }                                                                                                \
+        if (odd) EMX_OCC((k_persist_slab<b, MOVE_STRETCH, false, true>))                                 \
+        EMX_OCC((k_persist_slab<b, MOVE_STRETCH, false, false>))                                         \
     }
     EMX_CASE(5) EMX_CASE(6) EMX_CASE(7) EMX_CASE(8)
 #undef EMX_CASE

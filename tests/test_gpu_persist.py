@@ -379,7 +379,7 @@ def test_persistent_launches_and_the_step_api_interleave():
 
 def test_what_does_not_qualify():
     # (round 6: ndim 66 ... 128 even and odd ndim up to 63 do qualify now -- k_persist_slab, emx_podd.hip: tests/test_gpu_persist_slab.py)
-    for N, D, why in ((1000, 64, "half an ensemble of whole 16-walker tiles"), (4096, 130, "ndim above 128: the wide path"), (4096, 67, "odd ndim above 64"),
+    for N, D, why in ((1000, 64, "half an ensemble of whole 16-walker tiles"), (4096, 130, "ndim above 128: the wide path"), (4096, 129, "odd ndim above 128"),
                       (131072, 64, "more tiles than waves"), (480, 64, "below persist_min_walkers"), (65536, 128, "the per-half-step slab kernel is level there")):
         ens = native_ens(dense_spec(N, D), 1)
         assert not ens.persist_info()["qualifies"], why

@@ -78,12 +78,12 @@ def test_one_xcd_form_gives_the_bits_of_the_per_half_step_path(N, D, move, store
 
 def test_mixture_of_stretch_and_de_and_what_does_not_qualify():
     """a stretch + DE schedule: runs of each move in launches of their own; a schedule with the snooker move (four rows a walker: no
-    slab form) and odd ndim keep the per-half-step launches -- and all of them agree with the control"""
+    slab form), the DE move at an odd ndim and ndim above 128 keep the per-half-step launches -- and all of them agree with the control"""
     spec = full_spec(16384, 128, "dense", [S("stretch"), S("de")], weights=[0.6, 0.4], seed=9)
     p, c = _run(spec, 1, 1, 40, 1, True), _run(spec, 0, 1, 40, 1, True)
     assert p["info"]["launches"] > 0 and c["info"]["launches"] == 0
     _same(p, c)
-    for moves, D in (([S("snooker")], 128), ([S("stretch")], 127)):
+    for moves, D in (([S("snooker")], 128), ([S("de")], 127), ([S("stretch")], 129)):
         spec = full_spec(4096, D, "dense", moves, seed=10)
         ens = native_ens(spec, 1)
         ens.run(5, 1, False)
@@ -205,3 +205,23 @@ def test_odd_ndim_in_exact_mode_and_in_a_mixture():
     p, c = _run(spec, 1, 1, 48, 1, True), _run(spec, 0, 1, 48, 1, True)
     assert p["info"]["launches"] > 0 and c["info"]["launches"] == 0
     _same(p, c)
+
+
+@pytest.mark.parametrize("N,D,store,thin_by,local", [(32768, 127, False, 1, 0), (16384, 65, True, 1, 0), (8192, 97, False, 1, 0), (4096, 127, True, 2, 1),
+                                                     (1024, 65, False, 1, 1), (2048, 111, True, 1, 1), (49152, 81, False, 1, 0)])
+def test_odd_ndim_above_64_takes_the_slab_kernel(N, D, store, thin_by, local):
+    """odd ndim 65 ... 127, stretch move: k_persist_slab in its 8-byte-granular form (the 16-lane register layout, rows moved 8 bytes at
+    a time) against the launch-per-half-step kernels, which run such an ndim in rows of 32 lanes -- the same bits; the DE move at an
+    odd ndim keeps the launches"""
+    spec = full_spec(N, D, "dense", [S("stretch")], seed=21)
+    p = _run(spec, 1, 2, 21, thin_by, store, local=local, tuning={"persist_slab": 2})
+    c = _run(spec, 0, 2, 21, thin_by, store)
+    assert p["info"]["qualifies"] and p["info"]["launches"] >= 4 and p["info"]["halfsteps"] == 84 * thin_by
+    assert (p["info"]["local_launches"] == p["info"]["launches"]) == bool(local) and c["info"]["launches"] == 0 and p["acc"].any()
+    _same(p, c)
+    if N == 1024:
+        spec = full_spec(N, D, "dense", [S("de")], seed=21)
+        ens = native_ens(spec, 1)
+        ens.run(5, 1, False)
+        assert ens.persist_info()["launches"] == 0 and ens.status() == 0
+        ens.close()
