@@ -3276,7 +3276,7 @@ static int run_impl(emx_ctx* c, int64_t nsteps, int32_t thin_by, int32_t store);
 // ---- persistent half-steps ------------------------------------------------------------------------------------------
 // The headline shape -- stretch / DE steps of two splits and snooker steps of four, the fused dense Gaussian target at an even
 // ndim up to 64, Philox plans, a single replica, an ensemble whose half-step is exactly one 16-walker tile per wave of a
-// co-resident grid of about one workgroup per CU (persist_shape) -- runs up to 32 half-steps per launch in k_persist
+// co-resident grid of about one workgroup per CU (persist_shape) -- runs up to 40 half-steps per launch (PERSIST_MAX_ITERS: twenty stretch / DE steps) in k_persist
 // (emx_kernels.hpp); in a mixture of moves a launch takes the consecutive steps of one move.
 // (Measured and dropped: the next batch's plan kernel on a stream of its own next to the running persistent launch -- no
 // difference, 20.6 us/step either way: what the plan kernel's waves gain in overlap the lock-stepped half-steps lose to them;
@@ -3331,7 +3331,9 @@ static bool persist_slab_ok(const emx_ctx* c) {
     // (65 536 walkers on 256 CUs) -- the persistent form is level or 1-4 % behind (43.7 against 43.3 us/step at ndim 128, 38.9 / 37.8
     // at 112, DE 53.5 / 51.5: its barrier and agent-scope accesses cost what the launch gap and the image staging did;
     // profiles/r06/pslab.txt): those shapes keep the launches.  Tuning "persist_slab" = 2 takes the persistent form there too (tests).
-    if (c->tune_persist_slab != 2 && c->Dp >= 112 && c->N / 2 / 16 >= 8 * (int64_t)c->num_cu) return false;
+    // (an ODD ndim has no slab kernel among the launches -- rows of 32 lanes, four waves a CU: 62 / 73 us/step at 65 536 x 97 / 127 -- and
+    // takes the persistent form at every size)
+    if (c->tune_persist_slab != 2 && c->Dp >= 112 && c->N / 2 / 16 >= 8 * (int64_t)c->num_cu && !(c->D & 1)) return false;
     // even ndim 66 ... 128 (pick_shape: rows of 16 lanes, two coordinates a lane); odd ndim 65 ... 127 (pick_shape: rows of 32 lanes, one
     // coordinate a lane, for the launch-per-half-step kernels -- the persistent kernel keeps the 16-lane register layout and moves the
     // rows 8 bytes at a time, emx_pslab.hip)
@@ -3717,13 +3719,15 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
                 lds = cap.lds;
             }
             PersistIter& I = P.it[n++];
-            I.order = cap.a.order;
-            I.p0 = cap.a.p0;
-            I.p1 = cap.a.p1;
-            I.p2 = cap.a.p2;
-            I.s0 = cap.a.s0;
-            I.logu = cap.a.logu;
-            I.fac = cap.a.fac;
+            {   // one pointer for the plan's columns: every slot is one block in the layout PersistCols spells out
+                const char* blk = reinterpret_cast<const char*>(cap.a.order);
+                const size_t NN = (size_t)c->N;
+                NEED(c, (const void*)cap.a.p0 == (const void*)(blk + NN * 4) && (const void*)cap.a.s0 == (const void*)(blk + NN * 8) &&
+                            (const void*)cap.a.p1 == (const void*)(blk + NN * 24) && (const void*)cap.a.p2 == (const void*)(blk + NN * 28) &&
+                            (const void*)cap.a.logu == (const void*)(blk + NN * 32) && (const void*)cap.a.fac == (const void*)(blk + NN * 40),
+                     "persistent half-steps: the plan slot is not one block in the expected layout");
+                I.plan = blk;
+            }
             I.chain = cap.a.chain;
             I.chain_lp = cap.a.chain_lp;
             I.pos0 = cap.a.pos0;

@@ -1275,15 +1275,33 @@ __device__ __forceinline__ void store_scope(T* p, T v) {
         store_agent(p, v);
 }
 
-constexpr int PERSIST_MAX_ITERS = 32;
+// Half-steps a persistent launch can hold.  Round 6: 40 (32 before) -- twenty stretch / DE steps, so that an emx_run of 20 steps (the
+// block length the bench is driven with) is ONE launch, not 16 + 4; a half-step's descriptor shrank from 96 to 48 bytes for it (the
+// plan's seven columns are one pointer: every plan slot is one block [order|p0] [s0|uacc] [p1|p2] [logu|fac]), the kernel arguments
+// from 3.5 to 2.4 KB.
+constexpr int PERSIST_MAX_ITERS = 40;
 constexpr int PERSIST_BAR_WORDS = 12 * 32;   // PersistArgs::bar
 struct PersistIter {
-    const int32_t *order, *p0, *p1, *p2;  // (p1: the DE move's second partner; p1, p2: the snooker move's z1, z2)
-    const double *s0, *logu, *fac;
+    const char* plan;              // the plan slot's block: [order|p0] int32, [s0|uacc] f64, [p1|p2] int32, [logu|fac] f64, N entries a column
     double *chain, *chain_lp;      // this step's row of the stored chain (backend.py:229), or nullptr
     int32_t pos0, split;
     double gammas;                 // k_persist_mix: the snooker move's scale of THIS half-step (HalfStepArgs::gammas is the first captured step's)
     int32_t kind, shift;           // MOVE_MIX: the half-step's move; it has 2^-shift as many tiles as the grid has waves (k_persist_mix: mix_tile)
+};
+// ... as the kernels read it: the columns spelled out (p1: the DE move's second partner; p1, p2: the snooker move's z1, z2)
+struct PersistCols {
+    const int32_t *order, *p0, *p1, *p2;
+    const double *s0, *logu, *fac;
+    double *chain, *chain_lp;
+    int32_t pos0, split;
+    double gammas;
+    int32_t kind, shift;
+    __host__ __device__ __forceinline__ PersistCols(const PersistIter& it, size_t N)
+        : order(reinterpret_cast<const int32_t*>(it.plan)), p0(reinterpret_cast<const int32_t*>(it.plan) + N),
+          p1(reinterpret_cast<const int32_t*>(it.plan + N * 24)), p2(reinterpret_cast<const int32_t*>(it.plan + N * 24) + N),
+          s0(reinterpret_cast<const double*>(it.plan + N * 8)), logu(reinterpret_cast<const double*>(it.plan + N * 32)),
+          fac(reinterpret_cast<const double*>(it.plan + N * 32) + N), chain(it.chain), chain_lp(it.chain_lp), pos0(it.pos0), split(it.split),
+          gammas(it.gammas), kind(it.kind), shift(it.shift) {}
 };
 struct PersistArgs {
     HalfStepArgs base;
@@ -1299,6 +1317,7 @@ struct PersistArgs {
     unsigned seq;                  // number of this launch (left in the barrier block's fourth `go` word once its grid is known co-resident)
     unsigned* started_host;        // pinned host word (or null): `seq` again, for the host -- launch k + 1 has started, so launch k is over
 };
+static_assert(sizeof(PersistArgs) <= 4096, "kernel arguments of the persistent kernels");
 
 // The one-XCD form's barrier: every workgroup of the grid runs on ONE XCD (k_persist<..., LOCAL>), so its L2 is the point of
 // coherence.  What that allows was measured flavour by flavour (tools/exp/xcd_local_probe.hip, profiles/r04/xcd_local_probe.txt):
@@ -1513,7 +1532,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     double s0v[PF], facv[PF], my_logu, my_lpo;
     Row<G, V, CH> xi[PF];
     {
-        const PersistIter& I = P.it[0];
+        const PersistCols I(P.it[0], (size_t)P.base.N);
         const int pbase = I.pos0 + t0;
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
@@ -1542,7 +1561,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         cwi[k] = 0;
     }
     for (int n = 0; n < P.niter; ++n) {
-        const PersistIter& I = P.it[n];
+        const PersistCols I(P.it[n], (size_t)P.base.N);
         // -------- partner rows: the walkers the previous half-step updated --------
         Row<G, V, CH> xa[PF], xb[DE ? PF : 1], xc[SN ? PF : 1];
 #pragma unroll
@@ -1553,7 +1572,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         }
         // -------- plan entries of the next half-step (written by the plan kernel before this launch) --------
         const bool more = n + 1 < P.niter;
-        const PersistIter& J = P.it[more ? n + 1 : n];
+        const PersistCols J(P.it[more ? n + 1 : n], (size_t)P.base.N);
         const bool pre = more && J.split != 0;                   // its own walkers are this half-step's complement
         const unsigned stamp = P.epoch0 + (unsigned)n + 1u;      // of this half-step (never 0 before the counters wrap)
         int wi_n[PF], ja_n[PF], jb_n[DE ? PF : 1], jc_n[SN ? PF : 1], my_i_n;

@@ -99,7 +99,7 @@ static __global__ __launch_bounds__(512) void k_persist_mix(const PersistArgs P)
     double s0v[PF], facv[PF], my_logu = 0.0, my_lpo = 0.0;
     Row<G, V, CH> xi[PF];
     if (act) {
-        const PersistIter& I = P.it[0];
+        const PersistCols I(P.it[0], (size_t)P.base.N);
         const int pbase = I.pos0 + t0;
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
@@ -128,9 +128,9 @@ static __global__ __launch_bounds__(512) void k_persist_mix(const PersistArgs P)
         cwi[k] = 0;
     }
     for (int n = 0; n < P.niter; ++n) {
-        const PersistIter& I = P.it[n];
+        const PersistCols I(P.it[n], (size_t)P.base.N);
         const bool more = n + 1 < P.niter;
-        const PersistIter& J = P.it[more ? n + 1 : n];
+        const PersistCols J(P.it[more ? n + 1 : n], (size_t)P.base.N);
         const bool pre = more && J.split != 0;                   // its own walkers are this half-step's complement
         const unsigned stamp = P.epoch0 + (unsigned)n + 1u;      // of this half-step (never 0 before the counters wrap)
         int wi_n[PF], ja_n[PF], jb_n[DE ? PF : 1], jc_n[SNA ? PF : 1], my_i_n = 0;

@@ -133,7 +133,7 @@ static __global__ __launch_bounds__(512) void k_persist_slab(const PersistArgs P
     int wi[PPT], ja[PPT], jb[DE ? PPT : 1];
     double s0v[PPT];
     {
-        const PersistIter& I = P.it[0];
+        const PersistCols I(P.it[0], (size_t)P.base.N);
         const int pbase = I.pos0 + t0;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -145,7 +145,7 @@ static __global__ __launch_bounds__(512) void k_persist_slab(const PersistArgs P
         }
     }
     for (int n = 0; n < P.niter; ++n) {
-        const PersistIter& I = P.it[n];
+        const PersistCols I(P.it[n], (size_t)P.base.N);
         const int mypos = I.pos0 + t0 + myrow;
         if (!PRE && n > 0) {
             const int pbase = I.pos0 + t0;
@@ -207,7 +207,7 @@ static __global__ __launch_bounds__(512) void k_persist_slab(const PersistArgs P
         int wi_n[PRE ? PPT : 1], ja_n[PRE ? PPT : 1];
         double s0_n[PRE ? PPT : 1];
         if constexpr (PRE) {
-            const PersistIter& J = P.it[more ? n + 1 : n];
+            const PersistCols J(P.it[more ? n + 1 : n], (size_t)P.base.N);
             const int pbase = J.pos0 + t0;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {

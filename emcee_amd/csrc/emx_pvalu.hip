@@ -89,7 +89,7 @@ static __global__ __launch_bounds__(512) void k_persist_valu(const PersistArgs P
     constexpr int LD = EMX_CPOL_SC1, ST = LOCAL ? 0 : EMX_CPOL_SC1;      // loads agent-scope (LOCAL: answered by this XCD's L2); stores plain / agent-scope
     int wi[PF], ja[PF], jb[DE ? PF : 1], jc[SN ? PF : 1];
     double s0v[PF], facv[PF], loguv[PF];
-    auto plan_of = [&](const PersistIter& I, int (&w)[PF], int (&a)[PF], int (&b)[DE ? PF : 1], int (&c3)[SN ? PF : 1], double (&s)[PF],
+    auto plan_of = [&](const PersistCols& I, int (&w)[PF], int (&a)[PF], int (&b)[DE ? PF : 1], int (&c3)[SN ? PF : 1], double (&s)[PF],
                        double (&f)[PF], double (&lu)[PF]) {
         const int pbase = I.pos0 + t0;
 #pragma unroll
@@ -104,9 +104,9 @@ static __global__ __launch_bounds__(512) void k_persist_valu(const PersistArgs P
             lu[k] = I.logu[pos];
         }
     };
-    plan_of(P.it[0], wi, ja, jb, jc, s0v, facv, loguv);
+    plan_of(PersistCols(P.it[0], (size_t)P.base.N), wi, ja, jb, jc, s0v, facv, loguv);
     for (int n = 0; n < P.niter; ++n) {
-        const PersistIter& I = P.it[n];
+        const PersistCols I(P.it[n], (size_t)P.base.N);
         // -------- own rows, partner rows, current log-probs: one round trip behind the barrier --------
         Row<G, V, CH> xi[PF], xa[PF], xb[DE ? PF : 1], xc[SN ? PF : 1];
         double lpo[PF];
@@ -122,7 +122,7 @@ static __global__ __launch_bounds__(512) void k_persist_valu(const PersistArgs P
         const bool more = n + 1 < P.niter;
         int wi_n[PF], ja_n[PF], jb_n[DE ? PF : 1], jc_n[SN ? PF : 1];
         double s0_n[PF], fac_n[PF], logu_n[PF];
-        plan_of(P.it[more ? n + 1 : n], wi_n, ja_n, jb_n, jc_n, s0_n, fac_n, logu_n);
+        plan_of(PersistCols(P.it[more ? n + 1 : n], (size_t)P.base.N), wi_n, ja_n, jb_n, jc_n, s0_n, fac_n, logu_n);
         // -------- proposals, target, decision, commit --------
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
