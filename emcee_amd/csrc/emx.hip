@@ -387,6 +387,7 @@ struct emx_ctx {
     int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
     int64_t tune_persist_slab = 1;       // 0: dense targets of padded ndim 80 ... 128 never take the persistent slab kernel (emx_pslab.hip)
     int64_t persist_slab_launches = 0;
+    int64_t tune_persist_max_halfsteps = PERSIST_MAX_ITERS;      // half-steps a persistent launch may hold (<= PERSIST_MAX_ITERS = 40)
     int64_t tune_mt_device_min_regen = 786432;      // the device producer's first ensemble size where the host pipeline's stretch steps are regen steps (mtdev_eligible)
     int64_t tune_mt_regen_min = 16384;   // exact mode, host pipeline with device finish: from this many walkers on a stretch step's fixed-length draws are made again
                                          // on the device from the generator's state (k_plan_regen) instead of crossing PCIe; 0: never
@@ -1482,6 +1483,10 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
     if (!strcmp(key, "mt_regen_min_walkers")) {      // 0: never k_plan_regen (takes effect when a pipeline starts)
         PIPE_STOP(c);
         c->tune_mt_regen_min = v < 0 ? 0 : v;
+        return 0;
+    }
+    if (!strcmp(key, "persist_max_halfsteps")) {
+        c->tune_persist_max_halfsteps = v;
         return 0;
     }
     if (!strcmp(key, "persist_slab")) {      // 0: padded ndim 80 ... 128 on the per-half-step launches (k_halfstep_slab / k_halfstep)
@@ -3643,7 +3648,15 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     bool launch_local = false;           // the one-XCD form: an eight times larger grid of which every eighth workgroup works
     bool launch_mix = false;             // DE and snooker steps of a mixture in this launch (k_persist_mix)
     double launch_gammas = 0.0;
+    // Philox plans live in a ring of TWO batches of sixteen steps (PLAN_RING): a launch may read the plans of at most two batches --
+    // a third would be written into the half of the ring whose slots this very launch still reads (round 6, when a launch grew from
+    // sixteen to twenty steps: a call that started three steps before a batch boundary took plans of three batches)
+    int batches_touched = (!mtmode && !c->prepared.empty() && c->prepared.front().step == c->ph_step) ? 1 : 0;
     while (i0 + steps < total) {
+        if (!mtmode && (c->prepared.empty() || c->prepared.front().step != c->ph_step)) {
+            if (batches_touched >= 2) break;
+            ++batches_touched;
+        }
         // the move of the step that would follow: off its plan, or -- the batch of plans is used up: the next one is made during this
         // capture, i.e. enqueued BEFORE this launch, into the other half of the plan ring -- from the Philox stream directly
         int next_move = -1;
@@ -3658,7 +3671,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         }
         int need = launch_S;               // half-steps of the step that would follow
         if (launch_mix && next_move >= 0) need = c->moves[next_move].nsplits;
-        if (n + need > PERSIST_MAX_ITERS) break;
+        if (n + need > (int)std::min<int64_t>(PERSIST_MAX_ITERS, std::max<int64_t>(4, c->tune_persist_max_halfsteps))) break;
         if (devp) {
             if (steps > 0 && c->mtdev && c->mtdev_taken % MTDEV_BATCH == 0) break;      // one produced batch per launch
         } else if (mtmode) {

@@ -779,3 +779,36 @@ def test_exact_mode_launches_that_cannot_become_resident_are_redone(N, D, target
     for key in c:
         if key != "rng":
             assert np.array_equal(p[key], c[key]), key
+
+
+@pytest.mark.parametrize("N,D,target,moves,weights", [
+    (8192, 64, "dense", [S("stretch")], None), (65536, 64, "dense", [S("stretch")], None), (4096, 10, "iso", [S("stretch")], None),
+    (4096, 128, "dense", [S("stretch")], None), (4096, 33, "dense", [S("de")], None), (8192, 64, "dense", [S("de"), S("snooker")], [0.8, 0.2]),
+])
+@pytest.mark.parametrize("calls,nsteps,thin_by,store", [(2, 45, 1, True), (3, 13, 3, False), (2, 19, 3, True), (4, 29, 1, False)])
+def test_a_launch_reads_the_plans_of_two_batches_at_most(N, D, target, moves, weights, calls, nsteps, thin_by, store):
+    """Round 6: a persistent launch holds up to 40 half-steps (twenty stretch steps), the ring of Philox plans two batches of sixteen
+    steps.  A call that starts a few steps before a batch boundary would take plans of THREE batches -- the third written into the half
+    of the ring the launch still reads (found by the suite the day the launches grew: every kernel family, the second call of a
+    run).  run_persist ends the launch there.  Calls whose starts fall everywhere in a batch, against the per-half-step launches."""
+    spec = full_spec(N, D, target, moves, weights=weights, seed=23)
+    recs = []
+    for persist in (1, 0):
+        ens = native_ens(spec, persist)
+        ens.set_tuning("small_kernel", 0)
+        if store:
+            ens.chain_config(calls * nsteps)
+        for _ in range(calls):
+            ens.run(nsteps, thin_by, store)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        rec = dict(x=x, lp=lp, acc=ens.accepted_mask(), info=ens.persist_info())
+        if store:
+            rec.update(chain=ens.chain_read(0, 0, calls * nsteps), counts=ens.accepted_counts())
+        ens.close()
+        recs.append(rec)
+    p, c = recs
+    assert p["info"]["launches"] > 0 and c["info"]["launches"] == 0
+    for key in c:
+        if key != "info":
+            assert np.array_equal(p[key], c[key]), key
