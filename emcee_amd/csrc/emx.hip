@@ -392,7 +392,6 @@ struct emx_ctx {
     int64_t tune_mt_regen_min = 16384;   // exact mode, host pipeline with device finish: from this many walkers on a stretch step's fixed-length draws are made again
                                          // on the device from the generator's state (k_plan_regen) instead of crossing PCIe; 0: never
     int64_t pipe_regen_steps = 0;
-    int64_t tune_mt_regen_side = 0;      // 1 / 2: k_plan_regen (and k_plan_raw) on the upload stream, under the step before (pipe_take)
     int64_t tune_persist_odd = 1;        // 0: dense targets of odd ndim never take k_persist (emx_podd.hip)
     int64_t tune_persist_slab_skew = 1;  // k_persist_slab: the second wave of a SIMD starts its row loads when its sibling's have arrived (0: at once; 2 ... 4: earlier)
     int64_t tune_persist_slab_local_max = 4096;      // largest ensemble that takes the one-XCD form of k_persist_slab (beyond: the device-wide form; measured, profiles/r06/pslab.txt)
@@ -1476,10 +1475,6 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         c->tune_mt_device_min_regen = v;
         return 0;
     }
-    if (!strcmp(key, "mt_regen_side")) {
-        c->tune_mt_regen_side = v < 0 ? 0 : (v > 2 ? 2 : v);
-        return 0;
-    }
     if (!strcmp(key, "mt_regen_min_walkers")) {      // 0: never k_plan_regen (takes effect when a pipeline starts)
         PIPE_STOP(c);
         c->tune_mt_regen_min = v < 0 ? 0 : v;
@@ -2357,10 +2352,10 @@ static int pipe_take(emx_ctx* c) {
     // runs on the consumer's stream, in front of the half-steps that need it.  (A large plan in two halves on two streams -- one
     // copy engine moves 1.57 MB in 37 us, two in 30, profiles/r05/h2d_rate.txt -- was slower end to end and is gone: round 6.)
     HIPOK(c, hipMemcpyAsync(s.order, s.host, bytes, hipMemcpyHostToDevice, c->up_stream));
-    // tuning "mt_regen_side" (experiment): 1: k_plan_regen behind the copy on the upload stream -- 30 registers a lane, four waves and
-    // 5 KB of LDS a workgroup: it fits on a CU beside a half-step kernel's workgroup and runs under the step before; 2: k_plan_raw (30
-    // registers too) there as well
-    const int side = info.regen ? (int)c->tune_mt_regen_side : 0;
+    // (k_plan_regen behind the copy on the upload stream, under the step before -- its 30-register workgroups fit beside a half-step
+    // kernel's -- was measured: 43.8-45.4 against 50.0-50.3 us/step at 65 536 walkers in one session, 78-81 against 69-71 at 131 072 in
+    // another; profiles/r06/exact_regen_side.txt, exact_persist_regen.txt.  Not kept: up to 65 536 walkers the persistent launches'
+    // batched finish is the path anyway.)
     PlanRegenArgs G{};
     if (info.regen) {
         G.dev = reinterpret_cast<char*>(s.order);
@@ -2380,18 +2375,16 @@ static int pipe_take(emx_ctx* c) {
         R.wr_p1 = info.regen ? 1 : 0;
         for (int k = 0; k <= info.S; ++k) R.off[k] = info.off[k];
     }
-    if (side >= 1) hipLaunchKernelGGL(k_plan_regen, dim3((unsigned)info.regen_nseg), dim3(256), 0, c->up_stream, G);
-    if (side >= 2) hipLaunchKernelGGL(k_plan_raw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->up_stream, R);
     HIPOK(c, hipEventRecord(s.uploaded, c->up_stream));
     HIPOK(c, hipStreamWaitEvent(c->stream, s.uploaded, 0));
     if (info.raw) {
         // device finish: the columns hold `order` and generator words (or accepted randint values); converted in place -- a regen
         // step's fixed-length draws are first made again from the generator states the upload brought (k_plan_regen)
         if (info.regen) {
-            if (side < 1) hipLaunchKernelGGL(k_plan_regen, dim3((unsigned)info.regen_nseg), dim3(256), 0, c->stream, G);
+            hipLaunchKernelGGL(k_plan_regen, dim3((unsigned)info.regen_nseg), dim3(256), 0, c->stream, G);
             c->pipe_regen_steps++;
         }
-        if (side < 2) hipLaunchKernelGGL(k_plan_raw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, R);
+        hipLaunchKernelGGL(k_plan_raw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, R);
         c->pipe_raw_steps++;
         cur.devplan = true;                 // (emx_plan_get: the finished columns exist on the device only)
     } else {

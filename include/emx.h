@@ -108,6 +108,7 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   "persist_mix"              1         0: DE and snooker steps of a mixture in launches of their own
  *   "persist_span"             1         0: a launch ends with its Philox plan batch
  *   "persist_min_walkers"      512       smallest ensemble             "persist_timeout_ms"   2000      bound of a barrier wait
+ *   "persist_max_halfsteps"    40        half-steps a launch may hold (<= 40: twenty stretch / DE steps; a launch never reads plans of more than two batches)
  *   "persist_gauss_wpb"        0 (auto)  waves per workgroup of k_persist_gauss
  *   "persist_exact"            1         0: exact mode (EMX_RNG_MT19937) on the per-half-step launches with an upload per step
  *   "persist_exact_mix"        1         0: ... for one move only      "persist_exact_steps"  16        steps per launch (<= 16)
@@ -121,7 +122,6 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   "mt_device"                1         0: never the device producer; 1: from "mt_device_min_walkers" (147456) on -- from "mt_device_min_walkers_regen"
  *                                        (786432) where the host pipeline's stretch steps are regen steps; 2: from 8192 on
  *   "persist_exact_regen_max_walkers"  131072   exact mode: largest ensemble of the device-wide persistent form when its plans go up as generator states
- *   "mt_regen_side"            0         per-step uploads: 1 / 2: k_plan_regen (and k_plan_raw) on the upload stream, under the step before
  *   "mt_tok_wshift" / "mt_tok_tail"  11 / 2048   the device tokenizer's window rule    "mt_device_lookahead"  batches ahead
  *   -- exchanges --
  *   "direct_timeout_ms"        bound of the device-side barriers of the direct and replay exchanges (the first of an emx_run: 6x)
