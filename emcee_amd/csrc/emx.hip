@@ -1555,6 +1555,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "full_plan")) {     // 1: native plans with every column (default 0: what the fused kernel reads)
+        PIPE_STOP(c);                    // (the exact-mode pipeline hands its steps over finished when every column is asked for)
         c->tune_full_plan = v ? 1 : 0;
         drop_prepared(c);
         return 0;
@@ -1808,6 +1809,11 @@ int emx_set_target(emx_ctx* c, int32_t kind, const double* p0, const double* p1,
         HIPOK(c, hipMalloc((void**)&ntp1, n1 * 8));
         HIPOK(c, hipMemcpy(ntp1, src1, n1 * 8, hipMemcpyHostToDevice));
     }
+    // A running exact-mode pipeline was configured for the target that goes away here (device finish -- raw / regen steps -- is a
+    // matter of the target and the consumer: pipe_start): it is retired, the generator continues behind the last step taken.  (Round-5
+    // advisor: emx_set_target left it running; emx_run restarts a pipeline whose consumer changed, but a hand-over mode chosen for
+    // the OLD target must not outlive it either.)
+    PIPE_STOP(c);
     HIPOK(c, hipStreamSynchronize(c->stream));      // no kernel still reads the old parameters
     drop_prepared(c);                               // plans made ahead were shaped (lean or full) for the previous target
     std::swap(c->tp0, ntp0);                        // the guard now frees the OLD buffers
