@@ -12,6 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _run(cmd, tmp_path, extra_env=None, timeout=300):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update({"EMX_BENCH_STUB": "tests.stubs.bench_stub", "EMX_BENCH_STUB_DIR": str(tmp_path), "PYTHONPATH": ROOT,
@@ -91,7 +98,7 @@ def test_a_spent_time_budget_skips_the_rest_and_says_so(tmp_path):
 
 def test_torchrun_path_is_the_same_code(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "c2"]
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "c2"]
     r, lines = _run(cmd, tmp_path)
     assert r.returncode == 0, r.stderr[-2000:]
     js = [ln for ln in lines if ln.startswith("{")]

@@ -12,6 +12,38 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_world(mp, target, world, args, timeout=180):
+    """`world` spawned processes of target(rank, world, port, *args, q) on a port that is free now; their results.  The
+    processes are daemons and are ended if one of them fails or stalls, so a failed rendezvous cannot hold the test
+    session at exit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=timeout) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.kill()
+    return res
+
+
 def _worker(rank, world, port, name, nst, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
@@ -45,16 +77,7 @@ def test_sharded_protocol_over_gloo(name, world):
     from helpers import load_golden
     g = load_golden(name)
     nst = 6
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, nst, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world(mp, _worker, world, (name, nst,))
     for rank, chain, lp, acc in res:
         if "snooker" in name:
             np.testing.assert_allclose(chain, g["chain"][:nst], rtol=1e-12, atol=1e-14)
@@ -99,16 +122,7 @@ def test_pull_protocol_over_gloo(name, world):
     from helpers import load_golden
     g = load_golden(name)
     nst = 6
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_pull_worker, args=(r, world, port, name, nst, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world(mp, _pull_worker, world, (name, nst,))
     exact = "snooker" not in name
     acc_total = (np.diff(g["chain"][: nst], axis=0, prepend=g["p0"][None]) != 0).any(axis=2).sum(axis=0)
     for rank, lo, hi, chain, lp, x, lpf, acc in res:
@@ -158,16 +172,7 @@ def test_logprob_protocol_over_gloo(name, world):
     from helpers import load_golden
     g = load_golden(name)
     nst = 6
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_logprob_worker, args=(r, world, port, name, nst, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world(mp, _logprob_worker, world, (name, nst,))
     exact = "snooker" not in name
     N = g["p0"].shape[0]
     total_eval = 0
@@ -218,16 +223,7 @@ def test_replay_protocol_over_gloo(name, world):
     from helpers import load_golden
     g = load_golden(name)
     nst = 6
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 34500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_replay_worker, args=(r, world, port, name, nst, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world(mp, _replay_worker, world, (name, nst,))
     exact = "snooker" not in name
     N, D = g["p0"].shape
     acc_total = (np.diff(g["chain"][: nst], axis=0, prepend=g["p0"][None]) != 0).any(axis=2).sum(axis=0)
@@ -281,16 +277,7 @@ def test_python_log_prob_calls_are_shared_out_over_gloo():
     the function on its share only.  No GPU involved: compute_log_prob is host code."""
     import torch.multiprocessing as mp
     world = 3
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 34500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_shared_lp_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world(mp, _shared_lp_worker, world, ())
     X = np.random.RandomState(4).randn(37, 3)
     want = -0.5 * np.sum(X * X, axis=1)
     shares = {0: 13, 1: 13, 2: 11}
@@ -343,16 +330,7 @@ def test_direct_protocol_between_processes(name, world):
     from helpers import load_golden
     g = load_golden(name)
     nst = 6
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, name, nst, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_world(mp, _direct_worker, world, (name, nst,))
     for rank, lo, hi, chain, lp in res:
         if "snooker" not in name:
             assert np.array_equal(chain[:, lo:hi], g["chain"][:nst, lo:hi]), "rank %d diverged" % rank
