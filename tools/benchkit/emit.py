@@ -30,7 +30,11 @@ def _num(x, digits=6):
     if isinstance(x, bool) or x is None:
         return x
     if isinstance(x, float):
-        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+        if x != x or abs(x) == float("inf"):
+            return None
+        if x.is_integer() and abs(x) < 1e9:          # (counts stay exact)
+            return x
+        return float("%.*g" % (digits, x))
     return x
 
 
