@@ -1316,6 +1316,7 @@ struct PersistArgs {
     int32_t niter;
     unsigned seq;                  // number of this launch (left in the barrier block's fourth `go` word once its grid is known co-resident)
     unsigned* started_host;        // pinned host word (or null): `seq` again, for the host -- launch k + 1 has started, so launch k is over
+    int32_t stagger;               // > 0: some waves issue their partner loads later than the others (persist_stagger_wait)
 };
 static_assert(sizeof(PersistArgs) <= 4096, "kernel arguments of the persistent kernels");
 
@@ -1397,6 +1398,18 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
 // LOCAL (the one-XCD form): only the workgroups with blockIdx & 7 == 0 get here; they count in ONE agent-scope counter (once per
 // launch: it need not be cheap), each adds the XCD it really runs on to a mask, and the last arriver opens the barrier only when the
 // mask names a single XCD -- otherwise the launch gives up, untouched, exactly like a grid that could not become co-resident.
+// After a barrier every wave of the grid asks for its partner rows at once.  Waves that ask a little later (PersistArgs::stagger = how *
+// 256 + units of 64 clocks; how 0: the second wave of every SIMD -- waves 4-7 of the workgroup --, 1: the odd waves, 2: the waves of
+// SIMDs 2 and 3, 4: the waves of SIMD k wait k units) leave the memory pipeline to the others first: 65 536 x 64 stretch 20.75-20.93 ->
+// 20.13-20.21 us/step with the waves of SIMDs 2 and 3 waiting 256-384 clocks (one late wave a SIMD: 20.5-20.6; every wave at its own
+// time, or the wait placed in front of the MFMA phase instead: nothing), with stored chain rows 27.7-28.0 -> 27.1-27.4 with the second
+// wave of every SIMD waiting 512 (profiles/r06/stagger_ab.md).
+__device__ __forceinline__ void persist_stagger_wait(int stagger, int wib) {
+    const int how = stagger >> 8, cnt = stagger & 255;
+    const int units = how == 0 ? (wib >> 2) : how == 1 ? (wib & 1) : how == 2 ? ((wib >> 1) & 1) : (wib & 3);
+    for (int s = 0; s < cnt * units; ++s) __builtin_amdgcn_s_sleep(1);
+}
+
 template <bool LOCAL = false>
 __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
     __shared__ int ok_s;
@@ -1564,6 +1577,7 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         const PersistCols I(P.it[n], (size_t)P.base.N);
         // -------- partner rows: the walkers the previous half-step updated --------
         Row<G, V, CH> xa[PF], xb[DE ? PF : 1], xc[SN ? PF : 1];
+        persist_stagger_wait(P.stagger, wib);
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             load_row_agent<G, V, CH, CPOL>(xa[k], Xr, ja[k], D, gl);

@@ -166,6 +166,7 @@ static __global__ __launch_bounds__(512) void k_persist_mix(const PersistArgs P)
         if (act) {
         // -------- partner rows: the walkers the previous half-step updated --------
         Row<G, V, CH> xa[PF], xb[DE ? PF : 1], xc[SNA ? PF : 1];
+        persist_stagger_wait(P.stagger, wib);
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             load_row_agent<G, V, CH, CPOL>(xa[k], Xr, ja[k], D, gl);

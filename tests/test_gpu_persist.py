@@ -813,3 +813,27 @@ def test_a_launch_reads_the_plans_of_two_batches_at_most(N, D, target, moves, we
     for key in c:
         if key != "info":
             assert np.array_equal(p[key], c[key]), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,target,moves,weights", [
+    (65536, 64, "dense", [S("stretch")], None), (16384, 64, "dense", [S("de"), S("snooker")], [0.8, 0.2]),
+])
+def test_the_staggered_partner_loads_change_no_bit(N, D, target, moves, weights):
+    """Round 6: the waves of SIMDs 2 and 3 ask for their partner rows 256 clocks after the others (persist_stagger_wait; by default in
+    device-wide stretch launches without stored rows).  A wait, nothing else: every form of it leaves the same ensemble as none."""
+    spec = full_spec(N, D, target, moves, weights=weights, seed=29)
+    recs = []
+    for stagger in (0, -1, 516, 8, 1027, 300):
+        ens = native_ens(spec, 1)
+        ens.set_tuning("persist_stagger", stagger)
+        for _ in range(2):
+            ens.run(21, 1, False)
+        assert ens.status() == 0
+        x, lp = ens.get_state()
+        assert ens.persist_info()["launches"] > 0
+        recs.append((x, lp, ens.accepted_mask()))
+        ens.close()
+    for r in recs[1:]:
+        for a, b in zip(recs[0], r):
+            assert np.array_equal(a, b)

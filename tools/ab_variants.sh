@@ -8,7 +8,7 @@ $HOSTCXX -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -pthread -c 
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -Wno-constant-logical-operand -fPIC -fvisibility=hidden $flags -mllvm -amdgpu-sched-strategy=max-ilp -c emx_hot.hip -o /tmp/emx_hot_ab_$name.o || exit 1
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -Wno-constant-logical-operand -fPIC -fvisibility=hidden -shared $flags /tmp/emx_mtpipe_ab.o /tmp/emx_mtjump_ab.o /tmp/emx_hot_ab_$name.o emx.hip emx_small.hip emx_aux.hip emx_wide.hip emx_mtdev.hip emx_slab.hip emx_pvalu.hip emx_pmix.hip -o ../libemx_$name.so -ldl -pthread &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -Wno-constant-logical-operand -fPIC -fvisibility=hidden -shared $flags /tmp/emx_mtpipe_ab.o /tmp/emx_mtjump_ab.o /tmp/emx_hot_ab_$name.o emx.hip emx_small.hip emx_aux.hip emx_wide.hip emx_mtdev.hip emx_slab.hip emx_pvalu.hip emx_pmix.hip emx_pslab.hip emx_podd.hip -o ../libemx_$name.so -ldl -pthread &
 done
 wait
 ls -la ../libemx_*.so

@@ -28,6 +28,9 @@ def main(N=65536, D=64, store=0):
     wl = bench.Workload("c2" if D == 64 else "c3", N)
     ens = DeviceEnsemble(wl.N, wl.D, device=0)
     wl.install(ens, "philox")
+    import json
+    for key, val in json.loads(os.environ.get("EMX_AB_TUNE", "{}")).items():
+        ens.set_tuning(key, val)
     if store:
         ens.chain_config(4000)
     ens.run(200, 1, bool(store))
@@ -53,6 +56,7 @@ def main(N=65536, D=64, store=0):
     # the barrier is passed niter - 1 times a launch, the other phases niter times
     per[:, 5] *= niter / np.maximum(niter - 1, 1)
     names = NAMES
+    print("tuning %s, library %s" % (os.environ.get("EMX_AB_TUNE", "{}"), os.path.basename(_STAMPS)))
     print("k_persist %d x %d%s: %d workgroup-launch samples (%d half-steps a launch), counter tick %.2f ns, persist launches so far %d"
           % (N, D, ", stored chain" if store else "", len(raw), int(np.median(niter)), ns_per_tick, info["launches"]))
     print("  wave-0 lifetime per half-step: median %.2f us" % np.median(wall_ns / niter / 1e3))
