@@ -2478,7 +2478,7 @@ static int pipe_fetch_deferred(emx_ctx* c) {
     }
     F.delay_ticks = (unsigned)(c->tune_fetch_delay_us * 100);
     F.arrived = c->pipe_arrived;
-    F.avoid_xcc = (c->persist_bar && c->tune_fetch_avoid) ? c->persist_bar + 9 * 32 + 4 : nullptr;
+    F.avoid_xcc = (c->persist_bar && c->tune_fetch_avoid) ? c->persist_bar + 9 * PERSIST_BAR_STRIDE + 4 : nullptr;
     F.host_done = c->pipe_done;
     F.done_value = (unsigned long long)(c->pipe_deferred.back().first + 1);
     F.pieces_x = (int32_t)((c->N + 255) / 256);
@@ -3881,7 +3881,7 @@ static int persist_settle(emx_ctx* c) {
         return 0;
     }
     unsigned w[4] = {0, 0, 0, 0};
-    HIPOK(c, hipMemcpy(w, c->persist_bar + 9 * 32, sizeof(w), hipMemcpyDeviceToHost));
+    HIPOK(c, hipMemcpy(w, c->persist_bar + 9 * PERSIST_BAR_STRIDE, sizeof(w), hipMemcpyDeviceToHost));
     if (w[1] != 1u) {           // not (only) a clean handshake time-out: a direct-exchange barrier, or the middle of a launch
         c->plog.clear();
         return 0;

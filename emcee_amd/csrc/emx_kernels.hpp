@@ -1280,7 +1280,9 @@ __device__ __forceinline__ void store_scope(T* p, T v) {
 // plan's seven columns are one pointer: every plan slot is one block [order|p0] [s0|uacc] [p1|p2] [logu|fac]), the kernel arguments
 // from 3.5 to 2.4 KB.
 constexpr int PERSIST_MAX_ITERS = 40;
-constexpr int PERSIST_BAR_WORDS = 12 * 32;   // PersistArgs::bar
+constexpr int PERSIST_BAR_STRIDE = 32;          // words between the blocks of PersistArgs::bar: a cache line each (4 KB or 64 KB apart -- other
+                                                // channels of the memory side -- changes nothing: profiles/r06/barrier/bar_stride_ab.txt)
+constexpr int PERSIST_BAR_WORDS = 12 * PERSIST_BAR_STRIDE;   // PersistArgs::bar
 struct PersistIter {
     const char* plan;              // the plan slot's block: [order|p0] int32, [s0|uacc] f64, [p1|p2] int32, [logu|fac] f64, N entries a column
     double *chain, *chain_lp;      // this step's row of the stored chain (backend.py:229), or nullptr
@@ -1331,7 +1333,7 @@ __device__ __forceinline__ void persist_barrier_local(const PersistArgs& P, unsi
     __syncthreads();
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        const __amdgpu_buffer_rsrc_t Fr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.bar + 10 * 32), 0, 64 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t Fr = __builtin_amdgcn_make_buffer_rsrc((void*)(P.bar + 10 * PERSIST_BAR_STRIDE), 0, 64 * 4, 0x00020000);
         if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(k, Fr, (int)bid * 4, 0, 0);
         const unsigned long long t0 = wall_clock64();
         for (;;) {
@@ -1343,7 +1345,7 @@ __device__ __forceinline__ void persist_barrier_local(const PersistArgs& P, unsi
             if (wall_clock64() - t0 > P.timeout_ticks) {
                 if (lane == 0) {
                     raise_status(P.base.status, ST_EXCHANGE_TIMEOUT);
-                    __hip_atomic_store(P.bar + 9 * 32 + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // 2: in the middle of a launch
+                    __hip_atomic_store(P.bar + 9 * PERSIST_BAR_STRIDE + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // 2: in the middle of a launch
                     __builtin_amdgcn_raw_buffer_store_b32(1u, Fr, 32 * 4, 0, 0);
                 }
                 break;
@@ -1358,16 +1360,18 @@ __device__ __forceinline__ void persist_barrier_local(const PersistArgs& P, unsi
 // read-modify-write atomics by words -- hierarchical (flag words polled inside an XCD's L2, one word per XCD across: 2.55 us, the
 // step time unchanged within 0.5 %) and flat (a word per workgroup, everybody polls all of them: 4.6 us) -- both bit-equal, neither
 // faster; they were removed again (profiles/r06/hier_barrier.md names the commits that hold them).
-// What the barrier costs is three trips to the memory side whichever instruction makes them.
+// What the barrier costs is three trips to the memory side whichever instruction makes them.  One trip -- arrive without waiting for the
+// count, every workgroup polling the eight per-XCD counters themselves -- is slower still (65 536 x 64: 21.8 -> 25.2 us/step,
+// profiles/r06/barrier/one_trip_bar_form_ab.txt): 256 pollers on the lines the arrivals are counted in delay the arrivals.
 __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits (agent-scope stores) are visible to the device
     __syncthreads();
     if (threadIdx.x == 0) {
         const int xcd = blockIdx.x & 7;
         const unsigned per = (gridDim.x + 7 - xcd) / 8;
-        unsigned* xctr = P.bar + xcd * 32;
-        unsigned* gctr = P.bar + 8 * 32;
-        unsigned* go = P.bar + 9 * 32;                            // [go | dead]: one 8-byte word, polled with one load
+        unsigned* xctr = P.bar + xcd * PERSIST_BAR_STRIDE;
+        unsigned* gctr = P.bar + 8 * PERSIST_BAR_STRIDE;
+        unsigned* go = P.bar + 9 * PERSIST_BAR_STRIDE;                            // [go | dead]: one 8-byte word, polled with one load
         const unsigned old = __hip_atomic_fetch_add(xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == k * per - 1) {
             const unsigned o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1389,15 +1393,6 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
     __syncthreads();
 }
 
-// The first barrier of a launch, BEFORE anything is written: every workgroup of the grid reports in.  Once it has been passed the
-// whole grid is resident (nothing leaves a CU before it exits), so the barriers between the half-steps can only be late, never
-// unmet.  When it is NOT passed in time -- another process holds the CUs with a persistent grid of its own -- the launch gives
-// up with the ensemble untouched: the dead mark (1: clean) sends home the workgroups that start later and every launch queued
-// behind this one, and the host redoes those launches' steps on the per-half-step path (persist_recover, emx.hip).
-// -> false: leave without a store.
-// LOCAL (the one-XCD form): only the workgroups with blockIdx & 7 == 0 get here; they count in ONE agent-scope counter (once per
-// launch: it need not be cheap), each adds the XCD it really runs on to a mask, and the last arriver opens the barrier only when the
-// mask names a single XCD -- otherwise the launch gives up, untouched, exactly like a grid that could not become co-resident.
 // After a barrier every wave of the grid asks for its partner rows at once.  Waves that ask a little later (PersistArgs::stagger = how *
 // 256 + units of 64 clocks; how 0: the second wave of every SIMD -- waves 4-7 of the workgroup --, 1: the odd waves, 2: the waves of
 // SIMDs 2 and 3, 4: the waves of SIMD k wait k units) leave the memory pipeline to the others first: 65 536 x 64 stretch 20.75-20.93 ->
@@ -1410,6 +1405,15 @@ __device__ __forceinline__ void persist_stagger_wait(int stagger, int wib) {
     for (int s = 0; s < cnt * units; ++s) __builtin_amdgcn_s_sleep(1);
 }
 
+// The first barrier of a launch, BEFORE anything is written: every workgroup of the grid reports in.  Once it has been passed the
+// whole grid is resident (nothing leaves a CU before it exits), so the barriers between the half-steps can only be late, never
+// unmet.  When it is NOT passed in time -- another process holds the CUs with a persistent grid of its own -- the launch gives
+// up with the ensemble untouched: the dead mark (1: clean) sends home the workgroups that start later and every launch queued
+// behind this one, and the host redoes those launches' steps on the per-half-step path (persist_recover, emx.hip).
+// -> false: leave without a store.
+// LOCAL (the one-XCD form): only the workgroups with blockIdx & 7 == 0 get here; they count in ONE agent-scope counter (once per
+// launch: it need not be cheap), each adds the XCD it really runs on to a mask, and the last arriver opens the barrier only when the
+// mask names a single XCD -- otherwise the launch gives up, untouched, exactly like a grid that could not become co-resident.
 template <bool LOCAL = false>
 __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
     __shared__ int ok_s;
@@ -1417,9 +1421,9 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
         const unsigned k = LOCAL ? P.hepoch0 + 1u : P.epoch0 + 1u;
         const int xcd = LOCAL ? 0 : (int)(blockIdx.x & 7);
         const unsigned per = LOCAL ? gridDim.x >> 3 : (gridDim.x + 7 - xcd) / 8;
-        unsigned* xctr = P.bar + xcd * 32;
-        unsigned* gctr = P.bar + 8 * 32;
-        unsigned* go = P.bar + 9 * 32;
+        unsigned* xctr = P.bar + xcd * PERSIST_BAR_STRIDE;
+        unsigned* gctr = P.bar + 8 * PERSIST_BAR_STRIDE;
+        unsigned* go = P.bar + 9 * PERSIST_BAR_STRIDE;
         int ok = 1;
         const unsigned long long v0 = __hip_atomic_load(reinterpret_cast<unsigned long long*>(go), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((v0 >> 32) != 0ull) {
