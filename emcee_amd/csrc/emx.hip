@@ -387,7 +387,7 @@ struct emx_ctx {
     int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
     int64_t tune_persist_slab = 1;       // 0: dense targets of padded ndim 80 ... 128 never take the persistent slab kernel (emx_pslab.hip)
     int64_t persist_slab_launches = 0;
-    int64_t tune_persist_stagger = -1;       // -1: 516 (the waves of SIMDs 2 and 3 wait 256 clocks) for device-wide stretch launches that store no chain rows, else none
+    int64_t tune_persist_stagger = -1;       // -1: 516 (the waves of SIMDs 2 and 3 wait 256 clocks) for device-wide stretch launches that store no chain rows, 528 for DE + snooker mixtures, else none
     int64_t tune_persist_max_halfsteps = PERSIST_MAX_ITERS;      // half-steps a persistent launch may hold (<= PERSIST_MAX_ITERS = 40)
     int64_t tune_mt_device_min_regen = 786432;      // the device producer's first ensemble size where the host pipeline's stretch steps are regen steps (mtdev_eligible)
     int64_t tune_mt_regen_min = 16384;   // exact mode, host pipeline with device finish: from this many walkers on a stretch step's fixed-length draws are made again
@@ -3788,8 +3788,11 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     }
     P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
     // (k_persist's stretch form without stored rows is where it was measured to pay: persist_stagger_wait, csrc/emx_kernels.hpp)
+    // (and k_persist_mix with a longer wait: c4 30.0-30.2 -> 29.5-29.8 us/step)
     P.stagger = c->tune_persist_stagger >= 0 ? (int32_t)c->tune_persist_stagger
-                                             : (launch_move == EMX_MOVE_STRETCH && !launch_mix && !launch_local && !store) ? 516 : 0;
+                : (launch_local || store)    ? 0
+                : launch_mix                 ? 528
+                : launch_move == EMX_MOVE_STRETCH ? 516 : 0;
     c->persist_epoch += (unsigned)n;          // the handshake and the n - 1 barriers between the half-steps
     P.seq = ++c->persist_seq;
     lg.seq = P.seq;

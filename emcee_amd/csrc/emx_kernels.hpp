@@ -1362,8 +1362,11 @@ __device__ __forceinline__ void persist_barrier_local(const PersistArgs& P, unsi
 // faster; they were removed again (profiles/r06/hier_barrier.md names the commits that hold them).
 // What the barrier costs is three trips to the memory side whichever instruction makes them.  One trip -- arrive without waiting for the
 // count, every workgroup polling the eight per-XCD counters themselves -- is slower still (65 536 x 64: 21.8 -> 25.2 us/step,
-// profiles/r06/barrier/one_trip_bar_form_ab.txt): 256 pollers on the lines the arrivals are counted in delay the arrivals.
-__device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k) {
+// profiles/r06/barrier/one_trip_bar_form_ab.txt): 256 pollers on the lines the arrivals are counted in delay the arrivals.  And TWO trips
+// -- the last arriver of an XCD adds to `go` itself, which counts eight a barrier, nobody is elected a second time -- change nothing
+// (20.37-20.53 against 20.24-20.31 us/step, barrier/bar_two_trip_ab.txt): what a workgroup waits for at the barrier is the slowest
+// workgroup, not the mechanism (barrier/barrier_skew.txt).
+__device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k, unsigned long long* wall = nullptr) {      // (wall: instrumented build, [arrived, released] on the 100 MHz clock)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits (agent-scope stores) are visible to the device
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1372,6 +1375,7 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
         unsigned* xctr = P.bar + xcd * PERSIST_BAR_STRIDE;
         unsigned* gctr = P.bar + 8 * PERSIST_BAR_STRIDE;
         unsigned* go = P.bar + 9 * PERSIST_BAR_STRIDE;                            // [go | dead]: one 8-byte word, polled with one load
+        if (wall) wall[0] = wall_clock64();
         const unsigned old = __hip_atomic_fetch_add(xctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == k * per - 1) {
             const unsigned o2 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1389,6 +1393,7 @@ __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k
                 break;
             }
         }
+        if (wall) wall[1] = wall_clock64();
     }
     __syncthreads();
 }
@@ -1738,7 +1743,8 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
         if constexpr (LOCAL)
             persist_barrier_local(P, P.lepoch0 + (unsigned)n + 1u, bid, ngroups);
         else
-            persist_barrier(P, P.epoch0 + (unsigned)n + 2u);       // (+ 1: the handshake was this launch's first barrier)
+            persist_barrier(P, P.epoch0 + (unsigned)n + 2u,       // (+ 1: the handshake was this launch's first barrier)
+                            (EMX_OPT_STAMPS && A.dbg) ? A.dbg + 4096 + ((size_t)n * ngroups + bid) * 2 : nullptr);
         EMX_PSTAMP(5);       // device-wide barrier
         // -------- roll over --------
 #pragma unroll
