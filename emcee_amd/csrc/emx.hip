@@ -3789,8 +3789,11 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     P.timeout_ticks = 100000000ull * (unsigned long long)std::max<int64_t>(1, c->tune_persist_timeout_ms) / 1000ull;       // 100 MHz wall clock
     // (k_persist's stretch form without stored rows is where it was measured to pay: persist_stagger_wait, csrc/emx_kernels.hpp)
     // (and k_persist_mix with a longer wait: c4 30.0-30.2 -> 29.5-29.8 us/step)
+    // (k_persist_valu has no such wait; nor has k_persist_slab, whose sibling skew it did not improve: 65 536 x 128 44.1-44.3 us/step with
+    // either or both, 44.8-45.2 with neither, profiles/r06/stagger/pslab_stagger_ab.txt)
+    const bool fam_dense64 = c->target == EMX_TARGET_DENSE_GAUSS && c->Dp <= 64;
     P.stagger = c->tune_persist_stagger >= 0 ? (int32_t)c->tune_persist_stagger
-                : (launch_local || store)    ? 0
+                : (launch_local || store || !fam_dense64) ? 0
                 : launch_mix                 ? 528
                 : launch_move == EMX_MOVE_STRETCH ? 516 : 0;
     c->persist_epoch += (unsigned)n;          // the handshake and the n - 1 barriers between the half-steps
