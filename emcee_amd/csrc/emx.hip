@@ -3794,7 +3794,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
     const bool fam_dense64 = c->target == EMX_TARGET_DENSE_GAUSS && c->Dp <= 64;
     P.stagger = c->tune_persist_stagger >= 0 ? (int32_t)c->tune_persist_stagger
                 : (launch_local || store || !fam_dense64) ? 0
-                : launch_mix                 ? 528
+                : (launch_mix || launch_move == EMX_MOVE_DE) ? 528
                 : launch_move == EMX_MOVE_STRETCH ? 516 : 0;
     c->persist_epoch += (unsigned)n;          // the handshake and the n - 1 barriers between the half-steps
     P.seq = ++c->persist_seq;

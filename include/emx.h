@@ -110,7 +110,7 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   "persist_min_walkers"      512       smallest ensemble             "persist_timeout_ms"   2000      bound of a barrier wait
  *   "persist_stagger"          -1        how * 256 + n: some waves of a k_persist / k_persist_mix workgroup ask for their partner rows n x 64 clocks
  *                                        after the others (how 0: waves 4-7, 1: odd waves, 2: the waves of SIMDs 2 and 3, 4: SIMD k waits k n); -1: 516
- *                                        for device-wide stretch launches without stored rows, 528 for DE + snooker mixtures (k_persist_mix), else 0
+ *                                        for device-wide stretch launches without stored rows, 528 for the DE move and DE + snooker mixtures (k_persist_mix), else 0
  *                                        (profiles/r06/stagger_ab.md)
  *   "persist_max_halfsteps"    40        half-steps a launch may hold (<= 40: twenty stretch / DE steps; a launch never reads plans of more than two batches)
  *   "persist_gauss_wpb"        0 (auto)  waves per workgroup of k_persist_gauss
