@@ -139,7 +139,8 @@ def main(argv=None):
     traffic_fresh = None          # (bytes, per_halfstep)
     traffic_source = ("profiles/pmc_traffic.json (static: `bench.py --pmc` of the builder's closing session of round 4, profiles/r04/bench_n1_pmc.json -- "
                       "two rocprofv3 --pmc passes of this command, 2 x FETCH_SIZE + WRITE_SIZE per half-step of k_persist; re-measured in round 5 "
-                      "by tools/pmc_r05.sh, profiles/r05/pmc_traffic_r05.json: 1 224 B per walker-update = 40.1 MB per half-step; not re-measured by "
+                      "by tools/pmc_r05.sh, profiles/r05/pmc_traffic_r05.json, and by `bench.py --pmc` in round 6's closing session, "
+                      "profiles/r06/bench_n1_pmc_z2.json: 1 224 B per walker-update = 40.1 MB per half-step each time; not re-measured by "
                       "THIS run; `bench.py --pmc` re-measures)")
     if args.pmc and not sharded:
         fresh, why, per_hs = refresh_pmc_traffic(args)

@@ -394,12 +394,17 @@ def refresh_pmc_traffic(args):
                "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
         env = dict(os.environ)
         env.setdefault("TMPDIR", "/tmp")
+        # the child's FULL record (its stdout line is the compact one, without the launch counts): a file of its own
+        env["EMX_BENCH_DETAIL"] = os.path.join(d, "child_detail.json")
         try:
             cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, env=env, cwd=ROOT)
             child = None
-            for ln in cp.stdout.decode(errors="replace").splitlines():
-                if ln.startswith("{") and '"metric"' in ln:
-                    child = json.loads(ln)
+            if os.path.exists(env["EMX_BENCH_DETAIL"]):
+                child = json.load(open(env["EMX_BENCH_DETAIL"]))
+            else:
+                for ln in cp.stdout.decode(errors="replace").splitlines():
+                    if ln.startswith("{") and '"metric"' in ln:
+                        child = json.loads(ln)
             ptot = (child or {}).get("persist") or {}
             agg = collections.defaultdict(list)
             persist_sum = 0.0
