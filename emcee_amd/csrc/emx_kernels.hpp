@@ -1365,7 +1365,7 @@ __device__ __forceinline__ void persist_barrier_local(const PersistArgs& P, unsi
 // profiles/r06/barrier/one_trip_bar_form_ab.txt): 256 pollers on the lines the arrivals are counted in delay the arrivals.  And TWO trips
 // -- the last arriver of an XCD adds to `go` itself, which counts eight a barrier, nobody is elected a second time -- change nothing
 // (20.37-20.53 against 20.24-20.31 us/step, barrier/bar_two_trip_ab.txt): what a workgroup waits for at the barrier is the slowest
-// workgroup, not the mechanism (barrier/barrier_skew.txt).
+// workgroup, not the mechanism (barrier/barrier_skew.txt).  A copy of `go` per XCD (32 pollers a line): c4 -0.7 %, c2 +5 % (bar_replicas_ab.txt).
 __device__ __forceinline__ void persist_barrier(const PersistArgs& P, unsigned k, unsigned long long* wall = nullptr) {      // (wall: instrumented build, [arrived, released] on the 100 MHz clock)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's commits (agent-scope stores) are visible to the device
     __syncthreads();
