@@ -11,9 +11,9 @@ hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t ld
     return launch_one<8, 2, 4, MOVE_STRETCH, 4, 1>(grid, block, lds, st, a);
 }
 
-template <int G, int V, int CH, int DPB, int MOVE, bool LOCAL = false>
+template <int G, int V, int CH, int DPB, int MOVE, bool LOCAL = false, bool ROWS_LATE = false>
 static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-    auto kern = k_persist<G, V, CH, DPB, MOVE, LOCAL>;
+    auto kern = k_persist<G, V, CH, DPB, MOVE, LOCAL, ROWS_LATE>;
     static size_t lds_granted[MAX_DEVICES] = {};
     int dev = 0;
     if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES && lds > lds_granted[dev]) {
@@ -26,7 +26,16 @@ static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t 
 }
 
 // padded ndim 16 * dpb, even ndim (two coordinates per lane): rows of 8 lanes, dpb = 1 ... 4
-hipError_t launch_hot_persist_dense(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+// rows_late: the stretch move's device-wide form that asks for the next half-step's own rows behind the MFMA phase (launches that store
+// chain rows: k_persist's ROWS_LATE)
+hipError_t launch_hot_persist_dense(int dpb, int move, int local, int rows_late, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
+    if (rows_late && !local && move == MOVE_STRETCH) {
+#define EMX_SCASE(b, ch) \
+    if (dpb == b) return launch_persist<8, 2, ch, b, MOVE_STRETCH, false, true>(grid, block, lds, st, P);
+        EMX_SCASE(1, 1) EMX_SCASE(2, 2) EMX_SCASE(3, 4) EMX_SCASE(4, 4)
+#undef EMX_SCASE
+        return hipErrorInvalidValue;
+    }
     if (local) {          // the one-XCD form
 #define EMX_LCASE(b, ch)                                                                                           \
     if (dpb == b)                                                                                                  \

@@ -1486,7 +1486,7 @@ __device__ __forceinline__ bool persist_handshake(const PersistArgs& P) {
     return ok_s != 0;
 }
 
-template <int G, int V, int CH, int DPB, int MOVE = MOVE_STRETCH, bool LOCAL = false>
+template <int G, int V, int CH, int DPB, int MOVE = MOVE_STRETCH, bool LOCAL = false, bool ROWS_LATE = false>
 static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
     static_assert(MOVE == MOVE_STRETCH || MOVE == MOVE_DE || MOVE == MOVE_SNOOKER, "the red / blue moves");
     // LOCAL: the one-XCD form for small ensembles.  The dispatcher deals workgroups to the eight XCDs in turn (workgroup i -> XCD
@@ -1615,6 +1615,8 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             my_i_n = J.order[pbase + myrow];
             my_logu_n = J.logu[pbase + myrow];
         }
+        // (the scheduler puts these loads BEHIND the wait for the partner rows.  Forced in front of it -- a scheduling barrier here -- the
+        // step is 2.4 % slower, 20.17 -> 20.65 us: ten more requests in front of the rows; profiles/r06/stagger/entries_early_ab.txt)
         // -------- proposals -> the wave's LDS tile (R = Q - mu), kept in registers for the commit --------
         if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         EMX_PSTAMP(0);       // partner rows (and the next half-step's plan entries) have arrived
@@ -1661,8 +1663,12 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
             }
         }
         // -------- own rows of the next half-step: in flight during the MFMA phase (speculative unless `pre`) --------
+        // ROWS_LATE (round 6; the instantiation of launches that store chain rows): they are asked for BEHIND the MFMA phase, under the
+        // decisions, the commit and the barrier -- in front of it they share the memory pipeline with the 17 MB of chain rows of the
+        // half-step before (65 536 x 64 with the chain stored every step: 27.6-27.9 -> 26.3-26.4 us/step; without stored rows the same
+        // move costs 4 %: 20.25 -> 21.1, hence a template parameter; profiles/r06/stagger/ownrows_late_ab*.txt)
         double my_lpo_n = 0.0;
-        if (more) {
+        if (!ROWS_LATE && more) {
 #pragma unroll
             for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH, CPOL>(xi[k], Xr, wi_n[k], D, gl);
             my_lpo_n = load_agent(A.lp + my_i_n);
@@ -1688,6 +1694,13 @@ static __global__ __launch_bounds__(512) void k_persist(const PersistArgs P) {
                 for (int r = 0; r < 4; ++r) part[r] = fma(accv[r], accv[r], part[r]);
             }
             my_qf = row16_sum4(part[0], part[1], part[2], part[3], lane);
+        }
+        if (ROWS_LATE && more) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < PF; ++k) load_row_agent<G, V, CH, CPOL>(xi[k], Xr, wi_n[k], D, gl);
+            my_lpo_n = load_agent(A.lp + my_i_n);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (prof) { asm volatile("s_nop 0" ::: "memory"); }
         EMX_PSTAMP(2);       // MFMA chain + reductions

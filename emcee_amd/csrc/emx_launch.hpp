@@ -31,7 +31,7 @@ hipError_t launch_hot_stretch_dense64(int lean, dim3 grid, dim3 block, size_t ld
 // ... and its persistent form (k_persist; padded ndim 16 ... 64 with two coordinates per lane, stretch or DE move): `P.niter`
 // half-steps in one launch.  The grid must be co-resident
 // (one workgroup per CU at most).
-hipError_t launch_hot_persist_dense(int dpb, int move, int local, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
+hipError_t launch_hot_persist_dense(int dpb, int move, int local, int rows_late, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P);
 // workgroups of that k_persist instantiation a CU holds at once, by the runtime's occupancy calculator
 hipError_t hot_persist_occupancy(int dpb, int move, int threads, size_t lds, int* per_cu);
 // ... and the Gaussian Metropolis move's (k_persist_gauss: a wave keeps its walkers in registers; no barrier, any grid)
