@@ -387,7 +387,7 @@ struct emx_ctx {
     int persist_mix_fits = -1;           // the mixed instantiation's grid is co-resident (asked once)
     int64_t tune_persist_slab = 1;       // 0: dense targets of padded ndim 80 ... 128 never take the persistent slab kernel (emx_pslab.hip)
     int64_t persist_slab_launches = 0;
-    int64_t tune_persist_rows_late = 1;      // launches that store chain rows take k_persist's ROWS_LATE instantiation (stretch, device-wide, even ndim <= 64)
+    int64_t tune_persist_rows_late = 1;      // launches that store chain rows take k_persist's ROWS_LATE instantiation (stretch, even ndim <= 64): 0 never, 1 where measured to pay, 2 always
     int64_t tune_persist_stagger = -1;       // -1: 516 (the waves of SIMDs 2 and 3 wait 256 clocks) for device-wide stretch launches that store no chain rows, 528 for DE + snooker mixtures, else none
     int64_t tune_persist_max_halfsteps = PERSIST_MAX_ITERS;      // half-steps a persistent launch may hold (<= PERSIST_MAX_ITERS = 40)
     int64_t tune_mt_device_min_regen = 786432;      // the device producer's first ensemble size where the host pipeline's stretch steps are regen steps (mtdev_eligible)
@@ -1483,7 +1483,7 @@ int emx_set_tuning(emx_ctx* c, const char* key, int64_t v) {
         return 0;
     }
     if (!strcmp(key, "persist_rows_late")) {
-        c->tune_persist_rows_late = v ? 1 : 0;
+        c->tune_persist_rows_late = v < 0 ? 0 : v > 2 ? 2 : v;
         return 0;
     }
     if (!strcmp(key, "persist_stagger")) {
@@ -3823,6 +3823,11 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         }
         if (prof) HIPOK(c, hipEventRecord(e0, c->stream));
         hipError_t e;
+        // launches that store chain rows: the one-XCD form, and the device-wide form when every CU has eight tiles a half-step (65 536 x 64:
+        // 27.6 -> 26.3 us/step; 8 192: 14.7 -> 14.1, 4 096: 10.05 -> 9.8; but 16 384 / 32 768 walkers, two / four tiles a CU: +1.5 %;
+        // profiles/r06/stagger/rows_late_mid.txt) -- tuning persist_rows_late 0: never, 1: this rule, 2: always
+        const bool rows_late = store && (c->tune_persist_rows_late == 2 ||
+                                         (c->tune_persist_rows_late == 1 && (launch_local || c->N / 2 / 16 >= 8 * (int64_t)c->num_cu)));
         if (c->target != EMX_TARGET_DENSE_GAUSS) {
             const Shape shv = pick_shape(c->D, c->D);
             e = launch_persist_valu(shv.G, shv.V, shv.CH, launch_move, launch_local ? 1 : 0, grid, block, c->stream, P);
@@ -3837,7 +3842,7 @@ static int run_persist(emx_ctx* c, int64_t i0, int64_t total, int32_t thin_by, i
         } else if (c->D & 1) {
             e = launch_persist_dense_odd(c->Dp / 16, launch_move, launch_local ? 1 : 0, grid, block, lds, c->stream, P);
         } else {
-            e = launch_hot_persist_dense(c->Dp / 16, launch_move, launch_local ? 1 : 0, (store && c->tune_persist_rows_late) ? 1 : 0, grid, block, lds, c->stream, P);
+            e = launch_hot_persist_dense(c->Dp / 16, launch_move, launch_local ? 1 : 0, rows_late ? 1 : 0, grid, block, lds, c->stream, P);
         }
         if (launch_local) c->persist_local_launches++;
         if (e != hipSuccess) FAIL(c, -2, "persistent half-step launch failed: %s", hipGetErrorString(e));

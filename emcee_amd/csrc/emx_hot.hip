@@ -29,9 +29,11 @@ static hipError_t launch_persist(dim3 grid, dim3 block, size_t lds, hipStream_t 
 // rows_late: the stretch move's device-wide form that asks for the next half-step's own rows behind the MFMA phase (launches that store
 // chain rows: k_persist's ROWS_LATE)
 hipError_t launch_hot_persist_dense(int dpb, int move, int local, int rows_late, dim3 grid, dim3 block, size_t lds, hipStream_t st, const PersistArgs& P) {
-    if (rows_late && !local && move == MOVE_STRETCH) {
-#define EMX_SCASE(b, ch) \
-    if (dpb == b) return launch_persist<8, 2, ch, b, MOVE_STRETCH, false, true>(grid, block, lds, st, P);
+    if (rows_late && move == MOVE_STRETCH) {
+#define EMX_SCASE(b, ch)                                                                                       \
+    if (dpb == b)                                                                                              \
+        return local ? launch_persist<8, 2, ch, b, MOVE_STRETCH, true, true>(grid, block, lds, st, P)          \
+                     : launch_persist<8, 2, ch, b, MOVE_STRETCH, false, true>(grid, block, lds, st, P);
         EMX_SCASE(1, 1) EMX_SCASE(2, 2) EMX_SCASE(3, 4) EMX_SCASE(4, 4)
 #undef EMX_SCASE
         return hipErrorInvalidValue;

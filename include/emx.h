@@ -108,8 +108,9 @@ int emx_status(emx_ctx* ctx, uint32_t* bits);
  *   "persist_mix"              1         0: DE and snooker steps of a mixture in launches of their own
  *   "persist_span"             1         0: a launch ends with its Philox plan batch
  *   "persist_min_walkers"      512       smallest ensemble             "persist_timeout_ms"   2000      bound of a barrier wait
- *   "persist_rows_late"        1         launches that store chain rows (stretch move, device-wide, even ndim <= 64) ask for the next half-step's own rows
- *                                        behind the MFMA phase instead of in front of it (k_persist<..., ROWS_LATE>; 0: as the others)
+ *   "persist_rows_late"        1         launches that store chain rows (stretch move, even ndim <= 64) ask for the next half-step's own rows behind the
+ *                                        MFMA phase instead of in front of it (k_persist<..., ROWS_LATE>): 1 the one-XCD form and device-wide launches
+ *                                        with eight tiles a CU and half-step (65 536 walkers), 2 always, 0 never
  *   "persist_stagger"          -1        how * 256 + n: some waves of a k_persist / k_persist_mix workgroup ask for their partner rows n x 64 clocks
  *                                        after the others (how 0: waves 4-7, 1: odd waves, 2: the waves of SIMDs 2 and 3, 4: SIMD k waits k n); -1: 516
  *                                        for device-wide stretch launches without stored rows, 528 for the DE move and DE + snooker mixtures (k_persist_mix), else 0

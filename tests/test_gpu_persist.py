@@ -840,17 +840,16 @@ def test_the_staggered_partner_loads_change_no_bit(N, D, target, moves, weights)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,D,thin_by", [(32768, 64, 1), (16384, 48, 2), (65536, 32, 1)])
+@pytest.mark.parametrize("N,D,thin_by", [(32768, 64, 1), (16384, 48, 2), (65536, 32, 1), (4096, 64, 1), (1024, 32, 3)])
 def test_stored_launches_take_the_late_own_rows_and_change_no_bit(N, D, thin_by):
     """Round 6: launches that store chain rows run k_persist<..., ROWS_LATE> (the next half-step's own rows asked for behind the MFMA
     phase; tuning persist_rows_late).  Same chain, log-probs, counts and final state as the other instantiation and as the launches."""
     spec = full_spec(N, D, "dense", [S("stretch")], seed=31)
     nsteps = 6                      # stored steps; thin_by iterations each
     recs = []
-    for persist, late in ((1, 1), (1, 0), (0, 1)):
+    for persist, late in ((1, 2), (1, 0), (0, 1)):
         ens = native_ens(spec, persist)
         ens.set_tuning("persist_rows_late", late)
-        ens.set_tuning("persist_local", 0)
         ens.chain_config(nsteps)
         ens.run(nsteps, thin_by, True)
         assert ens.status() == 0
